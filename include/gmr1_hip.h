@@ -1,0 +1,118 @@
+/*
+ * gmr1_hip.h -- C ABI of the MI355X-native GMR-1 receive hot path.
+ *
+ * Two families of entry points live in libgmr1_hip.so:
+ *
+ *  1. The reference's own per-burst C API (declared in include/osmocom/gmr1/
+ *     {sdr,l1}/.h of this repo, same names / argument meaning / return values
+ *     as osmocom/osmo-gmr) -- each call is blocking: H2D, one kernel, D2H.
+ *
+ *  2. The batched entry points below, which are what a high-rate caller binds.
+ *     "_dev" variants take DEVICE pointers (inputs already resident in HBM) and
+ *     a hipStream_t passed as void*; they only enqueue work.  The variants
+ *     without "_dev" take HOST pointers and stage through HBM themselves.
+ *
+ * Every function returns 0 on success or a negative errno; the per-burst
+ * status (the reference's own return value) is written to rv[].  There is NO
+ * CPU fallback: without a usable HIP device every call fails with -ENODEV.
+ *
+ * Reference interfaces replaced (osmocom/osmo-gmr, paths relative to the
+ * reference tree):
+ *   gmr1_hip_demod_batch*        -> gmr1_pi4cxpsk_demod   include/osmocom/gmr1/sdr/pi4cxpsk.h:101-105
+ *   gmr1_hip_detect_batch*       -> gmr1_pi4cxpsk_detect  include/osmocom/gmr1/sdr/pi4cxpsk.h:107-110
+ *   gmr1_hip_bcch_decode_batch*  -> gmr1_bcch_decode      include/osmocom/gmr1/l1/bcch.h:38
+ *   gmr1_hip_ccch_decode_batch*  -> gmr1_ccch_decode      include/osmocom/gmr1/l1/ccch.h:38
+ *   gmr1_hip_facch3_decode_batch*-> gmr1_facch3_decode    include/osmocom/gmr1/l1/facch3.h:39-40
+ *   gmr1_hip_tch3_decode_batch*  -> gmr1_tch3_decode      include/osmocom/gmr1/l1/tch3.h:40-42
+ *   gmr1_hip_rx_bcch_ccch_batch* -> rx_bcch / rx_ccch     src/gmr1_rx.c:746-850 (demod + decode of one burst)
+ *   gmr1_hip_fcch_rough_batch*   -> gmr1_fcch_rough       include/osmocom/gmr1/sdr/fcch.h:47-49
+ *   gmr1_hip_fcch_fine_batch*    -> gmr1_fcch_fine + gmr1_fcch_snr  include/osmocom/gmr1/sdr/fcch.h:55-61
+ */
+#ifndef GMR1_HIP_H
+#define GMR1_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMR1_HIP_MAX_SYNC       4
+#define GMR1_HIP_MAX_CHUNKS     8
+#define GMR1_HIP_MAX_SYNC_SYMS  32
+#define GMR1_HIP_MAX_WINDOW     256   /* max search window (lags) the demod kernel handles */
+#define GMR1_HIP_MAX_IN_LEN     2048  /* max samples per burst window */
+
+/* burst type ids (order of include/osmocom/gmr1/sdr/nb.h:37-46) */
+enum gmr1_hip_burst_id {
+	GMR1_HIP_BCCH = 0, GMR1_HIP_DC2, GMR1_HIP_DC6, GMR1_HIP_DC12,
+	GMR1_HIP_NT3_SPEECH, GMR1_HIP_NT3_FACCH, GMR1_HIP_NT6, GMR1_HIP_NT9,
+	GMR1_HIP_RACH, GMR1_HIP_SDCCH, GMR1_HIP_N_BURSTS
+};
+
+/* flat, pointer-free copy of a struct gmr1_pi4cxpsk_burst */
+struct gmr1_hip_chunk {
+	int32_t pos, len;
+	uint8_t syms[GMR1_HIP_MAX_SYNC_SYMS];
+};
+
+struct gmr1_hip_burst_flat {
+	char    name[16];
+	float   rotation;
+	int32_t nbits, guard_pre, guard_post, len, ebits;
+	int32_t n_sync;
+	int32_t n_sync_chunks[GMR1_HIP_MAX_SYNC];
+	struct gmr1_hip_chunk sync[GMR1_HIP_MAX_SYNC][GMR1_HIP_MAX_CHUNKS];
+	int32_t n_data;
+	struct gmr1_hip_chunk data[GMR1_HIP_MAX_CHUNKS];
+};
+
+/* ---- library / device ---------------------------------------------------- */
+int         gmr1_hip_init(int device);          /* optional; selects the HIP device     */
+const char *gmr1_hip_last_error(void);
+const char *gmr1_hip_version(void);
+int         gmr1_hip_burst_info(int burst_id, struct gmr1_hip_burst_flat *out);
+
+/* ---- normal-burst demodulation (any burst type, one type per call) ------- */
+/* iq: interleaved float32 I/Q; burst i occupies iq[offset[i] .. offset[i]+in_len) (complex samples).
+ * Optional outputs may be NULL.  ebits is n x ebits_stride int8, ssyms n x bt.len float. */
+int gmr1_hip_demod_batch_dev(void *stream, int burst_id, int n, int sps, int in_len,
+                             const float *iq, const uint64_t *offset, const float *freq_shift,
+                             int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                             float *toa, float *freq_err, float *ssyms, int32_t *rv);
+int gmr1_hip_demod_batch(int burst_id, int n, int sps, int in_len,
+                         const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
+                         int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                         float *toa, float *freq_err, float *ssyms, int32_t *rv);
+
+/* ---- layer-1 channel decoding (soft bits in, L2 out) --------------------- */
+int gmr1_hip_bcch_decode_batch_dev(void *stream, int n, const int8_t *ebits /* n x 424 */,
+                                   uint8_t *l2 /* n x 24 */, int32_t *crc, int32_t *conv);
+int gmr1_hip_ccch_decode_batch_dev(void *stream, int n, const int8_t *ebits /* n x 432 */,
+                                   uint8_t *l2 /* n x 24 */, int32_t *crc, int32_t *conv);
+int gmr1_hip_bcch_decode_batch(int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv);
+int gmr1_hip_ccch_decode_batch(int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv);
+
+/* ---- fused BCCH / CCCH receive: demod + descramble + deinterleave + Viterbi + CRC
+ * kind[i]: 0 = BCCH burst (window 234*sps + 20*sps), 1 = CCCH on a DC6 burst
+ * (window 234*sps + 10*sps), the windows gmr1_rx.c:759,809 cut.
+ * crc[i]: 0 pass, 1 fail, -1 when the demodulator found no sync (rv[i] != 0). */
+int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
+                                    const float *iq, const uint64_t *offset, const uint8_t *kind,
+                                    const float *freq_shift,
+                                    uint8_t *l2 /* n x 24 */, int32_t *crc, int32_t *conv,
+                                    float *toa, float *freq_err,
+                                    int8_t *ebits /* n x 432, optional */,
+                                    float *ssyms /* n x 234, optional */, int32_t *rv);
+int gmr1_hip_rx_bcch_ccch_batch(int n, int sps,
+                                const float *iq, uint64_t iq_len, const uint64_t *offset, const uint8_t *kind,
+                                const float *freq_shift,
+                                uint8_t *l2, int32_t *crc, int32_t *conv,
+                                float *toa, float *freq_err,
+                                int8_t *ebits, float *ssyms, int32_t *rv);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* GMR1_HIP_H */

@@ -1,0 +1,422 @@
+/*
+ * oracle/orc_3p.c -- TEST INFRASTRUCTURE ONLY.  See orc_3p.h for the
+ * "parity unpinned" statement and the list of third-party libraries whose
+ * published algorithms are restated here.
+ *
+ * DECISIONS (also listed in DESIGN.md):
+ *  D1  osmo_conv_decode = the GENERIC libosmocore decoder (unsigned 32-bit
+ *      accumulated error, MAX_AE 0x00ffffff, metric ((in - (+-127))^2 >> 9),
+ *      erasures (in == 0) cost nothing, strict '>' survivor update so ties
+ *      keep the lower-numbered predecessor).  Newer libosmocore may route
+ *      K=5/K=7 codes to an SSE/AVX decoder whose metric scaling, tie-breaks
+ *      and return value differ; conv_rv parity with such a build is
+ *      best-effort.
+ *  D2  sig_normalize takes mean / sigma over ALL input samples (not only the
+ *      decimated ones).
+ *  D3  peak_energy_find: window energies are summed directly in ascending
+ *      order for each window start, the first maximum wins; EARLY_LATE
+ *      bisects from +-1 sample with incr 0.5 halving while incr > 1/1024.
+ *  D3b interpolate_point uses taps floor(pos)-10 .. floor(pos)+10, the upper
+ *      bound clipped to len-1 EXCLUSIVE when it would run past the vector.
+ *  D4  tail-biting decode: first pass starts from state 0 (others MAX_AE),
+ *      metrics are min-normalised, second pass re-scans, best end state
+ *      (lowest index on ties) is traced back without forcing start==end.
+ *  D5  the 117/468-point DFT is evaluated in double and rounded to float.
+ */
+#include "orc_3p.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAX_AE 0x00ffffffu
+
+/* ------------------------------------------------------------------------ */
+/* Convolutional codes                                                      */
+/* ------------------------------------------------------------------------ */
+
+static int parity(unsigned v)
+{
+	v ^= v >> 16; v ^= v >> 8; v ^= v >> 4; v ^= v >> 2; v ^= v >> 1;
+	return v & 1;
+}
+
+/* reg = (state << 1) | bit ; bit i of reg is D^i ; output word MSB = g0
+ * (checked against every table of reference src/l1/conv.c) */
+void orc_conv_make(struct orc_conv_code *c, int N, int K, int len,
+                   enum orc_conv_term term, const unsigned *polys)
+{
+	int ns = 1 << (K - 1);
+	memset(c, 0, sizeof(*c));
+	c->N = N; c->K = K; c->len = len; c->term = term;
+	for (int s = 0; s < ns; s++)
+		for (int b = 0; b < 2; b++) {
+			unsigned reg = ((unsigned)s << 1) | (unsigned)b, w = 0;
+			for (int j = 0; j < N; j++)
+				w = (w << 1) | (unsigned)parity(reg & polys[j]);
+			c->next_output[s][b] = (uint8_t)w;
+			c->next_state[s][b] = (uint8_t)(reg & (unsigned)(ns - 1));
+		}
+	c->n_punct = 0;
+	c->punct[0] = -1;
+}
+
+int orc_conv_output_length(const struct orc_conv_code *c)
+{
+	int steps = c->len + (c->term == ORC_TERM_FLUSH ? c->K - 1 : 0);
+	return steps * c->N - c->n_punct;
+}
+
+void orc_conv_encode(const struct orc_conv_code *c, const orc_ubit_t *in, orc_ubit_t *out)
+{
+	int ns = 1 << (c->K - 1);
+	int state = 0, o = 0, p = 0, idx = 0;
+	int steps = c->len + (c->term == ORC_TERM_FLUSH ? c->K - 1 : 0);
+
+	if (c->term == ORC_TERM_TAIL_BITING) {
+		/* preset the register with the last K-1 data bits */
+		for (int i = c->len - (c->K - 1); i < c->len; i++)
+			state = ((state << 1) | (in[i] & 1)) & (ns - 1);
+	}
+	for (int i = 0; i < steps; i++) {
+		int b = (i < c->len) ? (in[i] & 1) : 0;
+		unsigned w = c->next_output[state][b];
+		for (int j = 0; j < c->N; j++, idx++) {
+			if (c->n_punct && c->punct[p] == idx) { p++; continue; }
+			out[o++] = (orc_ubit_t)((w >> (c->N - 1 - j)) & 1);
+		}
+		state = c->next_state[state][b];
+	}
+}
+
+/* one trellis pass; hist[step*ns + state] = predecessor */
+static int conv_scan(const struct orc_conv_code *c, const orc_sbit_t *in,
+                     int n_steps, int flush, int step0,
+                     unsigned *ae, uint8_t *hist, int *p_idx)
+{
+	int ns = 1 << (c->K - 1);
+	unsigned ae_next[256];
+	int i_idx = 0;
+
+	for (int i = 0; i < n_steps; i++) {
+		orc_sbit_t sym[8];
+		for (int s = 0; s < ns; s++)
+			ae_next[s] = MAX_AE;
+		for (int j = 0; j < c->N; j++) {
+			int idx = (step0 + i) * c->N + j;
+			if (c->n_punct && c->punct[*p_idx] == idx) {
+				sym[j] = 0;
+				(*p_idx)++;
+			} else {
+				sym[j] = in[i_idx++];
+			}
+		}
+		for (int s = 0; s < ns; s++) {
+			for (int b = 0; b < (flush ? 1 : 2); b++) {
+				unsigned out = c->next_output[s][b];
+				int t = c->next_state[s][b];
+				int nae = (int)ae[s];
+				for (int j = 0; j < c->N; j++) {
+					int is = sym[j];
+					if (is) {
+						int ov = ((out >> (c->N - 1 - j)) & 1) ? -127 : 127;
+						int e = is - ov;
+						nae += (e * e) >> 9;
+					}
+				}
+				if (ae_next[t] > (unsigned)nae) {
+					ae_next[t] = (unsigned)nae;
+					hist[(step0 + i) * ns + t] = (uint8_t)s;
+				}
+			}
+		}
+		memcpy(ae, ae_next, sizeof(unsigned) * (size_t)ns);
+	}
+	return i_idx;
+}
+
+int orc_conv_decode(const struct orc_conv_code *c, const orc_sbit_t *in, orc_ubit_t *out)
+{
+	int ns = 1 << (c->K - 1);
+	int total = c->len + (c->term == ORC_TERM_FLUSH ? c->K - 1 : 0);
+	unsigned ae[256];
+	uint8_t *hist = calloc((size_t)total * (size_t)ns, 1);
+	int p_idx = 0, l, n, cur, min_state;
+	unsigned min_ae;
+
+	for (int s = 0; s < ns; s++)
+		ae[s] = s ? MAX_AE : 0;
+
+	if (c->term == ORC_TERM_TAIL_BITING) {
+		unsigned m = MAX_AE;
+		conv_scan(c, in, c->len, 0, 0, ae, hist, &p_idx);
+		for (int s = 0; s < ns; s++) if (ae[s] < m) m = ae[s];
+		for (int s = 0; s < ns; s++) ae[s] -= m;
+		p_idx = 0;
+	}
+
+	l = conv_scan(c, in, c->len, 0, 0, ae, hist, &p_idx);
+	if (c->term == ORC_TERM_FLUSH)
+		conv_scan(c, in + l, c->K - 1, 1, c->len, ae, hist, &p_idx);
+
+	if (c->term == ORC_TERM_FLUSH) {
+		min_state = 0;
+		min_ae = ae[0];
+	} else {
+		min_ae = MAX_AE;
+		min_state = -1;
+		for (int s = 0; s < ns; s++)
+			if (ae[s] < min_ae) { min_ae = ae[s]; min_state = s; }
+		if (min_state < 0) { free(hist); return -1; }
+	}
+
+	cur = min_state;
+	n = total;
+	if (c->term == ORC_TERM_FLUSH) {
+		for (int i = 0; i < c->K - 1; i++)
+			cur = hist[(n - 1 - i) * ns + cur];
+		n -= c->K - 1;
+	}
+	for (int i = n - 1; i >= 0; i--) {
+		int nxt = cur;
+		cur = hist[i * ns + cur];
+		out[i] = (c->next_state[cur][0] == nxt) ? 0 : 1;
+	}
+	free(hist);
+	return (int)min_ae;
+}
+
+/* ------------------------------------------------------------------------ */
+/* CRC / bits                                                               */
+/* ------------------------------------------------------------------------ */
+
+uint32_t orc_crc_compute_bits(const struct orc_crc_code *c, const orc_ubit_t *in, int len)
+{
+	uint32_t top = 1u << (c->bits - 1), mask = (top << 1) - 1, crc = c->init;
+	for (int i = 0; i < len; i++) {
+		uint32_t bit = in[i] & 1;
+		crc ^= bit << (c->bits - 1);
+		crc = (crc & top) ? ((crc << 1) ^ c->poly) : (crc << 1);
+	}
+	crc ^= c->remainder;
+	return crc & mask;
+}
+
+void orc_crc_set_bits(const struct orc_crc_code *c, const orc_ubit_t *in, int len, orc_ubit_t *crc_bits)
+{
+	uint32_t crc = orc_crc_compute_bits(c, in, len);
+	for (int i = 0; i < c->bits; i++)
+		crc_bits[i] = (orc_ubit_t)((crc >> (c->bits - 1 - i)) & 1);
+}
+
+int orc_crc_check_bits(const struct orc_crc_code *c, const orc_ubit_t *in, int len, const orc_ubit_t *crc_bits)
+{
+	uint32_t crc = orc_crc_compute_bits(c, in, len);
+	for (int i = 0; i < c->bits; i++)
+		if (crc_bits[i] ^ ((crc >> (c->bits - 1 - i)) & 1))
+			return 1;
+	return 0;
+}
+
+void orc_pbit2ubit_lsb(orc_ubit_t *out, const uint8_t *in, int n)
+{
+	for (int k = 0; k < n; k++)
+		out[k] = (in[k >> 3] >> (k & 7)) & 1;
+}
+
+void orc_ubit2pbit_lsb(uint8_t *out, const orc_ubit_t *in, int n)
+{
+	for (int k = 0; k < n; k++) {
+		uint8_t m = (uint8_t)(1u << (k & 7));
+		if (in[k]) out[k >> 3] |= m; else out[k >> 3] &= (uint8_t)~m;
+	}
+}
+
+void orc_pbit2ubit_msb(orc_ubit_t *out, const uint8_t *in, int n)
+{
+	for (int k = 0; k < n; k++)
+		out[k] = (in[k >> 3] >> (7 - (k & 7))) & 1;
+}
+
+void orc_ubit2pbit_msb(uint8_t *out, const orc_ubit_t *in, int n)
+{
+	/* osmo_ubit2pbit: every touched byte is fully rewritten */
+	int nbytes = (n + 7) >> 3;
+	memset(out, 0, (size_t)nbytes);
+	for (int k = 0; k < n; k++)
+		if (in[k]) out[k >> 3] |= (uint8_t)(1u << (7 - (k & 7)));
+}
+
+/* ------------------------------------------------------------------------ */
+/* cxvec math                                                               */
+/* ------------------------------------------------------------------------ */
+
+#define PIf 3.14159265358979323846f
+
+static float normsq(orc_cf c) { return crealf(c) * crealf(c) + cimagf(c) * cimagf(c); }
+
+float orc_sinc(float x)
+{
+	if (x >= 0.01f || x <= -0.01f)
+		return sinf(x) / x;
+	return 1.0f;
+}
+
+int orc_sig_normalize(const orc_cf *sig, int len, int decim, float freq_shift, orc_cf *out)
+{
+	int l = len / decim;
+	orc_cf avg = 0.0f;
+	float sigma = 0.0f, stddev;
+
+	for (int i = 0; i < len; i++)
+		avg += sig[i];
+	avg /= (float)len;
+	for (int i = 0; i < len; i++)
+		sigma += normsq(sig[i] - avg);
+	sigma /= (float)len;
+	stddev = sqrtf(sigma);
+	if (stddev == 0.0f)
+		stddev = 1.0f;
+	for (int i = 0, j = 0; i < l; i++, j += decim)
+		out[i] = (sig[j] - avg) / stddev;
+	if (freq_shift != 0.0f)
+		for (int i = 0; i < l; i++) {
+			float ph = freq_shift * (float)i;
+			out[i] *= (cosf(ph) + I * sinf(ph));
+		}
+	return l;
+}
+
+int orc_correlate(const orc_cf *f, int f_len, const orc_cf *g, int g_len, int step, orc_cf *out)
+{
+	int l = g_len - f_len * step + 1;
+	for (int m = 0; m < l; m++) {
+		orc_cf acc = 0.0f;
+		for (int n = 0, mn = m; n < f_len; n++, mn += step)
+			acc += conjf(f[n]) * g[mn];
+		out[m] = acc;
+	}
+	return l;
+}
+
+orc_cf orc_interpolate_point(const orc_cf *cv, int len, float pos)
+{
+	const int N = 10;
+	int i = (int)floorf(pos);
+	int b = i - N, e = i + N + 1;
+	orc_cf val = 0.0f;
+
+	if (b < 0) b = 0;
+	if (e >= len) e = len - 1;
+	for (i = b; i < e; i++)
+		val += cv[i] * orc_sinc(PIf * ((float)i - pos));
+	return val;
+}
+
+float orc_peak_energy_find(const orc_cf *cv, int len, int win, enum orc_peak_alg alg, orc_cf *peak_val)
+{
+	int mi = 0;
+	float me = -1.0f, pos;
+
+	if (win > len)
+		win = len;
+	for (int m = 0; m + win <= len; m++) {
+		float e = 0.0f;
+		for (int k = 0; k < win; k++)
+			e += normsq(cv[m + k]);
+		if (e > me) { me = e; mi = m; }
+	}
+
+	if (alg == ORC_PEAK_WEIGH_WIN) {
+		float num = 0.0f, den = 0.0f;
+		for (int k = 0; k < win; k++) {
+			float e = normsq(cv[mi + k]);
+			num += e * (float)(mi + k);
+			den += e;
+		}
+		pos = num / den;
+	} else {
+		int p = mi;
+		float pe = -1.0f, early, late, incr = 0.5f;
+		for (int k = 0; k < win; k++) {
+			float e = normsq(cv[mi + k]);
+			if (e > pe) { pe = e; p = mi + k; }
+		}
+		early = (float)p - 1.0f;
+		late  = (float)p + 1.0f;
+		while (incr > (1.0f / 1024.0f)) {
+			float ee = normsq(orc_interpolate_point(cv, len, early));
+			float le = normsq(orc_interpolate_point(cv, len, late));
+			if (ee > le)      { early -= incr; late -= incr; }
+			else if (ee < le) { early += incr; late += incr; }
+			else break;
+			incr /= 2.0f;
+		}
+		pos = early + 1.0f;
+	}
+	if (peak_val)
+		*peak_val = orc_interpolate_point(cv, len, pos);
+	return pos;
+}
+
+void orc_peaks_scan(const orc_cf *cv, int len, int *idx, int N)
+{
+	/* indices of the N largest |.|^2, descending; first index wins ties */
+	for (int k = 0; k < N; k++) {
+		int best = -1;
+		float be = -1.0f;
+		for (int i = 0; i < len; i++) {
+			int used = 0;
+			for (int q = 0; q < k; q++) if (idx[q] == i) used = 1;
+			if (used) continue;
+			float e = normsq(cv[i]);
+			if (e > be) { be = e; best = i; }
+		}
+		idx[k] = best;
+	}
+}
+
+void orc_rotate(orc_cf *v, int len, float rps)
+{
+	for (int i = 0; i < len; i++) {
+		float ph = rps * (float)i;
+		v[i] *= (cosf(ph) + I * sinf(ph));
+	}
+}
+
+void orc_scale(orc_cf *v, int len, orc_cf s)
+{
+	for (int i = 0; i < len; i++)
+		v[i] *= s;
+}
+
+void orc_convolve_nodelay_real(const float *f, int f_len, const orc_cf *g, int g_len, orc_cf *out)
+{
+	int half = f_len >> 1;
+	for (int n = 0; n < g_len; n++) {
+		orc_cf acc = 0.0f;
+		for (int k = 0; k < f_len; k++) {
+			int j = n + half - k;
+			if (j >= 0 && j < g_len)
+				acc += f[k] * g[j];
+		}
+		out[n] = acc;
+	}
+}
+
+void orc_dft_forward(orc_cf *v, int len)
+{
+	double complex *tmp = malloc(sizeof(double complex) * (size_t)len);
+	for (int k = 0; k < len; k++) {
+		double complex acc = 0.0;
+		for (int n = 0; n < len; n++) {
+			long kn = ((long)k * n) % len;
+			double ph = -2.0 * M_PI * (double)kn / (double)len;
+			acc += (double complex)v[n] * (cos(ph) + I * sin(ph));
+		}
+		tmp[k] = acc;
+	}
+	for (int k = 0; k < len; k++)
+		v[k] = (orc_cf)tmp[k];
+	free(tmp);
+}

@@ -1,0 +1,105 @@
+/*
+ * oracle/orc_gmr1.h -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * CPU restatement of the reference's GMR-1 receive hot path (SURVEY.md
+ * section 8a rows a1-a21).  Function names are the reference's with the
+ * gmr1_ prefix replaced by orc_; each definition cites the reference
+ * file:line it follows.  PARITY UNPINNED (see orc_3p.h): the reference
+ * has no tests or vectors and cannot be built in this image because its
+ * arithmetic lives in libosmocore / libosmo-dsp / FFTW3f, which are absent.
+ */
+#ifndef ORC_GMR1_H
+#define ORC_GMR1_H
+
+#include "orc_3p.h"
+
+/* ---- sdr: burst descriptions (reference include/osmocom/gmr1/sdr/pi4cxpsk.h:43-98) */
+
+#define ORC_MAX_SYNC      4
+#define ORC_MAX_CHUNKS    8
+#define ORC_MAX_SYNC_SYMS 32
+
+struct orc_chunk { int pos, len; uint8_t syms[ORC_MAX_SYNC_SYMS]; };
+
+struct orc_burst {
+	const char *name;
+	float rotation;     /* per-symbol rotation (rad)      */
+	int nbits;          /* ebits per symbol (1 or 2)      */
+	int guard_pre, guard_post;
+	int len;            /* symbols incl. guard            */
+	int ebits;
+	int n_sync;         /* number of alternative sync sequences */
+	int n_sync_chunks[ORC_MAX_SYNC];
+	struct orc_chunk sync[ORC_MAX_SYNC][ORC_MAX_CHUNKS];
+	int n_data;
+	struct orc_chunk data[ORC_MAX_CHUNKS];   /* syms unused */
+};
+
+enum orc_burst_id {
+	ORC_BURST_BCCH = 0, ORC_BURST_DC2, ORC_BURST_DC6, ORC_BURST_DC12,
+	ORC_BURST_NT3_SPEECH, ORC_BURST_NT3_FACCH, ORC_BURST_NT6, ORC_BURST_NT9,
+	ORC_BURST_RACH, ORC_BURST_SDCCH, ORC_BURST__COUNT
+};
+
+const struct orc_burst *orc_burst_get(int id);
+
+int orc_pi4cxpsk_demod(const struct orc_burst *bt, const orc_cf *in, int in_len,
+                       int sps, float freq_shift, orc_sbit_t *ebits,
+                       int *sync_id_p, float *toa_p, float *freq_err_p,
+                       float *ssyms_out /* optional: bt->len soft symbols */);
+int orc_pi4cxpsk_detect(const struct orc_burst *const *bts, int n_bts, float e_toa,
+                        const orc_cf *in, int in_len, int sps, float freq_shift,
+                        int *bt_id_p, int *sync_id_p, float *toa_p);
+int orc_pi4cxpsk_mod_order(const orc_cf *in, int in_len, int sps, float freq_shift);
+int orc_pi4cxpsk_mod(const struct orc_burst *bt, const orc_ubit_t *ebits, int sync_id, orc_cf *out);
+
+/* ---- sdr: FCCH (reference include/osmocom/gmr1/sdr/fcch.h:36-61) */
+
+struct orc_fcch_burst { float freq; int len; };
+extern const struct orc_fcch_burst orc_fcch_burst, orc_fcch3_lband_burst, orc_fcch3_sband_burst;
+
+int orc_fcch_rough(const struct orc_fcch_burst *bt, const orc_cf *in, int in_len,
+                   int sps, float freq_shift, int *toa);
+int orc_fcch_rough_multi(const struct orc_fcch_burst *bt, const orc_cf *in, int in_len,
+                         int sps, float freq_shift, int *peaks_toa, int N);
+int orc_fcch_fine(const struct orc_fcch_burst *bt, const orc_cf *in, int in_len,
+                  int sps, float freq_shift, int *toa, float *freq_error);
+int orc_fcch_snr(const struct orc_fcch_burst *bt, const orc_cf *in, int in_len,
+                 int sps, float freq_shift, float *snr);
+
+/* ---- l1 primitives */
+
+void orc_scramble_sbit(orc_sbit_t *out, const orc_sbit_t *in, int len);
+void orc_scramble_ubit(orc_ubit_t *out, const orc_ubit_t *in, int len);
+void orc_interleave_intra(void *out, const void *in, int N);
+void orc_deinterleave_intra(void *out, const void *in, int N);
+
+/* ---- l1 channel codecs */
+
+void orc_bcch_encode(orc_ubit_t *bits_e, const uint8_t *l2);
+int  orc_bcch_decode(uint8_t *l2, const orc_sbit_t *bits_e, int *conv_rv);
+void orc_ccch_encode(orc_ubit_t *bits_e, const uint8_t *l2);
+int  orc_ccch_decode(uint8_t *l2, const orc_sbit_t *bits_e, int *conv_rv);
+void orc_facch3_encode(orc_ubit_t *bits_e, const uint8_t *l2,
+                       const orc_ubit_t *bits_s, const orc_ubit_t *ciph);
+int  orc_facch3_decode(uint8_t *l2, orc_ubit_t *bits_s, const orc_sbit_t *bits_e,
+                       const orc_ubit_t *ciph, int *conv_rv);
+/* NOTE: the reference's tch3 ENCODER passes its conv in/out swapped
+ * (tch3.c:81); orc_tch3_encode is the evidently intended encoder. */
+void orc_tch3_encode(orc_ubit_t *bits_e, const uint8_t *frame0, const uint8_t *frame1,
+                     const orc_ubit_t *bits_s, const orc_ubit_t *ciph, int m);
+void orc_tch3_decode(uint8_t *frame0, uint8_t *frame1, orc_ubit_t *bits_s,
+                     const orc_sbit_t *bits_e, const orc_ubit_t *ciph, int m,
+                     int *conv0_rv, int *conv1_rv);
+
+/* ---- batch drivers used by tests and by bench.py's cpu_baseline leg only */
+
+/* kind: 0 = BCCH (orc_burst BCCH + bcch_decode), 1 = CCCH (DC6 + ccch_decode) */
+void orc_demod_decode_batch(int n, const orc_cf *iq, const uint64_t *offset,
+                            const uint8_t *kind, int sps, const float *freq_shift,
+                            uint8_t *l2 /* n*24 */, int32_t *crc, int32_t *conv,
+                            float *toa, float *freq_err,
+                            orc_sbit_t *ebits /* optional n*432 */,
+                            float *ssyms /* optional n*234 */, int32_t *rv);
+
+#endif

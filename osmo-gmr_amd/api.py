@@ -1,0 +1,240 @@
+"""ctypes mirror of the C ABI in include/gmr1_hip.h (libgmr1_hip.so).
+
+This is plumbing only: every function forwards to the shared library, which runs
+HIP kernels.  There is no Python or CPU implementation behind these calls --
+if the library is missing or no GPU is usable they raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MAX_SYNC, MAX_CHUNKS, MAX_SYNC_SYMS = 4, 8, 32
+BURST_IDS = ["bcch", "dc2", "dc6", "dc12", "nt3_speech", "nt3_facch", "nt6", "nt9", "rach", "sdcch"]
+
+# every symbol include/gmr1_hip.h and include/osmocom/gmr1/**.h declare
+EXPORTED_FUNCTIONS = [
+    "gmr1_hip_init", "gmr1_hip_last_error", "gmr1_hip_version", "gmr1_hip_burst_info",
+    "gmr1_hip_demod_batch_dev", "gmr1_hip_demod_batch",
+    "gmr1_hip_bcch_decode_batch_dev", "gmr1_hip_ccch_decode_batch_dev",
+    "gmr1_hip_bcch_decode_batch", "gmr1_hip_ccch_decode_batch",
+    "gmr1_hip_rx_bcch_ccch_batch_dev", "gmr1_hip_rx_bcch_ccch_batch",
+    "gmr1_pi4cxpsk_demod", "gmr1_bcch_decode", "gmr1_ccch_decode",
+]
+EXPORTED_DATA = [
+    "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
+    "gmr1_bcch_burst", "gmr1_dc2_burst", "gmr1_dc6_burst", "gmr1_dc12_burst",
+    "gmr1_nt3_speech_burst", "gmr1_nt3_facch_burst", "gmr1_nt6_burst", "gmr1_nt9_burst",
+    "gmr1_rach_burst", "gmr1_sdcch_burst",
+]
+
+
+class Chunk(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("len", C.c_int32), ("syms", C.c_uint8 * MAX_SYNC_SYMS)]
+
+
+class BurstFlat(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 16), ("rotation", C.c_float), ("nbits", C.c_int32),
+        ("guard_pre", C.c_int32), ("guard_post", C.c_int32), ("len", C.c_int32), ("ebits", C.c_int32),
+        ("n_sync", C.c_int32), ("n_sync_chunks", C.c_int32 * MAX_SYNC),
+        ("sync", (Chunk * MAX_CHUNKS) * MAX_SYNC),
+        ("n_data", C.c_int32), ("data", Chunk * MAX_CHUNKS),
+    ]
+
+
+class CxVec(C.Structure):
+    """struct osmo_cxvec (include/osmocom/gmr1/compat.h)."""
+    _fields_ = [("len", C.c_int), ("max_len", C.c_int), ("flags", C.c_int), ("data", C.c_void_p)]
+
+
+class Gmr1HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = False):
+    """dlopen libgmr1_hip.so (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        if build_if_missing:
+            _build.build()
+        else:
+            raise Gmr1HipError(
+                f"{path} is missing: the HIP extension has not been built "
+                "(run __graft_entry__.build()); there is no CPU fallback")
+    _lib = C.CDLL(path)
+    _lib.gmr1_hip_last_error.restype = C.c_char_p
+    _lib.gmr1_hip_version.restype = C.c_char_p
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gmr1_hip_last_error().decode(errors="replace")
+        raise Gmr1HipError(f"{what} failed with {rc}: {msg}")
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a, dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def burst_info(name_or_id) -> BurstFlat:
+    i = BURST_IDS.index(name_or_id) if isinstance(name_or_id, str) else int(name_or_id)
+    out = BurstFlat()
+    _check(load().gmr1_hip_burst_info(C.c_int(i), C.byref(out)), "gmr1_hip_burst_info")
+    return out
+
+
+def burst_format(name_or_id):
+    """Product burst table -> synth.BurstFormat."""
+    from . import synth
+    b = burst_info(name_or_id)
+    sync = []
+    for s in range(b.n_sync):
+        sync.append([(b.sync[s][c].pos, [int(b.sync[s][c].syms[k]) for k in range(b.sync[s][c].len)])
+                     for c in range(b.n_sync_chunks[s])])
+    data = [(b.data[c].pos, b.data[c].len) for c in range(b.n_data)]
+    return synth.BurstFormat(b.name.decode(), float(b.rotation), b.nbits, b.len, b.ebits, sync, data)
+
+
+def init(device: int = 0):
+    _check(load().gmr1_hip_init(C.c_int(device)), "gmr1_hip_init")
+
+
+# ---------------------------------------------------------------------------
+# host-pointer batch calls (numpy in, numpy out)
+# ---------------------------------------------------------------------------
+def demod_batch(burst, iq, offset, in_len, sps=4, freq_shift=None, want_ssyms=True):
+    bid = BURST_IDS.index(burst) if isinstance(burst, str) else int(burst)
+    info = burst_info(bid)
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    eb = np.zeros((n, info.ebits), np.int8)
+    sid = np.zeros(n, np.int32)
+    toa = np.zeros(n, np.float32)
+    fe = np.zeros(n, np.float32)
+    ss = np.zeros((n, info.len), np.float32) if want_ssyms else None
+    rv = np.zeros(n, np.int32)
+    rc = load().gmr1_hip_demod_batch(
+        C.c_int(bid), C.c_int(n), C.c_int(sps), C.c_int(in_len), p_iq, C.c_uint64(iq.size), p_off, fs_p,
+        eb.ctypes.data_as(C.c_void_p), C.c_int(info.ebits), sid.ctypes.data_as(C.c_void_p),
+        toa.ctypes.data_as(C.c_void_p), fe.ctypes.data_as(C.c_void_p),
+        ss.ctypes.data_as(C.c_void_p) if ss is not None else None, rv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_demod_batch")
+    return dict(rv=rv, ebits=eb, sync_id=sid, toa=toa, freq_err=fe, ssyms=ss)
+
+
+def _l1_batch(fn, ebits, neb):
+    ebits, p = _np(ebits, np.int8)
+    ebits = ebits.reshape(-1, neb)
+    n = ebits.shape[0]
+    l2 = np.zeros((n, 24), np.uint8)
+    crc = np.zeros(n, np.int32)
+    conv = np.zeros(n, np.int32)
+    rc = getattr(load(), fn)(C.c_int(n), p, l2.ctypes.data_as(C.c_void_p),
+                             crc.ctypes.data_as(C.c_void_p), conv.ctypes.data_as(C.c_void_p))
+    _check(rc, fn)
+    return l2, crc, conv
+
+
+def bcch_decode_batch(ebits):
+    return _l1_batch("gmr1_hip_bcch_decode_batch", ebits, 424)
+
+
+def ccch_decode_batch(ebits):
+    return _l1_batch("gmr1_hip_ccch_decode_batch", ebits, 432)
+
+
+def rx_bcch_ccch_batch(iq, offset, kind, sps=4, freq_shift=None, want_ebits=True, want_ssyms=True):
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    kind, p_kind = _np(kind, np.uint8)
+    n = kind.size
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    out = dict(l2=np.zeros((n, 24), np.uint8), crc=np.zeros(n, np.int32), conv=np.zeros(n, np.int32),
+               toa=np.zeros(n, np.float32), freq_err=np.zeros(n, np.float32), rv=np.zeros(n, np.int32))
+    eb = np.zeros((n, 432), np.int8) if want_ebits else None
+    ss = np.zeros((n, 234), np.float32) if want_ssyms else None
+    rc = load().gmr1_hip_rx_bcch_ccch_batch(
+        C.c_int(n), C.c_int(sps), p_iq, C.c_uint64(iq.size), p_off, p_kind, fs_p,
+        out["l2"].ctypes.data_as(C.c_void_p), out["crc"].ctypes.data_as(C.c_void_p),
+        out["conv"].ctypes.data_as(C.c_void_p), out["toa"].ctypes.data_as(C.c_void_p),
+        out["freq_err"].ctypes.data_as(C.c_void_p),
+        eb.ctypes.data_as(C.c_void_p) if eb is not None else None,
+        ss.ctypes.data_as(C.c_void_p) if ss is not None else None,
+        out["rv"].ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_rx_bcch_ccch_batch")
+    out["ebits"], out["ssyms"] = eb, ss
+    return out
+
+
+# ---------------------------------------------------------------------------
+# reference-style single-burst calls (the legacy C API, through ctypes)
+# ---------------------------------------------------------------------------
+def pi4cxpsk_demod(burst_name: str, iq, sps=4, freq_shift=0.0):
+    """gmr1_pi4cxpsk_demod(&gmr1_<name>_burst, cxvec, ...) exactly as C callers use it."""
+    L = load()
+    bt = C.c_void_p.in_dll(L, f"gmr1_{burst_name}_burst")   # address of the exported struct
+    info = burst_info(burst_name)
+    iq = np.ascontiguousarray(iq, np.complex64)
+    vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    eb = np.zeros(info.ebits, np.int8)
+    sid, toa, fe = C.c_int(-1), C.c_float(), C.c_float()
+    f = L.gmr1_pi4cxpsk_demod
+    f.restype = C.c_int
+    rv = f(C.c_void_p(C.addressof(bt)), C.byref(vec), C.c_int(sps), C.c_float(freq_shift),
+           eb.ctypes.data_as(C.c_void_p), C.byref(sid), C.byref(toa), C.byref(fe))
+    return dict(rv=rv, ebits=eb, sync_id=sid.value, toa=toa.value, freq_err=fe.value)
+
+
+def _decode1(fn, ebits):
+    ebits = np.ascontiguousarray(ebits, np.int8)
+    l2 = np.zeros(24, np.uint8)
+    cv = C.c_int()
+    f = getattr(load(), fn)
+    f.restype = C.c_int
+    rv = f(l2.ctypes.data_as(C.c_void_p), ebits.ctypes.data_as(C.c_void_p), C.byref(cv))
+    return l2, rv, cv.value
+
+
+def bcch_decode(ebits):
+    return _decode1("gmr1_bcch_decode", ebits)
+
+
+def ccch_decode(ebits):
+    return _decode1("gmr1_ccch_decode", ebits)
+
+
+# ---------------------------------------------------------------------------
+# device-pointer calls (torch tensors as plumbing for HBM + streams)
+# ---------------------------------------------------------------------------
+def rx_bcch_ccch_batch_dev(stream, n, sps, iq, offset, kind, freq_shift, l2, crc, conv, toa, freq_err,
+                           ebits, ssyms, rv):
+    """All tensor arguments are device pointers (ints) or None."""
+    f = load().gmr1_hip_rx_bcch_ccch_batch_dev
+    f.restype = C.c_int
+    vp = lambda x: C.c_void_p(x) if x else None
+    rc = f(vp(stream), C.c_int(n), C.c_int(sps), vp(iq), vp(offset), vp(kind), vp(freq_shift),
+           vp(l2), vp(crc), vp(conv), vp(toa), vp(freq_err), vp(ebits), vp(ssyms), vp(rv))
+    _check(rc, "gmr1_hip_rx_bcch_ccch_batch_dev")

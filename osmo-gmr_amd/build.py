@@ -1,0 +1,75 @@
+"""Build csrc/ into libgmr1_hip.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container as
+the "does it build" check and the resulting .so travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgmr1_hip.so")
+ARCH = "gfx950"
+
+HIP_SOURCES = ["rx_kernels.hip", "fcch_kernels.hip"]
+CXX_SOURCES = ["capi.cpp", "host_tables.cpp"]
+
+COMMON = [
+    "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+    "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def sources():
+    out = []
+    for s in HIP_SOURCES + CXX_SOURCES:
+        p = os.path.join(CSRC, s)
+        if os.path.exists(p):
+            out.append(p)
+    return out
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    for d, _, files in os.walk(os.path.join(ROOT, "include")):
+        deps += [os.path.join(d, f) for f in files]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    for src in sources():
+        obj = os.path.splitext(src)[0] + ".o"
+        cmd = [hipcc()] + COMMON + ["--offload-arch=" + ARCH, "-c", src, "-o", obj]
+        if src.endswith(".hip"):
+            cmd.insert(1, "-xhip")
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

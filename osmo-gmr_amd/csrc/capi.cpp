@@ -1,0 +1,457 @@
+// capi.cpp -- the C-ABI shim: reference-compatible per-burst calls and the
+// batched entry points of include/gmr1_hip.h.  Host code only; every compute
+// step is a HIP kernel (rx_kernels.hip).  There is no CPU fallback: without a
+// HIP device every call returns -ENODEV.
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include <osmocom/gmr1/l1/bcch.h>
+#include <osmocom/gmr1/l1/ccch.h>
+
+#include "gmr1_dev.h"
+#include "host_tables.h"
+
+namespace gmr1 {
+namespace {
+
+thread_local char t_err[256] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(t_err, sizeof(t_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+	do {                                                                               \
+		hipError_t e_ = (expr);                                                        \
+		if (e_ != hipSuccess)                                                          \
+			return fail(e_ == hipErrorNoDevice ? -ENODEV : -EIO, "%s: %s", #expr,      \
+			            hipGetErrorString(e_));                                        \
+	} while (0)
+
+constexpr int kMaxDevices = 16;
+
+struct DevState {
+	bool ready = false;
+	DevBurst *types = nullptr;      // kNumTypes descriptors in HBM
+};
+
+std::mutex g_mu;
+DevState g_dev[kMaxDevices];
+DevBurst g_host_types[kNumTypes];
+bool g_host_types_ready = false;
+
+int host_types()
+{
+	if (g_host_types_ready)
+		return 0;
+	tables_init();
+	std::memset(g_host_types, 0, sizeof(g_host_types));
+	for (int i = 0; i < GMR1_HIP_N_BURSTS; i++) {
+		gmr1_hip_burst_flat f;
+		int rv = flatten(kBuiltin[i], &f, kBuiltinName[i]);
+		if (rv == 0)
+			rv = to_dev(f, &g_host_types[i]);
+		if (rv)
+			return fail(rv, "built-in burst table %d is inconsistent", i);
+	}
+	g_host_types_ready = true;
+	return 0;
+}
+
+// per-device state for the CURRENT device
+int dev_state(DevState **out)
+{
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0)
+		return fail(-ENODEV, "no HIP device available (%s)", hipGetErrorString(e));
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	if (dev < 0 || dev >= kMaxDevices)
+		return fail(-EINVAL, "device index %d out of range", dev);
+	std::lock_guard<std::mutex> lk(g_mu);
+	DevState &s = g_dev[dev];
+	if (!s.ready) {
+		int rv = host_types();
+		if (rv)
+			return rv;
+		HIP_TRY(hipMalloc(&s.types, sizeof(g_host_types)));
+		HIP_TRY(hipMemcpy(s.types, g_host_types, sizeof(g_host_types), hipMemcpyHostToDevice));
+		s.ready = true;
+	}
+	*out = &s;
+	return 0;
+}
+
+// RAII device buffer for the host-pointer variants
+struct DBuf {
+	void *p = nullptr;
+	~DBuf() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+	template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+int window_len(int burst_len, int sps, int win) { return burst_len * sps + win; }
+
+}  // namespace
+}  // namespace gmr1
+
+using namespace gmr1;
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// library / device
+// ---------------------------------------------------------------------------
+const char *gmr1_hip_version(void) { return "gmr1-hip 0.1 (gfx950)"; }
+const char *gmr1_hip_last_error(void) { return t_err; }
+
+int gmr1_hip_init(int device)
+{
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0)
+		return fail(-ENODEV, "no HIP device available (%s)", hipGetErrorString(e));
+	if (device < 0 || device >= count)
+		return fail(-EINVAL, "device %d not in [0,%d)", device, count);
+	HIP_TRY(hipSetDevice(device));
+	DevState *s;
+	return dev_state(&s);
+}
+
+int gmr1_hip_burst_info(int burst_id, struct gmr1_hip_burst_flat *out)
+{
+	if (burst_id < 0 || burst_id >= GMR1_HIP_N_BURSTS || !out)
+		return fail(-EINVAL, "bad burst id %d", burst_id);
+	return flatten(kBuiltin[burst_id], out, kBuiltinName[burst_id]);
+}
+
+// ---------------------------------------------------------------------------
+// demod batch
+// ---------------------------------------------------------------------------
+static int demod_dev_impl(hipStream_t st, const DevBurst *types, int type, const DevBurst &ht,
+                          int n, int sps, int in_len, const float *iq, const uint64_t *offset,
+                          const float *freq_shift, int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                          float *toa, float *freq_err, float *ssyms, int32_t *rv)
+{
+	if (n < 0 || !iq || !offset || !rv)
+		return fail(-EINVAL, "demod: n/iq/offset/rv are required");
+	if (sps < 4 || sps > 16)
+		return fail(-EINVAL, "demod: sps=%d unsupported (this build handles 4..16)", sps);
+	const int w = in_len - ht.len * sps + 1;
+	if (w < 1 || w > kMaxWindow || in_len > kMaxInLen)
+		return fail(-EINVAL, "demod: window of %d samples gives %d lags (1..%d supported, <= %d samples)",
+		            in_len, w, kMaxWindow, kMaxInLen);
+	if (ebits && ebits_stride < ht.ebits)
+		return fail(-EINVAL, "demod: ebits_stride %d < %d", ebits_stride, ht.ebits);
+	RxArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.n = n; a.sps = sps; a.in_len[0] = a.in_len[1] = in_len;
+	a.fixed_type = type;
+	a.ebits_stride = ebits_stride;
+	a.ssyms_stride = ht.len;
+	a.types = types;
+	a.iq = reinterpret_cast<const float2 *>(iq);
+	a.offset = offset; a.freq_shift = freq_shift;
+	a.ebits = ebits; a.sync_id = sync_id; a.toa = toa; a.freq_err = freq_err; a.ssyms = ssyms; a.rv = rv;
+	HIP_TRY(launch_rx(a, false, in_len, st));
+	return 0;
+}
+
+int gmr1_hip_demod_batch_dev(void *stream, int burst_id, int n, int sps, int in_len,
+                             const float *iq, const uint64_t *offset, const float *freq_shift,
+                             int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                             float *toa, float *freq_err, float *ssyms, int32_t *rv)
+{
+	if (burst_id < 0 || burst_id >= GMR1_HIP_N_BURSTS)
+		return fail(-EINVAL, "bad burst id %d", burst_id);
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	return demod_dev_impl((hipStream_t)stream, s->types, burst_id, g_host_types[burst_id], n, sps, in_len,
+	                      iq, offset, freq_shift, ebits, ebits_stride, sync_id, toa, freq_err, ssyms, rv);
+}
+
+// host-pointer staging shared by the batch wrapper and the legacy call
+static int demod_host_impl(int type, const DevBurst &ht, const DevBurst *custom,
+                           int n, int sps, int in_len, const float *iq, uint64_t iq_len,
+                           const uint64_t *offset, const float *freq_shift,
+                           int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                           float *toa, float *freq_err, float *ssyms, int32_t *rv)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0)
+		return 0;
+	for (int i = 0; i < n; i++)
+		if (offset[i] + (uint64_t)in_len > iq_len)
+			return fail(-EINVAL, "burst %d runs past the end of iq", i);
+	hipStream_t st = nullptr;
+	if (custom)
+		HIP_TRY(hipMemcpy(s->types + kCustomSlot, custom, sizeof(DevBurst), hipMemcpyHostToDevice));
+	DBuf d_iq, d_off, d_fs, d_eb, d_sid, d_toa, d_fe, d_ss, d_rv;
+	HIP_TRY(d_iq.alloc(iq_len * 8));
+	HIP_TRY(d_off.alloc((size_t)n * 8));
+	HIP_TRY(d_rv.alloc((size_t)n * 4));
+	HIP_TRY(hipMemcpy(d_iq.p, iq, iq_len * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_off.p, offset, (size_t)n * 8, hipMemcpyHostToDevice));
+	if (freq_shift) {
+		HIP_TRY(d_fs.alloc((size_t)n * 4));
+		HIP_TRY(hipMemcpy(d_fs.p, freq_shift, (size_t)n * 4, hipMemcpyHostToDevice));
+	}
+	if (ebits) HIP_TRY(d_eb.alloc((size_t)n * ebits_stride));
+	if (sync_id) HIP_TRY(d_sid.alloc((size_t)n * 4));
+	if (toa) HIP_TRY(d_toa.alloc((size_t)n * 4));
+	if (freq_err) HIP_TRY(d_fe.alloc((size_t)n * 4));
+	if (ssyms) HIP_TRY(d_ss.alloc((size_t)n * ht.len * 4));
+	r = demod_dev_impl(st, s->types, type, ht, n, sps, in_len, d_iq.as<float>(), d_off.as<uint64_t>(),
+	                   freq_shift ? d_fs.as<float>() : nullptr, ebits ? d_eb.as<int8_t>() : nullptr,
+	                   ebits_stride, sync_id ? d_sid.as<int32_t>() : nullptr,
+	                   toa ? d_toa.as<float>() : nullptr, freq_err ? d_fe.as<float>() : nullptr,
+	                   ssyms ? d_ss.as<float>() : nullptr, d_rv.as<int32_t>());
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(st));
+	HIP_TRY(hipMemcpy(rv, d_rv.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (ebits) HIP_TRY(hipMemcpy(ebits, d_eb.p, (size_t)n * ebits_stride, hipMemcpyDeviceToHost));
+	if (sync_id) HIP_TRY(hipMemcpy(sync_id, d_sid.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (toa) HIP_TRY(hipMemcpy(toa, d_toa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (freq_err) HIP_TRY(hipMemcpy(freq_err, d_fe.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (ssyms) HIP_TRY(hipMemcpy(ssyms, d_ss.p, (size_t)n * ht.len * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int gmr1_hip_demod_batch(int burst_id, int n, int sps, int in_len,
+                         const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
+                         int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                         float *toa, float *freq_err, float *ssyms, int32_t *rv)
+{
+	if (burst_id < 0 || burst_id >= GMR1_HIP_N_BURSTS)
+		return fail(-EINVAL, "bad burst id %d", burst_id);
+	int r = host_types();
+	if (r) return r;
+	return demod_host_impl(burst_id, g_host_types[burst_id], nullptr, n, sps, in_len, iq, iq_len, offset,
+	                       freq_shift, ebits, ebits_stride, sync_id, toa, freq_err, ssyms, rv);
+}
+
+// ---------------------------------------------------------------------------
+// reference-compatible single burst demodulation (pi4cxpsk.h:101-105)
+// ---------------------------------------------------------------------------
+int gmr1_pi4cxpsk_demod(struct gmr1_pi4cxpsk_burst *burst_type,
+                        struct osmo_cxvec *burst_in, int sps, float freq_shift,
+                        sbit_t *ebits, int *sync_id_p, float *toa_p, float *freq_err_p)
+{
+	if (!burst_type || !burst_in || !burst_in->data || !ebits)
+		return fail(-EINVAL, "gmr1_pi4cxpsk_demod: NULL argument");
+	int r = host_types();
+	if (r) return r;
+	int type = -1;
+	for (int i = 0; i < GMR1_HIP_N_BURSTS; i++)
+		if (burst_type == kBuiltin[i])
+			type = i;
+	DevBurst custom;
+	const DevBurst *cp = nullptr;
+	if (type < 0) {
+		gmr1_hip_burst_flat f;
+		r = flatten(burst_type, &f, "custom");
+		if (r == 0) r = to_dev(f, &custom);
+		if (r) return fail(r, "gmr1_pi4cxpsk_demod: unsupported burst description");
+		type = kCustomSlot;
+		cp = &custom;
+	}
+	const DevBurst &ht = cp ? custom : g_host_types[type];
+	const uint64_t off = 0;
+	int32_t rv = 0, sid = -1;
+	float toa = 0.f, fe = 0.f;
+	r = demod_host_impl(type, ht, cp, 1, sps, burst_in->len, reinterpret_cast<const float *>(burst_in->data),
+	                    (uint64_t)burst_in->len, &off, &freq_shift, reinterpret_cast<int8_t *>(ebits), ht.ebits,
+	                    &sid, &toa, &fe, nullptr, &rv);
+	if (r) return r;
+	if (rv) return rv;
+	if (sync_id_p) *sync_id_p = sid;
+	if (toa_p) *toa_p = toa;
+	if (freq_err_p) *freq_err_p = fe;
+	return 0;
+}
+
+// ---------------------------------------------------------------------------
+// layer 1
+// ---------------------------------------------------------------------------
+static int l1_dev(hipStream_t st, int chain, int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv)
+{
+	if (n < 0 || !ebits || !l2 || !crc || !conv)
+		return fail(-EINVAL, "l1 decode: NULL argument");
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	L1Args a;
+	a.n = n; a.chain = chain; a.ebits = ebits; a.l2 = l2; a.crc = crc; a.conv = conv;
+	HIP_TRY(launch_l1(a, st));
+	return 0;
+}
+
+static int l1_host(int chain, int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv)
+{
+	const int neb = chain == kChainCcch ? 432 : 424;
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0) return 0;
+	DBuf d_eb, d_l2, d_crc, d_conv;
+	HIP_TRY(d_eb.alloc((size_t)n * neb));
+	HIP_TRY(d_l2.alloc((size_t)n * 24));
+	HIP_TRY(d_crc.alloc((size_t)n * 4));
+	HIP_TRY(d_conv.alloc((size_t)n * 4));
+	HIP_TRY(hipMemcpy(d_eb.p, ebits, (size_t)n * neb, hipMemcpyHostToDevice));
+	r = l1_dev(nullptr, chain, n, d_eb.as<int8_t>(), d_l2.as<uint8_t>(), d_crc.as<int32_t>(), d_conv.as<int32_t>());
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(l2, d_l2.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(crc, d_crc.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(conv, d_conv.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int gmr1_hip_bcch_decode_batch_dev(void *stream, int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv)
+{
+	return l1_dev((hipStream_t)stream, kChainBcch, n, ebits, l2, crc, conv);
+}
+
+int gmr1_hip_ccch_decode_batch_dev(void *stream, int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv)
+{
+	return l1_dev((hipStream_t)stream, kChainCcch, n, ebits, l2, crc, conv);
+}
+
+int gmr1_hip_bcch_decode_batch(int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv)
+{
+	return l1_host(kChainBcch, n, ebits, l2, crc, conv);
+}
+
+int gmr1_hip_ccch_decode_batch(int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv)
+{
+	return l1_host(kChainCcch, n, ebits, l2, crc, conv);
+}
+
+// reference-compatible single-burst decoders (bcch.h:38, ccch.h:38).  A device
+// failure cannot be reported through the reference's "crc result" return value
+// without being mistaken for a CRC verdict, so it is returned as -errno (< 0).
+int gmr1_bcch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv)
+{
+	int32_t crc = 0, conv = 0;
+	int r = l1_host(kChainBcch, 1, reinterpret_cast<const int8_t *>(bits_e), l2, &crc, &conv);
+	if (r) return r;
+	if (conv_rv) *conv_rv = conv;
+	return crc;
+}
+
+int gmr1_ccch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv)
+{
+	int32_t crc = 0, conv = 0;
+	int r = l1_host(kChainCcch, 1, reinterpret_cast<const int8_t *>(bits_e), l2, &crc, &conv);
+	if (r) return r;
+	if (conv_rv) *conv_rv = conv;
+	return crc;
+}
+
+// ---------------------------------------------------------------------------
+// fused BCCH / CCCH receive
+// ---------------------------------------------------------------------------
+int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
+                                    const float *iq, const uint64_t *offset, const uint8_t *kind,
+                                    const float *freq_shift,
+                                    uint8_t *l2, int32_t *crc, int32_t *conv,
+                                    float *toa, float *freq_err,
+                                    int8_t *ebits, float *ssyms, int32_t *rv)
+{
+	if (n < 0 || !iq || !offset || !kind || !l2 || !crc || !conv || !rv)
+		return fail(-EINVAL, "rx_bcch_ccch: iq/offset/kind/l2/crc/conv/rv are required");
+	if (sps < 4 || sps > 8)
+		return fail(-EINVAL, "rx_bcch_ccch: sps=%d unsupported (4..8)", sps);
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	RxArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.n = n; a.sps = sps;
+	a.in_len[0] = window_len(234, sps, 20 * sps);   // gmr1_rx.c:759
+	a.in_len[1] = window_len(234, sps, 10 * sps);   // gmr1_rx.c:809
+	a.fixed_type = -1;
+	a.ebits_stride = 432;
+	a.ssyms_stride = 234;
+	a.types = s->types;
+	a.iq = reinterpret_cast<const float2 *>(iq);
+	a.offset = offset; a.kind = kind; a.freq_shift = freq_shift;
+	a.l2 = l2; a.crc = crc; a.conv = conv; a.toa = toa; a.freq_err = freq_err;
+	a.ebits = ebits; a.ssyms = ssyms; a.rv = rv;
+	if (a.in_len[0] > kMaxInLen)
+		return fail(-EINVAL, "rx_bcch_ccch: window too long");
+	HIP_TRY(launch_rx(a, true, a.in_len[0], (hipStream_t)stream));
+	return 0;
+}
+
+int gmr1_hip_rx_bcch_ccch_batch(int n, int sps,
+                                const float *iq, uint64_t iq_len, const uint64_t *offset, const uint8_t *kind,
+                                const float *freq_shift,
+                                uint8_t *l2, int32_t *crc, int32_t *conv,
+                                float *toa, float *freq_err,
+                                int8_t *ebits, float *ssyms, int32_t *rv)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0) return 0;
+	if (!iq || !offset || !kind || !l2 || !crc || !conv || !rv)
+		return fail(-EINVAL, "rx_bcch_ccch: iq/offset/kind/l2/crc/conv/rv are required");
+	for (int i = 0; i < n; i++) {
+		const uint64_t len = (uint64_t)window_len(234, sps, (kind[i] ? 10 : 20) * sps);
+		if (offset[i] + len > iq_len)
+			return fail(-EINVAL, "burst %d runs past the end of iq", i);
+	}
+	DBuf d_iq, d_off, d_kind, d_fs, d_l2, d_crc, d_conv, d_toa, d_fe, d_eb, d_ss, d_rv;
+	HIP_TRY(d_iq.alloc(iq_len * 8));
+	HIP_TRY(d_off.alloc((size_t)n * 8));
+	HIP_TRY(d_kind.alloc((size_t)n));
+	HIP_TRY(d_l2.alloc((size_t)n * 24));
+	HIP_TRY(d_crc.alloc((size_t)n * 4));
+	HIP_TRY(d_conv.alloc((size_t)n * 4));
+	HIP_TRY(d_toa.alloc((size_t)n * 4));
+	HIP_TRY(d_fe.alloc((size_t)n * 4));
+	HIP_TRY(d_rv.alloc((size_t)n * 4));
+	if (freq_shift) HIP_TRY(d_fs.alloc((size_t)n * 4));
+	if (ebits) HIP_TRY(d_eb.alloc((size_t)n * 432));
+	if (ssyms) HIP_TRY(d_ss.alloc((size_t)n * 234 * 4));
+	HIP_TRY(hipMemcpy(d_iq.p, iq, iq_len * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_off.p, offset, (size_t)n * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_kind.p, kind, (size_t)n, hipMemcpyHostToDevice));
+	if (freq_shift) HIP_TRY(hipMemcpy(d_fs.p, freq_shift, (size_t)n * 4, hipMemcpyHostToDevice));
+	r = gmr1_hip_rx_bcch_ccch_batch_dev(nullptr, n, sps, d_iq.as<float>(), d_off.as<uint64_t>(), d_kind.as<uint8_t>(),
+	                                    freq_shift ? d_fs.as<float>() : nullptr,
+	                                    d_l2.as<uint8_t>(), d_crc.as<int32_t>(), d_conv.as<int32_t>(),
+	                                    d_toa.as<float>(), d_fe.as<float>(),
+	                                    ebits ? d_eb.as<int8_t>() : nullptr, ssyms ? d_ss.as<float>() : nullptr,
+	                                    d_rv.as<int32_t>());
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(l2, d_l2.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(crc, d_crc.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(conv, d_conv.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(rv, d_rv.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (toa) HIP_TRY(hipMemcpy(toa, d_toa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (freq_err) HIP_TRY(hipMemcpy(freq_err, d_fe.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (ebits) HIP_TRY(hipMemcpy(ebits, d_eb.p, (size_t)n * 432, hipMemcpyDeviceToHost));
+	if (ssyms) HIP_TRY(hipMemcpy(ssyms, d_ss.p, (size_t)n * 234 * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// gmr1_dev.h -- device-side data layout shared by the kernels and the host shim.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gmr1_hip.h"
+
+namespace gmr1 {
+
+constexpr int kMaxSync = GMR1_HIP_MAX_SYNC;
+constexpr int kMaxChunks = GMR1_HIP_MAX_CHUNKS;
+constexpr int kMaxSyncSyms = GMR1_HIP_MAX_SYNC_SYMS;
+constexpr int kMaxWindow = GMR1_HIP_MAX_WINDOW;
+constexpr int kMaxInLen = GMR1_HIP_MAX_IN_LEN;
+constexpr int kMaxCoef = 128;          // sync symbols of one sequence (RACH: 99)
+constexpr int kNumTypes = 16;          // descriptor table slots (10 built in + custom)
+constexpr int kCustomSlot = 15;
+
+// Burst format as the kernels read it (uniform / scalar loads).
+struct DevChunk {
+	int16_t pos, len;
+	uint8_t syms[kMaxSyncSyms];
+};
+
+struct DevBurst {
+	float rotation;
+	int32_t nbits, len, ebits;
+	int32_t n_sync;
+	int32_t n_chunks[kMaxSync];
+	int32_t sync_tl[kMaxSync];          // total sync symbols of each sequence
+	DevChunk sync[kMaxSync][kMaxChunks];
+	int32_t n_data;
+	int16_t dpos[kMaxChunks], dlen[kMaxChunks], dcum[kMaxChunks];
+};
+
+// L1 chain selector for the fused kernel / decode kernels
+enum Chain : int { kChainNone = 0, kChainBcch = 1, kChainCcch = 2 };
+
+struct RxArgs {
+	int n;                 // bursts
+	int sps;
+	int in_len[2];         // window length per kind (fused) ; [0] used when fixed_type >= 0
+	int fixed_type;        // >= 0: every burst has this type, demod only
+	int ebits_stride;
+	int ssyms_stride;
+	const DevBurst *types; // descriptor table (device)
+	const float2 *iq;
+	const uint64_t *offset;
+	const uint8_t *kind;
+	const float *freq_shift;
+	// outputs (device, optional unless noted)
+	uint8_t *l2;           // n x 24
+	int32_t *crc, *conv;
+	float *toa, *freq_err;
+	int8_t *ebits;
+	float *ssyms;
+	int32_t *rv;           // required
+	int32_t *sync_id;
+};
+
+struct L1Args {
+	int n;
+	int chain;             // kChainBcch / kChainCcch
+	const int8_t *ebits;   // n x (424|432)
+	uint8_t *l2;
+	int32_t *crc, *conv;
+};
+
+// launchers (rx_kernels.hip)
+hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t stream);
+hipError_t launch_l1(const L1Args &a, hipStream_t stream);
+size_t rx_lds_bytes(int max_in_len);
+
+}  // namespace gmr1

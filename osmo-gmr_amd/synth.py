@@ -1,0 +1,348 @@
+"""Seeded synthetic GMR-1 signal generator (numpy, host side).
+
+Produces the inputs BASELINE.md's configs describe: random L2 payloads run
+through this module's OWN channel encoders (written from the ETSI chains the
+reference implements in src/l1/{bcch,ccch,facch3,tch3}.c), mapped onto the
+burst formats of src/sdr/nb.c, pi/4-rotated, pulse shaped to sps samples per
+symbol and impaired (timing, CFO, phase, gain, AWGN).  Also the FCCH
+dual-chirp streams of config 2.
+
+Nothing here touches ``oracle/``: tests cross-check these encoders against the
+oracle's, and bench.py uses this module to fill HBM with its workload.
+
+Pulse: the reference demodulator samples symbols directly (no matched filter,
+pi4cxpsk.c:286-297) because the channelizer in utils/gmr1_rx_sdr.py:523-529
+already applied the receive RRC(0.35); the signal it sees is therefore a
+raised-cosine (alpha 0.35) pulse train, which is what is generated here, with
+noise added at the matched-filter output (variance N0 per complex sample for
+unit symbol energy).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+SYM_RATE = 23400
+
+
+# --------------------------------------------------------------------------
+# burst formats
+# --------------------------------------------------------------------------
+@dataclass
+class BurstFormat:
+    name: str
+    rotation: float
+    nbits: int
+    length: int
+    ebits: int
+    sync: list  # list (per sync sequence) of list of (pos, [symbols])
+    data: list  # list of (pos, len)
+
+    def data_positions(self) -> np.ndarray:
+        return np.concatenate([np.arange(p, p + l) for p, l in self.data])
+
+
+# --------------------------------------------------------------------------
+# bit-level primitives (vectorised over a leading batch axis)
+# --------------------------------------------------------------------------
+def unpack_lsb(data: np.ndarray, nbits: int) -> np.ndarray:
+    """bytes (B, n) -> bits (B, nbits), bit k = byte k>>3, bit k&7."""
+    data = np.asarray(data, dtype=np.uint8)
+    bits = np.unpackbits(data, axis=-1, bitorder="little")
+    return bits[..., :nbits]
+
+
+def unpack_msb(data: np.ndarray, nbits: int) -> np.ndarray:
+    data = np.asarray(data, dtype=np.uint8)
+    bits = np.unpackbits(data, axis=-1, bitorder="big")
+    return bits[..., :nbits]
+
+
+def crc_bits(bits: np.ndarray, nbits_crc: int, poly: int) -> np.ndarray:
+    """MSB-first CRC register, init 0, no final xor; returns (B, nbits_crc)."""
+    bits = np.asarray(bits, dtype=np.uint32)
+    top = 1 << (nbits_crc - 1)
+    mask = (1 << nbits_crc) - 1
+    crc = np.zeros(bits.shape[:-1], dtype=np.uint32)
+    for i in range(bits.shape[-1]):
+        crc ^= bits[..., i] << (nbits_crc - 1)
+        hi = (crc & top) != 0
+        crc = (crc << 1) & mask
+        crc = np.where(hi, crc ^ (poly & mask), crc)
+    out = np.stack([(crc >> (nbits_crc - 1 - j)) & 1 for j in range(nbits_crc)], axis=-1)
+    return out.astype(np.uint8)
+
+
+def conv_encode(bits: np.ndarray, polys, K: int, flush: bool = True,
+                tail_biting: bool = False) -> np.ndarray:
+    """Feed-forward convolutional encoder; poly bit i is the D^i tap.
+
+    Output (B, steps*N) in the order g0,g1,.. per input bit."""
+    bits = np.asarray(bits, dtype=np.uint8)
+    B, L = bits.shape
+    if tail_biting:
+        pre = bits[:, L - (K - 1):]
+        seq = np.concatenate([pre, bits], axis=1)
+        steps = L
+    elif flush:
+        seq = np.concatenate([np.zeros((B, K - 1), np.uint8), bits,
+                              np.zeros((B, K - 1), np.uint8)], axis=1)
+        steps = L + K - 1
+    else:
+        seq = np.concatenate([np.zeros((B, K - 1), np.uint8), bits], axis=1)
+        steps = L
+    out = np.zeros((B, steps, len(polys)), np.uint8)
+    for j, g in enumerate(polys):
+        acc = np.zeros((B, steps), np.uint8)
+        for d in range(K):
+            if (g >> d) & 1:
+                acc ^= seq[:, K - 1 - d:K - 1 - d + steps]
+        out[:, :, j] = acc
+    return out.reshape(B, steps * len(polys))
+
+
+def interleave_intra(bits: np.ndarray, N: int) -> np.ndarray:
+    kc = np.arange(8 * N)
+    kep = N * ((5 * kc) & 7) + (kc >> 3)
+    out = np.empty_like(bits)
+    out[..., kep] = bits[..., kc]
+    return out
+
+
+def scramble_mask(n: int) -> np.ndarray:
+    r = 0x4D4B
+    out = np.zeros(n, np.uint8)
+    for i in range(n):
+        b = ((r >> 14) ^ r) & 1
+        r = ((r << 1) | b) & 0xFFFF
+        out[i] = b
+    return out
+
+
+K5_12 = (0x19, 0x17)
+K5_14 = (0x19, 0x17, 0x15, 0x1F)
+K7_TCH3 = (0x6D, 0x4F)
+
+
+# --------------------------------------------------------------------------
+# channel encoders
+# --------------------------------------------------------------------------
+def bcch_encode(l2: np.ndarray) -> np.ndarray:
+    """(B,24) bytes -> (B,424) encoded hard bits."""
+    u = unpack_lsb(l2, 192)
+    u = np.concatenate([u, crc_bits(u, 16, 0x1021)], axis=1)
+    c = conv_encode(u, K5_12, 5)
+    ep = interleave_intra(c, 53)
+    return ep ^ scramble_mask(424)
+
+
+def ccch_encode(l2: np.ndarray) -> np.ndarray:
+    """(B,24) bytes -> (B,432) encoded hard bits (4 + 424 + 4)."""
+    u = unpack_lsb(l2, 192)
+    u = np.concatenate([u, crc_bits(u, 16, 0x1021)], axis=1)
+    c = conv_encode(u, K5_12, 5)
+    B = c.shape[0]
+    ep = np.zeros((B, 432), np.uint8)
+    ep[:, 4:428] = interleave_intra(c, 53)
+    return ep ^ scramble_mask(432)
+
+
+def facch3_encode(l2: np.ndarray, bits_s: np.ndarray) -> np.ndarray:
+    """(B,10) bytes (76 bits used), (B,32) status bits -> (B,4,104)."""
+    u = unpack_lsb(l2, 76)
+    u = np.concatenate([u, crc_bits(u, 16, 0x1021)], axis=1)
+    c = conv_encode(u, K5_14, 5)          # (B, 384)
+    B = c.shape[0]
+    i = np.arange(384)
+    cp = np.empty_like(c)
+    cp[:, (i & 3) * 96 + (i >> 2)] = c
+    out = np.zeros((B, 4, 104), np.uint8)
+    scr = scramble_mask(96)
+    for b in range(4):
+        xmy = interleave_intra(cp[:, 96 * b:96 * b + 96], 12) ^ scr
+        out[:, b, :22] = xmy[:, :22]
+        out[:, b, 22:30] = bits_s[:, 8 * b:8 * b + 8]
+        out[:, b, 30:] = xmy[:, 22:]
+    return out
+
+
+def tch3_perm() -> np.ndarray:
+    kc = np.arange(104)
+    ii, ij = kc % 24, kc // 24
+    return np.where(ii < 8, ij + 5 * ii, ij + 4 * ii + 8)
+
+
+def tch3_encode(frame0: np.ndarray, frame1: np.ndarray, bits_s: np.ndarray, m: int = 0) -> np.ndarray:
+    """two (B,10) speech frames + (B,4) status -> (B,212)."""
+    B = frame0.shape[0]
+    epp = np.zeros((B, 208), np.uint8)
+    perm = tch3_perm()
+    for i, fr in enumerate((frame0, frame1)):
+        d = unpack_msb(fr, 80)
+        c96 = conv_encode(d[:, :48], K7_TCH3, 7, flush=False, tail_biting=True)
+        keep = (np.arange(96) % 4) != 3           # P(1;2): every 4th bit punctured
+        c = np.concatenate([c96[:, keep], d[:, 48:]], axis=1)   # 72 + 32
+        ep = np.empty((B, 104), np.uint8)
+        ep[:, perm] = c
+        if m:
+            epp[:, 104 * i:104 * i + 104] = ep
+        else:
+            epp[:, i::2] = ep
+    xmy = epp ^ scramble_mask(208)
+    out = np.zeros((B, 212), np.uint8)
+    out[:, :52] = xmy[:, :52]
+    out[:, 52:56] = bits_s
+    out[:, 56:] = xmy[:, 52:]
+    return out
+
+
+# --------------------------------------------------------------------------
+# modulation + channel
+# --------------------------------------------------------------------------
+_CQPSK_BITS2SYM = np.array([0, 1, 3, 2])   # bits (b0 b1 MSB first) -> symbol index
+
+
+def map_symbols(fmt: BurstFormat, ebits: np.ndarray, sync_id=0) -> np.ndarray:
+    """(B, ebits) hard bits -> (B, length) complex64 symbols at 1 sps, pi/4 rotated."""
+    B = ebits.shape[0]
+    sym = np.zeros((B, fmt.length), np.complex64)
+    sync_id = np.broadcast_to(np.asarray(sync_id), (B,))
+    for sid in np.unique(sync_id):
+        rows = np.nonzero(sync_id == sid)[0]
+        for pos, syms in fmt.sync[int(sid)]:
+            idx = np.asarray(syms)
+            if fmt.nbits == 2:
+                v = np.exp(1j * (np.pi / 2) * idx)
+            else:
+                v = np.where(idx == 0, 1.0, -1.0)
+            sym[np.ix_(rows, np.arange(pos, pos + len(syms)))] = v.astype(np.complex64)
+    dpos = fmt.data_positions()
+    if fmt.nbits == 2:
+        idx = _CQPSK_BITS2SYM[(ebits[:, 0::2].astype(np.int64) << 1) | ebits[:, 1::2]]
+        v = np.exp(1j * (np.pi / 2) * idx)
+    else:
+        v = 1.0 - 2.0 * ebits.astype(np.float64)
+    sym[:, dpos] = v.astype(np.complex64)
+    sym *= np.exp(1j * fmt.rotation * np.arange(fmt.length)).astype(np.complex64)
+    return sym
+
+
+def rc_pulse(t: np.ndarray, alpha: float = 0.35) -> np.ndarray:
+    """Raised-cosine pulse, t in symbols."""
+    t = np.asarray(t, dtype=np.float64)
+    den = 1.0 - (2.0 * alpha * t) ** 2
+    sing = np.abs(den) < 1e-9
+    den = np.where(sing, 1.0, den)
+    g = np.sinc(t) * np.cos(np.pi * alpha * t) / den
+    return np.where(sing, (np.pi / 4) * np.sinc(1.0 / (2 * alpha)), g)
+
+
+@dataclass
+class BurstBatch:
+    iq: np.ndarray          # (B, stride) complex64 windows
+    stride: int
+    in_len: int             # samples of each window that belong to the burst window
+    toa: np.ndarray         # true TOA (samples, fractional) relative to window start
+    cfo: np.ndarray         # rad / sample
+    extra: dict = field(default_factory=dict)
+
+
+def synth_windows(fmt: BurstFormat, symbols: np.ndarray, sps: int, win: int, rng: np.random.Generator,
+                  *, toa_jitter: int = 0, frac: bool = False, cfo_hz_std: float = 0.0,
+                  esn0_db=None, gain_db_std: float = 0.0, span: int = 5,
+                  stride: int | None = None) -> BurstBatch:
+    """Shape (B, length) symbols into (B, stride) sample windows of length*sps + win.
+
+    The burst nominally starts win/2 samples into the window (gmr1_rx.c:149-170).
+    """
+    B, L = symbols.shape
+    in_len = L * sps + win
+    if stride is None:
+        stride = in_len
+    e_toa = win // 2
+    jit = rng.integers(-toa_jitter, toa_jitter + 1, size=B) if toa_jitter else np.zeros(B, np.int64)
+    fr = rng.uniform(-0.5, 0.5, size=B) if frac else np.zeros(B)
+    toa = e_toa + jit + fr
+
+    # burst-relative samples 4i+p, i in [-span, L+span): x[n] = sum_m s[i-m] g(m + (p - fr)/sps)
+    pad = span
+    spad = np.zeros((B, L + 4 * pad), np.complex64)
+    spad[:, 2 * pad:2 * pad + L] = symbols
+    n_sym_out = L + 2 * pad
+    body = np.zeros((sps, B, n_sym_out), np.complex64)      # phase-major: contiguous accumulations
+    tmp = np.empty((B, n_sym_out), np.complex64)
+    for p in range(sps):
+        for m in range(-span, span + 1):
+            coef = rc_pulse(m + (p - fr) / sps).astype(np.float32)      # (B,)
+            # output symbol slot i (burst index i - pad) uses s[i - pad - m]
+            np.multiply(spad[:, pad - m:pad - m + n_sym_out], coef[:, None], out=tmp)
+            body[p] += tmp
+    # sample k of the burst body <-> burst-relative n = k - pad*sps
+    body = np.ascontiguousarray(body.transpose(1, 2, 0)).reshape(B, n_sym_out * sps)
+
+    out = np.zeros((B, stride), np.complex64)
+    start = (e_toa + jit) - pad * sps                 # window index of body[0]
+    for s0 in np.unique(start):
+        rows = np.nonzero(start == s0)[0]
+        lo = max(0, s0)
+        hi = min(in_len, s0 + body.shape[1])
+        out[rows, lo:hi] = body[rows, lo - s0:hi - s0]
+    del body, tmp
+
+    n = np.arange(in_len, dtype=np.float32)
+    cfo = rng.normal(0.0, cfo_hz_std, size=B) * (2 * np.pi / (SYM_RATE * sps)) if cfo_hz_std else np.zeros(B)
+    ph0 = rng.uniform(0, 2 * np.pi, size=B)
+    ph = ph0.astype(np.float32)[:, None] + cfo.astype(np.float32)[:, None] * n[None, :]
+    rot = np.empty((B, in_len), np.complex64)
+    rot.real = np.cos(ph)
+    rot.imag = np.sin(ph)
+    out[:, :in_len] *= rot
+    del rot, ph
+
+    if esn0_db is not None:
+        esn0 = np.broadcast_to(np.asarray(esn0_db, dtype=np.float64), (B,))
+        sigma = np.sqrt(10.0 ** (-esn0 / 10.0) / 2.0).astype(np.float32)
+        noise = rng.standard_normal((B, in_len * 2), dtype=np.float32)
+        noise *= sigma[:, None]
+        out[:, :in_len] += noise.view(np.complex64)
+        del noise
+
+    if gain_db_std:
+        g = 10.0 ** (rng.normal(0.0, gain_db_std, size=B) / 20.0)
+        out *= g[:, None].astype(np.float32)
+
+    return BurstBatch(iq=out, stride=stride, in_len=in_len, toa=toa, cfo=cfo)
+
+
+# --------------------------------------------------------------------------
+# FCCH streams (config 2)
+# --------------------------------------------------------------------------
+def fcch_dual_chirp(freq: float, length: int, sps: int, frac: float = 0.0) -> np.ndarray:
+    """sqrt(2) cos(phi(t)), phi = freq*2pi/len * (t - len/2)^2, t in symbols (fcch.c:167-193)."""
+    t = (np.arange(length * sps) - frac) / sps - length / 2.0
+    return (np.sqrt(2.0) * np.cos(freq * 2 * np.pi / length * t * t)).astype(np.float32)
+
+
+def synth_fcch_stream(n_samples: int, sps: int, rng: np.random.Generator, *, snr_db: float = 6.0,
+                      cfo_hz: float = 0.0, first: int | None = None, period_sym: int = 7488,
+                      freq: float = 0.32, length: int = 117):
+    """AWGN (variance 1 per complex sample) + FCCH dual chirp every period_sym symbols.
+
+    Returns (stream complex64, list of true start samples)."""
+    noise = rng.standard_normal((n_samples, 2), dtype=np.float32)
+    x = ((noise[:, 0] + 1j * noise[:, 1]) / np.sqrt(2.0)).astype(np.complex64)
+    amp = np.sqrt(10.0 ** (snr_db / 10.0) / 1.0)   # dual chirp has mean-square 1
+    chirp = fcch_dual_chirp(freq, length, sps) * np.float32(amp)
+    if first is None:
+        first = int(rng.integers(0, period_sym * sps))
+    starts = []
+    pos = first
+    while pos + chirp.size <= n_samples:
+        x[pos:pos + chirp.size] += chirp
+        starts.append(pos)
+        pos += period_sym * sps
+    if cfo_hz:
+        n = np.arange(n_samples)
+        x *= np.exp(1j * 2 * np.pi * cfo_hz / (SYM_RATE * sps) * n).astype(np.complex64)
+    return x, starts

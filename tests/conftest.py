@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    from __graft_entry__ import load_package
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def gpu_api(pkg):
+    """The product API, initialised on device 0 (GPU tests only)."""
+    pkg.api.load()
+    pkg.api.init(0)
+    return pkg.api

@@ -1,0 +1,296 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liborc.so")
+
+MAX_SYNC, MAX_CHUNKS, MAX_SYNC_SYMS = 4, 8, 32
+BURST_IDS = ["bcch", "dc2", "dc6", "dc12", "nt3_speech", "nt3_facch", "nt6", "nt9", "rach", "sdcch"]
+
+
+class Chunk(C.Structure):
+    _fields_ = [("pos", C.c_int), ("len", C.c_int), ("syms", C.c_uint8 * MAX_SYNC_SYMS)]
+
+
+class Burst(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p), ("rotation", C.c_float), ("nbits", C.c_int),
+        ("guard_pre", C.c_int), ("guard_post", C.c_int), ("len", C.c_int), ("ebits", C.c_int),
+        ("n_sync", C.c_int), ("n_sync_chunks", C.c_int * MAX_SYNC),
+        ("sync", (Chunk * MAX_CHUNKS) * MAX_SYNC),
+        ("n_data", C.c_int), ("data", Chunk * MAX_CHUNKS),
+    ]
+
+
+class FcchBurst(C.Structure):
+    _fields_ = [("freq", C.c_float), ("len", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liborc.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.orc_burst_get.restype = C.POINTER(Burst)
+        _lib.orc_burst_get.argtypes = [C.c_int]
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def burst(name_or_id):
+    i = BURST_IDS.index(name_or_id) if isinstance(name_or_id, str) else int(name_or_id)
+    return lib().orc_burst_get(i)
+
+
+def burst_format(name_or_id):
+    """oracle burst table -> synth.BurstFormat (for cross checks)."""
+    from __graft_entry__ import load_package
+    synth = load_package().synth
+    b = burst(name_or_id).contents
+    sync = []
+    for s in range(b.n_sync):
+        chunks = []
+        for c in range(b.n_sync_chunks[s]):
+            ch = b.sync[s][c]
+            chunks.append((ch.pos, [int(ch.syms[k]) for k in range(ch.len)]))
+        sync.append(chunks)
+    data = [(b.data[c].pos, b.data[c].len) for c in range(b.n_data)]
+    return synth.BurstFormat(b.name.decode(), float(b.rotation), b.nbits, b.len, b.ebits, sync, data)
+
+
+# ---- l1 ---------------------------------------------------------------------
+def _enc(fn, l2, nbits, *extra):
+    l2 = np.ascontiguousarray(l2, np.uint8)
+    out = np.zeros((l2.shape[0], nbits), np.uint8)
+    f = getattr(lib(), fn)
+    for i in range(l2.shape[0]):
+        f(_p(out[i], C.c_uint8), _p(l2[i], C.c_uint8), *extra)
+    return out
+
+
+def bcch_encode(l2):
+    return _enc("orc_bcch_encode", l2, 424)
+
+
+def ccch_encode(l2):
+    return _enc("orc_ccch_encode", l2, 432)
+
+
+def _dec24(fn, ebits):
+    ebits = np.ascontiguousarray(ebits, np.int8)
+    n = ebits.shape[0]
+    l2 = np.zeros((n, 24), np.uint8)
+    crc = np.zeros(n, np.int32)
+    conv = np.zeros(n, np.int32)
+    f = getattr(lib(), fn)
+    f.restype = C.c_int
+    cv = C.c_int()
+    for i in range(n):
+        crc[i] = f(_p(l2[i], C.c_uint8), _p(ebits[i], C.c_int8), C.byref(cv))
+        conv[i] = cv.value
+    return l2, crc, conv
+
+
+def bcch_decode(ebits):
+    return _dec24("orc_bcch_decode", ebits)
+
+
+def ccch_decode(ebits):
+    return _dec24("orc_ccch_decode", ebits)
+
+
+def facch3_encode(l2, bits_s):
+    l2 = np.ascontiguousarray(l2, np.uint8)
+    bits_s = np.ascontiguousarray(bits_s, np.uint8)
+    out = np.zeros((l2.shape[0], 4, 104), np.uint8)
+    for i in range(l2.shape[0]):
+        lib().orc_facch3_encode(_p(out[i], C.c_uint8), _p(l2[i], C.c_uint8), _p(bits_s[i], C.c_uint8), None)
+    return out
+
+
+def facch3_decode(ebits):
+    ebits = np.ascontiguousarray(ebits, np.int8).reshape(-1, 416)
+    n = ebits.shape[0]
+    l2 = np.zeros((n, 10), np.uint8)
+    s = np.zeros((n, 32), np.uint8)
+    crc = np.zeros(n, np.int32)
+    conv = np.zeros(n, np.int32)
+    f = lib().orc_facch3_decode
+    f.restype = C.c_int
+    cv = C.c_int()
+    for i in range(n):
+        crc[i] = f(_p(l2[i], C.c_uint8), _p(s[i], C.c_uint8), _p(ebits[i], C.c_int8), None, C.byref(cv))
+        conv[i] = cv.value
+    return l2, s, crc, conv
+
+
+def tch3_encode(f0, f1, bits_s, m=0):
+    f0 = np.ascontiguousarray(f0, np.uint8)
+    f1 = np.ascontiguousarray(f1, np.uint8)
+    bits_s = np.ascontiguousarray(bits_s, np.uint8)
+    out = np.zeros((f0.shape[0], 212), np.uint8)
+    for i in range(f0.shape[0]):
+        lib().orc_tch3_encode(_p(out[i], C.c_uint8), _p(f0[i], C.c_uint8), _p(f1[i], C.c_uint8),
+                              _p(bits_s[i], C.c_uint8), None, C.c_int(m))
+    return out
+
+
+def tch3_decode(ebits, m=0):
+    ebits = np.ascontiguousarray(ebits, np.int8)
+    n = ebits.shape[0]
+    f0 = np.zeros((n, 10), np.uint8)
+    f1 = np.zeros((n, 10), np.uint8)
+    s = np.zeros((n, 4), np.uint8)
+    c0 = np.zeros(n, np.int32)
+    c1 = np.zeros(n, np.int32)
+    a, b = C.c_int(), C.c_int()
+    for i in range(n):
+        lib().orc_tch3_decode(_p(f0[i], C.c_uint8), _p(f1[i], C.c_uint8), _p(s[i], C.c_uint8),
+                              _p(ebits[i], C.c_int8), None, C.c_int(m), C.byref(a), C.byref(b))
+        c0[i], c1[i] = a.value, b.value
+    return f0, f1, s, c0, c1
+
+
+def scramble_sbit(x):
+    x = np.ascontiguousarray(x, np.int8)
+    out = np.zeros_like(x)
+    lib().orc_scramble_sbit(_p(out, C.c_int8), _p(x, C.c_int8), C.c_int(x.size))
+    return out
+
+
+def deinterleave_intra(x, N):
+    x = np.ascontiguousarray(x, np.uint8)
+    out = np.zeros_like(x)
+    lib().orc_deinterleave_intra(_p(out, C.c_uint8), _p(x, C.c_uint8), C.c_int(N))
+    return out
+
+
+# ---- sdr ----------------------------------------------------------------------
+def demod(bt, iq, sps, freq_shift=0.0):
+    """single-burst demod -> dict(rv, ebits, sync_id, toa, freq_err, ssyms)."""
+    b = burst(bt)
+    iq = np.ascontiguousarray(iq, np.complex64)
+    eb = np.zeros(b.contents.ebits, np.int8)
+    ss = np.zeros(b.contents.len, np.float32)
+    sid, toa, fe = C.c_int(-1), C.c_float(), C.c_float()
+    f = lib().orc_pi4cxpsk_demod
+    f.restype = C.c_int
+    rv = f(b, _p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_float(freq_shift),
+           _p(eb, C.c_int8), C.byref(sid), C.byref(toa), C.byref(fe), _p(ss, C.c_float))
+    return dict(rv=rv, ebits=eb, sync_id=sid.value, toa=toa.value, freq_err=fe.value, ssyms=ss)
+
+
+def detect(bts, e_toa, iq, sps, freq_shift=0.0):
+    arr = (C.POINTER(Burst) * len(bts))(*[burst(b) for b in bts])
+    iq = np.ascontiguousarray(iq, np.complex64)
+    bid, sid, toa = C.c_int(-1), C.c_int(-1), C.c_float()
+    f = lib().orc_pi4cxpsk_detect
+    f.restype = C.c_int
+    rv = f(arr, C.c_int(len(bts)), C.c_float(e_toa), _p(iq, C.c_float), C.c_int(iq.size),
+           C.c_int(sps), C.c_float(freq_shift), C.byref(bid), C.byref(sid), C.byref(toa))
+    return dict(rv=rv, bt_id=bid.value, sync_id=sid.value, toa=toa.value)
+
+
+def mod_order(iq, sps, freq_shift=0.0):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    f = lib().orc_pi4cxpsk_mod_order
+    f.restype = C.c_int
+    return f(_p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_float(freq_shift))
+
+
+def mod(bt, ebits, sync_id=0):
+    b = burst(bt)
+    ebits = np.ascontiguousarray(ebits, np.uint8)
+    out = np.zeros(b.contents.len, np.complex64)
+    lib().orc_pi4cxpsk_mod(b, _p(ebits, C.c_uint8), C.c_int(sync_id), _p(out, C.c_float))
+    return out
+
+
+def _fcch(which="fcch"):
+    return FcchBurst.in_dll(lib(), {"fcch": "orc_fcch_burst", "fcch3_lband": "orc_fcch3_lband_burst",
+                                    "fcch3_sband": "orc_fcch3_sband_burst"}[which])
+
+
+def fcch_rough(iq, sps, freq_shift=0.0, which="fcch"):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    toa = C.c_int()
+    f = lib().orc_fcch_rough
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch(which)), _p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_float(freq_shift), C.byref(toa))
+    return rv, toa.value
+
+
+def fcch_rough_multi(iq, sps, freq_shift=0.0, N=16, which="fcch"):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    toas = np.zeros(N, np.int32)
+    f = lib().orc_fcch_rough_multi
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch(which)), _p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_float(freq_shift),
+           _p(toas, C.c_int), C.c_int(N))
+    return rv, toas[:max(rv, 0)].copy()
+
+
+def fcch_fine(iq, sps, freq_shift=0.0, which="fcch"):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    toa, fe = C.c_int(), C.c_float()
+    f = lib().orc_fcch_fine
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch(which)), _p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_float(freq_shift),
+           C.byref(toa), C.byref(fe))
+    return rv, toa.value, fe.value
+
+
+def fcch_snr(iq, sps, freq_shift=0.0, which="fcch"):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    snr = C.c_float()
+    f = lib().orc_fcch_snr
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch(which)), _p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_float(freq_shift), C.byref(snr))
+    return rv, snr.value
+
+
+def demod_decode_batch(iq, offset, kind, sps=4, freq_shift=None, want_ebits=True, want_ssyms=True):
+    """BCCH/CCCH fused chain over a batch; iq is a flat complex64 array."""
+    iq = np.ascontiguousarray(iq, np.complex64).reshape(-1)
+    offset = np.ascontiguousarray(offset, np.uint64)
+    kind = np.ascontiguousarray(kind, np.uint8)
+    n = kind.size
+    out = dict(l2=np.zeros((n, 24), np.uint8), crc=np.zeros(n, np.int32), conv=np.zeros(n, np.int32),
+               toa=np.zeros(n, np.float32), freq_err=np.zeros(n, np.float32), rv=np.zeros(n, np.int32))
+    eb = np.zeros((n, 432), np.int8) if want_ebits else None
+    ss = np.zeros((n, 234), np.float32) if want_ssyms else None
+    fs = np.ascontiguousarray(freq_shift, np.float32) if freq_shift is not None else None
+    lib().orc_demod_decode_batch(
+        C.c_int(n), _p(iq, C.c_float), _p(offset, C.c_uint64), _p(kind, C.c_uint8), C.c_int(sps),
+        _p(fs, C.c_float) if fs is not None else None,
+        _p(out["l2"], C.c_uint8), _p(out["crc"], C.c_int32), _p(out["conv"], C.c_int32),
+        _p(out["toa"], C.c_float), _p(out["freq_err"], C.c_float),
+        _p(eb, C.c_int8) if eb is not None else None,
+        _p(ss, C.c_float) if ss is not None else None, _p(out["rv"], C.c_int32))
+    out["ebits"], out["ssyms"] = eb, ss
+    return out
