@@ -1,0 +1,119 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol the
+headers declare, carries the same burst tables as the oracle, and refuses to compute
+without a GPU (no CPU fallback)."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    funcs, data = set(), set()
+    for h in glob.glob(os.path.join(ROOT, "include", "**", "*.h"), recursive=True):
+        txt = open(h).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"//[^\n]*", "", txt)
+        funcs |= set(re.findall(r"\b(gmr1_[a-z0-9_]+)\s*\(", txt))
+        data |= set(re.findall(r"extern\s+(?:const\s+)?struct\s+\w+\s+(gmr1_\w+)\s*;", txt))
+    return funcs, data
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.api.load()
+    funcs, data = _declared_symbols()
+    assert funcs and data
+    for name in sorted(funcs | data):
+        assert hasattr(lib, name), f"{name} is declared in include/ but not exported"
+    # and the python mirror lists the same set
+    assert set(pkg.api.EXPORTED_FUNCTIONS) == funcs
+    assert set(pkg.api.EXPORTED_DATA) == data
+
+
+def test_version_and_error_strings(pkg):
+    lib = pkg.api.load()
+    assert b"gfx950" in lib.gmr1_hip_version()
+    assert isinstance(lib.gmr1_hip_last_error(), bytes)
+
+
+def test_burst_tables_equal_oracle_tables(pkg, orc):
+    """Two independent transcriptions of ETSI TS 101 376-5-2 7.4 (reference src/sdr/nb.c)."""
+    for name in pkg.api.BURST_IDS:
+        assert pkg.api.burst_format(name) == orc.burst_format(name), name
+    with pytest.raises(pkg.api.Gmr1HipError):
+        pkg.api.burst_info(99)
+
+
+def test_burst_table_invariants(pkg):
+    for name in pkg.api.BURST_IDS:
+        f = pkg.api.burst_format(name)
+        used = np.zeros(f.length, int)
+        for p, l in f.data:
+            used[p:p + l] += 1
+        assert sum(l for _, l in f.data) * f.nbits == f.ebits
+        for seq in f.sync:
+            u = used.copy()
+            for p, syms in seq:
+                u[p:p + len(syms)] += 1
+                assert max(syms) < (1 << f.nbits) * (2 if f.nbits == 1 else 1)
+            assert u.max() == 1, name                     # sync and data never overlap
+            assert u[:2].sum() == 0 and u[-3:].sum() == 0  # guard symbols stay empty
+
+
+def test_exported_struct_layout_matches_reference_abi(pkg):
+    """gmr1_bcch_burst etc. are pointer-linked structs laid out like the reference's
+    (include/osmocom/gmr1/sdr/pi4cxpsk.h:43-98); walk one through raw memory."""
+    lib = pkg.api.load()
+
+    class Mod(C.Structure):
+        _fields_ = [("rotation", C.c_float), ("nbits", C.c_int), ("syms", C.c_void_p), ("bits", C.c_void_p)]
+
+    class Sync(C.Structure):
+        _fields_ = [("pos", C.c_int), ("len", C.c_int), ("syms", C.c_uint8 * 32), ("_ref", C.c_void_p)]
+
+    class Data(C.Structure):
+        _fields_ = [("pos", C.c_int), ("len", C.c_int)]
+
+    class Burst(C.Structure):
+        _fields_ = [("mod", C.POINTER(Mod)), ("guard_pre", C.c_int), ("guard_post", C.c_int),
+                    ("len", C.c_int), ("ebits", C.c_int), ("sync", C.POINTER(Sync) * 4),
+                    ("data", C.POINTER(Data))]
+
+    b = Burst.in_dll(lib, "gmr1_dc6_burst")
+    assert (b.guard_pre, b.guard_post, b.len, b.ebits) == (2, 3, 234, 432)
+    assert abs(b.mod.contents.rotation - np.pi / 4) < 1e-6 and b.mod.contents.nbits == 2
+    assert (b.sync[0][0].pos, b.sync[0][0].len, list(b.sync[0][0].syms[:7])) == (28, 7, [0, 0, 0, 2, 2, 0, 2])
+    assert b.sync[0][3].pos == -1 and not b.sync[1]
+    assert (b.data[1].pos, b.data[1].len) == (35, 84) and b.data[4].pos == -1
+    sd = Burst.in_dll(lib, "gmr1_sdcch_burst")
+    assert all(bool(sd.sync[i]) for i in range(4))       # 4 sequences, no NULL terminator
+
+
+def test_no_cpu_fallback(pkg):
+    """Without a usable GPU every compute entry point fails loudly (-ENODEV)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    eb = np.zeros((4, 424), np.int8)
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.bcch_decode_batch(eb)
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.rx_bcch_ccch_batch(np.zeros(2048, np.complex64), [0], [0])
+    l2, rv, _ = pkg.api.bcch_decode(eb[0])
+    assert rv == -19
+
+
+def test_product_does_not_reference_oracle():
+    """Nothing under the package or include/ may import, include or link the oracle."""
+    bad = []
+    for d in ("osmo-gmr_amd", "include"):
+        for path in glob.glob(os.path.join(ROOT, d, "**", "*"), recursive=True):
+            if os.path.isfile(path) and path.endswith((".py", ".h", ".hip", ".cpp", ".c")):
+                txt = open(path, errors="replace").read()
+                if re.search(r"oracle_lib|liborc|orc_[a-z0-9_]+\(|#include\s+\"orc_", txt):
+                    bad.append(path)
+    assert not bad, bad

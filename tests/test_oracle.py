@@ -1,0 +1,228 @@
+"""CPU tests of the oracle (oracle/) against every known answer available.
+
+The reference ships no tests, vectors or fixtures and cannot be
+built here (libosmocore / libosmo-dsp / FFTW absent), so the oracle's parity with
+the reference is UNPINNED.  What can be pinned is checked here:
+  * known answers derivable from the reference's own in-tree code,
+    committed under tests/golden/ with the script that derived them;
+  * the structural identities the reference's design implies (round trips);
+  * an independent second implementation of every encoder (osmo-gmr_amd/synth.py).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _golden():
+    with open(os.path.join(GOLDEN, "known_answers.json")) as f:
+        return json.load(f)
+
+
+# ---------------------------------------------------------------------------
+# known answers from in-tree reference code
+# ---------------------------------------------------------------------------
+def test_scrambler_known_answers(orc):
+    g = _golden()["scrambler"]
+    ones = np.full(432, 1, np.int8)
+    out = orc.scramble_sbit(ones)
+    bits = (out < 0).astype(int)
+    assert "".join(map(str, bits[:64])) == g["first64"]
+    for n, cnt in g["ones_in_first"].items():
+        assert int(bits[:int(n)].sum()) == cnt
+    # involution
+    x = np.random.default_rng(0).integers(-127, 128, 432).astype(np.int8)
+    assert np.array_equal(orc.scramble_sbit(orc.scramble_sbit(x)), x)
+
+
+def test_deinterleave_known_answers(orc):
+    g = _golden()["deinterleave_intra_53_first16"]
+    x = (np.arange(424) % 251).astype(np.uint8)
+    idx = np.arange(424)
+    out = orc.deinterleave_intra(x, 53)
+    # out[kc] = in[idx[kc]] with the documented index pattern
+    pos = {int(v): i for i, v in enumerate(x[:251])}
+    kep = 53 * ((5 * idx) & 7) + (idx >> 3)
+    assert list(kep[:16]) == g
+    assert np.array_equal(out, x[kep])
+
+
+def test_conv_tables_match_reference_spot_values(orc):
+    """orc_conv_make(polys) reproduces rows of the reference's trellis tables (conv.c)."""
+    import ctypes as C
+
+    class Code(C.Structure):
+        _fields_ = [("N", C.c_int), ("K", C.c_int), ("len", C.c_int), ("term", C.c_int),
+                    ("next_output", (C.c_uint8 * 2) * 256), ("next_state", (C.c_uint8 * 2) * 256),
+                    ("n_punct", C.c_int), ("punct", C.c_int * 1024)]
+
+    g = _golden()["conv_spot"]
+    for name, spec in g.items():
+        c = Code()
+        polys = (C.c_uint * len(spec["polys"]))(*spec["polys"])
+        orc.lib().orc_conv_make(C.byref(c), len(spec["polys"]), spec["K"], 10, 0, polys)
+        for s, row in spec["next_output_rows"].items():
+            assert [c.next_output[int(s)][0], c.next_output[int(s)][1]] == row, (name, s)
+        for s in range(1 << (spec["K"] - 1)):
+            assert [c.next_state[s][0], c.next_state[s][1]] == [(2 * s) % (1 << (spec["K"] - 1)),
+                                                                (2 * s + 1) % (1 << (spec["K"] - 1))]
+
+
+def test_fcch_constants():
+    g = _golden()["fcch"]
+    assert 23400 / 117 == g["bin_hz"]
+    assert abs(2 * 0.32 * 23400 ** 2 / (117 * 1000) - g["chirp_rate_hz_per_ms"]) < 1e-9
+    assert 320 * 23400 // 1000 == g["bcch_period_symbols"]
+
+
+# ---------------------------------------------------------------------------
+# encoders: oracle vs the independent numpy implementation
+# ---------------------------------------------------------------------------
+def test_encoders_agree_with_synth(orc, pkg):
+    rng = np.random.default_rng(5)
+    l2 = rng.integers(0, 256, (40, 24), dtype=np.uint8)
+    assert np.array_equal(orc.bcch_encode(l2), pkg.synth.bcch_encode(l2))
+    assert np.array_equal(orc.ccch_encode(l2), pkg.synth.ccch_encode(l2))
+    l2f = rng.integers(0, 256, (40, 10), dtype=np.uint8)
+    l2f[:, 9] &= 0x0F
+    s = rng.integers(0, 2, (40, 32), dtype=np.uint8)
+    assert np.array_equal(orc.facch3_encode(l2f, s), pkg.synth.facch3_encode(l2f, s))
+    f0 = rng.integers(0, 256, (40, 10), dtype=np.uint8)
+    f1 = rng.integers(0, 256, (40, 10), dtype=np.uint8)
+    s4 = rng.integers(0, 2, (40, 4), dtype=np.uint8)
+    for m in (0, 1):
+        assert np.array_equal(orc.tch3_encode(f0, f1, s4, m), pkg.synth.tch3_encode(f0, f1, s4, m))
+
+
+# ---------------------------------------------------------------------------
+# encode -> decode round trips (the reference's own structural identity)
+# ---------------------------------------------------------------------------
+def _soft(bits, amp=127):
+    return (amp * (1 - 2 * bits.astype(np.int16))).astype(np.int8)
+
+
+def test_bcch_ccch_roundtrip(orc):
+    rng = np.random.default_rng(6)
+    l2 = rng.integers(0, 256, (50, 24), dtype=np.uint8)
+    for enc, dec in ((orc.bcch_encode, orc.bcch_decode), (orc.ccch_encode, orc.ccch_decode)):
+        e = enc(l2)
+        out, crc, conv = dec(_soft(e))
+        assert not crc.any() and np.array_equal(out, l2) and not conv.any()
+        # a handful of bit errors are corrected, conv_rv counts their cost
+        sb = _soft(e, 100)
+        sb[:, 10] = -sb[:, 10]
+        sb[:, 200] = -sb[:, 200]
+        out, crc, conv = dec(sb)
+        assert not crc.any() and np.array_equal(out, l2) and (conv > 0).all()
+        # erasures cost nothing
+        sb = _soft(e)
+        sb[:, ::7] = 0
+        out, crc, conv = dec(sb)
+        assert not crc.any() and np.array_equal(out, l2) and not conv.any()
+        # garbage fails the CRC
+        junk = rng.integers(-128, 128, sb.shape).astype(np.int8)
+        assert dec(junk)[1].mean() > 0.9
+
+
+def test_facch3_roundtrip(orc):
+    rng = np.random.default_rng(7)
+    l2 = rng.integers(0, 256, (30, 10), dtype=np.uint8)
+    l2[:, 9] &= 0x0F
+    s = rng.integers(0, 2, (30, 32), dtype=np.uint8)
+    e = orc.facch3_encode(l2, s)
+    out, sb, crc, conv = orc.facch3_decode(_soft(e))
+    assert not crc.any() and np.array_equal(out, l2) and np.array_equal(sb, s) and not conv.any()
+
+
+def test_tch3_roundtrip(orc):
+    rng = np.random.default_rng(8)
+    f0 = rng.integers(0, 256, (30, 10), dtype=np.uint8)
+    f1 = rng.integers(0, 256, (30, 10), dtype=np.uint8)
+    s = rng.integers(0, 2, (30, 4), dtype=np.uint8)
+    for m in (0, 1):
+        e = orc.tch3_encode(f0, f1, s, m)
+        o0, o1, so, c0, c1 = orc.tch3_decode(_soft(e), m)
+        assert np.array_equal(o0, f0) and np.array_equal(o1, f1) and np.array_equal(so, s)
+        assert not c0.any() and not c1.any()
+        sb = _soft(e, 90)
+        sb[:, 5] = -sb[:, 5]           # one coded-bit error per frame is corrected
+        o0, o1, so, c0, c1 = orc.tch3_decode(sb, m)
+        assert np.array_equal(o0[:, :6], f0[:, :6]) and np.array_equal(o1[:, :6], f1[:, :6])
+
+
+# ---------------------------------------------------------------------------
+# modem
+# ---------------------------------------------------------------------------
+def test_mod_demod_roundtrip_1sps_upsampled(orc, pkg):
+    """gmr1_pi4cxpsk_mod output (1 sps, gmr1_rach_gen.c:57-61 recipe) repeated to sps=4
+    demodulates back to the same bits for every burst format."""
+    rng = np.random.default_rng(9)
+    for name in orc.BURST_IDS:
+        fmt = orc.burst_format(name)
+        for sid in range(len(fmt.sync)):
+            bits = rng.integers(0, 2, fmt.ebits, dtype=np.uint8)
+            sym = orc.mod(name, bits, sid)
+            assert np.allclose(sym, pkg.synth.map_symbols(fmt, bits[None], sync_id=sid)[0], atol=3e-4), name
+            x = np.zeros(fmt.length * 4 + 16, np.complex64)
+            x[8:8 + fmt.length * 4] = np.repeat(sym, 4)
+            x *= np.exp(1j * 0.7)
+            d = orc.demod(name, x, 4)
+            # reference quirk (pi4cxpsk.c:207-237): the accumulator is not cleared between sync
+            # sequences, so the last sequence always ranks first -- preserved for parity
+            assert d["rv"] == 0 and d["sync_id"] == len(fmt.sync) - 1, name
+            if sid == len(fmt.sync) - 1:
+                assert np.array_equal((d["ebits"] < 0).astype(np.uint8), bits), name
+                assert 6.5 <= d["toa"] <= 12.5
+
+
+def test_demod_synthetic_config1(orc, pkg):
+    """BASELINE config 1: one BCCH burst, TOA 40, no noise / 10 dB."""
+    import workloads
+    for esn0 in (200.0, 10.0):
+        wl = workloads.bcch_ccch_mix(pkg, n=7, seed=1, esn0_db=(esn0,), toa_jitter=0, frac=False,
+                                     cfo_hz_std=0.0, gain_db_std=0.0)
+        ref = orc.demod_decode_batch(wl["iq"], wl["offset"], wl["kind"], sps=4)
+        assert not ref["crc"].any()
+        assert np.array_equal(ref["l2"], wl["l2"])
+        assert np.abs(ref["toa"] - wl["toa"]).max() < 0.6
+        if esn0 > 100:
+            assert (np.abs(ref["ebits"][0][:424]) >= 120).mean() > 0.95
+
+
+def test_detect_and_mod_order(orc, pkg):
+    rng = np.random.default_rng(10)
+    f_sp, f_fa = pkg.api.burst_format("nt3_speech"), pkg.api.burst_format("nt3_facch")
+    for which, fmt in ((1, f_sp), (0, f_fa)):
+        bits = rng.integers(0, 2, (1, fmt.ebits), dtype=np.uint8)
+        sym = pkg.synth.map_symbols(fmt, bits)
+        bb = pkg.synth.synth_windows(fmt, sym, 4, 6, rng, esn0_db=15.0)
+        d = orc.detect(["nt3_facch", "nt3_speech"], 3.0, bb.iq[0, :bb.in_len], 4)
+        assert d["rv"] == 0 and d["bt_id"] == which
+        assert orc.mod_order(bb.iq[0, :bb.in_len], 4) == (4 if fmt.nbits == 2 else 2)
+
+
+def test_fcch_rough_fine_snr(orc, pkg):
+    rng = np.random.default_rng(2)
+    sps = 4
+    x, starts = pkg.synth.synth_fcch_stream(93600, sps, rng, snr_db=6.0, cfo_hz=0.0, first=5000)
+    rv, toa = orc.fcch_rough(x[:30888], sps)
+    assert rv == 0 and abs(toa - 5000) <= 2 * sps
+    burst = x[toa:toa + 117 * sps]
+    rv, ftoa, ferr = orc.fcch_fine(burst, sps)
+    assert rv == 0 and abs(toa + ftoa - 5000) <= sps and abs(ferr) < 0.02
+    rv, snr = orc.fcch_snr(x[toa + ftoa:toa + ftoa + 117 * sps], sps)
+    assert rv == 0 and snr > 3.0
+    # CFO shows up as freq_error (rad/sym), sign and size
+    cfo = 600.0
+    x2, _ = pkg.synth.synth_fcch_stream(93600, sps, rng, snr_db=10.0, cfo_hz=cfo, first=5000)
+    rv, ftoa, ferr = orc.fcch_fine(x2[5000:5000 + 468], sps)
+    assert abs(ferr - 2 * np.pi * cfo / 23400) < 0.02
+    # wrong length is rejected like the reference (-EINVAL)
+    assert orc.fcch_fine(x[:400], sps)[0] == -22
+    # multi: two cycles, 650 ms minimum
+    rv, toas = orc.fcch_rough_multi(x[:60840], sps)
+    assert rv >= 1 and min(abs(int(t) - 5000) for t in toas) <= 2 * sps
+    assert orc.fcch_rough_multi(x[:30000], sps)[0] == -22
