@@ -155,11 +155,11 @@ def test_demod_generic_burst_types(gpu_api, orc, pkg):
                 assert d.max() < 1e-4, (name, d.max())
                 assert np.abs(got["ebits"][i].astype(int) - o["ebits"].astype(int)).max() <= 1
         # Reference quirk (pi4cxpsk.c:207-237): the correlation accumulator is not
-        # cleared between sync sequences, so the LAST sequence always wins the power ranking.
-        # Reproduced for parity: sync_id is n_sync-1, and bits are only right when that was sent.
-        assert np.all(got["sync_id"] == len(fmt.sync) - 1), name
-        sent_last = sid == len(fmt.sync) - 1
-        assert (hard[sent_last] != ebits[sent_last]).mean() < 0.02, name
+        # cleared between sync sequences, so later sequences are ranked (and timed) on the sum of all
+        # earlier correlations.  It is reproduced for parity (checked against the oracle above); the
+        # sent bits are therefore only guaranteed to come back for single-sequence formats.
+        if len(fmt.sync) == 1:
+            assert (hard != ebits).mean() < 0.02, name
 
 
 def test_legacy_pi4cxpsk_demod_call(gpu_api, orc, pkg):
