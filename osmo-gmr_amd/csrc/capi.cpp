@@ -5,6 +5,7 @@
 #include <cerrno>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -42,8 +43,7 @@ int fail(int code, const char *fmt, ...)
 constexpr int kMaxDevices = 16;
 
 struct DevState {
-	bool ready = false;
-	DevBurst *types = nullptr;      // kNumTypes descriptors in HBM
+	bool ready = false;             // burst descriptors uploaded to this device's __constant__ memory
 };
 
 std::mutex g_mu;
@@ -86,8 +86,8 @@ int dev_state(DevState **out)
 		int rv = host_types();
 		if (rv)
 			return rv;
-		HIP_TRY(hipMalloc(&s.types, sizeof(g_host_types)));
-		HIP_TRY(hipMemcpy(s.types, g_host_types, sizeof(g_host_types), hipMemcpyHostToDevice));
+		HIP_TRY(upload_types(g_host_types, 0, kNumTypes, nullptr));
+		HIP_TRY(hipStreamSynchronize(nullptr));
 		s.ready = true;
 	}
 	*out = &s;
@@ -140,7 +140,17 @@ int gmr1_hip_burst_info(int burst_id, struct gmr1_hip_burst_flat *out)
 // ---------------------------------------------------------------------------
 // demod batch
 // ---------------------------------------------------------------------------
-static int demod_dev_impl(hipStream_t st, const DevBurst *types, int type, const DevBurst &ht,
+static int dbg_stop_env()
+{
+	static int v = -1;
+	if (v < 0) {
+		const char *e = getenv("GMR1_HIP_DBG_STOP");
+		v = e ? atoi(e) : 0;
+	}
+	return v;
+}
+
+static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
                           int n, int sps, int in_len, const float *iq, const uint64_t *offset,
                           const float *freq_shift, int8_t *ebits, int ebits_stride, int32_t *sync_id,
                           float *toa, float *freq_err, float *ssyms, int32_t *rv)
@@ -161,7 +171,7 @@ static int demod_dev_impl(hipStream_t st, const DevBurst *types, int type, const
 	a.fixed_type = type;
 	a.ebits_stride = ebits_stride;
 	a.ssyms_stride = ht.len;
-	a.types = types;
+	a.dbg_stop = dbg_stop_env();
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.freq_shift = freq_shift;
 	a.ebits = ebits; a.sync_id = sync_id; a.toa = toa; a.freq_err = freq_err; a.ssyms = ssyms; a.rv = rv;
@@ -179,7 +189,7 @@ int gmr1_hip_demod_batch_dev(void *stream, int burst_id, int n, int sps, int in_
 	DevState *s;
 	int r = dev_state(&s);
 	if (r) return r;
-	return demod_dev_impl((hipStream_t)stream, s->types, burst_id, g_host_types[burst_id], n, sps, in_len,
+	return demod_dev_impl((hipStream_t)stream, burst_id, g_host_types[burst_id], n, sps, in_len,
 	                      iq, offset, freq_shift, ebits, ebits_stride, sync_id, toa, freq_err, ssyms, rv);
 }
 
@@ -200,7 +210,7 @@ static int demod_host_impl(int type, const DevBurst &ht, const DevBurst *custom,
 			return fail(-EINVAL, "burst %d runs past the end of iq", i);
 	hipStream_t st = nullptr;
 	if (custom)
-		HIP_TRY(hipMemcpy(s->types + kCustomSlot, custom, sizeof(DevBurst), hipMemcpyHostToDevice));
+		HIP_TRY(upload_types(custom, kCustomSlot, 1, st));
 	DBuf d_iq, d_off, d_fs, d_eb, d_sid, d_toa, d_fe, d_ss, d_rv;
 	HIP_TRY(d_iq.alloc(iq_len * 8));
 	HIP_TRY(d_off.alloc((size_t)n * 8));
@@ -216,7 +226,7 @@ static int demod_host_impl(int type, const DevBurst &ht, const DevBurst *custom,
 	if (toa) HIP_TRY(d_toa.alloc((size_t)n * 4));
 	if (freq_err) HIP_TRY(d_fe.alloc((size_t)n * 4));
 	if (ssyms) HIP_TRY(d_ss.alloc((size_t)n * ht.len * 4));
-	r = demod_dev_impl(st, s->types, type, ht, n, sps, in_len, d_iq.as<float>(), d_off.as<uint64_t>(),
+	r = demod_dev_impl(st, type, ht, n, sps, in_len, d_iq.as<float>(), d_off.as<uint64_t>(),
 	                   freq_shift ? d_fs.as<float>() : nullptr, ebits ? d_eb.as<int8_t>() : nullptr,
 	                   ebits_stride, sync_id ? d_sid.as<int32_t>() : nullptr,
 	                   toa ? d_toa.as<float>() : nullptr, freq_err ? d_fe.as<float>() : nullptr,
@@ -389,7 +399,7 @@ int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
 	a.fixed_type = -1;
 	a.ebits_stride = 432;
 	a.ssyms_stride = 234;
-	a.types = s->types;
+	a.dbg_stop = dbg_stop_env();
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.kind = kind; a.freq_shift = freq_shift;
 	a.l2 = l2; a.crc = crc; a.conv = conv; a.toa = toa; a.freq_err = freq_err;

@@ -13,6 +13,7 @@ constexpr int kMaxChunks = GMR1_HIP_MAX_CHUNKS;
 constexpr int kMaxSyncSyms = GMR1_HIP_MAX_SYNC_SYMS;
 constexpr int kMaxWindow = GMR1_HIP_MAX_WINDOW;
 constexpr int kMaxInLen = GMR1_HIP_MAX_IN_LEN;
+constexpr int kMaxLen = 480;            // symbols per burst (DC12: 468)
 constexpr int kMaxCoef = 128;          // sync symbols of one sequence (RACH: 99)
 constexpr int kNumTypes = 16;          // descriptor table slots (10 built in + custom)
 constexpr int kCustomSlot = 15;
@@ -32,6 +33,7 @@ struct DevBurst {
 	DevChunk sync[kMaxSync][kMaxChunks];
 	int32_t n_data;
 	int16_t dpos[kMaxChunks], dlen[kMaxChunks], dcum[kMaxChunks];
+	int16_t ord_of_sym[kMaxLen];        // data-symbol ordinal of each symbol, -1 if not data
 };
 
 // L1 chain selector for the fused kernel / decode kernels
@@ -44,7 +46,7 @@ struct RxArgs {
 	int fixed_type;        // >= 0: every burst has this type, demod only
 	int ebits_stride;
 	int ssyms_stride;
-	const DevBurst *types; // descriptor table (device)
+	int dbg_stop;          // profiling aid: 0 = run everything, N = stop after phase N
 	const float2 *iq;
 	const uint64_t *offset;
 	const uint8_t *kind;
@@ -68,6 +70,8 @@ struct L1Args {
 };
 
 // launchers (rx_kernels.hip)
+// descriptors live in __constant__ memory of the current device
+hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream);
 hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t stream);
 hipError_t launch_l1(const L1Args &a, hipStream_t stream);
 size_t rx_lds_bytes(int max_in_len);

@@ -236,12 +236,19 @@ int to_dev(const gmr1_hip_burst_flat &f, DevBurst *d)
 			return -22;
 		d->sync_tl[i] = tl;
 	}
+	if (f.len > kMaxLen)
+		return -22;
+	for (int i = 0; i < kMaxLen; i++)
+		d->ord_of_sym[i] = -1;
 	d->n_data = f.n_data;
 	int cum = 0;
 	for (int c = 0; c < f.n_data; c++) {
 		d->dpos[c] = (int16_t)f.data[c].pos;
 		d->dlen[c] = (int16_t)f.data[c].len;
 		d->dcum[c] = (int16_t)cum;
+		if (f.data[c].pos >= 0 && f.data[c].pos + f.data[c].len <= f.len)
+			for (int i = 0; i < f.data[c].len; i++)
+				d->ord_of_sym[f.data[c].pos + i] = (int16_t)(cum + i);
 		cum += f.data[c].len;
 		if (f.data[c].pos + f.data[c].len > f.len)
 			return -22;

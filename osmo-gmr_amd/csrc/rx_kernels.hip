@@ -1,28 +1,32 @@
 // rx_kernels.hip -- normal-burst receive kernels for gfx950 (MI355X).
 //
-//   k_rx<DECODE=false> : pi/4-CxPSK burst demodulation, one burst per wavefront
-//                        (reference src/sdr/pi4cxpsk.c:520-602 gmr1_pi4cxpsk_demod)
-//   k_rx<DECODE=true>  : the same, four bursts per wavefront back to back, followed
-//                        by the BCCH/CCCH layer-1 chain for the four bursts at once:
-//                        descramble + de-interleave folded into the branch-metric
-//                        gather, 16-state K=5 rate-1/2 Viterbi with one burst per
-//                        16-lane DPP row, traceback, CRC16, LSB-first packing
-//                        (reference src/l1/bcch.c:83-103, src/l1/ccch.c:87-107 and
-//                        libosmocore's generic osmo_conv_decode).
-//   k_l1               : the layer-1 chain alone on soft bits read from HBM.
+//   k_rx<.., DECODE=false> : pi/4-CxPSK burst demodulation, one burst per wavefront
+//                            (reference src/sdr/pi4cxpsk.c:520-602 gmr1_pi4cxpsk_demod)
+//   k_rx<.., DECODE=true>  : the same, four bursts per wavefront back to back, followed
+//                            by the BCCH/CCCH layer-1 chain for the four bursts at once:
+//                            descramble + de-interleave folded into the branch-metric
+//                            gather, 16-state K=5 rate-1/2 Viterbi with one burst per
+//                            16-lane DPP row, traceback, CRC16, LSB-first packing
+//                            (reference src/l1/bcch.c:83-103, src/l1/ccch.c:87-107 and
+//                            libosmocore's generic osmo_conv_decode).
+//   k_l1                   : the layer-1 chain alone on soft bits read from HBM.
 //
 // Design notes (DESIGN.md has the long form):
 //   * Work-groups are single 64-lane wavefronts: every hand-off goes through the
 //     wave's own LDS slice and needs no s_barrier.
 //   * Samples are loaded once from HBM with coalesced 8-byte-per-lane loads, DC /
 //     power normalised in registers and parked in LDS; everything else reads LDS.
+//   * Burst formats live in __constant__ memory and are read with scalar loads.
 //   * The sync search never derotates the window: |sum conj(ref_n) x[.] e^{j th n}|
 //     is evaluated with per-burst rotated coefficients, which drops ~1000
 //     sincos per burst.  Only the 234 decimated symbols are derotated.
+//   * The sinc interpolation of the early/late timing loop needs one sine per
+//     point: sin(pi (k - f)) = -(-1)^k sin(pi f) for integer tap offsets k.
 //   * Viterbi state s lives in lane rotr^k(s) of its row at trellis step k, so the
 //     add-compare-select butterfly is in place: the partner metric is one DPP
-//     lane-xor away and no metric ever moves.  Decisions are collected in VGPRs: lane (k mod 64)
-//     keeps the 64-bit ballot of step k (4 bursts x 16 states).
+//     lane-xor away and no metric ever moves.  Lane (k mod 64) keeps the 64-bit
+//     decision ballot of step k (4 bursts x 16 states); the traceback walks
+//     LOCATIONS, not states, so it needs no rotation either.
 #include "gmr1_dev.h"
 
 namespace gmr1 {
@@ -36,25 +40,52 @@ namespace gmr1 {
 static constexpr float kPif = 3.14159265358979323846f;
 static constexpr uint32_t kMaxAe = 0x00ffffffu;   // libosmocore MAX_AE
 static constexpr int kSteps12 = 212;              // 208 data + 4 flush steps (BCCH/CCCH)
-static constexpr int kEbitsLds = 704;             // >= 662 (NT9), multiple of 16
+static constexpr int kEbRow = 448;                // LDS bytes per soft-bit row (>= 432, /16)
+static constexpr int kEbitsLds = 704;             // single-burst soft-bit buffer (>= 662)
 
 // ---------------------------------------------------------------------------
-// compile-time tables
+// constant memory
 // ---------------------------------------------------------------------------
-struct ScrTable { uint32_t w[24]; };
-static constexpr ScrTable make_scr()
+__constant__ DevBurst c_types[kNumTypes];
+
+hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream)
 {
-	// GMR-1 scrambler (reference src/l1/scramb.c:39-52): 15-bit LFSR, seed 0x4d4b
-	ScrTable t{};
-	uint16_t r = 0x4d4b;
-	for (int i = 0; i < 24 * 32; i++) {
-		uint32_t b = ((r >> 14) ^ r) & 1u;
-		r = (uint16_t)((r << 1) | b);
-		t.w[i >> 5] |= b << (i & 31);
+	return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_types), host, sizeof(DevBurst) * (size_t)count,
+	                              sizeof(DevBurst) * (size_t)first, hipMemcpyHostToDevice, stream);
+}
+
+// Per trellis step of the BCCH / CCCH chain: where the two soft bits of the step
+// sit in the burst's e-bit order and whether the scrambler flips them
+//   bits  0..9  index of c[2k]   bit 10 its scrambling bit
+//   bits 16..25 index of c[2k+1] bit 26 its scrambling bit
+// (interleave.c:73-87 with N=53, scramb.c:39-73; CCCH: 4 leading pad bits, ccch.c:95-96)
+struct StepTable { uint32_t w[2][kSteps12]; };
+static constexpr StepTable make_steps()
+{
+	StepTable t{};
+	for (int chain = 0; chain < 2; chain++) {
+		const int off = chain ? 4 : 0;
+		// scrambling sequence over the e-bit positions
+		bool scr[448] = {};
+		uint16_t r = 0x4d4b;
+		for (int i = 0; i < 448; i++) {
+			uint32_t b = ((r >> 14) ^ r) & 1u;
+			r = (uint16_t)((r << 1) | b);
+			scr[i] = b != 0;
+		}
+		for (int k = 0; k < kSteps12; k++) {
+			uint32_t w = 0;
+			for (int j = 0; j < 2; j++) {
+				const int kc = 2 * k + j;
+				const int ei = 53 * ((5 * kc) & 7) + (kc >> 3) + off;
+				w |= ((uint32_t)ei | (scr[ei] ? 0x400u : 0u)) << (16 * j);
+			}
+			t.w[chain][k] = w;
+		}
 	}
 	return t;
 }
-__constant__ ScrTable c_scr = make_scr();
+__constant__ StepTable c_steps = make_steps();
 
 struct SynTable { uint16_t s[208]; };
 static constexpr SynTable make_syn()
@@ -77,63 +108,17 @@ static constexpr SynTable make_syn()
 __constant__ SynTable c_syn = make_syn();
 
 // ---------------------------------------------------------------------------
-// small helpers
+// cross-lane helpers (DPP: no LDS traffic)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		v += __shfl_xor(v, o);
-	return v;
-}
-
-__device__ __forceinline__ float half_sum(float v)   // within each 32-lane half
-{
-#pragma unroll
-	for (int o = 16; o > 0; o >>= 1)
-		v += __shfl_xor(v, o);
-	return v;
-}
-
-__device__ __forceinline__ float cabs_d(float re, float im)
-{
-	// glibc hypotf evaluates in double; do the same so |.| agrees to the last bit
-	return (float)sqrt((double)re * (double)re + (double)im * (double)im);
-}
-
-__device__ __forceinline__ float2 cmul(float2 a, float2 b)
-{
-	return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-// conj(ref) * v for ref = modulating value of sync symbol `sym` (exact: ref is +-1 / +-j)
-__device__ __forceinline__ float2 conj_ref_mul(int nbits, int sym, float2 v)
-{
-	if (nbits == 2) {
-		switch (sym & 3) {
-		case 0: return v;
-		case 1: return make_float2(v.y, -v.x);
-		case 2: return make_float2(-v.x, -v.y);
-		default: return make_float2(-v.y, v.x);
-		}
-	}
-	return (sym & 1) ? make_float2(-v.x, -v.y) : v;
-}
-
-__device__ __forceinline__ uint32_t rotl4(uint32_t x, int r) { return ((x << r) | (x >> (4 - r))) & 15u; }
-__device__ __forceinline__ uint32_t rotr4(uint32_t x, int r) { return ((x >> r) | (x << (4 - r))) & 15u; }
-
-// K=5 rate-1/2 code (g0 = 1+D^3+D^4, g1 = 1+D+D^2+D^4; reference src/l1/conv.c:123-145)
-__device__ __forceinline__ uint32_t out_k5_12(uint32_t s, uint32_t b)
-{
-	uint32_t reg = (s << 1) | b;
-	return ((uint32_t)(__popc(reg & 0x19u) & 1) << 1) | (uint32_t)(__popc(reg & 0x17u) & 1);
-}
-
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t v)
 {
 	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v)
+{
+	return __builtin_bit_cast(float, dpp<CTRL>(__builtin_bit_cast(uint32_t, v)));
 }
 
 // value of lane (l ^ X) within a 16-lane row, X in {8,4,2,1}
@@ -145,18 +130,118 @@ __device__ __forceinline__ uint32_t row_xor(uint32_t v)
 	else if constexpr (X == 2) return dpp<0x4E>(v);                // quad_perm [2,3,0,1]
 	else return dpp<0xB1>(v);                                      // quad_perm [1,0,3,2]
 }
+template <int X>
+__device__ __forceinline__ float row_xorf(float v)
+{
+	return __builtin_bit_cast(float, row_xor<X>(__builtin_bit_cast(uint32_t, v)));
+}
+
+// every lane gets the sum over its 16-lane row
+__device__ __forceinline__ float row_sum(float v)
+{
+	v += row_xorf<1>(v);
+	v += row_xorf<2>(v);
+	v += row_xorf<4>(v);
+	v += row_xorf<8>(v);
+	return v;
+}
+
+__device__ __forceinline__ float lane_val(float v, int l)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+	v = row_sum(v);
+	return (lane_val(v, 0) + lane_val(v, 16)) + (lane_val(v, 32) + lane_val(v, 48));
+}
+
+// ---------------------------------------------------------------------------
+// math helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+	return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// sin / cos for |x| up to a few thousand radians: two-constant Cody-Waite reduction
+// by pi/2 (exact to ~1e-10 thanks to fma) and the classic single-precision minimax
+// polynomials on [-pi/4, pi/4]; ~1 ulp, so results track libm's to the last bit or two.
+__device__ __forceinline__ void sincos_fast(float x, float &s, float &c)
+{
+	const float k = rintf(x * 0.636619772367581343f);
+	float r = fmaf(-k, 1.57079637050628662109375f, x);
+	r = fmaf(-k, -4.37113900018624283e-8f, r);
+	const float z = r * r;
+	float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+	sp = fmaf(sp, z, -1.6666654611e-1f);
+	sp = fmaf(sp * z, r, r);
+	float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+	cp = fmaf(cp, z, 4.166664568298827e-2f);
+	cp = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+	const int q = (int)k;
+	const float ss = (q & 1) ? cp : sp;
+	const float cc = (q & 1) ? sp : cp;
+	s = (q & 2) ? -ss : ss;
+	c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// atan2 with ~1.5e-7 absolute error: octant folding + one reciprocal + degree-9 minimax
+__device__ __forceinline__ float atan2_fast(float y, float x)
+{
+	const float ax = fabsf(x), ay = fabsf(y);
+	const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+	const bool big = mn > 0.41421356237f * mx;             // tan(pi/8)
+	const float num = big ? (mn - mx) : mn;
+	const float den = big ? (mn + mx) : mx;
+	const float t = num * __builtin_amdgcn_rcpf(den);
+	const float z = t * t;
+	float p = fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f);
+	p = fmaf(p, z, 1.99777106478e-1f);
+	p = fmaf(p, z, -3.33329491539e-1f);
+	float a = fmaf(p * z, t, t);
+	a += big ? 0.785398163397448309f : 0.0f;
+	a = (ay > ax) ? (1.57079632679489662f - a) : a;
+	a = (x < 0.0f) ? (kPif - a) : a;
+	a = (mx == 0.0f) ? 0.0f : a;
+	return (y < 0.0f) ? -a : a;
+}
+
+// conj(ref) * v for ref = modulating value of sync symbol `sym` (exact: ref is +-1 / +-j)
+__device__ __forceinline__ float2 conj_ref_mul(int nbits, int sym, float2 v)
+{
+	if (nbits == 2) {
+		// sym0: ( x, y)  sym1: ( y,-x)  sym2: (-x,-y)  sym3: (-y, x)
+		const bool odd = (sym & 1) != 0;
+		const float a = odd ? v.y : v.x, b = odd ? v.x : v.y;
+		return make_float2((sym & 2) ? -a : a, ((sym + 1) & 2) ? -b : b);
+	}
+	return (sym & 1) ? make_float2(-v.x, -v.y) : v;
+}
+
+// K=5 rate-1/2 code (g0 = 1+D^3+D^4, g1 = 1+D+D^2+D^4; reference src/l1/conv.c:123-145)
+__device__ __forceinline__ uint32_t out_k5_12(uint32_t s, uint32_t b)
+{
+	uint32_t reg = (s << 1) | b;
+	return ((uint32_t)(__popc(reg & 0x19u) & 1) << 1) | (uint32_t)(__popc(reg & 0x17u) & 1);
+}
+__device__ __forceinline__ uint32_t rotl4(uint32_t x, int r) { return ((x << r) | (x >> (4 - r))) & 15u; }
 
 // ---------------------------------------------------------------------------
 // LDS carve-up of one wavefront
+//   [x | aux | eb]   aux = corr + coef during the sync search, y afterwards
+//   after the 4 demods of a fused wave, bm and surv overlay x
 // ---------------------------------------------------------------------------
 struct Lds {
 	float2 *x;        // normalised input window           [max_in_len]
-	float *corr;      // accumulated sync correlation      [kMaxWindow]
-	float2 *coef;     // rotated sync reference            [kMaxCoef]
-	float2 *y;        // decimated symbols                 [max_len]
-	int8_t *eb;       // soft bits of the current burst    [kEbitsLds]
-	uint32_t *bm;     // branch metrics, 4 rows x 212      (DECODE only)
-	uint64_t *surv;   // survivor ballots, aliases x       [212]
+	float *corr;      // accumulated sync correlation      [kMaxWindow]      (aux)
+	float2 *coef;     // rotated sync reference            [kMaxCoef]        (aux + 1 KiB)
+	float2 *y;        // decimated symbols                 [max_len]         (aux)
+	int8_t *eb;       // soft bits: 4 rows (fused) or one buffer
+	uint32_t *bm;     // branch metrics 4 x 212            (overlays x)
+	uint64_t *surv;   // survivor ballots [212]            (overlays x, after bm)
+	uint32_t *ubits;  // decoded bits, 4 rows x 8 words    (overlays x, after surv)
 };
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
@@ -164,26 +249,49 @@ __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t
 __host__ __device__ inline size_t lds_layout(int max_in_len, int max_len, bool decode, size_t *off)
 {
 	size_t o = 0;
-	off[0] = o; o += align16((size_t)max_in_len * 8);
-	off[1] = o; o += kMaxWindow * 4;
-	off[2] = o; o += kMaxCoef * 8;
-	off[3] = o; o += align16((size_t)max_len * 8);
-	off[4] = o; o += kEbitsLds;
-	off[5] = o; if (decode) o += 4 * kSteps12 * 4;
+	size_t xbytes = align16((size_t)max_in_len * 8);
+	const size_t dec_bytes = 4 * kSteps12 * 4 + kSteps12 * 8 + 4 * 8 * 4;
+	if (decode && xbytes < dec_bytes)
+		xbytes = align16(dec_bytes);
+	off[0] = o; o += xbytes;
+	size_t aux = kMaxWindow * 4 + kMaxCoef * 8;
+	if (aux < align16((size_t)max_len * 8))
+		aux = align16((size_t)max_len * 8);
+	off[1] = o; o += aux;
+	off[2] = o; o += decode ? 4 * kEbRow : kEbitsLds;
 	return align16(o);
+}
+
+__device__ __forceinline__ Lds lds_carve(unsigned char *raw, int max_in_len, int max_len, bool decode)
+{
+	size_t off[3];
+	lds_layout(max_in_len, max_len, decode, off);
+	Lds L;
+	L.x = reinterpret_cast<float2 *>(raw + off[0]);
+	L.corr = reinterpret_cast<float *>(raw + off[1]);
+	L.coef = reinterpret_cast<float2 *>(raw + off[1] + kMaxWindow * 4);
+	L.y = reinterpret_cast<float2 *>(raw + off[1]);
+	L.eb = reinterpret_cast<int8_t *>(raw + off[2]);
+	L.bm = reinterpret_cast<uint32_t *>(raw + off[0]);
+	L.surv = reinterpret_cast<uint64_t *>(raw + off[0] + 4 * kSteps12 * 4);
+	L.ubits = reinterpret_cast<uint32_t *>(raw + off[0] + 4 * kSteps12 * 4 + kSteps12 * 8);
+	return L;
 }
 
 // ---------------------------------------------------------------------------
 // demodulation of one burst by one wavefront
 // returns the reference's rv (0, or -1 when no sync sequence has power)
 // ---------------------------------------------------------------------------
-template <int NPL>
-__device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restrict__ in, int in_len,
-                         int sps, float freq_shift, const Lds &L, int lane,
-                         int &sync_id_o, float &toa_o, float &ferr_o, float *__restrict__ g_ssyms)
+template <int NPL, int SPS>
+__device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, int sps_rt,
+                         float freq_shift, const Lds &L, int8_t *__restrict__ eb, int lane,
+                         int dbg_stop, int &sync_id_o, float &toa_o, float &ferr_o,
+                         float *__restrict__ g_ssyms)
 {
-	const int nbits = bt->nbits;
-	const int blen = bt->len;
+	const DevBurst &bt = c_types[type];
+	const int sps = SPS ? SPS : sps_rt;
+	const int nbits = bt.nbits;
+	const int blen = bt.len;
 	const int w = in_len - blen * sps + 1;
 
 	// ---- load + normalise (osmo_cxvec_sig_normalize, decim 1) ------------------
@@ -221,32 +329,34 @@ __device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restri
 	}
 	for (int j = lane; j < w; j += 64)
 		L.corr[j] = 0.f;
+	if (dbg_stop == 1) return -100;
 
 	// per-sample derotation step (pi4cxpsk.c:539)
-	const float fs = (freq_shift - bt->rotation) / (float)sps;
+	const float fs = (freq_shift - bt.rotation) / (float)sps;
 
 	// ---- sync search (pi4cxpsk.c:184-268) --------------------------------------
 	float p_toa = 0.f, p_pwr = 0.f;
 	int p_idx = -1;
 	const int win = w < 3 ? w : 3;
+	const int nsync = bt.n_sync;
 
-	for (int sq = 0; sq < bt->n_sync; sq++) {
-		const int tl = bt->sync_tl[sq];
-		const int nch = bt->n_chunks[sq];
+	for (int sq = 0; sq < nsync; sq++) {
+		const int tl = bt.sync_tl[sq];
+		const int nch = bt.n_chunks[sq];
 
 		// rotated reference: conj(ref_n) * e^{j fs sps n}; the common phase of a lag
 		// drops out under |.|, so the window itself is never derotated here
 		WSYNC();
 		for (int n = lane; n < tl; n += 64) {
-			int ch = 0, base = 0;
-			while (n >= base + bt->sync[sq][ch].len) {
-				base += bt->sync[sq][ch].len;
-				ch++;
+			int ch = 0, base = 0, cum = 0;
+			for (int c = 0; c < nch - 1; c++) {
+				cum += bt.sync[sq][c].len;
+				if (n >= cum) { base = cum; ch = c + 1; }
 			}
 			const int nn = n - base;
-			const int sym = bt->sync[sq][ch].syms[nn];
+			const int sym = bt.sync[sq][ch].syms[nn];
 			float s, c;
-			sincosf(fs * (float)(nn * sps), &s, &c);
+			sincos_fast(fs * (float)(nn * sps), s, c);
 			L.coef[n] = conj_ref_mul(nbits, sym, make_float2(c, s));
 		}
 		WSYNC();
@@ -255,69 +365,85 @@ __device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restri
 			float cj = L.corr[j];
 			int base = 0;
 			for (int ch = 0; ch < nch; ch++) {
-				const int pos = bt->sync[sq][ch].pos, len = bt->sync[sq][ch].len;
+				const int pos = bt.sync[sq][ch].pos, len = bt.sync[sq][ch].len;
 				const float2 *xp = L.x + pos * sps + j;
+				const float2 *cp = L.coef + base;
 				float ar = 0.f, ai = 0.f;
 				for (int n = 0; n < len; n++) {
 					const float2 x = xp[n * sps];
-					const float2 cf = L.coef[base + n];
+					const float2 cf = cp[n];
 					ar = fmaf(cf.x, x.x, fmaf(-cf.y, x.y, ar));
 					ai = fmaf(cf.x, x.y, fmaf(cf.y, x.x, ai));
 				}
 				base += len;
-				cj += cabs_d(ar, ai);
+				cj += sqrtf(fmaf(ar, ar, ai * ai));
 			}
 			L.corr[j] = cj;
 		}
 		WSYNC();
+		if (dbg_stop == 2) return -100;
 
-		// osmo_cxvec_peak_energy_find(corr, 3, PEAK_EARLY_LATE, &peak)
-		float bv = -1.f;
-		int bi = 0x7fffffff;
+		// ---- osmo_cxvec_peak_energy_find(corr, 3, PEAK_EARLY_LATE, &peak) ----------
+		// key = (energy bits << 32) | ~index : max key = highest energy, lowest index on ties
+		unsigned long long key = 0;
 		for (int m = lane; m + win <= w; m += 64) {
 			float e = 0.f;
 			for (int k = 0; k < win; k++) {
-				float c = L.corr[m + k];
+				const float c = L.corr[m + k];
 				e += c * c;
 			}
-			if (e > bv) { bv = e; bi = m; }
+			const unsigned long long kk =
+				((unsigned long long)__builtin_bit_cast(uint32_t, e) << 32) | (uint32_t)(~m);
+			key = kk > key ? kk : key;
 		}
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
-			float ov = __shfl_xor(bv, o);
-			int oi = __shfl_xor(bi, o);
-			if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+			const unsigned long long ok = __shfl_xor(key, o);
+			key = ok > key ? ok : key;
 		}
-		const int mi = (bi == 0x7fffffff) ? 0 : bi;
+		int mi = (int)(~(uint32_t)key);
+		if (mi < 0 || mi + win > w)
+			mi = 0;
 		int p = mi;
 		{
 			float pe = -1.f;
 			for (int k = 0; k < win; k++) {
-				float c = L.corr[mi + k];
-				float e = c * c;
+				const float c = L.corr[mi + k];
+				const float e = c * c;
 				if (e > pe) { pe = e; p = mi + k; }
 			}
 		}
 
-		// sinc-interpolated value of corr at `pos`: lanes t<21 of each 32-lane half
-		auto interp_term = [&](float pos, int t) -> float {
-			const int i0 = (int)floorf(pos);
+		// sinc-interpolated corr at `pos` (libosmo-dsp interpolate_point, 21 taps):
+		// lanes t = 0..20 of each 32-lane half hold one tap of that half's position.
+		// tap weight sinc(pi (i - pos)) with i - pos = k - f  ->  -(-1)^k sin(pi f) / (pi (k - f))
+		const int t = lane & 31;
+		auto interp_term = [&](float pos) -> float {
+			const float fl = floorf(pos);
+			const int i0 = (int)fl;
+			const float f = pos - fl;
 			int b = i0 - 10, e = i0 + 11;
 			if (b < 0) b = 0;
 			if (e >= w) e = w - 1;
 			const int i = i0 - 10 + t;
-			if (t >= 21 || i < b || i >= e)
-				return 0.f;
+			const bool valid = t < 21 && i >= b && i < e;
 			const float xx = kPif * ((float)i - pos);
-			const float sc = (xx >= 0.01f || xx <= -0.01f) ? (sinf(xx) / xx) : 1.0f;
-			return L.corr[i] * sc;
+			const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f), argument in turns
+			const float sg = (t & 1) ? S : -S;                     // k = t - 10 has the parity of t
+			const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
+			const float c = L.corr[valid ? i : 0];
+			return valid ? c * wgt : 0.0f;
+		};
+		auto half_total = [&](float v, int half) -> float {
+			v = row_sum(v);
+			return lane_val(v, 32 * half) + lane_val(v, 32 * half + 16);
 		};
 
 		float early = (float)p - 1.0f, late = (float)p + 1.0f, incr = 0.5f;
 		while (incr > (1.0f / 1024.0f)) {
-			float t = interp_term(lane < 32 ? early : late, lane & 31);
-			t = half_sum(t);
-			const float ev = __shfl(t, 0), lv = __shfl(t, 32);
+			const float term = row_sum(interp_term(lane < 32 ? early : late));
+			const float ev = lane_val(term, 0) + lane_val(term, 16);
+			const float lv = lane_val(term, 32) + lane_val(term, 48);
 			const float ee = ev * ev, le = lv * lv;
 			if (ee > le)      { early -= incr; late -= incr; }
 			else if (ee < le) { early += incr; late += incr; }
@@ -325,8 +451,7 @@ __device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restri
 			incr *= 0.5f;
 		}
 		const float s_toa = early + 1.0f;
-		float pk = interp_term(s_toa, lane & 31);
-		pk = __shfl(half_sum(pk), 0);
+		float pk = half_total(interp_term(s_toa), 0);
 		pk = pk / (float)tl;
 		const float s_pwr = pk * pk;
 		if (s_pwr > p_pwr) {
@@ -335,6 +460,7 @@ __device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restri
 			p_idx = sq;
 		}
 	}
+	if (dbg_stop == 3) return -100;
 
 	sync_id_o = p_idx;
 	toa_o = p_toa;
@@ -343,44 +469,53 @@ __device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restri
 		return -1;
 	}
 	const int sq = p_idx;
-	const int nch = bt->n_chunks[sq];
+	const int nch = bt.n_chunks[sq];
 
 	// ---- align + decimate (pi4cxpsk.c:286-297), derotating only what is kept ----
+	// symbols stay in registers: lane l owns symbols l, l+64, l+128, ...
+	constexpr int NSYM = NPL > 16 ? 8 : 4;       // 4 x 64 >= 234, 8 x 64 >= 468
+	float2 ys[NSYM];
 	const int d = (int)roundf(p_toa);
-	for (int i = lane; i < blen; i += 64) {
+	WSYNC();                                     // aux region switches from corr/coef to y
+#pragma unroll
+	for (int r = 0; r < NSYM; r++) {
+		const int i = lane + 64 * r;
 		const int j = i * sps + d;
-		float2 x = (j >= 0 && j < in_len) ? L.x[j] : make_float2(0.f, 0.f);
+		float2 x = (i < blen && j >= 0 && j < in_len) ? L.x[j] : make_float2(0.f, 0.f);
 		if (fs != 0.0f) {
 			float s, c;
-			sincosf(fs * (float)j, &s, &c);
+			sincos_fast(fs * (float)j, s, c);
 			x = cmul(x, make_float2(c, s));
 		}
-		L.y[i] = x;
+		ys[r] = x;
+		if (i < blen)
+			L.y[i] = x;
 	}
 	WSYNC();
+	if (dbg_stop == 4) return -100;
 
 	// ---- fine frequency error from the sync chunks (pi4cxpsk.c:360-406) ---------
 	float ffe = 0.f;
 	if (nch > 1) {
 		float cr = 0.f, ci = 0.f;
 		if (lane < nch) {
-			const int pos = bt->sync[sq][lane].pos, len = bt->sync[sq][lane].len;
+			const int pos = bt.sync[sq][lane].pos, len = bt.sync[sq][lane].len;
 			for (int j = 0; j < len; j++) {
-				float2 t = conj_ref_mul(nbits, bt->sync[sq][lane].syms[j], L.y[pos + j]);
-				cr += t.x;
-				ci += t.y;
+				const float2 tt = conj_ref_mul(nbits, bt.sync[sq][lane].syms[j], L.y[pos + j]);
+				cr += tt.x;
+				ci += tt.y;
 			}
 		}
 		float f = 0.f;
-		float ppos = (float)bt->sync[sq][0].pos + (float)bt->sync[sq][0].len / 2.0f;
-		float pr = __shfl(cr, 0), pi = __shfl(ci, 0);
+		float ppos = (float)bt.sync[sq][0].pos + (float)bt.sync[sq][0].len / 2.0f;
+		float pr = lane_val(cr, 0), pi = lane_val(ci, 0);
 		for (int i = 1; i < nch; i++) {
-			const float cpos = (float)bt->sync[sq][i].pos + (float)bt->sync[sq][i].len / 2.0f;
-			const float r = __shfl(cr, i), q = __shfl(ci, i);
+			const float cpos = (float)bt.sync[sq][i].pos + (float)bt.sync[sq][i].len / 2.0f;
+			const float r = lane_val(cr, i), q = lane_val(ci, i);
 			// corr[i] * conj(corr[i-1])
 			const float re = r * pr - q * (-pi);
 			const float im = r * (-pi) + q * pr;
-			f += atan2f(im, re) / (cpos - ppos);
+			f += atan2_fast(im, re) / (cpos - ppos);
 			ppos = cpos; pr = r; pi = q;
 		}
 		f /= (float)(nch - 1);
@@ -391,59 +526,72 @@ __device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restri
 	// ---- rotate by -ffe (pi4cxpsk.c:574-575), in registers -------------------------
 	if (ffe != 0.0f) {
 		const float rps = -ffe;
-		for (int i = lane; i < blen; i += 64) {
+		WSYNC();
+#pragma unroll
+		for (int r = 0; r < NSYM; r++) {
+			const int i = lane + 64 * r;
 			float s, c;
-			sincosf(rps * (float)i, &s, &c);
-			L.y[i] = cmul(L.y[i], make_float2(c, s));
+			sincos_fast(rps * (float)i, s, c);
+			ys[r] = cmul(ys[r], make_float2(c, s));
+			if (i < blen)
+				L.y[i] = ys[r];
 		}
 		WSYNC();
 	}
 
 	// ---- carrier phase from the sync symbols (pi4cxpsk.c:415-433) ------------------
-	float phr = 0.f, phi = 0.f;
-	for (int ch = 0; ch < nch; ch++) {
-		const int pos = bt->sync[sq][ch].pos, len = bt->sync[sq][ch].len;
-		for (int j = 0; j < len; j++) {
-			float2 t = conj_ref_mul(nbits, bt->sync[sq][ch].syms[j], L.y[pos + j]);
-			phr += t.x;
-			phi += t.y;
+	// lane n < tl takes sync symbol n; the reference's sequential sum becomes a tree
+	float tr = 0.f, ti = 0.f;
+	{
+		const int tl = bt.sync_tl[sq];
+		for (int n = lane; n < tl; n += 64) {
+			int ch = 0, base = 0, cum = 0;
+			for (int c = 0; c < nch - 1; c++) {
+				cum += bt.sync[sq][c].len;
+				if (n >= cum) { base = cum; ch = c + 1; }
+			}
+			const int nn = n - base;
+			const float2 tt = conj_ref_mul(nbits, bt.sync[sq][ch].syms[nn], L.y[bt.sync[sq][ch].pos + nn]);
+			tr += tt.x;
+			ti += tt.y;
 		}
 	}
-	const float pm = cabs_d(phr, phi);
+	const float phr = wave_sum(tr), phi = wave_sum(ti);
+	const float pm = sqrtf(fmaf(phr, phr, phi * phi));
 	const float2 cph = make_float2(phr / pm, -(phi / pm));   // conj(phasor)
+	if (dbg_stop == 5) return -100;
 
 	// ---- soft symbols + soft bits (pi4cxpsk.c:442-503) ------------------------------
-	const float dd = (2.0f * kPif) / (float)(1 << nbits);
+	const float inv_dd = (float)(1 << nbits) / (2.0f * kPif);
 	const int mask = (1 << nbits) - 1;
-	const int nd = bt->n_data;
-	for (int i = lane; i < blen; i += 64) {
-		const float2 yy = cmul(L.y[i], cph);
-		const float sv = atan2f(yy.y, yy.x) / dd;
+#pragma unroll
+	for (int r = 0; r < NSYM; r++) {
+		const int i = lane + 64 * r;
+		if (i >= blen)
+			continue;
+		const float2 yy = cmul(ys[r], cph);
+		const float sv = atan2_fast(yy.y, yy.x) * inv_dd;
 		if (g_ssyms)
 			g_ssyms[i] = sv;
-		int ord = -1;
-		for (int c = 0; c < nd; c++) {
-			const int dp = bt->dpos[c], dl = bt->dlen[c];
-			if (i >= dp && i < dp + dl)
-				ord = bt->dcum[c] + (i - dp);
-		}
+		const int ord = bt.ord_of_sym[i];
 		if (ord >= 0) {
-			const float svr = roundf(sv);
-			const int sp = (int)svr & mask;
-			const int ss = (svr > sv ? (sp - 1) : (sp + 1)) & mask;
-			const int dq = (int)roundf((2.0f * fabsf(svr - sv)) * 64.0f);
+			const float svr2 = roundf(sv);
+			const int sp = (int)svr2 & mask;
+			const int ss = (svr2 > sv ? (sp - 1) : (sp + 1)) & mask;
+			const int dq = (int)roundf((2.0f * fabsf(svr2 - sv)) * 64.0f);
 			if (nbits == 2) {
 				// symbol -> bits 0:00 1:01 2:11 3:10 (pi4cxpsk.c:95-100)
 				const int p0 = sp >> 1, p1 = (sp ^ (sp >> 1)) & 1;
 				const int s0 = ss >> 1, s1 = (ss ^ (ss >> 1)) & 1;
 				const int v0 = 127 - ((p0 ^ s0) ? dq : (dq >> 1));
 				const int v1 = 127 - ((p1 ^ s1) ? dq : (dq >> 1));
-				L.eb[2 * ord]     = (int8_t)(p0 ? -v0 : v0);
-				L.eb[2 * ord + 1] = (int8_t)(p1 ? -v1 : v1);
+				const uint32_t pk2 = (uint32_t)(uint8_t)(int8_t)(p0 ? -v0 : v0) |
+				                     ((uint32_t)(uint8_t)(int8_t)(p1 ? -v1 : v1) << 8);
+				*reinterpret_cast<uint16_t *>(eb + 2 * ord) = (uint16_t)pk2;
 			} else {
 				const int p0 = sp & 1, s0 = ss & 1;
 				const int v0 = 127 - ((p0 ^ s0) ? dq : (dq >> 1));
-				L.eb[ord] = (int8_t)(p0 ? -v0 : v0);
+				eb[ord] = (int8_t)(p0 ? -v0 : v0);
 			}
 		}
 	}
@@ -453,20 +601,20 @@ __device__ int demod_one(const DevBurst *__restrict__ bt, const float2 *__restri
 
 // ---------------------------------------------------------------------------
 // branch metrics of one burst into bm[0..212): byte ov = cost of coded word ov
-// (descramble + de-interleave folded into the gather)
+// (descramble + de-interleave folded into the gather via c_steps)
 //   bcch.c:91-92 / ccch.c:95-96, interleave.c:73-87, scramb.c:63-73
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ eb, int off,
+__device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ eb, int chain,
                                                      uint32_t *__restrict__ bm, int lane)
 {
 	for (int k = lane; k < kSteps12; k += 64) {
+		const uint32_t st = c_steps.w[chain][k];
 		int c0[2], c1[2];
 #pragma unroll
 		for (int j = 0; j < 2; j++) {
-			const int kc = 2 * k + j;
-			const int ei = 53 * ((5 * kc) & 7) + (kc >> 3) + off;
-			int v = eb[ei];
-			if ((c_scr.w[ei >> 5] >> (ei & 31)) & 1u)
+			const uint32_t h = st >> (16 * j);
+			int v = eb[h & 0x3ffu];
+			if (h & 0x400u)
 				v = (int8_t)(-v);
 			const int e0 = v - 127, e1 = v + 127;
 			c0[j] = v ? ((e0 * e0) >> 9) : 0;
@@ -480,7 +628,7 @@ __device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ 
 // ---------------------------------------------------------------------------
 // 4 x (K=5, rate 1/2, 208 bits + flush) Viterbi, one burst per 16-lane row
 // ---------------------------------------------------------------------------
-template <int PH>
+template <int PH, bool EDGE>
 __device__ __forceinline__ void acs_step(uint32_t &ae, uint32_t bmw, uint32_t sh_own, uint32_t sh_par,
                                          bool b_is_one, bool flush, unsigned long long &ballot)
 {
@@ -488,17 +636,35 @@ __device__ __forceinline__ void acs_step(uint32_t &ae, uint32_t bmw, uint32_t sh
 	const uint32_t n_own = ae + ((bmw >> sh_own) & 0xffu);
 	const uint32_t n_par = par + ((bmw >> sh_par) & 0xffu);
 	uint32_t nw = n_own < n_par ? n_own : n_par;
-	nw = nw < kMaxAe ? nw : kMaxAe;
 	// hi predecessor ((t>>1)+8) wins only when strictly better: ties keep the lower state
 	const bool dec = b_is_one ? (n_own < n_par) : (n_par < n_own);
-	if (flush && b_is_one)
-		nw = kMaxAe;            // flush steps only take the b=0 transitions
+	if (EDGE) {
+		// unreachable states carry MAX_AE and never grow (the first 4 and the flush steps)
+		nw = nw < kMaxAe ? nw : kMaxAe;
+		if (flush && b_is_one)
+			nw = kMaxAe;        // flush steps only take the b=0 transitions
+	}
 	ae = nw;
 	ballot = __ballot(dec);
 }
 
-__device__ void decode4_k5_12(const uint32_t *__restrict__ bm /* 4 x 212 */, uint64_t *__restrict__ surv,
-                              int lane, uint32_t words[7], uint32_t &syn_o, uint32_t &final_ae)
+#define ACS4(EDGE, FL)                                                                             \
+	do {                                                                                           \
+		const uint4 bw = *reinterpret_cast<const uint4 *>(bmr + k);                                \
+		unsigned long long m;                                                                      \
+		acs_step<0, EDGE>(ae, bw.x, sh_own[0], sh_par[0], b1[0], FL, m);                           \
+		if (lane == kk + 0) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
+		acs_step<1, EDGE>(ae, bw.y, sh_own[1], sh_par[1], b1[1], FL, m);                           \
+		if (lane == kk + 1) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
+		acs_step<2, EDGE>(ae, bw.z, sh_own[2], sh_par[2], b1[2], FL, m);                           \
+		if (lane == kk + 2) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
+		acs_step<3, EDGE>(ae, bw.w, sh_own[3], sh_par[3], b1[3], FL, m);                           \
+		if (lane == kk + 3) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
+	} while (0)
+
+// bm: 4 rows x 212 words; surv: 212 ballots; ubits: 4 rows x 8 words (decoded bits, LSB first)
+__device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restrict__ surv,
+                              uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae)
 {
 	const int row = lane >> 4;
 	const uint32_t loc = (uint32_t)lane & 15u;
@@ -515,122 +681,134 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm /* 4 x 212 */, uin
 	uint32_t ae = loc ? kMaxAe : 0u;
 	const uint32_t *bmr = bm + row * kSteps12;
 
-	int slo[4] = {0, 0, 0, 0}, shi[4] = {0, 0, 0, 0};
-#pragma unroll
+	// forward pass; lane (k & 63) keeps the ballot of step k, flushed to LDS every 64 steps
+#pragma unroll 1
 	for (int blk = 0; blk < 4; blk++) {
-		const int kend = (kSteps12 - blk * 64) < 64 ? (kSteps12 - blk * 64) : 64;
-		for (int kk = 0; kk < kend; kk += 4) {
-			const int k = blk * 64 + kk;
-			const bool fl = k >= 208;
-			unsigned long long m;
-			acs_step<0>(ae, bmr[k + 0], sh_own[0], sh_par[0], b1[0], fl, m);
-			slo[blk] = (lane == kk + 0) ? (int)(uint32_t)m : slo[blk];
-			shi[blk] = (lane == kk + 0) ? (int)(uint32_t)(m >> 32) : shi[blk];
-			acs_step<1>(ae, bmr[k + 1], sh_own[1], sh_par[1], b1[1], fl, m);
-			slo[blk] = (lane == kk + 1) ? (int)(uint32_t)m : slo[blk];
-			shi[blk] = (lane == kk + 1) ? (int)(uint32_t)(m >> 32) : shi[blk];
-			acs_step<2>(ae, bmr[k + 2], sh_own[2], sh_par[2], b1[2], fl, m);
-			slo[blk] = (lane == kk + 2) ? (int)(uint32_t)m : slo[blk];
-			shi[blk] = (lane == kk + 2) ? (int)(uint32_t)(m >> 32) : shi[blk];
-			acs_step<3>(ae, bmr[k + 3], sh_own[3], sh_par[3], b1[3], fl, m);
-			slo[blk] = (lane == kk + 3) ? (int)(uint32_t)m : slo[blk];
-			shi[blk] = (lane == kk + 3) ? (int)(uint32_t)(m >> 32) : shi[blk];
+		uint32_t s_lo = 0, s_hi = 0;
+		const int k0 = blk * 64;
+		const int kend = (kSteps12 - k0) < 64 ? (kSteps12 - k0) : 64;
+		int kk = 0;
+		if (blk == 0) {
+			const int k = 0;
+			ACS4(true, false);
+			kk = 4;
 		}
+		const int kmain = (blk == 3) ? kend - 4 : kend;    // last 4 steps of the block 3 are the flush
+		for (; kk < kmain; kk += 4) {
+			const int k = k0 + kk;
+			ACS4(false, false);
+		}
+		if (blk == 3) {
+			const int k = k0 + kk;
+			ACS4(true, true);
+		}
+		if (lane < kend)
+			surv[k0 + lane] = (uint64_t)s_lo | ((uint64_t)s_hi << 32);
 	}
 	// 212 = 53 * 4 steps: the layout is back to identity, state 0 sits in lane 0 of the row
 	final_ae = ae;
-
-	WSYNC();
-#pragma unroll
-	for (int blk = 0; blk < 4; blk++) {
-		const int k = blk * 64 + lane;
-		if (k < kSteps12)
-			surv[k] = (uint64_t)(uint32_t)slo[blk] | ((uint64_t)(uint32_t)shi[blk] << 32);
-	}
 	WSYNC();
 
-	// traceback: one lane per row (osmo_conv_decode_get_output, end state 0 after flush)
-	uint32_t syn = 0;
-#pragma unroll
-	for (int i = 0; i < 7; i++)
-		words[i] = 0;
+	// traceback, one lane per row, walking LOCATIONS: the state that ends step k in location L
+	// came from location (L with bit (3 - k%4) := decision), because the butterfly is in place.
+	// Its newest input bit (the decoded bit of step k) is bit 0 of the state = bit (k+1)%4-th
+	// rotation of L.  (osmo_conv_decode_get_output, end state 0 after flush)
 	if (loc == 0) {
 		const uint16_t *s16 = reinterpret_cast<const uint16_t *>(surv) + row;
-		uint32_t cur = 0;
-		for (int k = kSteps12 - 1; k >= 208; k--) {
-			const uint32_t l = rotr4(cur, (k + 1) & 3);
-			const uint32_t dbit = ((uint32_t)s16[4 * k] >> l) & 1u;
-			cur = (cur >> 1) | (dbit << 3);
-		}
+		uint32_t L = 0;   // state 0 after step 211 sits in location 0
+		// flush steps 211..208 (phases 3,2,1,0): no output
 #pragma unroll
+		for (int k = kSteps12 - 1; k >= 208; k--) {
+			const int pb = 3 - (k & 3);
+			const uint32_t dbit = ((uint32_t)s16[4 * k] >> L) & 1u;
+			L = (L & ~(1u << pb)) | (dbit << pb);
+		}
 		for (int wi = 6; wi >= 0; wi--) {
 			uint32_t wv = 0;
-			for (int bit = (wi == 6 ? 15 : 31); bit >= 0; bit--) {
-				const int k = wi * 32 + bit;
-				const uint32_t l = rotr4(cur, (k + 1) & 3);
-				const uint32_t dbit = ((uint32_t)s16[4 * k] >> l) & 1u;
-				const uint32_t ob = cur & 1u;
-				wv |= ob << bit;
-				syn ^= ob ? (uint32_t)c_syn.s[k] : 0u;
-				cur = (cur >> 1) | (dbit << 3);
+			const int top = (wi == 6) ? 15 : 31;
+#pragma unroll 4
+			for (int bit = top; bit >= 0; bit--) {
+				const int k = wi * 32 + bit;          // k % 4 == bit % 4
+				const int pb = 3 - (bit & 3);
+				// state after step k = rotl^{(k+1)%4}(L); its bit 0 is bit (4 - (k+1)%4) % 4 of L
+				const int ob_pos = (4 - ((bit + 1) & 3)) & 3;
+				const uint32_t dbit = ((uint32_t)s16[4 * k] >> L) & 1u;
+				wv |= ((L >> ob_pos) & 1u) << bit;
+				L = (L & ~(1u << pb)) | (dbit << pb);
 			}
-			words[wi] = wv;
+			ubits[row * 8 + wi] = wv;
 		}
 	}
+	WSYNC();
+
+	// CRC16 over the 208 decoded bits, 13 bits per lane of the row, XOR-reduced with DPP
+	uint32_t syn = 0;
+	{
+		const uint32_t *ub = ubits + row * 8;
+#pragma unroll
+		for (int q = 0; q < 13; q++) {
+			const int k = (int)loc * 13 + q;
+			const uint32_t bit = (ub[k >> 5] >> (k & 31)) & 1u;
+			syn ^= bit ? (uint32_t)c_syn.s[k] : 0u;
+		}
+		syn ^= row_xor<1>(syn);
+		syn ^= row_xor<2>(syn);
+		syn ^= row_xor<4>(syn);
+		syn ^= row_xor<8>(syn);
+	}
 	syn_o = syn;
+}
+
+__device__ __forceinline__ void store_l2(uint8_t *l2, const uint32_t *ub)
+{
+	uint32_t *l2w = reinterpret_cast<uint32_t *>(l2);
+#pragma unroll
+	for (int i = 0; i < 6; i++)
+		l2w[i] = ub[i];
 }
 
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int NPL, bool DECODE>
+template <int NPL, int SPS, bool DECODE>
 __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
-	size_t off[6];
-	lds_layout(max_in_len, max_len, DECODE, off);
-	Lds L;
-	L.x = reinterpret_cast<float2 *>(lds_raw + off[0]);
-	L.corr = reinterpret_cast<float *>(lds_raw + off[1]);
-	L.coef = reinterpret_cast<float2 *>(lds_raw + off[2]);
-	L.y = reinterpret_cast<float2 *>(lds_raw + off[3]);
-	L.eb = reinterpret_cast<int8_t *>(lds_raw + off[4]);
-	L.bm = reinterpret_cast<uint32_t *>(lds_raw + off[5]);
-	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[0]);
+	const Lds L = lds_carve(lds_raw, max_in_len, max_len, DECODE);
 
 	constexpr int PER = DECODE ? 4 : 1;
 	const int g0 = blockIdx.x * PER;
-	int row_ok = 0;   // bit q set: burst q of this wave demodulated fine
+	int row_ok = 0;       // bit q: burst q of this wave demodulated fine
+	int row_chain = 0;    // bit q: burst q is CCCH
 
 	for (int q = 0; q < PER; q++) {
 		const int g = g0 + q;
-		if (g >= a.n) {
-			if (DECODE)
-				for (int k = lane; k < kSteps12; k += 64)
-					L.bm[q * kSteps12 + k] = 0;
-			continue;
-		}
-		int type, in_len, chain_off = 0;
+		if (g >= a.n)
+			break;
+		int type, in_len;
 		if (DECODE) {
 			const int kind = a.kind[g] ? 1 : 0;
 			type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
 			in_len = a.in_len[kind];
-			chain_off = kind ? 4 : 0;
+			row_chain |= kind << q;
 		} else {
 			type = a.fixed_type;
 			in_len = a.in_len[0];
 		}
 		type = __builtin_amdgcn_readfirstlane(type);
 		in_len = __builtin_amdgcn_readfirstlane(in_len);
-		const DevBurst *bt = a.types + type;
 		const float fsh = a.freq_shift ? a.freq_shift[g] : 0.0f;
 		int sid = -1;
 		float toa = 0.f, fe = 0.f;
 		float *gss = a.ssyms ? a.ssyms + (size_t)g * a.ssyms_stride : nullptr;
+		int8_t *eb = L.eb + (DECODE ? q * kEbRow : 0);
 
 		WSYNC();
-		const int rv = demod_one<NPL>(bt, a.iq + a.offset[g], in_len, a.sps, fsh, L, lane, sid, toa, fe, gss);
+		const int rv = demod_one<NPL, SPS>(type, a.iq + a.offset[g], in_len, a.sps, fsh, L, eb, lane,
+		                                   a.dbg_stop, sid, toa, fe, gss);
+		if (rv == -100)
+			continue;    // profiling build-out: phase cut-off
 
 		if (lane == 0) {
 			a.rv[g] = rv;
@@ -638,41 +816,45 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 			if (a.toa) a.toa[g] = rv ? 0.f : toa;
 			if (a.freq_err) a.freq_err[g] = rv ? 0.f : fe;
 		}
-		const int neb = bt->ebits;
 		if (a.ebits) {
+			const int neb = c_types[type].ebits;
 			int8_t *ge = a.ebits + (size_t)g * a.ebits_stride;
 			for (int i = lane; i < a.ebits_stride; i += 64)
-				ge[i] = (rv == 0 && i < neb) ? L.eb[i] : (int8_t)0;
+				ge[i] = (rv == 0 && i < neb) ? eb[i] : (int8_t)0;
 		}
 		if (rv && gss)
-			for (int i = lane; i < bt->len; i += 64)
+			for (int i = lane; i < c_types[type].len; i += 64)
 				gss[i] = 0.f;
-		if (DECODE) {
-			if (rv == 0) {
-				row_ok |= 1 << q;
-				branch_metrics_k5_12(L.eb, chain_off, L.bm + q * kSteps12, lane);
+		if (rv == 0)
+			row_ok |= 1 << q;
+	}
+
+	if (DECODE) {
+		if (a.dbg_stop && a.dbg_stop < 7)
+			return;
+		WSYNC();     // x is dead from here on: bm / surv / ubits overlay it
+		for (int q = 0; q < 4; q++) {
+			if ((row_ok >> q) & 1) {
+				branch_metrics_k5_12(L.eb + q * kEbRow, (row_chain >> q) & 1, L.bm + q * kSteps12, lane);
 			} else {
 				for (int k = lane; k < kSteps12; k += 64)
 					L.bm[q * kSteps12 + k] = 0;
 			}
 		}
-	}
-
-	if (DECODE) {
 		WSYNC();
-		uint32_t words[7], syn, fae;
-		decode4_k5_12(L.bm, L.surv, lane, words, syn, fae);
+		if (a.dbg_stop == 7)
+			return;
+		uint32_t syn, fae;
+		decode4_k5_12(L.bm, L.surv, L.ubits, lane, syn, fae);
 		const int row = lane >> 4;
 		const int g = g0 + row;
 		if ((lane & 15) == 0 && g < a.n) {
-			uint32_t *l2w = reinterpret_cast<uint32_t *>(a.l2 + (size_t)g * 24);
 			if ((row_ok >> row) & 1) {
-#pragma unroll
-				for (int i = 0; i < 6; i++)
-					l2w[i] = words[i];
+				store_l2(a.l2 + (size_t)g * 24, L.ubits + row * 8);
 				a.crc[g] = syn ? 1 : 0;
 				a.conv[g] = (int32_t)fae;
 			} else {
+				uint32_t *l2w = reinterpret_cast<uint32_t *>(a.l2 + (size_t)g * 24);
 #pragma unroll
 				for (int i = 0; i < 6; i++)
 					l2w[i] = 0;
@@ -685,37 +867,41 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 
 __global__ __launch_bounds__(64) void k_l1(L1Args a)
 {
-	__shared__ __align__(16) int8_t s_eb[kEbitsLds];
+	__shared__ __align__(16) int8_t s_eb[4 * kEbRow];
 	__shared__ __align__(16) uint32_t s_bm[4 * kSteps12];
 	__shared__ __align__(16) uint64_t s_surv[kSteps12];
+	__shared__ __align__(16) uint32_t s_ub[4 * 8];
 	const int lane = threadIdx.x;
 	const int g0 = blockIdx.x * 4;
 	const int neb = a.chain == kChainCcch ? 432 : 424;
-	const int off = a.chain == kChainCcch ? 4 : 0;
+	const int chain = a.chain == kChainCcch ? 1 : 0;
 
+	// soft bits HBM -> LDS, 4 bytes per lane
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
-		WSYNC();
 		if (g < a.n) {
-			const int8_t *src = a.ebits + (size_t)g * neb;
-			for (int i = lane; i < neb; i += 64)
-				s_eb[i] = src[i];
-			WSYNC();
-			branch_metrics_k5_12(s_eb, off, s_bm + q * kSteps12, lane);
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ebits + (size_t)g * neb);
+			uint32_t *dst = reinterpret_cast<uint32_t *>(s_eb + q * kEbRow);
+			for (int i = lane; i < neb / 4; i += 64)
+				dst[i] = src[i];
+		}
+	}
+	WSYNC();
+	for (int q = 0; q < 4; q++) {
+		if (g0 + q < a.n) {
+			branch_metrics_k5_12(s_eb + q * kEbRow, chain, s_bm + q * kSteps12, lane);
 		} else {
 			for (int k = lane; k < kSteps12; k += 64)
 				s_bm[q * kSteps12 + k] = 0;
 		}
 	}
 	WSYNC();
-	uint32_t words[7], syn, fae;
-	decode4_k5_12(s_bm, s_surv, lane, words, syn, fae);
-	const int g = g0 + (lane >> 4);
+	uint32_t syn, fae;
+	decode4_k5_12(s_bm, s_surv, s_ub, lane, syn, fae);
+	const int row = lane >> 4;
+	const int g = g0 + row;
 	if ((lane & 15) == 0 && g < a.n) {
-		uint32_t *l2w = reinterpret_cast<uint32_t *>(a.l2 + (size_t)g * 24);
-#pragma unroll
-		for (int i = 0; i < 6; i++)
-			l2w[i] = words[i];
+		store_l2(a.l2 + (size_t)g * 24, s_ub + row * 8);
 		a.crc[g] = syn ? 1 : 0;
 		a.conv[g] = (int32_t)fae;
 	}
@@ -724,24 +910,16 @@ __global__ __launch_bounds__(64) void k_l1(L1Args a)
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-static int g_max_len_cache = 468;
-
-size_t rx_lds_bytes(int max_in_len)
+template <int NPL, int SPS>
+static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int max_len, hipStream_t stream)
 {
-	size_t off[6];
-	return lds_layout(max_in_len, g_max_len_cache, true, off);
-}
-
-template <int NPL>
-static hipError_t launch_rx_npl(const RxArgs &a, bool decode, int max_in_len, int max_len, hipStream_t stream)
-{
-	size_t off[6];
+	size_t off[3];
 	const size_t lds = lds_layout(max_in_len, max_len, decode, off);
 	if (decode) {
 		const int grid = (a.n + 3) / 4;
-		hipLaunchKernelGGL((k_rx<NPL, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
+		hipLaunchKernelGGL((k_rx<NPL, SPS, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
 	} else {
-		hipLaunchKernelGGL((k_rx<NPL, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
+		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
 	}
 	return hipGetLastError();
 }
@@ -754,9 +932,14 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 		return hipErrorInvalidValue;
 	// symbols per burst: fused path is BCCH/DC6 (234); generic path sizes for the longest format
 	const int max_len = decode ? 234 : 468;
-	if (max_in_len <= 1024)
-		return launch_rx_npl<16>(a, decode, max_in_len, max_len, stream);
-	return launch_rx_npl<32>(a, decode, max_in_len, max_len, stream);
+	if (max_in_len <= 1024) {
+		if (a.sps == 4)
+			return launch_rx_t<16, 4>(a, decode, max_in_len, max_len, stream);
+		return launch_rx_t<16, 0>(a, decode, max_in_len, max_len, stream);
+	}
+	if (a.sps == 4)
+		return launch_rx_t<32, 4>(a, decode, max_in_len, max_len, stream);
+	return launch_rx_t<32, 0>(a, decode, max_in_len, max_len, stream);
 }
 
 hipError_t launch_l1(const L1Args &a, hipStream_t stream)
