@@ -295,12 +295,19 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 	const int w = in_len - blen * sps + 1;
 
 	// ---- load + normalise (osmo_cxvec_sig_normalize, decim 1) ------------------
+	// rows k < nfull are whole (no lane test); row nfull is the ragged tail
 	float2 v[NPL];
 	float sr = 0.f, si = 0.f;
+	const int nfull = in_len >> 6;
+	const bool tail = (lane + 64 * nfull) < in_len;
 #pragma unroll
 	for (int k = 0; k < NPL; k++) {
-		int idx = lane + 64 * k;
-		v[k] = (idx < in_len) ? in[idx] : make_float2(0.f, 0.f);
+		if (k < nfull)
+			v[k] = in[lane + 64 * k];
+		else if (k == nfull && tail)
+			v[k] = in[lane + 64 * k];
+		else
+			v[k] = make_float2(0.f, 0.f);
 		sr += v[k].x;
 		si += v[k].y;
 	}
@@ -310,11 +317,11 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 	float acc = 0.f;
 #pragma unroll
 	for (int k = 0; k < NPL; k++) {
-		int idx = lane + 64 * k;
-		v[k].x -= avr;
-		v[k].y -= avi;
-		if (idx < in_len)
-			acc += v[k].x * v[k].x + v[k].y * v[k].y;
+		if (k < nfull || (k == nfull && tail)) {
+			v[k].x -= avr;
+			v[k].y -= avi;
+			acc = fmaf(v[k].x, v[k].x, fmaf(v[k].y, v[k].y, acc));
+		}
 	}
 	float sigma = wave_sum(acc) / (float)in_len;
 	float stddev = sqrtf(sigma);
@@ -323,9 +330,8 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 	const float inv = 1.0f / stddev;
 #pragma unroll
 	for (int k = 0; k < NPL; k++) {
-		int idx = lane + 64 * k;
-		if (idx < in_len)
-			L.x[idx] = make_float2(v[k].x * inv, v[k].y * inv);
+		if (k < nfull || (k == nfull && tail))
+			L.x[lane + 64 * k] = make_float2(v[k].x * inv, v[k].y * inv);
 	}
 	for (int j = lane; j < w; j += 64)
 		L.corr[j] = 0.f;
@@ -471,97 +477,104 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 	const int sq = p_idx;
 	const int nch = bt.n_chunks[sq];
 
-	// ---- align + decimate (pi4cxpsk.c:286-297), derotating only what is kept ----
-	// symbols stay in registers: lane l owns symbols l, l+64, l+128, ...
-	constexpr int NSYM = NPL > 16 ? 8 : 4;       // 4 x 64 >= 234, 8 x 64 >= 468
-	float2 ys[NSYM];
+	// ---- everything after the sync search works in the PHASE domain ----------------
+	// The reference rotates the decimated burst three times (derotation e^{j fs n},
+	// fine frequency e^{-j f i}, carrier conj(phasor)) and then takes cargf() of each
+	// symbol (pi4cxpsk.c:286-297,574-581,442-460).  arg() of that product is
+	//     arg(x[i sps + d]) + fs (i sps + d) - f i - arg(phasor)      (mod 2 pi)
+	// so only the <= 17 sync symbols are ever rotated as complex numbers; the 234
+	// symbols cost one atan2 and a few adds each.  Soft bits only depend on the phase.
 	const int d = (int)roundf(p_toa);
-	WSYNC();                                     // aux region switches from corr/coef to y
-#pragma unroll
-	for (int r = 0; r < NSYM; r++) {
-		const int i = lane + 64 * r;
-		const int j = i * sps + d;
-		float2 x = (i < blen && j >= 0 && j < in_len) ? L.x[j] : make_float2(0.f, 0.f);
-		if (fs != 0.0f) {
-			float s, c;
-			sincos_fast(fs * (float)j, s, c);
-			x = cmul(x, make_float2(c, s));
-		}
-		ys[r] = x;
-		if (i < blen)
-			L.y[i] = x;
-	}
-	WSYNC();
-	if (dbg_stop == 4) return -100;
+	const int row = lane >> 4, col = lane & 15;
+
+	auto reduce_2pi = [](float a) -> float {
+		const float k = rintf(a * 0.159154943091895336f);
+		a = fmaf(-k, 6.2831854820251465f, a);
+		return fmaf(-k, -1.7484555e-7f, a);
+	};
+	// conj(ref) * derotated sample of sync symbol j of chunk c (pi4cxpsk.c:386-388)
+	auto sync_term = [&](int c, int j) -> float2 {
+		const int idx = (bt.sync[sq][c].pos + j) * sps + d;
+		float2 x = (idx >= 0 && idx < in_len) ? L.x[idx] : make_float2(0.f, 0.f);
+		float s, cc;
+		sincos_fast(fs * (float)idx, s, cc);
+		x = cmul(x, make_float2(cc, s));
+		return conj_ref_mul(nbits, bt.sync[sq][c].syms[j], x);
+	};
 
 	// ---- fine frequency error from the sync chunks (pi4cxpsk.c:360-406) ---------
+	// one chunk per 16-lane row, one sync symbol per lane; chunk sums by DPP
 	float ffe = 0.f;
 	if (nch > 1) {
-		float cr = 0.f, ci = 0.f;
-		if (lane < nch) {
-			const int pos = bt.sync[sq][lane].pos, len = bt.sync[sq][lane].len;
-			for (int j = 0; j < len; j++) {
-				const float2 tt = conj_ref_mul(nbits, bt.sync[sq][lane].syms[j], L.y[pos + j]);
-				cr += tt.x;
-				ci += tt.y;
+		float sumr[kMaxChunks], sumi[kMaxChunks];
+#pragma unroll
+		for (int c0 = 0; c0 < kMaxChunks; c0 += 4) {
+			if (c0 < nch) {
+				const int c = c0 + row;
+				float tr = 0.f, ti = 0.f;
+				if (c < nch) {
+					const int len = bt.sync[sq][c].len;
+					for (int j = col; j < len; j += 16) {
+						const float2 tt = sync_term(c, j);
+						tr += tt.x;
+						ti += tt.y;
+					}
+				}
+				tr = row_sum(tr);
+				ti = row_sum(ti);
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					sumr[c0 + r] = lane_val(tr, 16 * r);
+					sumi[c0 + r] = lane_val(ti, 16 * r);
+				}
 			}
 		}
 		float f = 0.f;
-		float ppos = (float)bt.sync[sq][0].pos + (float)bt.sync[sq][0].len / 2.0f;
-		float pr = lane_val(cr, 0), pi = lane_val(ci, 0);
-		for (int i = 1; i < nch; i++) {
-			const float cpos = (float)bt.sync[sq][i].pos + (float)bt.sync[sq][i].len / 2.0f;
-			const float r = lane_val(cr, i), q = lane_val(ci, i);
-			// corr[i] * conj(corr[i-1])
-			const float re = r * pr - q * (-pi);
-			const float im = r * (-pi) + q * pr;
-			f += atan2_fast(im, re) / (cpos - ppos);
-			ppos = cpos; pr = r; pi = q;
+#pragma unroll
+		for (int i = 1; i < kMaxChunks; i++) {
+			if (i < nch) {
+				const float ppos = (float)bt.sync[sq][i - 1].pos + (float)bt.sync[sq][i - 1].len / 2.0f;
+				const float cpos = (float)bt.sync[sq][i].pos + (float)bt.sync[sq][i].len / 2.0f;
+				// corr[i] * conj(corr[i-1])
+				const float re = sumr[i] * sumr[i - 1] - sumi[i] * (-sumi[i - 1]);
+				const float im = sumr[i] * (-sumi[i - 1]) + sumi[i] * sumr[i - 1];
+				f += atan2_fast(im, re) / (cpos - ppos);
+			}
 		}
 		f /= (float)(nch - 1);
 		ffe = f;
 	}
 	ferr_o = ffe;
+	const float rps = -ffe;            // pi4cxpsk.c:574-575
+	if (dbg_stop == 4) return -100;
 
-	// ---- rotate by -ffe (pi4cxpsk.c:574-575), in registers -------------------------
-	if (ffe != 0.0f) {
-		const float rps = -ffe;
-		WSYNC();
-#pragma unroll
-		for (int r = 0; r < NSYM; r++) {
-			const int i = lane + 64 * r;
-			float s, c;
-			sincos_fast(rps * (float)i, s, c);
-			ys[r] = cmul(ys[r], make_float2(c, s));
-			if (i < blen)
-				L.y[i] = ys[r];
-		}
-		WSYNC();
-	}
-
-	// ---- carrier phase from the sync symbols (pi4cxpsk.c:415-433) ------------------
-	// lane n < tl takes sync symbol n; the reference's sequential sum becomes a tree
+	// ---- carrier phase from the (frequency-corrected) sync symbols (pi4cxpsk.c:415-433)
 	float tr = 0.f, ti = 0.f;
-	{
-		const int tl = bt.sync_tl[sq];
-		for (int n = lane; n < tl; n += 64) {
-			int ch = 0, base = 0, cum = 0;
-			for (int c = 0; c < nch - 1; c++) {
-				cum += bt.sync[sq][c].len;
-				if (n >= cum) { base = cum; ch = c + 1; }
+#pragma unroll
+	for (int c0 = 0; c0 < kMaxChunks; c0 += 4) {
+		if (c0 < nch) {
+			const int c = c0 + row;
+			if (c < nch) {
+				const int pos = bt.sync[sq][c].pos, len = bt.sync[sq][c].len;
+				for (int j = col; j < len; j += 16) {
+					float2 tt = sync_term(c, j);
+					if (ffe != 0.0f) {
+						float s, cc;
+						sincos_fast(rps * (float)(pos + j), s, cc);
+						tt = cmul(tt, make_float2(cc, s));
+					}
+					tr += tt.x;
+					ti += tt.y;
+				}
 			}
-			const int nn = n - base;
-			const float2 tt = conj_ref_mul(nbits, bt.sync[sq][ch].syms[nn], L.y[bt.sync[sq][ch].pos + nn]);
-			tr += tt.x;
-			ti += tt.y;
 		}
 	}
 	const float phr = wave_sum(tr), phi = wave_sum(ti);
-	const float pm = sqrtf(fmaf(phr, phr, phi * phi));
-	const float2 cph = make_float2(phr / pm, -(phi / pm));   // conj(phasor)
+	const float psi = atan2_fast(phi, phr);      // arg(phasor); |phasor| never matters
 	if (dbg_stop == 5) return -100;
 
 	// ---- soft symbols + soft bits (pi4cxpsk.c:442-503) ------------------------------
+	constexpr int NSYM = NPL > 16 ? 8 : 4;       // 4 x 64 >= 234, 8 x 64 >= 468
 	const float inv_dd = (float)(1 << nbits) / (2.0f * kPif);
 	const int mask = (1 << nbits) - 1;
 #pragma unroll
@@ -569,8 +582,11 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 		const int i = lane + 64 * r;
 		if (i >= blen)
 			continue;
-		const float2 yy = cmul(ys[r], cph);
-		const float sv = atan2_fast(yy.y, yy.x) * inv_dd;
+		const int j = i * sps + d;
+		const float2 x = (j >= 0 && j < in_len) ? L.x[j] : make_float2(0.f, 0.f);
+		float th = atan2_fast(x.y, x.x) + reduce_2pi(fs * (float)j);
+		th = reduce_2pi(fmaf(rps, (float)i, th) - psi);
+		const float sv = (x.x == 0.0f && x.y == 0.0f) ? 0.0f : th * inv_dd;   // cargf(0) = 0
 		if (g_ssyms)
 			g_ssyms[i] = sv;
 		const int ord = bt.ord_of_sym[i];
@@ -617,8 +633,8 @@ __device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ 
 			if (h & 0x400u)
 				v = (int8_t)(-v);
 			const int e0 = v - 127, e1 = v + 127;
-			c0[j] = v ? ((e0 * e0) >> 9) : 0;
-			c1[j] = v ? ((e1 * e1) >> 9) : 0;
+			c0[j] = v ? (__mul24(e0, e0) >> 9) : 0;
+			c1[j] = v ? (__mul24(e1, e1) >> 9) : 0;
 		}
 		bm[k] = (uint32_t)(c0[0] + c0[1]) | ((uint32_t)(c0[0] + c1[1]) << 8) |
 		        ((uint32_t)(c1[0] + c0[1]) << 16) | ((uint32_t)(c1[0] + c1[1]) << 24);
@@ -628,16 +644,19 @@ __device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ 
 // ---------------------------------------------------------------------------
 // 4 x (K=5, rate 1/2, 208 bits + flush) Viterbi, one burst per 16-lane row
 // ---------------------------------------------------------------------------
+// returns the 64-bit decision ballot of the step (bit = lane: 1 if the hi predecessor won)
 template <int PH, bool EDGE>
-__device__ __forceinline__ void acs_step(uint32_t &ae, uint32_t bmw, uint32_t sh_own, uint32_t sh_par,
-                                         bool b_is_one, bool flush, unsigned long long &ballot)
+__device__ __forceinline__ unsigned long long acs_step(uint32_t &ae, uint32_t bmw, uint32_t sh_own,
+                                                       uint32_t sh_par, unsigned long long own_is_hi,
+                                                       bool b_is_one, bool flush)
 {
 	const uint32_t par = row_xor<(8 >> PH)>(ae);
 	const uint32_t n_own = ae + ((bmw >> sh_own) & 0xffu);
 	const uint32_t n_par = par + ((bmw >> sh_par) & 0xffu);
-	uint32_t nw = n_own < n_par ? n_own : n_par;
 	// hi predecessor ((t>>1)+8) wins only when strictly better: ties keep the lower state
-	const bool dec = b_is_one ? (n_own < n_par) : (n_par < n_own);
+	const unsigned long long own_lt = __ballot(n_own < n_par);
+	const unsigned long long par_lt = __ballot(n_par < n_own);
+	uint32_t nw = n_own < n_par ? n_own : n_par;
 	if (EDGE) {
 		// unreachable states carry MAX_AE and never grow (the first 4 and the flush steps)
 		nw = nw < kMaxAe ? nw : kMaxAe;
@@ -645,21 +664,21 @@ __device__ __forceinline__ void acs_step(uint32_t &ae, uint32_t bmw, uint32_t sh
 			nw = kMaxAe;        // flush steps only take the b=0 transitions
 	}
 	ae = nw;
-	ballot = __ballot(dec);
+	return (own_lt & own_is_hi) | (par_lt & ~own_is_hi);
 }
 
 #define ACS4(EDGE, FL)                                                                             \
 	do {                                                                                           \
 		const uint4 bw = *reinterpret_cast<const uint4 *>(bmr + k);                                \
-		unsigned long long m;                                                                      \
-		acs_step<0, EDGE>(ae, bw.x, sh_own[0], sh_par[0], b1[0], FL, m);                           \
-		if (lane == kk + 0) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
-		acs_step<1, EDGE>(ae, bw.y, sh_own[1], sh_par[1], b1[1], FL, m);                           \
-		if (lane == kk + 1) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
-		acs_step<2, EDGE>(ae, bw.z, sh_own[2], sh_par[2], b1[2], FL, m);                           \
-		if (lane == kk + 2) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
-		acs_step<3, EDGE>(ae, bw.w, sh_own[3], sh_par[3], b1[3], FL, m);                           \
-		if (lane == kk + 3) { s_lo = (uint32_t)m; s_hi = (uint32_t)(m >> 32); }                    \
+		const unsigned long long m0 = acs_step<0, EDGE>(ae, bw.x, sh_own[0], sh_par[0], hi[0], b1[0], FL); \
+		const unsigned long long m1 = acs_step<1, EDGE>(ae, bw.y, sh_own[1], sh_par[1], hi[1], b1[1], FL); \
+		const unsigned long long m2 = acs_step<2, EDGE>(ae, bw.z, sh_own[2], sh_par[2], hi[2], b1[2], FL); \
+		const unsigned long long m3 = acs_step<3, EDGE>(ae, bw.w, sh_own[3], sh_par[3], hi[3], b1[3], FL); \
+		if (lane == 0) {                                                                           \
+			uint4 *sp = reinterpret_cast<uint4 *>(surv + k);                                       \
+			sp[0] = make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32)); \
+			sp[1] = make_uint4((uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)m3, (uint32_t)(m3 >> 32)); \
+		}                                                                                          \
 	} while (0)
 
 // bm: 4 rows x 212 words; surv: 212 ballots; ubits: 4 rows x 8 words (decoded bits, LSB first)
@@ -670,40 +689,26 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 	const uint32_t loc = (uint32_t)lane & 15u;
 	uint32_t sh_own[4], sh_par[4];
 	bool b1[4];
+	unsigned long long hi[4];
 #pragma unroll
 	for (int ph = 0; ph < 4; ph++) {
 		const uint32_t s = rotl4(loc, ph);
 		const uint32_t b = s >> 3;
 		b1[ph] = b != 0;
+		hi[ph] = __ballot(b1[ph]);
 		sh_own[ph] = 8u * out_k5_12(s, b);
 		sh_par[ph] = 8u * out_k5_12(s ^ 8u, b);
 	}
 	uint32_t ae = loc ? kMaxAe : 0u;
 	const uint32_t *bmr = bm + row * kSteps12;
 
-	// forward pass; lane (k & 63) keeps the ballot of step k, flushed to LDS every 64 steps
-#pragma unroll 1
-	for (int blk = 0; blk < 4; blk++) {
-		uint32_t s_lo = 0, s_hi = 0;
-		const int k0 = blk * 64;
-		const int kend = (kSteps12 - k0) < 64 ? (kSteps12 - k0) : 64;
-		int kk = 0;
-		if (blk == 0) {
-			const int k = 0;
-			ACS4(true, false);
-			kk = 4;
-		}
-		const int kmain = (blk == 3) ? kend - 4 : kend;    // last 4 steps of the block 3 are the flush
-		for (; kk < kmain; kk += 4) {
-			const int k = k0 + kk;
+	// forward pass, 4 trellis steps per iteration; lane 0 parks the four ballots in LDS
+	{
+		int k = 0;
+		ACS4(true, false);
+		for (k = 4; k < 208; k += 4)
 			ACS4(false, false);
-		}
-		if (blk == 3) {
-			const int k = k0 + kk;
-			ACS4(true, true);
-		}
-		if (lane < kend)
-			surv[k0 + lane] = (uint64_t)s_lo | ((uint64_t)s_hi << 32);
+		ACS4(true, true);      // k = 208: flush
 	}
 	// 212 = 53 * 4 steps: the layout is back to identity, state 0 sits in lane 0 of the row
 	final_ae = ae;
@@ -711,33 +716,33 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 
 	// traceback, one lane per row, walking LOCATIONS: the state that ends step k in location L
 	// came from location (L with bit (3 - k%4) := decision), because the butterfly is in place.
-	// Its newest input bit (the decoded bit of step k) is bit 0 of the state = bit (k+1)%4-th
-	// rotation of L.  (osmo_conv_decode_get_output, end state 0 after flush)
+	// The decision of step k is the input bit of step k-4 (the oldest bit of the predecessor
+	// state), so the decoded bits are the decisions met on the way: u[k-4] = d_k, k = 211..4.
+	// (osmo_conv_decode_get_output, end state 0 after flush)
 	if (loc == 0) {
 		const uint16_t *s16 = reinterpret_cast<const uint16_t *>(surv) + row;
-		uint32_t L = 0;   // state 0 after step 211 sits in location 0
-		// flush steps 211..208 (phases 3,2,1,0): no output
-#pragma unroll
-		for (int k = kSteps12 - 1; k >= 208; k--) {
-			const int pb = 3 - (k & 3);
-			const uint32_t dbit = ((uint32_t)s16[4 * k] >> L) & 1u;
-			L = (L & ~(1u << pb)) | (dbit << pb);
-		}
-		for (int wi = 6; wi >= 0; wi--) {
-			uint32_t wv = 0;
-			const int top = (wi == 6) ? 15 : 31;
-#pragma unroll 4
-			for (int bit = top; bit >= 0; bit--) {
-				const int k = wi * 32 + bit;          // k % 4 == bit % 4
-				const int pb = 3 - (bit & 3);
-				// state after step k = rotl^{(k+1)%4}(L); its bit 0 is bit (4 - (k+1)%4) % 4 of L
-				const int ob_pos = (4 - ((bit + 1) & 3)) & 3;
-				const uint32_t dbit = ((uint32_t)s16[4 * k] >> L) & 1u;
-				wv |= ((L >> ob_pos) & 1u) << bit;
-				L = (L & ~(1u << pb)) | (dbit << pb);
+		uint32_t L = 0;    // state 0 after step 211 sits in location 0
+		uint32_t ub = 0;
+#define TB_STEP(W, PB)                                           \
+		do {                                                     \
+			const uint32_t x = ((uint32_t)(W) << (PB)) >> L;     \
+			L = (L & ~(1u << (PB))) | (x & (1u << (PB)));        \
+			ub = (ub << 1) | ((x >> (PB)) & 1u);                 \
+		} while (0)
+		for (int g = 52; g >= 1; g--) {
+			const int k = 4 * g;
+			const uint32_t w0 = s16[4 * (k + 0)], w1 = s16[4 * (k + 1)];
+			const uint32_t w2 = s16[4 * (k + 2)], w3 = s16[4 * (k + 3)];
+			TB_STEP(w3, 0);     // step k+3: phase 3 -> partner bit 0
+			TB_STEP(w2, 1);
+			TB_STEP(w1, 2);
+			TB_STEP(w0, 3);
+			if (((g - 1) & 7) == 0) {
+				ubits[row * 8 + ((g - 1) >> 3)] = ub;
+				ub = 0;
 			}
-			ubits[row * 8 + wi] = wv;
 		}
+#undef TB_STEP
 	}
 	WSYNC();
 
