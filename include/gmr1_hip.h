@@ -19,14 +19,12 @@
  * Reference interfaces replaced (osmocom/osmo-gmr, paths relative to the
  * reference tree):
  *   gmr1_hip_demod_batch*        -> gmr1_pi4cxpsk_demod   include/osmocom/gmr1/sdr/pi4cxpsk.h:101-105
- *   gmr1_hip_detect_batch*       -> gmr1_pi4cxpsk_detect  include/osmocom/gmr1/sdr/pi4cxpsk.h:107-110
  *   gmr1_hip_bcch_decode_batch*  -> gmr1_bcch_decode      include/osmocom/gmr1/l1/bcch.h:38
  *   gmr1_hip_ccch_decode_batch*  -> gmr1_ccch_decode      include/osmocom/gmr1/l1/ccch.h:38
- *   gmr1_hip_facch3_decode_batch*-> gmr1_facch3_decode    include/osmocom/gmr1/l1/facch3.h:39-40
- *   gmr1_hip_tch3_decode_batch*  -> gmr1_tch3_decode      include/osmocom/gmr1/l1/tch3.h:40-42
  *   gmr1_hip_rx_bcch_ccch_batch* -> rx_bcch / rx_ccch     src/gmr1_rx.c:746-850 (demod + decode of one burst)
  *   gmr1_hip_fcch_rough_batch*   -> gmr1_fcch_rough       include/osmocom/gmr1/sdr/fcch.h:47-49
- *   gmr1_hip_fcch_fine_batch*    -> gmr1_fcch_fine + gmr1_fcch_snr  include/osmocom/gmr1/sdr/fcch.h:55-61
+ *   gmr1_hip_fcch_fine_batch*    -> gmr1_fcch_fine        include/osmocom/gmr1/sdr/fcch.h:55-57
+ *   gmr1_hip_fcch_snr_batch*     -> gmr1_fcch_snr         include/osmocom/gmr1/sdr/fcch.h:59-61
  */
 #ifndef GMR1_HIP_H
 #define GMR1_HIP_H
@@ -110,6 +108,31 @@ int gmr1_hip_rx_bcch_ccch_batch(int n, int sps,
                                 uint8_t *l2, int32_t *crc, int32_t *conv,
                                 float *toa, float *freq_err,
                                 int8_t *ebits, float *ssyms, int32_t *rv);
+
+/* ---- FCCH acquisition ------------------------------------------------------
+ * fcch_type: 0 gmr1_fcch_burst, 1 gmr1_fcch3_lband_burst, 2 gmr1_fcch3_sband_burst.
+ * rough: n search windows of `len` samples each -> toa[i] (samples), rv[i] (0 / -errno).
+ * fine / snr: n bursts of exactly burst_len*sps samples each.
+ * The rough sweep keeps a grow-only device scratch per GPU (decimated streams +
+ * partials, about len/sps*8 bytes per stream). */
+int gmr1_hip_fcch_rough_batch_dev(void *stream, int fcch_type, int n, int sps, int len,
+                                  const float *iq, const uint64_t *offset, const float *freq_shift,
+                                  int32_t *toa, int32_t *rv);
+int gmr1_hip_fcch_rough_batch(int fcch_type, int n, int sps, int len,
+                              const float *iq, uint64_t iq_len, const uint64_t *offset,
+                              const float *freq_shift, int32_t *toa, int32_t *rv);
+int gmr1_hip_fcch_fine_batch_dev(void *stream, int fcch_type, int n, int sps,
+                                 const float *iq, const uint64_t *offset, const float *freq_shift,
+                                 int32_t *toa, float *freq_error);
+int gmr1_hip_fcch_fine_batch(int fcch_type, int n, int sps,
+                             const float *iq, uint64_t iq_len, const uint64_t *offset,
+                             const float *freq_shift, int32_t *toa, float *freq_error);
+int gmr1_hip_fcch_snr_batch_dev(void *stream, int fcch_type, int n, int sps,
+                                const float *iq, const uint64_t *offset, const float *freq_shift,
+                                float *snr);
+int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
+                            const float *iq, uint64_t iq_len, const uint64_t *offset,
+                            const float *freq_shift, float *snr);
 
 #ifdef __cplusplus
 }

@@ -24,12 +24,17 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_bcch_decode_batch", "gmr1_hip_ccch_decode_batch",
     "gmr1_hip_rx_bcch_ccch_batch_dev", "gmr1_hip_rx_bcch_ccch_batch",
     "gmr1_pi4cxpsk_demod", "gmr1_bcch_decode", "gmr1_ccch_decode",
+    "gmr1_hip_fcch_rough_batch_dev", "gmr1_hip_fcch_rough_batch",
+    "gmr1_hip_fcch_fine_batch_dev", "gmr1_hip_fcch_fine_batch",
+    "gmr1_hip_fcch_snr_batch_dev", "gmr1_hip_fcch_snr_batch",
+    "gmr1_fcch_rough", "gmr1_fcch_fine", "gmr1_fcch_snr",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
     "gmr1_bcch_burst", "gmr1_dc2_burst", "gmr1_dc6_burst", "gmr1_dc12_burst",
     "gmr1_nt3_speech_burst", "gmr1_nt3_facch_burst", "gmr1_nt6_burst", "gmr1_nt9_burst",
     "gmr1_rach_burst", "gmr1_sdcch_burst",
+    "gmr1_fcch_burst", "gmr1_fcch3_lband_burst", "gmr1_fcch3_sband_burst",
 ]
 
 
@@ -238,3 +243,113 @@ def rx_bcch_ccch_batch_dev(stream, n, sps, iq, offset, kind, freq_shift, l2, crc
     rc = f(vp(stream), C.c_int(n), C.c_int(sps), vp(iq), vp(offset), vp(kind), vp(freq_shift),
            vp(l2), vp(crc), vp(conv), vp(toa), vp(freq_err), vp(ebits), vp(ssyms), vp(rv))
     _check(rc, "gmr1_hip_rx_bcch_ccch_batch_dev")
+
+
+# ---------------------------------------------------------------------------
+# FCCH acquisition
+# ---------------------------------------------------------------------------
+FCCH_TYPES = ["fcch", "fcch3_lband", "fcch3_sband"]
+FCCH_LEN = [117, 468, 468]
+
+
+class FcchBurst(C.Structure):
+    """struct gmr1_fcch_burst (include/osmocom/gmr1/sdr/fcch.h)."""
+    _fields_ = [("freq", C.c_float), ("len", C.c_int)]
+
+
+def _fcch_id(t):
+    return FCCH_TYPES.index(t) if isinstance(t, str) else int(t)
+
+
+def fcch_rough_batch(iq, offset, length, sps=4, freq_shift=None, fcch_type="fcch"):
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    toa = np.zeros(n, np.int32)
+    rv = np.zeros(n, np.int32)
+    rc = load().gmr1_hip_fcch_rough_batch(
+        C.c_int(_fcch_id(fcch_type)), C.c_int(n), C.c_int(sps), C.c_int(length), p_iq, C.c_uint64(iq.size),
+        p_off, fs_p, toa.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_fcch_rough_batch")
+    return toa, rv
+
+
+def fcch_fine_batch(iq, offset, sps=4, freq_shift=None, fcch_type="fcch"):
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    toa = np.zeros(n, np.int32)
+    fe = np.zeros(n, np.float32)
+    rc = load().gmr1_hip_fcch_fine_batch(
+        C.c_int(_fcch_id(fcch_type)), C.c_int(n), C.c_int(sps), p_iq, C.c_uint64(iq.size), p_off, fs_p,
+        toa.ctypes.data_as(C.c_void_p), fe.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_fcch_fine_batch")
+    return toa, fe
+
+
+def fcch_snr_batch(iq, offset, sps=4, freq_shift=None, fcch_type="fcch"):
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    snr = np.zeros(n, np.float32)
+    rc = load().gmr1_hip_fcch_snr_batch(
+        C.c_int(_fcch_id(fcch_type)), C.c_int(n), C.c_int(sps), p_iq, C.c_uint64(iq.size), p_off, fs_p,
+        snr.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_fcch_snr_batch")
+    return snr
+
+
+def _fcch_struct(fcch_type):
+    name = {"fcch": "gmr1_fcch_burst", "fcch3_lband": "gmr1_fcch3_lband_burst",
+            "fcch3_sband": "gmr1_fcch3_sband_burst"}[fcch_type]
+    return FcchBurst.in_dll(load(), name)
+
+
+def fcch_rough(iq, sps=4, freq_shift=0.0, fcch_type="fcch"):
+    """gmr1_fcch_rough(&gmr1_fcch_burst, cxvec, sps, freq_shift, &toa): the reference's own call."""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    toa = C.c_int()
+    f = load().gmr1_fcch_rough
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch_struct(fcch_type)), C.byref(vec), C.c_int(sps), C.c_float(freq_shift), C.byref(toa))
+    return rv, toa.value
+
+
+def fcch_fine(iq, sps=4, freq_shift=0.0, fcch_type="fcch"):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    toa, fe = C.c_int(), C.c_float()
+    f = load().gmr1_fcch_fine
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch_struct(fcch_type)), C.byref(vec), C.c_int(sps), C.c_float(freq_shift),
+           C.byref(toa), C.byref(fe))
+    return rv, toa.value, fe.value
+
+
+def fcch_snr(iq, sps=4, freq_shift=0.0, fcch_type="fcch"):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    snr = C.c_float()
+    f = load().gmr1_fcch_snr
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch_struct(fcch_type)), C.byref(vec), C.c_int(sps), C.c_float(freq_shift), C.byref(snr))
+    return rv, snr.value
+
+
+def fcch_rough_batch_dev(stream, fcch_type, n, sps, length, iq, offset, freq_shift, toa, rv):
+    f = load().gmr1_hip_fcch_rough_batch_dev
+    f.restype = C.c_int
+    vp = lambda x: C.c_void_p(x) if x else None
+    rc = f(vp(stream), C.c_int(_fcch_id(fcch_type)), C.c_int(n), C.c_int(sps), C.c_int(length),
+           vp(iq), vp(offset), vp(freq_shift), vp(toa), vp(rv))
+    _check(rc, "gmr1_hip_fcch_rough_batch_dev")

@@ -15,13 +15,20 @@
 #include <osmocom/gmr1/l1/bcch.h>
 #include <osmocom/gmr1/l1/ccch.h>
 
-#include "gmr1_dev.h"
-#include "host_tables.h"
+#include "capi_common.h"
 
 namespace gmr1 {
-namespace {
 
+namespace {
 thread_local char t_err[256] = "";
+std::mutex g_mu;
+constexpr int kMaxDevices = 16;
+DevState g_dev[kMaxDevices];
+bool g_host_types_ready = false;
+FcchTables g_fcch_tables;
+}  // namespace
+
+DevBurst g_host_types[kNumTypes];
 
 int fail(int code, const char *fmt, ...)
 {
@@ -32,24 +39,7 @@ int fail(int code, const char *fmt, ...)
 	return code;
 }
 
-#define HIP_TRY(expr)                                                                  \
-	do {                                                                               \
-		hipError_t e_ = (expr);                                                        \
-		if (e_ != hipSuccess)                                                          \
-			return fail(e_ == hipErrorNoDevice ? -ENODEV : -EIO, "%s: %s", #expr,      \
-			            hipGetErrorString(e_));                                        \
-	} while (0)
-
-constexpr int kMaxDevices = 16;
-
-struct DevState {
-	bool ready = false;             // burst descriptors uploaded to this device's __constant__ memory
-};
-
-std::mutex g_mu;
-DevState g_dev[kMaxDevices];
-DevBurst g_host_types[kNumTypes];
-bool g_host_types_ready = false;
+const char *last_error() { return t_err; }
 
 int host_types()
 {
@@ -65,11 +55,11 @@ int host_types()
 		if (rv)
 			return fail(rv, "built-in burst table %d is inconsistent", i);
 	}
+	fcch_tables_init(&g_fcch_tables);
 	g_host_types_ready = true;
 	return 0;
 }
 
-// per-device state for the CURRENT device
 int dev_state(DevState **out)
 {
 	int count = 0;
@@ -87,6 +77,7 @@ int dev_state(DevState **out)
 		if (rv)
 			return rv;
 		HIP_TRY(upload_types(g_host_types, 0, kNumTypes, nullptr));
+		HIP_TRY(upload_fcch_tables(&g_fcch_tables, nullptr));
 		HIP_TRY(hipStreamSynchronize(nullptr));
 		s.ready = true;
 	}
@@ -94,17 +85,28 @@ int dev_state(DevState **out)
 	return 0;
 }
 
-// RAII device buffer for the host-pointer variants
-struct DBuf {
-	void *p = nullptr;
-	~DBuf() { if (p) (void)hipFree(p); }
-	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
-	template <typename T> T *as() { return static_cast<T *>(p); }
-};
+int dev_workspace(DevState *s, size_t bytes, void **out)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	if (s->ws_bytes < bytes) {
+		if (s->ws) {
+			HIP_TRY(hipDeviceSynchronize());
+			HIP_TRY(hipFree(s->ws));
+			s->ws = nullptr;
+			s->ws_bytes = 0;
+		}
+		const size_t want = bytes + bytes / 4;
+		HIP_TRY(hipMalloc(&s->ws, want));
+		s->ws_bytes = want;
+	}
+	*out = s->ws;
+	return 0;
+}
 
+namespace {
 int window_len(int burst_len, int sps, int win) { return burst_len * sps + win; }
-
 }  // namespace
+
 }  // namespace gmr1
 
 using namespace gmr1;
@@ -115,7 +117,7 @@ extern "C" {
 // library / device
 // ---------------------------------------------------------------------------
 const char *gmr1_hip_version(void) { return "gmr1-hip 0.1 (gfx950)"; }
-const char *gmr1_hip_last_error(void) { return t_err; }
+const char *gmr1_hip_last_error(void) { return last_error(); }
 
 int gmr1_hip_init(int device)
 {

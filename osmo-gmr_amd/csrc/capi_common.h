@@ -1,0 +1,49 @@
+// capi_common.h -- helpers shared by the C-ABI translation units (host only).
+#pragma once
+
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include "gmr1_dev.h"
+#include "host_tables.h"
+
+namespace gmr1 {
+
+int fail(int code, const char *fmt, ...);
+const char *last_error();
+
+#define HIP_TRY(expr)                                                                  \
+	do {                                                                               \
+		hipError_t e_ = (expr);                                                        \
+		if (e_ != hipSuccess)                                                          \
+			return ::gmr1::fail(e_ == hipErrorNoDevice ? -ENODEV : -EIO, "%s: %s", #expr, \
+			                    hipGetErrorString(e_));                                \
+	} while (0)
+
+struct DevState {
+	bool ready = false;       // constant tables uploaded to this device
+	void *ws = nullptr;       // grow-only scratch for kernels that need workspace
+	size_t ws_bytes = 0;
+};
+
+extern DevBurst g_host_types[kNumTypes];
+int host_types();
+// state of the CURRENT device; uploads the constant tables on first use
+int dev_state(DevState **out);
+// grow-only device scratch of the current device (not for concurrent streams)
+int dev_workspace(DevState *s, size_t bytes, void **out);
+
+// RAII device buffer for the host-pointer variants
+struct DBuf {
+	void *p = nullptr;
+	~DBuf() { if (p) (void)hipFree(p); }
+	hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+	template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace gmr1

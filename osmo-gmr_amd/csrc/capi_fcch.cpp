@@ -1,0 +1,262 @@
+// capi_fcch.cpp -- C-ABI entry points of the FCCH acquisition kernels.
+#include "capi_common.h"
+
+using namespace gmr1;
+
+namespace {
+
+int fcch_tab_of(const struct gmr1_fcch_burst *bt)
+{
+	for (int i = 0; i < kFcchTabs; i++)
+		if (bt == kFcchBuiltin[i])
+			return i;
+	// a caller-provided descriptor with the parameters of a built-in one is accepted too
+	for (int i = 0; i < kFcchTabs; i++)
+		if (bt && bt->len == kFcchBuiltin[i]->len && bt->freq == kFcchBuiltin[i]->freq)
+			return i;
+	return -1;
+}
+
+int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq, const uint64_t *offset,
+              const float *freq_shift, int32_t *toa, int32_t *rv, float *energy, size_t energy_stride)
+{
+	if (tab < 0 || tab >= kFcchTabs)
+		return fail(-EINVAL, "fcch: unknown burst type");
+	if (n < 0 || !iq || !offset || (!toa && !energy))
+		return fail(-EINVAL, "fcch_rough: NULL argument");
+	if (sps < 1 || sps > 16)
+		return fail(-EINVAL, "fcch_rough: sps=%d out of range", sps);
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n == 0) return 0;
+	const int ntaps = kFcchBuiltin[tab]->len;
+	const int ndec = len / sps;
+	const int nlags = ndec - ntaps + 1;
+	if (nlags < 5)
+		return fail(-EINVAL, "fcch_rough: window of %d samples is too short", len);
+	FcchRoughArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.n = n; a.len = len; a.sps = sps; a.tab = tab;
+	a.iq = reinterpret_cast<const float2 *>(iq);
+	a.offset = offset; a.freq_shift = freq_shift;
+	a.n_stat_tiles = fcch_stat_tiles(len);
+	a.n_lag_tiles = fcch_lag_tiles(nlags);
+	a.dec_stride = ((size_t)ndec + 15) & ~(size_t)15;
+	const size_t b_dec = (size_t)n * a.dec_stride * 8;
+	const size_t b_par = (((size_t)n * a.n_stat_tiles * 16) + 255) & ~(size_t)255;
+	const size_t b_best = (((size_t)n * a.n_lag_tiles * 32) + 255) & ~(size_t)255;
+	void *ws;
+	r = dev_workspace(s, b_dec + b_par + b_best, &ws);
+	if (r) return r;
+	a.dec = static_cast<float2 *>(ws);
+	a.partial = reinterpret_cast<float *>(static_cast<char *>(ws) + b_dec);
+	a.tile_best = reinterpret_cast<float *>(static_cast<char *>(ws) + b_dec + b_par);
+	a.energy = energy; a.energy_stride = energy_stride;
+	a.toa = toa; a.rv = rv;
+	HIP_TRY(launch_fcch_rough(a, ntaps, st));
+	return 0;
+}
+
+int fine_dev(hipStream_t st, int tab, int mode, int n, int sps, const float *iq, const uint64_t *offset,
+             const float *freq_shift, int32_t *toa, float *freq_err, float *snr)
+{
+	if (tab < 0 || tab >= kFcchTabs)
+		return fail(-EINVAL, "fcch: unknown burst type");
+	if (n < 0 || !iq || !offset || (mode == 0 && (!toa || !freq_err)) || (mode == 1 && !snr))
+		return fail(-EINVAL, "fcch_fine/snr: NULL argument");
+	if (sps < 1 || sps > 16)
+		return fail(-EINVAL, "fcch_fine/snr: sps=%d out of range", sps);
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	FcchFineArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.n = n; a.sps = sps; a.tab = tab; a.mode = mode;
+	a.iq = reinterpret_cast<const float2 *>(iq);
+	a.offset = offset; a.freq_shift = freq_shift;
+	a.toa = toa; a.freq_err = freq_err; a.snr = snr;
+	HIP_TRY(launch_fcch_fine(a, kFcchBuiltin[tab]->len, st));
+	return 0;
+}
+
+// shared host staging: copies iq + offsets (+ freq_shift) in, runs `body`, copies results out
+struct Staged {
+	DBuf iq, off, fs;
+	int stage(int n, const float *h_iq, uint64_t iq_len, const uint64_t *h_off, const float *h_fs,
+	          uint64_t need)
+	{
+		for (int i = 0; i < n; i++)
+			if (h_off[i] + need > iq_len)
+				return fail(-EINVAL, "window %d runs past the end of iq", i);
+		HIP_TRY(iq.alloc(iq_len * 8));
+		HIP_TRY(off.alloc((size_t)n * 8));
+		HIP_TRY(hipMemcpy(iq.p, h_iq, iq_len * 8, hipMemcpyHostToDevice));
+		HIP_TRY(hipMemcpy(off.p, h_off, (size_t)n * 8, hipMemcpyHostToDevice));
+		if (h_fs) {
+			HIP_TRY(fs.alloc((size_t)n * 4));
+			HIP_TRY(hipMemcpy(fs.p, h_fs, (size_t)n * 4, hipMemcpyHostToDevice));
+		}
+		return 0;
+	}
+};
+
+}  // namespace
+
+extern "C" {
+
+int gmr1_hip_fcch_rough_batch_dev(void *stream, int fcch_type, int n, int sps, int len,
+                                  const float *iq, const uint64_t *offset, const float *freq_shift,
+                                  int32_t *toa, int32_t *rv)
+{
+	return rough_dev((hipStream_t)stream, fcch_type, n, sps, len, iq, offset, freq_shift, toa, rv, nullptr, 0);
+}
+
+int gmr1_hip_fcch_rough_batch(int fcch_type, int n, int sps, int len,
+                              const float *iq, uint64_t iq_len, const uint64_t *offset,
+                              const float *freq_shift, int32_t *toa, int32_t *rv)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0) return 0;
+	if (!iq || !offset || !toa)
+		return fail(-EINVAL, "fcch_rough: NULL argument");
+	Staged st;
+	r = st.stage(n, iq, iq_len, offset, freq_shift, (uint64_t)len);
+	if (r) return r;
+	DBuf d_toa, d_rv;
+	HIP_TRY(d_toa.alloc((size_t)n * 4));
+	HIP_TRY(d_rv.alloc((size_t)n * 4));
+	r = rough_dev(nullptr, fcch_type, n, sps, len, st.iq.as<float>(), st.off.as<uint64_t>(),
+	              freq_shift ? st.fs.as<float>() : nullptr, d_toa.as<int32_t>(), d_rv.as<int32_t>(), nullptr, 0);
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(toa, d_toa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (rv) HIP_TRY(hipMemcpy(rv, d_rv.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int gmr1_hip_fcch_fine_batch_dev(void *stream, int fcch_type, int n, int sps,
+                                 const float *iq, const uint64_t *offset, const float *freq_shift,
+                                 int32_t *toa, float *freq_error)
+{
+	return fine_dev((hipStream_t)stream, fcch_type, 0, n, sps, iq, offset, freq_shift, toa, freq_error, nullptr);
+}
+
+int gmr1_hip_fcch_snr_batch_dev(void *stream, int fcch_type, int n, int sps,
+                                const float *iq, const uint64_t *offset, const float *freq_shift,
+                                float *snr)
+{
+	return fine_dev((hipStream_t)stream, fcch_type, 1, n, sps, iq, offset, freq_shift, nullptr, nullptr, snr);
+}
+
+int gmr1_hip_fcch_fine_batch(int fcch_type, int n, int sps,
+                             const float *iq, uint64_t iq_len, const uint64_t *offset,
+                             const float *freq_shift, int32_t *toa, float *freq_error)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0) return 0;
+	if (fcch_type < 0 || fcch_type >= kFcchTabs || !iq || !offset || !toa || !freq_error)
+		return fail(-EINVAL, "fcch_fine: bad argument");
+	Staged st;
+	r = st.stage(n, iq, iq_len, offset, freq_shift, (uint64_t)kFcchBuiltin[fcch_type]->len * sps);
+	if (r) return r;
+	DBuf d_toa, d_fe;
+	HIP_TRY(d_toa.alloc((size_t)n * 4));
+	HIP_TRY(d_fe.alloc((size_t)n * 4));
+	r = fine_dev(nullptr, fcch_type, 0, n, sps, st.iq.as<float>(), st.off.as<uint64_t>(),
+	             freq_shift ? st.fs.as<float>() : nullptr, d_toa.as<int32_t>(), d_fe.as<float>(), nullptr);
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(toa, d_toa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(freq_error, d_fe.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
+                            const float *iq, uint64_t iq_len, const uint64_t *offset,
+                            const float *freq_shift, float *snr)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0) return 0;
+	if (fcch_type < 0 || fcch_type >= kFcchTabs || !iq || !offset || !snr)
+		return fail(-EINVAL, "fcch_snr: bad argument");
+	Staged st;
+	r = st.stage(n, iq, iq_len, offset, freq_shift, (uint64_t)kFcchBuiltin[fcch_type]->len * sps);
+	if (r) return r;
+	DBuf d_snr;
+	HIP_TRY(d_snr.alloc((size_t)n * 4));
+	r = fine_dev(nullptr, fcch_type, 1, n, sps, st.iq.as<float>(), st.off.as<uint64_t>(),
+	             freq_shift ? st.fs.as<float>() : nullptr, nullptr, nullptr, d_snr.as<float>());
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(snr, d_snr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// ---- reference-compatible single calls (fcch.h:47-61) ---------------------------------------
+int gmr1_fcch_rough(const struct gmr1_fcch_burst *burst_type,
+                    struct osmo_cxvec *search_win_in, int sps, float freq_shift, int *toa)
+{
+	if (!burst_type || !search_win_in || !search_win_in->data || !toa)
+		return fail(-EINVAL, "gmr1_fcch_rough: NULL argument");
+	const int tab = fcch_tab_of(burst_type);
+	if (tab < 0)
+		return fail(-EINVAL, "gmr1_fcch_rough: unknown FCCH burst type");
+	const uint64_t off = 0;
+	int32_t t = 0, rv = 0;
+	int r = gmr1_hip_fcch_rough_batch(tab, 1, sps, search_win_in->len,
+	                                  reinterpret_cast<const float *>(search_win_in->data),
+	                                  (uint64_t)search_win_in->len, &off, &freq_shift, &t, &rv);
+	if (r) return r;
+	if (rv) return rv;
+	*toa = t;
+	return 0;
+}
+
+int gmr1_fcch_fine(const struct gmr1_fcch_burst *burst_type,
+                   struct osmo_cxvec *burst_in, int sps, float freq_shift, int *toa, float *freq_error)
+{
+	if (!burst_type || !burst_in || !burst_in->data || !toa || !freq_error)
+		return fail(-EINVAL, "gmr1_fcch_fine: NULL argument");
+	const int tab = fcch_tab_of(burst_type);
+	if (tab < 0)
+		return fail(-EINVAL, "gmr1_fcch_fine: unknown FCCH burst type");
+	if (sps < 1 || burst_in->len / sps != burst_type->len)      // fcch.c:546-551
+		return fail(-EINVAL, "gmr1_fcch_fine: burst must be len*sps samples");
+	const uint64_t off = 0;
+	int32_t t = 0;
+	float fe = 0.f;
+	int r = gmr1_hip_fcch_fine_batch(tab, 1, sps, reinterpret_cast<const float *>(burst_in->data),
+	                                 (uint64_t)burst_in->len, &off, &freq_shift, &t, &fe);
+	if (r) return r;
+	*toa = t;
+	*freq_error = fe;
+	return 0;
+}
+
+int gmr1_fcch_snr(const struct gmr1_fcch_burst *burst_type,
+                  struct osmo_cxvec *burst_in, int sps, float freq_shift, float *snr)
+{
+	if (!burst_type || !burst_in || !burst_in->data || !snr)
+		return fail(-EINVAL, "gmr1_fcch_snr: NULL argument");
+	const int tab = fcch_tab_of(burst_type);
+	if (tab < 0)
+		return fail(-EINVAL, "gmr1_fcch_snr: unknown FCCH burst type");
+	if (sps < 1 || burst_in->len / sps != burst_type->len)      // fcch.c:671-675
+		return fail(-EINVAL, "gmr1_fcch_snr: burst must be len*sps samples");
+	const uint64_t off = 0;
+	float v = 0.f;
+	int r = gmr1_hip_fcch_snr_batch(tab, 1, sps, reinterpret_cast<const float *>(burst_in->data),
+	                                (uint64_t)burst_in->len, &off, &freq_shift, &v);
+	if (r) return r;
+	*snr = v;
+	return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,507 @@
+// fcch_kernels.hip -- FCCH acquisition kernels for gfx950 (MI355X).
+//
+//   k_fcch_stats  : one pass over the raw search window: complex sum and sum |x|^2 partials
+//                   per tile, and the sps-decimated samples written compactly
+//                   (osmo_cxvec_sig_normalize with decimation, reference src/sdr/fcch.c:230,366)
+//   k_fcch_corr   : normalise + frequency-shift on the way into LDS, 117-tap real dual-chirp
+//                   correlation with 8 lags per lane register blocking (sliding window in
+//                   registers, chirp taps from the scalar cache), energies, best 5-sample
+//                   energy window of the tile (fcch.c:233-238, osmo_cxvec_peak_energy_find)
+//   k_fcch_pick   : per stream: best window over tiles, energy centroid, toa (fcch.c:241)
+//   k_fcch_fine   : one wavefront per burst: normalise, mix with up / down chirp (or the dual
+//                   chirp for the SNR estimate), direct N-point DFT, 5-bin centroid / 6 largest
+//                   bins (fcch.c:512-628 gmr1_fcch_fine, fcch.c:643-708 gmr1_fcch_snr)
+//
+// HBM traffic per 1-s stream (93 600 samples): 748.8 kB read once, 187 kB decimated written and
+// read back, a few kB of partials: 1.5x the algorithmic bytes.  The correlation is 10.9 MFLOP per
+// stream (14.6 flop/B), so the sweep sits near the HBM / fp32-VALU ridge; no MFMA (real x complex
+// FIR, "do not reshape into GEMMs").
+#include "gmr1_dev.h"
+
+namespace gmr1 {
+
+static constexpr float kPif = 3.14159265358979323846f;
+
+__constant__ FcchTables c_fcch;
+
+hipError_t upload_fcch_tables(const FcchTables *host, hipStream_t stream)
+{
+	return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fcch), host, sizeof(FcchTables), 0, hipMemcpyHostToDevice, stream);
+}
+
+// ---------------------------------------------------------------------------
+// helpers (same forms as rx_kernels.hip)
+// ---------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dppf(float v)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum(float v)
+{
+	v += dppf<0xB1>(v);                 // xor 1
+	v += dppf<0x4E>(v);                 // xor 2
+	v += dppf<0x1B>(dppf<0x141>(v));    // xor 4
+	v += dppf<0x128>(v);                // xor 8
+	return v;
+}
+__device__ __forceinline__ float lane_val(float v, int l)
+{
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+	v = row_sum(v);
+	return (lane_val(v, 0) + lane_val(v, 16)) + (lane_val(v, 32) + lane_val(v, 48));
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		v += __shfl_xor(v, o);
+	return v;
+}
+__device__ __forceinline__ void sincos_fast(float x, float &s, float &c)
+{
+	const float k = rintf(x * 0.636619772367581343f);
+	float r = fmaf(-k, 1.57079637050628662109375f, x);
+	r = fmaf(-k, -4.37113900018624283e-8f, r);
+	const float z = r * r;
+	float sp = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+	sp = fmaf(sp, z, -1.6666654611e-1f);
+	sp = fmaf(sp * z, r, r);
+	float cp = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+	cp = fmaf(cp, z, 4.166664568298827e-2f);
+	cp = fmaf(cp * z, z, fmaf(-0.5f, z, 1.0f));
+	const int q = (int)k;
+	const float ss = (q & 1) ? cp : sp;
+	const float cc = (q & 1) ? sp : cp;
+	s = (q & 2) ? -ss : ss;
+	c = ((q + 1) & 2) ? -cc : cc;
+}
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+	return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// ---------------------------------------------------------------------------
+// pass 1: statistics + decimation
+//   grid (tiles, streams), 256 threads; tile = kStatSpan raw samples
+// ---------------------------------------------------------------------------
+static constexpr int kStatSpan = 8192;
+
+__global__ __launch_bounds__(256) void k_fcch_stats(FcchRoughArgs a)
+{
+	const int s = blockIdx.y, tile = blockIdx.x;
+	const float2 *__restrict__ in = a.iq + a.offset[s];
+	float2 *__restrict__ dec = a.dec + (size_t)s * a.dec_stride;
+	const int begin = tile * kStatSpan;
+	const int end = min(begin + kStatSpan, a.len);
+	const int ndec = a.len / a.sps;
+	float sr = 0.f, si = 0.f, sq = 0.f;
+	for (int i = begin + (int)threadIdx.x; i < end; i += 256) {
+		const float2 v = in[i];
+		sr += v.x;
+		si += v.y;
+		sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
+		if (a.sps == 4) {
+			if ((i & 3) == 0 && (i >> 2) < ndec)
+				dec[i >> 2] = v;
+		} else if (i % a.sps == 0 && i / a.sps < ndec) {
+			dec[i / a.sps] = v;
+		}
+	}
+	__shared__ float red[3][4];
+	sr = wave_sum(sr); si = wave_sum(si); sq = wave_sum(sq);
+	const int wv = threadIdx.x >> 6;
+	if ((threadIdx.x & 63) == 0) { red[0][wv] = sr; red[1][wv] = si; red[2][wv] = sq; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		float *p = a.partial + ((size_t)s * a.n_stat_tiles + tile) * 4;
+		p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+		p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+		p[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+		p[3] = 0.f;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// pass 2: correlation, energies, best 5-window per tile
+//   grid (lag tiles, streams), 256 threads, 8 lags per thread
+// ---------------------------------------------------------------------------
+static constexpr int kLagsPerThread = 8;
+static constexpr int kTileLags = 256 * kLagsPerThread;          // 2048
+static constexpr int kTileStep = kTileLags - 4;                 // windows of 5 overlap the next tile by 4
+static constexpr int kMaxTaps = 480;
+
+// padded LDS index: one spare slot per 8 samples makes the 8-sample lane stride conflict-free
+__host__ __device__ __forceinline__ constexpr int pad8(int i) { return i + (i >> 3); }
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_fcch_corr(FcchRoughArgs a)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float2 *xs = reinterpret_cast<float2 *>(lds_raw);                    // pad8(kTileLags + NT + 8) samples
+	float *en = reinterpret_cast<float *>(xs + pad8(kTileLags + NT + 8) + 1);   // kTileLags energies
+	__shared__ float s_stat[4];
+	__shared__ float s_best[4];
+	__shared__ int s_bidx[4];
+
+	const int s = blockIdx.y, tile = blockIdx.x;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int ndec = a.len / a.sps;
+	const int nlags = ndec - NT + 1;
+	const int m0 = tile * kTileStep;
+	const float2 *__restrict__ dec = a.dec + (size_t)s * a.dec_stride;
+
+	// ---- stream statistics from the pass-1 partials (every block redoes this tiny reduction)
+	if (wv == 0) {
+		double dr = 0.0, di = 0.0, dq = 0.0;
+		for (int t = lane; t < a.n_stat_tiles; t += 64) {
+			const float *p = a.partial + ((size_t)s * a.n_stat_tiles + t) * 4;
+			dr += p[0]; di += p[1]; dq += p[2];
+		}
+		dr = wave_sum_d(dr); di = wave_sum_d(di); dq = wave_sum_d(dq);
+		if (lane == 0) {
+			const double n = (double)a.len;
+			const double ar = dr / n, ai = di / n;
+			// sigma^2 = mean |x - avg|^2 = mean |x|^2 - |avg|^2
+			double var = dq / n - (ar * ar + ai * ai);
+			if (var < 0.0) var = 0.0;
+			float sd = sqrtf((float)var);
+			if (sd == 0.0f) sd = 1.0f;
+			s_stat[0] = (float)ar; s_stat[1] = (float)ai; s_stat[2] = 1.0f / sd;
+		}
+	}
+	__syncthreads();
+	const float avr = s_stat[0], avi = s_stat[1], inv = s_stat[2];
+	const float fs = a.freq_shift ? a.freq_shift[s] : 0.0f;
+
+	// ---- stage normalised (and frequency shifted) samples m0 .. m0 + kTileLags + NT - 2
+	const int nstage = kTileLags + NT - 1;
+	for (int i = tid; i < nstage; i += 256) {
+		const int gi = m0 + i;
+		float2 v = make_float2(0.f, 0.f);
+		if (gi < ndec) {
+			v = dec[gi];
+			v.x = (v.x - avr) * inv;
+			v.y = (v.y - avi) * inv;
+			if (fs != 0.0f) {
+				float sn, cs;
+				sincos_fast(fs * (float)gi, sn, cs);
+				v = cmul(v, make_float2(cs, sn));
+			}
+		}
+		xs[pad8(i)] = v;
+	}
+	__syncthreads();
+
+	// ---- 8 consecutive lags per thread, sliding 8-sample register window
+	const float *__restrict__ ref = c_fcch.dual[a.tab];
+	float2 acc[kLagsPerThread];
+	float2 win[kLagsPerThread];
+	const int base = tid * kLagsPerThread;
+#pragma unroll
+	for (int q = 0; q < kLagsPerThread; q++) {
+		acc[q] = make_float2(0.f, 0.f);
+		win[q] = xs[pad8(base + q)];
+	}
+	// tap n multiplies sample (lag + n): window slot q holds sample base + n + q
+	for (int n0 = 0; n0 < NT; n0 += kLagsPerThread) {
+#pragma unroll
+		for (int u = 0; u < kLagsPerThread; u++) {
+			const int n = n0 + u;
+			if (n < NT) {
+				const float r = ref[n];
+#pragma unroll
+				for (int q = 0; q < kLagsPerThread; q++) {
+					const float2 x = win[(u + q) % kLagsPerThread];
+					acc[q].x = fmaf(r, x.x, acc[q].x);
+					acc[q].y = fmaf(r, x.y, acc[q].y);
+				}
+				// slot u is now free: refill with sample base + n + 8
+				win[u] = xs[pad8(base + n + kLagsPerThread)];
+			}
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < kLagsPerThread; q++) {
+		const int m = m0 + base + q;
+		const float e = (m < nlags) ? fmaf(acc[q].x, acc[q].x, acc[q].y * acc[q].y) : -1.0f;
+		en[base + q] = e;
+		if (a.energy && m < nlags && (tile == 0 || base + q >= 4))
+			a.energy[(size_t)s * a.energy_stride + m] = e;
+	}
+	__syncthreads();
+
+	// ---- best 5-sample window starting inside this tile (first maximum wins)
+	float bv = -1.0f;
+	int bi = 0x7fffffff;
+	for (int i = tid; i < kTileStep; i += 256) {
+		const int m = m0 + i;
+		if (m + 5 <= nlags) {
+			float e = 0.f;
+#pragma unroll
+			for (int k = 0; k < 5; k++)
+				e += en[i + k];
+			if (e > bv) { bv = e; bi = m; }
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const float ov = __shfl_xor(bv, o);
+		const int oi = __shfl_xor(bi, o);
+		if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+	}
+	if (lane == 0) { s_best[wv] = bv; s_bidx[wv] = bi; }
+	__syncthreads();
+	if (tid == 0) {
+		for (int q = 1; q < 4; q++)
+			if (s_best[q] > bv || (s_best[q] == bv && s_bidx[q] < bi)) { bv = s_best[q]; bi = s_bidx[q]; }
+		float *o = a.tile_best + ((size_t)s * a.n_lag_tiles + tile) * 8;
+		o[0] = bv;
+		o[1] = __builtin_bit_cast(float, bi);
+		if (bi != 0x7fffffff) {
+			for (int k = 0; k < 5; k++)
+				o[2 + k] = en[bi - m0 + k];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// pass 3: per stream, best tile -> centroid -> toa    (one wavefront per stream)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fcch_pick(FcchRoughArgs a)
+{
+	const int s = blockIdx.x, lane = threadIdx.x;
+	float bv = -1.0f;
+	int bi = 0x7fffffff, bt = 0;
+	for (int t = lane; t < a.n_lag_tiles; t += 64) {
+		const float *o = a.tile_best + ((size_t)s * a.n_lag_tiles + t) * 8;
+		const float v = o[0];
+		const int i = __builtin_bit_cast(int, o[1]);
+		if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bt = t; }
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const float ov = __shfl_xor(bv, o);
+		const int oi = __shfl_xor(bi, o);
+		const int ot = __shfl_xor(bt, o);
+		if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bt = ot; }
+	}
+	if (lane == 0) {
+		int toa = 0, rv = 0;
+		if (bi == 0x7fffffff) {
+			rv = -22;
+		} else {
+			// PEAK_WEIGH_WIN: energy-weighted centroid of the 5 samples
+			const float *o = a.tile_best + ((size_t)s * a.n_lag_tiles + bt) * 8;
+			float num = 0.f, den = 0.f;
+			for (int k = 0; k < 5; k++) {
+				num += o[2 + k] * (float)(bi + k);
+				den += o[2 + k];
+			}
+			const float pos = num / den;
+			toa = (int)round((double)(pos * (float)a.sps));     // fcch.c:241
+		}
+		a.toa[s] = toa;
+		if (a.rv) a.rv[s] = rv;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// fine acquisition / SNR: one wavefront per burst of exactly len*sps samples
+// ---------------------------------------------------------------------------
+// mode 0: gmr1_fcch_fine (toa, freq_error) ; mode 1: gmr1_fcch_snr
+template <int N>
+__global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
+{
+	constexpr int PER = (N + 63) / 64;       // bins / symbols per lane
+	__shared__ float2 s_up[N], s_dn[N];
+	__shared__ float s_e[2][N];
+	const int b = blockIdx.x, lane = threadIdx.x;
+	const int sps = a.sps, nraw = N * sps;
+	const float2 *__restrict__ in = a.iq + a.offset[b];
+	const float fs = a.freq_shift ? a.freq_shift[b] : 0.0f;
+	const int tab = a.tab;
+
+	// statistics over all raw samples (osmo_cxvec_sig_normalize)
+	float sr = 0.f, si = 0.f;
+	for (int i = lane; i < nraw; i += 64) {
+		const float2 v = in[i];
+		sr += v.x; si += v.y;
+	}
+	sr = wave_sum(sr); si = wave_sum(si);
+	const float avr = sr / (float)nraw, avi = si / (float)nraw;
+	float sq = 0.f;
+	for (int i = lane; i < nraw; i += 64) {
+		const float2 v = in[i];
+		const float dx = v.x - avr, dy = v.y - avi;
+		sq = fmaf(dx, dx, fmaf(dy, dy, sq));
+	}
+	float sd = sqrtf(wave_sum(sq) / (float)nraw);
+	if (sd == 0.0f) sd = 1.0f;
+	const float inv = 1.0f / sd;
+
+	// normalise, shift, mix
+	for (int i = lane; i < N; i += 64) {
+		float2 v = in[i * sps];
+		v.x = (v.x - avr) * inv;
+		v.y = (v.y - avi) * inv;
+		if (fs != 0.0f) {
+			float sn, cs;
+			sincos_fast(fs * (float)i, sn, cs);
+			v = cmul(v, make_float2(cs, sn));
+		}
+		if (a.mode == 0) {
+			// burst * ref_up / ref_down, then centre the spectrum on bin N/2 (fcch.c:563-580)
+			const float2 shf = c_fcch.shift[tab][i];
+			s_up[i] = cmul(cmul(v, c_fcch.up[tab][i]), shf);
+			const float2 dn = make_float2(c_fcch.up[tab][i].x, -c_fcch.up[tab][i].y);   // down = conj(up)
+			s_dn[i] = cmul(cmul(v, dn), shf);
+		} else {
+			const float r = c_fcch.dual[tab][i];
+			s_up[i] = make_float2(v.x * r, v.y * r);
+		}
+	}
+	__syncthreads();
+
+	// direct DFT, bins lane, lane+64, ...
+	float2 xu[PER], xd[PER];
+#pragma unroll
+	for (int p = 0; p < PER; p++) {
+		const int k = lane + 64 * p;
+		float2 au = make_float2(0.f, 0.f), ad = make_float2(0.f, 0.f);
+		if (k < N) {
+			int idx = 0;
+			for (int n = 0; n < N; n++) {
+				const float2 tw = c_fcch.twid[tab][idx];
+				const float2 u = s_up[n];
+				au.x = fmaf(u.x, tw.x, fmaf(-u.y, tw.y, au.x));
+				au.y = fmaf(u.x, tw.y, fmaf(u.y, tw.x, au.y));
+				if (a.mode == 0) {
+					const float2 dd = s_dn[n];
+					ad.x = fmaf(dd.x, tw.x, fmaf(-dd.y, tw.y, ad.x));
+					ad.y = fmaf(dd.x, tw.y, fmaf(dd.y, tw.x, ad.y));
+				}
+				idx += k;
+				if (idx >= N) idx -= N;
+			}
+			s_e[0][k] = fmaf(au.x, au.x, au.y * au.y);
+			s_e[1][k] = fmaf(ad.x, ad.x, ad.y * ad.y);
+		}
+		xu[p] = au; xd[p] = ad;
+	}
+	__syncthreads();
+
+	if (a.mode == 0) {
+		// 5-bin energy window centroid of both spectra (PEAK_WEIGH_WIN)
+		float peak[2];
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			float bv = -1.0f;
+			int bi = 0x7fffffff;
+			for (int m = lane; m + 5 <= N; m += 64) {
+				float e = 0.f;
+				for (int k = 0; k < 5; k++)
+					e += s_e[h][m + k];
+				if (e > bv) { bv = e; bi = m; }
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const float ov = __shfl_xor(bv, o);
+				const int oi = __shfl_xor(bi, o);
+				if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+			}
+			if (bi == 0x7fffffff) bi = 0;
+			float num = 0.f, den = 0.f;
+			for (int k = 0; k < 5; k++) {
+				num += s_e[h][bi + k] * (float)(bi + k);
+				den += s_e[h][bi + k];
+			}
+			peak[h] = num / den;
+		}
+		if (lane == 0) {
+			// fcch.c:600-615
+			const int mid = N >> 1;
+			const float bin_hz = 23400.0f / (float)N;
+			const float pu = (peak[0] - (float)mid) * bin_hz;
+			const float pd = (peak[1] - (float)mid) * bin_hz;
+			const float ferr_hz = (pu + pd) / 2.0f;
+			a.freq_err[b] = (2.0f * kPif * ferr_hz) / 23400.0f;
+			const float chirp_rate = (2.0f * c_fcch.freq[tab] * 23400.0f * 23400.0f) / (float)(N * 1000);
+			const float toa_ms = ((pu - pd) / 2.0f) / chirp_rate;
+			const float toa_samples = (toa_ms * 23400.0f * (float)sps) / 1000.0f;
+			a.toa[b] = (int)round((double)toa_samples);
+		}
+	} else {
+		// 6 largest bins, descending, first index wins ties (osmo_cxvec_peaks_scan)
+		float top[6];
+		for (int r = 0; r < 6; r++) {
+			float bv = -1.0f;
+			int bi = 0x7fffffff;
+			for (int k = lane; k < N; k += 64) {
+				const float e = s_e[0][k];
+				if (e > bv) { bv = e; bi = k; }
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const float ov = __shfl_xor(bv, o);
+				const int oi = __shfl_xor(bi, o);
+				if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+			}
+			top[r] = bv;
+			__syncthreads();
+			if (lane == 0 && bi != 0x7fffffff)
+				s_e[0][bi] = -2.0f;          // taken
+			__syncthreads();
+		}
+		if (lane == 0)
+			a.snr[b] = (top[0] + top[1]) / (top[4] + top[5]);      // fcch.c:701-702
+	}
+	(void)xu; (void)xd;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+int fcch_stat_tiles(int len) { return (len + kStatSpan - 1) / kStatSpan; }
+int fcch_lag_tiles(int nlags) { return nlags <= 0 ? 0 : (nlags + kTileStep - 1) / kTileStep; }
+
+template <int NT>
+static void launch_corr(const FcchRoughArgs &a, hipStream_t st)
+{
+	const size_t lds = (size_t)(pad8(kTileLags + NT + 8) + 1) * 8 + (size_t)kTileLags * 4 + 64;
+	hipLaunchKernelGGL((k_fcch_corr<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), lds, st, a);
+}
+
+hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t st)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_fcch_stats, dim3(a.n_stat_tiles, a.n), dim3(256), 0, st, a);
+	if (ntaps == 117)
+		launch_corr<117>(a, st);
+	else if (ntaps == 468)
+		launch_corr<468>(a, st);
+	else
+		return hipErrorInvalidValue;
+	if (a.toa)
+		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t st)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	if (nsym == 117)
+		hipLaunchKernelGGL((k_fcch_fine<117>), dim3(a.n), dim3(64), 0, st, a);
+	else if (nsym == 468)
+		hipLaunchKernelGGL((k_fcch_fine<468>), dim3(a.n), dim3(64), 0, st, a);
+	else
+		return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
+}  // namespace gmr1

@@ -69,6 +69,46 @@ struct L1Args {
 	int32_t *crc, *conv;
 };
 
+// ---- FCCH -------------------------------------------------------------------
+constexpr int kFcchTabs = 3;          // gmr1_fcch_burst, gmr1_fcch3_lband_burst, gmr1_fcch3_sband_burst
+constexpr int kFcchMaxLen = 480;      // symbols (117 / 468)
+
+struct FcchTables {
+	float  dual[kFcchTabs][kFcchMaxLen];    // sqrt(2) cos(phi)                 fcch.c:167-193
+	float2 up[kFcchTabs][kFcchMaxLen];      // sqrt(2)/2 e^{+j phi}             fcch.c:92-121
+	float2 shift[kFcchTabs][kFcchMaxLen];   // e^{j 2 pi (len/2) i / len}       fcch.c:575-580
+	float2 twid[kFcchTabs][kFcchMaxLen];    // e^{-2 pi j k / len}
+	float  freq[kFcchTabs];
+	int    len[kFcchTabs];
+};
+
+struct FcchRoughArgs {
+	int n, len, sps, tab;
+	const float2 *iq;
+	const uint64_t *offset;
+	const float *freq_shift;
+	float2 *dec;  size_t dec_stride;        // decimated samples per stream
+	float *partial;  int n_stat_tiles;      // 4 floats per (stream, tile)
+	float *tile_best;  int n_lag_tiles;     // 8 floats per (stream, lag tile)
+	float *energy;  size_t energy_stride;   // optional |corr|^2 per lag
+	int32_t *toa, *rv;
+};
+
+struct FcchFineArgs {
+	int n, sps, tab, mode;                  // mode 0 fine, 1 snr
+	const float2 *iq;
+	const uint64_t *offset;
+	const float *freq_shift;
+	int32_t *toa;
+	float *freq_err, *snr;
+};
+
+hipError_t upload_fcch_tables(const FcchTables *host, hipStream_t stream);
+int fcch_stat_tiles(int len);
+int fcch_lag_tiles(int nlags);
+hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t stream);
+hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t stream);
+
 // launchers (rx_kernels.hip)
 // descriptors live in __constant__ memory of the current device
 hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream);

@@ -259,3 +259,47 @@ int to_dev(const gmr1_hip_burst_flat &f, DevBurst *d)
 }
 
 }  // namespace gmr1
+
+// ---------------------------------------------------------------------------
+// FCCH
+// ---------------------------------------------------------------------------
+extern "C" {
+const struct gmr1_fcch_burst gmr1_fcch_burst        = {0.32f, 3 * 39};     // fcch.c:50-53
+const struct gmr1_fcch_burst gmr1_fcch3_lband_burst = {0.32f, 12 * 39};    // fcch.c:59-62
+const struct gmr1_fcch_burst gmr1_fcch3_sband_burst = {0.16f, 12 * 39};    // fcch.c:67-70
+}
+
+namespace gmr1 {
+
+const struct gmr1_fcch_burst *const kFcchBuiltin[kFcchTabs] = {
+	&gmr1_fcch_burst, &gmr1_fcch3_lband_burst, &gmr1_fcch3_sband_burst,
+};
+
+void fcch_tables_init(FcchTables *t)
+{
+	std::memset(t, 0, sizeof(*t));
+	const float pif = 3.14159265358979323846f;
+	for (int k = 0; k < kFcchTabs; k++) {
+		const struct gmr1_fcch_burst *b = kFcchBuiltin[k];
+		const int len = b->len;
+		t->freq[k] = b->freq;
+		t->len[k] = len;
+		// single-precision formulas exactly as the reference evaluates them at sps = 1
+		const float sq2 = sqrtf(2.0f), sq2d2 = sqrtf(2.0f) / 2.0f;
+		const float phase_base = b->freq * 2.0f * pif / (float)len;
+		const float halfpos = (float)len / 2.0f;
+		const int mid = len >> 1;
+		for (int i = 0; i < len; i++) {
+			const float pos = ((float)i / 1.0f) - halfpos;
+			const float ph = phase_base * (pos * pos);
+			t->dual[k][i] = sq2 * cosf(ph);
+			t->up[k][i] = make_float2(sq2d2 * cosf(ph), sq2d2 * sinf(ph));
+			const float phf = 2.0f * pif * (float)mid / (float)len * (float)i;
+			t->shift[k][i] = make_float2((float)cos((double)phf), (float)sin((double)phf));
+			const double tw = -2.0 * M_PI * (double)i / (double)len;
+			t->twid[k][i] = make_float2((float)cos(tw), (float)sin(tw));
+		}
+	}
+}
+
+}  // namespace gmr1

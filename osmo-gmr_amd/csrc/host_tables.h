@@ -3,6 +3,7 @@
 
 #include <osmocom/gmr1/sdr/pi4cxpsk.h>
 #include <osmocom/gmr1/sdr/nb.h>
+#include <osmocom/gmr1/sdr/fcch.h>
 
 #include "gmr1_dev.h"
 
@@ -16,5 +17,10 @@ void tables_init();
 int flatten(const gmr1_pi4cxpsk_burst *b, gmr1_hip_burst_flat *out, const char *name);
 // flat copy -> kernel descriptor; 0 or -EINVAL (limits: kMaxCoef sync symbols per sequence)
 int to_dev(const gmr1_hip_burst_flat &f, DevBurst *d);
+
+// FCCH reference waveforms and DFT tables, computed on the host with the reference's own float
+// formulas (fcch.c:92-121,167-193,575-580) so they match a CPU build bit for bit
+void fcch_tables_init(FcchTables *t);
+extern const struct gmr1_fcch_burst *const kFcchBuiltin[kFcchTabs];
 
 }  // namespace gmr1
