@@ -21,6 +21,8 @@
  *   gmr1_hip_demod_batch*        -> gmr1_pi4cxpsk_demod   include/osmocom/gmr1/sdr/pi4cxpsk.h:101-105
  *   gmr1_hip_bcch_decode_batch*  -> gmr1_bcch_decode      include/osmocom/gmr1/l1/bcch.h:38
  *   gmr1_hip_ccch_decode_batch*  -> gmr1_ccch_decode      include/osmocom/gmr1/l1/ccch.h:38
+ *   gmr1_hip_facch3_decode_batch*-> gmr1_facch3_decode    include/osmocom/gmr1/l1/facch3.h:39-40
+ *   gmr1_hip_tch3_decode_batch*  -> gmr1_tch3_decode      include/osmocom/gmr1/l1/tch3.h:40-42
  *   gmr1_hip_rx_bcch_ccch_batch* -> rx_bcch / rx_ccch     src/gmr1_rx.c:746-850 (demod + decode of one burst)
  *   gmr1_hip_fcch_rough_batch*   -> gmr1_fcch_rough       include/osmocom/gmr1/sdr/fcch.h:47-49
  *   gmr1_hip_fcch_fine_batch*    -> gmr1_fcch_fine        include/osmocom/gmr1/sdr/fcch.h:55-57
@@ -108,6 +110,20 @@ int gmr1_hip_rx_bcch_ccch_batch(int n, int sps,
                                 uint8_t *l2, int32_t *crc, int32_t *conv,
                                 float *toa, float *freq_err,
                                 int8_t *ebits, float *ssyms, int32_t *rv);
+
+/* ---- traffic channel layer 1 -------------------------------------------------
+ * FACCH3: n frames, each 4 bursts x 104 soft bits (n x 416) -> l2 n x 10, optional
+ * bits_s n x 32, crc / conv per frame; ciph optional n x 384 keystream bits.
+ * TCH3: n speech bursts x 212 soft bits -> frames n x 2 x 10 (frame0 then frame1),
+ * optional bits_s n x 4, conv n x 2; ciph optional n x 208; m = multiplexing mode. */
+int gmr1_hip_facch3_decode_batch_dev(void *stream, int n, const int8_t *ebits, const uint8_t *ciph,
+                                     uint8_t *l2, uint8_t *bits_s, int32_t *crc, int32_t *conv);
+int gmr1_hip_facch3_decode_batch(int n, const int8_t *ebits, const uint8_t *ciph,
+                                 uint8_t *l2, uint8_t *bits_s, int32_t *crc, int32_t *conv);
+int gmr1_hip_tch3_decode_batch_dev(void *stream, int n, int m, const int8_t *ebits, const uint8_t *ciph,
+                                   uint8_t *frames, uint8_t *bits_s, int32_t *conv);
+int gmr1_hip_tch3_decode_batch(int n, int m, const int8_t *ebits, const uint8_t *ciph,
+                               uint8_t *frames, uint8_t *bits_s, int32_t *conv);
 
 /* ---- FCCH acquisition ------------------------------------------------------
  * fcch_type: 0 gmr1_fcch_burst, 1 gmr1_fcch3_lband_burst, 2 gmr1_fcch3_sband_burst.

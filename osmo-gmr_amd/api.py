@@ -28,6 +28,9 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_fcch_fine_batch_dev", "gmr1_hip_fcch_fine_batch",
     "gmr1_hip_fcch_snr_batch_dev", "gmr1_hip_fcch_snr_batch",
     "gmr1_fcch_rough", "gmr1_fcch_fine", "gmr1_fcch_snr",
+    "gmr1_hip_facch3_decode_batch_dev", "gmr1_hip_facch3_decode_batch",
+    "gmr1_hip_tch3_decode_batch_dev", "gmr1_hip_tch3_decode_batch",
+    "gmr1_facch3_decode", "gmr1_tch3_decode",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -353,3 +356,68 @@ def fcch_rough_batch_dev(stream, fcch_type, n, sps, length, iq, offset, freq_shi
     rc = f(vp(stream), C.c_int(_fcch_id(fcch_type)), C.c_int(n), C.c_int(sps), C.c_int(length),
            vp(iq), vp(offset), vp(freq_shift), vp(toa), vp(rv))
     _check(rc, "gmr1_hip_fcch_rough_batch_dev")
+
+
+# ---------------------------------------------------------------------------
+# traffic-channel layer 1
+# ---------------------------------------------------------------------------
+def facch3_decode_batch(ebits, ciph=None):
+    """ebits (n, 4, 104) or (n, 416) int8 -> l2 (n,10), bits_s (n,32), crc, conv."""
+    ebits, p = _np(ebits, np.int8)
+    ebits = ebits.reshape(-1, 416)
+    n = ebits.shape[0]
+    cp = None
+    if ciph is not None:
+        ciph, cp = _np(ciph, np.uint8)
+    l2 = np.zeros((n, 10), np.uint8)
+    s = np.zeros((n, 32), np.uint8)
+    crc = np.zeros(n, np.int32)
+    conv = np.zeros(n, np.int32)
+    rc = load().gmr1_hip_facch3_decode_batch(C.c_int(n), p, cp, l2.ctypes.data_as(C.c_void_p),
+                                             s.ctypes.data_as(C.c_void_p), crc.ctypes.data_as(C.c_void_p),
+                                             conv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_facch3_decode_batch")
+    return l2, s, crc, conv
+
+
+def tch3_decode_batch(ebits, m=0, ciph=None):
+    """ebits (n, 212) int8 -> frame0 (n,10), frame1 (n,10), bits_s (n,4), conv0, conv1."""
+    ebits, p = _np(ebits, np.int8)
+    ebits = ebits.reshape(-1, 212)
+    n = ebits.shape[0]
+    cp = None
+    if ciph is not None:
+        ciph, cp = _np(ciph, np.uint8)
+    fr = np.zeros((n, 2, 10), np.uint8)
+    s = np.zeros((n, 4), np.uint8)
+    conv = np.zeros((n, 2), np.int32)
+    rc = load().gmr1_hip_tch3_decode_batch(C.c_int(n), C.c_int(m), p, cp, fr.ctypes.data_as(C.c_void_p),
+                                           s.ctypes.data_as(C.c_void_p), conv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_tch3_decode_batch")
+    return fr[:, 0], fr[:, 1], s, conv[:, 0], conv[:, 1]
+
+
+def facch3_decode(ebits):
+    """gmr1_facch3_decode(l2, bits_s, bits_e, NULL, &conv): the reference's own call."""
+    ebits = np.ascontiguousarray(ebits, np.int8).reshape(416)
+    l2 = np.zeros(10, np.uint8)
+    s = np.zeros(32, np.uint8)
+    cv = C.c_int()
+    f = load().gmr1_facch3_decode
+    f.restype = C.c_int
+    rv = f(l2.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), ebits.ctypes.data_as(C.c_void_p),
+           None, C.byref(cv))
+    return l2, s, rv, cv.value
+
+
+def tch3_decode(ebits, m=0):
+    ebits = np.ascontiguousarray(ebits, np.int8).reshape(212)
+    f0 = np.zeros(10, np.uint8)
+    f1 = np.zeros(10, np.uint8)
+    s = np.zeros(4, np.uint8)
+    c0, c1 = C.c_int(), C.c_int()
+    f = load().gmr1_tch3_decode
+    f.restype = None
+    f(f0.ctypes.data_as(C.c_void_p), f1.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
+      ebits.ctypes.data_as(C.c_void_p), None, C.c_int(m), C.byref(c0), C.byref(c1))
+    return f0, f1, s, c0.value, c1.value

@@ -109,6 +109,29 @@ int fcch_lag_tiles(int nlags);
 hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t stream);
 hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t stream);
 
+// ---- traffic-channel layer 1 (l1_kernels.hip) -------------------------------
+struct Facch3Args {
+	int n;                     // frames (each = 4 bursts x 104 soft bits)
+	const int8_t *ebits;       // n x 416
+	const uint8_t *ciph;       // optional n x 384 keystream bits
+	uint8_t *l2;               // n x 10
+	uint8_t *bits_s;           // optional n x 32 status bits
+	int32_t *crc, *conv;
+};
+
+struct Tch3Args {
+	int n;                     // bursts (212 soft bits each, two speech frames)
+	int m;                     // multiplexing mode 0 / 1
+	const int8_t *ebits;       // n x 212
+	const uint8_t *ciph;       // optional n x 208 keystream bits
+	uint8_t *frames;           // n x 2 x 10
+	uint8_t *bits_s;           // optional n x 4
+	int32_t *conv;             // optional n x 2
+};
+
+hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
+hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);
+
 // launchers (rx_kernels.hip)
 // descriptors live in __constant__ memory of the current device
 hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream);
