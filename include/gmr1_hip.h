@@ -19,6 +19,8 @@
  * Reference interfaces replaced (osmocom/osmo-gmr, paths relative to the
  * reference tree):
  *   gmr1_hip_demod_batch*        -> gmr1_pi4cxpsk_demod   include/osmocom/gmr1/sdr/pi4cxpsk.h:101-105
+ *   gmr1_hip_detect_batch*       -> gmr1_pi4cxpsk_detect  include/osmocom/gmr1/sdr/pi4cxpsk.h:107-110
+ *   gmr1_hip_mod_order_batch*    -> gmr1_pi4cxpsk_mod_order include/osmocom/gmr1/sdr/pi4cxpsk.h:112-113
  *   gmr1_hip_bcch_decode_batch*  -> gmr1_bcch_decode      include/osmocom/gmr1/l1/bcch.h:38
  *   gmr1_hip_ccch_decode_batch*  -> gmr1_ccch_decode      include/osmocom/gmr1/l1/ccch.h:38
  *   gmr1_hip_facch3_decode_batch*-> gmr1_facch3_decode    include/osmocom/gmr1/l1/facch3.h:39-40
@@ -84,6 +86,19 @@ int gmr1_hip_demod_batch(int burst_id, int n, int sps, int in_len,
                          const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
                          int8_t *ebits, int ebits_stride, int32_t *sync_id,
                          float *toa, float *freq_err, float *ssyms, int32_t *rv);
+
+/* ---- burst type detection / modulation order -------------------------------
+ * burst_ids: 1..4 candidate types (same length / modulation family); e_toa optional. */
+int gmr1_hip_detect_batch_dev(void *stream, int n_types, const int *burst_ids, int n, int sps, int in_len,
+                              const float *iq, const uint64_t *offset, const float *freq_shift,
+                              const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv);
+int gmr1_hip_detect_batch(int n_types, const int *burst_ids, int n, int sps, int in_len,
+                          const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
+                          const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv);
+int gmr1_hip_mod_order_batch_dev(void *stream, int n, int sps, int in_len,
+                                 const float *iq, const uint64_t *offset, const float *freq_shift, int32_t *order);
+int gmr1_hip_mod_order_batch(int n, int sps, int in_len, const float *iq, uint64_t iq_len,
+                             const uint64_t *offset, const float *freq_shift, int32_t *order);
 
 /* ---- layer-1 channel decoding (soft bits in, L2 out) --------------------- */
 int gmr1_hip_bcch_decode_batch_dev(void *stream, int n, const int8_t *ebits /* n x 424 */,

@@ -63,6 +63,15 @@ int gmr1_pi4cxpsk_demod(struct gmr1_pi4cxpsk_burst *burst_type,
                         struct osmo_cxvec *burst_in, int sps, float freq_shift,
                         sbit_t *ebits, int *sync_id_p, float *toa_p, float *freq_err_p);
 
+/* which of the NULL-terminated candidate types (same length and modulation family) is this
+ * burst?  e_toa >= 0 weights the decision by 1/|e_toa - toa|.  0 on success, -errno otherwise */
+int gmr1_pi4cxpsk_detect(struct gmr1_pi4cxpsk_burst **burst_types, float e_toa,
+                         struct osmo_cxvec *burst_in, int sps, float freq_shift,
+                         int *bt_id_p, int *sync_id_p, float *toa_p);
+
+/* 2 for BPSK, 4 for QPSK (x^2 vs x^4 line power), < 0 on error */
+int gmr1_pi4cxpsk_mod_order(struct osmo_cxvec *burst_in, int sps, float freq_shift);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,9 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_facch3_decode_batch_dev", "gmr1_hip_facch3_decode_batch",
     "gmr1_hip_tch3_decode_batch_dev", "gmr1_hip_tch3_decode_batch",
     "gmr1_facch3_decode", "gmr1_tch3_decode",
+    "gmr1_hip_detect_batch_dev", "gmr1_hip_detect_batch",
+    "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
+    "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -421,3 +424,67 @@ def tch3_decode(ebits, m=0):
     f(f0.ctypes.data_as(C.c_void_p), f1.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p),
       ebits.ctypes.data_as(C.c_void_p), None, C.c_int(m), C.byref(c0), C.byref(c1))
     return f0, f1, s, c0.value, c1.value
+
+
+# ---------------------------------------------------------------------------
+# burst type detection / modulation order
+# ---------------------------------------------------------------------------
+def detect_batch(bursts, iq, offset, in_len, sps=4, freq_shift=None, e_toa=None):
+    ids = np.array([BURST_IDS.index(b) if isinstance(b, str) else int(b) for b in bursts], np.int32)
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = et_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    if e_toa is not None:
+        et, et_p = _np(np.broadcast_to(np.asarray(e_toa, np.float32), (n,)), np.float32)
+    bt = np.zeros(n, np.int32)
+    sid = np.zeros(n, np.int32)
+    toa = np.zeros(n, np.float32)
+    rv = np.zeros(n, np.int32)
+    rc = load().gmr1_hip_detect_batch(
+        C.c_int(ids.size), ids.ctypes.data_as(C.c_void_p), C.c_int(n), C.c_int(sps), C.c_int(in_len), p_iq,
+        C.c_uint64(iq.size), p_off, fs_p, et_p, bt.ctypes.data_as(C.c_void_p), sid.ctypes.data_as(C.c_void_p),
+        toa.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_detect_batch")
+    return dict(rv=rv, bt_id=bt, sync_id=sid, toa=toa)
+
+
+def mod_order_batch(iq, offset, in_len, sps=4, freq_shift=None):
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    order = np.zeros(n, np.int32)
+    rc = load().gmr1_hip_mod_order_batch(C.c_int(n), C.c_int(sps), C.c_int(in_len), p_iq, C.c_uint64(iq.size),
+                                         p_off, fs_p, order.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_mod_order_batch")
+    return order
+
+
+def pi4cxpsk_detect(burst_names, e_toa, iq, sps=4, freq_shift=0.0):
+    """gmr1_pi4cxpsk_detect({&gmr1_a_burst, &gmr1_b_burst, NULL}, e_toa, cxvec, ...) as C callers use it."""
+    L = load()
+    arr = (C.c_void_p * (len(burst_names) + 1))()
+    for i, nm in enumerate(burst_names):
+        arr[i] = C.addressof(C.c_void_p.in_dll(L, f"gmr1_{nm}_burst"))
+    arr[len(burst_names)] = None
+    iq = np.ascontiguousarray(iq, np.complex64)
+    vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    bt, sid, toa = C.c_int(-1), C.c_int(-1), C.c_float()
+    f = L.gmr1_pi4cxpsk_detect
+    f.restype = C.c_int
+    rv = f(arr, C.c_float(e_toa), C.byref(vec), C.c_int(sps), C.c_float(freq_shift),
+           C.byref(bt), C.byref(sid), C.byref(toa))
+    return dict(rv=rv, bt_id=bt.value, sync_id=sid.value, toa=toa.value)
+
+
+def pi4cxpsk_mod_order(iq, sps=4, freq_shift=0.0):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    f = load().gmr1_pi4cxpsk_mod_order
+    f.restype = C.c_int
+    return f(C.byref(vec), C.c_int(sps), C.c_float(freq_shift))

@@ -61,6 +61,26 @@ struct RxArgs {
 	int32_t *sync_id;
 };
 
+struct DetectArgs {
+	int n, sps, in_len;
+	int n_types;
+	int types[4];          // candidate burst types (same length / modulation family)
+	const float2 *iq;
+	const uint64_t *offset;
+	const float *freq_shift;
+	const float *e_toa;    // optional expected TOA per burst (< 0 or NULL: not used)
+	int32_t *bt_id, *sync_id, *rv;
+	float *toa;
+};
+
+struct ModOrderArgs {
+	int n, sps, in_len;
+	const float2 *iq;
+	const uint64_t *offset;
+	const float *freq_shift;
+	int32_t *order;        // 2 (BPSK) or 4 (QPSK)
+};
+
 struct L1Args {
 	int n;
 	int chain;             // kChainBcch / kChainCcch
@@ -137,6 +157,8 @@ hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);
 hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream);
 hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t stream);
 hipError_t launch_l1(const L1Args &a, hipStream_t stream);
+hipError_t launch_detect(const DetectArgs &a, hipStream_t stream);
+hipError_t launch_mod_order(const ModOrderArgs &a, hipStream_t stream);
 size_t rx_lds_bytes(int max_in_len);
 
 }  // namespace gmr1

@@ -254,9 +254,8 @@ __host__ __device__ inline size_t lds_layout(int max_in_len, int max_len, bool d
 	if (decode && xbytes < dec_bytes)
 		xbytes = align16(dec_bytes);
 	off[0] = o; o += xbytes;
-	size_t aux = kMaxWindow * 4 + kMaxCoef * 8;
-	if (aux < align16((size_t)max_len * 8))
-		aux = align16((size_t)max_len * 8);
+	(void)max_len;                        // symbols are no longer staged in LDS
+	const size_t aux = kMaxWindow * 4 + kMaxCoef * 8;
 	off[1] = o; o += aux;
 	off[2] = o; o += decode ? 4 * kEbRow : kEbitsLds;
 	return align16(o);
@@ -279,21 +278,13 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *raw, int max_in_len, int
 }
 
 // ---------------------------------------------------------------------------
-// demodulation of one burst by one wavefront
-// returns the reference's rv (0, or -1 when no sync sequence has power)
+// building blocks of the demodulator, one burst per wavefront
 // ---------------------------------------------------------------------------
-template <int NPL, int SPS>
-__device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, int sps_rt,
-                         float freq_shift, const Lds &L, int8_t *__restrict__ eb, int lane,
-                         int dbg_stop, int &sync_id_o, float &toa_o, float &ferr_o,
-                         float *__restrict__ g_ssyms)
-{
-	const DevBurst &bt = c_types[type];
-	const int sps = SPS ? SPS : sps_rt;
-	const int nbits = bt.nbits;
-	const int blen = bt.len;
-	const int w = in_len - blen * sps + 1;
 
+// window HBM -> registers -> LDS, DC and power normalised
+template <int NPL>
+__device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, int in_len, const Lds &L, int lane)
+{
 	// ---- load + normalise (osmo_cxvec_sig_normalize, decim 1) ------------------
 	// rows k < nfull are whole (no lane test); row nfull is the ragged tail
 	float2 v[NPL];
@@ -333,12 +324,21 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 		if (k < nfull || (k == nfull && tail))
 			L.x[lane + 64 * k] = make_float2(v[k].x * inv, v[k].y * inv);
 	}
+}
+
+// sync sequence search over the normalised window in L.x with derotation step fs (rad/sample).
+// Returns the winning sequence (-1: none has power), its fractional TOA and power.
+template <int SPS>
+__device__ int sync_search(int type, int in_len, int sps_rt, float fs, const Lds &L, int lane,
+                           int dbg_stop, float &toa_o, float &pwr_o)
+{
+	const DevBurst &bt = c_types[type];
+	const int sps = SPS ? SPS : sps_rt;
+	const int nbits = bt.nbits;
+	const int w = in_len - bt.len * sps + 1;
+	WSYNC();
 	for (int j = lane; j < w; j += 64)
 		L.corr[j] = 0.f;
-	if (dbg_stop == 1) return -100;
-
-	// per-sample derotation step (pi4cxpsk.c:539)
-	const float fs = (freq_shift - bt.rotation) / (float)sps;
 
 	// ---- sync search (pi4cxpsk.c:184-268) --------------------------------------
 	float p_toa = 0.f, p_pwr = 0.f;
@@ -466,7 +466,34 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 			p_idx = sq;
 		}
 	}
-	if (dbg_stop == 3) return -100;
+	toa_o = p_toa;
+	pwr_o = p_pwr;
+	return p_idx;
+}
+
+// ---------------------------------------------------------------------------
+// demodulation of one burst by one wavefront
+// returns the reference's rv (0, or -1 when no sync sequence has power)
+// ---------------------------------------------------------------------------
+template <int NPL, int SPS>
+__device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, int sps_rt,
+                         float freq_shift, const Lds &L, int8_t *__restrict__ eb, int lane,
+                         int dbg_stop, int &sync_id_o, float &toa_o, float &ferr_o,
+                         float *__restrict__ g_ssyms)
+{
+	const DevBurst &bt = c_types[type];
+	const int sps = SPS ? SPS : sps_rt;
+	const int nbits = bt.nbits;
+	const int blen = bt.len;
+
+	load_normalise<NPL>(in, in_len, L, lane);
+	if (dbg_stop == 1) return -100;
+
+	// per-sample derotation step (pi4cxpsk.c:539)
+	const float fs = (freq_shift - bt.rotation) / (float)sps;
+	float p_toa = 0.f, p_pwr = 0.f;
+	const int p_idx = sync_search<SPS>(type, in_len, sps_rt, fs, L, lane, dbg_stop, p_toa, p_pwr);
+	if (p_idx == -100 || dbg_stop == 3) return -100;
 
 	sync_id_o = p_idx;
 	toa_o = p_toa;
@@ -870,6 +897,85 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 	}
 }
 
+// ---------------------------------------------------------------------------
+// burst type detection (reference src/sdr/pi4cxpsk.c:617-682 gmr1_pi4cxpsk_detect):
+// normalise once with the rotation of the first candidate type, run the sync search of
+// every candidate, weight the power by 1/|e_toa - toa|, keep the strongest.
+// ---------------------------------------------------------------------------
+template <int NPL, int SPS>
+__global__ __launch_bounds__(64) void k_detect(DetectArgs a, int max_in_len)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const int lane = threadIdx.x;
+	const Lds L = lds_carve(lds_raw, max_in_len, 0, false);
+	const int g = blockIdx.x;
+	const int sps = SPS ? SPS : a.sps;
+	load_normalise<NPL>(a.iq + a.offset[g], a.in_len, L, lane);
+	const float fsh = a.freq_shift ? a.freq_shift[g] : 0.0f;
+	const float fs = (fsh - c_types[a.types[0]].rotation) / (float)sps;
+	const float e_toa = a.e_toa ? a.e_toa[g] : -1.0f;
+	int p_id = -1, p_sid = -1, rv = 0;
+	float p_toa = 0.f, p_pwr = 0.f;
+	for (int id = 0; id < a.n_types; id++) {
+		float toa, pwr;
+		const int sid = sync_search<SPS>(a.types[id], a.in_len, a.sps, fs, L, lane, 0, toa, pwr);
+		if (sid < 0) {
+			rv = sid;
+			break;
+		}
+		if (e_toa >= 0.0f)
+			pwr = (float)((double)pwr / fabs((double)(e_toa - toa)));
+		if (pwr > p_pwr) {
+			p_id = id; p_sid = sid; p_pwr = pwr; p_toa = toa;
+		}
+	}
+	if (lane == 0) {
+		a.rv[g] = rv;
+		if (a.bt_id) a.bt_id[g] = rv ? -1 : p_id;
+		if (a.sync_id) a.sync_id[g] = rv ? -1 : p_sid;
+		if (a.toa) a.toa[g] = rv ? 0.f : p_toa;
+	}
+}
+
+// ---------------------------------------------------------------------------
+// modulation order estimate (reference src/sdr/pi4cxpsk.c:693-729 gmr1_pi4cxpsk_mod_order):
+// w = v^2 / |v|^2 on the pi/4-derotated window; BPSK if |sum w|^2 >= |sum w^2|^2 / 2, else QPSK
+// ---------------------------------------------------------------------------
+template <int NPL>
+__global__ __launch_bounds__(64) void k_mod_order(ModOrderArgs a, int max_in_len)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const int lane = threadIdx.x;
+	const Lds L = lds_carve(lds_raw, max_in_len, 0, false);
+	const int g = blockIdx.x;
+	load_normalise<NPL>(a.iq + a.offset[g], a.in_len, L, lane);
+	WSYNC();
+	const float fsh = a.freq_shift ? a.freq_shift[g] : 0.0f;
+	const float fs = (fsh - (kPif / 4)) / (float)a.sps;
+	float sbr = 0.f, sbi = 0.f, sqr = 0.f, sqi = 0.f;
+	for (int i = lane; i < a.in_len; i += 64) {
+		float2 v = L.x[i];
+		if (fs != 0.0f) {
+			float s, c;
+			sincos_fast(fs * (float)i, s, c);
+			v = cmul(v, make_float2(c, s));
+		}
+		const float nn = v.x * v.x + v.y * v.y;
+		const float2 vv = cmul(v, v);
+		const float2 w = make_float2(vv.x / nn, vv.y / nn);
+		const float2 ww = cmul(w, w);
+		sbr += w.x; sbi += w.y;
+		sqr += ww.x; sqi += ww.y;
+	}
+	sbr = wave_sum(sbr); sbi = wave_sum(sbi);
+	sqr = wave_sum(sqr); sqi = wave_sum(sqi);
+	if (lane == 0) {
+		const float pb = sbr * sbr + sbi * sbi;
+		const float pq = sqr * sqr + sqi * sqi;
+		a.order[g] = pb < (pq / 2.0f) ? 4 : 2;
+	}
+}
+
 __global__ __launch_bounds__(64) void k_l1(L1Args a)
 {
 	__shared__ __align__(16) int8_t s_eb[4 * kEbRow];
@@ -945,6 +1051,43 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 	if (a.sps == 4)
 		return launch_rx_t<32, 4>(a, decode, max_in_len, max_len, stream);
 	return launch_rx_t<32, 0>(a, decode, max_in_len, max_len, stream);
+}
+
+hipError_t launch_detect(const DetectArgs &a, hipStream_t stream)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	if (a.in_len > kMaxInLen)
+		return hipErrorInvalidValue;
+	size_t off[3];
+	const size_t lds = lds_layout(a.in_len, 0, false, off);
+	if (a.in_len <= 1024) {
+		if (a.sps == 4)
+			hipLaunchKernelGGL((k_detect<16, 4>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+		else
+			hipLaunchKernelGGL((k_detect<16, 0>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+	} else {
+		if (a.sps == 4)
+			hipLaunchKernelGGL((k_detect<32, 4>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+		else
+			hipLaunchKernelGGL((k_detect<32, 0>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_mod_order(const ModOrderArgs &a, hipStream_t stream)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	if (a.in_len > kMaxInLen)
+		return hipErrorInvalidValue;
+	size_t off[3];
+	const size_t lds = lds_layout(a.in_len, 0, false, off);
+	if (a.in_len <= 1024)
+		hipLaunchKernelGGL((k_mod_order<16>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+	else
+		hipLaunchKernelGGL((k_mod_order<32>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+	return hipGetLastError();
 }
 
 hipError_t launch_l1(const L1Args &a, hipStream_t stream)

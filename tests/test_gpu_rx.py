@@ -177,3 +177,41 @@ def test_legacy_pi4cxpsk_demod_call(gpu_api, orc, pkg):
         if g["toa"] == o["toa"]:
             assert np.abs(g["ebits"].astype(int) - o["ebits"].astype(int)).max() <= 1
             assert abs(g["freq_err"] - o["freq_err"]) < 1e-5
+
+
+def test_detect_and_mod_order(gpu_api, orc, pkg):
+    """gmr1_pi4cxpsk_detect between the two NT3 burst types (rx_tch3, gmr1_rx.c:584) and
+    gmr1_pi4cxpsk_mod_order, batch and single-call forms, vs the oracle."""
+    rng = np.random.default_rng(41)
+    sps, win, n = 4, 6, 60
+    f_sp, f_fa = pkg.api.burst_format("nt3_speech"), pkg.api.burst_format("nt3_facch")
+    in_len = 117 * sps + win
+    iq = np.zeros((n, in_len), np.complex64)
+    truth = np.zeros(n, int)
+    for i in range(n):
+        which = int(rng.integers(0, 2))          # 0 = facch (first in the list), 1 = speech
+        fmt = f_sp if which else f_fa
+        bits = rng.integers(0, 2, (1, fmt.ebits), dtype=np.uint8)
+        sym = pkg.synth.map_symbols(fmt, bits, sync_id=int(rng.integers(0, len(fmt.sync))))
+        bb = pkg.synth.synth_windows(fmt, sym, sps, win, rng, toa_jitter=1, frac=True, cfo_hz_std=30.0,
+                                     esn0_db=float(rng.choice([8.0, 15.0])))
+        iq[i] = bb.iq[0, :in_len]
+        truth[i] = which
+    offset = (np.arange(n) * in_len).astype(np.uint64)
+    for e_toa in (3.0, None):
+        got = gpu_api.detect_batch(["nt3_facch", "nt3_speech"], iq, offset, in_len, sps=sps, e_toa=e_toa)
+        for i in range(n):
+            o = orc.detect(["nt3_facch", "nt3_speech"], -1.0 if e_toa is None else e_toa, iq[i], sps)
+            assert got["rv"][i] == o["rv"] == 0
+            assert got["bt_id"][i] == o["bt_id"], (i, e_toa)
+            assert got["sync_id"][i] == o["sync_id"], (i, e_toa)
+            assert abs(got["toa"][i] - o["toa"]) < 16 / 1024
+    assert (got["bt_id"] == truth).mean() > 0.9
+    d = gpu_api.pi4cxpsk_detect(["nt3_facch", "nt3_speech"], 3.0, iq[0], sps)
+    o = orc.detect(["nt3_facch", "nt3_speech"], 3.0, iq[0], sps)
+    assert d["rv"] == 0 and d["bt_id"] == o["bt_id"] and d["sync_id"] == o["sync_id"]
+    order = gpu_api.mod_order_batch(iq, offset, in_len, sps=sps)
+    for i in range(n):
+        assert order[i] == orc.mod_order(iq[i], sps), i
+    assert (order == np.where(truth == 1, 4, 2)).mean() >= 0.8      # the estimator itself errs at 8 dB
+    assert gpu_api.pi4cxpsk_mod_order(iq[1], sps) == order[1]
