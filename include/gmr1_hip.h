@@ -27,6 +27,7 @@
  *   gmr1_hip_tch3_decode_batch*  -> gmr1_tch3_decode      include/osmocom/gmr1/l1/tch3.h:40-42
  *   gmr1_hip_rx_bcch_ccch_batch* -> rx_bcch / rx_ccch     src/gmr1_rx.c:746-850 (demod + decode of one burst)
  *   gmr1_hip_fcch_rough_batch*   -> gmr1_fcch_rough       include/osmocom/gmr1/sdr/fcch.h:47-49
+ *   gmr1_hip_fcch_rough_multi_batch* -> gmr1_fcch_rough_multi include/osmocom/gmr1/sdr/fcch.h:51-53
  *   gmr1_hip_fcch_fine_batch*    -> gmr1_fcch_fine        include/osmocom/gmr1/sdr/fcch.h:55-57
  *   gmr1_hip_fcch_snr_batch*     -> gmr1_fcch_snr         include/osmocom/gmr1/sdr/fcch.h:59-61
  */
@@ -152,6 +153,13 @@ int gmr1_hip_fcch_rough_batch_dev(void *stream, int fcch_type, int n, int sps, i
 int gmr1_hip_fcch_rough_batch(int fcch_type, int n, int sps, int len,
                               const float *iq, uint64_t iq_len, const uint64_t *offset,
                               const float *freq_shift, int32_t *toa, int32_t *rv);
+/* rough_multi: peaks_toa is n x N, count[i] = peaks found or -EINVAL (fcch.c:425-427) */
+int gmr1_hip_fcch_rough_multi_batch_dev(void *stream, int fcch_type, int n, int sps, int len,
+                                        const float *iq, const uint64_t *offset, const float *freq_shift,
+                                        int32_t *peaks_toa, int N, int32_t *count);
+int gmr1_hip_fcch_rough_multi_batch(int fcch_type, int n, int sps, int len,
+                                    const float *iq, uint64_t iq_len, const uint64_t *offset,
+                                    const float *freq_shift, int32_t *peaks_toa, int N, int32_t *count);
 int gmr1_hip_fcch_fine_batch_dev(void *stream, int fcch_type, int n, int sps,
                                  const float *iq, const uint64_t *offset, const float *freq_shift,
                                  int32_t *toa, float *freq_error);

@@ -26,6 +26,13 @@ int gmr1_fcch_rough(const struct gmr1_fcch_burst *burst_type,
                     struct osmo_cxvec *search_win_in, int sps, float freq_shift,
                     int *toa);
 
+/* multi-FCCH detection on >= 650 ms of signal: up to N positions ranked by power, duplicates one
+ * BCCH period apart removed.  Returns the number found (>= 0) or -errno (-EINVAL: window too short
+ * or no consistent 320 ms periodicity) */
+int gmr1_fcch_rough_multi(const struct gmr1_fcch_burst *burst_type,
+                          struct osmo_cxvec *search_win_in, int sps, float freq_shift,
+                          int *toa, int N);
+
 /* fine timing + frequency error (rad/symbol) on exactly len*sps samples; -EINVAL otherwise */
 int gmr1_fcch_fine(const struct gmr1_fcch_burst *burst_type,
                    struct osmo_cxvec *burst_in, int sps, float freq_shift,

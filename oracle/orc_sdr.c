@@ -507,7 +507,10 @@ int orc_fcch_rough_multi(const struct orc_fcch_burst *bt, const orc_cf *in, int 
 	l = orc_sig_normalize(in, in_len, sps, freq_shift, win);
 	corr = malloc(sizeof(orc_cf) * (size_t)l);
 	cl = orc_correlate(ref, bt->len, win, l, 1, corr);
-	cp = malloc(sizeof(float) * (size_t)cl);
+	/* The reference reads corr_pwr[i+Lp] for i < Lw (fcch.c:438) which runs up to 8 entries past
+	 * the array when the measured period exceeds 7488 on a minimum-length (650 ms) window; those
+	 * reads are defined as 0 here. */
+	cp = calloc((size_t)cl + 64, sizeof(float));
 
 	Lw = (320 * SYM_RATE) / 1000 + bt->len;
 	Lp = (320 * SYM_RATE) / 1000;

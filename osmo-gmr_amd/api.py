@@ -27,7 +27,8 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_fcch_rough_batch_dev", "gmr1_hip_fcch_rough_batch",
     "gmr1_hip_fcch_fine_batch_dev", "gmr1_hip_fcch_fine_batch",
     "gmr1_hip_fcch_snr_batch_dev", "gmr1_hip_fcch_snr_batch",
-    "gmr1_fcch_rough", "gmr1_fcch_fine", "gmr1_fcch_snr",
+    "gmr1_fcch_rough", "gmr1_fcch_fine", "gmr1_fcch_snr", "gmr1_fcch_rough_multi",
+    "gmr1_hip_fcch_rough_multi_batch_dev", "gmr1_hip_fcch_rough_multi_batch",
     "gmr1_hip_facch3_decode_batch_dev", "gmr1_hip_facch3_decode_batch",
     "gmr1_hip_tch3_decode_batch_dev", "gmr1_hip_tch3_decode_batch",
     "gmr1_facch3_decode", "gmr1_tch3_decode",
@@ -488,3 +489,30 @@ def pi4cxpsk_mod_order(iq, sps=4, freq_shift=0.0):
     f = load().gmr1_pi4cxpsk_mod_order
     f.restype = C.c_int
     return f(C.byref(vec), C.c_int(sps), C.c_float(freq_shift))
+
+
+def fcch_rough_multi_batch(iq, offset, length, sps=4, freq_shift=None, N=16, fcch_type="fcch"):
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    toa = np.zeros((n, N), np.int32)
+    cnt = np.zeros(n, np.int32)
+    rc = load().gmr1_hip_fcch_rough_multi_batch(
+        C.c_int(_fcch_id(fcch_type)), C.c_int(n), C.c_int(sps), C.c_int(length), p_iq, C.c_uint64(iq.size),
+        p_off, fs_p, toa.ctypes.data_as(C.c_void_p), C.c_int(N), cnt.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_fcch_rough_multi_batch")
+    return cnt, toa
+
+
+def fcch_rough_multi(iq, sps=4, freq_shift=0.0, N=16, fcch_type="fcch"):
+    iq = np.ascontiguousarray(iq, np.complex64)
+    vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    toa = np.zeros(N, np.int32)
+    f = load().gmr1_fcch_rough_multi
+    f.restype = C.c_int
+    rv = f(C.byref(_fcch_struct(fcch_type)), C.byref(vec), C.c_int(sps), C.c_float(freq_shift),
+           toa.ctypes.data_as(C.c_void_p), C.c_int(N))
+    return rv, toa[:max(rv, 0)].copy()

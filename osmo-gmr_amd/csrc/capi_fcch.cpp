@@ -199,6 +199,75 @@ int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
 	return 0;
 }
 
+int gmr1_hip_fcch_rough_multi_batch_dev(void *stream, int fcch_type, int n, int sps, int len,
+                                        const float *iq, const uint64_t *offset, const float *freq_shift,
+                                        int32_t *peaks_toa, int N, int32_t *count)
+{
+	if (fcch_type < 0 || fcch_type >= kFcchTabs || !peaks_toa || !count || N < 1 || N > 32)
+		return fail(-EINVAL, "fcch_rough_multi: bad argument");
+	if (len < ((650 * 23400 * sps) / 1000))                       // fcch.c:355-356
+		return fail(-EINVAL, "fcch_rough_multi: needs at least 650 ms of signal");
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0) return 0;
+	const int blen = kFcchBuiltin[fcch_type]->len;
+	const int nlags = len / sps - blen + 1;
+	const size_t estride = ((size_t)nlags + 63) & ~(size_t)63;
+	// the energy plane lives behind the rough sweep's own scratch: ask for both at once
+	const int ndec = len / sps;
+	const size_t b_dec = (size_t)n * ((((size_t)ndec + 15) & ~(size_t)15) * 8);
+	const size_t b_par = (((size_t)n * fcch_stat_tiles(len) * 16) + 255) & ~(size_t)255;
+	const size_t b_best = (((size_t)n * fcch_lag_tiles(nlags) * 32) + 255) & ~(size_t)255;
+	const size_t b_rough = b_dec + b_par + b_best;
+	void *ws;
+	r = dev_workspace(s, b_rough + (size_t)n * estride * 4, &ws);
+	if (r) return r;
+	float *energy = reinterpret_cast<float *>(static_cast<char *>(ws) + b_rough);
+	r = rough_dev((hipStream_t)stream, fcch_type, n, sps, len, iq, offset, freq_shift, nullptr, nullptr,
+	              energy, estride);
+	if (r) return r;
+	FcchMultiArgs m;
+	std::memset(&m, 0, sizeof(m));
+	m.n = n; m.sps = sps; m.burst_len = blen; m.N = N;
+	m.nlags = nlags;
+	m.Lp = (320 * 23400) / 1000;                                  // fcch.c:380-383
+	m.Lw = m.Lp + blen;
+	m.energy = energy; m.energy_stride = estride;
+	m.toa = peaks_toa; m.count = count;
+	HIP_TRY(launch_fcch_multi(m, (hipStream_t)stream));
+	return 0;
+}
+
+int gmr1_hip_fcch_rough_multi_batch(int fcch_type, int n, int sps, int len,
+                                    const float *iq, uint64_t iq_len, const uint64_t *offset,
+                                    const float *freq_shift, int32_t *peaks_toa, int N, int32_t *count)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0) return 0;
+	if (!iq || !offset || !peaks_toa || !count || N < 1 || N > 32)
+		return fail(-EINVAL, "fcch_rough_multi: bad argument");
+	if (len < ((650 * 23400 * sps) / 1000))
+		return fail(-EINVAL, "fcch_rough_multi: needs at least 650 ms of signal");
+	Staged st;
+	r = st.stage(n, iq, iq_len, offset, freq_shift, (uint64_t)len);
+	if (r) return r;
+	DBuf d_toa, d_cnt;
+	HIP_TRY(d_toa.alloc((size_t)n * N * 4));
+	HIP_TRY(d_cnt.alloc((size_t)n * 4));
+	HIP_TRY(hipMemset(d_toa.p, 0, (size_t)n * N * 4));
+	r = gmr1_hip_fcch_rough_multi_batch_dev(nullptr, fcch_type, n, sps, len, st.iq.as<float>(), st.off.as<uint64_t>(),
+	                                        freq_shift ? st.fs.as<float>() : nullptr, d_toa.as<int32_t>(), N,
+	                                        d_cnt.as<int32_t>());
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(peaks_toa, d_toa.p, (size_t)n * N * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(count, d_cnt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
 // ---- reference-compatible single calls (fcch.h:47-61) ---------------------------------------
 int gmr1_fcch_rough(const struct gmr1_fcch_burst *burst_type,
                     struct osmo_cxvec *search_win_in, int sps, float freq_shift, int *toa)
@@ -217,6 +286,28 @@ int gmr1_fcch_rough(const struct gmr1_fcch_burst *burst_type,
 	if (rv) return rv;
 	*toa = t;
 	return 0;
+}
+
+int gmr1_fcch_rough_multi(const struct gmr1_fcch_burst *burst_type,
+                          struct osmo_cxvec *search_win_in, int sps, float freq_shift, int *peaks_toa, int N)
+{
+	if (!burst_type || !search_win_in || !search_win_in->data || !peaks_toa)
+		return fail(-EINVAL, "gmr1_fcch_rough_multi: NULL argument");
+	const int tab = fcch_tab_of(burst_type);
+	if (tab < 0)
+		return fail(-EINVAL, "gmr1_fcch_rough_multi: unknown FCCH burst type");
+	if (N < 1 || N > 32)
+		return fail(-EINVAL, "gmr1_fcch_rough_multi: N must be 1..32");
+	const uint64_t off = 0;
+	int32_t cnt = 0;
+	int32_t tmp[32] = {0};
+	int r = gmr1_hip_fcch_rough_multi_batch(tab, 1, sps, search_win_in->len,
+	                                        reinterpret_cast<const float *>(search_win_in->data),
+	                                        (uint64_t)search_win_in->len, &off, &freq_shift, tmp, N, &cnt);
+	if (r) return r;
+	for (int i = 0; i < N && i < cnt; i++)
+		peaks_toa[i] = tmp[i];
+	return cnt;
 }
 
 int gmr1_fcch_fine(const struct gmr1_fcch_burst *burst_type,

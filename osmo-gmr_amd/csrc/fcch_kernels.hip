@@ -463,6 +463,160 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// multi-FCCH detection on the correlation power of a >= 650 ms window
+// (reference src/sdr/fcch.c:341-496 gmr1_fcch_rough_multi, :264-326 _peak_record)
+//   one 256-thread work-group per stream; the O(N) reductions are parallel, the short
+//   ordered tail (peak list maintenance) is done by lane 0 exactly as the reference does
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float *red, int tid)
+{
+	v = wave_sum(v);
+	__syncthreads();
+	if ((tid & 63) == 0) red[tid >> 6] = v;
+	__syncthreads();
+	return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float *v = reinterpret_cast<float *>(lds_raw);          // Lw mixed-cycle values
+	__shared__ float red[4];
+	__shared__ float s_bv[4];
+	__shared__ int s_bi[4];
+	__shared__ int s_scal[4];
+	__shared__ float s_th;
+	__shared__ unsigned int s_flags[256];                   // Lw <= 8192 threshold flags
+
+	const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const float *__restrict__ cp = a.energy + (size_t)s * a.energy_stride;
+	const int cl = a.nlags;
+	const int Lw = a.Lw;
+	int Lp = a.Lp;
+
+	// ---- strongest lag within the first Lw (first maximum, must exceed 0)
+	float bv = 0.0f;
+	int bi = 0x7fffffff;
+	for (int i = tid; i < Lw && i < cl; i += 256) {
+		const float e = cp[i];
+		if (e > bv) { bv = e; bi = i; }
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const float ov = __shfl_xor(bv, o);
+		const int oi = __shfl_xor(bi, o);
+		if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+	}
+	if (lane == 0) { s_bv[wv] = bv; s_bi[wv] = bi; }
+	__syncthreads();
+	if (tid == 0) {
+		for (int q = 1; q < 4; q++)
+			if (s_bv[q] > bv || (s_bv[q] == bv && s_bi[q] < bi)) { bv = s_bv[q]; bi = s_bi[q]; }
+		const int pwr_max_idx = (bi == 0x7fffffff) ? 0 : bi;
+		// the twin peak one BCCH period later (fcch.c:398-430)
+		float pwrs0 = 0.f, pwrs1 = 0.f, pk0 = 0.f, pk1 = 0.f;
+		for (int i = -10; i <= 10; i++) {
+			int j = pwr_max_idx + i;
+			if (j > 0 && j < cl) { pwrs0 += cp[j]; pk0 += cp[j] * (float)j; }
+			j += Lp;
+			if (j > 0 && j < cl) { pwrs1 += cp[j]; pk1 += cp[j] * (float)j; }
+		}
+		pk0 /= pwrs0;
+		pk1 /= pwrs1;
+		const int nLp = (int)round((double)(pk1 - pk0));
+		s_scal[0] = nLp;
+		s_scal[1] = (abs(nLp - Lp) > 10) ? 1 : 0;       // also true for NaN -> INT_MIN
+	}
+	__syncthreads();
+	if (s_scal[1]) {
+		if (tid == 0)
+			a.count[s] = -22;
+		return;
+	}
+	Lp = s_scal[0];
+
+	// ---- mix the two cycles, mean, standard deviation, threshold (fcch.c:435-454)
+	float sum = 0.f;
+	for (int i = tid; i < Lw; i += 256) {
+		// lags past the end of the sweep count as 0 (the reference over-reads there, fcch.c:438)
+		const float m = (i + Lp < cl) ? sqrtf(cp[i] * cp[i + Lp]) : 0.0f;
+		v[i] = m;
+		sum += m;
+	}
+	const float avg = block_sum(sum, red, tid) / (float)Lw;
+	float sq = 0.f;
+	for (int i = tid; i < Lw; i += 256) {
+		const float d = v[i] - avg;
+		sq = fmaf(d, d, sq);
+	}
+	const float stddev = sqrtf(block_sum(sq, red, tid) / (float)Lw);
+	const float th = avg + 3.0f * stddev;
+
+	// ---- threshold flags, 32 lags per word
+	for (int wd = tid; wd < 256; wd += 256) {
+		unsigned int f = 0;
+		for (int b = 0; b < 32; b++) {
+			const int i = wd * 32 + b;
+			if (i >= 1 && i < Lw - 1 && v[i] > th)
+				f |= 1u << b;
+		}
+		s_flags[wd] = f;
+	}
+	__syncthreads();
+
+	// ---- ordered tail: rising edges, 3-point interpolation, ranked de-duplicated list
+	if (tid == 0) {
+		int *toa = a.toa + (size_t)s * a.N;
+		float pwr[32];
+		const int N = a.N;
+		int n = 0;
+		const int sps = a.sps;
+		const int half = (a.burst_len * sps) >> 1;
+		bool prev = false;
+		for (int wd = 0; wd * 32 < Lw; wd++) {
+			unsigned int f = s_flags[wd];
+			if (!f) { prev = false; continue; }
+			for (int b = 0; b < 32; b++) {
+				const bool cur = (f >> b) & 1u;
+				if (cur && !prev) {
+					const int i = wd * 32 + b;
+					const float p_pwr = v[i - 1] + v[i] + v[i + 1];
+					const float p_fpos = (-v[i - 1] + v[i + 1]) / p_pwr;
+					const int p_pos = (int)round((double)(((float)i + p_fpos) * (float)sps));
+					// _peak_record
+					int has_dupe = 0;
+					for (int q = 0; q < n; q++) {
+						const int dd = (toa[q] % Lp) - (p_pos % Lp);
+						if (abs(dd) > half)
+							continue;
+						if (pwr[q] > p_pwr) {
+							if (!has_dupe) has_dupe = 1;
+							continue;
+						}
+						for (int j = q; j < n - 1; j++) { toa[j] = toa[j + 1]; pwr[j] = pwr[j + 1]; }
+						n--;
+						has_dupe = -1;
+					}
+					if (has_dupe <= 0) {
+						int q = 0;
+						for (; q < n; q++)
+							if (p_pwr > pwr[q]) break;
+						if (q != N) {
+							for (int j = N - 1; j > q; j--) { toa[j] = toa[j - 1]; pwr[j] = pwr[j - 1]; }
+							toa[q] = p_pos;
+							pwr[q] = p_pwr;
+							if (n != N) n++;
+						}
+					}
+				}
+				prev = cur;
+			}
+		}
+		a.count[s] = n;
+	}
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 int fcch_stat_tiles(int len) { return (len + kStatSpan - 1) / kStatSpan; }
@@ -488,6 +642,16 @@ hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t st)
 		return hipErrorInvalidValue;
 	if (a.toa)
 		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_fcch_multi(const FcchMultiArgs &a, hipStream_t st)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	if (a.Lw > 8192 || a.N > 32)
+		return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_fcch_multi, dim3(a.n), dim3(256), (size_t)a.Lw * 4, st, a);
 	return hipGetLastError();
 }
 

@@ -114,6 +114,14 @@ struct FcchRoughArgs {
 	int32_t *toa, *rv;
 };
 
+struct FcchMultiArgs {
+	int n, sps, burst_len, N;
+	int nlags, Lw, Lp;
+	const float *energy;  size_t energy_stride;
+	int32_t *toa;          // n x N
+	int32_t *count;        // n : peaks found, or -EINVAL
+};
+
 struct FcchFineArgs {
 	int n, sps, tab, mode;                  // mode 0 fine, 1 snr
 	const float2 *iq;
@@ -127,6 +135,7 @@ hipError_t upload_fcch_tables(const FcchTables *host, hipStream_t stream);
 int fcch_stat_tiles(int len);
 int fcch_lag_tiles(int nlags);
 hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t stream);
+hipError_t launch_fcch_multi(const FcchMultiArgs &a, hipStream_t stream);
 hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t stream);
 
 // ---- traffic-channel layer 1 (l1_kernels.hip) -------------------------------

@@ -91,3 +91,34 @@ def test_fcch3_long_chirp(gpu_api, orc, pkg):
     t, fe = gpu_api.fcch_fine_batch(b, np.zeros(1, np.uint64), sps=SPS, fcch_type="fcch3_lband")
     rv, ot, ofe = orc.fcch_fine(b, SPS, which="fcch3_lband")
     assert rv == 0 and t[0] == ot and abs(fe[0] - ofe) < 1e-4
+
+
+def test_fcch_rough_multi(gpu_api, orc, pkg):
+    """gmr1_fcch_rough_multi on 650 ms windows with 1-3 overlapping FCCH trains (fcch_multi_process,
+    gmr1_rx.c:658-664): ranked peak list identical to the oracle."""
+    rng = np.random.default_rng(13)
+    ns = 60840
+    n = 6
+    x = np.zeros((n, ns), np.complex64)
+    for i in range(n):
+        s, _ = pkg.synth.synth_fcch_stream(ns, SPS, rng, snr_db=6.0, cfo_hz=float(rng.uniform(-300, 300)),
+                                           first=int(rng.integers(200, 5000)))
+        for extra in range(i % 3):                       # overlay weaker trains at other offsets
+            s2, _ = pkg.synth.synth_fcch_stream(ns, SPS, rng, snr_db=3.0, cfo_hz=float(rng.uniform(-300, 300)),
+                                                first=int(rng.integers(8000, 25000)))
+            s = s + 0.7 * s2
+        x[i] = s
+    offset = (np.arange(n) * ns).astype(np.uint64)
+    cnt, toa = gpu_api.fcch_rough_multi_batch(x, offset, ns, sps=SPS, N=16)
+    for i in range(n):
+        orv, otoa = orc.fcch_rough_multi(x[i], SPS, N=16)
+        assert cnt[i] == orv, (i, cnt[i], orv)
+        assert list(toa[i, :max(orv, 0)]) == list(otoa), (i, toa[i], otoa)
+        assert orv >= 1
+    # single call, too-short window (-EINVAL like the reference), pure noise (no 320 ms periodicity)
+    rv, t = gpu_api.fcch_rough_multi(x[2], SPS, 0.0, 16)
+    assert rv == cnt[2] and list(t) == list(toa[2, :rv])
+    assert gpu_api.fcch_rough_multi(x[0][:30000], SPS)[0] == -22
+    noise = (rng.standard_normal(ns) + 1j * rng.standard_normal(ns)).astype(np.complex64)
+    g = gpu_api.fcch_rough_multi_batch(noise, np.zeros(1, np.uint64), ns, sps=SPS)[0][0]
+    assert g == orc.fcch_rough_multi(noise, SPS)[0]
