@@ -99,16 +99,30 @@ __global__ __launch_bounds__(256) void k_fcch_stats(FcchRoughArgs a)
 	const int end = min(begin + kStatSpan, a.len);
 	const int ndec = a.len / a.sps;
 	float sr = 0.f, si = 0.f, sq = 0.f;
-	for (int i = begin + (int)threadIdx.x; i < end; i += 256) {
-		const float2 v = in[i];
-		sr += v.x;
-		si += v.y;
-		sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
-		if (a.sps == 4) {
-			if ((i & 3) == 0 && (i >> 2) < ndec)
-				dec[i >> 2] = v;
-		} else if (i % a.sps == 0 && i / a.sps < ndec) {
-			dec[i / a.sps] = v;
+	const bool vec_ok = ((a.offset[s] & 1ull) == 0) && a.sps == 4 && (end - begin) == kStatSpan;
+	if (vec_ok) {
+		// 16-byte loads: two samples per lane, 4 loads in flight; sample 2t is the decimated one
+		// when (begin + 2t) % 4 == 0, i.e. on even t (begin is a multiple of 8192)
+		const float4 *in4 = reinterpret_cast<const float4 *>(in + begin);
+		const bool keep = (threadIdx.x & 1) == 0;
+#pragma unroll 4
+		for (int it = 0; it < kStatSpan / 512; it++) {
+			const float4 p = in4[it * 256 + (int)threadIdx.x];
+			sr += p.x + p.z;
+			si += p.y + p.w;
+			sq = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, fmaf(p.w, p.w, sq))));
+			const int di = (begin + it * 512 + 2 * (int)threadIdx.x) >> 2;
+			if (keep && di < ndec)
+				dec[di] = make_float2(p.x, p.y);
+		}
+	} else {
+		for (int i = begin + (int)threadIdx.x; i < end; i += 256) {
+			const float2 v = in[i];
+			sr += v.x;
+			si += v.y;
+			sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
+			if (i % a.sps == 0 && i / a.sps < ndec)
+				dec[i / a.sps] = v;
 		}
 	}
 	__shared__ float red[3][4];
@@ -207,6 +221,8 @@ __global__ __launch_bounds__(256) void k_fcch_corr(FcchRoughArgs a)
 		win[q] = xs[pad8(base + q)];
 	}
 	// tap n multiplies sample (lag + n): window slot q holds sample base + n + q
+	// (kept rolled: fully unrolled the 117 taps need 256 VGPRs and one wave per SIMD)
+#pragma unroll 1
 	for (int n0 = 0; n0 < NT; n0 += kLagsPerThread) {
 #pragma unroll
 		for (int u = 0; u < kLagsPerThread; u++) {

@@ -39,3 +39,50 @@ def bcch_ccch_mix(pkg, n, seed, esn0_db=(6.0, 10.0, 20.0), sps=4, toa_jitter=8, 
         iq[idx] = bb.iq
         toa[rows] = bb.toa
     return dict(iq=iq, offset=offset, kind=kind, l2=l2, toa=toa, esn0=esn0, in_len=lens)
+
+
+def fcch_streams(pkg, n, seed, n_samples=93600, sps=4, snr_db=(0.0, 6.0), cfo_hz=2000.0):
+    """n independent 1-s streams, AWGN + dual-chirp FCCH every 320 ms,
+    SNR 0 / +6 dB, CFO uniform +-2 kHz.  Returns dict(iq (n, n_samples) complex64, offset, starts)."""
+    synth = pkg.synth
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, n_samples * 2), dtype=np.float32).view(np.complex64)
+    x *= np.float32(1.0 / np.sqrt(2.0))
+    chirp = synth.fcch_dual_chirp(0.32, 117, sps)
+    period = 7488 * sps
+    first = rng.integers(0, period, size=n)
+    snr = rng.choice(np.asarray(snr_db, dtype=np.float64), size=n)
+    amp = np.sqrt(10.0 ** (snr / 10.0)).astype(np.float32)
+    starts = []
+    for i in range(n):
+        st = []
+        pos = int(first[i])
+        while pos + chirp.size <= n_samples:
+            x[i, pos:pos + chirp.size] += chirp * amp[i]
+            st.append(pos)
+            pos += period
+        starts.append(st)
+    cfo = rng.uniform(-cfo_hz, cfo_hz, size=n)
+    step = (2 * np.pi * cfo / (synth.SYM_RATE * sps)).astype(np.float32)
+    t = np.arange(n_samples, dtype=np.float32)
+    for i0 in range(0, n, 64):          # chunked to bound temporaries
+        ph = step[i0:i0 + 64, None] * t[None, :]
+        rot = np.empty(ph.shape, np.complex64)
+        rot.real = np.cos(ph)
+        rot.imag = np.sin(ph)
+        x[i0:i0 + 64] *= rot
+    offset = (np.arange(n, dtype=np.uint64) * np.uint64(n_samples))
+    return dict(iq=x, offset=offset, starts=starts, cfo=cfo, snr=snr, n_samples=n_samples)
+
+
+def tch3_bursts(pkg, n, seed, m=0, sigma=40.0):
+    """BASELINE.md config 5, l1-only variant: n NT3 speech bursts as int8 soft bits (212 each)."""
+    rng = np.random.default_rng(seed)
+    f0 = rng.integers(0, 256, (n, 10), dtype=np.uint8)
+    f1 = rng.integers(0, 256, (n, 10), dtype=np.uint8)
+    s = rng.integers(0, 2, (n, 4), dtype=np.uint8)
+    bits = pkg.synth.tch3_encode(f0, f1, s, m)
+    eb = 80.0 * (1.0 - 2.0 * bits.astype(np.float32))
+    eb += rng.standard_normal(eb.shape, dtype=np.float32) * np.float32(sigma)
+    eb = np.clip(np.rint(eb), -127, 127).astype(np.int8)
+    return dict(ebits=eb, frame0=f0, frame1=f1, status=s, m=m)
