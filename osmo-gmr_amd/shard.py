@@ -1,0 +1,107 @@
+"""Sharding of the receive path over the GPUs of one node (one process per GPU).
+
+The units of this path are independent: pre-cut bursts (configs 3 / 5) never
+interact except inside a FACCH3 group of 4, and ARFCNs (config 4) never interact at all.  So
+the compute is sharded with NO data-path collective; the only exchanges are the two the
+north star names, both outside the kernels:
+
+  * scatter of per-ARFCN IQ slices from the rank that holds the capture (point-to-point
+    send/recv, one peer per xGMI link -- not a ring),
+  * gather of the fixed-size decoded-frame records back to that rank.
+
+torch.distributed is plumbing here: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
+CPU tests (tests/test_shard.py runs world_size 2).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# decoded frame record, 40 bytes
+RECORD_DTYPE = np.dtype([
+    ("arfcn", "<u2"), ("chain", "u1"), ("type", "u1"), ("fn", "<u4"),
+    ("tn", "u1"), ("crc", "u1"), ("len", "u1"), ("pad", "u1"),
+    ("conv", "<i4"), ("l2", "u1", (24,)),
+])
+assert RECORD_DTYPE.itemsize == 40
+
+
+def partition_contiguous(n_units: int, world: int, rank: int, group: int = 1):
+    """Contiguous block [start, stop) of `n_units` for `rank`; block edges fall on multiples of
+    `group` (FACCH3: 4 bursts form one frame and must stay on one GPU)."""
+    n_groups = -(-n_units // group)
+    per = -(-n_groups // world)
+    g0 = min(rank * per, n_groups)
+    g1 = min(g0 + per, n_groups)
+    return min(g0 * group, n_units), min(g1 * group, n_units)
+
+
+def owner_of_arfcn(arfcn_index: int, world: int) -> int:
+    """ARFCN a -> rank a mod world (8 ARFCN per GPU for the 64-ARFCN capture of config 4)."""
+    return arfcn_index % world
+
+
+def my_arfcns(n_arfcn: int, world: int, rank: int):
+    return [a for a in range(n_arfcn) if owner_of_arfcn(a, world) == rank]
+
+
+def scatter_iq(slices, n_arfcn: int, n_samples: int, src: int = 0, device=None):
+    """Rank `src` holds `slices[a]` (complex64 tensors of n_samples); every rank returns
+    {arfcn: tensor} for the ARFCNs it owns.  Point-to-point isend/irecv, all in flight at once."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = my_arfcns(n_arfcn, world, rank)
+    out = {}
+    ops = []
+    if rank == src:
+        for a in range(n_arfcn):
+            r = owner_of_arfcn(a, world)
+            t = torch.view_as_real(slices[a]).contiguous()
+            if device is not None:
+                t = t.to(device)
+            if r == src:
+                out[a] = torch.view_as_complex(t)
+            else:
+                ops.append(dist.P2POp(dist.isend, t, r, tag=a))
+    else:
+        bufs = {}
+        for a in mine:
+            bufs[a] = torch.empty((n_samples, 2), dtype=torch.float32, device=device)
+            ops.append(dist.P2POp(dist.irecv, bufs[a], src, tag=a))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != src:
+        out = {a: torch.view_as_complex(b) for a, b in bufs.items()}
+    return out
+
+
+def gather_records(records: np.ndarray, dst: int = 0, device=None):
+    """Gather variable-length record arrays (RECORD_DTYPE) on rank `dst`.
+
+    Counts travel by all_gather (world x 8 bytes), payloads as padded fixed-size blocks.
+    Returns the concatenation ordered by (arfcn, fn, tn, chain) on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+    cnt = torch.tensor([records.size], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(c.item()) for c in counts]
+    cap = max(max(counts), 1)
+    buf = np.zeros(cap, dtype=RECORD_DTYPE)
+    buf[:records.size] = records
+    payload = torch.from_numpy(buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize).copy())
+    if device is not None:
+        payload = payload.to(device)
+    blocks = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(blocks, payload)      # < 0.5 MB in total for an ARFCN-minute: latency bound
+    if rank != dst:
+        return None
+    parts = [blocks[r].cpu().numpy().reshape(-1).view(RECORD_DTYPE)[:counts[r]] for r in range(world)]
+    allr = np.concatenate(parts) if parts else np.zeros(0, RECORD_DTYPE)
+    order = np.lexsort((allr["chain"], allr["tn"], allr["fn"], allr["arfcn"]))
+    return allr[order]

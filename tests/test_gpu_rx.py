@@ -215,3 +215,29 @@ def test_detect_and_mod_order(gpu_api, orc, pkg):
         assert order[i] == orc.mod_order(iq[i], sps), i
     assert (order == np.where(truth == 1, 4, 2)).mean() >= 0.8      # the estimator itself errs at 8 dB
     assert gpu_api.pi4cxpsk_mod_order(iq[1], sps) == order[1]
+
+
+def test_fused_rx_full_size_properties(gpu_api, orc, pkg):
+    """BASELINE.json configs[2] at full size (100 000 bursts): size-independent properties --
+    every CRC-passing burst returns exactly the payload that was sent, the pass rate is what the
+    channel allows, two runs are bit-identical, and a strided sample agrees with the oracle."""
+    n = 100_000
+    wl = workloads.bcch_ccch_mix(pkg, n=n, seed=3)
+    a = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4, want_ebits=False, want_ssyms=False)
+    b = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4, want_ebits=False, want_ssyms=False)
+    for k in ("l2", "crc", "conv", "toa", "freq_err", "rv"):
+        assert np.array_equal(a[k], b[k]), f"run-to-run difference in {k}"
+    good = a["crc"] == 0
+    assert not a["rv"].any()
+    assert good.mean() > 0.95
+    assert np.array_equal(a["l2"][good], wl["l2"][good])
+    assert np.abs(a["toa"][good] - wl["toa"][good]).max() < 2.5       # TOA estimate tracks the truth
+    # a checksum of checksums over the payloads, against the generator's
+    assert int(a["l2"][good].astype(np.uint64).sum()) == int(wl["l2"][good].astype(np.uint64).sum())
+    # strided sample vs the oracle (CRC verdicts and payloads)
+    idx = np.arange(0, n, 53)
+    sub_off = wl["offset"][idx]
+    ref = orc.demod_decode_batch(wl["iq"], sub_off, wl["kind"][idx], sps=4, want_ebits=False, want_ssyms=False)
+    assert np.array_equal(ref["crc"], a["crc"][idx])
+    ok = ref["crc"] == 0
+    assert np.array_equal(ref["l2"][ok], a["l2"][idx][ok])
