@@ -254,9 +254,11 @@ __host__ __device__ inline size_t lds_layout(int max_in_len, int max_len, bool d
 	if (decode && xbytes < dec_bytes)
 		xbytes = align16(dec_bytes);
 	off[0] = o; o += xbytes;
-	(void)max_len;                        // symbols are no longer staged in LDS
-	const size_t aux = kMaxWindow * 4 + kMaxCoef * 8;
-	off[1] = o; o += aux;
+	// aux = correlation accumulator + rotated sync reference.  The fused BCCH / CCCH path knows
+	// its formats (<= max_len lags, 17 sync symbols), which keeps 15 wavefronts per CU resident
+	const size_t corr_bytes = decode ? align16((size_t)max_len * 4) : (size_t)kMaxWindow * 4;
+	const size_t coef_bytes = decode ? 32 * 8 : (size_t)kMaxCoef * 8;
+	off[1] = o; o += corr_bytes + coef_bytes;
 	off[2] = o; o += decode ? 4 * kEbRow : kEbitsLds;
 	return align16(o);
 }
@@ -268,7 +270,7 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *raw, int max_in_len, int
 	Lds L;
 	L.x = reinterpret_cast<float2 *>(raw + off[0]);
 	L.corr = reinterpret_cast<float *>(raw + off[1]);
-	L.coef = reinterpret_cast<float2 *>(raw + off[1] + kMaxWindow * 4);
+	L.coef = reinterpret_cast<float2 *>(raw + off[1] + (decode ? align16((size_t)max_len * 4) : (size_t)kMaxWindow * 4));
 	L.y = reinterpret_cast<float2 *>(raw + off[1]);
 	L.eb = reinterpret_cast<int8_t *>(raw + off[2]);
 	L.bm = reinterpret_cast<uint32_t *>(raw + off[0]);
@@ -304,6 +306,10 @@ __device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, in
 	}
 	sr = wave_sum(sr);
 	si = wave_sum(si);
+	// mean / sigma only fix the DC offset and an overall scale that nothing downstream depends
+	// on, so reciprocals (1 ulp) stand in for the reference's divisions and square root
+	const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
+	// (the mean keeps the true division: a constant window must normalise to exactly zero)
 	const float avr = sr / (float)in_len, avi = si / (float)in_len;
 	float acc = 0.f;
 #pragma unroll
@@ -314,11 +320,11 @@ __device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, in
 			acc = fmaf(v[k].x, v[k].x, fmaf(v[k].y, v[k].y, acc));
 		}
 	}
-	float sigma = wave_sum(acc) / (float)in_len;
-	float stddev = sqrtf(sigma);
+	float sigma = wave_sum(acc) * inv_n;
+	float stddev = __builtin_amdgcn_sqrtf(sigma);
 	if (stddev == 0.0f)
 		stddev = 1.0f;
-	const float inv = 1.0f / stddev;
+	const float inv = __builtin_amdgcn_rcpf(stddev);
 #pragma unroll
 	for (int k = 0; k < NPL; k++) {
 		if (k < nfull || (k == nfull && tail))
@@ -458,7 +464,7 @@ __device__ int sync_search(int type, int in_len, int sps_rt, float fs, const Lds
 		}
 		const float s_toa = early + 1.0f;
 		float pk = half_total(interp_term(s_toa), 0);
-		pk = pk / (float)tl;
+		pk = pk * __builtin_amdgcn_rcpf((float)tl);     // only ranked and tested against 0
 		const float s_pwr = pk * pk;
 		if (s_pwr > p_pwr) {
 			p_pwr = s_pwr;
@@ -1042,7 +1048,8 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 	if (max_in_len > kMaxInLen)
 		return hipErrorInvalidValue;
 	// symbols per burst: fused path is BCCH/DC6 (234); generic path sizes for the longest format
-	const int max_len = decode ? 234 : 468;
+	// third kernel argument: lags the correlation accumulator must hold (fused path: 20*sps + 1)
+	const int max_len = decode ? (20 * a.sps + 1) : kMaxWindow;
 	if (max_in_len <= 1024) {
 		if (a.sps == 4)
 			return launch_rx_t<16, 4>(a, decode, max_in_len, max_len, stream);
