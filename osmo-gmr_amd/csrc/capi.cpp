@@ -402,6 +402,14 @@ int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
 	a.ebits_stride = 432;
 	a.ssyms_stride = 234;
 	a.dbg_stop = dbg_stop_env();
+	{
+		static int impl = -1;
+		if (impl < 0) {
+			const char *e = getenv("GMR1_HIP_RX_IMPL");
+			impl = e ? atoi(e) : 0;
+		}
+		a.impl = impl;
+	}
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.kind = kind; a.freq_shift = freq_shift;
 	a.l2 = l2; a.crc = crc; a.conv = conv; a.toa = toa; a.freq_err = freq_err;

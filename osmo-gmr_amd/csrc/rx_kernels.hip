@@ -285,7 +285,8 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *raw, int max_in_len, int
 
 // window HBM -> registers -> LDS, DC and power normalised
 template <int NPL>
-__device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, int in_len, const Lds &L, int lane)
+__device__ __forceinline__ void load_normalise_stats(const float2 *__restrict__ in, int in_len, const Lds &L, int lane,
+                                                     float &avr_o, float &avi_o, float &inv_o)
 {
 	// ---- load + normalise (osmo_cxvec_sig_normalize, decim 1) ------------------
 	// rows k < nfull are whole (no lane test); row nfull is the ragged tail
@@ -330,6 +331,16 @@ __device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, in
 		if (k < nfull || (k == nfull && tail))
 			L.x[lane + 64 * k] = make_float2(v[k].x * inv, v[k].y * inv);
 	}
+	avr_o = avr;
+	avi_o = avi;
+	inv_o = inv;
+}
+
+template <int NPL>
+__device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, int in_len, const Lds &L, int lane)
+{
+	float a, b, c;
+	load_normalise_stats<NPL>(in, in_len, L, lane, a, b, c);
 }
 
 // sync sequence search over the normalised window in L.x with derotation step fs (rad/sample).
@@ -904,6 +915,472 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 }
 
 // ---------------------------------------------------------------------------
+// k_rx4 -- fused BCCH / CCCH receive, four bursts per wavefront, with the serial phases
+// (timing bisection, sync-symbol arithmetic) done ONCE for the four bursts, one burst per
+// 16-lane row, instead of once per burst with most lanes idle:
+//
+//   pass 1, per burst : load + normalise -> LDS window, sync correlation -> corr[q][.]
+//   rows              : peak window argmax, early/late bisection (21 taps on 16 lanes),
+//                       interpolated peak power                       -> toa, rv per row
+//   rows              : sync symbols re-read from L2 / Infinity Cache, chunk sums,
+//                       fine frequency error, carrier phase           -> ffe, psi per row
+//   pass 2, per burst : 234 symbols re-read (stride sps), phase-domain soft symbols / bits
+//   rows              : branch metrics, Viterbi, traceback, CRC (decode4_k5_12)
+//
+// The second read of a burst happens a few microseconds after the first and is served by the
+// L2 / Infinity Cache; it buys back ~650 VALU instructions per burst.
+// Single-sequence burst formats only (BCCH, DC6), which is all the fused path handles.
+// ---------------------------------------------------------------------------
+struct Lds4 {
+	float2 *x;        // normalised window of the burst being correlated   [max_in_len]
+	float *corr;      // 4 x cw correlation magnitudes
+	float2 *coef;     // 32 rotated sync reference values
+	int8_t *eb;       // 4 soft-bit rows
+	uint32_t *bm;     // overlays x after pass 1
+	uint64_t *surv;
+	uint32_t *ubits;
+};
+
+__host__ __device__ inline size_t lds4_layout(int max_in_len, int cw, size_t *off)
+{
+	size_t o = 0;
+	size_t xbytes = align16((size_t)max_in_len * 8);
+	const size_t dec_bytes = 4 * kSteps12 * 4 + kSteps12 * 8 + 4 * 8 * 4;
+	if (xbytes < dec_bytes)
+		xbytes = align16(dec_bytes);
+	// the window is dead once pass 1 is over: soft-bit rows, branch metrics, survivors and decoded
+	// bits all overlay it; only the correlation magnitudes and the sync reference sit beside it
+	if (xbytes < dec_bytes + 4 * 432)
+		xbytes = align16(dec_bytes + 4 * 432);
+	off[0] = o; o += xbytes;
+	off[1] = o; o += align16((size_t)4 * cw * 4);
+	off[2] = o; o += 18 * 8;
+	off[3] = dec_bytes;            // soft-bit rows, inside the window region
+	return align16(o);
+}
+
+// 64-bit max within each 16-lane row
+template <int X>
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
+{
+	const uint32_t lo = row_xor<X>((uint32_t)k), hi = row_xor<X>((uint32_t)(k >> 32));
+	const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+	return o > k ? o : k;
+}
+
+template <int NPL, int SPS>
+__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int max_in_len, int cw)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const int lane = threadIdx.x;
+	const int row = lane >> 4, col = lane & 15;
+	const int sps = SPS ? SPS : a.sps;
+	size_t off[4];
+	lds4_layout(max_in_len, cw, off);
+	Lds4 L;
+	L.x = reinterpret_cast<float2 *>(lds_raw + off[0]);
+	L.corr = reinterpret_cast<float *>(lds_raw + off[1]);
+	L.coef = reinterpret_cast<float2 *>(lds_raw + off[2]);
+	L.eb = reinterpret_cast<int8_t *>(lds_raw + off[3]);
+	L.bm = reinterpret_cast<uint32_t *>(lds_raw + off[0]);
+	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[0] + 4 * kSteps12 * 4);
+	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + 4 * kSteps12 * 4 + kSteps12 * 8);
+	Lds Lx;                      // view for load_normalise
+	Lx.x = L.x;
+
+	const int g0 = blockIdx.x * 4;
+	const int g_row = g0 + row;                       // this row's burst
+	const bool row_live = g_row < a.n;
+
+	// per-row (lane-resident) burst parameters
+	const int kind_r = row_live ? (a.kind[g_row] ? 1 : 0) : 0;
+	const int type_r = kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
+	const int in_len_r = a.in_len[kind_r];
+	const float fsh_r = (row_live && a.freq_shift) ? a.freq_shift[g_row] : 0.0f;
+	const DevBurst &bt_r = c_types[type_r];
+	const float fs_r = (fsh_r - bt_r.rotation) / (float)sps;     // pi4cxpsk.c:539
+	const int w_r = in_len_r - bt_r.len * sps + 1;
+	const float2 *__restrict__ in_r = a.iq + (row_live ? a.offset[g_row] : 0);
+	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
+
+	// =========================== pass 1: correlation magnitudes ===========================
+	for (int q = 0; q < 4; q++) {
+		const int g = g0 + q;
+		if (g >= a.n)
+			break;
+		const int kind = __builtin_amdgcn_readfirstlane(a.kind[g] ? 1 : 0);
+		const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
+		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
+		const DevBurst &bt = c_types[type];
+		const int nbits = bt.nbits;
+		const int w = in_len - bt.len * sps + 1;
+		const float fsh = a.freq_shift ? a.freq_shift[g] : 0.0f;
+		const float fs = (fsh - bt.rotation) / (float)sps;
+
+		WSYNC();
+		float avr, avi, inv;
+		load_normalise_stats<NPL>(a.iq + a.offset[g], in_len, Lx, lane, avr, avi, inv);
+		if (row == q) { avr_r = avr; avi_r = avi; }
+
+		// rotated reference of the (single) sync sequence
+		const int tl = bt.sync_tl[0];
+		const int nch = bt.n_chunks[0];
+		for (int n = lane; n < tl; n += 64) {
+			int ch = 0, base = 0, cum = 0;
+			for (int c = 0; c < nch - 1; c++) {
+				cum += bt.sync[0][c].len;
+				if (n >= cum) { base = cum; ch = c + 1; }
+			}
+			const int nn = n - base;
+			float s, c;
+			sincos_fast(fs * (float)(nn * sps), s, c);
+			L.coef[n] = conj_ref_mul(nbits, bt.sync[0][ch].syms[nn], make_float2(c, s));
+		}
+		WSYNC();
+		float *corr = L.corr + q * cw;
+		for (int j = lane; j < w; j += 64) {
+			float cj = 0.f;
+			int base = 0;
+			for (int ch = 0; ch < nch; ch++) {
+				const int pos = bt.sync[0][ch].pos, len = bt.sync[0][ch].len;
+				const float2 *xp = L.x + pos * sps + j;
+				const float2 *cp = L.coef + base;
+				float ar = 0.f, ai = 0.f;
+				for (int n = 0; n < len; n++) {
+					const float2 x = xp[n * sps];
+					const float2 cf = cp[n];
+					ar = fmaf(cf.x, x.x, fmaf(-cf.y, x.y, ar));
+					ai = fmaf(cf.x, x.y, fmaf(cf.y, x.x, ai));
+				}
+				base += len;
+				cj += sqrtf(fmaf(ar, ar, ai * ai));
+			}
+			corr[j] = cj;
+		}
+	}
+	WSYNC();
+	if (a.dbg_stop == 2) return;
+
+	// =========================== rows: peak + early/late timing ===========================
+	// osmo_cxvec_peak_energy_find(corr, 3, PEAK_EARLY_LATE, &peak), pi4cxpsk.c:240
+	const float *cr = L.corr + row * cw;
+	const int win = w_r < 3 ? w_r : 3;
+	unsigned long long key = 0;
+	for (int m = col; m + win <= w_r; m += 16) {
+		float e = 0.f;
+		for (int k = 0; k < win; k++) {
+			const float c = cr[m + k];
+			e += c * c;
+		}
+		const unsigned long long kk = ((unsigned long long)__builtin_bit_cast(uint32_t, e) << 32) | (uint32_t)(~m);
+		key = kk > key ? kk : key;
+	}
+	key = row_max_u64<1>(key);
+	key = row_max_u64<2>(key);
+	key = row_max_u64<4>(key);
+	key = row_max_u64<8>(key);
+	int mi = (int)(~(uint32_t)key);
+	if (mi < 0 || mi + win > w_r)
+		mi = 0;
+	int p = mi;
+	{
+		float pe = -1.f;
+		for (int k = 0; k < win; k++) {
+			const float c = cr[mi + k];
+			const float e = c * c;
+			if (e > pe) { pe = e; p = mi + k; }
+		}
+	}
+	// interpolated correlation at `pos` and at `pos + 2` (same fractional part, same weights):
+	// lane col holds taps k = col - 10 and k = col + 6 (the latter for col < 5): 21 taps
+	auto interp2 = [&](float pos, float &se, float &sl) {
+		const float fl = floorf(pos);
+		const int i0 = (int)fl;
+		const float f = pos - fl;
+		const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f)
+		const float sg = (col & 1) ? S : -S;                   // k has the parity of col
+		float acc_e = 0.f, acc_l = 0.f;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int k = col - 10 + 16 * h;
+			const float xx = kPif * ((float)k - f);
+			const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
+			const bool tap = (h == 0) || (col < 5);
+#pragma unroll
+			for (int pt = 0; pt < 2; pt++) {
+				const int ib = i0 + 2 * pt;
+				int b = ib - 10, e = ib + 11;
+				if (b < 0) b = 0;
+				if (e >= w_r) e = w_r - 1;
+				const int i = ib + k;
+				const bool valid = tap && i >= b && i < e;
+				const float c = cr[valid ? i : 0];
+				const float term = valid ? c * wgt : 0.0f;
+				if (pt == 0) acc_e += term; else acc_l += term;
+			}
+		}
+		se = row_sum(acc_e);
+		sl = row_sum(acc_l);
+	};
+	float early = (float)p - 1.0f, incr = 0.5f;
+	bool active = true;
+#pragma unroll 1
+	for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
+		float se, sl;
+		interp2(early, se, sl);
+		const float ee = se * se, le = sl * sl;
+		if (active) {
+			if (ee > le) early -= incr;
+			else if (ee < le) early += incr;
+			else active = false;
+		}
+		incr *= 0.5f;
+	}
+	const float toa_r = early + 1.0f;
+	float pk, dummy;
+	interp2(toa_r, pk, dummy);
+	pk = pk * __builtin_amdgcn_rcpf((float)bt_r.sync_tl[0]);
+	const bool found_r = (pk * pk) > 0.0f;            // p_pwr starts at 0: needs strictly more
+	if (a.dbg_stop == 3) return;
+	const int d_r = (int)roundf(toa_r);
+
+	// pass-2 operands of a burst (its 234 symbols at stride sps from sample d, re-read from
+	// L2 / Infinity Cache): fetched one burst ahead of their use
+	struct Sym4 { float2 x[4]; int ord[4]; int ok; };
+	auto fetch = [&](int q, Sym4 &o) {
+		const int g = g0 + q;
+		o.ok = 0;
+#pragma unroll
+		for (int r = 0; r < 4; r++) { o.x[r] = make_float2(0.f, 0.f); o.ord[r] = -1; }
+		if (g >= a.n)
+			return;
+		const int src = 16 * q;
+		const int kind = __builtin_amdgcn_readlane(kind_r, src);
+		const DevBurst &bt = c_types[kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH];
+		const int in_len = __builtin_amdgcn_readlane(in_len_r, src);
+		const int d = __builtin_amdgcn_readlane(d_r, src);
+		const float2 *__restrict__ in = a.iq + a.offset[g];
+		const int blen = bt.len;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int i = lane + 64 * r;
+			const int j = i * sps + d;
+			if (i < blen) {
+				o.ord[r] = bt.ord_of_sym[i];
+				if (j >= 0 && j < in_len) {
+					o.x[r] = in[j];
+					o.ok |= 1 << r;
+				}
+			}
+		}
+	};
+	Sym4 first;
+	fetch(0, first);
+
+	// =========================== rows: sync symbols, frequency, phase ===========================
+	const int nbits_r = bt_r.nbits;
+	const int nch_r = bt_r.n_chunks[0];
+	const int tl_r = bt_r.sync_tl[0];
+	float ffe_r = 0.f, psi_r = 0.f;
+	{
+		// lane col holds sync symbols n = col and n = col + 16 (< tl <= 32)
+		float2 t0[2];
+		int chn[2], spos[2];
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			const int n = col + 16 * h;
+			t0[h] = make_float2(0.f, 0.f);
+			chn[h] = -1;
+			spos[h] = 0;
+			if (n < tl_r && row_live) {
+				int ch = 0, base = 0, cum = 0;
+				for (int c = 0; c < nch_r - 1; c++) {
+					cum += bt_r.sync[0][c].len;
+					if (n >= cum) { base = cum; ch = c + 1; }
+				}
+				const int nn = n - base;
+				const int sp = bt_r.sync[0][ch].pos + nn;
+				const int idx = sp * sps + d_r;
+				float2 x = make_float2(0.f, 0.f);
+				if (idx >= 0 && idx < in_len_r) {
+					x = in_r[idx];
+					x.x -= avr_r;
+					x.y -= avi_r;
+				}
+				float s, c;
+				sincos_fast(fs_r * (float)idx, s, c);
+				x = cmul(x, make_float2(c, s));
+				t0[h] = conj_ref_mul(nbits_r, bt_r.sync[0][ch].syms[nn], x);
+				chn[h] = ch;
+				spos[h] = sp;
+			}
+		}
+		// chunk sums (pi4cxpsk.c:381-389); the window scale 1/sigma is irrelevant to every angle
+		if (nch_r > 1) {
+			float sumr[4], sumi[4];
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const float pr = (chn[0] == c ? t0[0].x : 0.f) + (chn[1] == c ? t0[1].x : 0.f);
+				const float pi = (chn[0] == c ? t0[0].y : 0.f) + (chn[1] == c ? t0[1].y : 0.f);
+				sumr[c] = row_sum(pr);
+				sumi[c] = row_sum(pi);
+			}
+			float f = 0.f;
+#pragma unroll
+			for (int i = 1; i < 4; i++) {
+				if (i < nch_r) {
+					const float ppos = (float)bt_r.sync[0][i - 1].pos + (float)bt_r.sync[0][i - 1].len / 2.0f;
+					const float cpos = (float)bt_r.sync[0][i].pos + (float)bt_r.sync[0][i].len / 2.0f;
+					const float re = sumr[i] * sumr[i - 1] - sumi[i] * (-sumi[i - 1]);
+					const float im = sumr[i] * (-sumi[i - 1]) + sumi[i] * sumr[i - 1];
+					f += atan2_fast(im, re) / (cpos - ppos);
+				}
+			}
+			ffe_r = f / (float)(nch_r - 1);
+		}
+		// carrier phase of the frequency-corrected sync symbols (pi4cxpsk.c:415-433,574-575)
+		float tr = 0.f, ti = 0.f;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			float2 tt = t0[h];
+			if (ffe_r != 0.0f) {
+				float s, c;
+				sincos_fast(-ffe_r * (float)spos[h], s, c);
+				tt = cmul(tt, make_float2(c, s));
+			}
+			tr += tt.x;
+			ti += tt.y;
+		}
+		psi_r = atan2_fast(row_sum(ti), row_sum(tr));
+	}
+	if (a.dbg_stop == 5) return;
+
+	// per-burst results
+	if (col == 0 && row_live) {
+		const int rv = found_r ? 0 : -1;
+		a.rv[g_row] = rv;
+		if (a.sync_id) a.sync_id[g_row] = found_r ? 0 : -1;
+		if (a.toa) a.toa[g_row] = found_r ? toa_r : 0.f;
+		if (a.freq_err) a.freq_err[g_row] = found_r ? ffe_r : 0.f;
+	}
+
+	// =========================== pass 2: soft symbols / soft bits ===========================
+	int row_ok = 0, row_chain = 0;
+	Sym4 cur = first;
+	for (int q = 0; q < 4; q++) {
+		const int g = g0 + q;
+		if (g >= a.n)
+			break;
+		Sym4 nxt;
+		if (q + 1 < 4)
+			fetch(q + 1, nxt);          // next burst's samples travel while this one is worked on
+		const int src = 16 * q;
+		const bool found = __builtin_amdgcn_readlane((int)found_r, src) != 0;
+		const int kind = __builtin_amdgcn_readlane(kind_r, src);
+		const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
+		const DevBurst &bt = c_types[type];
+		const int d = __builtin_amdgcn_readlane(d_r, src);
+		const float fs = lane_val(fs_r, src);
+		const float rps = -lane_val(ffe_r, src);
+		const float psi = lane_val(psi_r, src);
+		const float avr = lane_val(avr_r, src), avi = lane_val(avi_r, src);
+		const int blen = bt.len, nbits = bt.nbits;
+		float *gss = a.ssyms ? a.ssyms + (size_t)g * a.ssyms_stride : nullptr;
+		int8_t *eb = L.eb + q * 432;
+		row_chain |= kind << q;
+		if (!found) {
+			if (a.ebits)
+				for (int i = lane; i < a.ebits_stride; i += 64)
+					a.ebits[(size_t)g * a.ebits_stride + i] = 0;
+			if (gss)
+				for (int i = lane; i < blen; i += 64)
+					gss[i] = 0.f;
+			cur = nxt;
+			continue;
+		}
+		row_ok |= 1 << q;
+		const float inv_dd = (float)(1 << nbits) / (2.0f * kPif);
+		const int mask = (1 << nbits) - 1;
+		auto reduce_2pi = [](float v) -> float {
+			const float k = rintf(v * 0.159154943091895336f);
+			v = fmaf(-k, 6.2831854820251465f, v);
+			return fmaf(-k, -1.7484555e-7f, v);
+		};
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int i = lane + 64 * r;
+			if (i >= blen)
+				continue;
+			const int j = i * sps + d;
+			float2 x = cur.x[r];
+			if (cur.ok & (1 << r)) {
+				x.x -= avr;
+				x.y -= avi;
+			}
+			float th = atan2_fast(x.y, x.x) + reduce_2pi(fs * (float)j);
+			th = reduce_2pi(fmaf(rps, (float)i, th) - psi);
+			const float sv = (x.x == 0.0f && x.y == 0.0f) ? 0.0f : th * inv_dd;   // cargf(0) = 0
+			if (gss)
+				gss[i] = sv;
+			const int ord = cur.ord[r];
+			if (ord >= 0) {
+				const float svr2 = roundf(sv);
+				const int sp = (int)svr2 & mask;
+				const int ss = (svr2 > sv ? (sp - 1) : (sp + 1)) & mask;
+				const int dq = (int)roundf((2.0f * fabsf(svr2 - sv)) * 64.0f);
+				const int p0 = sp >> 1, p1 = (sp ^ (sp >> 1)) & 1;
+				const int s0 = ss >> 1, s1 = (ss ^ (ss >> 1)) & 1;
+				const int v0 = 127 - ((p0 ^ s0) ? dq : (dq >> 1));
+				const int v1 = 127 - ((p1 ^ s1) ? dq : (dq >> 1));
+				const uint32_t pk2 = (uint32_t)(uint8_t)(int8_t)(p0 ? -v0 : v0) |
+				                     ((uint32_t)(uint8_t)(int8_t)(p1 ? -v1 : v1) << 8);
+				*reinterpret_cast<uint16_t *>(eb + 2 * ord) = (uint16_t)pk2;
+			}
+		}
+		if (a.ebits) {
+			WSYNC();
+			const int neb = bt.ebits;
+			int8_t *ge = a.ebits + (size_t)g * a.ebits_stride;
+			for (int i = lane; i < a.ebits_stride; i += 64)
+				ge[i] = i < neb ? eb[i] : (int8_t)0;
+		}
+		cur = nxt;
+	}
+	if (a.dbg_stop && a.dbg_stop < 7)
+		return;
+
+	// =========================== rows: layer 1 ===========================
+	WSYNC();     // the window is dead: bm / surv / ubits overlay it
+	for (int q = 0; q < 4; q++) {
+		if ((row_ok >> q) & 1) {
+			branch_metrics_k5_12(L.eb + q * 432, (row_chain >> q) & 1, L.bm + q * kSteps12, lane);
+		} else {
+			for (int k = lane; k < kSteps12; k += 64)
+				L.bm[q * kSteps12 + k] = 0;
+		}
+	}
+	WSYNC();
+	if (a.dbg_stop == 7)
+		return;
+	uint32_t syn, fae;
+	decode4_k5_12(L.bm, L.surv, L.ubits, lane, syn, fae);
+	if (col == 0 && row_live) {
+		if ((row_ok >> row) & 1) {
+			store_l2(a.l2 + (size_t)g_row * 24, L.ubits + row * 8);
+			a.crc[g_row] = syn ? 1 : 0;
+			a.conv[g_row] = (int32_t)fae;
+		} else {
+			uint32_t *l2w = reinterpret_cast<uint32_t *>(a.l2 + (size_t)g_row * 24);
+#pragma unroll
+			for (int i = 0; i < 6; i++)
+				l2w[i] = 0;
+			a.crc[g_row] = -1;
+			a.conv[g_row] = 0;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
 // burst type detection (reference src/sdr/pi4cxpsk.c:617-682 gmr1_pi4cxpsk_detect):
 // normalise once with the rotation of the first candidate type, run the sync search of
 // every candidate, weight the power by 1/|e_toa - toa|, keep the strongest.
@@ -1034,7 +1511,14 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 	const size_t lds = lds_layout(max_in_len, max_len, decode, off);
 	if (decode) {
 		const int grid = (a.n + 3) / 4;
-		hipLaunchKernelGGL((k_rx<NPL, SPS, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
+		if (a.impl == 1) {
+			hipLaunchKernelGGL((k_rx<NPL, SPS, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
+		} else {
+			const int cw = (max_len + 15) & ~15;
+			size_t off4[4];
+			const size_t lds4 = lds4_layout(max_in_len, cw, off4);
+			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid), dim3(64), lds4, stream, a, max_in_len, cw);
+		}
 	} else {
 		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
 	}
