@@ -259,7 +259,7 @@ def main():
                    "bursts_per_gpu": n, "global_bursts": world * n, "sps": 4,
                    "parallelism": f"bursts sharded over {world} rank(s), no collective"},
         "iq_msamp_per_s": world * (n_bcch * 1016 + (n - n_bcch) * 976) * args.steps / wall / 1e6,
-        "roofline": {"bound": "hbm", "kernel": "k_rx<16,true>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_rx4<16,4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         "checks": {"crc_pass_frac": decoded_frac, "payloads_match_sent": payload_ok,

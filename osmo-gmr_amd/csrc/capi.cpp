@@ -416,6 +416,19 @@ int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
 	a.ebits = ebits; a.ssyms = ssyms; a.rv = rv;
 	if (a.in_len[0] > kMaxInLen)
 		return fail(-EINVAL, "rx_bcch_ccch: window too long");
+	{
+		// samples of the sync-chunk windows: sum over chunks of len*sps + w - 1
+		const int ty[2] = {GMR1_HIP_BCCH, GMR1_HIP_DC6};
+		a.stage_samples = 0;
+		for (int k = 0; k < 2; k++) {
+			const DevBurst &bt = g_host_types[ty[k]];
+			const int w = a.in_len[k] - bt.len * sps + 1;
+			int tot = 0;
+			for (int c = 0; c < bt.n_chunks[0]; c++)
+				tot += bt.sync[0][c].len * sps + w - 1;
+			if (tot > a.stage_samples) a.stage_samples = tot;
+		}
+	}
 	HIP_TRY(launch_rx(a, true, a.in_len[0], (hipStream_t)stream));
 	return 0;
 }

@@ -336,6 +336,46 @@ __device__ __forceinline__ void load_normalise_stats(const float2 *__restrict__ 
 	inv_o = inv;
 }
 
+// window statistics only (mean, 1/sigma); the samples stay in registers and are dropped
+template <int NPL>
+__device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in_len, int lane,
+                                           float &avr_o, float &avi_o, float &inv_o)
+{
+	float2 v[NPL];
+	float sr = 0.f, si = 0.f;
+	const int nfull = in_len >> 6;
+	const bool tail = (lane + 64 * nfull) < in_len;
+#pragma unroll
+	for (int k = 0; k < NPL; k++) {
+		if (k < nfull)
+			v[k] = in[lane + 64 * k];
+		else if (k == nfull && tail)
+			v[k] = in[lane + 64 * k];
+		else
+			v[k] = make_float2(0.f, 0.f);
+		sr += v[k].x;
+		si += v[k].y;
+	}
+	sr = wave_sum(sr);
+	si = wave_sum(si);
+	const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
+	const float avr = sr / (float)in_len, avi = si / (float)in_len;     // true division, see load_normalise
+	float acc = 0.f;
+#pragma unroll
+	for (int k = 0; k < NPL; k++) {
+		if (k < nfull || (k == nfull && tail)) {
+			const float dx = v[k].x - avr, dy = v[k].y - avi;
+			acc = fmaf(dx, dx, fmaf(dy, dy, acc));
+		}
+	}
+	float stddev = __builtin_amdgcn_sqrtf(wave_sum(acc) * inv_n);
+	if (stddev == 0.0f)
+		stddev = 1.0f;
+	avr_o = avr;
+	avi_o = avi;
+	inv_o = __builtin_amdgcn_rcpf(stddev);
+}
+
 template <int NPL>
 __device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, int in_len, const Lds &L, int lane)
 {
@@ -941,22 +981,33 @@ struct Lds4 {
 	uint32_t *ubits;
 };
 
-__host__ __device__ inline size_t lds4_layout(int max_in_len, int cw, size_t *off)
+__host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t *off)
 {
-	size_t o = 0;
-	size_t xbytes = align16((size_t)max_in_len * 8);
+	// pass 1 keeps only the sync-chunk windows of the burst in LDS (everything else it needs is in
+	// registers; pass 2 re-reads from L2).  Decode-time data overlays all of it:
+	//   [stage | corr 4 x cw | coef]   during pass 1 and the timing rows
+	//   [bm | surv | ubits | 4 soft-bit rows]   from pass 2 on
 	const size_t dec_bytes = 4 * kSteps12 * 4 + kSteps12 * 8 + 4 * 8 * 4;
-	if (xbytes < dec_bytes)
-		xbytes = align16(dec_bytes);
-	// the window is dead once pass 1 is over: soft-bit rows, branch metrics, survivors and decoded
-	// bits all overlay it; only the correlation magnitudes and the sync reference sit beside it
-	if (xbytes < dec_bytes + 4 * 432)
-		xbytes = align16(dec_bytes + 4 * 432);
-	off[0] = o; o += xbytes;
-	off[1] = o; o += align16((size_t)4 * cw * 4);
-	off[2] = o; o += 18 * 8;
-	off[3] = dec_bytes;            // soft-bit rows, inside the window region
-	return align16(o);
+	const size_t stage_bytes = align16((size_t)stage_samples * 8);
+	const size_t corr_bytes = align16((size_t)4 * cw * 4);
+	off[0] = 0;
+	off[1] = stage_bytes;
+	off[2] = stage_bytes + corr_bytes;
+	off[3] = dec_bytes;            // soft-bit rows
+	size_t total = stage_bytes + corr_bytes + 18 * 8;
+	if (total < dec_bytes + 4 * 432)
+		total = dec_bytes + 4 * 432;
+	return align16(total);
+}
+
+// samples of the sync-chunk windows a burst type needs staged: sum over chunks of len*sps + w - 1
+__host__ __device__ inline int stage_samples_of(const DevBurst &bt, int sps, int in_len)
+{
+	const int w = in_len - bt.len * sps + 1;
+	int n = 0;
+	for (int c = 0; c < bt.n_chunks[0]; c++)
+		n += bt.sync[0][c].len * sps + w - 1;
+	return n;
 }
 
 // 64-bit max within each 16-lane row
@@ -969,14 +1020,14 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 }
 
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int max_in_len, int cw)
+__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
 	const int row = lane >> 4, col = lane & 15;
 	const int sps = SPS ? SPS : a.sps;
 	size_t off[4];
-	lds4_layout(max_in_len, cw, off);
+	lds4_layout(stage_samples, cw, off);
 	Lds4 L;
 	L.x = reinterpret_cast<float2 *>(lds_raw + off[0]);
 	L.corr = reinterpret_cast<float *>(lds_raw + off[1]);
@@ -985,8 +1036,6 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int max_in_len, int cw)
 	L.bm = reinterpret_cast<uint32_t *>(lds_raw + off[0]);
 	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[0] + 4 * kSteps12 * 4);
 	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + 4 * kSteps12 * 4 + kSteps12 * 8);
-	Lds Lx;                      // view for load_normalise
-	Lx.x = L.x;
 
 	const int g0 = blockIdx.x * 4;
 	const int g_row = g0 + row;                       // this row's burst
@@ -1017,14 +1066,33 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int max_in_len, int cw)
 		const float fsh = a.freq_shift ? a.freq_shift[g] : 0.0f;
 		const float fs = (fsh - bt.rotation) / (float)sps;
 
-		WSYNC();
+		const float2 *__restrict__ in = a.iq + a.offset[g];
 		float avr, avi, inv;
-		load_normalise_stats<NPL>(a.iq + a.offset[g], in_len, Lx, lane, avr, avi, inv);
+		load_stats<NPL>(in, in_len, lane, avr, avi, inv);
 		if (row == q) { avr_r = avr; avi_r = avi; }
 
-		// rotated reference of the (single) sync sequence
 		const int tl = bt.sync_tl[0];
 		const int nch = bt.n_chunks[0];
+		// stage the sync-chunk windows, normalised: window c = samples [pos_c sps, pos_c sps + len_c sps + w - 1)
+		// (a second, L1/L2-served read of ~300 of the burst's samples; the rest never touches LDS)
+		WSYNC();
+		{
+			int total = 0;
+			for (int c = 0; c < nch; c++)
+				total += bt.sync[0][c].len * sps + w - 1;
+			for (int sidx = lane; sidx < total; sidx += 64) {
+				int wb = 0, src = 0;
+				for (int c = 0; c < nch; c++) {
+					const int wl = bt.sync[0][c].len * sps + w - 1;
+					if (sidx >= wb && sidx < wb + wl)
+						src = bt.sync[0][c].pos * sps + (sidx - wb);
+					wb += wl;
+				}
+				const float2 v = in[src];
+				L.x[sidx] = make_float2((v.x - avr) * inv, (v.y - avi) * inv);
+			}
+		}
+		// rotated reference of the (single) sync sequence
 		for (int n = lane; n < tl; n += 64) {
 			int ch = 0, base = 0, cum = 0;
 			for (int c = 0; c < nch - 1; c++) {
@@ -1040,10 +1108,10 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int max_in_len, int cw)
 		float *corr = L.corr + q * cw;
 		for (int j = lane; j < w; j += 64) {
 			float cj = 0.f;
-			int base = 0;
+			int base = 0, wb = 0;
 			for (int ch = 0; ch < nch; ch++) {
-				const int pos = bt.sync[0][ch].pos, len = bt.sync[0][ch].len;
-				const float2 *xp = L.x + pos * sps + j;
+				const int len = bt.sync[0][ch].len;
+				const float2 *xp = L.x + wb + j;          // staged window of this chunk
 				const float2 *cp = L.coef + base;
 				float ar = 0.f, ai = 0.f;
 				for (int n = 0; n < len; n++) {
@@ -1053,6 +1121,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int max_in_len, int cw)
 					ai = fmaf(cf.x, x.y, fmaf(cf.y, x.x, ai));
 				}
 				base += len;
+				wb += len * sps + w - 1;
 				cj += sqrtf(fmaf(ar, ar, ai * ai));
 			}
 			corr[j] = cj;
@@ -1516,8 +1585,8 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 		} else {
 			const int cw = (max_len + 15) & ~15;
 			size_t off4[4];
-			const size_t lds4 = lds4_layout(max_in_len, cw, off4);
-			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid), dim3(64), lds4, stream, a, max_in_len, cw);
+			const size_t lds4 = lds4_layout(a.stage_samples, cw, off4);
+			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid), dim3(64), lds4, stream, a, a.stage_samples, cw);
 		}
 	} else {
 		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
