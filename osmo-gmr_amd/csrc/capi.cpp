@@ -159,8 +159,8 @@ static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
 {
 	if (n < 0 || !iq || !offset || !rv)
 		return fail(-EINVAL, "demod: n/iq/offset/rv are required");
-	if (sps < 4 || sps > 16)
-		return fail(-EINVAL, "demod: sps=%d unsupported (this build handles 4..16)", sps);
+	if (sps < 1 || sps > 16)
+		return fail(-EINVAL, "demod: sps=%d out of range (1..16)", sps);
 	const int w = in_len - ht.len * sps + 1;
 	if (w < 1 || w > kMaxWindow || in_len > kMaxInLen)
 		return fail(-EINVAL, "demod: window of %d samples gives %d lags (1..%d supported, <= %d samples)",

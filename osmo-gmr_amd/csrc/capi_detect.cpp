@@ -13,8 +13,8 @@ int gmr1_hip_detect_batch_dev(void *stream, int n_types, const int *burst_ids, i
 		return fail(-EINVAL, "detect: NULL argument");
 	if (n_types < 1 || n_types > 4)
 		return fail(-EINVAL, "detect: 1..4 candidate burst types");
-	if (sps < 4 || sps > 16)
-		return fail(-EINVAL, "detect: sps=%d unsupported (4..16)", sps);
+	if (sps < 1 || sps > 16)
+		return fail(-EINVAL, "detect: sps=%d out of range (1..16)", sps);
 	DevState *s;
 	int r = dev_state(&s);
 	if (r) return r;

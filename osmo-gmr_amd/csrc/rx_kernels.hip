@@ -571,6 +571,41 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 	const int d = (int)roundf(p_toa);
 	const int row = lane >> 4, col = lane & 15;
 
+	// align (pi4cxpsk.c:280-348): at sps >= 4 symbol i is sample i*sps + d.  Below 4 samples per
+	// symbol the reference first applies a 21-tap sinc fractional delay (osmo_cxvec_convolve,
+	// CONV_NO_DELAY) when |toa - d| > 0.1.  It does so on the DEROTATED burst; with
+	// g[m] = x[m] e^{j fs m} the delayed sample is e^{j fs n} sum_k (p_k e^{j fs (10-k)}) x[n+10-k], so the
+	// rotation moves into 21 complex taps and the common e^{j fs n} stays in the phase domain.
+	const float ofs_frac = p_toa - (float)d;
+	const bool frac_on = (sps < 4) && (fabsf(ofs_frac) > 0.1f);
+	if (frac_on) {
+		WSYNC();
+		if (lane < 21) {
+			const float xx = kPif * ((float)(lane - 10) + ofs_frac);
+			const float pv = (xx >= 0.01f || xx <= -0.01f) ? (sinf(xx) / xx) : 1.0f;
+			float s, c;
+			sincos_fast(fs * (float)(10 - lane), s, c);
+			L.coef[lane] = make_float2(pv * c, pv * s);
+		}
+		WSYNC();
+	}
+	auto pick = [&](int j) -> float2 {
+		if (j < 0 || j >= in_len)
+			return make_float2(0.f, 0.f);
+		if (!frac_on)
+			return L.x[j];
+		float2 acc = make_float2(0.f, 0.f);
+		for (int k = 0; k < 21; k++) {
+			const int m = j + 10 - k;
+			if (m >= 0 && m < in_len) {
+				const float2 q = L.coef[k], x = L.x[m];
+				acc.x = fmaf(q.x, x.x, fmaf(-q.y, x.y, acc.x));
+				acc.y = fmaf(q.x, x.y, fmaf(q.y, x.x, acc.y));
+			}
+		}
+		return acc;
+	};
+
 	auto reduce_2pi = [](float a) -> float {
 		const float k = rintf(a * 0.159154943091895336f);
 		a = fmaf(-k, 6.2831854820251465f, a);
@@ -579,7 +614,7 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 	// conj(ref) * derotated sample of sync symbol j of chunk c (pi4cxpsk.c:386-388)
 	auto sync_term = [&](int c, int j) -> float2 {
 		const int idx = (bt.sync[sq][c].pos + j) * sps + d;
-		float2 x = (idx >= 0 && idx < in_len) ? L.x[idx] : make_float2(0.f, 0.f);
+		float2 x = pick(idx);
 		float s, cc;
 		sincos_fast(fs * (float)idx, s, cc);
 		x = cmul(x, make_float2(cc, s));
@@ -667,7 +702,7 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 		if (i >= blen)
 			continue;
 		const int j = i * sps + d;
-		const float2 x = (j >= 0 && j < in_len) ? L.x[j] : make_float2(0.f, 0.f);
+		const float2 x = pick(j);
 		float th = atan2_fast(x.y, x.x) + reduce_2pi(fs * (float)j);
 		th = reduce_2pi(fmaf(rps, (float)i, th) - psi);
 		const float sv = (x.x == 0.0f && x.y == 0.0f) ? 0.0f : th * inv_dd;   // cargf(0) = 0

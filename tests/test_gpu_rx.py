@@ -241,3 +241,33 @@ def test_fused_rx_full_size_properties(gpu_api, orc, pkg):
     assert np.array_equal(ref["crc"], a["crc"][idx])
     ok = ref["crc"] == 0
     assert np.array_equal(ref["l2"][ok], a["l2"][idx][ok])
+
+
+def test_demod_low_oversampling(gpu_api, orc, pkg):
+    """sps < 4: the reference's sinc fractional-delay branch (pi4cxpsk.c:298-343), and sps 1."""
+    rng = np.random.default_rng(51)
+    for sps, name, win in ((2, "bcch", 20), (2, "nt3_speech", 4), (3, "dc6", 12), (1, "bcch", 6), (8, "dc2", 32)):
+        fmt = pkg.api.burst_format(name)
+        n = 16
+        ebits = rng.integers(0, 2, size=(n, fmt.ebits), dtype=np.uint8)
+        sym = pkg.synth.map_symbols(fmt, ebits)
+        bb = pkg.synth.synth_windows(fmt, sym, sps, win, rng, toa_jitter=1 if win >= 8 else 0, frac=sps > 1,
+                                     cfo_hz_std=20.0, esn0_db=18.0)
+        offset = (np.arange(n) * bb.stride).astype(np.uint64)
+        got = gpu_api.demod_batch(name, bb.iq, offset, bb.in_len, sps=sps)
+        nfrac = 0
+        for i in range(n):
+            o = orc.demod(name, bb.iq[i, :bb.in_len], sps)
+            assert got["rv"][i] == o["rv"] == 0, (sps, name)
+            assert abs(got["toa"][i] - o["toa"]) < 16 / 1024, (sps, name)
+            if got["toa"][i] == o["toa"]:
+                dss = np.abs(got["ssyms"][i] - o["ssyms"])
+                span = 2.0 ** fmt.nbits
+                dss = np.minimum(dss, np.abs(dss - span))
+                assert dss.max() < 1e-4, (sps, name, dss.max())
+                assert np.abs(got["ebits"][i].astype(int) - o["ebits"].astype(int)).max() <= 1
+                nfrac += abs(o["toa"] - round(o["toa"])) > 0.1
+        if sps in (2, 3):
+            assert nfrac >= 3, "the fractional-delay branch was not exercised"
+        hard = (got["ebits"] < 0).astype(np.uint8)
+        assert (hard != ebits).mean() < 0.03, (sps, name)
