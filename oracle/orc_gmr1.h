@@ -102,4 +102,21 @@ void orc_demod_decode_batch(int n, const orc_cf *iq, const uint64_t *offset,
                             orc_sbit_t *ebits /* optional n*432 */,
                             float *ssyms /* optional n*234 */, int32_t *rv);
 
+/* ---- receive control loop of one BCCH carrier (reference src/gmr1_rx.c:605-895) */
+
+#define ORC_RX_TYPE_BCCH 1      /* GSMTAP_GMR1_BCCH */
+#define ORC_RX_TYPE_CCCH 2      /* GSMTAP_GMR1_CCCH */
+
+struct orc_rx_record {          /* what gmr1_rx hands to GSMTAP for a frame whose CRC passed */
+	uint16_t arfcn;
+	uint8_t  chain, type;
+	uint32_t fn;
+	uint8_t  tn, crc, len, pad;
+	int32_t  conv;
+	uint8_t  l2[24];
+};
+
+int orc_rx_run(const orc_cf *iq, int len, int sps, int arfcn,
+               struct orc_rx_record *out, int max_records, int *n_records, int *n_chains);
+
 #endif

@@ -1,0 +1,245 @@
+/*
+ * oracle/orc_rx.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the receive control loop of
+ * the reference's gmr1_rx application for one BCCH carrier (reference src/gmr1_rx.c): FCCH single
+ * acquisition, multi-FCCH survivor selection, then the frame-by-frame BCCH / CCCH loop with its
+ * tracking feedback (align, freq_err, TDMA position from SI1).  TCH follow-up (IMM.ASS ->
+ * rx_tch3 / rx_tch9), GSMTAP transport and stderr logging are outside the scope;
+ * what GSMTAP would have carried is returned as records.  PARITY UNPINNED, see orc_3p.h.
+ */
+#include "orc_gmr1.h"
+
+#include <errno.h>
+#include <math.h>
+#include <string.h>
+
+#define START_DISCARD 8000          /* gmr1_rx.c:52 */
+#define SYM_RATE 23400
+#define PIf 3.14159265358979323846f
+
+struct chan_desc {                  /* gmr1_rx.c:93-115, the fields this scope uses */
+	const orc_cf *iq;
+	int len;
+	int sps;
+	int align;
+	float freq_err;
+	int fn;
+	int sa_sirfn_delay;
+	int sa_bcch_stn;
+};
+
+struct sink {
+	struct orc_rx_record *out;
+	int max, n;
+	int arfcn, chain;
+};
+
+static void emit(struct sink *s, int type, int fn, int tn, const uint8_t *l2, int conv)
+{
+	if (s->n < s->max) {
+		struct orc_rx_record *r = &s->out[s->n];
+		memset(r, 0, sizeof(*r));
+		r->arfcn = (uint16_t)s->arfcn;
+		r->chain = (uint8_t)s->chain;
+		r->type = (uint8_t)type;
+		r->fn = (uint32_t)fn;
+		r->tn = (uint8_t)tn;
+		r->crc = 0;
+		r->len = 24;
+		r->conv = conv;
+		memcpy(r->l2, l2, 24);
+	}
+	s->n++;
+}
+
+static float to_hz(float f_rps) { return (SYM_RATE * f_rps) / (2.0f * PIf); }
+
+/* gmr1_rx.c:149-170 */
+static int burst_map(const struct chan_desc *cd, int burst_len, int tn, int win, int *begin_o, int *len_o)
+{
+	int etoa = win >> 1;
+	int begin = cd->align + (cd->sps * tn * 39) - etoa;
+	int len = (burst_len * cd->sps) + win;
+	if ((begin + len) > cd->len)
+		return -EIO;
+	*begin_o = begin;
+	*len_o = len;
+	return etoa;
+}
+
+/* gmr1_rx.c:172-182 */
+static float burst_energy(const orc_cf *b, int len)
+{
+	float e = 0.0f;
+	int bd = len >> 5;
+	for (int i = bd; i < len - bd; i++)
+		e += crealf(b[i]) * crealf(b[i]) + cimagf(b[i]) * cimagf(b[i]);
+	e /= len;
+	return e;
+}
+
+/* gmr1_rx.c:194-233 */
+static void bcch_tdma_align(struct chan_desc *cd, const uint8_t *l2)
+{
+	int delay, stn, superframe, multiframe, mffn_hi, fn;
+	if ((l2[0] & 0xf8) != 0x08)
+		return;
+	if ((l2[9] & 0xfc) != 0x80)
+		return;
+	delay = (l2[10] >> 3) & 0x0f;
+	stn = ((l2[10] << 2) & 0x1c) | (l2[11] >> 6);
+	superframe = ((l2[11] & 0x3f) << 7) | (l2[12] >> 1);
+	multiframe = ((l2[12] & 0x01) << 1) | (l2[13] >> 7);
+	mffn_hi = ((l2[13] & 0x40) >> 6);
+	fn = (superframe << 6) | (multiframe << 4) | (mffn_hi << 3) | ((2 + delay) & 7);
+	cd->align += (cd->sa_bcch_stn - stn) * 39 * cd->sps;
+	cd->fn = fn;
+	cd->sa_sirfn_delay = delay;
+	cd->sa_bcch_stn = stn;
+}
+
+/* gmr1_rx.c:746-798 */
+static void rx_bcch(struct chan_desc *cd, float *energy, struct sink *s)
+{
+	const struct orc_burst *bt = orc_burst_get(ORC_BURST_BCCH);
+	orc_sbit_t ebits[424];
+	uint8_t l2[24];
+	float freq_err, toa;
+	int begin, len, rv, crc, conv, e_toa;
+
+	e_toa = burst_map(cd, bt->len, cd->sa_bcch_stn, 20 * cd->sps, &begin, &len);
+	if (e_toa < 0)
+		return;
+	rv = orc_pi4cxpsk_demod(bt, cd->iq + begin, len, cd->sps, -cd->freq_err, ebits, NULL, &toa, &freq_err, NULL);
+	if (rv)
+		return;
+	*energy = burst_energy(cd->iq + begin, len);
+	crc = orc_bcch_decode(l2, ebits, &conv);
+	if (!crc) {
+		cd->align += ((int)roundf(toa)) - e_toa;
+		cd->freq_err += freq_err;
+		bcch_tdma_align(cd, l2);
+		emit(s, ORC_RX_TYPE_BCCH, cd->fn, cd->sa_bcch_stn, l2, conv);
+	}
+}
+
+/* gmr1_rx.c:800-850 */
+static void rx_ccch(struct chan_desc *cd, float min_energy, struct sink *s)
+{
+	const struct orc_burst *bt = orc_burst_get(ORC_BURST_DC6);
+	orc_sbit_t ebits[432];
+	uint8_t l2[24];
+	int begin, len, rv, crc, conv, e_toa;
+
+	e_toa = burst_map(cd, bt->len, cd->sa_bcch_stn, 10 * cd->sps, &begin, &len);
+	if (e_toa < 0)
+		return;
+	if (burst_energy(cd->iq + begin, len) < min_energy)
+		return;
+	rv = orc_pi4cxpsk_demod(bt, cd->iq + begin, len, cd->sps, -cd->freq_err, ebits, NULL, NULL, NULL, NULL);
+	if (rv)
+		return;
+	crc = orc_ccch_decode(l2, ebits, &conv);
+	if (!crc)
+		emit(s, ORC_RX_TYPE_CCCH, cd->fn, cd->sa_bcch_stn, l2, conv);
+}
+
+/* gmr1_rx.c:852-895 */
+static void process_bcch(struct chan_desc *cd, struct sink *s)
+{
+	int frame_len = cd->sps * 24 * 39;
+	float bcch_energy = nanf("inf");
+	while (1) {
+		int sirfn = (cd->fn - cd->sa_sirfn_delay) & 63;
+		if (sirfn % 8 == 2)
+			rx_bcch(cd, &bcch_energy, s);
+		if ((sirfn % 8 != 0) && (sirfn % 8 != 2))
+			rx_ccch(cd, bcch_energy / 2.0f, s);
+		cd->fn++;
+		cd->align += frame_len;
+		if ((cd->align + 2 * frame_len) > cd->len)
+			break;
+	}
+}
+
+int orc_rx_run(const orc_cf *iq, int len, int sps, int arfcn,
+               struct orc_rx_record *out, int max_records, int *n_records, int *n_chains)
+{
+	struct chan_desc cd;
+	struct sink s = { out, max_records, 0, arfcn, 0 };
+	int rv, toa, base_align, mtoa[16], n_fcch, i, j;
+	float ref_snr = 0.0f, ref_freq_err = 0.0f;
+	const struct orc_fcch_burst *ft = &orc_fcch_burst;
+
+	*n_records = 0;
+	if (n_chains) *n_chains = 0;
+	memset(&cd, 0, sizeof(cd));
+	cd.iq = iq; cd.len = len; cd.sps = sps;
+	cd.align = START_DISCARD;                       /* gmr1_rx.c:906-909 */
+
+	/* fcch_single_init, gmr1_rx.c:605-639 */
+	{
+		int wl = (330 * SYM_RATE * sps) / 1000;
+		if (cd.align + wl > len)
+			return -1;
+		rv = orc_fcch_rough(ft, iq + cd.align, wl, sps, 0.0f, &toa);
+		if (rv)
+			return rv;
+		cd.align += toa;
+		/* the reference does not check this win_map (gmr1_rx.c:627); out of samples = error here */
+		if (cd.align + ft->len * sps > len)
+			return -1;
+		rv = orc_fcch_fine(ft, iq + cd.align, ft->len * sps, sps, 0.0f, &toa, &cd.freq_err);
+		if (rv)
+			return rv;
+		cd.align += toa;
+	}
+
+	/* fcch_multi_process, gmr1_rx.c:643-744 */
+	base_align = cd.align - ft->len * sps;
+	if (base_align < 0)
+		base_align = 0;
+	{
+		int wl = (650 * SYM_RATE * sps) / 1000;
+		if (base_align + wl > len)
+			return -1;
+		rv = orc_fcch_rough_multi(ft, iq + base_align, wl, sps, -cd.freq_err, mtoa, 16);
+		if (rv < 0)
+			return rv;
+		n_fcch = rv;
+	}
+	for (i = 0, j = 0; i < n_fcch; i++) {
+		float freq_err, snr = 0.0f;
+		int ftoa;
+		if (base_align + mtoa[i] < 0 || base_align + mtoa[i] + ft->len * sps > len)
+			return -1;
+		rv = orc_fcch_fine(ft, iq + base_align + mtoa[i], ft->len * sps, sps, -cd.freq_err, &ftoa, &freq_err);
+		if (rv)
+			return rv;
+		if (base_align + mtoa[i] + ftoa < 0 || base_align + mtoa[i] + ftoa + ft->len * sps > len)
+			return -1;
+		orc_fcch_snr(ft, iq + base_align + mtoa[i] + ftoa, ft->len * sps, sps, -(cd.freq_err + freq_err), &snr);
+		if (i == 0) {
+			ref_snr = snr;
+			ref_freq_err = freq_err;
+		} else {
+			if (snr < 2.0f)
+				continue;
+			if (snr < (ref_snr / 6.0f))
+				continue;
+			if (to_hz((float)fabs(ref_freq_err - freq_err)) > 500.0f)
+				continue;
+		}
+		mtoa[j++] = mtoa[i] + ftoa;
+	}
+	n_fcch = j;
+	if (n_chains) *n_chains = n_fcch;
+
+	for (i = 0; i < n_fcch; i++) {
+		struct chan_desc cdl = cd;
+		cdl.align = base_align + mtoa[i];
+		s.chain = i;
+		process_bcch(&cdl, &s);
+	}
+	*n_records = s.n;
+	return 0;
+}

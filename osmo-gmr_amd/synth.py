@@ -315,6 +315,108 @@ def synth_windows(fmt: BurstFormat, symbols: np.ndarray, sps: int, win: int, rng
     return BurstBatch(iq=out, stride=stride, in_len=in_len, toa=toa, cfo=cfo)
 
 
+def shape_bursts(symbols: np.ndarray, sps: int, frac, span: int = 5) -> np.ndarray:
+    """Raised-cosine shaping of (B, L) symbol rows to sps samples per symbol.
+
+    Returns (B, (L + 2*span) * sps): sample k belongs to burst-relative time (k - span*sps) samples,
+    delayed by `frac` (scalar or (B,)) samples."""
+    B, L = symbols.shape
+    fr = np.broadcast_to(np.asarray(frac, dtype=np.float64), (B,))
+    pad = span
+    spad = np.zeros((B, L + 4 * pad), np.complex64)
+    spad[:, 2 * pad:2 * pad + L] = symbols
+    n_sym_out = L + 2 * pad
+    body = np.zeros((sps, B, n_sym_out), np.complex64)
+    tmp = np.empty((B, n_sym_out), np.complex64)
+    for p in range(sps):
+        for m in range(-span, span + 1):
+            coef = rc_pulse(m + (p - fr) / sps).astype(np.float32)
+            np.multiply(spad[:, pad - m:pad - m + n_sym_out], coef[:, None], out=tmp)
+            body[p] += tmp
+    return np.ascontiguousarray(body.transpose(1, 2, 0)).reshape(B, n_sym_out * sps)
+
+
+def si1_payload(rng: np.random.Generator, fn: np.ndarray, delay: int, stn: int) -> np.ndarray:
+    """BCCH System Information type 1 with a 'Seg 2A bis' carrying the TDMA position, as
+    bcch_tdma_align() parses it (reference src/gmr1_rx.c:194-233).  fn is the frame number of
+    the frame the burst is sent in; its low three bits must equal (2 + delay) & 7."""
+    fn = np.asarray(fn, dtype=np.int64)
+    B = fn.size
+    assert np.all((fn & 7) == ((2 + delay) & 7))
+    l2 = rng.integers(0, 256, size=(B, 24), dtype=np.uint8)
+    superframe = (fn >> 6) & 0x1FFF
+    multiframe = (fn >> 4) & 3
+    mffn_hi = (fn >> 3) & 1
+    l2[:, 0] = 0x08 | (l2[:, 0] & 0x07)
+    l2[:, 9] = 0x80 | (l2[:, 9] & 0x03)
+    l2[:, 10] = ((delay & 0x0F) << 3) | ((stn >> 2) & 0x07)
+    l2[:, 11] = ((stn & 3) << 6) | ((superframe >> 7) & 0x3F)
+    l2[:, 12] = ((superframe & 0x7F) << 1) | ((multiframe >> 1) & 1)
+    l2[:, 13] = ((multiframe & 1) << 7) | (mffn_hi << 6) | (l2[:, 13] & 0x3F)
+    return l2
+
+
+def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: int, sps: int,
+                       rng: np.random.Generator, *, stn: int = 3, delay: int = 2, fn0: int | None = None,
+                       t0: int | None = None, frac: float = 0.0, esn0_db: float = 15.0, cfo_hz: float = 0.0,
+                       p_idle: float = 0.15, fcch_db: float = 0.0):
+    """One ARFCN of BASELINE.md config 4: FCCH + BCCH (SI1 w/ Seg 2A bis) + CCCH on the
+    24-slot / 40 ms TDMA grid (reference src/gmr1_rx.c:852-895 schedule).
+
+    Frame k starts at sample t0 + k*24*39*sps and has frame number fn0 + k; with
+    sirfn = (fn - delay) & 63:  sirfn % 8 == 0 -> FCCH, == 2 -> BCCH, else CCCH (DC6) unless idle;
+    all on timeslot stn.  Returns (stream complex64, list of dicts describing what was sent)."""
+    frame_len = 24 * 39 * sps
+    if t0 is None:
+        t0 = int(rng.integers(0, frame_len))
+    if fn0 is None:
+        fn0 = int(rng.integers(0, 1 << 18))
+    sigma = np.sqrt(10.0 ** (-esn0_db / 10.0) / 2.0)
+    x = rng.standard_normal((n_samples, 2), dtype=np.float32).view(np.complex64).reshape(-1)
+    x *= np.float32(sigma)
+    span = 5
+    n_frames = (n_samples - t0) // frame_len + 1
+    fns = fn0 + np.arange(n_frames)
+    sirfn = (fns - delay) & 63
+    sent = []
+    # FCCH
+    chirp = fcch_dual_chirp(0.32, 117, sps, frac) * np.float32(10.0 ** (fcch_db / 20.0) / np.sqrt(2.0) * np.sqrt(2.0))
+    for k in np.nonzero(sirfn % 8 == 0)[0]:
+        pos = t0 + k * frame_len + stn * 39 * sps
+        if pos >= 0 and pos + chirp.size <= n_samples:
+            x[pos:pos + chirp.size] += chirp
+            sent.append(dict(type="fcch", fn=int(fns[k]), pos=pos))
+    # BCCH
+    kb = np.nonzero(sirfn % 8 == 2)[0]
+    if kb.size:
+        l2 = si1_payload(rng, fns[kb], delay, stn)
+        other = rng.random(kb.size) < 0.25            # some BCCH bursts carry another SI: no TDMA info
+        l2[other, 0] = 0x10 | (l2[other, 0] & 0x07)
+        body = shape_bursts(map_symbols(fmt_bcch, bcch_encode(l2)), sps, frac, span)
+        for i, k in enumerate(kb):
+            pos = t0 + k * frame_len + stn * 39 * sps - span * sps
+            if pos >= 0 and pos + body.shape[1] <= n_samples:
+                x[pos:pos + body.shape[1]] += body[i]
+                sent.append(dict(type="bcch", fn=int(fns[k]), pos=pos + span * sps, l2=l2[i].copy()))
+    # CCCH
+    kc = np.nonzero((sirfn % 8 != 0) & (sirfn % 8 != 2))[0]
+    kc = kc[rng.random(kc.size) >= p_idle]
+    if kc.size:
+        l2 = rng.integers(0, 256, size=(kc.size, 24), dtype=np.uint8)
+        l2[:, 1] &= 0xF7                              # never an IMM.ASS (gmr1_rx.c:235-239): no TCH follow-up
+        body = shape_bursts(map_symbols(fmt_dc6, ccch_encode(l2)), sps, frac, span)
+        for i, k in enumerate(kc):
+            pos = t0 + k * frame_len + stn * 39 * sps - span * sps
+            if pos >= 0 and pos + body.shape[1] <= n_samples:
+                x[pos:pos + body.shape[1]] += body[i]
+                sent.append(dict(type="ccch", fn=int(fns[k]), pos=pos + span * sps, l2=l2[i].copy()))
+    if cfo_hz:
+        n = np.arange(n_samples, dtype=np.float64)
+        ph = (2 * np.pi * cfo_hz / (SYM_RATE * sps)) * n
+        x *= np.exp(1j * ph).astype(np.complex64)
+    return x, sent
+
+
 # --------------------------------------------------------------------------
 # FCCH streams (config 2)
 # --------------------------------------------------------------------------

@@ -294,3 +294,22 @@ def demod_decode_batch(iq, offset, kind, sps=4, freq_shift=None, want_ebits=True
         _p(ss, C.c_float) if ss is not None else None, _p(out["rv"], C.c_int32))
     out["ebits"], out["ssyms"] = eb, ss
     return out
+
+
+# ---- receive control loop (gmr1_rx equivalent for one BCCH carrier) ----------------------------
+RX_RECORD = np.dtype([("arfcn", "<u2"), ("chain", "u1"), ("type", "u1"), ("fn", "<u4"),
+                      ("tn", "u1"), ("crc", "u1"), ("len", "u1"), ("pad", "u1"),
+                      ("conv", "<i4"), ("l2", "u1", (24,))])
+
+
+def rx_run(iq, sps=4, arfcn=0, max_records=4096):
+    """orc_rx_run: FCCH acquisition + BCCH/CCCH frame loop of the reference's gmr1_rx on one carrier.
+    Returns (rv, records (RX_RECORD array), n_chains)."""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    out = np.zeros(max_records, RX_RECORD)
+    n, nch = C.c_int(), C.c_int()
+    f = lib().orc_rx_run
+    f.restype = C.c_int
+    rv = f(_p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_int(arfcn),
+           out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n), C.byref(nch))
+    return rv, out[:min(n.value, max_records)].copy(), nch.value

@@ -86,3 +86,27 @@ def tch3_bursts(pkg, n, seed, m=0, sigma=40.0):
     eb += rng.standard_normal(eb.shape, dtype=np.float32) * np.float32(sigma)
     eb = np.clip(np.rint(eb), -127, 127).astype(np.int8)
     return dict(ebits=eb, frame0=f0, frame1=f1, status=s, m=m)
+
+
+def bcch_carrier(pkg, seed, seconds=2.0, sps=4, **kw):
+    """One BCCH carrier (one ARFCN): FCCH + SI1 BCCH + CCCH on the TDMA grid."""
+    from importlib import import_module
+    synth = import_module(pkg.__name__ + ".synth")
+    rng = np.random.default_rng(seed)
+    fb = pkg.api.burst_format("bcch")
+    fd = pkg.api.burst_format("dc6")
+    n = int(seconds * 23400 * sps)
+    return synth.synth_bcch_carrier(fb, fd, n, sps, rng, **kw)
+
+
+def match_records(records, sent):
+    """(#BCCH records whose (fn, l2) equal a sent burst, #BCCH records, #CCCH matched by payload, #CCCH records,
+    #BCCH records matched by payload alone)."""
+    sb = {(s["fn"], bytes(s["l2"])) for s in sent if s["type"] == "bcch"}
+    sc = {bytes(s["l2"]) for s in sent if s["type"] == "ccch"}
+    rb = [r for r in records if r["type"] == 1]
+    rc = [r for r in records if r["type"] == 2]
+    mb = sum((int(r["fn"]), bytes(r["l2"])) in sb for r in rb)
+    mc = sum(bytes(r["l2"]) in sc for r in rc)
+    mp = sum(bytes(r["l2"]) in {l for _, l in sb} for r in rb)
+    return mb, len(rb), mc, len(rc), mp
