@@ -173,6 +173,43 @@ int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
                             const float *iq, uint64_t iq_len, const uint64_t *offset,
                             const float *freq_shift, float *snr);
 
+/* ------------------------------------------------------------------------
+ * The gmr1_rx receive loop over many BCCH carriers (reference src/gmr1_rx.c:605-895 and
+ * main() :897-975, one process per capture file there).
+ *
+ * Carrier i is the complex64 stream iq[offset[i] .. offset[i]+length[i]) at sps samples per
+ * symbol (offset / length / arfcn / out / status / n_chains are HOST arrays; iq is a device
+ * pointer for _dev, a host pointer otherwise).  For every carrier: FCCH acquisition
+ * (fcch_single_init), multi-FCCH survivor selection (fcch_multi_process), then per chain the
+ * BCCH / CCCH frame loop with its time / frequency / SI1 TDMA feedback (process_bcch, rx_bcch,
+ * rx_ccch, bcch_tdma_align).  Every frame whose CRC passed comes back as one record -- what the
+ * reference hands to gsmtap_sendmsg (gmr1_rx.c:793-795, 845-847) -- ordered by carrier, chain,
+ * time.  n_records = records found (only the first max_records are stored).
+ * status[i] = 0 or the negative value main() would have exited with for that carrier;
+ * n_chains[i] = FCCH chains followed.  TCH follow-up after IMM.ASS is not performed.
+ * arfcn may be NULL (records then carry the carrier index). */
+struct gmr1_hip_rx_record {
+	uint16_t arfcn;
+	uint8_t  chain;      /* FCCH chain within the carrier          */
+	uint8_t  type;       /* 1 = GSMTAP_GMR1_BCCH, 2 = GSMTAP_GMR1_CCCH */
+	uint32_t fn;
+	uint8_t  tn;
+	uint8_t  crc;        /* always 0: only frames whose CRC passed */
+	uint8_t  len;        /* 24                                     */
+	uint8_t  pad;
+	int32_t  conv;       /* Viterbi path metric, as logged by the reference */
+	uint8_t  l2[24];
+};
+
+int gmr1_hip_rx_run_dev(void *stream, int n_arfcn, int sps, const float *iq,
+                        const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                        struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                        int32_t *status, int32_t *n_chains);
+int gmr1_hip_rx_run(int n_arfcn, int sps, const float *iq, uint64_t iq_len,
+                    const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                    struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                    int32_t *status, int32_t *n_chains);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,8 @@ static int burst_map(const struct chan_desc *cd, int burst_len, int tn, int win,
 	int etoa = win >> 1;
 	int begin = cd->align + (cd->sps * tn * 39) - etoa;
 	int len = (burst_len * cd->sps) + win;
-	if ((begin + len) > cd->len)
+	/* begin < 0 reads before the capture in the reference (undefined); refused here (decision D6) */
+	if (begin < 0 || (begin + len) > cd->len)
 		return -EIO;
 	*begin_o = begin;
 	*len_o = len;

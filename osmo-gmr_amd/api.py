@@ -35,6 +35,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_detect_batch_dev", "gmr1_hip_detect_batch",
     "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
+    "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -516,3 +517,46 @@ def fcch_rough_multi(iq, sps=4, freq_shift=0.0, N=16, fcch_type="fcch"):
     rv = f(C.byref(_fcch_struct(fcch_type)), C.byref(vec), C.c_int(sps), C.c_float(freq_shift),
            toa.ctypes.data_as(C.c_void_p), C.c_int(N))
     return rv, toa[:max(rv, 0)].copy()
+
+
+# ---------------------------------------------------------------------------
+# gmr1_rx receive loop over many BCCH carriers (reference src/gmr1_rx.c:605-895)
+# ---------------------------------------------------------------------------
+RX_RECORD = np.dtype([("arfcn", "<u2"), ("chain", "u1"), ("type", "u1"), ("fn", "<u4"),
+                      ("tn", "u1"), ("crc", "u1"), ("len", "u1"), ("pad", "u1"),
+                      ("conv", "<i4"), ("l2", "u1", (24,))])
+assert RX_RECORD.itemsize == 40
+
+
+def _rx_run_call(fname, head_args, n, offset, length, arfcn, max_records):
+    offset, p_off = _np(offset, np.uint64)
+    length, p_len = _np(length, np.uint64)
+    p_arfcn = None
+    if arfcn is not None:
+        arfcn, p_arfcn = _np(arfcn, np.uint16)
+    out = np.zeros(max(max_records, 1), RX_RECORD)
+    n_rec = C.c_int(0)
+    status = np.zeros(max(n, 1), np.int32)
+    chains = np.zeros(max(n, 1), np.int32)
+    f = getattr(load(), fname)
+    f.restype = C.c_int
+    rc = f(*head_args, p_off, p_len, p_arfcn, out.ctypes.data_as(C.c_void_p), C.c_int(max_records),
+           C.byref(n_rec), status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p))
+    _check(rc, fname)
+    return out[:min(n_rec.value, max_records)].copy(), status[:n], chains[:n], n_rec.value
+
+
+def rx_run(iq, offset, length, sps=4, arfcn=None, max_records=1 << 16):
+    """gmr1_hip_rx_run: iq is one host complex64 buffer holding every carrier; carrier i is
+    iq[offset[i] : offset[i] + length[i]].  Returns (records RX_RECORD[], status[n], n_chains[n], n_found)."""
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    n = len(offset)
+    head = (C.c_int(n), C.c_int(sps), p_iq, C.c_uint64(iq.size))
+    return _rx_run_call("gmr1_hip_rx_run", head, n, offset, length, arfcn, max_records)
+
+
+def rx_run_dev(stream, iq_ptr, offset, length, sps=4, arfcn=None, max_records=1 << 16):
+    """gmr1_hip_rx_run_dev: as rx_run with the capture already in HBM (iq_ptr = device address)."""
+    n = len(offset)
+    head = (C.c_void_p(stream) if stream else None, C.c_int(n), C.c_int(sps), C.c_void_p(iq_ptr))
+    return _rx_run_call("gmr1_hip_rx_run_dev", head, n, offset, length, arfcn, max_records)

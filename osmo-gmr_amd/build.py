@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libgmr1_hip.so")
 ARCH = "gfx950"
 
 HIP_SOURCES = ["rx_kernels.hip", "fcch_kernels.hip", "l1_kernels.hip"]
-CXX_SOURCES = ["capi.cpp", "capi_fcch.cpp", "capi_l1.cpp", "capi_detect.cpp", "host_tables.cpp"]
+CXX_SOURCES = ["capi.cpp", "capi_fcch.cpp", "capi_l1.cpp", "capi_detect.cpp", "capi_rx.cpp", "host_tables.cpp"]
 
 COMMON = [
     "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",

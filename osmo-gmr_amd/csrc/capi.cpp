@@ -379,12 +379,15 @@ int gmr1_ccch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv)
 // ---------------------------------------------------------------------------
 // fused BCCH / CCCH receive
 // ---------------------------------------------------------------------------
-int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
-                                    const float *iq, const uint64_t *offset, const uint8_t *kind,
-                                    const float *freq_shift,
-                                    uint8_t *l2, int32_t *crc, int32_t *conv,
-                                    float *toa, float *freq_err,
-                                    int8_t *ebits, float *ssyms, int32_t *rv)
+}  // extern "C" (closed for the shared implementation below)
+
+namespace gmr1 {
+int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
+                          const float *iq, const uint64_t *offset, const uint8_t *kind,
+                          const float *freq_shift,
+                          uint8_t *l2, int32_t *crc, int32_t *conv,
+                          float *toa, float *freq_err, float *energy,
+                          int8_t *ebits, float *ssyms, int32_t *rv)
 {
 	if (n < 0 || !iq || !offset || !kind || !l2 || !crc || !conv || !rv)
 		return fail(-EINVAL, "rx_bcch_ccch: iq/offset/kind/l2/crc/conv/rv are required");
@@ -414,6 +417,7 @@ int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
 	a.offset = offset; a.kind = kind; a.freq_shift = freq_shift;
 	a.l2 = l2; a.crc = crc; a.conv = conv; a.toa = toa; a.freq_err = freq_err;
 	a.ebits = ebits; a.ssyms = ssyms; a.rv = rv;
+	a.energy = energy;
 	if (a.in_len[0] > kMaxInLen)
 		return fail(-EINVAL, "rx_bcch_ccch: window too long");
 	{
@@ -429,8 +433,22 @@ int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
 			if (tot > a.stage_samples) a.stage_samples = tot;
 		}
 	}
-	HIP_TRY(launch_rx(a, true, a.in_len[0], (hipStream_t)stream));
+	HIP_TRY(launch_rx(a, true, a.in_len[0], stream));
 	return 0;
+}
+}  // namespace gmr1
+
+extern "C" {
+
+int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
+                                    const float *iq, const uint64_t *offset, const uint8_t *kind,
+                                    const float *freq_shift,
+                                    uint8_t *l2, int32_t *crc, int32_t *conv,
+                                    float *toa, float *freq_err,
+                                    int8_t *ebits, float *ssyms, int32_t *rv)
+{
+	return rx_bcch_ccch_dev_impl((hipStream_t)stream, n, sps, iq, offset, kind, freq_shift, l2, crc, conv,
+	                             toa, freq_err, nullptr, ebits, ssyms, rv);
 }
 
 int gmr1_hip_rx_bcch_ccch_batch(int n, int sps,

@@ -38,6 +38,14 @@ int dev_state(DevState **out);
 // grow-only device scratch of the current device (not for concurrent streams)
 int dev_workspace(DevState *s, size_t bytes, void **out);
 
+// fused BCCH / CCCH receive with the optional burst_energy() output (capi.cpp)
+int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
+                          const float *iq, const uint64_t *offset, const uint8_t *kind,
+                          const float *freq_shift,
+                          uint8_t *l2, int32_t *crc, int32_t *conv,
+                          float *toa, float *freq_err, float *energy,
+                          int8_t *ebits, float *ssyms, int32_t *rv);
+
 // RAII device buffer for the host-pointer variants
 struct DBuf {
 	void *p = nullptr;

@@ -1,0 +1,461 @@
+// capi_rx.cpp -- the receive control loop of the reference's gmr1_rx application
+// (reference src/gmr1_rx.c:605-895, main() :897-975) over MANY BCCH carriers at once.
+//
+// The reference walks one carrier frame by frame on the CPU: one FCCH acquisition, then per
+// 40 ms frame one BCCH or CCCH burst through demod + decode, feeding time / frequency / TDMA
+// position back into the next frame.  That feedback only crosses a BCCH frame (rx_bcch is the
+// only writer of align / freq_err / fn / sa_*), so between two BCCH frames of one chain every
+// burst is independent, and different chains / carriers are independent throughout.  The driver
+// below therefore runs in ROUNDS: each live chain contributes the CCCH bursts up to and including
+// its next BCCH burst, all of them go through ONE fused k_rx4 launch, the host applies the BCCH
+// feedback (a few integers per chain) and the next round starts.  FCCH acquisition is three
+// batched sweeps (rough / rough_multi / fine + snr) over all carriers.  The arithmetic of every
+// step runs on the GPU; the host keeps only the per-chain integers the reference keeps in
+// struct chan_desc.  There is no CPU fallback.
+//
+// Out of scope exactly as SURVEY.md 8f says: TCH3 / TCH9 follow-up after an IMM.ASS, GSMTAP
+// transport, per-burst stderr logging.  What GSMTAP would have carried comes back as records.
+
+#include "capi_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/gmr1_hip.h"
+
+using namespace gmr1;
+
+namespace {
+
+constexpr int kStartDiscard = 8000;   // gmr1_rx.c:52
+constexpr int kSymRate = 23400;
+constexpr int kFcchLen = 117;         // gmr1_fcch_burst.len, fcch.c:50-54
+constexpr int kMaxPeaks = 16;         // gmr1_rx.c:650
+constexpr int kPerRound = 8;          // bursts one chain may contribute to a round
+
+float to_hz(float f_rps) { return (kSymRate * f_rps) / (2.0f * 3.14159265358979323846f); }
+
+struct RxChain {
+	int a;                // carrier index
+	int chain;            // chain index within the carrier
+	uint64_t base;        // first sample of the carrier in iq
+	int len;              // samples of the carrier
+	int align;
+	float freq_err;
+	int fn, delay, stn;
+	float bcch_energy;
+	bool done;
+	std::vector<gmr1_hip_rx_record> rec;
+};
+
+struct Item {             // one burst of a round
+	int chain_idx;
+	int is_bcch;
+	int fn, tn, e_toa;
+	float min_energy;
+};
+
+// gmr1_rx.c:149-170 (begin < 0 is an out-of-bounds read in the reference; refused here and in the oracle)
+int burst_map(const RxChain &c, int sps, int burst_len, int tn, int win, int *begin)
+{
+	const int etoa = win >> 1;
+	const int b = c.align + sps * tn * 39 - etoa;
+	const int l = burst_len * sps + win;
+	if (b < 0 || b + l > c.len)
+		return -EIO;
+	*begin = b;
+	return etoa;
+}
+
+// gmr1_rx.c:194-233: SI1 "Segment 2A bis" -> TDMA position
+void bcch_tdma_align(RxChain &c, int sps, const uint8_t *l2)
+{
+	if ((l2[0] & 0xf8) != 0x08)
+		return;
+	if ((l2[9] & 0xfc) != 0x80)
+		return;
+	const int delay = (l2[10] >> 3) & 0x0f;
+	const int stn = ((l2[10] << 2) & 0x1c) | (l2[11] >> 6);
+	const int superframe = ((l2[11] & 0x3f) << 7) | (l2[12] >> 1);
+	const int multiframe = ((l2[12] & 0x01) << 1) | (l2[13] >> 7);
+	const int mffn_hi = (l2[13] & 0x40) >> 6;
+	const int fn = (superframe << 6) | (multiframe << 4) | (mffn_hi << 3) | ((2 + delay) & 7);
+	c.align += (c.stn - stn) * 39 * sps;
+	c.fn = fn;
+	c.delay = delay;
+	c.stn = stn;
+}
+
+void emit(RxChain &c, uint16_t arfcn, int type, int fn, int tn, const uint8_t *l2, int conv)
+{
+	gmr1_hip_rx_record r;
+	std::memset(&r, 0, sizeof(r));
+	r.arfcn = arfcn;
+	r.chain = (uint8_t)c.chain;
+	r.type = (uint8_t)type;
+	r.fn = (uint32_t)fn;
+	r.tn = (uint8_t)tn;
+	r.crc = 0;
+	r.len = 24;
+	r.conv = conv;
+	std::memcpy(r.l2, l2, 24);
+	c.rec.push_back(r);
+}
+
+struct Pinned {
+	void *p = nullptr;
+	~Pinned() { if (p) (void)hipHostFree(p); }
+	hipError_t alloc(size_t n) { return hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault); }
+	template <typename T> T *at(size_t off) { return reinterpret_cast<T *>(static_cast<char *>(p) + off); }
+};
+
+template <typename T> T *dat(DBuf &d, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(d.p) + off); }
+
+size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+}  // namespace
+
+extern "C" {
+
+int gmr1_hip_rx_run_dev(void *stream_, int n_arfcn, int sps, const float *iq,
+                        const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                        struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                        int32_t *status, int32_t *n_chains)
+{
+	hipStream_t st = (hipStream_t)stream_;
+	if (n_records) *n_records = 0;
+	if (n_arfcn < 0 || !iq || !offset || !length || !n_records || (max_records > 0 && !out) || max_records < 0)
+		return fail(-EINVAL, "rx_run: iq/offset/length/n_records (and out when max_records > 0) are required");
+	if (sps < 4 || sps > 8)
+		return fail(-EINVAL, "rx_run: sps=%d unsupported (4..8)", sps);
+	DevState *ds;
+	int r = dev_state(&ds);
+	if (r) return r;
+	if (n_arfcn == 0) return 0;
+	for (int i = 0; i < n_arfcn; i++)
+		if (length[i] > 0x7fffffffull)
+			return fail(-EINVAL, "rx_run: carrier %d longer than 2^31-1 samples", i);
+
+	const int A = n_arfcn;
+	const int flen = kFcchLen * sps;
+	std::vector<int32_t> stat(A, 0), nch(A, 0);
+	std::vector<int> align(A, kStartDiscard), base_align(A, 0);
+	std::vector<float> ferr(A, 0.0f);
+
+	// ---- scratch for the acquisition sweeps: per carrier / per candidate --------------------
+	const size_t C = (size_t)A * kMaxPeaks;
+	DBuf d_off, d_fs, d_i0, d_i1, d_f0;
+	HIP_TRY(d_off.alloc(C * 8));
+	HIP_TRY(d_fs.alloc(C * 4));
+	HIP_TRY(d_i0.alloc(C * 4));
+	HIP_TRY(d_i1.alloc(C * 4));
+	HIP_TRY(d_f0.alloc(C * 4));
+	std::vector<uint64_t> h_off(C);
+	std::vector<float> h_fs(C), h_f0(C);
+	std::vector<int32_t> h_i0(C), h_i1(C);
+	std::vector<int> idx;            // carriers (or candidates) of the current sweep
+	idx.reserve(C);
+
+	auto push_inputs = [&](size_t n, bool with_fs) -> int {
+		HIP_TRY(hipMemcpyAsync(d_off.p, h_off.data(), n * 8, hipMemcpyHostToDevice, st));
+		if (with_fs)
+			HIP_TRY(hipMemcpyAsync(d_fs.p, h_fs.data(), n * 4, hipMemcpyHostToDevice, st));
+		return 0;
+	};
+
+	// ---- fcch_single_init (gmr1_rx.c:605-639): rough over 330 ms, then fine ------------------
+	{
+		const int wl = (330 * kSymRate * sps) / 1000;
+		idx.clear();
+		for (int i = 0; i < A; i++) {
+			if ((uint64_t)align[i] + wl > length[i]) { stat[i] = -1; continue; }
+			h_off[idx.size()] = offset[i] + align[i];
+			idx.push_back(i);
+		}
+		const int n = (int)idx.size();
+		if (n) {
+			if ((r = push_inputs(n, false))) return r;
+			r = gmr1_hip_fcch_rough_batch_dev(st, 0, n, sps, wl, iq, d_off.as<uint64_t>(), nullptr,
+			                                  d_i0.as<int32_t>(), d_i1.as<int32_t>());
+			if (r) return r;
+			HIP_TRY(hipMemcpyAsync(h_i0.data(), d_i0.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_i1.data(), d_i1.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			for (int k = 0; k < n; k++) {
+				const int i = idx[k];
+				if (h_i1[k]) { stat[i] = h_i1[k]; continue; }
+				align[i] += h_i0[k];
+				if ((uint64_t)align[i] + flen > length[i]) stat[i] = -1;
+			}
+		}
+		idx.clear();
+		for (int i = 0; i < A; i++) {
+			if (stat[i]) continue;
+			h_off[idx.size()] = offset[i] + align[i];
+			idx.push_back(i);
+		}
+		const int m = (int)idx.size();
+		if (m) {
+			if ((r = push_inputs(m, false))) return r;
+			r = gmr1_hip_fcch_fine_batch_dev(st, 0, m, sps, iq, d_off.as<uint64_t>(), nullptr,
+			                                 d_i0.as<int32_t>(), d_f0.as<float>());
+			if (r) return r;
+			HIP_TRY(hipMemcpyAsync(h_i0.data(), d_i0.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_f0.data(), d_f0.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			for (int k = 0; k < m; k++) {
+				const int i = idx[k];
+				align[i] += h_i0[k];
+				ferr[i] = h_f0[k];
+			}
+		}
+	}
+
+	// ---- fcch_multi_process (gmr1_rx.c:643-744) -----------------------------------------------
+	std::vector<RxChain> chains;
+	{
+		const int wl = (650 * kSymRate * sps) / 1000;
+		idx.clear();
+		for (int i = 0; i < A; i++) {
+			if (stat[i]) continue;
+			base_align[i] = std::max(0, align[i] - flen);
+			if ((uint64_t)base_align[i] + wl > length[i]) { stat[i] = -1; continue; }
+			h_off[idx.size()] = offset[i] + base_align[i];
+			h_fs[idx.size()] = -ferr[i];
+			idx.push_back(i);
+		}
+		const int n = (int)idx.size();
+		std::vector<int32_t> peaks((size_t)std::max(n, 1) * kMaxPeaks), count(std::max(n, 1));
+		DBuf d_peaks, d_count;
+		HIP_TRY(d_peaks.alloc((size_t)std::max(n, 1) * kMaxPeaks * 4));
+		HIP_TRY(d_count.alloc((size_t)std::max(n, 1) * 4));
+		if (n) {
+			if ((r = push_inputs(n, true))) return r;
+			r = gmr1_hip_fcch_rough_multi_batch_dev(st, 0, n, sps, wl, iq, d_off.as<uint64_t>(), d_fs.as<float>(),
+			                                        d_peaks.as<int32_t>(), kMaxPeaks, d_count.as<int32_t>());
+			if (r) return r;
+			HIP_TRY(hipMemcpyAsync(peaks.data(), d_peaks.p, (size_t)n * kMaxPeaks * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(count.data(), d_count.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+		}
+		// candidates of every carrier, flattened; a carrier with any candidate out of its
+		// samples is dropped as a whole (the oracle's early return, see orc_rx.c)
+		struct Cand { int i, k, mtoa, ftoa; float fe, snr; };
+		std::vector<Cand> cand;
+		for (int q = 0; q < n; q++) {
+			const int i = idx[q];
+			if (count[q] < 0) { stat[i] = count[q]; continue; }
+			bool ok = true;
+			for (int k = 0; k < count[q]; k++) {
+				const int64_t p = (int64_t)base_align[i] + peaks[(size_t)q * kMaxPeaks + k];
+				if (p < 0 || p + flen > (int64_t)length[i]) ok = false;
+			}
+			if (!ok) { stat[i] = -1; continue; }
+			for (int k = 0; k < count[q]; k++)
+				cand.push_back({i, k, peaks[(size_t)q * kMaxPeaks + k], 0, 0.f, 0.f});
+		}
+		const int nc = (int)cand.size();
+		if (nc) {
+			for (int k = 0; k < nc; k++) {
+				h_off[k] = offset[cand[k].i] + base_align[cand[k].i] + cand[k].mtoa;
+				h_fs[k] = -ferr[cand[k].i];
+			}
+			if ((r = push_inputs(nc, true))) return r;
+			r = gmr1_hip_fcch_fine_batch_dev(st, 0, nc, sps, iq, d_off.as<uint64_t>(), d_fs.as<float>(),
+			                                 d_i0.as<int32_t>(), d_f0.as<float>());
+			if (r) return r;
+			HIP_TRY(hipMemcpyAsync(h_i0.data(), d_i0.p, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_f0.data(), d_f0.p, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			for (int k = 0; k < nc; k++) {
+				cand[k].ftoa = h_i0[k];
+				cand[k].fe = h_f0[k];
+				const int i = cand[k].i;
+				const int64_t p = (int64_t)base_align[i] + cand[k].mtoa + cand[k].ftoa;
+				if (p < 0 || p + flen > (int64_t)length[i]) stat[i] = -1;
+			}
+			// SNR at the refined position, with the refined frequency (gmr1_rx.c:693-702)
+			std::vector<int> live;
+			for (int k = 0; k < nc; k++) {
+				if (stat[cand[k].i]) continue;
+				const int i = cand[k].i;
+				h_off[live.size()] = offset[i] + base_align[i] + cand[k].mtoa + cand[k].ftoa;
+				h_fs[live.size()] = -(ferr[i] + cand[k].fe);
+				live.push_back(k);
+			}
+			const int nl = (int)live.size();
+			if (nl) {
+				if ((r = push_inputs(nl, true))) return r;
+				r = gmr1_hip_fcch_snr_batch_dev(st, 0, nl, sps, iq, d_off.as<uint64_t>(), d_fs.as<float>(), d_f0.as<float>());
+				if (r) return r;
+				HIP_TRY(hipMemcpyAsync(h_f0.data(), d_f0.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
+				HIP_TRY(hipStreamSynchronize(st));
+				for (int q = 0; q < nl; q++)
+					cand[live[q]].snr = h_f0[q];
+			}
+			// survivor selection, candidate order, first one is the reference (gmr1_rx.c:704-733)
+			float ref_snr = 0.f, ref_fe = 0.f;
+			for (int k = 0; k < nc; k++) {
+				const Cand &cd = cand[k];
+				const int i = cd.i;
+				if (stat[i]) continue;
+				if (cd.k == 0) {
+					ref_snr = cd.snr;
+					ref_fe = cd.fe;
+				} else {
+					if (cd.snr < 2.0f) continue;
+					if (cd.snr < ref_snr / 6.0f) continue;
+					if (to_hz(std::fabs(ref_fe - cd.fe)) > 500.0f) continue;
+				}
+				RxChain c;
+				c.a = i;
+				c.chain = nch[i]++;
+				c.base = offset[i];
+				c.len = (int)length[i];
+				c.align = base_align[i] + cd.mtoa + cd.ftoa;
+				c.freq_err = ferr[i];
+				c.fn = 0; c.delay = 0; c.stn = 0;
+				c.bcch_energy = std::nanf("inf");
+				c.done = false;
+				chains.push_back(std::move(c));
+			}
+		}
+	}
+
+	// ---- process_bcch (gmr1_rx.c:852-895) for every chain, in rounds ---------------------------
+	const int frame_len = sps * 24 * 39;
+	const size_t cap = std::max<size_t>(1, chains.size() * kPerRound);
+	// one staging block each way: [offset | freq_shift | kind] down, [l2 | crc | conv | toa | fe | rv | energy] up
+	const size_t o_off = 0, o_fs = up16(o_off + cap * 8), o_kind = up16(o_fs + cap * 4), in_bytes = up16(o_kind + cap);
+	const size_t o_l2 = 0, o_crc = up16(o_l2 + cap * 24), o_conv = up16(o_crc + cap * 4), o_toa = up16(o_conv + cap * 4),
+	             o_fe = up16(o_toa + cap * 4), o_rv = up16(o_fe + cap * 4), o_en = up16(o_rv + cap * 4),
+	             out_bytes = up16(o_en + cap * 4);
+	DBuf d_in, d_out;
+	Pinned p_in, p_out;
+	HIP_TRY(d_in.alloc(in_bytes));
+	HIP_TRY(d_out.alloc(out_bytes));
+	HIP_TRY(p_in.alloc(in_bytes));
+	HIP_TRY(p_out.alloc(out_bytes));
+	std::vector<Item> items;
+	items.reserve(cap);
+
+	auto advance = [&](RxChain &c) {
+		c.fn++;
+		c.align += frame_len;
+		if (c.align + 2 * frame_len > c.len)
+			c.done = true;
+	};
+
+	for (;;) {
+		items.clear();
+		for (size_t ci = 0; ci < chains.size(); ci++) {
+			RxChain &c = chains[ci];
+			int cnt = 0;
+			while (!c.done && cnt < kPerRound - 1) {
+				const int m = ((c.fn - c.delay) & 63) % 8;
+				int begin;
+				if (m == 2) {
+					const int e = burst_map(c, sps, 234, c.stn, 20 * sps, &begin);
+					if (e >= 0) {
+						const size_t k = items.size();
+						items.push_back({(int)ci, 1, c.fn, c.stn, e, 0.f});
+						p_in.at<uint64_t>(o_off)[k] = c.base + (uint64_t)begin;
+						p_in.at<float>(o_fs)[k] = -c.freq_err;
+						p_in.at<uint8_t>(o_kind)[k] = 0;
+						break;          // the frame completes once the burst's result is known
+					}
+				} else if (m != 0) {
+					const int e = burst_map(c, sps, 234, c.stn, 10 * sps, &begin);
+					if (e >= 0) {
+						const size_t k = items.size();
+						items.push_back({(int)ci, 0, c.fn, c.stn, e, c.bcch_energy / 2.0f});
+						p_in.at<uint64_t>(o_off)[k] = c.base + (uint64_t)begin;
+						p_in.at<float>(o_fs)[k] = -c.freq_err;
+						p_in.at<uint8_t>(o_kind)[k] = 1;
+						cnt++;
+					}
+				}
+				advance(c);
+			}
+		}
+		const int n = (int)items.size();
+		if (!n)
+			break;
+		HIP_TRY(hipMemcpyAsync(d_in.p, p_in.p, in_bytes, hipMemcpyHostToDevice, st));
+		r = rx_bcch_ccch_dev_impl(st, n, sps, iq, dat<uint64_t>(d_in, o_off), dat<uint8_t>(d_in, o_kind),
+		                          dat<float>(d_in, o_fs), dat<uint8_t>(d_out, o_l2), dat<int32_t>(d_out, o_crc),
+		                          dat<int32_t>(d_out, o_conv), dat<float>(d_out, o_toa), dat<float>(d_out, o_fe),
+		                          dat<float>(d_out, o_en), nullptr, nullptr, dat<int32_t>(d_out, o_rv));
+		if (r) return r;
+		HIP_TRY(hipMemcpyAsync(p_out.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		for (int k = 0; k < n; k++) {
+			const Item &it = items[k];
+			RxChain &c = chains[it.chain_idx];
+			const uint16_t an = arfcn ? arfcn[c.a] : (uint16_t)c.a;
+			const int rv = p_out.at<int32_t>(o_rv)[k];
+			const int crc = p_out.at<int32_t>(o_crc)[k];
+			const float en = p_out.at<float>(o_en)[k];
+			const uint8_t *l2 = p_out.at<uint8_t>(o_l2) + (size_t)k * 24;
+			if (it.is_bcch) {
+				// rx_bcch, gmr1_rx.c:746-798
+				if (!rv) {
+					c.bcch_energy = en;
+					if (!crc) {
+						c.align += (int)roundf(p_out.at<float>(o_toa)[k]) - it.e_toa;
+						c.freq_err += p_out.at<float>(o_fe)[k];
+						bcch_tdma_align(c, sps, l2);
+						emit(c, an, 1 /* GSMTAP_GMR1_BCCH */, c.fn, c.stn, l2, p_out.at<int32_t>(o_conv)[k]);
+					}
+				}
+				advance(c);
+			} else {
+				// rx_ccch, gmr1_rx.c:800-850 (energy gate first, :813-816)
+				if (en < it.min_energy)
+					continue;
+				if (!rv && !crc)
+					emit(c, an, 2 /* GSMTAP_GMR1_CCCH */, it.fn, it.tn, l2, p_out.at<int32_t>(o_conv)[k]);
+			}
+		}
+	}
+
+	// ---- hand back: carriers in order, chains in order, frames in order -------------------------
+	int total = 0;
+	for (const RxChain &c : chains) {       // chains were created carrier by carrier, chain by chain
+		for (const gmr1_hip_rx_record &rec : c.rec) {
+			if (total < max_records)
+				out[total] = rec;
+			total++;
+		}
+	}
+	*n_records = total;
+	for (int i = 0; i < A; i++) {
+		if (status) status[i] = stat[i];
+		if (n_chains) n_chains[i] = nch[i];
+	}
+	return 0;
+}
+
+int gmr1_hip_rx_run(int n_arfcn, int sps, const float *iq, uint64_t iq_len,
+                    const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                    struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                    int32_t *status, int32_t *n_chains)
+{
+	if (n_records) *n_records = 0;
+	DevState *ds;
+	int r = dev_state(&ds);
+	if (r) return r;
+	if (n_arfcn < 0 || !iq || !offset || !length)
+		return fail(-EINVAL, "rx_run: iq/offset/length are required");
+	for (int i = 0; i < n_arfcn; i++)
+		if (offset[i] + length[i] > iq_len)
+			return fail(-EINVAL, "rx_run: carrier %d runs past the end of iq", i);
+	DBuf d_iq;
+	HIP_TRY(d_iq.alloc(iq_len * 8));
+	HIP_TRY(hipMemcpy(d_iq.p, iq, iq_len * 8, hipMemcpyHostToDevice));
+	return gmr1_hip_rx_run_dev(nullptr, n_arfcn, sps, d_iq.as<float>(), offset, length, arfcn,
+	                           out, max_records, n_records, status, n_chains);
+}
+
+}  // extern "C"

@@ -57,6 +57,7 @@ struct RxArgs {
 	uint8_t *l2;           // n x 24
 	int32_t *crc, *conv;
 	float *toa, *freq_err;
+	float *energy;             // optional: burst_energy() of each window (gmr1_rx.c:172-182)
 	int8_t *ebits;
 	float *ssyms;
 	int32_t *rv;           // required

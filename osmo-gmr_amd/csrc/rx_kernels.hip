@@ -376,6 +376,25 @@ __device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in
 	inv_o = __builtin_amdgcn_rcpf(stddev);
 }
 
+// burst_energy() of the caller (gmr1_rx.c:172-182): sum |x|^2 over [len>>5, len - len>>5) of the RAW
+// window, divided by len.  Only the receive driver asks for it (RxArgs::energy); the window was
+// read a moment ago, so this second read is served by L1 / L2.
+template <int NPL>
+__device__ __noinline__ float window_energy(const float2 *__restrict__ in, int in_len, int lane)
+{
+	const int bd = in_len >> 5;
+	float e = 0.f;
+#pragma unroll
+	for (int k = 0; k < NPL; k++) {
+		const int idx = lane + 64 * k;
+		if (idx >= bd && idx < in_len - bd) {
+			const float2 v = in[idx];
+			e = fmaf(v.x, v.x, fmaf(v.y, v.y, e));
+		}
+	}
+	return wave_sum(e) / (float)in_len;
+}
+
 template <int NPL>
 __device__ __forceinline__ void load_normalise(const float2 *__restrict__ in, int in_len, const Lds &L, int lane)
 {
@@ -933,6 +952,11 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 		                                   a.dbg_stop, sid, toa, fe, gss);
 		if (rv == -100)
 			continue;    // profiling build-out: phase cut-off
+		if (a.energy) {
+			const float e = window_energy<NPL>(a.iq + a.offset[g], in_len, lane);
+			if (lane == 0)
+				a.energy[g] = e;
+		}
 
 		if (lane == 0) {
 			a.rv[g] = rv;
@@ -1105,6 +1129,11 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 		float avr, avi, inv;
 		load_stats<NPL>(in, in_len, lane, avr, avi, inv);
 		if (row == q) { avr_r = avr; avi_r = avi; }
+		if (a.energy) {
+			const float e = window_energy<NPL>(in, in_len, lane);
+			if (lane == 0)
+				a.energy[g] = e;
+		}
 
 		const int tl = bt.sync_tl[0];
 		const int nch = bt.n_chunks[0];

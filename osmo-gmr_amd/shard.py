@@ -105,3 +105,25 @@ def gather_records(records: np.ndarray, dst: int = 0, device=None):
     allr = np.concatenate(parts) if parts else np.zeros(0, RECORD_DTYPE)
     order = np.lexsort((allr["chain"], allr["tn"], allr["fn"], allr["arfcn"]))
     return allr[order]
+
+
+def rx_capture_sharded(api, slices, n_arfcn: int, n_samples: int, sps: int = 4, src: int = 0, device=None,
+                       max_records: int = 1 << 16):
+    """BASELINE.md config 4 end to end on the ranks of one node: rank `src` holds the channelised
+    capture (`slices[a]`, complex64 tensors of n_samples), every rank receives the ARFCNs it owns,
+    runs the receive loop on them (gmr1_hip_rx_run_dev, reference src/gmr1_rx.c:605-895) and the
+    decoded-frame records come back to `src`.  No collective touches the data path."""
+    import torch
+
+    mine = scatter_iq(slices, n_arfcn, n_samples, src=src, device=device)
+    ids = sorted(mine)
+    if ids:
+        iq = torch.cat([torch.view_as_real(mine[a]).reshape(-1) for a in ids]).contiguous()
+        offset = np.arange(len(ids), dtype=np.uint64) * np.uint64(n_samples)
+        length = np.full(len(ids), n_samples, np.uint64)
+        stream = torch.cuda.current_stream(iq.device).cuda_stream
+        rec, status, chains, found = api.rx_run_dev(stream, iq.data_ptr(), offset, length, sps=sps,
+                                                    arfcn=np.asarray(ids, np.uint16), max_records=max_records)
+    else:
+        rec = np.zeros(0, RECORD_DTYPE)
+    return gather_records(rec, dst=src, device=device)

@@ -28,6 +28,10 @@ def orc():
 @pytest.fixture(scope="session")
 def gpu_api(pkg):
     """The product API, initialised on device 0 (GPU tests only)."""
+    # torch carries its own ROCm runtime: when a test also uses torch for HBM tensors / streams,
+    # torch has to bring the runtime up first (the order bench.py uses), then the library binds to it
+    import torch
+    torch.cuda.init()
     pkg.api.load()
     pkg.api.init(0)
     return pkg.api
