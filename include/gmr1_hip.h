@@ -210,6 +210,11 @@ int gmr1_hip_rx_run(int n_arfcn, int sps, const float *iq, uint64_t iq_len,
                     struct gmr1_hip_rx_record *out, int max_records, int *n_records,
                     int32_t *status, int32_t *n_chains);
 
+/* The GSMTAP packet gmr1_gsmtap_makemsg (reference src/gsmtap.c:43-71, include/osmocom/gmr1/gsmtap.h:35-37)
+ * builds for one record: 16-byte gsmtap_hdr + L2.  Returns the packet length (16 + rec->len) or
+ * -EINVAL.  Host-only; works without a GPU.  with_arfcn = 0 leaves the arfcn field 0 as the reference does. */
+int gmr1_hip_gsmtap_pack(const struct gmr1_hip_rx_record *rec, int with_arfcn, uint8_t *buf, int buf_len);
+
 #ifdef __cplusplus
 }
 #endif

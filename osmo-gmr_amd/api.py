@@ -35,7 +35,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_detect_batch_dev", "gmr1_hip_detect_batch",
     "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
-    "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run",
+    "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -560,3 +560,15 @@ def rx_run_dev(stream, iq_ptr, offset, length, sps=4, arfcn=None, max_records=1 
     n = len(offset)
     head = (C.c_void_p(stream) if stream else None, C.c_int(n), C.c_int(sps), C.c_void_p(iq_ptr))
     return _rx_run_call("gmr1_hip_rx_run_dev", head, n, offset, length, arfcn, max_records)
+
+
+def gsmtap_pack(record, with_arfcn=False) -> bytes:
+    """gmr1_hip_gsmtap_pack: the GSMTAP packet the reference would send for one RX_RECORD (src/gsmtap.c:43-71)."""
+    rec = np.ascontiguousarray(np.asarray(record, RX_RECORD).reshape(1))
+    buf = (C.c_uint8 * 64)()
+    f = load().gmr1_hip_gsmtap_pack
+    f.restype = C.c_int
+    n = f(rec.ctypes.data_as(C.c_void_p), C.c_int(1 if with_arfcn else 0), buf, C.c_int(64))
+    if n < 0:
+        _check(n, "gmr1_hip_gsmtap_pack")
+    return bytes(buf[:n])

@@ -117,3 +117,19 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"oracle_lib|liborc|orc_[a-z0-9_]+\(|#include\s+\"orc_", txt):
                     bad.append(path)
     assert not bad, bad
+
+
+def test_gsmtap_packet_layout(pkg):
+    """gmr1_gsmtap_makemsg (reference src/gsmtap.c:43-71): version 2, 4-word header, type GMR1_UM,
+    frame number big-endian, sub_type = channel type, L2 appended.  Host-only, no GPU needed."""
+    api = pkg.api
+    rec = np.zeros(1, api.RX_RECORD)
+    rec["arfcn"], rec["type"], rec["fn"], rec["tn"], rec["len"] = 1007, 2, 0x00A1B2C3, 17, 24
+    rec["l2"][0] = np.arange(24, dtype=np.uint8) + 100
+    pkt = api.gsmtap_pack(rec[0])
+    assert len(pkt) == 40
+    assert pkt[:4] == bytes([2, 4, 0x0A, 17]) and pkt[4:8] == bytes(4)
+    assert pkt[8:12] == bytes([0x00, 0xA1, 0xB2, 0xC3]) and pkt[12] == 2 and pkt[13:16] == bytes(3)
+    assert pkt[16:] == bytes(range(100, 124))
+    pkt2 = api.gsmtap_pack(rec[0], with_arfcn=True)
+    assert pkt2[4:6] == bytes([1007 >> 8, 1007 & 0xFF]) and pkt2[6:] == pkt[6:]
