@@ -781,106 +781,217 @@ __device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ 
 
 // ---------------------------------------------------------------------------
 // 4 x (K=5, rate 1/2, 208 bits + flush) Viterbi, one burst per 16-lane row
+//
+// In-place butterfly: the two predecessors of a state always sit in two lanes of the row that
+// differ by an xor mask, and the two successor states are written back to the same two lanes.
+// The masks of the four phases are 8, 7, 2, 1 -- each ONE DPP control (row_ror:8,
+// row_half_mirror, quad_perm), so the partner's metric arrives folded into the add.  With
+// loc = c0*8 ^ c1*7 ^ c2*2 ^ c3*1, the predecessor state held by a lane in phase ph has bit i =
+// c[(3 - i + ph) & 3]; after 4 steps the layout is back where it started.
+//
+// One 32-bit word per state carries everything the step needs:
+//     [ path metric : 16 | decisions of the current 16-step window : 16 ]
+// The metric never exceeds 212 * 252 = 53 424; unreachable states carry 0xF000 (libosmocore's
+// MAX_AE plays the same role).  Before step j of a window the word of a lane that is the HIGH
+// predecessor ((t >> 1) + 8) of its butterfly has bit j set (tb).  The two candidates of a new
+// state are  own word + (cost << 16)  and  partner word + (cost << 16); v_min_u32 then (a) picks
+// the smaller metric, (b) on equal metrics keeps the LOW predecessor (osmo_conv_decode: strict
+// '>' on ascending states), and (c) leaves the decision in bit j of the winner's history --
+// four VALU instructions per trellis step (add, add with DPP, min, add next tb).  The cost byte
+// is fetched by every lane straight from the branch-metric words in LDS into the HIGH half of a
+// register (ds_read_u8_d16_hi; with SRAM-ECC the low half reads back as zero, which is what the
+// add wants), 8 steps ahead.
+//
+// The decision of step k is the oldest bit of the winning predecessor = input bit u[k-4].
+// Windows start at k = 4 + 16 m, so window m's 16 decisions ARE the decoded bits
+// u[16 m .. 16 m + 15], and its low 4 bits name the survivor's state at the start of the
+// window: the "traceback" is 13 dependent 16-bit LDS reads per burst.
 // ---------------------------------------------------------------------------
-// returns the 64-bit decision ballot of the step (bit = lane: 1 if the hi predecessor won)
-template <int PH, bool EDGE>
-__device__ __forceinline__ unsigned long long acs_step(uint32_t &ae, uint32_t bmw, uint32_t sh_own,
-                                                       uint32_t sh_par, unsigned long long own_is_hi,
-                                                       bool b_is_one, bool flush)
+constexpr uint32_t kSentinel = 0xF0000000u;
+
+// per row location: bits 0-7 own cost byte (2 bits per phase), 8-15 partner cost byte, 16-31 the
+// 16-step tb pattern (bit j set when the lane holds a HIGH predecessor in phase j & 3)
+struct DecTable { uint32_t v[16]; };
+static constexpr uint32_t dec_out(uint32_t s, uint32_t b)
 {
-	const uint32_t par = row_xor<(8 >> PH)>(ae);
-	const uint32_t n_own = ae + ((bmw >> sh_own) & 0xffu);
-	const uint32_t n_par = par + ((bmw >> sh_par) & 0xffu);
-	// hi predecessor ((t>>1)+8) wins only when strictly better: ties keep the lower state
-	const unsigned long long own_lt = __ballot(n_own < n_par);
-	const unsigned long long par_lt = __ballot(n_par < n_own);
-	uint32_t nw = n_own < n_par ? n_own : n_par;
-	if (EDGE) {
-		// unreachable states carry MAX_AE and never grow (the first 4 and the flush steps)
-		nw = nw < kMaxAe ? nw : kMaxAe;
-		if (flush && b_is_one)
-			nw = kMaxAe;        // flush steps only take the b=0 transitions
-	}
-	ae = nw;
-	return (own_lt & own_is_hi) | (par_lt & ~own_is_hi);
+	const uint32_t reg = (s << 1) | b;
+	uint32_t p0 = reg & 0x19u, p1 = reg & 0x17u;
+	p0 ^= p0 >> 4; p0 ^= p0 >> 2; p0 ^= p0 >> 1;
+	p1 ^= p1 >> 4; p1 ^= p1 >> 2; p1 ^= p1 >> 1;
+	return ((p0 & 1u) << 1) | (p1 & 1u);
 }
+static constexpr DecTable make_dec()
+{
+	DecTable t{};
+	for (uint32_t loc = 0; loc < 16; loc++) {
+		// loc in the basis {8, 7, 2, 1}
+		uint32_t c[4] = {0, 0, 0, 0};
+		c[0] = (loc >> 3) & 1u;
+		uint32_t x = loc & 7u;
+		c[1] = (x >> 2) & 1u;
+		x ^= c[1] ? 7u : 0u;
+		c[2] = (x >> 1) & 1u;
+		c[3] = x & 1u;
+		uint32_t e = 0;
+		for (int ph = 0; ph < 4; ph++) {
+			uint32_t sp = 0;
+			for (int i = 0; i < 4; i++)
+				sp |= c[(3 - i + ph) & 3] << i;
+			const uint32_t b = sp >> 3;
+			e |= dec_out(sp, b) << (2 * ph);
+			e |= dec_out(sp ^ 8u, b) << (8 + 2 * ph);
+			for (int j = ph; j < 16; j += 4)
+				e |= b << (16 + j);
+		}
+		t.v[loc] = e;
+	}
+	return t;
+}
+__constant__ DecTable c_dec = make_dec();
 
-#define ACS4(EDGE, FL)                                                                             \
-	do {                                                                                           \
-		const uint4 bw = *reinterpret_cast<const uint4 *>(bmr + k);                                \
-		const unsigned long long m0 = acs_step<0, EDGE>(ae, bw.x, sh_own[0], sh_par[0], hi[0], b1[0], FL); \
-		const unsigned long long m1 = acs_step<1, EDGE>(ae, bw.y, sh_own[1], sh_par[1], hi[1], b1[1], FL); \
-		const unsigned long long m2 = acs_step<2, EDGE>(ae, bw.z, sh_own[2], sh_par[2], hi[2], b1[2], FL); \
-		const unsigned long long m3 = acs_step<3, EDGE>(ae, bw.w, sh_own[3], sh_par[3], hi[3], b1[3], FL); \
-		if (lane == 0) {                                                                           \
-			uint4 *sp = reinterpret_cast<uint4 *>(surv + k);                                       \
-			sp[0] = make_uint4((uint32_t)m0, (uint32_t)(m0 >> 32), (uint32_t)m1, (uint32_t)(m1 >> 32)); \
-			sp[1] = make_uint4((uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)m3, (uint32_t)(m3 >> 32)); \
-		}                                                                                          \
-	} while (0)
+#define GMR1_DPP_PH0 "row_ror:8"
+#define GMR1_DPP_PH1 "row_half_mirror"
+#define GMR1_DPP_PH2 "quad_perm:[2,3,0,1]"
+#define GMR1_DPP_PH3 "quad_perm:[1,0,3,2]"
 
-// bm: 4 rows x 212 words; surv: 212 ballots; ubits: 4 rows x 8 words (decoded bits, LSB first)
+#define ACS_CORE(PH)                                                                               \
+	"s_waitcnt lgkmcnt(%[wt])\n\t"                                                                  \
+	"v_add_u32 %[t1], %[w], %[r]\n\t"                                                               \
+	"v_add_u32_dpp %[t2], %[w], %[q] " GMR1_DPP_PH##PH " row_mask:0xf bank_mask:0xf\n\t"            \
+	"v_min_u32 %[w], %[t1], %[t2]\n\t"
+// step with the operands of position J, prefetching the cost bytes of step J + 8; TN = tb of the next position
+#define ACS_PF(J, PH, WAIT, TN)                                                                    \
+	asm volatile(ACS_CORE(PH)                                                                      \
+	             "v_add_u32 %[w], %[w], %[tn]\n\t"                                                  \
+	             "ds_read_u8_d16_hi %[rn], %[ao] offset:%[off]\n\t"                                 \
+	             "ds_read_u8_d16_hi %[qn], %[ap] offset:%[off]\n\t"                                 \
+	             : [w] "+v"(w), [rn] "+v"(R[((J) + 8) & 15]), [qn] "+v"(Q[((J) + 8) & 15]),        \
+	               [t1] "=&v"(t1), [t2] "=&v"(t2)                                                    \
+	             : [r] "v"(R[J]), [q] "v"(Q[J]), [ao] "v"(ao[PH]), [ap] "v"(ap[PH]), [tn] "v"(TN),   \
+	               [off] "i"(4 * ((J) + 8)), [wt] "i"(WAIT))
+// step without prefetch
+#define ACS_NP(J, PH, WAIT, TN)                                                                    \
+	asm volatile(ACS_CORE(PH)                                                                      \
+	             "v_add_u32 %[w], %[w], %[tn]\n\t"                                                  \
+	             : [w] "+v"(w), [t1] "=&v"(t1), [t2] "=&v"(t2)                                       \
+	             : [r] "v"(R[J]), [q] "v"(Q[J]), [tn] "v"(TN), [wt] "i"(WAIT))
+// last step of a window: the caller clears the decisions and sets the first tb itself
+#define ACS_PF_END(J, PH, WAIT)                                                                    \
+	asm volatile(ACS_CORE(PH)                                                                      \
+	             "ds_read_u8_d16_hi %[rn], %[ao] offset:%[off]\n\t"                                 \
+	             "ds_read_u8_d16_hi %[qn], %[ap] offset:%[off]\n\t"                                 \
+	             : [w] "+v"(w), [rn] "+v"(R[((J) + 8) & 15]), [qn] "+v"(Q[((J) + 8) & 15]),        \
+	               [t1] "=&v"(t1), [t2] "=&v"(t2)                                                    \
+	             : [r] "v"(R[J]), [q] "v"(Q[J]), [ao] "v"(ao[PH]), [ap] "v"(ap[PH]),                 \
+	               [off] "i"(4 * ((J) + 8)), [wt] "i"(WAIT))
+#define ACS_NP_END(J, PH, WAIT)                                                                    \
+	asm volatile(ACS_CORE(PH)                                                                      \
+	             : [w] "+v"(w), [t1] "=&v"(t1), [t2] "=&v"(t2)                                       \
+	             : [r] "v"(R[J]), [q] "v"(Q[J]), [wt] "i"(WAIT))
+// cost bytes of step K (relative to the address registers) into the operands of position J
+#define ACS_LOAD(J, PH, K)                                                                         \
+	asm volatile("ds_read_u8_d16_hi %[rn], %[ao] offset:%[off]\n\t"                                 \
+	             "ds_read_u8_d16_hi %[qn], %[ap] offset:%[off]\n\t"                                 \
+	             : [rn] "+v"(R[J]), [qn] "+v"(Q[J])                                                  \
+	             : [ao] "v"(ao[PH]), [ap] "v"(ap[PH]), [off] "i"(4 * (K)))
+
+// bm: 4 rows x 212 words; surv: 13 x 64 halfwords of window decisions; ubits: 4 rows x 8 words
+// (decoded bits, LSB first)
 __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restrict__ surv,
                               uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae)
 {
+	typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
 	const int row = lane >> 4;
 	const uint32_t loc = (uint32_t)lane & 15u;
-	uint32_t sh_own[4], sh_par[4];
-	bool b1[4];
-	unsigned long long hi[4];
+	// per-location constants (c_dec): cost byte of the own / partner transition per phase, tb pattern
+	const uint32_t dc = c_dec.v[loc];
+	const uint32_t row_base = (uint32_t)(uintptr_t)(lds_cbyte *)(bm + row * kSteps12);
+	uint32_t ao[4], ap[4];      // LDS byte address of this lane's own / partner cost in step 0 of the phase
+	bool hi[4];
 #pragma unroll
 	for (int ph = 0; ph < 4; ph++) {
-		const uint32_t s = rotl4(loc, ph);
-		const uint32_t b = s >> 3;
-		b1[ph] = b != 0;
-		hi[ph] = __ballot(b1[ph]);
-		sh_own[ph] = 8u * out_k5_12(s, b);
-		sh_par[ph] = 8u * out_k5_12(s ^ 8u, b);
+		ao[ph] = row_base + ((dc >> (2 * ph)) & 3u);
+		ap[ph] = row_base + ((dc >> (8 + 2 * ph)) & 3u);
+		hi[ph] = ((dc >> (16 + ph)) & 1u) != 0;
 	}
-	uint32_t ae = loc ? kMaxAe : 0u;
-	const uint32_t *bmr = bm + row * kSteps12;
+	// cost << 16 of the own / partner transition, per window position (low halves stay zero whether
+	// or not the d16 load preserves them)
+	uint32_t R[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, Q[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t T[16];             // tie-break / decision bit of the position: set in HIGH-predecessor lanes
+#pragma unroll
+	for (int j = 0; j < 16; j++)
+		T[j] = (dc >> 16) & (1u << j);
+	uint32_t w = (loc ? kSentinel : 0u) | T[0];
+	uint32_t t1, t2;
+	uint16_t *dump = reinterpret_cast<uint16_t *>(surv) + lane;
 
-	// forward pass, 4 trellis steps per iteration; lane 0 parks the four ballots in LDS
-	{
-		int k = 0;
-		ACS4(true, false);
-		for (k = 4; k < 208; k += 4)
-			ACS4(false, false);
-		ACS4(true, true);      // k = 208: flush
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	// steps 0..3: the decisions are u[-4..-1], dropped
+	ACS_LOAD(0, 0, 0); ACS_LOAD(1, 1, 1); ACS_LOAD(2, 2, 2); ACS_LOAD(3, 3, 3);
+	ACS_NP(0, 0, 6, T[1]); ACS_NP(1, 1, 4, T[2]); ACS_NP(2, 2, 2, T[3]); ACS_NP_END(3, 3, 0);
+	w = (w & 0xffff0000u) | T[0];
+#pragma unroll
+	for (int ph = 0; ph < 4; ph++) {
+		ao[ph] += 16;
+		ap[ph] += 16;
 	}
-	// 212 = 53 * 4 steps: the layout is back to identity, state 0 sits in lane 0 of the row
-	final_ae = ae;
+	// window pipeline: the costs of 8 steps are always in flight
+	ACS_LOAD(0, 0, 0); ACS_LOAD(1, 1, 1); ACS_LOAD(2, 2, 2); ACS_LOAD(3, 3, 3);
+	ACS_LOAD(4, 0, 4); ACS_LOAD(5, 1, 5); ACS_LOAD(6, 2, 6); ACS_LOAD(7, 3, 7);
+#pragma unroll 1
+	for (int m = 0; m < 12; m++) {
+		ACS_PF(0, 0, 14, T[1]); ACS_PF(1, 1, 14, T[2]); ACS_PF(2, 2, 14, T[3]); ACS_PF(3, 3, 14, T[4]);
+		ACS_PF(4, 0, 14, T[5]); ACS_PF(5, 1, 14, T[6]); ACS_PF(6, 2, 14, T[7]); ACS_PF(7, 3, 14, T[8]);
+		ACS_PF(8, 0, 14, T[9]); ACS_PF(9, 1, 14, T[10]); ACS_PF(10, 2, 14, T[11]); ACS_PF(11, 3, 14, T[12]);
+		ACS_PF(12, 0, 14, T[13]); ACS_PF(13, 1, 14, T[14]); ACS_PF(14, 2, 14, T[15]); ACS_PF_END(15, 3, 14);
+		dump[m * 64] = (uint16_t)w;
+		w = (w & 0xffff0000u) | T[0];
+#pragma unroll
+		for (int ph = 0; ph < 4; ph++) {
+			ao[ph] += 64;
+			ap[ph] += 64;
+		}
+	}
+	// window 12: steps 196..211, the last four are the flush (b = 0 transitions only: the lanes
+	// whose new state ends in 1 become unreachable)
+	ACS_PF(0, 0, 14, T[1]); ACS_PF(1, 1, 14, T[2]); ACS_PF(2, 2, 14, T[3]); ACS_PF(3, 3, 14, T[4]);
+	ACS_PF(4, 0, 14, T[5]); ACS_PF(5, 1, 14, T[6]); ACS_PF(6, 2, 14, T[7]); ACS_PF(7, 3, 14, T[8]);
+	ACS_NP(8, 0, 14, T[9]); ACS_NP(9, 1, 12, T[10]); ACS_NP(10, 2, 10, T[11]); ACS_NP(11, 3, 8, T[12]);
+	ACS_NP_END(12, 0, 6);
+	w = hi[0] ? kSentinel : (w + T[13]);
+	ACS_NP_END(13, 1, 4);
+	w = hi[1] ? kSentinel : (w + T[14]);
+	ACS_NP_END(14, 2, 2);
+	w = hi[2] ? kSentinel : (w + T[15]);
+	ACS_NP_END(15, 3, 0);
+	w = hi[3] ? kSentinel : w;
+	dump[12 * 64] = (uint16_t)w;
+	// state 0 ends in location 0 of the row
+	final_ae = w >> 16;
 	WSYNC();
 
-	// traceback, one lane per row, walking LOCATIONS: the state that ends step k in location L
-	// came from location (L with bit (3 - k%4) := decision), because the butterfly is in place.
-	// The decision of step k is the input bit of step k-4 (the oldest bit of the predecessor
-	// state), so the decoded bits are the decisions met on the way: u[k-4] = d_k, k = 211..4.
-	// (osmo_conv_decode_get_output, end state 0 after flush)
+	// survivor chain, one lane per row: window m's decisions at the survivor's location are the
+	// decoded bits u[16 m ..]; their low nibble (u[16m-4 .. 16m-1] seen from window m) is the state
+	// at the start of the window, bit-reversed: h0 -> state bit 3 -> basis vector 8, h1 -> 7,
+	// h2 -> 2, h3 -> 1  (osmo_conv_decode_get_output, end state 0 after flush)
 	if (loc == 0) {
-		const uint16_t *s16 = reinterpret_cast<const uint16_t *>(surv) + row;
-		uint32_t L = 0;    // state 0 after step 211 sits in location 0
-		uint32_t ub = 0;
-#define TB_STEP(W, PB)                                           \
-		do {                                                     \
-			const uint32_t x = ((uint32_t)(W) << (PB)) >> L;     \
-			L = (L & ~(1u << (PB))) | (x & (1u << (PB)));        \
-			ub = (ub << 1) | ((x >> (PB)) & 1u);                 \
-		} while (0)
-		for (int g = 52; g >= 1; g--) {
-			const int k = 4 * g;
-			const uint32_t w0 = s16[4 * (k + 0)], w1 = s16[4 * (k + 1)];
-			const uint32_t w2 = s16[4 * (k + 2)], w3 = s16[4 * (k + 3)];
-			TB_STEP(w3, 0);     // step k+3: phase 3 -> partner bit 0
-			TB_STEP(w2, 1);
-			TB_STEP(w1, 2);
-			TB_STEP(w0, 3);
-			if (((g - 1) & 7) == 0) {
-				ubits[row * 8 + ((g - 1) >> 3)] = ub;
-				ub = 0;
-			}
+		const uint16_t *d16 = reinterpret_cast<const uint16_t *>(surv) + row * 16;
+		// location of the state whose reversed nibble is x, x = 0..15
+		constexpr unsigned long long kLocOf =
+			0x0ull | (0x8ull << 4) | (0x7ull << 8) | (0xFull << 12) | (0x2ull << 16) | (0xAull << 20) |
+			(0x5ull << 24) | (0xDull << 28) | (0x1ull << 32) | (0x9ull << 36) | (0x6ull << 40) |
+			(0xEull << 44) | (0x3ull << 48) | (0xBull << 52) | (0x4ull << 56) | (0xCull << 60);
+		uint32_t L = 0;
+		uint32_t prev = 0;
+#pragma unroll
+		for (int m = 12; m >= 0; m--) {
+			const uint32_t h = d16[m * 64 + L];
+			L = (uint32_t)(kLocOf >> (4 * (h & 15u))) & 15u;
+			if (m & 1)
+				prev = h;
+			else
+				ubits[row * 8 + (m >> 1)] = h | (m == 12 ? 0u : (prev << 16));
 		}
-#undef TB_STEP
 	}
 	WSYNC();
 
@@ -1141,19 +1252,16 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 		// (a second, L1/L2-served read of ~300 of the burst's samples; the rest never touches LDS)
 		WSYNC();
 		{
-			int total = 0;
-			for (int c = 0; c < nch; c++)
-				total += bt.sync[0][c].len * sps + w - 1;
-			for (int sidx = lane; sidx < total; sidx += 64) {
-				int wb = 0, src = 0;
-				for (int c = 0; c < nch; c++) {
-					const int wl = bt.sync[0][c].len * sps + w - 1;
-					if (sidx >= wb && sidx < wb + wl)
-						src = bt.sync[0][c].pos * sps + (sidx - wb);
-					wb += wl;
+			int wb = 0;
+			for (int c = 0; c < nch; c++) {
+				const int wl = bt.sync[0][c].len * sps + w - 1;
+				const float2 *__restrict__ src = in + bt.sync[0][c].pos * sps;
+				float2 *dst = L.x + wb;
+				for (int sidx = lane; sidx < wl; sidx += 64) {
+					const float2 v = src[sidx];
+					dst[sidx] = make_float2((v.x - avr) * inv, (v.y - avi) * inv);
 				}
-				const float2 v = in[src];
-				L.x[sidx] = make_float2((v.x - avr) * inv, (v.y - avi) * inv);
+				wb += wl;
 			}
 		}
 		// rotated reference of the (single) sync sequence
@@ -1224,36 +1332,35 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 			if (e > pe) { pe = e; p = mi + k; }
 		}
 	}
-	// interpolated correlation at `pos` and at `pos + 2` (same fractional part, same weights):
-	// lane col holds taps k = col - 10 and k = col + 6 (the latter for col < 5): 21 taps
+	// interpolated correlation at `pos` (lanes 0-7 of the row) and at `pos + 2` (lanes 8-15): same
+	// fractional part, so the same 21 weights; lane sub = col & 7 holds taps k = 3 sub - 10 + {0,1,2}
+	const int ipt = col >> 3, isub = col & 7;
 	auto interp2 = [&](float pos, float &se, float &sl) {
 		const float fl = floorf(pos);
-		const int i0 = (int)fl;
+		const int ib = (int)fl + 2 * ipt;
 		const float f = pos - fl;
-		const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f)
-		const float sg = (col & 1) ? S : -S;                   // k has the parity of col
-		float acc_e = 0.f, acc_l = 0.f;
+		const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
+		int b = ib - 10, e = ib + 11;
+		if (b < 0) b = 0;
+		if (e >= w_r) e = w_r - 1;
+		float acc = 0.f;
 #pragma unroll
-		for (int h = 0; h < 2; h++) {
-			const int k = col - 10 + 16 * h;
+		for (int t = 0; t < 3; t++) {
+			const int k = 3 * isub - 10 + t;
+			const float sg = ((isub + t) & 1) ? S : -S;
 			const float xx = kPif * ((float)k - f);
 			const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
-			const bool tap = (h == 0) || (col < 5);
-#pragma unroll
-			for (int pt = 0; pt < 2; pt++) {
-				const int ib = i0 + 2 * pt;
-				int b = ib - 10, e = ib + 11;
-				if (b < 0) b = 0;
-				if (e >= w_r) e = w_r - 1;
-				const int i = ib + k;
-				const bool valid = tap && i >= b && i < e;
-				const float c = cr[valid ? i : 0];
-				const float term = valid ? c * wgt : 0.0f;
-				if (pt == 0) acc_e += term; else acc_l += term;
-			}
+			const int i = ib + k;
+			const bool valid = k <= 10 && i >= b && i < e;
+			const float c = cr[valid ? i : 0];
+			acc += valid ? c * wgt : 0.0f;
 		}
-		se = row_sum(acc_e);
-		sl = row_sum(acc_l);
+		acc += row_xorf<1>(acc);
+		acc += row_xorf<2>(acc);
+		acc += row_xorf<4>(acc);
+		const float oth = row_xorf<8>(acc);
+		se = ipt ? oth : acc;
+		sl = ipt ? acc : oth;
 	};
 	float early = (float)p - 1.0f, incr = 0.5f;
 	bool active = true;
