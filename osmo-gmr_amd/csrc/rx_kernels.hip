@@ -87,6 +87,29 @@ static constexpr StepTable make_steps()
 }
 __constant__ StepTable c_steps = make_steps();
 
+// Viterbi input cost of one soft bit, libosmocore's generic decoder: ((in -+ 127)^2) >> 9, and 0 for
+// an erasure (in == 0).  Index = soft bit as uint8, + 256 when the scrambler flips it (the flipped
+// value is (int8)(-v), so -128 stays -128 exactly as in gmr1_scramble_sbit, scramb.c:63-73).
+// a[]: first coded bit of a step, cost replicated to the bytes of the words ov = 0..3 it belongs
+// to (byte ov holds c0 for ov < 2, c1 otherwise); b[]: second coded bit (c0 for even ov, c1 for odd).
+struct CostTable { uint32_t a[512], b[512]; };
+static constexpr CostTable make_cost()
+{
+	CostTable t{};
+	for (int idx = 0; idx < 512; idx++) {
+		int v = (int)(int8_t)(uint8_t)(idx & 255);
+		if (idx & 256)
+			v = (int)(int8_t)(uint8_t)(-v);
+		const int e0 = v - 127, e1 = v + 127;
+		const uint32_t c0 = v ? (uint32_t)((e0 * e0) >> 9) : 0u;
+		const uint32_t c1 = v ? (uint32_t)((e1 * e1) >> 9) : 0u;
+		t.a[idx] = c0 | (c0 << 8) | (c1 << 16) | (c1 << 24);
+		t.b[idx] = c0 | (c1 << 8) | (c0 << 16) | (c1 << 24);
+	}
+	return t;
+}
+__constant__ CostTable c_cost = make_cost();
+
 struct SynTable { uint16_t s[208]; };
 static constexpr SynTable make_syn()
 {
@@ -106,6 +129,20 @@ static constexpr SynTable make_syn()
 	return t;
 }
 __constant__ SynTable c_syn = make_syn();
+
+// the same table laid out for the decoder's CRC stage: lane `loc` of a row owns decoded bits
+// 13 loc .. 13 loc + 12; w[loc][p] = s[13 loc + 2p] | s[13 loc + 2p + 1] << 16 (two 128-bit loads per lane)
+struct SynRows { uint32_t w[16][8]; };
+static constexpr SynRows make_syn_rows()
+{
+	const SynTable t = make_syn();
+	SynRows r{};
+	for (int loc = 0; loc < 16; loc++)
+		for (int q = 0; q < 13; q++)
+			r.w[loc][q >> 1] |= (uint32_t)t.s[13 * loc + q] << (16 * (q & 1));
+	return r;
+}
+__constant__ __attribute__((aligned(16))) SynRows c_syn_rows = make_syn_rows();
 
 // ---------------------------------------------------------------------------
 // cross-lane helpers (DPP: no LDS traffic)
@@ -206,6 +243,29 @@ __device__ __forceinline__ float atan2_fast(float y, float x)
 	a = (x < 0.0f) ? (kPif - a) : a;
 	a = (mx == 0.0f) ? 0.0f : a;
 	return (y < 0.0f) ? -a : a;
+}
+
+// atan2(y, x) / (2 pi), same minimax polynomial as atan2_fast with the coefficients in turns;
+// atan2_turns(0, 0) = 0
+__device__ __forceinline__ float atan2_turns(float y, float x)
+{
+	const float ax = fabsf(x), ay = fabsf(y);
+	const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+	const bool big = mn > 0.41421356237f * mx;             // tan(pi/8)
+	const float num = big ? (mn - mx) : mn;
+	const float den = big ? (mn + mx) : mx;
+	const float t = num * __builtin_amdgcn_rcpf(den);
+	const float z = t * t;
+	float p = fmaf(z, 1.28179325e-2f, -2.20870226e-2f);     // atan2_fast's coefficients / (2 pi)
+	p = fmaf(p, z, 3.17955140e-2f);
+	p = fmaf(p, z, -5.30510363e-2f);
+	p = fmaf(p, z, 1.59154943e-1f);
+	float a = p * t;
+	a += big ? 0.125f : 0.0f;
+	a = (ay > ax) ? (0.25f - a) : a;
+	a = (x < 0.0f) ? (0.5f - a) : a;
+	a = (mx == 0.0f) ? 0.0f : a;
+	return __builtin_copysignf(a, y);
 }
 
 // conj(ref) * v for ref = modulating value of sync symbol `sym` (exact: ref is +-1 / +-j)
@@ -337,13 +397,15 @@ __device__ __forceinline__ void load_normalise_stats(const float2 *__restrict__ 
 }
 
 // window statistics only (mean, 1/sigma); the samples stay in registers and are dropped
-template <int NPL>
+// NFULL >= 0: the caller knows in_len >> 6 at compile time (the fused sps = 4 path: 1016 and 976
+// samples both have 15 whole rows), which removes the per-row branches
+template <int NPL, int NFULL = -1>
 __device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in_len, int lane,
                                            float &avr_o, float &avi_o, float &inv_o)
 {
 	float2 v[NPL];
 	float sr = 0.f, si = 0.f;
-	const int nfull = in_len >> 6;
+	const int nfull = NFULL >= 0 ? NFULL : (in_len >> 6);
 	const bool tail = (lane + 64 * nfull) < in_len;
 #pragma unroll
 	for (int k = 0; k < NPL; k++) {
@@ -763,19 +825,56 @@ __device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ 
 {
 	for (int k = lane; k < kSteps12; k += 64) {
 		const uint32_t st = c_steps.w[chain][k];
-		int c0[2], c1[2];
+		// the four byte sums c(a) + c(b) of a step come out of one add of two table words
+		const uint32_t ia = (uint32_t)(uint8_t)eb[st & 0x3ffu] | ((st >> 2) & 0x100u);
+		const uint32_t ib = (uint32_t)(uint8_t)eb[(st >> 16) & 0x3ffu] | ((st >> 18) & 0x100u);
+		bm[k] = c_cost.a[ia] + c_cost.b[ib];
+	}
+}
+
+// the four bursts of a fused wave at once: every lane owns steps lane + 64 it of each burst, and the
+// three dependent fetches (step descriptor -> soft bits -> cost words) are each issued for all 16
+// (burst, step) pairs before anything waits -- three memory round trips per wave instead of 48
+__device__ __forceinline__ void branch_metrics4_k5_12(const int8_t *__restrict__ eb, int eb_stride, int row_ok,
+                                                      int row_chain, uint32_t *__restrict__ bm, int lane)
+{
+	uint32_t st[2][4];
 #pragma unroll
-		for (int j = 0; j < 2; j++) {
-			const uint32_t h = st >> (16 * j);
-			int v = eb[h & 0x3ffu];
-			if (h & 0x400u)
-				v = (int8_t)(-v);
-			const int e0 = v - 127, e1 = v + 127;
-			c0[j] = v ? (__mul24(e0, e0) >> 9) : 0;
-			c1[j] = v ? (__mul24(e1, e1) >> 9) : 0;
+	for (int c = 0; c < 2; c++)
+#pragma unroll
+		for (int it = 0; it < 4; it++) {
+			const int k = lane + 64 * it;
+			st[c][it] = k < kSteps12 ? c_steps.w[c][k] : 0u;
 		}
-		bm[k] = (uint32_t)(c0[0] + c0[1]) | ((uint32_t)(c0[0] + c1[1]) << 8) |
-		        ((uint32_t)(c1[0] + c0[1]) << 16) | ((uint32_t)(c1[0] + c1[1]) << 24);
+	uint32_t ia[4][4], ib[4][4];
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const bool ch = ((row_chain >> q) & 1) != 0;
+		const int8_t *e = eb + q * eb_stride;
+#pragma unroll
+		for (int it = 0; it < 4; it++) {
+			const uint32_t s = ch ? st[1][it] : st[0][it];
+			ia[q][it] = (uint32_t)(uint8_t)e[s & 0x3ffu] | ((s >> 2) & 0x100u);
+			ib[q][it] = (uint32_t)(uint8_t)e[(s >> 16) & 0x3ffu] | ((s >> 18) & 0x100u);
+		}
+	}
+	uint32_t va[4][4], vb[4][4];
+#pragma unroll
+	for (int q = 0; q < 4; q++)
+#pragma unroll
+		for (int it = 0; it < 4; it++) {
+			va[q][it] = c_cost.a[ia[q][it]];
+			vb[q][it] = c_cost.b[ib[q][it]];
+		}
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		const bool ok = ((row_ok >> q) & 1) != 0;
+#pragma unroll
+		for (int it = 0; it < 4; it++) {
+			const int k = lane + 64 * it;
+			if (k < kSteps12)
+				bm[q * kSteps12 + k] = ok ? va[q][it] + vb[q][it] : 0u;
+		}
 	}
 }
 
@@ -968,6 +1067,9 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 	dump[12 * 64] = (uint16_t)w;
 	// state 0 ends in location 0 of the row
 	final_ae = w >> 16;
+	// this lane's CRC syndrome words travel while the survivor chain is walked
+	const uint4 sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][0]);
+	const uint4 sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][4]);
 	WSYNC();
 
 	// survivor chain, one lane per row: window m's decisions at the survivor's location are the
@@ -999,12 +1101,18 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 	uint32_t syn = 0;
 	{
 		const uint32_t *ub = ubits + row * 8;
+		const uint32_t k0 = loc * 13u;
+		const uint32_t lo = ub[k0 >> 5], hi2 = ub[(k0 >> 5) + 1];      // word 7 of a row is never a data word
+		const uint32_t cbits = __builtin_amdgcn_alignbit(hi2, lo, k0 & 31u);
+		const uint32_t sy[7] = {sy0.x, sy0.y, sy0.z, sy0.w, sy1.x, sy1.y, sy1.z};
+		uint32_t acc = 0;
 #pragma unroll
-		for (int q = 0; q < 13; q++) {
-			const int k = (int)loc * 13 + q;
-			const uint32_t bit = (ub[k >> 5] >> (k & 31)) & 1u;
-			syn ^= bit ? (uint32_t)c_syn.s[k] : 0u;
+		for (int pq = 0; pq < 7; pq++) {
+			const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)cbits, 2 * pq, 1);
+			const uint32_t m1 = pq < 6 ? (uint32_t)__builtin_amdgcn_sbfe((int)cbits, 2 * pq + 1, 1) : 0u;
+			acc ^= sy[pq] & ((m0 & 0xffffu) | (m1 & 0xffff0000u));
 		}
+		syn = (acc ^ (acc >> 16)) & 0xffffu;
 		syn ^= row_xor<1>(syn);
 		syn ^= row_xor<2>(syn);
 		syn ^= row_xor<4>(syn);
@@ -1238,7 +1346,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 
 		const float2 *__restrict__ in = a.iq + a.offset[g];
 		float avr, avi, inv;
-		load_stats<NPL>(in, in_len, lane, avr, avi, inv);
+		load_stats<NPL, (SPS == 4 && NPL == 16) ? 15 : -1>(in, in_len, lane, avr, avi, inv);
 		if (row == q) { avr_r = avr; avi_r = avi; }
 		if (a.energy) {
 			const float e = window_energy<NPL>(in, in_len, lane);
@@ -1539,41 +1647,46 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 			continue;
 		}
 		row_ok |= 1 << q;
-		const float inv_dd = (float)(1 << nbits) / (2.0f * kPif);
-		const int mask = (1 << nbits) - 1;
-		auto reduce_2pi = [](float v) -> float {
-			const float k = rintf(v * 0.159154943091895336f);
-			v = fmaf(-k, 6.2831854820251465f, v);
-			return fmaf(-k, -1.7484555e-7f, v);
-		};
+		// phase of symbol i in TURNS: arg(x_i) + fs (i sps + d) + rps i - psi  =  arg(x_i) + A i + B
+		// (pi4cxpsk.c:351-371 derotation, :574-588 frequency / phase correction, folded into one fma)
+		const float kInv2Pi = 0.159154943091895336f;
+		const float At = (fs * (float)sps + rps) * kInv2Pi;
+		float Bt = (fs * (float)d - psi) * kInv2Pi;
+		Bt -= rintf(Bt);
+		const float scale = (float)(1 << nbits);
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int i = lane + 64 * r;
 			if (i >= blen)
 				continue;
-			const int j = i * sps + d;
 			float2 x = cur.x[r];
 			if (cur.ok & (1 << r)) {
 				x.x -= avr;
 				x.y -= avi;
 			}
-			float th = atan2_fast(x.y, x.x) + reduce_2pi(fs * (float)j);
-			th = reduce_2pi(fmaf(rps, (float)i, th) - psi);
-			const float sv = (x.x == 0.0f && x.y == 0.0f) ? 0.0f : th * inv_dd;   // cargf(0) = 0
+			float th = fmaf(At, (float)i, atan2_turns(x.y, x.x) + Bt);
+			th -= rintf(th);
+			const float sv = (x.x == 0.0f && x.y == 0.0f) ? 0.0f : th * scale;   // cargf(0) = 0
 			if (gss)
 				gss[i] = sv;
 			const int ord = cur.ord[r];
 			if (ord >= 0) {
-				const float svr2 = roundf(sv);
-				const int sp = (int)svr2 & mask;
-				const int ss = (svr2 > sv ? (sp - 1) : (sp + 1)) & mask;
-				const int dq = (int)roundf((2.0f * fabsf(svr2 - sv)) * 64.0f);
-				const int p0 = sp >> 1, p1 = (sp ^ (sp >> 1)) & 1;
-				const int s0 = ss >> 1, s1 = (ss ^ (ss >> 1)) & 1;
-				const int v0 = 127 - ((p0 ^ s0) ? dq : (dq >> 1));
-				const int v1 = 127 - ((p1 ^ s1) ? dq : (dq >> 1));
-				const uint32_t pk2 = (uint32_t)(uint8_t)(int8_t)(p0 ? -v0 : v0) |
-				                     ((uint32_t)(uint8_t)(int8_t)(p1 ? -v1 : v1) << 8);
+				// soft bits of a pi/4-CQPSK symbol (pi4cxpsk.c:452-507): nearest symbol sp (Gray bits
+				// p0 p1), its neighbour on the side of sv, distance dq in 1/128 symbol; the bit that
+				// differs between the two gets 127 - dq, the other 127 - dq/2
+				const float svr = rintf(sv);
+				const float dl = svr - sv;
+				const int dq = (int)rintf(fabsf(dl) * 128.0f);   // roundf up to exact .5 ties
+				const uint32_t sp = (uint32_t)(int)svr & 3u;
+				const uint32_t neg = __builtin_bit_cast(uint32_t, dl) >> 31;    // neighbour is sp + 1
+				const bool f0 = ((sp ^ neg ^ 1u) & 1u) != 0;                    // boundary 1|2 or 3|0: p0 differs
+				const int m_near = 127 - dq, m_far = 127 - (dq >> 1);
+				int v0 = f0 ? m_near : m_far;
+				int v1 = f0 ? m_far : m_near;
+				const int s0 = -(int)(sp >> 1), s1 = -(int)((sp ^ (sp >> 1)) & 1u);
+				v0 = (v0 ^ s0) - s0;
+				v1 = (v1 ^ s1) - s1;
+				const uint32_t pk2 = ((uint32_t)v0 & 0xffu) | (((uint32_t)v1 & 0xffu) << 8);
 				*reinterpret_cast<uint16_t *>(eb + 2 * ord) = (uint16_t)pk2;
 			}
 		}
@@ -1591,14 +1704,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 
 	// =========================== rows: layer 1 ===========================
 	WSYNC();     // the window is dead: bm / surv / ubits overlay it
-	for (int q = 0; q < 4; q++) {
-		if ((row_ok >> q) & 1) {
-			branch_metrics_k5_12(L.eb + q * 432, (row_chain >> q) & 1, L.bm + q * kSteps12, lane);
-		} else {
-			for (int k = lane; k < kSteps12; k += 64)
-				L.bm[q * kSteps12 + k] = 0;
-		}
-	}
+	branch_metrics4_k5_12(L.eb, 432, row_ok, row_chain, L.bm, lane);
 	WSYNC();
 	if (a.dbg_stop == 7)
 		return;
@@ -1757,7 +1863,12 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 			const int cw = (max_len + 15) & ~15;
 			size_t off4[4];
 			const size_t lds4 = lds4_layout(a.stage_samples, cw, off4);
-			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid), dim3(64), lds4, stream, a, a.stage_samples, cw);
+			static size_t pad = (size_t)-1;     // profiling only: extra LDS per wave to cap the occupancy
+			if (pad == (size_t)-1) {
+				const char *e = getenv("GMR1_HIP_LDS_PAD");
+				pad = e ? (size_t)atoi(e) : 0;
+			}
+			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw);
 		}
 	} else {
 		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
