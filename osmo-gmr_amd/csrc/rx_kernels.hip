@@ -1264,8 +1264,10 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
 	// pass 1 keeps only the sync-chunk windows of the burst in LDS (everything else it needs is in
 	// registers; pass 2 re-reads from L2).  Decode-time data overlays all of it:
 	//   [stage | corr 4 x cw | coef]   during pass 1 and the timing rows
-	//   [bm | surv | ubits | 4 soft-bit rows]   from pass 2 on
-	const size_t dec_bytes = 4 * kSteps12 * 4 + kSteps12 * 8 + 4 * 8 * 4;
+	//   [bm | ubits | 4 soft-bit rows / window decisions]   from pass 2 on
+	// (the 13 x 64 halfwords of window decisions overlay the soft-bit rows, which are dead once the
+	// branch metrics exist)
+	const size_t dec_bytes = 4 * kSteps12 * 4 + 4 * 8 * 4;
 	const size_t stage_bytes = align16((size_t)stage_samples * 8);
 	const size_t corr_bytes = align16((size_t)4 * cw * 4);
 	off[0] = 0;
@@ -1298,7 +1300,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 }
 
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_rx4(RxArgs a, int stage_samples, int cw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
@@ -1312,8 +1314,8 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 	L.coef = reinterpret_cast<float2 *>(lds_raw + off[2]);
 	L.eb = reinterpret_cast<int8_t *>(lds_raw + off[3]);
 	L.bm = reinterpret_cast<uint32_t *>(lds_raw + off[0]);
-	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[0] + 4 * kSteps12 * 4);
-	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + 4 * kSteps12 * 4 + kSteps12 * 8);
+	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[3]);
+	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + 4 * kSteps12 * 4);
 
 	const int g0 = blockIdx.x * 4;
 	const int g_row = g0 + row;                       // this row's burst
