@@ -141,6 +141,22 @@ int gmr1_hip_tch3_decode_batch_dev(void *stream, int n, int m, const int8_t *ebi
 int gmr1_hip_tch3_decode_batch(int n, int m, const int8_t *ebits, const uint8_t *ciph,
                                uint8_t *frames, uint8_t *bits_s, int32_t *conv);
 
+/* ---- TCH3 follow-up pieces --------------------------------------------------
+ * DKAB demodulation (gmr1_dkab_demod, include/osmocom/gmr1/sdr/dkab.h:39-41): n windows of in_len
+ * samples (117 * sps + search window), p[i] = DKAB position; rv[i] = 0 found / 1 not found;
+ * ebits n x 8 (zero where not found), toa in samples.
+ * A5 keystream (gmr1_a5, include/osmocom/gmr1/l1/a5.h:37-41): one (key, frame number) per item,
+ * keys n x 8 bytes, dl / ul n x nbits ubits (either may be NULL); alg 0 = zeros, 1 = A5/1. */
+int gmr1_hip_dkab_demod_batch_dev(void *stream, int n, int sps, int in_len,
+                                  const float *iq, const uint64_t *offset, const float *freq_shift,
+                                  const int32_t *p, int8_t *ebits, float *toa, int32_t *rv);
+int gmr1_hip_dkab_demod_batch(int n, int sps, int in_len,
+                              const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
+                              const int32_t *p, int8_t *ebits, float *toa, int32_t *rv);
+int gmr1_hip_a5_batch_dev(void *stream, int n, int alg, int nbits,
+                          const uint8_t *keys, const uint32_t *fn, uint8_t *dl, uint8_t *ul);
+int gmr1_hip_a5_batch(int n, int alg, int nbits, const uint8_t *keys, const uint32_t *fn, uint8_t *dl, uint8_t *ul);
+
 /* ---- FCCH acquisition ------------------------------------------------------
  * fcch_type: 0 gmr1_fcch_burst, 1 gmr1_fcch3_lband_burst, 2 gmr1_fcch3_sband_burst.
  * rough: n search windows of `len` samples each -> toa[i] (samples), rv[i] (0 / -errno).

@@ -92,6 +92,13 @@ void orc_tch3_decode(uint8_t *frame0, uint8_t *frame1, orc_ubit_t *bits_s,
                      const orc_sbit_t *bits_e, const orc_ubit_t *ciph, int m,
                      int *conv0_rv, int *conv1_rv);
 
+/* ---- TCH3 follow-up pieces: DKAB demodulator (reference include/osmocom/gmr1/sdr/dkab.h:39-41) and
+ *      A5 keystream (reference include/osmocom/gmr1/l1/a5.h:37-41) */
+int  orc_dkab_demod(const orc_cf *in, int in_len, int sps, float freq_shift, int p,
+                    orc_sbit_t *ebits, float *toa_p);
+void orc_a5(int n, const uint8_t *key, uint32_t fn, int nbits, orc_ubit_t *dl, orc_ubit_t *ul);
+void orc_a5_1(const uint8_t *key, uint32_t fn, int nbits, orc_ubit_t *dl, orc_ubit_t *ul);
+
 /* ---- batch drivers used by tests and by bench.py's cpu_baseline leg only */
 
 /* kind: 0 = BCCH (orc_burst BCCH + bcch_decode), 1 = CCCH (DC6 + ccch_decode) */
@@ -106,6 +113,8 @@ void orc_demod_decode_batch(int n, const orc_cf *iq, const uint64_t *offset,
 
 #define ORC_RX_TYPE_BCCH 1      /* GSMTAP_GMR1_BCCH */
 #define ORC_RX_TYPE_CCCH 2      /* GSMTAP_GMR1_CCCH */
+#define ORC_RX_TYPE_TCH3 0x10       /* GSMTAP_GMR1_TCH3: two 10-byte speech frames (the reference only logs them) */
+#define ORC_RX_TYPE_TCH3_FACCH 0x12 /* GSMTAP_GMR1_TCH3 | GSMTAP_GMR1_FACCH, 10 bytes, fn = last burst's fn - 3 */
 
 struct orc_rx_record {          /* what gmr1_rx hands to GSMTAP for a frame whose CRC passed */
 	uint16_t arfcn;
@@ -118,5 +127,7 @@ struct orc_rx_record {          /* what gmr1_rx hands to GSMTAP for a frame whos
 
 int orc_rx_run(const orc_cf *iq, int len, int sps, int arfcn,
                struct orc_rx_record *out, int max_records, int *n_records, int *n_chains);
+int orc_rx_run_tch(const orc_cf *iq, const orc_cf *tch, int len, int sps, int arfcn, const uint8_t *kc,
+                   struct orc_rx_record *out, int max_records, int *n_records, int *n_chains);
 
 #endif

@@ -2,8 +2,9 @@
  * oracle/orc_rx.c -- TEST INFRASTRUCTURE ONLY.  CPU restatement of the receive control loop of
  * the reference's gmr1_rx application for one BCCH carrier (reference src/gmr1_rx.c): FCCH single
  * acquisition, multi-FCCH survivor selection, then the frame-by-frame BCCH / CCCH loop with its
- * tracking feedback (align, freq_err, TDMA position from SI1).  TCH follow-up (IMM.ASS ->
- * rx_tch3 / rx_tch9), GSMTAP transport and stderr logging are outside the scope;
+ * tracking feedback (align, freq_err, TDMA position from SI1), and the TCH3 follow-up after an
+ * IMMEDIATE ASSIGNMENT (DKAB / FACCH3 / speech on the traffic carrier, A5/1).  The TCH9 follow-up,
+ * GSMTAP transport and stderr logging are outside the scope;
  * what GSMTAP would have carried is returned as records.  PARITY UNPINNED, see orc_3p.h.
  */
 #include "orc_gmr1.h"
@@ -16,8 +17,21 @@
 #define SYM_RATE 23400
 #define PIf 3.14159265358979323846f
 
+struct tch3_state {                 /* gmr1_rx.c:59-78 */
+	int active;
+	int tn, p, ciph;
+	float energy_dkab, energy_burst;
+	int weak_cnt;
+	orc_sbit_t ebits[104 * 4];
+	uint32_t bi_fn[4];
+	int sync_id, burst_cnt;
+};
+
 struct chan_desc {                  /* gmr1_rx.c:93-115, the fields this scope uses */
 	const orc_cf *iq;
+	const orc_cf *tch;              /* traffic carrier, same length and timing as iq (may be NULL) */
+	struct tch3_state tch3_state;
+	uint8_t kc[8];
 	int len;
 	int sps;
 	int align;
@@ -32,6 +46,24 @@ struct sink {
 	int max, n;
 	int arfcn, chain;
 };
+
+static void emit_n(struct sink *s, int type, int fn, int tn, const uint8_t *l2, int n, int conv)
+{
+	if (s->n < s->max) {
+		struct orc_rx_record *r = &s->out[s->n];
+		memset(r, 0, sizeof(*r));
+		r->arfcn = (uint16_t)s->arfcn;
+		r->chain = (uint8_t)s->chain;
+		r->type = (uint8_t)type;
+		r->fn = (uint32_t)fn;
+		r->tn = (uint8_t)tn;
+		r->crc = 0;
+		r->len = (uint8_t)n;
+		r->conv = conv;
+		memcpy(r->l2, l2, (size_t)n);
+	}
+	s->n++;
+}
 
 static void emit(struct sink *s, int type, int fn, int tn, const uint8_t *l2, int conv)
 {
@@ -98,6 +130,150 @@ static void bcch_tdma_align(struct chan_desc *cd, const uint8_t *l2)
 	cd->sa_bcch_stn = stn;
 }
 
+/* ---- TCH3 follow-up (gmr1_rx.c:235-246, 355-600) -------------------------------------------- */
+
+static int ccch_is_imm_ass(const uint8_t *l2) { return (l2[1] == 0x06) && (l2[2] == 0x3f); }
+
+static void ccch_imm_ass_parse(const uint8_t *l2, int *rx_tn, int *p)
+{
+	*p = (l2[8] & 0xfc) >> 2;
+	*rx_tn = ((l2[8] & 0x03) << 3) | (l2[9] >> 5);
+}
+
+/* gmr1_rx.c:358-378: note what it does NOT reset (ciph, burst_cnt, bi_fn) */
+static void rx_tch3_init(struct chan_desc *cd, const uint8_t *imm_ass, float ref_energy)
+{
+	struct tch3_state *st = &cd->tch3_state;
+	st->active = 1;
+	ccch_imm_ass_parse(imm_ass, &st->tn, &st->p);
+	st->energy_burst = ref_energy * 0.75f;
+	st->energy_dkab = st->energy_burst / 8.0f;
+	st->weak_cnt = 0;
+	st->sync_id = 0;
+	memset(st->ebits, 0x00, sizeof(st->ebits));
+}
+
+/* gmr1_rx.c:397-450 */
+static void rx_tch3_facch_flush(struct chan_desc *cd, struct sink *s)
+{
+	struct tch3_state *st = &cd->tch3_state;
+	orc_ubit_t ciph_buf[96 * 4], *ciph;
+	uint8_t l2[10];
+	orc_ubit_t sbits[8 * 4];
+	int i, crc, conv;
+
+	if (st->ciph) {
+		ciph = ciph_buf;
+		for (i = 0; i < 4; i++)
+			orc_a5(1, cd->kc, st->bi_fn[i], 96, ciph + (96 * i), NULL);
+	} else
+		ciph = NULL;
+	crc = orc_facch3_decode(l2, sbits, st->ebits, ciph, &conv);
+	if (!st->ciph && crc) {
+		ciph = ciph_buf;
+		for (i = 0; i < 4; i++)
+			orc_a5(1, cd->kc, st->bi_fn[i], 96, ciph + (96 * i), NULL);
+		crc = orc_facch3_decode(l2, sbits, st->ebits, ciph, &conv);
+		if (!crc)
+			st->ciph = 1;
+	}
+	if (!crc)
+		emit_n(s, ORC_RX_TYPE_TCH3_FACCH, cd->fn - 3, st->tn, l2, 10, conv);
+	/* (an ASSIGNMENT COMMAND 1 would start the TCH9 follow-up when a CSD capture is given: not in scope) */
+	st->sync_id ^= 1;
+	st->burst_cnt = 0;
+	memset(st->bi_fn, 0xff, sizeof(st->bi_fn));
+	memset(st->ebits, 0x00, sizeof(st->ebits));
+}
+
+/* gmr1_rx.c:452-493 */
+static int rx_tch3_facch(struct chan_desc *cd, const orc_cf *burst, int len, struct sink *s)
+{
+	struct tch3_state *st = &cd->tch3_state;
+	orc_sbit_t ebits[104];
+	int rv, bi, sync_id;
+	float toa;
+
+	bi = cd->fn & 3;
+	rv = orc_pi4cxpsk_demod(orc_burst_get(ORC_BURST_NT3_FACCH), burst, len, cd->sps, -cd->freq_err,
+	                        ebits, &sync_id, &toa, NULL, NULL);
+	if (rv < 0)
+		return rv;
+	if (sync_id != st->sync_id)
+		rx_tch3_facch_flush(cd, s);
+	memcpy(&st->ebits[104 * bi], ebits, sizeof(orc_sbit_t) * 104);
+	st->sync_id = sync_id;
+	st->bi_fn[bi] = (uint32_t)cd->fn;
+	st->burst_cnt += 1;
+	if (st->burst_cnt == 4)
+		rx_tch3_facch_flush(cd, s);
+	return 0;
+}
+
+/* gmr1_rx.c:495-529; the reference only logs the two speech frames, here they are returned too */
+static int rx_tch3_speech(struct chan_desc *cd, const orc_cf *burst, int len, struct sink *s)
+{
+	orc_sbit_t ebits[212];
+	orc_ubit_t sbits[4], ciph[208];
+	uint8_t fr[20];
+	int rv, conv[2];
+	float toa;
+
+	rv = orc_pi4cxpsk_demod(orc_burst_get(ORC_BURST_NT3_SPEECH), burst, len, cd->sps, -cd->freq_err,
+	                        ebits, NULL, &toa, NULL, NULL);
+	if (rv < 0)
+		return rv;
+	orc_a5(cd->tch3_state.ciph, cd->kc, (uint32_t)cd->fn, 208, ciph, NULL);
+	orc_tch3_decode(fr, fr + 10, sbits, ebits, ciph, 0, &conv[0], &conv[1]);
+	emit_n(s, ORC_RX_TYPE_TCH3, cd->fn, cd->tch3_state.tn, fr, 20, (conv[0] & 0xffff) | (conv[1] << 16));
+	return 0;
+}
+
+/* gmr1_rx.c:531-600 */
+static int rx_tch3(struct chan_desc *cd, struct sink *s)
+{
+	const struct orc_burst *bts[2] = { orc_burst_get(ORC_BURST_NT3_FACCH), orc_burst_get(ORC_BURST_NT3_SPEECH) };
+	struct tch3_state *st = &cd->tch3_state;
+	const orc_cf *burst;
+	int begin, len, e_toa, rv, btid, sid;
+	float be, det, toa;
+
+	if (!st->active)
+		return 0;
+	if (!cd->tch)
+		return -EINVAL;
+	e_toa = burst_map(cd, bts[0]->len, st->tn, cd->sps + (cd->sps / 2), &begin, &len);
+	if (e_toa < 0)
+		return e_toa;
+	burst = cd->tch + begin;
+
+	be = burst_energy(burst, len);
+	det = (st->energy_dkab + st->energy_burst) / 4.0f;
+	if (be < det) {
+		orc_sbit_t ebits[8];
+		rv = orc_dkab_demod(burst, len, cd->sps, -cd->freq_err, st->p, ebits, &toa);
+		if (rv < 0)
+			return rv;
+		else if (rv == 1) {
+			if (st->weak_cnt++ > 8)
+				st->active = 0;
+		} else
+			st->energy_dkab = (0.1f * be) + (0.9f * st->energy_dkab);
+		return 0;
+	} else
+		st->weak_cnt = 0;
+	st->energy_burst = (0.1f * be) + (0.9f * st->energy_burst);
+
+	rv = orc_pi4cxpsk_detect(bts, 2, (float)e_toa, burst, len, cd->sps, -cd->freq_err, &btid, &sid, &toa);
+	if (rv < 0)
+		return rv;
+	if (btid == 0)
+		rv = rx_tch3_facch(cd, burst, len, s);
+	else
+		rv = rx_tch3_speech(cd, burst, len, s);
+	return rv;
+}
+
 /* gmr1_rx.c:746-798 */
 static void rx_bcch(struct chan_desc *cd, float *energy, struct sink *s)
 {
@@ -140,8 +316,11 @@ static void rx_ccch(struct chan_desc *cd, float min_energy, struct sink *s)
 	if (rv)
 		return;
 	crc = orc_ccch_decode(l2, ebits, &conv);
-	if (!crc)
+	if (!crc) {
+		if (ccch_is_imm_ass(l2))
+			rx_tch3_init(cd, l2, min_energy);
 		emit(s, ORC_RX_TYPE_CCCH, cd->fn, cd->sa_bcch_stn, l2, conv);
+	}
 }
 
 /* gmr1_rx.c:852-895 */
@@ -155,6 +334,7 @@ static void process_bcch(struct chan_desc *cd, struct sink *s)
 			rx_bcch(cd, &bcch_energy, s);
 		if ((sirfn % 8 != 0) && (sirfn % 8 != 2))
 			rx_ccch(cd, bcch_energy / 2.0f, s);
+		rx_tch3(cd, s);
 		cd->fn++;
 		cd->align += frame_len;
 		if ((cd->align + 2 * frame_len) > cd->len)
@@ -165,6 +345,14 @@ static void process_bcch(struct chan_desc *cd, struct sink *s)
 int orc_rx_run(const orc_cf *iq, int len, int sps, int arfcn,
                struct orc_rx_record *out, int max_records, int *n_records, int *n_chains)
 {
+	return orc_rx_run_tch(iq, NULL, len, sps, arfcn, NULL, out, max_records, n_records, n_chains);
+}
+
+/* main() with the optional tch.cfile and key arguments (gmr1_rx.c:897-975); kc NULL = the all-zero key
+ * the reference starts with */
+int orc_rx_run_tch(const orc_cf *iq, const orc_cf *tch, int len, int sps, int arfcn, const uint8_t *kc,
+                   struct orc_rx_record *out, int max_records, int *n_records, int *n_chains)
+{
 	struct chan_desc cd;
 	struct sink s = { out, max_records, 0, arfcn, 0 };
 	int rv, toa, base_align, mtoa[16], n_fcch, i, j;
@@ -174,7 +362,9 @@ int orc_rx_run(const orc_cf *iq, int len, int sps, int arfcn,
 	*n_records = 0;
 	if (n_chains) *n_chains = 0;
 	memset(&cd, 0, sizeof(cd));
-	cd.iq = iq; cd.len = len; cd.sps = sps;
+	cd.iq = iq; cd.tch = tch; cd.len = len; cd.sps = sps;
+	if (kc)
+		memcpy(cd.kc, kc, 8);
 	cd.align = START_DISCARD;                       /* gmr1_rx.c:906-909 */
 
 	/* fcch_single_init, gmr1_rx.c:605-639 */

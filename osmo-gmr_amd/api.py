@@ -36,6 +36,8 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
     "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
+    "gmr1_hip_dkab_demod_batch_dev", "gmr1_hip_dkab_demod_batch", "gmr1_dkab_demod",
+    "gmr1_hip_a5_batch_dev", "gmr1_hip_a5_batch", "gmr1_a5", "gmr1_a5_1",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -572,3 +574,66 @@ def gsmtap_pack(record, with_arfcn=False) -> bytes:
     if n < 0:
         _check(n, "gmr1_hip_gsmtap_pack")
     return bytes(buf[:n])
+
+
+# ---------------------------------------------------------------------------
+# TCH3 follow-up pieces: DKAB demodulator, A5 keystream
+# ---------------------------------------------------------------------------
+def dkab_demod_batch(iq, offset, in_len, p, sps=4, freq_shift=None):
+    """gmr1_hip_dkab_demod_batch -> (rv[n], ebits[n, 8], toa[n])"""
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    pp, p_p = _np(np.broadcast_to(np.asarray(p, np.int32), (n,)), np.int32)
+    fs_p = None
+    if freq_shift is not None:
+        fs, fs_p = _np(np.broadcast_to(np.asarray(freq_shift, np.float32), (n,)), np.float32)
+    eb = np.zeros((n, 8), np.int8)
+    toa = np.zeros(n, np.float32)
+    rv = np.zeros(n, np.int32)
+    f = load().gmr1_hip_dkab_demod_batch
+    f.restype = C.c_int
+    rc = f(C.c_int(n), C.c_int(sps), C.c_int(in_len), p_iq, C.c_uint64(iq.size), p_off, fs_p, p_p,
+           eb.ctypes.data_as(C.c_void_p), toa.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_dkab_demod_batch")
+    return rv, eb, toa
+
+
+def dkab_demod(iq, sps=4, freq_shift=0.0, p=0):
+    """gmr1_dkab_demod, the reference's own call -> (rv, ebits[8], toa)"""
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    v = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
+    eb = np.zeros(8, np.int8)
+    toa = C.c_float(0.0)
+    f = load().gmr1_dkab_demod
+    f.restype = C.c_int
+    rv = f(C.byref(v), C.c_int(sps), C.c_float(freq_shift), C.c_int(p), eb.ctypes.data_as(C.c_void_p), C.byref(toa))
+    if rv < 0:
+        _check(rv, "gmr1_dkab_demod")
+    return rv, eb, toa.value
+
+
+def a5_batch(alg, keys, fn, nbits, want_ul=False):
+    """gmr1_hip_a5_batch: keys (n, 8) or (8,), fn (n,) -> dl (n, nbits) [, ul]"""
+    fn, p_fn = _np(np.atleast_1d(fn), np.uint32)
+    n = fn.size
+    keys, p_k = _np(np.broadcast_to(np.asarray(keys, np.uint8).reshape(-1, 8), (n, 8)), np.uint8)
+    dl = np.zeros((n, nbits), np.uint8)
+    ul = np.zeros((n, nbits), np.uint8) if want_ul else None
+    f = load().gmr1_hip_a5_batch
+    f.restype = C.c_int
+    rc = f(C.c_int(n), C.c_int(alg), C.c_int(nbits), p_k, p_fn, dl.ctypes.data_as(C.c_void_p),
+           ul.ctypes.data_as(C.c_void_p) if want_ul else None)
+    _check(rc, "gmr1_hip_a5_batch")
+    return (dl, ul) if want_ul else dl
+
+
+def a5(n, key, fn, nbits):
+    """gmr1_a5, the reference's own call -> (dl, ul)"""
+    key, p_k = _np(key, np.uint8)
+    dl = np.full(nbits, 0xEE, np.uint8)
+    ul = np.full(nbits, 0xEE, np.uint8)
+    f = load().gmr1_a5
+    f.restype = None
+    f(C.c_int(n), p_k, C.c_uint32(int(fn)), C.c_int(nbits), dl.ctypes.data_as(C.c_void_p), ul.ctypes.data_as(C.c_void_p))
+    return dl, ul

@@ -161,6 +161,28 @@ struct Tch3Args {
 	int32_t *conv;             // optional n x 2
 };
 
+struct DkabArgs {
+	int n, sps, in_len;
+	const float2 *iq;
+	const uint64_t *offset;
+	const float *freq_shift;   // optional, rad/symbol
+	const int32_t *p;          // DKAB position per burst
+	int8_t *ebits;             // optional n x 8
+	float *toa;                // optional
+	int32_t *rv;               // 0 found, 1 not found, < 0 error
+};
+
+struct A5Args {
+	int n;                     // (key, fn) pairs
+	int alg;                   // 0: zeros, 1: A5/1
+	int nbits;
+	const uint8_t *keys;       // n x 8
+	const uint32_t *fn;
+	uint8_t *dl, *ul;          // optional n x nbits ubits each
+};
+
+hipError_t launch_dkab(const DkabArgs &a, hipStream_t stream);
+hipError_t launch_a5(const A5Args &a, hipStream_t stream);
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
 hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);
 

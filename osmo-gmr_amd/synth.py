@@ -148,8 +148,8 @@ def ccch_encode(l2: np.ndarray) -> np.ndarray:
     return ep ^ scramble_mask(432)
 
 
-def facch3_encode(l2: np.ndarray, bits_s: np.ndarray) -> np.ndarray:
-    """(B,10) bytes (76 bits used), (B,32) status bits -> (B,4,104)."""
+def facch3_encode(l2: np.ndarray, bits_s: np.ndarray, ciph: np.ndarray | None = None) -> np.ndarray:
+    """(B,10) bytes (76 bits used), (B,32) status bits [, (B,384) cipher stream] -> (B,4,104)."""
     u = unpack_lsb(l2, 76)
     u = np.concatenate([u, crc_bits(u, 16, 0x1021)], axis=1)
     c = conv_encode(u, K5_14, 5)          # (B, 384)
@@ -161,6 +161,8 @@ def facch3_encode(l2: np.ndarray, bits_s: np.ndarray) -> np.ndarray:
     scr = scramble_mask(96)
     for b in range(4):
         xmy = interleave_intra(cp[:, 96 * b:96 * b + 96], 12) ^ scr
+        if ciph is not None:
+            xmy = xmy ^ ciph[:, 96 * b:96 * b + 96]
         out[:, b, :22] = xmy[:, :22]
         out[:, b, 22:30] = bits_s[:, 8 * b:8 * b + 8]
         out[:, b, 30:] = xmy[:, 22:]
@@ -173,8 +175,9 @@ def tch3_perm() -> np.ndarray:
     return np.where(ii < 8, ij + 5 * ii, ij + 4 * ii + 8)
 
 
-def tch3_encode(frame0: np.ndarray, frame1: np.ndarray, bits_s: np.ndarray, m: int = 0) -> np.ndarray:
-    """two (B,10) speech frames + (B,4) status -> (B,212)."""
+def tch3_encode(frame0: np.ndarray, frame1: np.ndarray, bits_s: np.ndarray, m: int = 0,
+                ciph: np.ndarray | None = None) -> np.ndarray:
+    """two (B,10) speech frames + (B,4) status [, (B,208) cipher stream] -> (B,212)."""
     B = frame0.shape[0]
     epp = np.zeros((B, 208), np.uint8)
     perm = tch3_perm()
@@ -190,6 +193,8 @@ def tch3_encode(frame0: np.ndarray, frame1: np.ndarray, bits_s: np.ndarray, m: i
         else:
             epp[:, i::2] = ep
     xmy = epp ^ scramble_mask(208)
+    if ciph is not None:
+        xmy = xmy ^ ciph
     out = np.zeros((B, 212), np.uint8)
     out[:, :52] = xmy[:, :52]
     out[:, 52:56] = bits_s
@@ -336,6 +341,16 @@ def shape_bursts(symbols: np.ndarray, sps: int, frac, span: int = 5) -> np.ndarr
     return np.ascontiguousarray(body.transpose(1, 2, 0)).reshape(B, n_sym_out * sps)
 
 
+def imm_ass_payload(rng: np.random.Generator, tn: int, p: int) -> np.ndarray:
+    """A CCCH message gmr1_rx takes for an IMMEDIATE ASSIGNMENT (ccch_is_imm_ass / ccch_imm_ass_parse,
+    reference src/gmr1_rx.c:235-246): receive timeslot tn (5 bits), DKAB position p (6 bits)."""
+    l2 = rng.integers(0, 256, size=24, dtype=np.uint8)
+    l2[1], l2[2] = 0x06, 0x3F
+    l2[8] = ((p & 0x3F) << 2) | ((tn >> 3) & 0x03)
+    l2[9] = ((tn & 0x07) << 5) | (l2[9] & 0x1F)
+    return l2
+
+
 def si1_payload(rng: np.random.Generator, fn: np.ndarray, delay: int, stn: int) -> np.ndarray:
     """BCCH System Information type 1 with a 'Seg 2A bis' carrying the TDMA position, as
     bcch_tdma_align() parses it (reference src/gmr1_rx.c:194-233).  fn is the frame number of
@@ -359,13 +374,15 @@ def si1_payload(rng: np.random.Generator, fn: np.ndarray, delay: int, stn: int) 
 def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: int, sps: int,
                        rng: np.random.Generator, *, stn: int = 3, delay: int = 2, fn0: int | None = None,
                        t0: int | None = None, frac: float = 0.0, esn0_db: float = 15.0, cfo_hz: float = 0.0,
-                       p_idle: float = 0.15, fcch_db: float = 0.0):
+                       p_idle: float = 0.15, fcch_db: float = 0.0, imm_ass=()):
     """One ARFCN of BASELINE.md config 4: FCCH + BCCH (SI1 w/ Seg 2A bis) + CCCH on the
     24-slot / 40 ms TDMA grid (reference src/gmr1_rx.c:852-895 schedule).
 
     Frame k starts at sample t0 + k*24*39*sps and has frame number fn0 + k; with
     sirfn = (fn - delay) & 63:  sirfn % 8 == 0 -> FCCH, == 2 -> BCCH, else CCCH (DC6) unless idle;
-    all on timeslot stn.  Returns (stream complex64, list of dicts describing what was sent)."""
+    all on timeslot stn.  imm_ass = [(k, tn, p), ...]: the first CCCH burst sent at frame index >= k
+    carries an IMMEDIATE ASSIGNMENT to timeslot tn with DKAB position p (gmr1_rx.c:235-246).
+    Returns (stream complex64, list of dicts describing what was sent)."""
     frame_len = 24 * 39 * sps
     if t0 is None:
         t0 = int(rng.integers(0, frame_len))
@@ -403,13 +420,21 @@ def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: i
     kc = kc[rng.random(kc.size) >= p_idle]
     if kc.size:
         l2 = rng.integers(0, 256, size=(kc.size, 24), dtype=np.uint8)
-        l2[:, 1] &= 0xF7                              # never an IMM.ASS (gmr1_rx.c:235-239): no TCH follow-up
+        l2[:, 1] &= 0xF7                              # never an IMM.ASS (gmr1_rx.c:235-239) by accident
+        ia_of = {}
+        for (k_req, tn_a, p_a) in imm_ass:
+            later = np.nonzero(kc >= k_req)[0]
+            if later.size:
+                i_a = int(later[0])
+                l2[i_a] = imm_ass_payload(rng, tn_a, p_a)
+                ia_of[i_a] = (tn_a, p_a)
         body = shape_bursts(map_symbols(fmt_dc6, ccch_encode(l2)), sps, frac, span)
         for i, k in enumerate(kc):
             pos = t0 + k * frame_len + stn * 39 * sps - span * sps
             if pos >= 0 and pos + body.shape[1] <= n_samples:
                 x[pos:pos + body.shape[1]] += body[i]
-                sent.append(dict(type="ccch", fn=int(fns[k]), pos=pos + span * sps, l2=l2[i].copy()))
+                sent.append(dict(type="ccch", fn=int(fns[k]), pos=pos + span * sps, l2=l2[i].copy(), k=int(k),
+                                 imm_ass=ia_of.get(i)))
     if cfo_hz:
         n = np.arange(n_samples, dtype=np.float64)
         ph = (2 * np.pi * cfo_hz / (SYM_RATE * sps)) * n
@@ -448,3 +473,156 @@ def synth_fcch_stream(n_samples: int, sps: int, rng: np.random.Generator, *, snr
         n = np.arange(n_samples)
         x *= np.exp(1j * 2 * np.pi * cfo_hz / (SYM_RATE * sps) * n).astype(np.complex64)
     return x, starts
+
+
+# --------------------------------------------------------------------------
+# TCH3 follow-up (BASELINE.md config 4 with a traffic channel): A5/1, DKAB, the TCH carrier
+# --------------------------------------------------------------------------
+def a5_1(key, fn, nbits: int) -> np.ndarray:
+    """GMR-1 A5/1 downlink keystream (reference src/l1/a5.c:222-282), vectorised over frames:
+    key = 8 bytes, fn = (B,) frame numbers -> (B, nbits) bits."""
+    key = np.asarray(key, np.uint8)
+    fn = np.atleast_1d(np.asarray(fn, np.int64))
+    B = fn.size
+    lkey = np.tile(key[np.arange(8) ^ 1].astype(np.int64), (B, 1))
+    lkey[:, 6] ^= (fn & 0x0000F) << 4
+    lkey[:, 3] ^= (fn & 0x00030) << 2
+    lkey[:, 1] ^= (fn & 0x007C0) >> 3
+    lkey[:, 0] ^= (fn & 0x0F800) >> 11
+    lkey[:, 0] ^= (fn & 0x70000) >> 11
+    lkey &= 0xFF
+    lens = (19, 22, 23, 17)
+    taps = (0x072000, 0x311000, 0x660000, 0x013100)
+    r = [np.zeros(B, np.int64) for _ in range(4)]
+
+    def par(x):
+        x = x ^ (x >> 16)
+        x = x ^ (x >> 8)
+        x = x ^ (x >> 4)
+        x = x ^ (x >> 2)
+        x = x ^ (x >> 1)
+        return x & 1
+
+    def clk(x, i):
+        return ((x << 1) & ((1 << lens[i]) - 1)) | par(x & taps[i])
+
+    for i in range(64):
+        b = (lkey[:, i >> 3] >> (7 - (i & 7))) & 1
+        for j in range(4):
+            r[j] = clk(r[j], j) ^ b
+    for j in range(4):
+        r[j] |= 1
+
+    def step():
+        cb = [(r[3] >> 15) & 1, (r[3] >> 6) & 1, (r[3] >> 1) & 1]
+        m = ((cb[0] + cb[1] + cb[2]) >= 2).astype(np.int64)
+        for j in range(3):
+            r[j] = np.where(cb[j] == m, clk(r[j], j), r[j])
+        r[3] = clk(r[3], 3)
+
+    def maj(x, a, b, c):
+        return ((((x >> a) & 1) + ((x >> b) & 1) + ((x >> c) & 1)) >= 2).astype(np.int64)
+
+    for _ in range(250):
+        step()
+    out = np.zeros((B, nbits), np.uint8)
+    for i in range(nbits):
+        step()
+        m0 = maj(r[0], 1, 6, 15) ^ ((r[0] >> 11) & 1)
+        m1 = maj(r[1], 3, 8, 14) ^ ((r[1] >> 1) & 1)
+        m2 = maj(r[2], 4, 15, 19) ^ (r[2] & 1)
+        out[:, i] = m0 ^ m1 ^ m2
+    return out
+
+
+def dkab_symbols(bits: np.ndarray, p: int) -> np.ndarray:
+    """(B, 8) bits -> (B, 117) symbols of a DKAB: two keep-alive bursts of 5 pi/4-rotated BPSK symbols at
+    symbol 2 + p and 2 + p + 59, differentially encoded (bit = 1: phase flips), nothing in between --
+    what gmr1_dkab_demod looks for (reference src/sdr/dkab.c:57-181)."""
+    bits = np.asarray(bits, np.uint8)
+    B = bits.shape[0]
+    sym = np.zeros((B, 117), np.complex64)
+    for h in range(2):
+        s = np.ones(B)
+        base = 2 + p + 59 * h
+        for k in range(5):
+            if base + k < 117:
+                sym[:, base + k] = s
+            if k < 4:
+                s = s * (1.0 - 2.0 * bits[:, 4 * h + k])
+    sym *= np.exp(1j * (np.pi / 4) * np.arange(117)).astype(np.complex64)
+    return sym
+
+
+def synth_tch3_carrier(fmt_speech: BurstFormat, fmt_facch: BurstFormat, n_samples: int, sps: int,
+                       rng: np.random.Generator, *, t0: int, fn0: int, k_start: int, tn: int, p: int,
+                       kc=None, cipher_from: int | None = None, esn0_db: float = 25.0, cfo_hz: float = 0.0,
+                       frac: float = 0.0, mix=(0.35, 0.35, 0.3), k_stop: int | None = None):
+    """The traffic carrier of a TCH3 assignment, time-aligned with the BCCH carrier (same t0 / fn0):
+    from frame index k_start on, timeslot tn carries per frame a DKAB, an NT3 speech burst, or -- in
+    groups of four frames with fn & 3 = 0..3 -- the four bursts of a FACCH3 message (sync sequence
+    alternating per message).  mix = probabilities (dkab, speech, facch group) per decision.
+    Bursts from frame index `cipher_from` on are A5/1-ciphered with kc (speech: fn of the burst,
+    FACCH3: fn of each of its four bursts; reference src/gmr1_rx.c:390-399, 500-503).
+    Returns (stream, sent list of dicts)."""
+    frame_len = 24 * 39 * sps
+    sigma = np.sqrt(10.0 ** (-esn0_db / 10.0) / 2.0)
+    x = rng.standard_normal((n_samples, 2), dtype=np.float32).view(np.complex64).reshape(-1)
+    x *= np.float32(sigma)
+    span = 5
+    n_frames = (n_samples - t0) // frame_len - 1
+    if k_stop is not None:
+        n_frames = min(n_frames, k_stop)
+    sent = []
+
+    def put(k, symbols):
+        body = shape_bursts(symbols[None, :], sps, frac, span)[0]
+        pos = t0 + k * frame_len + tn * 39 * sps - span * sps
+        if pos >= 0 and pos + body.size <= n_samples:
+            x[pos:pos + body.size] += body
+            return True
+        return False
+
+    def ciphered(k):
+        return kc is not None and cipher_from is not None and k >= cipher_from
+
+    k = k_start
+    facch_sid = 0
+    while k < n_frames:
+        fn = fn0 + k
+        u = rng.random()
+        if u < mix[0]:
+            bits = rng.integers(0, 2, size=(1, 8), dtype=np.uint8)
+            if put(k, dkab_symbols(bits, p)[0]):
+                sent.append(dict(type="dkab", fn=fn, k=k, bits=bits[0]))
+            k += 1
+        elif u < mix[0] + mix[1] or (fn & 3) != 0 or k + 4 > n_frames:
+            f0 = rng.integers(0, 256, size=(1, 10), dtype=np.uint8)
+            f1 = rng.integers(0, 256, size=(1, 10), dtype=np.uint8)
+            sb = rng.integers(0, 2, size=(1, 4), dtype=np.uint8)
+            ciph = a5_1(kc, [fn], 208) if ciphered(k) else None
+            e = tch3_encode(f0, f1, sb, 0, ciph)
+            if put(k, map_symbols(fmt_speech, e)[0]):
+                sent.append(dict(type="speech", fn=fn, k=k, frame0=f0[0], frame1=f1[0], ciph=ciph is not None))
+            k += 1
+        else:
+            l2 = rng.integers(0, 256, size=(1, 10), dtype=np.uint8)
+            l2[0, 9] &= 0x0F                                  # 76 bits
+            if l2[0, 3] == 0x06 and l2[0, 4] == 0x2E:
+                l2[0, 4] = 0                                  # never an ASSIGNMENT COMMAND 1 by accident
+            sb = rng.integers(0, 2, size=(1, 32), dtype=np.uint8)
+            ciph = None
+            if ciphered(k):
+                ciph = np.concatenate([a5_1(kc, [fn + b], 96) for b in range(4)], axis=1)
+            e = facch3_encode(l2, sb, ciph)                   # (1, 4, 104)
+            ok = True
+            for b in range(4):
+                ok &= put(k + b, map_symbols(fmt_facch, e[:, b, :], sync_id=facch_sid)[0])
+            if ok:
+                sent.append(dict(type="facch3", fn=fn, k=k, l2=l2[0], sync_id=facch_sid, ciph=ciph is not None))
+            facch_sid ^= 1
+            k += 4
+    if cfo_hz:
+        n = np.arange(n_samples, dtype=np.float64)
+        x *= np.exp(1j * (2 * np.pi * cfo_hz / (SYM_RATE * sps)) * n).astype(np.complex64)
+    return x, sent

@@ -313,3 +313,46 @@ def rx_run(iq, sps=4, arfcn=0, max_records=4096):
     rv = f(_p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_int(arfcn),
            out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n), C.byref(nch))
     return rv, out[:min(n.value, max_records)].copy(), nch.value
+
+
+def dkab_demod(iq, sps=4, freq_shift=0.0, p=0):
+    """orc_dkab_demod -> (rv, ebits[8], toa)"""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    eb = np.zeros(8, np.int8)
+    toa = C.c_float(0.0)
+    f = lib().orc_dkab_demod
+    f.restype = C.c_int
+    rv = f(_p(iq, C.c_float), C.c_int(iq.size), C.c_int(sps), C.c_float(freq_shift), C.c_int(p),
+           eb.ctypes.data_as(C.c_void_p), C.byref(toa))
+    return rv, eb, toa.value
+
+
+def a5(n, key, fn, nbits):
+    """orc_a5 -> (dl bits, ul bits)"""
+    key = np.ascontiguousarray(key, np.uint8)
+    dl = np.zeros(nbits, np.uint8)
+    ul = np.zeros(nbits, np.uint8)
+    lib().orc_a5(C.c_int(n), key.ctypes.data_as(C.c_void_p), C.c_uint32(int(fn)), C.c_int(nbits),
+                 dl.ctypes.data_as(C.c_void_p), ul.ctypes.data_as(C.c_void_p))
+    return dl, ul
+
+
+def rx_run_tch(iq, tch, sps=4, arfcn=0, kc=None, max_records=1 << 16):
+    """orc_rx_run_tch: gmr1_rx with the traffic carrier `tch` (same length / timing as iq) and key kc."""
+    iq = np.ascontiguousarray(iq, np.complex64)
+    p_tch = None
+    if tch is not None:
+        tch = np.ascontiguousarray(tch, np.complex64)
+        assert tch.size == iq.size
+        p_tch = _p(tch, C.c_float)
+    p_kc = None
+    if kc is not None:
+        kc = np.ascontiguousarray(kc, np.uint8)
+        p_kc = kc.ctypes.data_as(C.c_void_p)
+    out = np.zeros(max_records, RX_RECORD)
+    n, nch = C.c_int(), C.c_int()
+    f = lib().orc_rx_run_tch
+    f.restype = C.c_int
+    rv = f(_p(iq, C.c_float), p_tch, C.c_int(iq.size), C.c_int(sps), C.c_int(arfcn), p_kc,
+           out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n), C.byref(nch))
+    return rv, out[:min(n.value, max_records)].copy(), nch.value

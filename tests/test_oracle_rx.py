@@ -40,3 +40,44 @@ def test_rx_loop_short_capture_is_an_error(orc):
     iq = np.zeros(20000, np.complex64)
     rv, rec, n_chains = orc.rx_run(iq, sps=4)
     assert rv < 0 and len(rec) == 0
+
+
+def test_a5_two_implementations_agree(orc, pkg):
+    """The reference holds no A5 vectors; the oracle's C restatement (a5.c) and the generator's numpy
+    one are written independently and must produce the same keystream."""
+    import importlib
+    synth = importlib.import_module(pkg.__name__ + ".synth")
+    rng = np.random.default_rng(4)
+    key = rng.integers(0, 256, 8, dtype=np.uint8)
+    fns = np.array([0, 1, 2, 0x3F, 0x7C0, 0xF800, 0x70000, 0x7FFFF, 123456])
+    ks = synth.a5_1(key, fns, 208)
+    for i, fn in enumerate(fns):
+        dl, ul = orc.a5(1, key, int(fn), 208)
+        assert np.array_equal(dl, ks[i])
+        assert ul.any() and not np.array_equal(dl, ul)
+    z, _ = orc.a5(0, key, 7, 32)
+    assert not z.any()
+
+
+def test_rx_loop_follows_tch3_assignment(orc, pkg):
+    """IMMEDIATE ASSIGNMENT on the CCCH -> DKAB / speech / FACCH3 on the traffic carrier (gmr1_rx.c:531-600),
+    ciphered part of the way with A5/1."""
+    kc = np.array([1, 2, 3, 4, 5, 6, 7, 8], np.uint8)
+    bcch, tch, sent, sent_t = workloads.bcch_tch_pair(pkg, 5, seconds=5.0, kc=kc, cipher_after=30)
+    rv, rec, n_chains = orc.rx_run_tch(bcch, tch, kc=kc)
+    assert rv == 0 and n_chains == 1
+    speech = {(s["fn"], bytes(s["frame0"]) + bytes(s["frame1"])) for s in sent_t if s["type"] == "speech"}
+    facch = {(s["fn"], bytes(s["l2"])) for s in sent_t if s["type"] == "facch3"}
+    rs = rec[rec["type"] == 0x10]
+    rf = rec[rec["type"] == 0x12]
+    # unciphered speech always decodes; ciphered speech only once a ciphered FACCH3 has switched ciph on
+    got = {(int(r["fn"]), bytes(r["l2"][:20])) for r in rs}
+    plain = {k for k, s in zip([(s["fn"], bytes(s["frame0"]) + bytes(s["frame1"])) for s in sent_t if s["type"] == "speech"],
+                               [s for s in sent_t if s["type"] == "speech"]) if not s["ciph"]}
+    assert plain <= got
+    assert len(got & speech) >= 0.9 * len(speech)
+    assert len({(int(r["fn"]), bytes(r["l2"][:10])) for r in rf} & facch) >= 1
+    assert np.all(rs["len"] == 20) and np.all(rf["len"] == 10) and np.all(rec["tn"][rec["type"] >= 0x10] == 11)
+    # without the traffic carrier nothing but BCCH / CCCH comes back, and they are the same frames
+    rv2, rec2, _ = orc.rx_run_tch(bcch, None)
+    assert np.array_equal(rec2, rec[rec["type"] < 0x10])

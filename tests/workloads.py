@@ -110,3 +110,28 @@ def match_records(records, sent):
     mc = sum(bytes(r["l2"]) in sc for r in rc)
     mp = sum(bytes(r["l2"]) in {l for _, l in sb} for r in rb)
     return mb, len(rb), mc, len(rc), mp
+
+
+def bcch_tch_pair(pkg, seed, seconds=4.0, sps=4, stn=3, delay=2, tn=11, p=20, k_ass=20, kc=None,
+                  cipher_after=None, esn0_db=25.0, cfo_hz=60.0, mix=(0.35, 0.35, 0.3), k_stop=None):
+    """A BCCH carrier whose CCCH carries an IMMEDIATE ASSIGNMENT around frame index k_ass, and the
+    traffic carrier it points to (timeslot tn, DKAB position p), time-aligned, same CFO.
+    cipher_after: frames after the assignment from which the TCH is A5/1-ciphered with kc."""
+    from importlib import import_module
+    synth = import_module(pkg.__name__ + ".synth")
+    rng = np.random.default_rng(seed)
+    n = int(seconds * 23400 * sps)
+    frame_len = 24 * 39 * sps
+    t0 = int(rng.integers(0, frame_len))
+    fn0 = int(rng.integers(0, 1 << 18))
+    fb, fd = pkg.api.burst_format("bcch"), pkg.api.burst_format("dc6")
+    fs, ff = pkg.api.burst_format("nt3_speech"), pkg.api.burst_format("nt3_facch")
+    bcch, sent = synth.synth_bcch_carrier(fb, fd, n, sps, rng, stn=stn, delay=delay, fn0=fn0, t0=t0,
+                                          esn0_db=esn0_db, cfo_hz=cfo_hz, imm_ass=[(k_ass, tn, p)])
+    ia = [s for s in sent if s["type"] == "ccch" and s.get("imm_ass")]
+    assert ia, "no CCCH frame carried the assignment"
+    k_start = ia[0]["k"]
+    tch, sent_t = synth.synth_tch3_carrier(fs, ff, n, sps, rng, t0=t0, fn0=fn0, k_start=k_start, tn=tn, p=p,
+                                           kc=kc, cipher_from=None if cipher_after is None else k_start + cipher_after,
+                                           esn0_db=esn0_db, cfo_hz=cfo_hz, mix=mix, k_stop=k_stop)
+    return bcch, tch, sent, sent_t
