@@ -226,6 +226,25 @@ int gmr1_hip_rx_run(int n_arfcn, int sps, const float *iq, uint64_t iq_len,
                     struct gmr1_hip_rx_record *out, int max_records, int *n_records,
                     int32_t *status, int32_t *n_chains);
 
+/* The same with the TCH3 follow-up (gmr1_rx's optional tch.cfile and key arguments, gmr1_rx.c:355-600,
+ * 897-975): tch holds, for every carrier, the traffic carrier an IMMEDIATE ASSIGNMENT on its CCCH points
+ * to -- same offset[] / length[] layout and timing as iq; kc = n_arfcn x 8 key bytes (NULL: the all-zero
+ * key the reference starts with).  After an assignment every frame's burst on the assigned timeslot is
+ * classified (energy -> DKAB | burst; burst -> FACCH3 | speech by sync detection), FACCH3 bursts are
+ * grouped by sync sequence and decoded (type 0x12 = GSMTAP_GMR1_TCH3 | GSMTAP_GMR1_FACCH, 10 bytes,
+ * fn = fn of the flush - 3), with A5/1 deciphering once a message only decodes ciphered.  Speech bursts
+ * come back as type 0x10 records of 20 bytes (two 10-byte frames; conv = conv0 | conv1 << 16) -- the
+ * reference decodes them but only logs them.  tch = NULL is gmr1_hip_rx_run*. */
+int gmr1_hip_rx_run_tch_dev(void *stream, int n_arfcn, int sps, const float *iq, const float *tch,
+                            const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                            const uint8_t *kc,
+                            struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                            int32_t *status, int32_t *n_chains);
+int gmr1_hip_rx_run_tch(int n_arfcn, int sps, const float *iq, const float *tch, uint64_t iq_len,
+                        const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn, const uint8_t *kc,
+                        struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                        int32_t *status, int32_t *n_chains);
+
 /* The GSMTAP packet gmr1_gsmtap_makemsg (reference src/gsmtap.c:43-71, include/osmocom/gmr1/gsmtap.h:35-37)
  * builds for one record: 16-byte gsmtap_hdr + L2.  Returns the packet length (16 + rec->len) or
  * -EINVAL.  Host-only; works without a GPU.  with_arfcn = 0 leaves the arfcn field 0 as the reference does. */

@@ -36,6 +36,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
     "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
+    "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch",
     "gmr1_hip_dkab_demod_batch_dev", "gmr1_hip_dkab_demod_batch", "gmr1_dkab_demod",
     "gmr1_hip_a5_batch_dev", "gmr1_hip_a5_batch", "gmr1_a5", "gmr1_a5_1",
 ]
@@ -637,3 +638,32 @@ def a5(n, key, fn, nbits):
     f.restype = None
     f(C.c_int(n), p_k, C.c_uint32(int(fn)), C.c_int(nbits), dl.ctypes.data_as(C.c_void_p), ul.ctypes.data_as(C.c_void_p))
     return dl, ul
+
+
+def rx_run_tch(iq, tch, offset, length, sps=4, arfcn=None, kc=None, max_records=1 << 16):
+    """gmr1_hip_rx_run_tch: rx_run with the traffic carriers `tch` (same layout as iq) and keys kc (n, 8)."""
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    p_tch = None
+    if tch is not None:
+        tch, p_tch = _np(np.asarray(tch).reshape(-1), np.complex64)
+        assert tch.size == iq.size
+    n = len(offset)
+    p_kc = None
+    if kc is not None:
+        kc, p_kc = _np(np.broadcast_to(np.asarray(kc, np.uint8).reshape(-1, 8), (n, 8)), np.uint8)
+    offset, p_off = _np(offset, np.uint64)
+    length, p_len = _np(length, np.uint64)
+    p_arfcn = None
+    if arfcn is not None:
+        arfcn, p_arfcn = _np(arfcn, np.uint16)
+    out = np.zeros(max(max_records, 1), RX_RECORD)
+    n_rec = C.c_int(0)
+    status = np.zeros(max(n, 1), np.int32)
+    chains = np.zeros(max(n, 1), np.int32)
+    f = load().gmr1_hip_rx_run_tch
+    f.restype = C.c_int
+    rc = f(C.c_int(n), C.c_int(sps), p_iq, p_tch, C.c_uint64(iq.size), p_off, p_len, p_arfcn, p_kc,
+           out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n_rec),
+           status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_rx_run_tch")
+    return out[:min(n_rec.value, max_records)].copy(), status[:n], chains[:n], n_rec.value

@@ -155,7 +155,7 @@ static int dbg_stop_env()
 static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
                           int n, int sps, int in_len, const float *iq, const uint64_t *offset,
                           const float *freq_shift, int8_t *ebits, int ebits_stride, int32_t *sync_id,
-                          float *toa, float *freq_err, float *ssyms, int32_t *rv)
+                          float *toa, float *freq_err, float *ssyms, int32_t *rv, float *energy = nullptr)
 {
 	if (n < 0 || !iq || !offset || !rv)
 		return fail(-EINVAL, "demod: n/iq/offset/rv are required");
@@ -177,9 +177,30 @@ static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.freq_shift = freq_shift;
 	a.ebits = ebits; a.sync_id = sync_id; a.toa = toa; a.freq_err = freq_err; a.ssyms = ssyms; a.rv = rv;
+	a.energy = energy;
 	HIP_TRY(launch_rx(a, false, in_len, st));
 	return 0;
 }
+
+}  // extern "C" (closed for the shared implementation below)
+
+namespace gmr1 {
+// built-in burst type, device pointers, with the burst_energy() output the receive loop needs
+int demod_dev_energy(hipStream_t st, int burst_id, int n, int sps, int in_len, const float *iq,
+                     const uint64_t *offset, const float *freq_shift, int8_t *ebits, int ebits_stride,
+                     int32_t *sync_id, float *toa, float *energy, int32_t *rv)
+{
+	if (burst_id < 0 || burst_id >= GMR1_HIP_N_BURSTS)
+		return fail(-EINVAL, "bad burst id %d", burst_id);
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	return demod_dev_impl(st, burst_id, g_host_types[burst_id], n, sps, in_len, iq, offset, freq_shift,
+	                      ebits, ebits_stride, sync_id, toa, nullptr, nullptr, rv, energy);
+}
+}  // namespace gmr1
+
+extern "C" {
 
 int gmr1_hip_demod_batch_dev(void *stream, int burst_id, int n, int sps, int in_len,
                              const float *iq, const uint64_t *offset, const float *freq_shift,

@@ -46,6 +46,11 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           float *toa, float *freq_err, float *energy,
                           int8_t *ebits, float *ssyms, int32_t *rv);
 
+// gmr1_hip_demod_batch_dev of a built-in burst type, plus burst_energy() of each window (capi.cpp)
+int demod_dev_energy(hipStream_t st, int burst_id, int n, int sps, int in_len, const float *iq,
+                     const uint64_t *offset, const float *freq_shift, int8_t *ebits, int ebits_stride,
+                     int32_t *sync_id, float *toa, float *energy, int32_t *rv);
+
 // RAII device buffer for the host-pointer variants
 struct DBuf {
 	void *p = nullptr;

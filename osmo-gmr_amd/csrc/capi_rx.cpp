@@ -36,6 +36,9 @@ constexpr int kPerRound = 8;          // bursts one chain may contribute to a ro
 
 float to_hz(float f_rps) { return (kSymRate * f_rps) / (2.0f * 3.14159265358979323846f); }
 
+struct FrameCtx { int align; float freq_err; int fn; };       // what rx_tch3 sees in a frame
+struct AssEvt { int frame; int tn, p; float ref_energy; };     // an IMMEDIATE ASSIGNMENT taken from the CCCH
+
 struct RxChain {
 	int a;                // carrier index
 	int chain;            // chain index within the carrier
@@ -47,6 +50,9 @@ struct RxChain {
 	float bcch_energy;
 	bool done;
 	std::vector<gmr1_hip_rx_record> rec;
+	std::vector<int> rec_frame;          // frame (index into log) each record belongs to
+	std::vector<FrameCtx> log;           // one entry per loop iteration of process_bcch (only with a traffic carrier)
+	std::vector<AssEvt> events;
 };
 
 struct Item {             // one burst of a round
@@ -54,6 +60,7 @@ struct Item {             // one burst of a round
 	int is_bcch;
 	int fn, tn, e_toa;
 	float min_energy;
+	int frame;            // index the frame has / will have in the chain's log
 };
 
 // gmr1_rx.c:149-170 (begin < 0 is an out-of-bounds read in the reference; refused here and in the oracle)
@@ -87,7 +94,7 @@ void bcch_tdma_align(RxChain &c, int sps, const uint8_t *l2)
 	c.stn = stn;
 }
 
-void emit(RxChain &c, uint16_t arfcn, int type, int fn, int tn, const uint8_t *l2, int conv)
+void emit(RxChain &c, uint16_t arfcn, int type, int fn, int tn, const uint8_t *l2, int conv, int frame, int len = 24)
 {
 	gmr1_hip_rx_record r;
 	std::memset(&r, 0, sizeof(r));
@@ -97,11 +104,38 @@ void emit(RxChain &c, uint16_t arfcn, int type, int fn, int tn, const uint8_t *l
 	r.fn = (uint32_t)fn;
 	r.tn = (uint8_t)tn;
 	r.crc = 0;
-	r.len = 24;
+	r.len = (uint8_t)len;
 	r.conv = conv;
-	std::memcpy(r.l2, l2, 24);
+	std::memcpy(r.l2, l2, (size_t)len);
 	c.rec.push_back(r);
+	c.rec_frame.push_back(frame);
 }
+
+// TCH3 state of a chain (struct tch3_state, gmr1_rx.c:59-78)
+struct Tch3State {
+	int active = 0;
+	int tn = 0, p = 0, ciph = 0;
+	float energy_dkab = 0.f, energy_burst = 0.f;
+	int weak_cnt = 0;
+	int8_t ebits[104 * 4] = {};
+	uint32_t bi_fn[4] = {0, 0, 0, 0};
+	int sync_id = 0, burst_cnt = 0;
+};
+
+struct TchItem {          // one frame of a chain in which rx_tch3 maps a burst
+	int chain_idx, frame;
+	int tn, p, e_toa;
+};
+
+struct TchJob {           // a decode the walk asks for: a speech burst or a FACCH3 flush
+	int chain_idx, frame;
+	int is_flush;
+	int fn;               // cd->fn when it happens
+	int tn;
+	int item;             // speech: index of the TchItem whose soft bits are decoded
+	int8_t ebits[104 * 4];    // flush: the four stored bursts
+	uint32_t bi_fn[4];
+};
 
 struct Pinned {
 	void *p = nullptr;
@@ -118,10 +152,11 @@ size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 extern "C" {
 
-int gmr1_hip_rx_run_dev(void *stream_, int n_arfcn, int sps, const float *iq,
-                        const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
-                        struct gmr1_hip_rx_record *out, int max_records, int *n_records,
-                        int32_t *status, int32_t *n_chains)
+int gmr1_hip_rx_run_tch_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
+                            const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                            const uint8_t *kc,
+                            struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                            int32_t *status, int32_t *n_chains)
 {
 	hipStream_t st = (hipStream_t)stream_;
 	if (n_records) *n_records = 0;
@@ -359,7 +394,7 @@ int gmr1_hip_rx_run_dev(void *stream_, int n_arfcn, int sps, const float *iq,
 					const int e = burst_map(c, sps, 234, c.stn, 20 * sps, &begin);
 					if (e >= 0) {
 						const size_t k = items.size();
-						items.push_back({(int)ci, 1, c.fn, c.stn, e, 0.f});
+						items.push_back({(int)ci, 1, c.fn, c.stn, e, 0.f, (int)c.log.size()});
 						p_in.at<uint64_t>(o_off)[k] = c.base + (uint64_t)begin;
 						p_in.at<float>(o_fs)[k] = -c.freq_err;
 						p_in.at<uint8_t>(o_kind)[k] = 0;
@@ -369,13 +404,15 @@ int gmr1_hip_rx_run_dev(void *stream_, int n_arfcn, int sps, const float *iq,
 					const int e = burst_map(c, sps, 234, c.stn, 10 * sps, &begin);
 					if (e >= 0) {
 						const size_t k = items.size();
-						items.push_back({(int)ci, 0, c.fn, c.stn, e, c.bcch_energy / 2.0f});
+						items.push_back({(int)ci, 0, c.fn, c.stn, e, c.bcch_energy / 2.0f, (int)c.log.size()});
 						p_in.at<uint64_t>(o_off)[k] = c.base + (uint64_t)begin;
 						p_in.at<float>(o_fs)[k] = -c.freq_err;
 						p_in.at<uint8_t>(o_kind)[k] = 1;
 						cnt++;
 					}
 				}
+				if (tch)
+					c.log.push_back({c.align, c.freq_err, c.fn});
 				advance(c);
 			}
 		}
@@ -406,16 +443,305 @@ int gmr1_hip_rx_run_dev(void *stream_, int n_arfcn, int sps, const float *iq,
 						c.align += (int)roundf(p_out.at<float>(o_toa)[k]) - it.e_toa;
 						c.freq_err += p_out.at<float>(o_fe)[k];
 						bcch_tdma_align(c, sps, l2);
-						emit(c, an, 1 /* GSMTAP_GMR1_BCCH */, c.fn, c.stn, l2, p_out.at<int32_t>(o_conv)[k]);
+						emit(c, an, 1 /* GSMTAP_GMR1_BCCH */, c.fn, c.stn, l2, p_out.at<int32_t>(o_conv)[k], it.frame);
 					}
 				}
+				if (tch)
+					c.log.push_back({c.align, c.freq_err, c.fn});     // rx_tch3 of this frame sees the updated state
 				advance(c);
 			} else {
 				// rx_ccch, gmr1_rx.c:800-850 (energy gate first, :813-816)
 				if (en < it.min_energy)
 					continue;
-				if (!rv && !crc)
-					emit(c, an, 2 /* GSMTAP_GMR1_CCCH */, it.fn, it.tn, l2, p_out.at<int32_t>(o_conv)[k]);
+				if (!rv && !crc) {
+					// IMM.ASS starts the TCH3 follow-up in this very frame (gmr1_rx.c:235-246, 836-841)
+					if (tch && l2[1] == 0x06 && l2[2] == 0x3f)
+						c.events.push_back({it.frame, ((l2[8] & 0x03) << 3) | (l2[9] >> 5), (l2[8] & 0xfc) >> 2,
+						                    it.min_energy});
+					emit(c, an, 2 /* GSMTAP_GMR1_CCCH */, it.fn, it.tn, l2, p_out.at<int32_t>(o_conv)[k], it.frame);
+				}
+			}
+		}
+	}
+
+	// ---- TCH3 follow-up (rx_tch3, gmr1_rx.c:355-600) ----------------------------------------------
+	// Nothing the traffic channel does feeds back into the BCCH / CCCH loop, so it runs afterwards,
+	// for all chains at once, in four steps:
+	//   A. for every frame from a chain's first assignment on, speculatively: burst energy, FACCH3
+	//      and speech demodulation, burst type detection, DKAB search         (4 batched launches)
+	//   B. host: the per-frame state machine (energy thresholds, DKAB / weak count, FACCH3 burst
+	//      grouping by sync sequence) over those results, producing the list of decodes it calls for
+	//   C. A5/1 keystreams and the TCH3 / FACCH3 decodes, each with and without deciphering
+	//   D. host: the ciphering state (a FACCH3 that only decodes ciphered switches it on) picks
+	//      the variant, records are emitted in frame order.
+	if (tch) {
+		std::vector<TchItem> titems;
+		const int twin = sps + (sps / 2);            // gmr1_rx.c:551
+		const int t_in_len = 117 * sps + twin;
+		const int t_etoa = twin >> 1;
+		for (size_t ci = 0; ci < chains.size(); ci++) {
+			RxChain &c = chains[ci];
+			if (c.events.empty())
+				continue;
+			size_t ev = 0;
+			for (int f = c.events[0].frame; f < (int)c.log.size(); f++) {
+				while (ev + 1 < c.events.size() && c.events[ev + 1].frame <= f)
+					ev++;
+				const int tn = c.events[ev].tn;
+				const int64_t begin = (int64_t)c.log[f].align + sps * tn * 39 - t_etoa;
+				if (begin < 0 || begin + t_in_len > c.len)
+					continue;                         // burst_map fails: rx_tch3 returns before touching anything
+				titems.push_back({(int)ci, f, tn, c.events[ev].p, t_etoa});
+			}
+		}
+		const int nt = (int)titems.size();
+		if (nt) {
+			std::vector<uint64_t> t_off(nt);
+			std::vector<float> t_fs(nt), t_et(nt);
+			std::vector<int32_t> t_p(nt);
+			for (int k = 0; k < nt; k++) {
+				const RxChain &c = chains[titems[k].chain_idx];
+				const FrameCtx &x = c.log[titems[k].frame];
+				t_off[k] = c.base + (uint64_t)((int64_t)x.align + sps * titems[k].tn * 39 - t_etoa);
+				t_fs[k] = -x.freq_err;
+				t_et[k] = (float)t_etoa;
+				t_p[k] = titems[k].p;
+			}
+			DBuf d_off2, d_fs2, d_et, d_pp, d_feb, d_fsid, d_frv, d_en, d_seb, d_srv, d_bt, d_dsid, d_dtoa, d_drv, d_krv, d_ftoa;
+			HIP_TRY(d_off2.alloc((size_t)nt * 8)); HIP_TRY(d_fs2.alloc((size_t)nt * 4)); HIP_TRY(d_et.alloc((size_t)nt * 4));
+			HIP_TRY(d_pp.alloc((size_t)nt * 4)); HIP_TRY(d_feb.alloc((size_t)nt * 104)); HIP_TRY(d_fsid.alloc((size_t)nt * 4));
+			HIP_TRY(d_frv.alloc((size_t)nt * 4)); HIP_TRY(d_en.alloc((size_t)nt * 4)); HIP_TRY(d_seb.alloc((size_t)nt * 212));
+			HIP_TRY(d_srv.alloc((size_t)nt * 4)); HIP_TRY(d_bt.alloc((size_t)nt * 4)); HIP_TRY(d_dsid.alloc((size_t)nt * 4));
+			HIP_TRY(d_dtoa.alloc((size_t)nt * 4)); HIP_TRY(d_drv.alloc((size_t)nt * 4)); HIP_TRY(d_krv.alloc((size_t)nt * 4));
+			HIP_TRY(d_ftoa.alloc((size_t)nt * 4));
+			HIP_TRY(hipMemcpyAsync(d_off2.p, t_off.data(), (size_t)nt * 8, hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(d_fs2.p, t_fs.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(d_et.p, t_et.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(d_pp.p, t_p.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
+			// A. speculative per-frame work
+			r = demod_dev_energy(st, GMR1_HIP_NT3_FACCH, nt, sps, t_in_len, tch, d_off2.as<uint64_t>(), d_fs2.as<float>(),
+			                     d_feb.as<int8_t>(), 104, d_fsid.as<int32_t>(), d_ftoa.as<float>(), d_en.as<float>(),
+			                     d_frv.as<int32_t>());
+			if (r) return r;
+			r = demod_dev_energy(st, GMR1_HIP_NT3_SPEECH, nt, sps, t_in_len, tch, d_off2.as<uint64_t>(), d_fs2.as<float>(),
+			                     d_seb.as<int8_t>(), 212, nullptr, nullptr, nullptr, d_srv.as<int32_t>());
+			if (r) return r;
+			{
+				const int ids[2] = {GMR1_HIP_NT3_FACCH, GMR1_HIP_NT3_SPEECH};     // gmr1_rx.c:534-538
+				r = gmr1_hip_detect_batch_dev(st, 2, ids, nt, sps, t_in_len, tch, d_off2.as<uint64_t>(), d_fs2.as<float>(),
+				                              d_et.as<float>(), d_bt.as<int32_t>(), d_dsid.as<int32_t>(), d_dtoa.as<float>(),
+				                              d_drv.as<int32_t>());
+				if (r) return r;
+			}
+			r = gmr1_hip_dkab_demod_batch_dev(st, nt, sps, t_in_len, tch, d_off2.as<uint64_t>(), d_fs2.as<float>(),
+			                                  d_pp.as<int32_t>(), nullptr, nullptr, d_krv.as<int32_t>());
+			if (r) return r;
+			std::vector<int8_t> h_feb((size_t)nt * 104), h_seb((size_t)nt * 212);
+			std::vector<int32_t> h_fsid(nt), h_frv(nt), h_srv(nt), h_bt(nt), h_drv(nt), h_krv(nt);
+			std::vector<float> h_en(nt);
+			HIP_TRY(hipMemcpyAsync(h_feb.data(), d_feb.p, (size_t)nt * 104, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_seb.data(), d_seb.p, (size_t)nt * 212, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_fsid.data(), d_fsid.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_frv.data(), d_frv.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_srv.data(), d_srv.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_bt.data(), d_bt.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_drv.data(), d_drv.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_krv.data(), d_krv.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_en.data(), d_en.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+
+			// B. the state machine of rx_tch3 (gmr1_rx.c:531-600) and its helpers, chain by chain
+			std::vector<TchJob> jobs;
+			{
+				int k = 0;
+				while (k < nt) {
+					const int ci = titems[k].chain_idx;
+					RxChain &c = chains[ci];
+					Tch3State ts;
+					size_t ev = 0;
+					auto flush = [&](int frame, int fn) {       // _rx_tch3_facch_flush, gmr1_rx.c:397-450 (decode deferred)
+						TchJob j;
+						j.chain_idx = ci; j.frame = frame; j.is_flush = 1; j.fn = fn; j.tn = ts.tn; j.item = -1;
+						std::memcpy(j.ebits, ts.ebits, sizeof(j.ebits));
+						std::memcpy(j.bi_fn, ts.bi_fn, sizeof(j.bi_fn));
+						jobs.push_back(j);
+						ts.sync_id ^= 1;
+						ts.burst_cnt = 0;
+						std::memset(ts.bi_fn, 0xff, sizeof(ts.bi_fn));
+						std::memset(ts.ebits, 0, sizeof(ts.ebits));
+					};
+					for (; k < nt && titems[k].chain_idx == ci; k++) {
+						const TchItem &ti = titems[k];
+						// assignments taken in this frame or in skipped ones (rx_tch3_init, gmr1_rx.c:358-378)
+						while (ev < c.events.size() && c.events[ev].frame <= ti.frame) {
+							const AssEvt &e = c.events[ev++];
+							ts.active = 1;
+							ts.tn = e.tn; ts.p = e.p;
+							ts.energy_burst = e.ref_energy * 0.75f;
+							ts.energy_dkab = ts.energy_burst / 8.0f;
+							ts.weak_cnt = 0;
+							ts.sync_id = 0;
+							std::memset(ts.ebits, 0, sizeof(ts.ebits));
+						}
+						if (!ts.active)
+							continue;
+						const int fn = c.log[ti.frame].fn;
+						const float be = h_en[k];
+						const float det = (ts.energy_dkab + ts.energy_burst) / 4.0f;
+						if (be < det) {
+							const int drv = h_krv[k];
+							if (drv < 0)
+								continue;
+							if (drv == 1) {
+								if (ts.weak_cnt++ > 8)
+									ts.active = 0;
+							} else
+								ts.energy_dkab = (0.1f * be) + (0.9f * ts.energy_dkab);
+							continue;
+						}
+						ts.weak_cnt = 0;
+						ts.energy_burst = (0.1f * be) + (0.9f * ts.energy_burst);
+						if (h_drv[k] < 0)
+							continue;
+						if (h_bt[k] == 0) {
+							// _rx_tch3_facch, gmr1_rx.c:452-493
+							if (h_frv[k] < 0)
+								continue;
+							const int bi = fn & 3;
+							if (h_fsid[k] != ts.sync_id)
+								flush(ti.frame, fn);
+							std::memcpy(&ts.ebits[104 * bi], &h_feb[(size_t)k * 104], 104);
+							ts.sync_id = h_fsid[k];
+							ts.bi_fn[bi] = (uint32_t)fn;
+							ts.burst_cnt += 1;
+							if (ts.burst_cnt == 4)
+								flush(ti.frame, fn);
+						} else {
+							// _rx_tch3_speech, gmr1_rx.c:495-529
+							if (h_srv[k] < 0)
+								continue;
+							TchJob j;
+							j.chain_idx = ci; j.frame = ti.frame; j.is_flush = 0; j.fn = fn; j.tn = ts.tn; j.item = k;
+							jobs.push_back(j);
+						}
+					}
+				}
+			}
+
+			// C. keystreams and decodes, plain and deciphered
+			std::vector<int> sj, fj;
+			for (size_t j = 0; j < jobs.size(); j++)
+				(jobs[j].is_flush ? fj : sj).push_back((int)j);
+			const int ns = (int)sj.size(), nf = (int)fj.size();
+			std::vector<uint8_t> s_fr[2], f_l2[2];
+			std::vector<int32_t> s_conv[2], f_crc[2], f_conv[2];
+			if (ns) {
+				std::vector<int8_t> eb((size_t)ns * 212);
+				std::vector<uint8_t> keys((size_t)ns * 8, 0);
+				std::vector<uint32_t> fns(ns);
+				for (int i = 0; i < ns; i++) {
+					const TchJob &j = jobs[sj[i]];
+					std::memcpy(&eb[(size_t)i * 212], &h_seb[(size_t)j.item * 212], 212);
+					if (kc) std::memcpy(&keys[(size_t)i * 8], kc + (size_t)chains[j.chain_idx].a * 8, 8);
+					fns[i] = (uint32_t)j.fn;
+				}
+				DBuf d_eb, d_k, d_fn, d_ks, d_fr, d_cv;
+				HIP_TRY(d_eb.alloc(eb.size())); HIP_TRY(d_k.alloc(keys.size())); HIP_TRY(d_fn.alloc((size_t)ns * 4));
+				HIP_TRY(d_ks.alloc((size_t)ns * 208)); HIP_TRY(d_fr.alloc((size_t)ns * 20)); HIP_TRY(d_cv.alloc((size_t)ns * 8));
+				HIP_TRY(hipMemcpyAsync(d_eb.p, eb.data(), eb.size(), hipMemcpyHostToDevice, st));
+				HIP_TRY(hipMemcpyAsync(d_k.p, keys.data(), keys.size(), hipMemcpyHostToDevice, st));
+				HIP_TRY(hipMemcpyAsync(d_fn.p, fns.data(), (size_t)ns * 4, hipMemcpyHostToDevice, st));
+				r = gmr1_hip_a5_batch_dev(st, ns, 1, 208, d_k.as<uint8_t>(), d_fn.as<uint32_t>(), d_ks.as<uint8_t>(), nullptr);
+				if (r) return r;
+				for (int v = 0; v < 2; v++) {
+					r = gmr1_hip_tch3_decode_batch_dev(st, ns, 0, d_eb.as<int8_t>(), v ? d_ks.as<uint8_t>() : nullptr,
+					                                   d_fr.as<uint8_t>(), nullptr, d_cv.as<int32_t>());
+					if (r) return r;
+					s_fr[v].resize((size_t)ns * 20);
+					s_conv[v].resize((size_t)ns * 2);
+					HIP_TRY(hipMemcpyAsync(s_fr[v].data(), d_fr.p, (size_t)ns * 20, hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipMemcpyAsync(s_conv[v].data(), d_cv.p, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipStreamSynchronize(st));
+				}
+			}
+			if (nf) {
+				std::vector<int8_t> eb((size_t)nf * 416);
+				std::vector<uint8_t> keys((size_t)nf * 4 * 8, 0);
+				std::vector<uint32_t> fns((size_t)nf * 4);
+				for (int i = 0; i < nf; i++) {
+					const TchJob &j = jobs[fj[i]];
+					std::memcpy(&eb[(size_t)i * 416], j.ebits, 416);
+					for (int b = 0; b < 4; b++) {
+						if (kc) std::memcpy(&keys[((size_t)i * 4 + b) * 8], kc + (size_t)chains[j.chain_idx].a * 8, 8);
+						fns[(size_t)i * 4 + b] = j.bi_fn[b];
+					}
+				}
+				DBuf d_eb, d_k, d_fn, d_ks, d_l2, d_crc, d_cv;
+				HIP_TRY(d_eb.alloc(eb.size())); HIP_TRY(d_k.alloc(keys.size())); HIP_TRY(d_fn.alloc((size_t)nf * 16));
+				HIP_TRY(d_ks.alloc((size_t)nf * 384)); HIP_TRY(d_l2.alloc((size_t)nf * 10)); HIP_TRY(d_crc.alloc((size_t)nf * 4));
+				HIP_TRY(d_cv.alloc((size_t)nf * 4));
+				HIP_TRY(hipMemcpyAsync(d_eb.p, eb.data(), eb.size(), hipMemcpyHostToDevice, st));
+				HIP_TRY(hipMemcpyAsync(d_k.p, keys.data(), keys.size(), hipMemcpyHostToDevice, st));
+				HIP_TRY(hipMemcpyAsync(d_fn.p, fns.data(), (size_t)nf * 16, hipMemcpyHostToDevice, st));
+				// 4 x 96 keystream bits per message, one per burst's frame number (gmr1_rx.c:409-412)
+				r = gmr1_hip_a5_batch_dev(st, nf * 4, 1, 96, d_k.as<uint8_t>(), d_fn.as<uint32_t>(), d_ks.as<uint8_t>(), nullptr);
+				if (r) return r;
+				for (int v = 0; v < 2; v++) {
+					r = gmr1_hip_facch3_decode_batch_dev(st, nf, d_eb.as<int8_t>(), v ? d_ks.as<uint8_t>() : nullptr,
+					                                     d_l2.as<uint8_t>(), nullptr, d_crc.as<int32_t>(), d_cv.as<int32_t>());
+					if (r) return r;
+					f_l2[v].resize((size_t)nf * 10);
+					f_crc[v].resize(nf);
+					f_conv[v].resize(nf);
+					HIP_TRY(hipMemcpyAsync(f_l2[v].data(), d_l2.p, (size_t)nf * 10, hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipMemcpyAsync(f_crc[v].data(), d_crc.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipMemcpyAsync(f_conv[v].data(), d_cv.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipStreamSynchronize(st));
+				}
+			}
+
+			// D. ciphering state and records, in the order things happened
+			{
+				std::vector<int> ciph(chains.size(), 0);
+				int is = 0, iff = 0;
+				for (size_t jj = 0; jj < jobs.size(); jj++) {
+					const TchJob &j = jobs[jj];
+					RxChain &c = chains[j.chain_idx];
+					const uint16_t an = arfcn ? arfcn[c.a] : (uint16_t)c.a;
+					int &cf = ciph[j.chain_idx];
+					if (!j.is_flush) {
+						const int v = cf ? 1 : 0;
+						const int32_t *cv = &s_conv[v][(size_t)is * 2];
+						emit(c, an, 0x10 /* GSMTAP_GMR1_TCH3 */, j.fn, j.tn, &s_fr[v][(size_t)is * 20],
+						     (cv[0] & 0xffff) | (cv[1] << 16), j.frame, 20);
+						is++;
+					} else {
+						int v = cf ? 1 : 0;
+						int crc = f_crc[v][iff];
+						if (!cf && crc) {                 // retry with ciphering (gmr1_rx.c:420-432)
+							v = 1;
+							crc = f_crc[1][iff];
+							if (!crc)
+								cf = 1;
+						}
+						if (!crc)
+							emit(c, an, 0x12 /* GSMTAP_GMR1_TCH3 | GSMTAP_GMR1_FACCH */, j.fn - 3, j.tn,
+							     &f_l2[v][(size_t)iff * 10], f_conv[v][iff], j.frame, 10);
+						iff++;
+					}
+				}
+			}
+			// frame order within each chain: BCCH / CCCH of a frame come before its TCH records
+			for (RxChain &c : chains) {
+				if (c.events.empty())
+					continue;
+				std::vector<size_t> order(c.rec.size());
+				for (size_t i = 0; i < order.size(); i++) order[i] = i;
+				std::stable_sort(order.begin(), order.end(),
+				                 [&](size_t x, size_t y) { return c.rec_frame[x] < c.rec_frame[y]; });
+				std::vector<gmr1_hip_rx_record> sorted(c.rec.size());
+				for (size_t i = 0; i < order.size(); i++) sorted[i] = c.rec[order[i]];
+				c.rec.swap(sorted);
 			}
 		}
 	}
@@ -435,6 +761,40 @@ int gmr1_hip_rx_run_dev(void *stream_, int n_arfcn, int sps, const float *iq,
 		if (n_chains) n_chains[i] = nch[i];
 	}
 	return 0;
+}
+
+int gmr1_hip_rx_run_dev(void *stream, int n_arfcn, int sps, const float *iq,
+                        const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                        struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                        int32_t *status, int32_t *n_chains)
+{
+	return gmr1_hip_rx_run_tch_dev(stream, n_arfcn, sps, iq, nullptr, offset, length, arfcn, nullptr,
+	                               out, max_records, n_records, status, n_chains);
+}
+
+int gmr1_hip_rx_run_tch(int n_arfcn, int sps, const float *iq, const float *tch, uint64_t iq_len,
+                        const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn, const uint8_t *kc,
+                        struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                        int32_t *status, int32_t *n_chains)
+{
+	if (n_records) *n_records = 0;
+	DevState *ds;
+	int r = dev_state(&ds);
+	if (r) return r;
+	if (n_arfcn < 0 || !iq || !offset || !length)
+		return fail(-EINVAL, "rx_run: iq/offset/length are required");
+	for (int i = 0; i < n_arfcn; i++)
+		if (offset[i] + length[i] > iq_len)
+			return fail(-EINVAL, "rx_run: carrier %d runs past the end of iq", i);
+	DBuf d_iq, d_tch;
+	HIP_TRY(d_iq.alloc(iq_len * 8));
+	HIP_TRY(hipMemcpy(d_iq.p, iq, iq_len * 8, hipMemcpyHostToDevice));
+	if (tch) {
+		HIP_TRY(d_tch.alloc(iq_len * 8));
+		HIP_TRY(hipMemcpy(d_tch.p, tch, iq_len * 8, hipMemcpyHostToDevice));
+	}
+	return gmr1_hip_rx_run_tch_dev(nullptr, n_arfcn, sps, d_iq.as<float>(), tch ? d_tch.as<float>() : nullptr,
+	                               offset, length, arfcn, kc, out, max_records, n_records, status, n_chains);
 }
 
 int gmr1_hip_rx_run(int n_arfcn, int sps, const float *iq, uint64_t iq_len,

@@ -123,3 +123,51 @@ def test_rx_capture_sharded_single_rank(gpu_api, orc, pkg):
     ref = np.concatenate([orc.rx_run(xs[a], sps=SPS, arfcn=a)[1] for a in range(3)])
     order = np.lexsort((ref["chain"], ref["tn"], ref["fn"], ref["arfcn"]))
     assert _key(rec) == _key(ref[order])
+
+
+def _key_n(rec):
+    return [(int(r["arfcn"]), int(r["chain"]), int(r["type"]), int(r["fn"]), int(r["tn"]), int(r["len"]),
+             bytes(r["l2"][:int(r["len"])])) for r in rec]
+
+
+def test_rx_loop_tch3_follow_up_matches_oracle(gpu_api, orc, pkg):
+    """IMM.ASS -> DKAB / speech / FACCH3 on the traffic carrier, plain and A5/1-ciphered (gmr1_rx.c:355-600):
+    the record sequence is the oracle's, carrier by carrier."""
+    rng = np.random.default_rng(77)
+    cases = [
+        dict(seed=5, seconds=5.0, kc=np.array([1, 2, 3, 4, 5, 6, 7, 8], np.uint8), cipher_after=30),
+        dict(seed=6, seconds=4.0, kc=None, cipher_after=None, tn=4, p=7, stn=1, delay=6),
+        dict(seed=7, seconds=4.5, kc=rng.integers(0, 256, 8, dtype=np.uint8), cipher_after=0, tn=20, p=33,
+             mix=(0.2, 0.3, 0.5)),
+        dict(seed=8, seconds=4.0, kc=None, cipher_after=None, tn=9, p=12, k_stop=45),      # the call ends: weak DKABs -> END
+    ]
+    bc, tc, kcs, sents = [], [], [], []
+    for cs in cases:
+        cs = dict(cs)
+        seed = cs.pop("seed")
+        b, t, s_b, s_t = workloads.bcch_tch_pair(pkg, seed, **cs)
+        bc.append(b); tc.append(t); sents.append(s_t)
+        kcs.append(cs["kc"] if cs["kc"] is not None else np.zeros(8, np.uint8))
+    # one carrier without a traffic capture worth speaking of: noise
+    b, t, _, _ = workloads.bcch_tch_pair(pkg, 9, seconds=3.0)
+    bc.append(b); tc.append((rng.standard_normal((b.size, 2)) * 0.05).astype(np.float32).view(np.complex64).reshape(-1))
+    kcs.append(np.zeros(8, np.uint8)); sents.append([])
+    length = np.array([x.size for x in bc], np.uint64)
+    offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.uint64)
+    rec, status, chains, found = gpu_api.rx_run_tch(np.concatenate(bc), np.concatenate(tc), offset, length, sps=SPS,
+                                                    kc=np.stack(kcs))
+    assert found == len(rec) and not status.any()
+    n_tch = 0
+    for i in range(len(bc)):
+        orv, orec, och = orc.rx_run_tch(bc[i], tc[i], sps=SPS, arfcn=i, kc=kcs[i])
+        mine = rec[rec["arfcn"] == i]
+        assert orv == 0 and chains[i] == och
+        assert _key_n(mine) == _key_n(orec), f"carrier {i}: records differ from the oracle's"
+        n_tch += int(np.sum(orec["type"] >= 0x10))
+        sp = {(s["fn"], bytes(s["frame0"]) + bytes(s["frame1"])) for s in sents[i] if s["type"] == "speech" and not s["ciph"]}
+        got = {(int(r["fn"]), bytes(r["l2"][:20])) for r in mine[mine["type"] == 0x10]}
+        assert sp <= got
+    assert n_tch > 100
+    # without the traffic carriers: exactly the BCCH / CCCH records
+    rec0, _, _, _ = gpu_api.rx_run(np.concatenate(bc), offset, length, sps=SPS)
+    assert _key_n(rec0) == _key_n(rec[rec["type"] < 0x10])
