@@ -190,6 +190,25 @@ int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
                             const float *freq_shift, float *snr);
 
 /* ------------------------------------------------------------------------
+ * Wideband capture -> per-ARFCN streams at sym_rate x sps (reference utils/gmr1_rx_sdr.py:391-602:
+ * PFBBase = 2x oversampled polyphase channelizer over n_chans = (ceil(fs / 31.25 kHz) + 1) & ~1 channels
+ * with firdes.low_pass(1, fs, 15.625 k, 7.8125 k); PFBOutputBranch = per-channel arbitrary resampler to
+ * 23.4 k x sps with a 32-phase root-raised-cosine bank, alpha 0.35, 11 symbols).
+ * Channel k is the carrier k x 31.25 kHz above the centre (k >= n_chans / 2: below, freq2index :478-485).
+ * rotation: optional pre-rotation in rad / sample (:444-448).  chan_idx: n_sel channel numbers (host);
+ * out: n_sel streams, out_stride complex samples apart; *n_out = samples written per stream.
+ * Built for sample rates that are n_chans x 31.25 kHz with n_chans = 64 (2.0 Msps); the
+ * pre-resampler (:451-459) and the multi-ARFCN synthesizer (:567-576) are not.
+ * gmr1_hip_channelize_plan reports sizes: n_mid = 2x oversampled samples per channel. */
+int gmr1_hip_channelize_plan(double samp_rate, int sps, uint64_t n_in,
+                             int32_t *n_chans, uint64_t *n_mid, uint64_t *n_out);
+int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in,
+                            float rotation, int n_sel, const int32_t *chan_idx,
+                            float *out, uint64_t out_stride, uint64_t *n_out);
+int gmr1_hip_channelize(double samp_rate, int sps, const float *wide, uint64_t n_in, float rotation,
+                        int n_sel, const int32_t *chan_idx, float *out, uint64_t out_stride, uint64_t *n_out);
+
+/* ------------------------------------------------------------------------
  * The gmr1_rx receive loop over many BCCH carriers (reference src/gmr1_rx.c:605-895 and
  * main() :897-975, one process per capture file there).
  *

@@ -1,0 +1,188 @@
+"""oracle/orc_chan.py -- TEST INFRASTRUCTURE ONLY (never imported by the product).
+
+CPU restatement (numpy, float64 accumulation) of the wideband -> per-ARFCN channelizer of the
+reference's recorder script, utils/gmr1_rx_sdr.py (Python 2 + GNU Radio, cannot be imported here):
+
+  PFBBase            :391-490  2x oversampled polyphase analysis filterbank over n_chans channels of
+                               chan_width = 31.25 kHz, prototype firdes.low_pass(1, fs, cw/2, cw/4)
+  PFBOutputParameters:493-557  per-channel arbitrary resampler to sym_rate * sps with a 32-phase
+  PFBOutputBranch    :560-602  root-raised-cosine bank (alpha 0.35, 11 symbols)
+
+The arithmetic of those blocks lives in GNU Radio 3.7 (gr-filter: firdes, pfb_channelizer_ccf,
+pfb_arb_resampler_ccf), which is absent from /root/reference and from this image.  What is restated
+here is their published algorithm:
+
+  firdes.low_pass / root_raised_cosine : the window-method / closed-form tap formulas of firdes.cc
+  pfb.channelizer_ccf(n, taps, 2)      : Y_k[t] = sum_s x[s] h[t D - s] exp(-j 2 pi k s / n), D = n / 2
+                                         (channel k = k * fs / n from the centre, k >= n/2 negative)
+  pfb.arb_resampler_ccf(rate, taps, 32): polyphase bank of 32 filters + the derivative bank,
+                                         out = f_j(x) + frac * f'_j(x), phase advancing by 32 / rate
+
+PARITY UNPINNED and, for this row, unpinnable here: block-internal delays / start-up transients of
+GNU Radio are not reproduced (a constant delay of each output stream), and no GNU Radio output
+exists to compare with.  tests/ pin this file by construction instead: a tone placed in ARFCN k comes
+out of channel k at the right rate, and a synthetic wideband capture of BCCH carriers decodes.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+SYM_RATE = 23400
+CHAN_WIDTH = 31250.0       # gmr1_rx_sdr.py: GMR-1 carrier raster
+
+
+# --------------------------------------------------------------------------- firdes
+def firdes_low_pass(gain: float, fs: float, cutoff: float, tw: float) -> np.ndarray:
+    """gr::filter::firdes::low_pass, Hamming window (max attenuation 53 dB)."""
+    ntaps = int(53.0 * fs / (22.0 * tw))
+    if (ntaps & 1) == 0:
+        ntaps += 1
+    M = (ntaps - 1) // 2
+    n = np.arange(-M, M + 1, dtype=np.float64)
+    w = 0.54 - 0.46 * np.cos(2.0 * np.pi * np.arange(ntaps) / (ntaps - 1))
+    fw = 2.0 * np.pi * cutoff / fs
+    with np.errstate(invalid="ignore", divide="ignore"):
+        taps = np.where(n == 0, fw / np.pi, np.sin(n * fw) / (n * np.pi)) * w
+    fmax = taps[M] + 2.0 * taps[M + 1:].sum()
+    return (taps * (gain / fmax)).astype(np.float32)
+
+
+def firdes_rrc(gain: float, fs: float, sym_rate: float, alpha: float, ntaps: int) -> np.ndarray:
+    """gr::filter::firdes::root_raised_cosine."""
+    ntaps |= 1
+    spb = fs / sym_rate
+    taps = np.zeros(ntaps, np.float64)
+    scale = 0.0
+    for i in range(ntaps):
+        xindx = i - ntaps // 2
+        x1 = math.pi * xindx / spb
+        x2 = 4.0 * alpha * xindx / spb
+        x3 = x2 * x2 - 1.0
+        if abs(x3) >= 0.000001:
+            if i != ntaps // 2:
+                num = math.cos((1 + alpha) * x1) + math.sin((1 - alpha) * x1) / (4 * alpha * xindx / spb)
+            else:
+                num = math.cos((1 + alpha) * x1) + (1 - alpha) * math.pi / (4 * alpha)
+            den = x3 * math.pi
+        else:
+            if alpha == 1:
+                taps[i] = -1
+                continue
+            x3 = (1 - alpha) * x1
+            x2 = (1 + alpha) * x1
+            num = (math.sin(x2) * (1 + alpha) * math.pi
+                   - math.cos(x3) * ((1 - alpha) * math.pi * spb) / (4 * alpha * xindx)
+                   + math.sin(x3) * spb * spb / (4 * alpha * xindx * xindx))
+            den = -32 * math.pi * alpha * alpha * xindx / spb
+        taps[i] = 4 * alpha * num / den
+        scale += taps[i]
+    return (taps * gain / scale).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- plan
+class Plan:
+    """Numbers gmr1_rx_sdr.py derives before it builds the flowgraph (PFBBase.__init__ :393-437,
+    PFBOutputParameters.__init__ :497-531), for width-1 ARFCNs and an integer channel count."""
+
+    def __init__(self, samp_rate: float, sps: int = 4, chan_width: float = CHAN_WIDTH):
+        self.samp_rate = float(samp_rate)
+        self.sps = sps
+        self.chan_width = chan_width
+        self.n_chans = (int(math.ceil(samp_rate / chan_width)) + 1) & ~1        # :408
+        resamp = (self.n_chans * chan_width) / samp_rate                        # :411
+        if abs(resamp - 1.0) >= 1e-5:
+            raise ValueError("sample rate is not n_chans x chan_width: the pre-resampler is not restated")
+        self.taps = firdes_low_pass(1.0, samp_rate, chan_width * 0.50, chan_width * 0.25)   # :432-437
+        chan_rate = chan_width
+        self.oversample = 2                                                     # :495
+        self.resamp = (SYM_RATE * sps) / (chan_rate * self.oversample)          # :522
+        self.nfilt = 32
+        self.taps_resamp = firdes_rrc(32.0, 32.0 * chan_rate * self.oversample, SYM_RATE, 0.35,
+                                      int(11.0 * 32 * chan_rate * self.oversample / SYM_RATE))   # :523-529
+        self.decim = self.n_chans // self.oversample
+
+    def freq2index(self, rel_freq: float):
+        """PFBBase.freq2index :478-485 with the centre already subtracted."""
+        idx = int(round(rel_freq / self.chan_width))
+        if idx >= self.n_chans // 2 or idx <= -(self.n_chans // 2):
+            return None
+        return idx + self.n_chans if idx < 0 else idx
+
+
+# --------------------------------------------------------------------------- blocks
+def pfb_channelizer_2x(x: np.ndarray, taps: np.ndarray, n_chans: int, rotation: float = 0.0) -> np.ndarray:
+    """Y[k, t] = sum_s x[s] h[t D - s] exp(-j 2 pi k s / n), D = n / 2, t = 0 .. len(x) // D - 1
+    (samples before the capture are zero).  rotation: optional pre-rotation in rad / sample (:444-448)."""
+    M, D = n_chans, n_chans // 2
+    x = np.asarray(x, np.complex128)
+    if rotation:
+        x = x * np.exp(1j * rotation * np.arange(x.size))
+    L = taps.size
+    P = -(-L // M) + 1
+    T = x.size // D
+    h = np.zeros(P * M + M, np.float64)
+    h[:L] = taps
+    xp = np.concatenate([np.zeros(P * M, np.complex128), x, np.zeros(M, np.complex128)])
+    out = np.empty((M, T), np.complex64)
+    r = np.arange(M)
+    for par in range(2):                      # even / odd output instants use different tap alignments
+        ts = np.arange(par, T, 2)
+        if ts.size == 0:
+            continue
+        v = np.zeros((ts.size, M), np.complex128)
+        for q in range(-P, 1):
+            # block q of instant t: samples s = (t D // M + q) M + r ; tap index t D - s
+            blk = (ts * D) // M + q
+            s = blk[:, None] * M + r[None, :]
+            ti = (ts * D)[:, None] - s
+            ok = (ti >= 0) & (ti < L)
+            v += np.where(ok, xp[s + P * M] * h[np.clip(ti, 0, L - 1)], 0.0)
+        out[:, ts] = np.fft.fft(v, axis=1).T.astype(np.complex64)
+    return out
+
+
+def arb_resampler(x: np.ndarray, rate: float, taps: np.ndarray, nfilt: int = 32, n_out: int | None = None) -> np.ndarray:
+    """gr::filter::kernel::pfb_arb_resampler_ccf: filter bank j = taps[j::nfilt], derivative bank from the
+    first difference of the prototype, out[n] = f_j(x) + acc * f'_j(x) with the phase (in 1 / nfilt input
+    samples) advancing by nfilt / rate per output, starting at filter (ntaps / 2) % nfilt.
+    Input sample i is aligned with the newest tap position; samples before the stream are zero."""
+    x = np.asarray(x, np.complex128)
+    ntaps = taps.size
+    tpf = -(-ntaps // nfilt)
+    tp = np.zeros(tpf * nfilt, np.float64)
+    tp[:ntaps] = taps
+    dt = np.zeros_like(tp)
+    dt[:ntaps - 1] = np.diff(tp[:ntaps])
+    bank = tp.reshape(tpf, nfilt).T           # bank[j, k] = taps[j + k nfilt]
+    dbank = dt.reshape(tpf, nfilt).T
+    # the phase advances by nfilt / rate per output; with rate = sym_rate * sps / (2 chan_width) that is the
+    # exact fraction num / den below, kept in integers so that no output lands on the wrong side of a
+    # filter boundary (GNU Radio accumulates it in a float and lets it drift)
+    from fractions import Fraction
+    step = Fraction(nfilt) / Fraction(rate).limit_denominator(1 << 20)
+    num, den = step.numerator, step.denominator
+    j0 = (ntaps // 2) % nfilt
+    if n_out is None:
+        n_out = ((x.size * nfilt - j0) * den) // num
+    n = np.arange(n_out, dtype=np.int64)
+    N = j0 * den + n * num
+    fl = N // den
+    acc = (N % den).astype(np.float64) / den
+    j = fl % nfilt
+    i_in = fl // nfilt
+    xp = np.concatenate([np.zeros(tpf, np.complex128), x, np.zeros(tpf + 2, np.complex128)])
+    o0 = np.zeros(n_out, np.complex128)
+    o1 = np.zeros(n_out, np.complex128)
+    for k in range(tpf):
+        s = xp[i_in - k + tpf]                # y = sum_k taps_j[k] x[i - k]
+        o0 += bank[j, k] * s
+        o1 += dbank[j, k] * s
+    return (o0 + o1 * acc).astype(np.complex64)
+
+
+def channelize(x: np.ndarray, plan: Plan, channels, rotation: float = 0.0, n_out: int | None = None):
+    """Wideband capture -> {channel index: stream at sym_rate * sps}."""
+    y = pfb_channelizer_2x(x, plan.taps, plan.n_chans, rotation)
+    return {int(k): arb_resampler(y[int(k)], plan.resamp, plan.taps_resamp, plan.nfilt, n_out) for k in channels}

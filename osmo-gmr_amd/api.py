@@ -37,6 +37,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
     "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
     "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch",
+    "gmr1_hip_channelize_plan", "gmr1_hip_channelize_dev", "gmr1_hip_channelize",
     "gmr1_hip_dkab_demod_batch_dev", "gmr1_hip_dkab_demod_batch", "gmr1_dkab_demod",
     "gmr1_hip_a5_batch_dev", "gmr1_hip_a5_batch", "gmr1_a5", "gmr1_a5_1",
 ]
@@ -667,3 +668,43 @@ def rx_run_tch(iq, tch, offset, length, sps=4, arfcn=None, kc=None, max_records=
            status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p))
     _check(rc, "gmr1_hip_rx_run_tch")
     return out[:min(n_rec.value, max_records)].copy(), status[:n], chains[:n], n_rec.value
+
+
+# ---------------------------------------------------------------------------
+# wideband -> per-ARFCN channelizer (reference utils/gmr1_rx_sdr.py:391-602)
+# ---------------------------------------------------------------------------
+def channelize_plan(samp_rate, sps, n_in):
+    """-> (n_chans, samples per 2x oversampled channel stream, output samples per channel)"""
+    nch, nm, no = C.c_int32(), C.c_uint64(), C.c_uint64()
+    f = load().gmr1_hip_channelize_plan
+    f.restype = C.c_int
+    _check(f(C.c_double(samp_rate), C.c_int(sps), C.c_uint64(n_in), C.byref(nch), C.byref(nm), C.byref(no)),
+           "gmr1_hip_channelize_plan")
+    return nch.value, nm.value, no.value
+
+
+def channelize(wide, samp_rate, channels, sps=4, rotation=0.0):
+    """gmr1_hip_channelize: host wideband complex64 -> (len(channels), n_out) complex64"""
+    wide, p_w = _np(np.asarray(wide).reshape(-1), np.complex64)
+    ch, p_ch = _np(channels, np.int32)
+    _, _, n_out = channelize_plan(samp_rate, sps, wide.size)
+    out = np.zeros((ch.size, n_out), np.complex64)
+    no = C.c_uint64()
+    f = load().gmr1_hip_channelize
+    f.restype = C.c_int
+    rc = f(C.c_double(samp_rate), C.c_int(sps), p_w, C.c_uint64(wide.size), C.c_float(rotation), C.c_int(ch.size), p_ch,
+           out.ctypes.data_as(C.c_void_p), C.c_uint64(n_out), C.byref(no))
+    _check(rc, "gmr1_hip_channelize")
+    return out
+
+
+def channelize_dev(stream, wide_ptr, n_in, samp_rate, channels, out_ptr, out_stride, sps=4, rotation=0.0):
+    ch, p_ch = _np(channels, np.int32)
+    no = C.c_uint64()
+    f = load().gmr1_hip_channelize_dev
+    f.restype = C.c_int
+    rc = f(C.c_void_p(stream) if stream else None, C.c_double(samp_rate), C.c_int(sps), C.c_void_p(wide_ptr),
+           C.c_uint64(n_in), C.c_float(rotation), C.c_int(ch.size), p_ch, C.c_void_p(out_ptr), C.c_uint64(out_stride),
+           C.byref(no))
+    _check(rc, "gmr1_hip_channelize_dev")
+    return no.value

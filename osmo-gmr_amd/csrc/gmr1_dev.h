@@ -181,6 +181,35 @@ struct A5Args {
 	uint8_t *dl, *ul;          // optional n x nbits ubits each
 };
 
+// wideband -> per-ARFCN channelizer (chan_kernels.hip)
+constexpr int kPfbMaxBlocks = 12;        // prototype taps / n_chans, rounded up, + 1
+struct PfbArgs {
+	int n_chans;               // 64
+	int n_blocks;              // taps per polyphase branch (<= kPfbMaxBlocks)
+	int ntaps;
+	long long n_in;            // wideband samples
+	long long T;               // output instants = n_in / (n_chans / 2)
+	float rotation;            // optional pre-rotation, rad / sample
+	const float2 *x;           // wideband capture
+	const float *taps;         // prototype low-pass, ntaps floats
+	const int32_t *slot;       // n_chans entries: output slot of channel k or -1
+	float2 *y;                 // n_slots x T, 2x oversampled channel streams
+};
+struct ResampArgs {
+	int n_slots;
+	int nfilt, tpf;            // 32 filters x tpf taps
+	int j0;                    // starting filter
+	long long num, den;        // phase step nfilt / rate = num / den, in 1 / nfilt input samples
+	long long T;               // input samples per stream
+	long long n_out;           // outputs per stream
+	long long out_stride;      // complex samples between output streams
+	const float2 *y;           // n_slots x T
+	const float2 *bank;        // nfilt x tpf (tap, derivative tap) pairs
+	float2 *out;
+};
+hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream);
+hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream);
+
 hipError_t launch_dkab(const DkabArgs &a, hipStream_t stream);
 hipError_t launch_a5(const A5Args &a, hipStream_t stream);
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);

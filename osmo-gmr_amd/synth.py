@@ -279,7 +279,7 @@ def synth_windows(fmt: BurstFormat, symbols: np.ndarray, sps: int, win: int, rng
     tmp = np.empty((B, n_sym_out), np.complex64)
     for p in range(sps):
         for m in range(-span, span + 1):
-            coef = rc_pulse(m + (p - fr) / sps).astype(np.float32)      # (B,)
+            coef = (rrc_pulse if pulse == "rrc" else rc_pulse)(m + (p - fr) / sps).astype(np.float32)      # (B,)
             # output symbol slot i (burst index i - pad) uses s[i - pad - m]
             np.multiply(spad[:, pad - m:pad - m + n_sym_out], coef[:, None], out=tmp)
             body[p] += tmp
@@ -320,8 +320,24 @@ def synth_windows(fmt: BurstFormat, symbols: np.ndarray, sps: int, win: int, rng
     return BurstBatch(iq=out, stride=stride, in_len=in_len, toa=toa, cfo=cfo)
 
 
-def shape_bursts(symbols: np.ndarray, sps: int, frac, span: int = 5) -> np.ndarray:
-    """Raised-cosine shaping of (B, L) symbol rows to sps samples per symbol.
+def rrc_pulse(t: np.ndarray, alpha: float = 0.35) -> np.ndarray:
+    """Root-raised-cosine pulse (unit energy per symbol at 1 sample / symbol), t in symbols."""
+    t = np.asarray(t, dtype=np.float64)
+    out = np.empty_like(t)
+    z = np.abs(t) < 1e-9
+    s = np.abs(np.abs(4.0 * alpha * t) - 1.0) < 1e-9
+    g = ~(z | s)
+    out[z] = 1.0 - alpha + 4.0 * alpha / np.pi
+    out[s] = (alpha / np.sqrt(2.0)) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * alpha)) + (1 - 2 / np.pi) * np.cos(np.pi / (4 * alpha)))
+    tg = t[g]
+    out[g] = (np.sin(np.pi * tg * (1 - alpha)) + 4 * alpha * tg * np.cos(np.pi * tg * (1 + alpha))) / (np.pi * tg * (1 - (4 * alpha * tg) ** 2))
+    return out
+
+
+def shape_bursts(symbols: np.ndarray, sps: int, frac, span: int = 5, pulse: str = "rc") -> np.ndarray:
+    """Raised-cosine (pulse="rc": what the demodulator expects to see) or root-raised-cosine
+    (pulse="rrc": what a transmitter sends, before the receive filter of a channelizer) shaping of
+    (B, L) symbol rows to sps samples per symbol.
 
     Returns (B, (L + 2*span) * sps): sample k belongs to burst-relative time (k - span*sps) samples,
     delayed by `frac` (scalar or (B,)) samples."""
@@ -335,7 +351,7 @@ def shape_bursts(symbols: np.ndarray, sps: int, frac, span: int = 5) -> np.ndarr
     tmp = np.empty((B, n_sym_out), np.complex64)
     for p in range(sps):
         for m in range(-span, span + 1):
-            coef = rc_pulse(m + (p - fr) / sps).astype(np.float32)
+            coef = (rrc_pulse if pulse == "rrc" else rc_pulse)(m + (p - fr) / sps).astype(np.float32)
             np.multiply(spad[:, pad - m:pad - m + n_sym_out], coef[:, None], out=tmp)
             body[p] += tmp
     return np.ascontiguousarray(body.transpose(1, 2, 0)).reshape(B, n_sym_out * sps)
@@ -374,7 +390,7 @@ def si1_payload(rng: np.random.Generator, fn: np.ndarray, delay: int, stn: int) 
 def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: int, sps: int,
                        rng: np.random.Generator, *, stn: int = 3, delay: int = 2, fn0: int | None = None,
                        t0: int | None = None, frac: float = 0.0, esn0_db: float = 15.0, cfo_hz: float = 0.0,
-                       p_idle: float = 0.15, fcch_db: float = 0.0, imm_ass=()):
+                       p_idle: float = 0.15, fcch_db: float = 0.0, imm_ass=(), pulse: str = "rc", span: int = 5):
     """One ARFCN of BASELINE.md config 4: FCCH + BCCH (SI1 w/ Seg 2A bis) + CCCH on the
     24-slot / 40 ms TDMA grid (reference src/gmr1_rx.c:852-895 schedule).
 
@@ -391,7 +407,6 @@ def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: i
     sigma = np.sqrt(10.0 ** (-esn0_db / 10.0) / 2.0)
     x = rng.standard_normal((n_samples, 2), dtype=np.float32).view(np.complex64).reshape(-1)
     x *= np.float32(sigma)
-    span = 5
     n_frames = (n_samples - t0) // frame_len + 1
     fns = fn0 + np.arange(n_frames)
     sirfn = (fns - delay) & 63
@@ -409,7 +424,7 @@ def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: i
         l2 = si1_payload(rng, fns[kb], delay, stn)
         other = rng.random(kb.size) < 0.25            # some BCCH bursts carry another SI: no TDMA info
         l2[other, 0] = 0x10 | (l2[other, 0] & 0x07)
-        body = shape_bursts(map_symbols(fmt_bcch, bcch_encode(l2)), sps, frac, span)
+        body = shape_bursts(map_symbols(fmt_bcch, bcch_encode(l2)), sps, frac, span, pulse)
         for i, k in enumerate(kb):
             pos = t0 + k * frame_len + stn * 39 * sps - span * sps
             if pos >= 0 and pos + body.shape[1] <= n_samples:
@@ -428,7 +443,7 @@ def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: i
                 i_a = int(later[0])
                 l2[i_a] = imm_ass_payload(rng, tn_a, p_a)
                 ia_of[i_a] = (tn_a, p_a)
-        body = shape_bursts(map_symbols(fmt_dc6, ccch_encode(l2)), sps, frac, span)
+        body = shape_bursts(map_symbols(fmt_dc6, ccch_encode(l2)), sps, frac, span, pulse)
         for i, k in enumerate(kc):
             pos = t0 + k * frame_len + stn * 39 * sps - span * sps
             if pos >= 0 and pos + body.shape[1] <= n_samples:

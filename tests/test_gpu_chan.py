@@ -1,0 +1,97 @@
+"""GPU tests of the wideband -> per-ARFCN channelizer (gmr1_hip_channelize*, reference
+utils/gmr1_rx_sdr.py:391-602) against the numpy restatement in oracle/orc_chan.py, and end to end:
+a synthetic wideband capture of BCCH carriers -> channelizer -> receive loop -> the frames that were sent."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import workloads
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+pytestmark = pytest.mark.gpu
+
+FS = 2.0e6
+
+
+def test_plan_matches_the_reference_formulas(gpu_api):
+    import orc_chan
+    pl = orc_chan.Plan(FS)
+    n_chans, n_mid, n_out = gpu_api.channelize_plan(FS, 4, 200000)
+    assert n_chans == pl.n_chans == 64 and n_mid == 200000 // 32
+    assert n_out == ((n_mid * 32 - (pl.taps_resamp.size // 2) % 32) * 117) // 2500
+    with pytest.raises(Exception):
+        gpu_api.channelize_plan(1.9e6, 4, 1000)            # not n_chans x 31.25 kHz: pre-resampler not built
+
+
+def test_channelizer_matches_oracle(gpu_api):
+    import orc_chan
+    pl = orc_chan.Plan(FS)
+    rng = np.random.default_rng(2)
+    n = 300000
+    x = (rng.standard_normal((n, 2)) * 0.3).astype(np.float32).view(np.complex64).reshape(-1)
+    s = np.arange(n)
+    for k, f, a in ((5, 1000.0, 1.0), (40, -4000.0, 0.5), (31, 9000.0, 2.0)):
+        kk = k if k < 32 else k - 64
+        x += (a * np.exp(2j * np.pi * ((kk * 31250.0 + f) / FS) * s)).astype(np.complex64)
+    chans = [5, 40, 31, 0, 63, 32]
+    got = gpu_api.channelize(x, FS, chans)
+    ref = orc_chan.channelize(x, pl, chans)
+    for i, k in enumerate(chans):
+        r = ref[k]
+        assert got[i].size == r.size
+        err = np.max(np.abs(got[i] - r))
+        assert err < 2e-4 * max(1.0, float(np.sqrt(np.mean(np.abs(r) ** 2)))), (k, err)
+    # the tones came out where they belong, at the right frequency (analytic check of oracle and kernel alike)
+    for i, (k, f, a) in enumerate(((5, 1000.0, 1.0), (40, -4000.0, 0.5), (31, 9000.0, 2.0))):
+        z = got[i][2000:20000].astype(np.complex128)
+        fest = np.angle(np.mean(z[1:] * np.conj(z[:-1]))) / (2 * np.pi) * 93600.0
+        assert abs(fest - f) < 30.0, (k, fest, f)
+        assert abs(np.sqrt(np.mean(np.abs(z) ** 2)) - a) < 0.25 * a
+    # pre-rotation moves everything by one raster step
+    rot = gpu_api.channelize(x, FS, [6], rotation=2 * np.pi * 31250.0 / FS)
+    assert np.max(np.abs(rot[0][3000:] - got[0][3000:])) < 5e-3
+
+
+def test_channelizer_device_resident_and_subset(gpu_api):
+    import torch
+    rng = np.random.default_rng(3)
+    n = 64 * 1000 + 17                                      # ragged tail
+    x = rng.standard_normal((n, 2)).astype(np.float32).view(np.complex64).reshape(-1)
+    full = gpu_api.channelize(x, FS, list(range(64)))
+    _, _, n_out = gpu_api.channelize_plan(FS, 4, n)
+    t = torch.from_numpy(x.view(np.float32)).cuda()
+    out = torch.zeros((2, n_out + 5, 2), dtype=torch.float32, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        w = gpu_api.channelize_dev(st.cuda_stream, t.data_ptr(), n, FS, [9, 50], out.data_ptr(), n_out + 5)
+    st.synchronize()
+    assert w == n_out
+    o = out.cpu().numpy().view(np.complex64).reshape(2, n_out + 5)
+    assert np.array_equal(o[0, :n_out], full[9]) and np.array_equal(o[1, :n_out], full[50])
+    assert not o[:, n_out:].any()
+    with pytest.raises(Exception):
+        gpu_api.channelize(x, FS, [3, 3])
+
+
+def test_wideband_capture_decodes_end_to_end(gpu_api, pkg):
+    carriers = ((3, dict(stn=3, delay=2, cfo_hz=80.0)), (17, dict(stn=10, delay=5, cfo_hz=-150.0)),
+                (60, dict(stn=0, delay=0, cfo_hz=20.0)))
+    wide, sents = workloads.wideband_capture(pkg, 11, seconds=2.5, carriers=carriers)
+    chans = [c for c, _ in carriers] + [30]                 # one raster position nobody transmits on
+    nb = gpu_api.channelize(wide, FS, chans)
+    n_out = nb.shape[1]
+    assert abs(n_out - 2.5 * 93600) < 200
+    offset = np.arange(len(chans), dtype=np.uint64) * np.uint64(n_out)
+    length = np.full(len(chans), n_out, np.uint64)
+    rec, status, chains, found = gpu_api.rx_run(nb.reshape(-1), offset, length, sps=4, arfcn=np.asarray(chans, np.uint16))
+    for ch, _ in carriers:
+        mine = rec[rec["arfcn"] == ch]
+        mb, nbc, mc, nc, mp = workloads.match_records(mine, sents[ch])
+        n_b = sum(s["type"] == "bcch" for s in sents[ch])
+        n_c = sum(s["type"] == "ccch" for s in sents[ch])
+        assert nbc >= n_b - 3 and mp == nbc, (ch, nbc, n_b, mp)
+        assert nc >= 0.8 * n_c and mc >= nc - 1, (ch, nc, n_c, mc)
+    assert len(rec[rec["arfcn"] == 30]) == 0

@@ -135,3 +135,30 @@ def bcch_tch_pair(pkg, seed, seconds=4.0, sps=4, stn=3, delay=2, tn=11, p=20, k_
                                            kc=kc, cipher_from=None if cipher_after is None else k_start + cipher_after,
                                            esn0_db=esn0_db, cfo_hz=cfo_hz, mix=mix, k_stop=k_stop)
     return bcch, tch, sent, sent_t
+
+
+def wideband_capture(pkg, seed, seconds=2.5, samp_rate=2.0e6, carriers=((3, {}), (17, {}), (60, {})), sps=4):
+    """A wideband capture (wideband container): each (channel, kwargs) is a BCCH
+    carrier sent with root-raised-cosine pulses on ARFCN raster position `channel` (k x 31.25 kHz from the
+    centre, k >= 32 below it), resampled 93.6 k -> samp_rate and summed.  Returns (wide, {channel: sent})."""
+    from importlib import import_module
+    from scipy.signal import resample_poly
+    synth = import_module(pkg.__name__ + ".synth")
+    rng = np.random.default_rng(seed)
+    n_nb = int(seconds * 23400 * sps)
+    up, down = 2500, 117                       # 2.0e6 / 93.6e3
+    assert abs(samp_rate / (23400 * sps) - up / down) < 1e-9
+    n_w = n_nb * up // down
+    wide = np.zeros(n_w, np.complex64)
+    sents = {}
+    fb, fd = pkg.api.burst_format("bcch"), pkg.api.burst_format("dc6")
+    t = np.arange(n_w, dtype=np.float64)
+    for ch, kw in carriers:
+        kw = dict(kw)
+        kw.setdefault("esn0_db", 25.0)
+        nb, sent = synth.synth_bcch_carrier(fb, fd, n_nb, sps, rng, pulse="rrc", span=8, **kw)
+        w = resample_poly(nb.astype(np.complex128), up, down)[:n_w]
+        k = ch if ch < 32 else ch - 64
+        wide += (w * np.exp(2j * np.pi * (k * 31250.0 / samp_rate) * t)).astype(np.complex64)
+        sents[ch] = sent
+    return wide, sents
