@@ -1,6 +1,5 @@
 // capi_chan.cpp -- C ABI of the wideband -> per-ARFCN channelizer (reference utils/gmr1_rx_sdr.py:391-602:
-// PFBBase, PFBOutputParameters, PFBOutputBranch; the GNU Radio blocks they configure are restated in
-// oracle/orc_chan.py).  The filter design (firdes.low_pass, firdes.root_raised_cosine) runs on the host
+// PFBBase, PFBOutputParameters, PFBOutputBranch, and the GNU Radio blocks they configure).  The filter design (firdes.low_pass, firdes.root_raised_cosine) runs on the host
 // in double precision, once per (sample rate, sps); everything per sample runs on the GPU.
 
 #include "capi_common.h"

@@ -2,8 +2,7 @@
 //
 // What the reference's recorder does with GNU Radio blocks (utils/gmr1_rx_sdr.py:391-602):
 // pfb.channelizer_ccf(n_chans, low_pass taps, 2x oversampled) followed, per ARFCN, by
-// pfb.arb_resampler_ccf(rate, 32-phase root-raised-cosine bank).  Restated in oracle/orc_chan.py;
-// here as two streaming kernels:
+// pfb.arb_resampler_ccf(rate, 32-phase root-raised-cosine bank).  Here as two streaming kernels:
 //
 //   k_pfb<64>  : Y_k[t] = sum_s x[s] h[t D - s] e^{-j 2 pi k s / 64},  D = 32.
 //                One wavefront walks a range of output instants; lane r owns the polyphase branch of

@@ -279,7 +279,7 @@ def synth_windows(fmt: BurstFormat, symbols: np.ndarray, sps: int, win: int, rng
     tmp = np.empty((B, n_sym_out), np.complex64)
     for p in range(sps):
         for m in range(-span, span + 1):
-            coef = (rrc_pulse if pulse == "rrc" else rc_pulse)(m + (p - fr) / sps).astype(np.float32)      # (B,)
+            coef = rc_pulse(m + (p - fr) / sps).astype(np.float32)      # (B,)
             # output symbol slot i (burst index i - pad) uses s[i - pad - m]
             np.multiply(spad[:, pad - m:pad - m + n_sym_out], coef[:, None], out=tmp)
             body[p] += tmp

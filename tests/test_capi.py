@@ -114,7 +114,7 @@ def test_product_does_not_reference_oracle():
         for path in glob.glob(os.path.join(ROOT, d, "**", "*"), recursive=True):
             if os.path.isfile(path) and path.endswith((".py", ".h", ".hip", ".cpp", ".c")):
                 txt = open(path, errors="replace").read()
-                if re.search(r"oracle_lib|liborc|orc_[a-z0-9_]+\(|#include\s+\"orc_", txt):
+                if re.search(r"oracle_lib|liborc|import\s+orc_chan|from\s+orc_chan|orc_[a-z0-9_]+\(|#include\s+\"orc_", txt):
                     bad.append(path)
     assert not bad, bad
 
