@@ -63,6 +63,7 @@ __device__ __forceinline__ void dif_stage(float &re, float &im, bool hi, float w
 	im = hi ? ti : si;
 }
 
+template <bool ROT>
 __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 {
 	__shared__ float2 tile[64 * (kPfbTile + 1)];
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 		float2 v = make_float2(0.f, 0.f);
 		if (b >= 0 && s < a.n_in) {
 			v = a.x[s];
-			if (a.rotation != 0.0f) {
+			if (ROT) {
 				// e^{j rotation s}: the angle reduced in double so that long captures keep their phase
 				const double ph = (double)a.rotation * (double)s;
 				const float fr = (float)(ph - 6.283185307179586 * rint(ph * 0.15915494309189535));
@@ -115,12 +116,14 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 	for (int q = 1; q < kPfbMaxBlocks; q++)
 		w[q] = load_block(b0 - q);
 
+	float2 nxt = load_block(b0);
 	for (int tt = 0; tt < kPfbSteps; tt += kPfbTile) {
 #pragma unroll 1
 		for (int u = 0; u < kPfbTile; u += 2) {
 			const long long t = t0 + tt + u;
-			// new block: it serves instants t (even) and t + 1
-			w[0] = load_block(t / 2);
+			// new block: it serves instants t (even) and t + 1; the one after it is already on its way
+			w[0] = nxt;
+			nxt = load_block(t / 2 + 1);
 			float er = 0.f, ei = 0.f, orr = 0.f, oi = 0.f;
 #pragma unroll
 			for (int q = 0; q < kPfbMaxBlocks; q++) {
@@ -166,63 +169,107 @@ hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream)
 	if (a.T <= 0)
 		return hipSuccess;
 	const long long grid = (a.T + kPfbSteps - 1) / kPfbSteps;
-	hipLaunchKernelGGL(k_pfb64, dim3((unsigned)grid), dim3(64), 0, stream, a);
+	if (a.rotation != 0.0f)
+		hipLaunchKernelGGL(k_pfb64<true>, dim3((unsigned)grid), dim3(64), 0, stream, a);
+	else
+		hipLaunchKernelGGL(k_pfb64<false>, dim3((unsigned)grid), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 // arbitrary resampler
+//
+// The phase step num/den is rational, so the (filter, fraction) pair of output n repeats with period
+// P = 32 den / gcd(num, 32 den) outputs = Q = num / gcd(...) inputs (936 outputs = 625 inputs at
+// sps 4).  A lane therefore owns ONE output phase p for a run of periods: its 30 effective taps
+// e[k] = b_j[k] + frac d_j[k] are computed once and stay in registers; per output it only reads its
+// 30 input samples from a wave-private LDS window (the 64 phases of a wave span ~43 + 30 inputs),
+// which the wave stages with coalesced loads one period ahead.  Single-wavefront work-groups, no
+// s_barrier; outputs of a wave are 64 consecutive samples = one 512-byte store.
 // ---------------------------------------------------------------------------
-static constexpr int kRsBlock = 256;
+static constexpr int kRsTaps = 30;           // taps per filter of the 941-tap / 32-phase bank
+static constexpr int kRsPeriods = 32;        // periods one wave walks
+static constexpr int kRsWin = 256;           // LDS window (samples) per wave, >= span
 
-__global__ __launch_bounds__(kRsBlock) void k_resamp(ResampArgs a, int span)
+__global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long long Q, int span)
 {
-	extern __shared__ __align__(16) unsigned char lds_raw[];
-	float2 *bank = reinterpret_cast<float2 *>(lds_raw);                   // nfilt x tpf (b, d)
-	float2 *xs = bank + a.nfilt * a.tpf;                                  // input span of this block
-	const int tid = threadIdx.x;
+	__shared__ float2 xs[kRsWin];
+	const int lane = threadIdx.x;
 	const int sl = blockIdx.y;
-	const long long n0 = (long long)blockIdx.x * kRsBlock;
-	for (int i = tid; i < a.nfilt * a.tpf; i += kRsBlock)
-		bank[i] = a.bank[i];
-	// input index of the block's first output; every output of the block reads [i - tpf + 1, i]
-	const long long N0 = (long long)a.j0 * a.den + n0 * a.num;
-	const long long i_first = (N0 / a.den) / a.nfilt - (a.tpf - 1);
-	const float2 *__restrict__ y = a.y + (long long)sl * a.T;
-	for (int i = tid; i < span; i += kRsBlock) {
-		const long long s = i_first + i;
-		xs[i] = (s >= 0 && s < a.T) ? y[s] : make_float2(0.f, 0.f);
-	}
-	__syncthreads();
-	const long long n = n0 + tid;
-	if (n >= a.n_out)
-		return;
-	const long long N = (long long)a.j0 * a.den + n * a.num;
-	const long long fl = N / a.den;
-	const float frac = (float)(N - fl * a.den) / (float)a.den;
+	const long long p0 = (long long)blockIdx.x * 64;
+	const long long p = p0 + lane;
+	const bool live = p < P;
+	// phase of this lane's outputs: exact integer arithmetic, once
+	const long long Np = (long long)a.j0 * a.den + (live ? p : p0) * a.num;
+	const long long fl = Np / a.den;
+	const float frac = (float)(Np - fl * a.den) / (float)a.den;
 	const int j = (int)(fl % a.nfilt);
-	const int base = (int)(fl / a.nfilt - i_first);                        // xs index of input sample i
-	const float2 *bj = bank + j * a.tpf;
-	float orr = 0.f, oi = 0.f;
-	for (int k = 0; k < a.tpf; k++) {
-		const float2 bd = bj[k];
-		const float e = fmaf(frac, bd.y, bd.x);
-		const float2 s = xs[base - k];
-		orr = fmaf(e, s.x, orr);
-		oi = fmaf(e, s.y, oi);
+	const long long ip = fl / a.nfilt;                                  // input index of period 0
+	const long long N0 = (long long)a.j0 * a.den + p0 * a.num;
+	const long long i_first = (N0 / a.den) / a.nfilt - (kRsTaps - 1);   // first input the wave needs (period 0)
+	const int base = (int)(ip - i_first);                               // window index of this lane's newest sample
+	float e[kRsTaps];
+#pragma unroll
+	for (int k = 0; k < kRsTaps; k++) {
+		const float2 bd = a.bank[j * kRsTaps + k];
+		e[k] = fmaf(frac, bd.y, bd.x);
 	}
-	a.out[(long long)sl * a.out_stride + n] = make_float2(orr, oi);
+	const float2 *__restrict__ y = a.y + (long long)sl * a.T;
+	float2 *__restrict__ out = a.out + (long long)sl * a.out_stride;
+	const long long m0 = (long long)blockIdx.z * kRsPeriods;
+
+	// window of period m: inputs i_first + m Q + [0, span)
+	float2 nx[4];
+	auto fetch = [&](long long m) {
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			const int w = lane + 64 * h;
+			const long long s = i_first + m * Q + w;
+			nx[h] = (w < span && s >= 0 && s < a.T) ? y[s] : make_float2(0.f, 0.f);
+		}
+	};
+	fetch(m0);
+	for (int mm = 0; mm < kRsPeriods; mm++) {
+		const long long m = m0 + mm;
+		if (m * P >= a.n_out)
+			break;
+		WSYNC();
+#pragma unroll
+		for (int h = 0; h < 4; h++)
+			if (lane + 64 * h < span)
+				xs[lane + 64 * h] = nx[h];
+		WSYNC();
+		if (mm + 1 < kRsPeriods)
+			fetch(m + 1);                       // next period's window travels during this one's arithmetic
+		float orr = 0.f, oi = 0.f;
+#pragma unroll
+		for (int k = 0; k < kRsTaps; k++) {
+			const float2 s = xs[base - k];
+			orr = fmaf(e[k], s.x, orr);
+			oi = fmaf(e[k], s.y, oi);
+		}
+		const long long n = m * P + p;
+		if (live && n < a.n_out)
+			out[n] = make_float2(orr, oi);
+	}
 }
 
 hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 {
 	if (a.n_out <= 0 || a.n_slots <= 0)
 		return hipSuccess;
-	// inputs one block of outputs can touch: (kRsBlock - 1) num / (den nfilt) + tpf, rounded up generously
-	const int span = (int)(((long long)(kRsBlock - 1) * a.num) / (a.den * a.nfilt)) + a.tpf + 3;
-	const size_t lds = ((size_t)a.nfilt * a.tpf + (size_t)span) * sizeof(float2);
-	const long long gx = (a.n_out + kRsBlock - 1) / kRsBlock;
-	hipLaunchKernelGGL(k_resamp, dim3((unsigned)gx, (unsigned)a.n_slots), dim3(kRsBlock), lds, stream, a, span);
+	if (a.tpf != kRsTaps)
+		return hipErrorInvalidValue;
+	long long g = a.num, b = a.den * a.nfilt;
+	while (b) { const long long t = g % b; g = b; b = t; }
+	const long long P = a.den * a.nfilt / g, Q = a.num / g;
+	// inputs the 64 phases of a wave can touch
+	const int span = (int)((63 * a.num) / (a.den * a.nfilt)) + kRsTaps + 2;
+	if (span > kRsWin)
+		return hipErrorInvalidValue;
+	const long long periods = (a.n_out + P - 1) / P;
+	const unsigned gx = (unsigned)((P + 63) / 64), gz = (unsigned)((periods + kRsPeriods - 1) / kRsPeriods);
+	hipLaunchKernelGGL(k_resamp, dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	return hipGetLastError();
 }
 
