@@ -271,3 +271,14 @@ def test_demod_low_oversampling(gpu_api, orc, pkg):
             assert nfrac >= 3, "the fractional-delay branch was not exercised"
         hard = (got["ebits"] < 0).astype(np.uint8)
         assert (hard != ebits).mean() < 0.03, (sps, name)
+
+
+@pytest.mark.parametrize("sps", [5, 8])
+def test_fused_rx_other_oversampling(gpu_api, orc, pkg, sps):
+    """The fused path at sps != 4 (generic k_rx4 instantiation; windows of 234 sps + 20 sps / 10 sps samples)."""
+    wl = workloads.bcch_ccch_mix(pkg, n=403, seed=7, sps=sps, toa_jitter=2 * sps)
+    got = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=sps)
+    ref = orc.demod_decode_batch(wl["iq"], wl["offset"], wl["kind"], sps=sps)
+    st = _compare_fused(got, ref, wl, label=f"sps{sps}")
+    print("fused parity:", st)
+    assert (got["crc"] == 0).mean() > 0.9

@@ -171,3 +171,14 @@ def test_rx_loop_tch3_follow_up_matches_oracle(gpu_api, orc, pkg):
     # without the traffic carriers: exactly the BCCH / CCCH records
     rec0, _, _, _ = gpu_api.rx_run(np.concatenate(bc), offset, length, sps=SPS)
     assert _key_n(rec0) == _key_n(rec[rec["type"] < 0x10])
+
+
+def test_rx_loop_at_sps_8(gpu_api, orc, pkg):
+    """The whole receive loop at another oversampling (gmr1_rx takes sps from the command line, gmr1_rx.c:917)."""
+    x, sent = workloads.bcch_carrier(pkg, 61, seconds=2.5, sps=8, stn=6, delay=3, cfo_hz=100.0)
+    rec, status, chains, found = gpu_api.rx_run(x, [0], [x.size], sps=8)
+    orv, orec, och = orc.rx_run(x, sps=8, arfcn=0)
+    assert status[0] == orv == 0 and chains[0] == och
+    assert _key(rec) == _key(orec)
+    mb, nb, mc, nc, mp = workloads.match_records(rec, sent)
+    assert nb >= 5 and mp == nb and mc >= nc - 1
