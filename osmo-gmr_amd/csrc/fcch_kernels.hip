@@ -105,15 +105,24 @@ __global__ __launch_bounds__(256) void k_fcch_stats(FcchRoughArgs a)
 		// when (begin + 2t) % 4 == 0, i.e. on even t (begin is a multiple of 8192)
 		const float4 *in4 = reinterpret_cast<const float4 *>(in + begin);
 		const bool keep = (threadIdx.x & 1) == 0;
-#pragma unroll 4
+		// all 16 loads of the tile are issued before the first is consumed (the stream is read once:
+		// nothing but memory-level parallelism hides the HBM latency)
+		typedef float v4f __attribute__((ext_vector_type(4)));
+		const v4f *in4v = reinterpret_cast<const v4f *>(in4);
+		float4 p[kStatSpan / 512];
+#pragma unroll
 		for (int it = 0; it < kStatSpan / 512; it++) {
-			const float4 p = in4[it * 256 + (int)threadIdx.x];
-			sr += p.x + p.z;
-			si += p.y + p.w;
-			sq = fmaf(p.x, p.x, fmaf(p.y, p.y, fmaf(p.z, p.z, fmaf(p.w, p.w, sq))));
+			const v4f t = __builtin_nontemporal_load(&in4v[it * 256 + (int)threadIdx.x]);
+			p[it] = make_float4(t.x, t.y, t.z, t.w);
+		}
+#pragma unroll
+		for (int it = 0; it < kStatSpan / 512; it++) {
+			sr += p[it].x + p[it].z;
+			si += p[it].y + p[it].w;
+			sq = fmaf(p[it].x, p[it].x, fmaf(p[it].y, p[it].y, fmaf(p[it].z, p[it].z, fmaf(p[it].w, p[it].w, sq))));
 			const int di = (begin + it * 512 + 2 * (int)threadIdx.x) >> 2;
 			if (keep && di < ndec)
-				dec[di] = make_float2(p.x, p.y);
+				dec[di] = make_float2(p[it].x, p[it].y);
 		}
 	} else {
 		for (int i = begin + (int)threadIdx.x; i < end; i += 256) {
