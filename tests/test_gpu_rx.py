@@ -282,3 +282,20 @@ def test_fused_rx_other_oversampling(gpu_api, orc, pkg, sps):
     st = _compare_fused(got, ref, wl, label=f"sps{sps}")
     print("fused parity:", st)
     assert (got["crc"] == 0).mean() > 0.9
+
+
+def test_empty_batches_are_no_ops(gpu_api):
+    """n = 0 everywhere: nothing is launched, nothing is touched, the call succeeds."""
+    z64 = np.zeros(0, np.uint64)
+    x = np.zeros(2048, np.complex64)
+    r = gpu_api.rx_bcch_ccch_batch(x, z64, np.zeros(0, np.uint8), sps=4)
+    assert r["l2"].shape == (0, 24) and r["crc"].size == 0
+    d = gpu_api.demod_batch("bcch", x, z64, 1016, sps=4)
+    assert d["rv"].size == 0
+    toa, rv = gpu_api.fcch_rough_batch(x, z64, 2048, sps=4)
+    assert toa.size == 0 and rv.size == 0
+    assert gpu_api.dkab_demod_batch(x, z64, 474, 0, sps=4)[0].size == 0
+    assert gpu_api.a5_batch(1, np.zeros(8, np.uint8), np.zeros(0, np.uint32), 208).shape == (0, 208)
+    rec, status, chains, found = gpu_api.rx_run(x, [], [], sps=4)
+    assert found == 0 and len(rec) == 0
+    assert gpu_api.channelize(np.zeros(6400, np.complex64), 2.0e6, []).shape[0] == 0
