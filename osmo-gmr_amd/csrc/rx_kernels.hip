@@ -6,9 +6,13 @@
 //                            by the BCCH/CCCH layer-1 chain for the four bursts at once:
 //                            descramble + de-interleave folded into the branch-metric
 //                            gather, 16-state K=5 rate-1/2 Viterbi with one burst per
-//                            16-lane DPP row, traceback, CRC16, LSB-first packing
+//                            16-lane DPP row, survivor walk, CRC16, LSB-first packing
 //                            (reference src/l1/bcch.c:83-103, src/l1/ccch.c:87-107 and
 //                            libosmocore's generic osmo_conv_decode).
+//   k_rx4                  : the default fused BCCH / CCCH kernel: the same arithmetic with the
+//                            serial phases (timing bisection, sync-symbol terms) done once for
+//                            the four bursts of a wave, one burst per 16-lane row.
+//   k_detect, k_mod_order  : gmr1_pi4cxpsk_detect / _mod_order (pi4cxpsk.c:617-729).
 //   k_l1                   : the layer-1 chain alone on soft bits read from HBM.
 //
 // Design notes (DESIGN.md has the long form):
@@ -22,11 +26,11 @@
 //     sincos per burst.  Only the 234 decimated symbols are derotated.
 //   * The sinc interpolation of the early/late timing loop needs one sine per
 //     point: sin(pi (k - f)) = -(-1)^k sin(pi f) for integer tap offsets k.
-//   * Viterbi state s lives in lane rotr^k(s) of its row at trellis step k, so the
-//     add-compare-select butterfly is in place: the partner metric is one DPP
-//     lane-xor away and no metric ever moves.  Lane (k mod 64) keeps the 64-bit
-//     decision ballot of step k (4 bursts x 16 states); the traceback walks
-//     LOCATIONS, not states, so it needs no rotation either.
+//   * The Viterbi butterfly is in place: the two predecessors of a state sit in two lanes
+//     of the row that differ by an xor mask (8, 7, 2, 1 over the four phases: one DPP control
+//     each), so the partner metric arrives folded into the add and no metric ever moves.  A
+//     state's 32-bit word is [metric:16 | decisions of the current 16-step window:16]; v_min_u32
+//     does compare, select, tie-break and decision recording at once (see decode4_k5_12).
 #include "gmr1_dev.h"
 
 namespace gmr1 {
@@ -300,7 +304,7 @@ struct Lds {
 	float2 *y;        // decimated symbols                 [max_len]         (aux)
 	int8_t *eb;       // soft bits: 4 rows (fused) or one buffer
 	uint32_t *bm;     // branch metrics 4 x 212            (overlays x)
-	uint64_t *surv;   // survivor ballots [212]            (overlays x, after bm)
+	uint64_t *surv;   // 13 x 64 halfwords of window decisions (overlays x, after bm)
 	uint32_t *ubits;  // decoded bits, 4 rows x 8 words    (overlays x, after surv)
 };
 
@@ -1237,20 +1241,24 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 // (timing bisection, sync-symbol arithmetic) done ONCE for the four bursts, one burst per
 // 16-lane row, instead of once per burst with most lanes idle:
 //
-//   pass 1, per burst : load + normalise -> LDS window, sync correlation -> corr[q][.]
-//   rows              : peak window argmax, early/late bisection (21 taps on 16 lanes),
-//                       interpolated peak power                       -> toa, rv per row
+//   pass 1, per burst : load -> statistics in registers, sync-chunk windows -> LDS (normalised),
+//                       sync correlation                              -> corr[q][.]
+//   rows              : peak window argmax, early/late bisection (21 taps, early point on lanes
+//                       0-7 and late point on lanes 8-15 of the row), interpolated peak power
+//                                                                     -> toa, rv per row
 //   rows              : sync symbols re-read from L2 / Infinity Cache, chunk sums,
 //                       fine frequency error, carrier phase           -> ffe, psi per row
-//   pass 2, per burst : 234 symbols re-read (stride sps), phase-domain soft symbols / bits
-//   rows              : branch metrics, Viterbi, traceback, CRC (decode4_k5_12)
+//   pass 2, per burst : 234 symbols re-read (stride sps), soft symbols from the phase in turns,
+//                       soft bits by Gray-boundary arithmetic
+//   rows              : branch metrics (table words, batched fetches), Viterbi, survivor walk,
+//                       CRC (decode4_k5_12)
 //
 // The second read of a burst happens a few microseconds after the first and is served by the
 // L2 / Infinity Cache; it buys back ~650 VALU instructions per burst.
 // Single-sequence burst formats only (BCCH, DC6), which is all the fused path handles.
 // ---------------------------------------------------------------------------
 struct Lds4 {
-	float2 *x;        // normalised window of the burst being correlated   [max_in_len]
+	float2 *x;        // normalised sync-chunk windows of the burst being correlated [stage_samples]
 	float *corr;      // 4 x cw correlation magnitudes
 	float2 *coef;     // 32 rotated sync reference values
 	int8_t *eb;       // 4 soft-bit rows
