@@ -108,7 +108,7 @@ def gather_records(records: np.ndarray, dst: int = 0, device=None):
 
 
 def rx_capture_sharded(api, slices, n_arfcn: int, n_samples: int, sps: int = 4, src: int = 0, device=None,
-                       max_records: int = 1 << 16):
+                       max_records: int = 1 << 16, arfcn_ids=None):
     """BASELINE.md config 4 end to end on the ranks of one node: rank `src` holds the channelised
     capture (`slices[a]`, complex64 tensors of n_samples), every rank receives the ARFCNs it owns,
     runs the receive loop on them (gmr1_hip_rx_run_dev, reference src/gmr1_rx.c:605-895) and the
@@ -122,8 +122,32 @@ def rx_capture_sharded(api, slices, n_arfcn: int, n_samples: int, sps: int = 4, 
         offset = np.arange(len(ids), dtype=np.uint64) * np.uint64(n_samples)
         length = np.full(len(ids), n_samples, np.uint64)
         stream = torch.cuda.current_stream(iq.device).cuda_stream
+        names = np.asarray(ids if arfcn_ids is None else [arfcn_ids[a] for a in ids], np.uint16)
         rec, status, chains, found = api.rx_run_dev(stream, iq.data_ptr(), offset, length, sps=sps,
-                                                    arfcn=np.asarray(ids, np.uint16), max_records=max_records)
+                                                    arfcn=names, max_records=max_records)
     else:
         rec = np.zeros(0, RECORD_DTYPE)
     return gather_records(rec, dst=src, device=device)
+
+
+def rx_wideband_sharded(api, wide, n_in: int, samp_rate: float, channels, sps: int = 4, src: int = 0,
+                        device=None, max_records: int = 1 << 16):
+    """BASELINE.json configs[3] from the wideband container: rank `src` holds the capture (`wide`, a
+    device tensor of n_in complex64 samples viewed as float32 pairs; other ranks pass None), channelizes
+    the requested raster positions (gmr1_hip_channelize_dev, reference utils/gmr1_rx_sdr.py:391-602), the
+    per-ARFCN streams go to their owners point to point, every rank runs the receive loop on its share
+    and the decoded frames come back to `src` (records carry the raster position as arfcn)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank()
+    channels = [int(c) for c in channels]
+    _, _, n_out = api.channelize_plan(samp_rate, sps, n_in)
+    slices = None
+    if rank == src:
+        out = torch.empty((len(channels), n_out, 2), dtype=torch.float32, device=wide.device)
+        stream = torch.cuda.current_stream(wide.device).cuda_stream
+        api.channelize_dev(stream, wide.data_ptr(), n_in, samp_rate, channels, out.data_ptr(), n_out, sps=sps)
+        slices = [torch.view_as_complex(out[i]) for i in range(len(channels))]
+    return rx_capture_sharded(api, slices, len(channels), n_out, sps=sps, src=src, device=device,
+                              max_records=max_records, arfcn_ids=channels)

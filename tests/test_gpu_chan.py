@@ -95,3 +95,24 @@ def test_wideband_capture_decodes_end_to_end(gpu_api, pkg):
         assert nbc >= n_b - 3 and mp == nbc, (ch, nbc, n_b, mp)
         assert nc >= 0.8 * n_c and mc >= nc - 1, (ch, nc, n_c, mc)
     assert len(rec[rec["arfcn"] == 30]) == 0
+
+
+def test_wideband_sharded_single_rank(gpu_api, pkg):
+    """configs[3] on a world of one: channelize -> scatter (local) -> receive loop -> gather."""
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    shard = import_module(pkg.__name__ + ".shard")
+    carriers = ((5, dict(stn=2, delay=1, cfo_hz=50.0)), (58, dict(stn=12, delay=4, cfo_hz=-60.0)))
+    wide, sents = workloads.wideband_capture(pkg, 21, seconds=2.0, carriers=carriers)
+    w = torch.from_numpy(wide.view(np.float32)).cuda()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29543", rank=0, world_size=1)
+    try:
+        rec = shard.rx_wideband_sharded(gpu_api, w, wide.size, FS, [5, 58, 20])
+    finally:
+        dist.destroy_process_group()
+    assert set(np.unique(rec["arfcn"])) == {5, 58}
+    for ch, _ in carriers:
+        mine = rec[rec["arfcn"] == ch]
+        mb, nbc, mc, nc, mp = workloads.match_records(mine, sents[ch])
+        assert nbc >= 3 and mp == nbc and mc >= nc - 1
