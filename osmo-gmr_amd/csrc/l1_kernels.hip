@@ -315,41 +315,86 @@ __device__ __forceinline__ int tch3_c(const int8_t *__restrict__ e, const uint8_
 	return flip ? (int)(int8_t)(-v) : v;
 }
 
-template <int PH, bool EDGE>
-__device__ __forceinline__ unsigned long long acs_k7(uint32_t &ae, uint32_t bmw, uint32_t sh_own, uint32_t sh_par,
-                                                     unsigned long long own_is_hi)
+// Per lane (= row location of a state) constants of the in-place 64-state butterfly.  The two
+// predecessors of a state sit in lanes that differ by the xor mask of the phase: 32, 16, 8, 7, 2, 1
+// (bpermute for the first two, one DPP control each for the rest).  With loc = c0*32 ^ c1*16 ^ c2*8 ^
+// c3*7 ^ c4*2 ^ c5*1, the predecessor state a lane holds in phase ph has bit i = c[(5 - i + ph) % 6];
+// after 6 steps the layout is back where it started.
+//   a[loc]  : bits 0-11 cost byte of the own transition per phase (2 bits each), 12-23 of the
+//             partner's, 24-29 "this lane holds the HIGH predecessor" per phase
+//   st[loc] : state held in phase 0;  loc_of[state] : its inverse
+struct K7Tab { uint32_t a[64]; uint8_t st[64]; uint8_t loc_of[64]; };
+static constexpr uint32_t k7_out(uint32_t s, uint32_t b)
 {
-	const uint32_t par = wave_xor<(32 >> PH)>(ae);
-	const uint32_t n_own = ae + ((bmw >> sh_own) & 0xffu);
-	const uint32_t n_par = par + ((bmw >> sh_par) & 0xffu);
-	const unsigned long long own_lt = __ballot(n_own < n_par);
-	const unsigned long long par_lt = __ballot(n_par < n_own);
-	uint32_t nw = n_own < n_par ? n_own : n_par;
-	if (EDGE)
-		nw = nw < kMaxAe ? nw : kMaxAe;
-	ae = nw;
-	return (own_lt & own_is_hi) | (par_lt & ~own_is_hi);
+	const uint32_t reg = (s << 1) | b;
+	uint32_t p0 = reg & 0x6du, p1 = reg & 0x4fu;
+	p0 ^= p0 >> 4; p0 ^= p0 >> 2; p0 ^= p0 >> 1;
+	p1 ^= p1 >> 4; p1 ^= p1 >> 2; p1 ^= p1 >> 1;
+	return ((p0 & 1u) << 1) | (p1 & 1u);
+}
+static constexpr K7Tab make_k7()
+{
+	K7Tab t{};
+	for (uint32_t loc = 0; loc < 64; loc++) {
+		uint32_t c[6] = {0, 0, 0, 0, 0, 0};
+		c[0] = (loc >> 5) & 1u;
+		c[1] = (loc >> 4) & 1u;
+		c[2] = (loc >> 3) & 1u;
+		uint32_t x = loc & 7u;
+		c[3] = (x >> 2) & 1u;
+		x ^= c[3] ? 7u : 0u;
+		c[4] = (x >> 1) & 1u;
+		c[5] = x & 1u;
+		uint32_t e = 0;
+		for (int ph = 0; ph < 6; ph++) {
+			uint32_t sp = 0;
+			for (int i = 0; i < 6; i++)
+				sp |= c[(5 - i + ph) % 6] << i;
+			const uint32_t b = sp >> 5;
+			e |= k7_out(sp, b) << (2 * ph);
+			e |= k7_out(sp ^ 32u, b) << (12 + 2 * ph);
+			e |= b << (24 + ph);
+			if (ph == 0) {
+				t.st[loc] = (uint8_t)sp;
+				t.loc_of[sp] = (uint8_t)loc;
+			}
+		}
+		t.a[loc] = e;
+	}
+	return t;
+}
+__constant__ K7Tab c_k7 = make_k7();
+
+// partner's word in phase PH
+template <int PH>
+__device__ __forceinline__ uint32_t k7_partner(uint32_t w)
+{
+	if constexpr (PH == 0) return (uint32_t)__shfl_xor((int)w, 32);
+	else if constexpr (PH == 1) return (uint32_t)__shfl_xor((int)w, 16);
+	else if constexpr (PH == 2) return dpp<0x128>(w);       // row_ror:8
+	else if constexpr (PH == 3) return dpp<0x141>(w);       // row_half_mirror: xor 7
+	else if constexpr (PH == 4) return dpp<0x4E>(w);        // quad_perm [2,3,0,1]
+	else return dpp<0xB1>(w);                               // quad_perm [1,0,3,2]
 }
 
-#define ACS_K7_6(EDGE, REC)                                                                       \
-	do {                                                                                          \
-		unsigned long long q[6];                                                                  \
-		q[0] = acs_k7<0, EDGE>(ae, s_bm[k + 0], sh_own[0], sh_par[0], hi[0]);                     \
-		q[1] = acs_k7<1, EDGE>(ae, s_bm[k + 1], sh_own[1], sh_par[1], hi[1]);                     \
-		q[2] = acs_k7<2, EDGE>(ae, s_bm[k + 2], sh_own[2], sh_par[2], hi[2]);                     \
-		q[3] = acs_k7<3, EDGE>(ae, s_bm[k + 3], sh_own[3], sh_par[3], hi[3]);                     \
-		q[4] = acs_k7<4, EDGE>(ae, s_bm[k + 4], sh_own[4], sh_par[4], hi[4]);                     \
-		q[5] = acs_k7<5, EDGE>(ae, s_bm[k + 5], sh_own[5], sh_par[5], hi[5]);                     \
-		if (REC && lane == 0) {                                                                   \
-			_Pragma("unroll") for (int u = 0; u < 6; u++) s_surv[k + u] = q[u];                   \
-		}                                                                                         \
-	} while (0)
+// One trellis step on the packed word [metric:16 | decisions of the current 12-step window:16]
+// (see decode4_k5_12 in rx_kernels.hip): candidates = word + (cost << 16); the HIGH-predecessor
+// lane carries the tie-break / decision bit of the position, so v_min_u32 selects, breaks ties
+// towards the low predecessor and records the decision at once.
+template <int PH>
+__device__ __forceinline__ uint32_t k7_step(uint32_t w, const uint8_t *__restrict__ cost, uint32_t o_own, uint32_t o_par)
+{
+	const uint32_t p = k7_partner<PH>(w);
+	const uint32_t t1 = ((uint32_t)cost[o_own] << 16) + w;
+	const uint32_t t2 = ((uint32_t)cost[o_par] << 16) + p;
+	return t1 < t2 ? t1 : t2;
+}
 
 __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 {
 	__shared__ __align__(16) int8_t s_e[216];
 	__shared__ __align__(16) uint32_t s_bm[kT3Steps];
-	__shared__ __align__(16) uint64_t s_surv[kT3Steps];
+	__shared__ uint16_t s_win[4][64];
 	const int lane = threadIdx.x;
 	const int g = blockIdx.x >> 1, fr = blockIdx.x & 1;
 	const int m = a.m;
@@ -381,43 +426,67 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	}
 	WSYNC();
 
-	// ---- in-place 64-state trellis: state s sits in lane rotr6^k(s) at step k
-	const uint32_t loc = (uint32_t)lane;
-	uint32_t sh_own[6], sh_par[6];
-	unsigned long long hi[6];
+	// ---- in-place 64-state trellis on packed words
+	const uint32_t tab = c_k7.a[lane];
+	uint32_t o_own[6], o_par[6];
+	uint32_t T[12];            // tie-break / decision bit of window position j, set in HIGH-predecessor lanes
 #pragma unroll
 	for (int ph = 0; ph < 6; ph++) {
-		const uint32_t s = rotl_n(loc, ph, 6);
-		const uint32_t b = s >> 5;
-		hi[ph] = __ballot(b != 0);
-		sh_own[ph] = 8u * out_k7_12(s, b);
-		sh_par[ph] = 8u * out_k7_12(s ^ 32u, b);
+		o_own[ph] = (tab >> (2 * ph)) & 3u;
+		o_par[ph] = (tab >> (12 + 2 * ph)) & 3u;
 	}
-	uint32_t ae = loc ? kMaxAe : 0u;          // D4: first pass starts in state 0
-	// pass 1 (warm-up), decisions not kept
-	{
-		int k = 0;
-		ACS_K7_6(true, false);
-		for (k = 6; k < kT3Steps; k += 6)
-			ACS_K7_6(false, false);
+#pragma unroll
+	for (int j = 0; j < 12; j++)
+		T[j] = ((tab >> (24 + (j % 6))) & 1u) << j;
+	const uint8_t *cost = reinterpret_cast<const uint8_t *>(s_bm);
+	constexpr uint32_t kSent = 0xF0000000u;       // unreachable (libosmocore: MAX_AE)
+
+	// pass 1 (warm-up from state 0, D4): only the metrics matter
+	uint32_t w = c_k7.st[lane] ? kSent : 0u;
+#pragma unroll
+	for (int k = 0; k < kT3Steps; k += 6) {
+		w = k7_step<0>(w, cost + 4 * (k + 0), o_own[0], o_par[0]);
+		w = k7_step<1>(w, cost + 4 * (k + 1), o_own[1], o_par[1]);
+		w = k7_step<2>(w, cost + 4 * (k + 2), o_own[2], o_par[2]);
+		w = k7_step<3>(w, cost + 4 * (k + 3), o_own[3], o_par[3]);
+		w = k7_step<4>(w, cost + 4 * (k + 4), o_own[4], o_par[4]);
+		w = k7_step<5>(w, cost + 4 * (k + 5), o_own[5], o_par[5]);
 	}
 	// rewind: subtract the minimum (osmo_conv_decode_rewind)
 	{
-		uint32_t mn = ae;
+		uint32_t mn = w >> 16;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
 			const uint32_t ov = (uint32_t)__shfl_xor((int)mn, o);
 			mn = ov < mn ? ov : mn;
 		}
-		ae -= mn;
+		w = (((w >> 16) - mn) << 16) | T[0];
 	}
-	// pass 2
-	for (int k = 0; k < kT3Steps; k += 6)
-		ACS_K7_6(false, true);
+	// pass 2: four windows of 12 steps; window m's decisions at a location are u[12m-6 .. 12m+5] of the
+	// path ending there, and the first six name the state at the start of the window
+#pragma unroll
+	for (int wm = 0; wm < 4; wm++) {
+		const int k = 12 * wm;
+		w = k7_step<0>(w, cost + 4 * (k + 0), o_own[0], o_par[0]) + T[1];
+		w = k7_step<1>(w, cost + 4 * (k + 1), o_own[1], o_par[1]) + T[2];
+		w = k7_step<2>(w, cost + 4 * (k + 2), o_own[2], o_par[2]) + T[3];
+		w = k7_step<3>(w, cost + 4 * (k + 3), o_own[3], o_par[3]) + T[4];
+		w = k7_step<4>(w, cost + 4 * (k + 4), o_own[4], o_par[4]) + T[5];
+		w = k7_step<5>(w, cost + 4 * (k + 5), o_own[5], o_par[5]) + T[6];
+		w = k7_step<0>(w, cost + 4 * (k + 6), o_own[0], o_par[0]) + T[7];
+		w = k7_step<1>(w, cost + 4 * (k + 7), o_own[1], o_par[1]) + T[8];
+		w = k7_step<2>(w, cost + 4 * (k + 8), o_own[2], o_par[2]) + T[9];
+		w = k7_step<3>(w, cost + 4 * (k + 9), o_own[3], o_par[3]) + T[10];
+		w = k7_step<4>(w, cost + 4 * (k + 10), o_own[4], o_par[4]) + T[11];
+		w = k7_step<5>(w, cost + 4 * (k + 11), o_own[5], o_par[5]);
+		s_win[wm][lane] = (uint16_t)w;
+		w = (w & 0xffff0000u) | T[0];
+	}
 	WSYNC();
 
-	// best end state: smallest metric, lowest state on ties (48 = 8 * 6 steps: layout = identity)
-	unsigned long long key = ((unsigned long long)ae << 32) | loc;
+	// best end state: smallest metric, lowest state on ties (48 = 8 * 6 steps: every state is back in its
+	// phase-0 location)
+	unsigned long long key = ((unsigned long long)(w >> 16) << 32) | c_k7.st[lane];
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
 		const unsigned long long ok = __shfl_xor(key, o);
@@ -426,24 +495,26 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	const uint32_t end_state = (uint32_t)key & 63u;
 	const uint32_t min_ae = (uint32_t)(key >> 32);
 
-	// ---- traceback (lane 0): u[k-6] = decision of step k for k = 47..6; u[47-j] = bit j of the end state
+	// ---- survivor chain (uniform across the wave): four dependent 16-bit reads.
+	// u[42..47] are the end state's bits (bit j = u[47 - j]); window m gives u[12m-6 .. 12m+5] LSB first
 	__shared__ uint32_t s_d[3];       // 80 decoded bits, bit k of the frame at word k>>5, bit k&31
-	if (lane == 0) {
-		uint32_t L = end_state;
-		uint32_t lo = 0, hi32 = 0;    // bits 0..31, 32..47
-		for (int j = 0; j < 6; j++) {
-			const uint32_t bit = (end_state >> j) & 1u;
-			hi32 |= bit << (47 - j - 32);
+	{
+		uint32_t L = c_k7.loc_of[end_state];
+		const uint32_t h3 = s_win[3][L];
+		L = c_k7.loc_of[__brev(h3 & 63u) >> 26];
+		const uint32_t h2 = s_win[2][L];
+		L = c_k7.loc_of[__brev(h2 & 63u) >> 26];
+		const uint32_t h1 = s_win[1][L];
+		L = c_k7.loc_of[__brev(h1 & 63u) >> 26];
+		const uint32_t h0 = s_win[0][L];
+		// u[0..5] = h0 >> 6, u[6..17] = h1, u[18..29] = h2, u[30..41] = h3, u[42..47] = rev6(end_state)
+		const unsigned long long u = (unsigned long long)((h0 >> 6) & 63u) | ((unsigned long long)(h1 & 0xfffu) << 6) |
+		                             ((unsigned long long)(h2 & 0xfffu) << 18) | ((unsigned long long)(h3 & 0xfffu) << 30) |
+		                             ((unsigned long long)(__brev(end_state) >> 26) << 42);
+		if (lane == 0) {
+			s_d[0] = (uint32_t)u;
+			s_d[1] = (uint32_t)(u >> 32);
 		}
-		for (int k = kT3Steps - 1; k >= 6; k--) {
-			const int pb = 5 - (k % 6);
-			const uint32_t d = (uint32_t)((s_surv[k] >> L) & 1ull);
-			L = (L & ~(1u << pb)) | (d << pb);
-			const int j = k - 6;
-			if (j < 32) lo |= d << j; else hi32 |= d << (j - 32);
-		}
-		s_d[0] = lo;
-		s_d[1] = hi32;
 	}
 	WSYNC();
 
