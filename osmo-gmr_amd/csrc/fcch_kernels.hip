@@ -155,7 +155,6 @@ __global__ __launch_bounds__(256) void k_fcch_stats(FcchRoughArgs a)
 static constexpr int kLagsPerThread = 8;
 static constexpr int kTileLags = 256 * kLagsPerThread;          // 2048
 static constexpr int kTileStep = kTileLags - 4;                 // windows of 5 overlap the next tile by 4
-static constexpr int kMaxTaps = 480;
 
 // padded LDS index: one spare slot per 8 samples makes the 8-sample lane stride conflict-free
 __host__ __device__ __forceinline__ constexpr int pad8(int i) { return i + (i >> 3); }
@@ -510,7 +509,6 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 	__shared__ float s_bv[4];
 	__shared__ int s_bi[4];
 	__shared__ int s_scal[4];
-	__shared__ float s_th;
 	__shared__ unsigned int s_flags[256];                   // Lw <= 8192 threshold flags
 
 	const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -4,8 +4,9 @@
 //              (reference src/l1/facch3.c:121-170): status demux, [decipher], descramble,
 //              intra-burst de-interleave (N=12), 4-way burst demux, K=5 rate-1/4 Viterbi
 //              (92 bits + flush), CRC16, LSB-first packing.  Four frames per wavefront, one per
-//              16-lane DPP row, the same in-place butterfly as the BCCH decoder; branch
-//              metrics are two v_dot4_u32_u8 per candidate.
+//              16-lane DPP row, the same packed [metric | window decisions] words and in-place
+//              butterfly as the BCCH decoder; the cost of a coded 4-bit word is the sum of two
+//              byte-table entries (coded bits 0-1, 2-3).
 //   k_tch3   : TCH3 speech, 212 soft bits -> 2 x 10 bytes + 4 status bits
 //              (reference src/l1/tch3.c:124-183): status demux, [decipher], descramble,
 //              frame demux (m), 104-permutation, K=7 tail-biting rate-1/2 Viterbi with
@@ -22,8 +23,6 @@ namespace gmr1 {
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");    \
 		__builtin_amdgcn_wave_barrier();                          \
 	} while (0)
-
-static constexpr uint32_t kMaxAe = 0x00ffffffu;
 
 // scrambler bits (reference src/l1/scramb.c:39-52), bit i of the sequence in word i>>5
 struct ScrBits { uint32_t w[8]; };
@@ -70,19 +69,6 @@ __device__ __forceinline__ uint32_t row_xor(uint32_t v)
 	else if constexpr (X == 2) return dpp<0x4E>(v);
 	else return dpp<0xB1>(v);
 }
-template <int X>
-__device__ __forceinline__ uint32_t wave_xor(uint32_t v)
-{
-	if constexpr (X >= 16) return (uint32_t)__shfl_xor((int)v, X);
-	else return row_xor<X>(v);
-}
-
-__device__ __forceinline__ uint32_t rotl_n(uint32_t x, int r, int bits)
-{
-	const uint32_t m = (1u << bits) - 1u;
-	return ((x << r) | (x >> (bits - r))) & m;
-}
-
 __device__ __forceinline__ int sbit_cost(int v, int bit)
 {
 	// ((in - (+-127))^2 >> 9), erasures cost nothing (libosmocore conv.c, generic decoder)
@@ -95,60 +81,77 @@ __device__ __forceinline__ int sbit_cost(int v, int bit)
 // ---------------------------------------------------------------------------
 static constexpr int kF3Steps = 96;       // 92 bits + 4 flush
 
-// K=5 rate-1/4 (g0 = 1+D^3+D^4, g1 = 1+D+D^2+D^4, g2 = 1+D^2+D^4, g3 = 1+D+D^2+D^3+D^4; conv.c:174-198)
-__device__ __forceinline__ uint32_t out_k5_14(uint32_t s, uint32_t b)
+// K=5 rate-1/4: g0 = 1+D^3+D^4, g1 = 1+D+D^2+D^4, g2 = 1+D^2+D^4, g3 = 1+D+D^2+D^3+D^4 (conv.c:174-198).
+// Per row location constants of the in-place 16-state butterfly with the masks 8, 7, 2, 1 (one DPP
+// control each; see decode4_k5_12 in rx_kernels.hip for the construction):
+//   ov[loc] : 4-bit coded word of the own transition per phase (bits 0-15) and of the partner's (16-31)
+//   hi[loc] : bit j set when the lane holds the HIGH predecessor in phase j & 3 (16-step pattern)
+struct K5r4Tab { uint32_t ov[16]; uint32_t hi[16]; };
+static constexpr uint32_t k5r4_out(uint32_t s, uint32_t b)
 {
 	const uint32_t reg = (s << 1) | b;
-	return ((uint32_t)(__popc(reg & 0x19u) & 1) << 3) | ((uint32_t)(__popc(reg & 0x17u) & 1) << 2) |
-	       ((uint32_t)(__popc(reg & 0x15u) & 1) << 1) | (uint32_t)(__popc(reg & 0x1fu) & 1);
-}
-// byte j of the mask = 1 when coded bit j (MSB of ov first) is a 1
-__device__ __forceinline__ uint32_t ones_mask4(uint32_t ov)
-{
-	return ((ov >> 3) & 1u) | (((ov >> 2) & 1u) << 8) | (((ov >> 1) & 1u) << 16) | ((ov & 1u) << 24);
-}
-
-template <int PH, bool EDGE>
-__device__ __forceinline__ unsigned long long acs14(uint32_t &ae, uint2 cst, uint32_t m1_own, uint32_t m1_par,
-                                                    unsigned long long own_is_hi, bool b_is_one, bool flush)
-{
-	const uint32_t par = row_xor<(8 >> PH)>(ae);
-	// branch metric = sum over the 4 coded bits of c0 (bit = 0) or c1 (bit = 1): two dot4 each
-	uint32_t n_own = __builtin_amdgcn_udot4(cst.x, 0x01010101u ^ m1_own, ae, false);
-	n_own = __builtin_amdgcn_udot4(cst.y, m1_own, n_own, false);
-	uint32_t n_par = __builtin_amdgcn_udot4(cst.x, 0x01010101u ^ m1_par, par, false);
-	n_par = __builtin_amdgcn_udot4(cst.y, m1_par, n_par, false);
-	const unsigned long long own_lt = __ballot(n_own < n_par);
-	const unsigned long long par_lt = __ballot(n_par < n_own);
-	uint32_t nw = n_own < n_par ? n_own : n_par;
-	if (EDGE) {
-		nw = nw < kMaxAe ? nw : kMaxAe;
-		if (flush && b_is_one)
-			nw = kMaxAe;
+	const uint32_t g[4] = {0x19u, 0x17u, 0x15u, 0x1fu};
+	uint32_t o = 0;
+	for (int i = 0; i < 4; i++) {
+		uint32_t p = reg & g[i];
+		p ^= p >> 4; p ^= p >> 2; p ^= p >> 1;
+		o = (o << 1) | (p & 1u);
 	}
-	ae = nw;
-	return (own_lt & own_is_hi) | (par_lt & ~own_is_hi);
+	return o;
+}
+static constexpr K5r4Tab make_k5r4()
+{
+	K5r4Tab t{};
+	for (uint32_t loc = 0; loc < 16; loc++) {
+		uint32_t c[4] = {0, 0, 0, 0};
+		c[0] = (loc >> 3) & 1u;
+		uint32_t x = loc & 7u;
+		c[1] = (x >> 2) & 1u;
+		x ^= c[1] ? 7u : 0u;
+		c[2] = (x >> 1) & 1u;
+		c[3] = x & 1u;
+		for (int ph = 0; ph < 4; ph++) {
+			uint32_t sp = 0;
+			for (int i = 0; i < 4; i++)
+				sp |= c[(3 - i + ph) & 3] << i;
+			const uint32_t b = sp >> 3;
+			t.ov[loc] |= k5r4_out(sp, b) << (4 * ph);
+			t.ov[loc] |= k5r4_out(sp ^ 8u, b) << (16 + 4 * ph);
+			for (int j = ph; j < 16; j += 4)
+				t.hi[loc] |= b << j;
+		}
+	}
+	return t;
+}
+__constant__ K5r4Tab c_k5r4 = make_k5r4();
+
+template <int PH>
+__device__ __forceinline__ uint32_t k5_partner(uint32_t w)
+{
+	if constexpr (PH == 0) return dpp<0x128>(w);            // row_ror:8
+	else if constexpr (PH == 1) return dpp<0x141>(w);       // row_half_mirror: xor 7
+	else if constexpr (PH == 2) return dpp<0x4E>(w);        // quad_perm [2,3,0,1]
+	else return dpp<0xB1>(w);                               // quad_perm [1,0,3,2]
 }
 
-#define ACS14_4(EDGE, FL)                                                                         \
-	do {                                                                                          \
-		const uint2 c0 = cstr[k + 0], c1 = cstr[k + 1], c2 = cstr[k + 2], c3 = cstr[k + 3];       \
-		const unsigned long long q0 = acs14<0, EDGE>(ae, c0, m_own[0], m_par[0], hi[0], b1[0], FL); \
-		const unsigned long long q1 = acs14<1, EDGE>(ae, c1, m_own[1], m_par[1], hi[1], b1[1], FL); \
-		const unsigned long long q2 = acs14<2, EDGE>(ae, c2, m_own[2], m_par[2], hi[2], b1[2], FL); \
-		const unsigned long long q3 = acs14<3, EDGE>(ae, c3, m_own[3], m_par[3], hi[3], b1[3], FL); \
-		if (lane == 0) {                                                                          \
-			uint4 *sp = reinterpret_cast<uint4 *>(surv + k);                                      \
-			sp[0] = make_uint4((uint32_t)q0, (uint32_t)(q0 >> 32), (uint32_t)q1, (uint32_t)(q1 >> 32)); \
-			sp[1] = make_uint4((uint32_t)q2, (uint32_t)(q2 >> 32), (uint32_t)q3, (uint32_t)(q3 >> 32)); \
-		}                                                                                         \
-	} while (0)
+// one rate-1/4 trellis step on the packed word [metric:16 | window decisions:16]; the cost of a coded
+// 4-bit word is A[word >> 2] + B[word & 3] (two byte tables per step: coded bits 0-1 and 2-3)
+template <int PH>
+__device__ __forceinline__ uint32_t k5r4_step(uint32_t w, const uint8_t *__restrict__ ab, uint32_t ov_own, uint32_t ov_par)
+{
+	const uint32_t p = k5_partner<PH>(w);
+	const uint32_t c_own = (uint32_t)ab[ov_own >> 2] + (uint32_t)ab[4 + (ov_own & 3u)];
+	const uint32_t c_par = (uint32_t)ab[ov_par >> 2] + (uint32_t)ab[4 + (ov_par & 3u)];
+	const uint32_t t1 = (c_own << 16) + w;
+	const uint32_t t2 = (c_par << 16) + p;
+	return t1 < t2 ? t1 : t2;
+}
 
 __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 {
 	__shared__ __align__(16) int8_t s_eb[4][416];
-	__shared__ __align__(16) uint2 s_cst[4][kF3Steps];      // per step: 4 x c0 bytes, 4 x c1 bytes
-	__shared__ __align__(16) uint64_t s_surv[kF3Steps];
+	__shared__ __align__(16) uint2 s_cst[4][kF3Steps];      // per step: A[4] (coded bits 0-1), B[4] (coded bits 2-3)
+	__shared__ uint16_t s_win[6][64];                       // window decisions per row location
 	__shared__ __align__(16) uint32_t s_ub[4][4];
 	const int lane = threadIdx.x;
 	const int row = lane >> 4;
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 	// xmy = e[0..21] | e[30..103]   (facch3.c:144-158, interleave.c:73-87)
 	for (int it = lane; it < 4 * kF3Steps; it += 64) {
 		const int q = it / kF3Steps, k = it % kF3Steps;
-		uint32_t c0w = 0, c1w = 0;
+		uint32_t c0[4], c1[4];
 #pragma unroll
 		for (int j = 0; j < 4; j++) {
 			const int i = 4 * k + j;              // index into bits_c
@@ -197,63 +200,93 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 				flip ^= a.ciph[(size_t)(f0 + q) * 384 + 96 * burst + p] != 0;
 			if (flip)
 				v = (int8_t)(-v);
-			c0w |= (uint32_t)sbit_cost(v, 0) << (8 * j);
-			c1w |= (uint32_t)sbit_cost(v, 1) << (8 * j);
+			c0[j] = (uint32_t)sbit_cost(v, 0);
+			c1[j] = (uint32_t)sbit_cost(v, 1);
 		}
-		s_cst[q][k] = make_uint2(c0w, c1w);
+		// byte x of A = cost of coded bits (0, 1) = (x >> 1, x & 1); B likewise for coded bits (2, 3)
+		const uint32_t aw = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
+		const uint32_t bw = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
+		s_cst[q][k] = make_uint2(aw, bw);
 	}
 	WSYNC();
 
-	// ---- forward pass (same in-place layout as decode4_k5_12 in rx_kernels.hip)
-	uint32_t m_own[4], m_par[4];
-	bool b1[4];
-	unsigned long long hi[4];
+	// ---- forward pass on packed words (see decode4_k5_12 in rx_kernels.hip): 4 steps whose decisions
+	// are u[-4..-1], five windows of 16 steps (u[16m .. 16m+15]) and a last one of 12 (u[80..91], the
+	// final four being the flush: only b = 0 transitions survive)
+	const uint32_t ovt = c_k5r4.ov[loc], hit = c_k5r4.hi[loc];
+	uint32_t ov_own[4], ov_par[4];
+	bool hi[4];
 #pragma unroll
 	for (int ph = 0; ph < 4; ph++) {
-		const uint32_t s = rotl_n(loc, ph, 4);
-		const uint32_t b = s >> 3;
-		b1[ph] = b != 0;
-		hi[ph] = __ballot(b1[ph]);
-		m_own[ph] = ones_mask4(out_k5_14(s, b));
-		m_par[ph] = ones_mask4(out_k5_14(s ^ 8u, b));
+		ov_own[ph] = (ovt >> (4 * ph)) & 15u;
+		ov_par[ph] = (ovt >> (16 + 4 * ph)) & 15u;
+		hi[ph] = ((hit >> ph) & 1u) != 0;
 	}
-	uint32_t ae = loc ? kMaxAe : 0u;
-	const uint2 *cstr = &s_cst[row][0];
-	uint64_t *surv = s_surv;
+	uint32_t T[16];
+#pragma unroll
+	for (int j = 0; j < 16; j++)
+		T[j] = hit & (1u << j);
+	constexpr uint32_t kSent = 0xF0000000u;
+	const uint8_t *cb = reinterpret_cast<const uint8_t *>(&s_cst[row][0]);
+	uint32_t w = (loc ? kSent : 0u) | T[0];
+	w = k5r4_step<0>(w, cb + 8 * 0, ov_own[0], ov_par[0]) + T[1];
+	w = k5r4_step<1>(w, cb + 8 * 1, ov_own[1], ov_par[1]) + T[2];
+	w = k5r4_step<2>(w, cb + 8 * 2, ov_own[2], ov_par[2]) + T[3];
+	w = k5r4_step<3>(w, cb + 8 * 3, ov_own[3], ov_par[3]);
+	w = (w & 0xffff0000u) | T[0];
+#pragma unroll 1
+	for (int wm = 0; wm < 5; wm++) {
+		const uint8_t *c = cb + 8 * (4 + 16 * wm);
+#pragma unroll
+		for (int j = 0; j < 16; j += 4) {
+			w = k5r4_step<0>(w, c + 8 * (j + 0), ov_own[0], ov_par[0]) + T[(j + 1) & 15];
+			w = k5r4_step<1>(w, c + 8 * (j + 1), ov_own[1], ov_par[1]) + T[(j + 2) & 15];
+			w = k5r4_step<2>(w, c + 8 * (j + 2), ov_own[2], ov_par[2]) + T[(j + 3) & 15];
+			w = k5r4_step<3>(w, c + 8 * (j + 3), ov_own[3], ov_par[3]) + (j + 4 < 16 ? T[(j + 4) & 15] : 0u);
+		}
+		s_win[wm][lane] = (uint16_t)w;
+		w = (w & 0xffff0000u) | T[0];
+	}
 	{
-		int k = 0;
-		ACS14_4(true, false);
-		for (k = 4; k < 92; k += 4)
-			ACS14_4(false, false);
-		ACS14_4(true, true);      // k = 92: flush
+		const uint8_t *c = cb + 8 * 84;
+#pragma unroll
+		for (int j = 0; j < 8; j += 4) {
+			w = k5r4_step<0>(w, c + 8 * (j + 0), ov_own[0], ov_par[0]) + T[j + 1];
+			w = k5r4_step<1>(w, c + 8 * (j + 1), ov_own[1], ov_par[1]) + T[j + 2];
+			w = k5r4_step<2>(w, c + 8 * (j + 2), ov_own[2], ov_par[2]) + T[j + 3];
+			w = k5r4_step<3>(w, c + 8 * (j + 3), ov_own[3], ov_par[3]) + T[j + 4];
+		}
+		w = k5r4_step<0>(w, c + 8 * 8, ov_own[0], ov_par[0]);
+		w = hi[0] ? kSent : (w + T[9]);
+		w = k5r4_step<1>(w, c + 8 * 9, ov_own[1], ov_par[1]);
+		w = hi[1] ? kSent : (w + T[10]);
+		w = k5r4_step<2>(w, c + 8 * 10, ov_own[2], ov_par[2]);
+		w = hi[2] ? kSent : (w + T[11]);
+		w = k5r4_step<3>(w, c + 8 * 11, ov_own[3], ov_par[3]);
+		w = hi[3] ? kSent : w;
+		s_win[5][lane] = (uint16_t)w;
 	}
-	const uint32_t final_ae = ae;
+	const uint32_t final_ae = w >> 16;        // state 0 ends in location 0 of the row
 	WSYNC();
 
-	// ---- traceback in location space; u[k-4] = decision of step k (see rx_kernels.hip)
+	// ---- survivor chain, one lane per row: six dependent 16-bit reads
 	if (loc == 0) {
-		const uint16_t *s16 = reinterpret_cast<const uint16_t *>(s_surv) + row;
-		uint32_t L = 0, ub = 0;
-#define TB_STEP(W, PB)                                           \
-		do {                                                     \
-			const uint32_t x = ((uint32_t)(W) << (PB)) >> L;     \
-			L = (L & ~(1u << (PB))) | (x & (1u << (PB)));        \
-			ub = (ub << 1) | ((x >> (PB)) & 1u);                 \
-		} while (0)
-		for (int g = 23; g >= 1; g--) {
-			const int k = 4 * g;
-			const uint32_t w0 = s16[4 * (k + 0)], w1 = s16[4 * (k + 1)];
-			const uint32_t w2 = s16[4 * (k + 2)], w3 = s16[4 * (k + 3)];
-			TB_STEP(w3, 0);
-			TB_STEP(w2, 1);
-			TB_STEP(w1, 2);
-			TB_STEP(w0, 3);
-			if (((g - 1) & 7) == 0) {
-				s_ub[row][(g - 1) >> 3] = ub;
-				ub = 0;
-			}
+		// location of the state whose reversed nibble is x (basis 8, 7, 2, 1)
+		constexpr unsigned long long kLocOf =
+			0x0ull | (0x8ull << 4) | (0x7ull << 8) | (0xFull << 12) | (0x2ull << 16) | (0xAull << 20) |
+			(0x5ull << 24) | (0xDull << 28) | (0x1ull << 32) | (0x9ull << 36) | (0x6ull << 40) |
+			(0xEull << 44) | (0x3ull << 48) | (0xBull << 52) | (0x4ull << 56) | (0xCull << 60);
+		const uint16_t *d16 = &s_win[0][row * 16];
+		uint32_t L = 0, prev = 0;
+#pragma unroll
+		for (int wm = 5; wm >= 0; wm--) {
+			const uint32_t h = d16[wm * 64 + L];
+			L = (uint32_t)(kLocOf >> (4 * (h & 15u))) & 15u;
+			if (wm & 1)
+				prev = wm == 5 ? (h & 0xfffu) : h;
+			else
+				s_ub[row][wm >> 1] = h | (prev << 16);
 		}
-#undef TB_STEP
 	}
 	WSYNC();
 
@@ -294,13 +327,6 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 // ---------------------------------------------------------------------------
 static constexpr int kT3Steps = 48;
 
-// K=7 rate-1/2 (g0 = 1+D^2+D^3+D^5+D^6, g1 = 1+D+D^2+D^3+D^6; conv.c:518-571)
-__device__ __forceinline__ uint32_t out_k7_12(uint32_t s, uint32_t b)
-{
-	const uint32_t reg = (s << 1) | b;
-	return ((uint32_t)(__popc(reg & 0x6du) & 1) << 1) | (uint32_t)(__popc(reg & 0x4fu) & 1);
-}
-
 // soft bit c[kc] of frame `fr` (tch3.c:141-172): returns the descrambled / deciphered value
 __device__ __forceinline__ int tch3_c(const int8_t *__restrict__ e, const uint8_t *__restrict__ ciph,
                                       int fr, int m, int kc)
@@ -315,6 +341,7 @@ __device__ __forceinline__ int tch3_c(const int8_t *__restrict__ e, const uint8_
 	return flip ? (int)(int8_t)(-v) : v;
 }
 
+// K=7 rate-1/2: g0 = 1+D^2+D^3+D^5+D^6, g1 = 1+D+D^2+D^3+D^6 (conv.c:518-571).
 // Per lane (= row location of a state) constants of the in-place 64-state butterfly.  The two
 // predecessors of a state sit in lanes that differ by the xor mask of the phase: 32, 16, 8, 7, 2, 1
 // (bpermute for the first two, one DPP control each for the rest).  With loc = c0*32 ^ c1*16 ^ c2*8 ^

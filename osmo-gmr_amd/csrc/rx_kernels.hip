@@ -42,7 +42,6 @@ namespace gmr1 {
 	} while (0)
 
 static constexpr float kPif = 3.14159265358979323846f;
-static constexpr uint32_t kMaxAe = 0x00ffffffu;   // libosmocore MAX_AE
 static constexpr int kSteps12 = 212;              // 208 data + 4 flush steps (BCCH/CCCH)
 static constexpr int kEbRow = 448;                // LDS bytes per soft-bit row (>= 432, /16)
 static constexpr int kEbitsLds = 704;             // single-burst soft-bit buffer (>= 662)
