@@ -99,6 +99,24 @@ int  orc_dkab_demod(const orc_cf *in, int in_len, int sps, float freq_shift, int
 void orc_a5(int n, const uint8_t *key, uint32_t fn, int nbits, orc_ubit_t *dl, orc_ubit_t *ul);
 void orc_a5_1(const uint8_t *key, uint32_t fn, int nbits, orc_ubit_t *dl, orc_ubit_t *ul);
 
+/* ---- NT9 codecs: FACCH9 (reference include/osmocom/gmr1/l1/facch9.h:36-41), TCH9 (l1/tch9.h:40-53),
+ *      inter-burst interleaver (l1/interleave.h:40-56) */
+enum orc_tch9_mode { ORC_TCH9_2k4 = 0, ORC_TCH9_4k8, ORC_TCH9_9k6 };   /* l1/tch9.h:40-45 */
+#define ORC_IL_MAXK 648
+struct orc_interleaver { int N, K, n; uint8_t bits_cpp[3 * ORC_IL_MAXK]; };
+void orc_interleaver_init(struct orc_interleaver *il, int N, int K);
+void orc_interleave_inter(struct orc_interleaver *il, void *bits_epp, const void *bits_ep);
+void orc_deinterleave_inter(struct orc_interleaver *il, void *bits_ep, const void *bits_epp);
+void orc_facch9_encode(orc_ubit_t *bits_e, const uint8_t *l2, const orc_ubit_t *bits_sacch,
+                       const orc_ubit_t *bits_status, const orc_ubit_t *ciph);
+int  orc_facch9_decode(uint8_t *l2, orc_sbit_t *bits_sacch, orc_sbit_t *bits_status,
+                       const orc_sbit_t *bits_e, const orc_ubit_t *ciph, int *conv_rv);
+void orc_tch9_encode(orc_ubit_t *bits_e, const uint8_t *l2, int mode, const orc_ubit_t *bits_sacch,
+                     const orc_ubit_t *bits_status, const orc_ubit_t *ciph, struct orc_interleaver *il);
+void orc_tch9_decode(uint8_t *l2, orc_sbit_t *bits_sacch, orc_sbit_t *bits_status, const orc_sbit_t *bits_e,
+                     int mode, const orc_ubit_t *ciph, struct orc_interleaver *il, int *conv_rv);
+int  orc_tch9_punct(int mode, int *idx);
+
 /* ---- batch drivers used by tests and by bench.py's cpu_baseline leg only */
 
 /* kind: 0 = BCCH (orc_burst BCCH + bcch_decode), 1 = CCCH (DC6 + ccch_decode) */

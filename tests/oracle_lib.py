@@ -356,3 +356,83 @@ def rx_run_tch(iq, tch, sps=4, arfcn=0, kc=None, max_records=1 << 16):
     rv = f(_p(iq, C.c_float), p_tch, C.c_int(iq.size), C.c_int(sps), C.c_int(arfcn), p_kc,
            out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n), C.byref(nch))
     return rv, out[:min(n.value, max_records)].copy(), nch.value
+
+
+class Interleaver(C.Structure):
+    """struct orc_interleaver"""
+    _fields_ = [("N", C.c_int), ("K", C.c_int), ("n", C.c_int), ("bits_cpp", C.c_uint8 * (3 * 648))]
+
+
+def facch9_encode(l2, sacch, status, ciph=None):
+    l2 = np.ascontiguousarray(l2, np.uint8)
+    e = np.zeros(662, np.uint8)
+    sacch = np.ascontiguousarray(sacch, np.uint8)
+    status = np.ascontiguousarray(status, np.uint8)
+    cp = None if ciph is None else np.ascontiguousarray(ciph, np.uint8).ctypes.data_as(C.c_void_p)
+    lib().orc_facch9_encode(e.ctypes.data_as(C.c_void_p), l2.ctypes.data_as(C.c_void_p),
+                            sacch.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p), cp)
+    return e
+
+
+def facch9_decode(ebits, ciph=None):
+    """-> (l2[38], sacch[10] sbits, status[4] sbits, crc, conv)"""
+    ebits = np.ascontiguousarray(ebits, np.int8)
+    l2 = np.zeros(38, np.uint8)
+    sacch = np.zeros(10, np.int8)
+    status = np.zeros(4, np.int8)
+    conv = C.c_int(0)
+    cp = None if ciph is None else np.ascontiguousarray(ciph, np.uint8).ctypes.data_as(C.c_void_p)
+    f = lib().orc_facch9_decode
+    f.restype = C.c_int
+    crc = f(l2.ctypes.data_as(C.c_void_p), sacch.ctypes.data_as(C.c_void_p), status.ctypes.data_as(C.c_void_p),
+            ebits.ctypes.data_as(C.c_void_p), cp, C.byref(conv))
+    return l2, sacch, status, crc, conv.value
+
+
+TCH9_BYTES = (18, 30, 60)      # 2k4, 4k8, 9k6 (tch9.c:92-94)
+
+
+def tch9_encode_seq(l2s, mode, sacch=None, status=None, ciph=None):
+    """Encode a sequence of TCH9 blocks of one channel (inter-burst interleaver carried along) -> (n, 662)"""
+    l2s = np.ascontiguousarray(l2s, np.uint8)
+    n = l2s.shape[0]
+    il = Interleaver()
+    lib().orc_interleaver_init(C.byref(il), C.c_int(3), C.c_int(648))
+    out = np.zeros((n, 662), np.uint8)
+    z10, z4 = np.zeros(10, np.uint8), np.zeros(4, np.uint8)
+    for i in range(n):
+        sa = z10 if sacch is None else np.ascontiguousarray(sacch[i], np.uint8)
+        stt = z4 if status is None else np.ascontiguousarray(status[i], np.uint8)
+        cp = None if ciph is None else np.ascontiguousarray(ciph[i], np.uint8).ctypes.data_as(C.c_void_p)
+        lib().orc_tch9_encode(out[i].ctypes.data_as(C.c_void_p), l2s[i].ctypes.data_as(C.c_void_p), C.c_int(mode),
+                              sa.ctypes.data_as(C.c_void_p), stt.ctypes.data_as(C.c_void_p), cp, C.byref(il))
+    return out
+
+
+def tch9_decode_seq(ebits, mode, ciph=None):
+    """Decode a sequence of TCH9 bursts of one channel -> (l2 (n, bytes), sacch (n, 10), status (n, 4), conv (n,))"""
+    ebits = np.ascontiguousarray(ebits, np.int8)
+    n = ebits.shape[0]
+    nb = TCH9_BYTES[mode]
+    il = Interleaver()
+    lib().orc_interleaver_init(C.byref(il), C.c_int(3), C.c_int(648))
+    l2 = np.zeros((n, nb), np.uint8)
+    sacch = np.zeros((n, 10), np.int8)
+    status = np.zeros((n, 4), np.int8)
+    conv = np.zeros(n, np.int32)
+    for i in range(n):
+        cv = C.c_int(0)
+        cp = None if ciph is None else np.ascontiguousarray(ciph[i], np.uint8).ctypes.data_as(C.c_void_p)
+        lib().orc_tch9_decode(l2[i].ctypes.data_as(C.c_void_p), sacch[i].ctypes.data_as(C.c_void_p),
+                              status[i].ctypes.data_as(C.c_void_p), ebits[i].ctypes.data_as(C.c_void_p),
+                              C.c_int(mode), cp, C.byref(il), C.byref(cv))
+        conv[i] = cv.value
+    return l2, sacch, status, conv
+
+
+def tch9_punct(mode):
+    idx = (C.c_int * 1024)()
+    f = lib().orc_tch9_punct
+    f.restype = C.c_int
+    n = f(C.c_int(mode), idx)
+    return np.array(idx[:n], np.int64)
