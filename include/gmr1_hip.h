@@ -157,6 +157,23 @@ int gmr1_hip_a5_batch_dev(void *stream, int n, int alg, int nbits,
                           const uint8_t *keys, const uint32_t *fn, uint8_t *dl, uint8_t *ul);
 int gmr1_hip_a5_batch(int n, int alg, int nbits, const uint8_t *keys, const uint32_t *fn, uint8_t *dl, uint8_t *ul);
 
+/* ---- NT9 bursts (662 soft bits): FACCH9 and TCH9 ---------------------------------
+ * FACCH9 (gmr1_facch9_decode, include/osmocom/gmr1/l1/facch9.h:39-41): n bursts -> l2 n x 38, sacch n x 10 and
+ * status n x 4 soft bits (optional), crc (0 = pass), conv.  ciph: optional n x 658 keystream bits.
+ * TCH9 (gmr1_tch9_decode, include/osmocom/gmr1/l1/tch9.h:40-53): mode 0 2k4 / 1 4k8 / 2 9k6
+ * (enum gmr1_tch9_mode) -> l2 of 18 / 30 / 60 bytes per burst.  The bursts are n_chan sequences of seq_len
+ * consecutive bursts each (channel after channel): the depth-3 inter-burst de-interleaver
+ * (gmr1_deinterleave_inter, l1/interleave.h:52-56) runs along every sequence from an all-zero state, so
+ * burst i of a sequence yields the block sent two bursts earlier.  No CRC (the reference has none). */
+int gmr1_hip_facch9_decode_batch_dev(void *stream, int n, const int8_t *ebits, const uint8_t *ciph,
+                                     uint8_t *l2, int8_t *sacch, int8_t *status, int32_t *crc, int32_t *conv);
+int gmr1_hip_facch9_decode_batch(int n, const int8_t *ebits, const uint8_t *ciph,
+                                 uint8_t *l2, int8_t *sacch, int8_t *status, int32_t *crc, int32_t *conv);
+int gmr1_hip_tch9_decode_batch_dev(void *stream, int n_chan, int seq_len, int mode, const int8_t *ebits,
+                                   const uint8_t *ciph, uint8_t *l2, int8_t *sacch, int8_t *status, int32_t *conv);
+int gmr1_hip_tch9_decode_batch(int n_chan, int seq_len, int mode, const int8_t *ebits, const uint8_t *ciph,
+                               uint8_t *l2, int8_t *sacch, int8_t *status, int32_t *conv);
+
 /* ---- FCCH acquisition ------------------------------------------------------
  * fcch_type: 0 gmr1_fcch_burst, 1 gmr1_fcch3_lband_burst, 2 gmr1_fcch3_sband_burst.
  * rough: n search windows of `len` samples each -> toa[i] (samples), rv[i] (0 / -errno).

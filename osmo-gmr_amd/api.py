@@ -38,6 +38,8 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
     "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch",
     "gmr1_hip_channelize_plan", "gmr1_hip_channelize_dev", "gmr1_hip_channelize",
+    "gmr1_hip_facch9_decode_batch_dev", "gmr1_hip_facch9_decode_batch", "gmr1_facch9_decode",
+    "gmr1_hip_tch9_decode_batch_dev", "gmr1_hip_tch9_decode_batch",
     "gmr1_hip_dkab_demod_batch_dev", "gmr1_hip_dkab_demod_batch", "gmr1_dkab_demod",
     "gmr1_hip_a5_batch_dev", "gmr1_hip_a5_batch", "gmr1_a5", "gmr1_a5_1",
 ]
@@ -708,3 +710,68 @@ def channelize_dev(stream, wide_ptr, n_in, samp_rate, channels, out_ptr, out_str
            C.byref(no))
     _check(rc, "gmr1_hip_channelize_dev")
     return no.value
+
+
+# ---------------------------------------------------------------------------
+# NT9 bursts: FACCH9, TCH9
+# ---------------------------------------------------------------------------
+TCH9_BYTES = (18, 30, 60)
+
+
+def facch9_decode_batch(ebits, ciph=None):
+    """(n, 662) soft bits -> (l2 (n, 38), sacch (n, 10), status (n, 4), crc (n,), conv (n,))"""
+    eb, p_eb = _np(ebits, np.int8)
+    n = eb.shape[0]
+    p_c = None
+    if ciph is not None:
+        c, p_c = _np(ciph, np.uint8)
+    l2 = np.zeros((n, 38), np.uint8)
+    sa = np.zeros((n, 10), np.int8)
+    stt = np.zeros((n, 4), np.int8)
+    crc = np.zeros(n, np.int32)
+    conv = np.zeros(n, np.int32)
+    f = load().gmr1_hip_facch9_decode_batch
+    f.restype = C.c_int
+    rc = f(C.c_int(n), p_eb, p_c, l2.ctypes.data_as(C.c_void_p), sa.ctypes.data_as(C.c_void_p),
+           stt.ctypes.data_as(C.c_void_p), crc.ctypes.data_as(C.c_void_p), conv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_facch9_decode_batch")
+    return l2, sa, stt, crc, conv
+
+
+def facch9_decode(ebits, ciph=None):
+    """gmr1_facch9_decode, the reference's own call -> (l2, sacch, status, crc, conv)"""
+    eb, p_eb = _np(ebits, np.int8)
+    p_c = None
+    if ciph is not None:
+        c, p_c = _np(ciph, np.uint8)
+    l2 = np.zeros(38, np.uint8)
+    sa = np.zeros(10, np.int8)
+    stt = np.zeros(4, np.int8)
+    conv = C.c_int(0)
+    f = load().gmr1_facch9_decode
+    f.restype = C.c_int
+    crc = f(l2.ctypes.data_as(C.c_void_p), sa.ctypes.data_as(C.c_void_p), stt.ctypes.data_as(C.c_void_p), p_eb, p_c,
+            C.byref(conv))
+    if crc < 0:
+        _check(crc, "gmr1_facch9_decode")
+    return l2, sa, stt, crc, conv.value
+
+
+def tch9_decode_batch(ebits, mode, seq_len, ciph=None):
+    """(n_chan * seq_len, 662) soft bits, channel after channel -> (l2 (n, bytes), sacch, status, conv)"""
+    eb, p_eb = _np(ebits, np.int8)
+    n = eb.shape[0]
+    assert n % seq_len == 0
+    p_c = None
+    if ciph is not None:
+        c, p_c = _np(ciph, np.uint8)
+    l2 = np.zeros((n, TCH9_BYTES[mode]), np.uint8)
+    sa = np.zeros((n, 10), np.int8)
+    stt = np.zeros((n, 4), np.int8)
+    conv = np.zeros(n, np.int32)
+    f = load().gmr1_hip_tch9_decode_batch
+    f.restype = C.c_int
+    rc = f(C.c_int(n // seq_len), C.c_int(seq_len), C.c_int(mode), p_eb, p_c, l2.ctypes.data_as(C.c_void_p),
+           sa.ctypes.data_as(C.c_void_p), stt.ctypes.data_as(C.c_void_p), conv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_tch9_decode_batch")
+    return l2, sa, stt, conv

@@ -212,6 +212,25 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream);
 
 hipError_t launch_dkab(const DkabArgs &a, hipStream_t stream);
 hipError_t launch_a5(const A5Args &a, hipStream_t stream);
+// NT9 bursts: FACCH9 and the three TCH9 modes share one decoder kernel (nt9_kernels.hip)
+struct Nt9Args {
+	int n;                     // bursts
+	int seq_len;               // TCH9: consecutive bursts per channel (inter-burst de-interleaver), FACCH9: 1
+	int kind;                  // 0 2k4, 1 4k8, 2 9k6 (enum gmr1_tch9_mode), 3 FACCH9
+	int N;                     // coded bits per input bit (5, 3, 2, 2)
+	int len;                   // data bits (144, 240, 480, 316)
+	const uint32_t *map;       // (len + 4) x N descriptors of the coded bits (see nt9_kernels.hip)
+	const int8_t *ebits;       // n x 662
+	const uint8_t *ciph;       // optional n x 658
+	uint8_t *l2;               // n x l2_bytes
+	int l2_bytes;              // 18, 30, 60, 38
+	int8_t *sacch;             // optional n x 10 soft bits
+	int8_t *status;            // optional n x 4 soft bits
+	int32_t *crc;              // FACCH9 only
+	int32_t *conv;             // optional
+};
+hipError_t launch_nt9(const Nt9Args &a, hipStream_t stream);
+
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
 hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);
 

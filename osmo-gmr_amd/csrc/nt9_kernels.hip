@@ -1,0 +1,381 @@
+// nt9_kernels.hip -- layer-1 decoders of the NT9 burst (662 soft bits): FACCH9 (reference
+// src/l1/facch9.c:106-144) and TCH9 in its three modes (reference src/l1/tch9.c:139-175), gfx950.
+//
+// All four are K=5 codes (16 states): FACCH9 rate 1/2 over 316 bits + CRC16; TCH9 9k6 rate 1/2 over 480
+// bits, 4k8 rate 1/3 over 240, 2k4 rate 1/5 over 144, each punctured down to 648 coded bits
+// (gmr1_puncturer_generate, punct.c:48-133).  One kernel, four bursts per wavefront, one per 16-lane DPP
+// row, with the packed [metric:16 | window decisions:16] word and the in-place butterfly (masks 8, 7, 2, 1)
+// of decode4_k5_12 (rx_kernels.hip).  What differs between the four is data:
+//
+//   * a per-kind MAP (built on the host, capi_nt9.cpp) that says, for every coded bit of every trellis
+//     step, whether it was punctured and otherwise where its soft bit sits in the burst: status / SACCH
+//     demux, [decipher], descramble, TCH9's depth-3 inter-burst de-interleaver (a coded bit may come from
+//     this burst or one of the two before it in the channel's sequence) and the intra-burst de-interleaver
+//     are all folded into that gather;
+//   * the number of byte tables a candidate's cost is the sum of (coded bits 0-1, 2-3, 4).
+//
+// The metric of 320 ... 484 steps does not fit 16 bits, so every 64 steps the row minimum is subtracted
+// (and added back into conv_rv at the end); comparisons never see the difference.
+#include "gmr1_dev.h"
+
+namespace gmr1 {
+
+#define WSYNC()                                                   \
+	do {                                                          \
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");    \
+		__builtin_amdgcn_wave_barrier();                          \
+	} while (0)
+
+// map entry: bit 31 punctured; bits 0-9 index into the burst's 662 e-bits; bit 10 scrambler flips it;
+// bits 11-20 index into bits_my (cipher stream position); bits 21-22 how many bursts back it was sent
+static constexpr uint32_t kMapPunct = 0x80000000u;
+
+// scrambler bits over 648 positions (reference src/l1/scramb.c:39-52) are folded into the map on the host
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppu(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int PH>
+__device__ __forceinline__ uint32_t partner(uint32_t w)
+{
+	if constexpr (PH == 0) return dppu<0x128>(w);            // row_ror:8
+	else if constexpr (PH == 1) return dppu<0x141>(w);       // row_half_mirror: xor 7
+	else if constexpr (PH == 2) return dppu<0x4E>(w);        // quad_perm [2,3,0,1]
+	else return dppu<0xB1>(w);                               // quad_perm [1,0,3,2]
+}
+template <int X>
+__device__ __forceinline__ uint32_t row_xor_min(uint32_t v)
+{
+	uint32_t o;
+	if constexpr (X == 8) o = dppu<0x128>(v);
+	else if constexpr (X == 4) o = dppu<0x1B>(dppu<0x141>(v));
+	else if constexpr (X == 2) o = dppu<0x4E>(v);
+	else o = dppu<0xB1>(v);
+	return o < v ? o : v;
+}
+
+// CRC16 syndromes of a 300-bit message followed by its 16 CRC bits, 20 bits per lane of a row
+struct Syn316 { uint16_t s[16][20]; };
+static constexpr Syn316 make_syn316()
+{
+	Syn316 t{};
+	for (int k = 0; k < 316; k++) {
+		uint32_t v = 0;
+		if (k < 300) {
+			uint32_t crc = 0x8000u;
+			for (int i = k; i < 300; i++)
+				crc = (crc & 0x8000u) ? (((crc << 1) ^ 0x1021u) & 0xffffu) : ((crc << 1) & 0xffffu);
+			v = crc;
+		} else {
+			v = 1u << (15 - (k - 300));
+		}
+		t.s[k / 20][k % 20] = (uint16_t)v;
+	}
+	return t;
+}
+__constant__ Syn316 c_syn316 = make_syn316();
+
+// per row location: coded word (<= 5 bits) of the own / partner transition per phase, HIGH-predecessor pattern
+struct K5Loc { uint32_t state[4]; uint32_t hi; };
+static constexpr K5Loc k5_loc(uint32_t loc)
+{
+	K5Loc r{};
+	uint32_t c[4] = {0, 0, 0, 0};
+	c[0] = (loc >> 3) & 1u;
+	uint32_t x = loc & 7u;
+	c[1] = (x >> 2) & 1u;
+	x ^= c[1] ? 7u : 0u;
+	c[2] = (x >> 1) & 1u;
+	c[3] = x & 1u;
+	for (int ph = 0; ph < 4; ph++) {
+		uint32_t sp = 0;
+		for (int i = 0; i < 4; i++)
+			sp |= c[(3 - i + ph) & 3] << i;
+		r.state[ph] = sp;
+		for (int j = ph; j < 16; j += 4)
+			r.hi |= (sp >> 3) << j;
+	}
+	return r;
+}
+struct K5Locs { uint32_t st[16]; uint32_t hi[16]; };       // st: 4 states x 4 bits packed
+static constexpr K5Locs make_k5locs()
+{
+	K5Locs t{};
+	for (uint32_t loc = 0; loc < 16; loc++) {
+		const K5Loc r = k5_loc(loc);
+		t.st[loc] = r.state[0] | (r.state[1] << 4) | (r.state[2] << 8) | (r.state[3] << 12);
+		t.hi[loc] = r.hi;
+	}
+	return t;
+}
+__constant__ K5Locs c_k5locs = make_k5locs();
+
+// generator polynomials (bit i = D^i; reference src/l1/conv.c:123-128, 148-154, 201-209), MSB of the word = g0
+__device__ __forceinline__ uint32_t coded_word(int N, uint32_t s, uint32_t b)
+{
+	const uint32_t reg = (s << 1) | b;
+	uint32_t o = 0;
+	if (N == 2) {
+		o = ((uint32_t)(__popc(reg & 0x19u) & 1) << 1) | (uint32_t)(__popc(reg & 0x17u) & 1);
+	} else {
+		const uint32_t g[5] = {0x15u, 0x1bu, 0x1fu, 0x1du, 0x17u};
+		for (int i = 0; i < N; i++)
+			o = (o << 1) | (uint32_t)(__popc(reg & g[i]) & 1);
+	}
+	return o;
+}
+
+__device__ __forceinline__ int sbit_cost(int v, int bit)
+{
+	const int e = bit ? v + 127 : v - 127;
+	return v ? (__mul24(e, e) >> 9) : 0;      // erasures (and punctured bits) cost nothing
+}
+
+static constexpr int kNt9MaxSteps = 484;
+static constexpr int kNt9MaxWin = 31;
+constexpr uint32_t kSent = 0xF0000000u;
+
+template <int PH, int NW>
+__device__ __forceinline__ uint32_t nt9_step(uint32_t w, const uint8_t *__restrict__ ct, const uint32_t (&o_own)[3],
+                                             const uint32_t (&o_par)[3])
+{
+	const uint32_t p = partner<PH>(w);
+	uint32_t c_own = ct[o_own[0]], c_par = ct[o_par[0]];
+	if (NW > 1) { c_own += ct[4 + o_own[1]]; c_par += ct[4 + o_par[1]]; }
+	if (NW > 2) { c_own += ct[8 + o_own[2]]; c_par += ct[8 + o_par[2]]; }
+	const uint32_t t1 = (c_own << 16) + w;
+	const uint32_t t2 = (c_par << 16) + p;
+	return t1 < t2 ? t1 : t2;
+}
+
+template <int NW>
+__global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const int lane = threadIdx.x;
+	const int row = lane >> 4;
+	const uint32_t loc = (uint32_t)lane & 15u;
+	const int S = a.len + 4;                         // trellis steps
+	const int N = a.N;
+	const int stride = 4 * NW;                       // bytes of cost tables per step
+	uint8_t *ct_all = lds_raw;                                                     // 4 x S x stride
+	uint16_t *win = reinterpret_cast<uint16_t *>(lds_raw + (size_t)4 * kNt9MaxSteps * stride);   // kNt9MaxWin x 64
+	uint32_t *ub = reinterpret_cast<uint32_t *>(win + kNt9MaxWin * 64);            // 4 x 16 words
+	const int g0 = blockIdx.x * 4;
+
+	// ---- cost tables of the four bursts: word A = coded bits (0, 1), B = (2, 3), C = (4)
+	for (int it = lane; it < 4 * S; it += 64) {
+		const int q = it / S, k = it % S;
+		const int g = g0 + q;
+		uint32_t c0[5] = {0, 0, 0, 0, 0}, c1[5] = {0, 0, 0, 0, 0};
+		if (g < a.n) {
+			const int pos = g % a.seq_len;               // position of the burst in its channel's sequence
+			for (int j = 0; j < N; j++) {
+				const uint32_t m = a.map[k * N + j];
+				if (m & kMapPunct)
+					continue;
+				const int back = (int)((m >> 21) & 3u);
+				if (back > pos)
+					continue;                            // before the first burst of the channel: zeros
+				const size_t src = (size_t)(g - back);
+				int v = a.ebits[src * 662 + (m & 0x3ffu)];
+				bool flip = ((m >> 10) & 1u) != 0;
+				if (a.ciph)
+					flip ^= a.ciph[src * 658 + ((m >> 11) & 0x3ffu)] != 0;
+				if (flip)
+					v = (int8_t)(-v);
+				c0[j] = (uint32_t)sbit_cost(v, 0);
+				c1[j] = (uint32_t)sbit_cost(v, 1);
+			}
+		}
+		uint32_t *dst = reinterpret_cast<uint32_t *>(ct_all + ((size_t)q * S + k) * stride);
+		if (N == 2) {
+			dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
+		} else {
+			dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
+			if (N == 3) {
+				dst[1] = c0[2] | (c1[2] << 8);
+			} else {
+				dst[1] = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
+				dst[2] = c0[4] | (c1[4] << 8);
+			}
+		}
+	}
+	WSYNC();
+
+	// ---- per-lane constants: table offsets of the own / partner coded words per phase
+	const uint32_t stp = c_k5locs.st[loc], hit = c_k5locs.hi[loc];
+	uint32_t o_own[4][3], o_par[4][3];
+	bool hi[4];
+#pragma unroll
+	for (int ph = 0; ph < 4; ph++) {
+		const uint32_t sp = (stp >> (4 * ph)) & 15u;
+		const uint32_t b = sp >> 3;
+		hi[ph] = b != 0;
+		const uint32_t wo = coded_word(N, sp, b), wp = coded_word(N, sp ^ 8u, b);
+		if (N == 2) {
+			o_own[ph][0] = wo; o_par[ph][0] = wp;
+			o_own[ph][1] = o_own[ph][2] = o_par[ph][1] = o_par[ph][2] = 0;
+		} else if (N == 3) {
+			o_own[ph][0] = wo >> 1; o_own[ph][1] = wo & 1u; o_own[ph][2] = 0;
+			o_par[ph][0] = wp >> 1; o_par[ph][1] = wp & 1u; o_par[ph][2] = 0;
+		} else {
+			o_own[ph][0] = wo >> 3; o_own[ph][1] = (wo >> 1) & 3u; o_own[ph][2] = wo & 1u;
+			o_par[ph][0] = wp >> 3; o_par[ph][1] = (wp >> 1) & 3u; o_par[ph][2] = wp & 1u;
+		}
+	}
+	uint32_t T[16];
+#pragma unroll
+	for (int j = 0; j < 16; j++)
+		T[j] = hit & (1u << j);
+
+	// ---- forward pass: 4 steps (decisions u[-4..-1]), full windows of 16, a last window of `tail`
+	// steps (16 or 12) whose final four are the flush
+	const uint8_t *ct = ct_all + (size_t)row * S * stride;
+	const int n_win = (a.len + 15) / 16;             // windows after the first four steps
+	const int tail = a.len - 16 * (n_win - 1);       // 16 or 12
+	uint32_t off = 0;                                // what has been subtracted from the metrics so far
+	uint32_t w = (loc ? kSent : 0u) | T[0];
+	w = nt9_step<0, NW>(w, ct + 0 * stride, o_own[0], o_par[0]) + T[1];
+	w = nt9_step<1, NW>(w, ct + 1 * stride, o_own[1], o_par[1]) + T[2];
+	w = nt9_step<2, NW>(w, ct + 2 * stride, o_own[2], o_par[2]) + T[3];
+	w = nt9_step<3, NW>(w, ct + 3 * stride, o_own[3], o_par[3]);
+	w = (w & 0xffff0000u) | T[0];
+#pragma unroll 1
+	for (int wm = 0; wm < n_win - 1; wm++) {
+		const uint8_t *c = ct + (size_t)(4 + 16 * wm) * stride;
+#pragma unroll
+		for (int j = 0; j < 16; j += 4) {
+			w = nt9_step<0, NW>(w, c + (j + 0) * stride, o_own[0], o_par[0]) + T[(j + 1) & 15];
+			w = nt9_step<1, NW>(w, c + (j + 1) * stride, o_own[1], o_par[1]) + T[(j + 2) & 15];
+			w = nt9_step<2, NW>(w, c + (j + 2) * stride, o_own[2], o_par[2]) + T[(j + 3) & 15];
+			w = nt9_step<3, NW>(w, c + (j + 3) * stride, o_own[3], o_par[3]) + (j + 4 < 16 ? T[(j + 4) & 15] : 0u);
+		}
+		win[wm * 64 + lane] = (uint16_t)w;
+		w = (w & 0xffff0000u) | T[0];
+		if ((wm & 3) == 3) {
+			// keep the metrics inside 16 bits: subtract the row minimum
+			uint32_t mn = w >> 16;
+			mn = row_xor_min<1>(mn);
+			mn = row_xor_min<2>(mn);
+			mn = row_xor_min<4>(mn);
+			mn = row_xor_min<8>(mn);
+			w -= mn << 16;
+			off += mn;
+		}
+	}
+	{
+		const uint8_t *c = ct + (size_t)(4 + 16 * (n_win - 1)) * stride;
+		const int body = tail - 4;                   // steps of the last window before the flush (12 or 8)
+#pragma unroll
+		for (int j = 0; j < 8; j += 4) {
+			w = nt9_step<0, NW>(w, c + (j + 0) * stride, o_own[0], o_par[0]) + T[j + 1];
+			w = nt9_step<1, NW>(w, c + (j + 1) * stride, o_own[1], o_par[1]) + T[j + 2];
+			w = nt9_step<2, NW>(w, c + (j + 2) * stride, o_own[2], o_par[2]) + T[j + 3];
+			w = nt9_step<3, NW>(w, c + (j + 3) * stride, o_own[3], o_par[3]) + T[j + 4];
+		}
+		if (body == 12) {
+			w = nt9_step<0, NW>(w, c + 8 * stride, o_own[0], o_par[0]) + T[9];
+			w = nt9_step<1, NW>(w, c + 9 * stride, o_own[1], o_par[1]) + T[10];
+			w = nt9_step<2, NW>(w, c + 10 * stride, o_own[2], o_par[2]) + T[11];
+			w = nt9_step<3, NW>(w, c + 11 * stride, o_own[3], o_par[3]) + T[12];
+		}
+		// flush: only b = 0 transitions survive (lanes whose new state ends in 1 become unreachable)
+		const uint32_t t1 = body == 12 ? T[13] : T[9], t2 = body == 12 ? T[14] : T[10], t3 = body == 12 ? T[15] : T[11];
+		w = nt9_step<0, NW>(w, c + (body + 0) * stride, o_own[0], o_par[0]);
+		w = hi[0] ? kSent : (w + t1);
+		w = nt9_step<1, NW>(w, c + (body + 1) * stride, o_own[1], o_par[1]);
+		w = hi[1] ? kSent : (w + t2);
+		w = nt9_step<2, NW>(w, c + (body + 2) * stride, o_own[2], o_par[2]);
+		w = hi[2] ? kSent : (w + t3);
+		w = nt9_step<3, NW>(w, c + (body + 3) * stride, o_own[3], o_par[3]);
+		w = hi[3] ? kSent : w;
+		win[(n_win - 1) * 64 + lane] = (uint16_t)w;
+	}
+	const uint32_t final_ae = (w >> 16) + off;       // state 0 ends in location 0 of the row
+	WSYNC();
+
+	// ---- survivor chain, one lane per row: window m's decisions at the survivor's location are decoded
+	// bits u[16m ..]; their low nibble names the state at the window start (bit-reversed)
+	if (loc == 0) {
+		constexpr unsigned long long kLocOf =
+			0x0ull | (0x8ull << 4) | (0x7ull << 8) | (0xFull << 12) | (0x2ull << 16) | (0xAull << 20) |
+			(0x5ull << 24) | (0xDull << 28) | (0x1ull << 32) | (0x9ull << 36) | (0x6ull << 40) |
+			(0xEull << 44) | (0x3ull << 48) | (0xBull << 52) | (0x4ull << 56) | (0xCull << 60);
+		const uint16_t *d16 = win + row * 16;
+		uint32_t L = 0, prev = 0;
+		for (int wm = n_win - 1; wm >= 0; wm--) {
+			uint32_t h = d16[wm * 64 + L];
+			L = (uint32_t)(kLocOf >> (4 * (h & 15u))) & 15u;
+			if (wm == n_win - 1 && tail == 12)
+				h &= 0xfffu;
+			if (wm & 1) {
+				prev = h;
+			} else {
+				ub[row * 16 + (wm >> 1)] = h | (prev << 16);
+				prev = 0;
+			}
+		}
+	}
+	WSYNC();
+
+	// ---- outputs
+	const int g = g0 + row;
+	if (g >= a.n)
+		return;
+	const uint32_t *u = ub + row * 16;
+	// L2 bytes: decoded bits LSB first (osmo_ubit2pbit_ext lsb mode) = the words as they stand
+	for (int i = (int)loc; i < a.l2_bytes; i += 16) {
+		uint32_t byte = (u[i >> 2] >> (8 * (i & 3))) & 0xffu;
+		const int bits_left = a.len - (a.kind == 3 ? 16 : 0) - 8 * i;   // FACCH9: 300 message bits
+		if (bits_left < 8)
+			byte &= (1u << (bits_left > 0 ? bits_left : 0)) - 1u;
+		a.l2[(size_t)g * a.l2_bytes + i] = (uint8_t)byte;
+	}
+	// status = e[52..55]; SACCH = bits_my[52..61] = e[56..65] after deciphering (facch9.c:118-131, tch9.c:152-165)
+	if (a.status && loc < 4)
+		a.status[(size_t)g * 4 + loc] = a.ebits[(size_t)g * 662 + 52 + loc];
+	if (a.sacch && loc < 10) {
+		int v = a.ebits[(size_t)g * 662 + 56 + loc];
+		if (a.ciph && a.ciph[(size_t)g * 658 + 52 + loc])
+			v = (int8_t)(-v);
+		a.sacch[(size_t)g * 10 + loc] = (int8_t)v;
+	}
+	if (a.kind == 3 && a.crc) {
+		// CRC16 over 300 + 16 bits: 20 bits per lane, XOR-reduced over the row
+		uint32_t syn = 0;
+		for (int q = 0; q < 20; q++) {
+			const int k = (int)loc * 20 + q;
+			if (k < 316 && ((u[k >> 5] >> (k & 31)) & 1u))
+				syn ^= c_syn316.s[loc][q];
+		}
+		syn ^= dppu<0xB1>(syn);
+		syn ^= dppu<0x4E>(syn);
+		syn ^= dppu<0x1B>(dppu<0x141>(syn));
+		syn ^= dppu<0x128>(syn);
+		if (loc == 0)
+			a.crc[g] = syn ? 1 : 0;
+	}
+	if (a.conv && loc == 0)
+		a.conv[g] = (int32_t)final_ae;
+}
+
+hipError_t launch_nt9(const Nt9Args &a, hipStream_t stream)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	const int nw = a.N == 2 ? 1 : (a.N == 3 ? 2 : 3);
+	const size_t lds = (size_t)4 * kNt9MaxSteps * 4 * nw + (size_t)kNt9MaxWin * 64 * 2 + 4 * 16 * 4;
+	const dim3 grid((a.n + 3) / 4);
+	if (nw == 1)
+		hipLaunchKernelGGL(k_nt9<1>, grid, dim3(64), lds, stream, a);
+	else if (nw == 2)
+		hipLaunchKernelGGL(k_nt9<2>, grid, dim3(64), lds, stream, a);
+	else
+		hipLaunchKernelGGL(k_nt9<3>, grid, dim3(64), lds, stream, a);
+	return hipGetLastError();
+}
+
+}  // namespace gmr1
