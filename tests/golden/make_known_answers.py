@@ -8,8 +8,11 @@ Appendix D2), re-derived by this script from the formulas the reference states:
   scrambler      reference src/l1/scramb.c:39-52  (reg 0x4d4b, b = (r>>14 ^ r)&1, r = r<<1|b)
   deinterleave   reference src/l1/interleave.c:81-86  (kep = N*((5*kc)&7) + (kc>>3), N=53)
   conv_spot      reference src/l1/conv.c: generator polynomials from the comments at
-                 :123-128 (k5_12), :174-181 (k5_14), :518-523 (tch3) and rows of the
-                 next_output tables at :130-135, :183-188, :525-542 read off the file
+                 :123-128 (k5_12), :148-154 (k5_13), :174-181 (k5_14), :201-209 (k5_15), :518-523 (tch3)
+                 and rows of the next_output tables at :130-135, :155-160, :183-188, :210-215, :525-542
+                 read off the file
+  tch9_punct     reference src/l1/tch9.c:72-78 + src/l1/punct.c:48-175: the 320 punctured positions of
+                 the 9k6 mode
   fcch           reference src/sdr/fcch.c:600-613 constants
 """
 import json
@@ -35,11 +38,17 @@ out = {
                   "next_output_rows": {"0": [0, 3], "1": [1, 2], "4": [2, 1], "8": [3, 0], "15": [1, 2]}},
         "k5_14": {"K": 5, "polys": [0x19, 0x17, 0x15, 0x1F],
                   "next_output_rows": {"0": [0, 15], "1": [5, 10], "4": [9, 6], "8": [15, 0], "15": [4, 11]}},
+        "k5_13": {"K": 5, "polys": [0x15, 0x1B, 0x1F],
+                  "next_output_rows": {"0": [0, 7], "1": [3, 4], "2": [5, 2], "7": [5, 2], "8": [7, 0], "15": [2, 5]}},
+        "k5_15": {"K": 5, "polys": [0x15, 0x1B, 0x1F, 0x1D, 0x17],
+                  "next_output_rows": {"0": [0, 31], "1": [13, 18], "3": [26, 5], "4": [14, 17], "8": [31, 0],
+                                       "15": [11, 20]}},
         "tch3_k7": {"K": 7, "polys": [0x6D, 0x4F],
                     "next_output_rows": {"0": [0, 3], "1": [1, 2], "2": [3, 0], "16": [2, 1], "32": [3, 0],
                                          "63": [0, 3]}},
     },
     "fcch": {"bin_hz": 200.0, "chirp_rate_hz_per_ms": 2995.2, "bcch_period_symbols": 7488},
+    "tch9_9k6_punctured": sorted([1, 5] + [10 + 6 * k for k in range(158)] + [13 + 6 * k for k in range(158)] + [963, 967]),
 }
 # SURVEY.md Appendix D2 lists these; assert the derivation agrees with what the survey recorded
 assert out["scrambler"]["first64"] == "0001001100011011110001000010010100001111100011000001010111101111"

@@ -6,8 +6,11 @@ import pytest
 
 def test_tch9_puncturing_arrays(orc):
     # 9k6 -> {1, 5} u {10 + 6k, 13 + 6k : k < 158} u {963, 967}: 320 of 968 coded bits
+    import json
+    import os
     p96 = orc.tch9_punct(2)
-    want = sorted([1, 5] + [10 + 6 * k for k in range(158)] + [13 + 6 * k for k in range(158)] + [963, 967])
+    with open(os.path.join(os.path.dirname(__file__), "golden", "known_answers.json")) as f:
+        want = json.load(f)["tch9_9k6_punctured"]
     assert list(p96) == want and len(want) == 320
     # every mode leaves exactly the 648 bits of an NT9 burst
     for mode, (n_out, n_p) in enumerate(((148 * 5, None), (244 * 3, None), (484 * 2, 320))):
