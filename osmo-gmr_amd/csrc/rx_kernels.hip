@@ -403,11 +403,8 @@ __device__ __forceinline__ void load_normalise_stats(const float2 *__restrict__ 
 // NFULL >= 0: the caller knows in_len >> 6 at compile time (the fused sps = 4 path: 1016 and 976
 // samples both have 15 whole rows), which removes the per-row branches
 template <int NPL, int NFULL = -1>
-__device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in_len, int lane,
-                                           float &avr_o, float &avi_o, float &inv_o)
+__device__ __forceinline__ void window_fetch(const float2 *__restrict__ in, int in_len, int lane, float2 (&v)[NPL])
 {
-	float2 v[NPL];
-	float sr = 0.f, si = 0.f;
 	const int nfull = NFULL >= 0 ? NFULL : (in_len >> 6);
 	const bool tail = (lane + 64 * nfull) < in_len;
 #pragma unroll
@@ -418,6 +415,18 @@ __device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in
 			v[k] = in[lane + 64 * k];
 		else
 			v[k] = make_float2(0.f, 0.f);
+	}
+}
+
+template <int NPL, int NFULL = -1>
+__device__ __forceinline__ void window_stats(const float2 (&v)[NPL], int in_len, int lane,
+                                             float &avr_o, float &avi_o, float &inv_o)
+{
+	float sr = 0.f, si = 0.f;
+	const int nfull = NFULL >= 0 ? NFULL : (in_len >> 6);
+	const bool tail = (lane + 64 * nfull) < in_len;
+#pragma unroll
+	for (int k = 0; k < NPL; k++) {
 		sr += v[k].x;
 		si += v[k].y;
 	}
@@ -439,6 +448,15 @@ __device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in
 	avr_o = avr;
 	avi_o = avi;
 	inv_o = __builtin_amdgcn_rcpf(stddev);
+}
+
+template <int NPL, int NFULL = -1>
+__device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in_len, int lane,
+                                           float &avr_o, float &avi_o, float &inv_o)
+{
+	float2 v[NPL];
+	window_fetch<NPL, NFULL>(in, in_len, lane, v);
+	window_stats<NPL, NFULL>(v, in_len, lane, avr_o, avi_o, inv_o);
 }
 
 // burst_energy() of the caller (gmr1_rx.c:172-182): sum |x|^2 over [len>>5, len - len>>5) of the RAW
@@ -1307,7 +1325,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 }
 
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_rx4(RxArgs a, int stage_samples, int cw)
+__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
@@ -1354,34 +1372,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 		const float fs = (fsh - bt.rotation) / (float)sps;
 
 		const float2 *__restrict__ in = a.iq + a.offset[g];
-		float avr, avi, inv;
-		load_stats<NPL, (SPS == 4 && NPL == 16) ? 15 : -1>(in, in_len, lane, avr, avi, inv);
-		if (row == q) { avr_r = avr; avi_r = avi; }
-		if (a.energy) {
-			const float e = window_energy<NPL>(in, in_len, lane);
-			if (lane == 0)
-				a.energy[g] = e;
-		}
-
 		const int tl = bt.sync_tl[0];
 		const int nch = bt.n_chunks[0];
-		// stage the sync-chunk windows, normalised: window c = samples [pos_c sps, pos_c sps + len_c sps + w - 1)
-		// (a second, L1/L2-served read of ~300 of the burst's samples; the rest never touches LDS)
-		WSYNC();
-		{
-			int wb = 0;
-			for (int c = 0; c < nch; c++) {
-				const int wl = bt.sync[0][c].len * sps + w - 1;
-				const float2 *__restrict__ src = in + bt.sync[0][c].pos * sps;
-				float2 *dst = L.x + wb;
-				for (int sidx = lane; sidx < wl; sidx += 64) {
-					const float2 v = src[sidx];
-					dst[sidx] = make_float2((v.x - avr) * inv, (v.y - avi) * inv);
-				}
-				wb += wl;
+		constexpr int NFULL = (SPS == 4 && NPL == 16) ? 15 : -1;
+		// everything that needs memory is asked for first -- the whole window (statistics) and, again,
+		// the ~300 samples under the sync chunks (they go to LDS; the second request hits the lines the
+		// first one is fetching) -- and what needs no data (the rotated reference) is computed while it
+		// travels
+		float2 wv[NPL];
+		window_fetch<NPL, NFULL>(in, in_len, lane, wv);
+		constexpr int SIT = SPS == 4 ? 2 : 4;            // 64-sample pieces per chunk window
+		float2 sv[3][SIT];
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
+			const float2 *__restrict__ src = in + (c < nch ? bt.sync[0][c].pos * sps : 0);
+#pragma unroll
+			for (int h = 0; h < SIT; h++) {
+				const int sidx = lane + 64 * h;
+				sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
 			}
 		}
 		// rotated reference of the (single) sync sequence
+		WSYNC();
 		for (int n = lane; n < tl; n += 64) {
 			int ch = 0, base = 0, cum = 0;
 			for (int c = 0; c < nch - 1; c++) {
@@ -1392,6 +1405,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7, 7))) void
 			float s, c;
 			sincos_fast(fs * (float)(nn * sps), s, c);
 			L.coef[n] = conj_ref_mul(nbits, bt.sync[0][ch].syms[nn], make_float2(c, s));
+		}
+		float avr, avi, inv;
+		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
+		if (row == q) { avr_r = avr; avi_r = avi; }
+		if (a.energy) {
+			const float e = window_energy<NPL>(in, in_len, lane);
+			if (lane == 0)
+				a.energy[g] = e;
+		}
+		// stage the sync-chunk windows, normalised: window c = samples [pos_c sps, pos_c sps + len_c sps + w - 1)
+		{
+			int wb = 0;
+#pragma unroll
+			for (int c = 0; c < 3; c++) {
+				const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
+#pragma unroll
+				for (int h = 0; h < SIT; h++) {
+					const int sidx = lane + 64 * h;
+					if (sidx < wl)
+						L.x[wb + sidx] = make_float2((sv[c][h].x - avr) * inv, (sv[c][h].y - avi) * inv);
+				}
+				wb += wl;
+			}
 		}
 		WSYNC();
 		float *corr = L.corr + q * cw;
