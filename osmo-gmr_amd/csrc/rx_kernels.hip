@@ -1358,6 +1358,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
 
 	// =========================== pass 1: correlation magnitudes ===========================
+	float2 wv[NPL];
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
 		if (g >= a.n)
@@ -1379,8 +1380,8 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 		// the ~300 samples under the sync chunks (they go to LDS; the second request hits the lines the
 		// first one is fetching) -- and what needs no data (the rotated reference) is computed while it
 		// travels
-		float2 wv[NPL];
-		window_fetch<NPL, NFULL>(in, in_len, lane, wv);
+		if (q == 0)
+			window_fetch<NPL, NFULL>(in, in_len, lane, wv);
 		constexpr int SIT = SPS == 4 ? 2 : 4;            // 64-sample pieces per chunk window
 		float2 sv[3][SIT];
 #pragma unroll
@@ -1409,6 +1410,11 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 		float avr, avi, inv;
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
 		if (row == q) { avr_r = avr; avi_r = avi; }
+		if (q + 1 < 4 && g + 1 < a.n) {
+			// the next burst's window travels during this burst's correlation
+			const int kind1 = __builtin_amdgcn_readfirstlane(a.kind[g + 1] ? 1 : 0);
+			window_fetch<NPL, NFULL>(a.iq + a.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
+		}
 		if (a.energy) {
 			const float e = window_energy<NPL>(in, in_len, lane);
 			if (lane == 0)
