@@ -1544,14 +1544,14 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 	const int d_r = (int)roundf(toa_r);
 
 	// pass-2 operands of a burst (its 234 symbols at stride sps from sample d, re-read from
-	// L2 / Infinity Cache): fetched one burst ahead of their use
-	struct Sym4 { float2 x[4]; int ord[4]; int ok; };
+	// L2 / Infinity Cache): fetched two bursts ahead of their use
+	struct Sym4 { float2 x[4]; int ok; };
 	auto fetch = [&](int q, Sym4 &o) {
 		const int g = g0 + q;
 		o.ok = 0;
 #pragma unroll
-		for (int r = 0; r < 4; r++) { o.x[r] = make_float2(0.f, 0.f); o.ord[r] = -1; }
-		if (g >= a.n)
+		for (int r = 0; r < 4; r++) o.x[r] = make_float2(0.f, 0.f);
+		if (q >= 4 || g >= a.n)
 			return;
 		const int src = 16 * q;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
@@ -1564,17 +1564,15 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 		for (int r = 0; r < 4; r++) {
 			const int i = lane + 64 * r;
 			const int j = i * sps + d;
-			if (i < blen) {
-				o.ord[r] = bt.ord_of_sym[i];
-				if (j >= 0 && j < in_len) {
-					o.x[r] = in[j];
-					o.ok |= 1 << r;
-				}
+			if (i < blen && j >= 0 && j < in_len) {
+				o.x[r] = in[j];
+				o.ok |= 1 << r;
 			}
 		}
 	};
-	Sym4 first;
+	Sym4 first, second;
 	fetch(0, first);
+	fetch(1, second);
 
 	// =========================== rows: sync symbols, frequency, phase ===========================
 	const int nbits_r = bt_r.nbits;
@@ -1665,14 +1663,13 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 
 	// =========================== pass 2: soft symbols / soft bits ===========================
 	int row_ok = 0, row_chain = 0;
-	Sym4 cur = first;
+	Sym4 cur = first, nxt = second;
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
 		if (g >= a.n)
 			break;
-		Sym4 nxt;
-		if (q + 1 < 4)
-			fetch(q + 1, nxt);          // next burst's samples travel while this one is worked on
+		Sym4 nxt2;
+		fetch(q + 2, nxt2);             // the samples of burst q + 2 travel while q and q + 1 are worked on
 		const int src = 16 * q;
 		const bool found = __builtin_amdgcn_readlane((int)found_r, src) != 0;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
@@ -1695,9 +1692,17 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 				for (int i = lane; i < blen; i += 64)
 					gss[i] = 0.f;
 			cur = nxt;
+			nxt = nxt2;
 			continue;
 		}
 		row_ok |= 1 << q;
+		// where the soft bits of symbol i go (position of the symbol's bits among the e-bits, -1: sync / guard)
+		int ordv[4];
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int i = lane + 64 * r;
+			ordv[r] = i < blen ? bt.ord_of_sym[i] : -1;
+		}
 		// phase of symbol i in TURNS: arg(x_i) + fs (i sps + d) + rps i - psi  =  arg(x_i) + A i + B
 		// (pi4cxpsk.c:351-371 derotation, :574-588 frequency / phase correction, folded into one fma)
 		const float kInv2Pi = 0.159154943091895336f;
@@ -1720,7 +1725,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 			const float sv = (x.x == 0.0f && x.y == 0.0f) ? 0.0f : th * scale;   // cargf(0) = 0
 			if (gss)
 				gss[i] = sv;
-			const int ord = cur.ord[r];
+			const int ord = ordv[r];
 			if (ord >= 0) {
 				// soft bits of a pi/4-CQPSK symbol (pi4cxpsk.c:452-507): nearest symbol sp (Gray bits
 				// p0 p1), its neighbour on the side of sv, distance dq in 1/128 symbol; the bit that
@@ -1749,6 +1754,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 				ge[i] = i < neb ? eb[i] : (int8_t)0;
 		}
 		cur = nxt;
+		nxt = nxt2;
 	}
 	if (a.dbg_stop && a.dbg_stop < 7)
 		return;
