@@ -281,6 +281,33 @@ int gmr1_hip_rx_run_tch(int n_arfcn, int sps, const float *iq, const float *tch,
                         struct gmr1_hip_rx_record *out, int max_records, int *n_records,
                         int32_t *status, int32_t *n_chains);
 
+/* The whole application: gmr1_rx with all its optional arguments (tch.cfile, key, tch_csd.cfile; gmr1_rx.c:897-975).
+ * csd holds, per carrier, the carrier of the TCH9 (circuit switched data) channel an ASSIGNMENT COMMAND 1
+ * on the FACCH3 points to -- same layout and timing as iq / tch.  From that message on every frame's NT9 burst
+ * on the assigned timeslot is demodulated, deciphered (A5/1, always) and decoded: sync sequence 0 -> FACCH9
+ * (type 0x1a = GSMTAP_GMR1_TCH9 | GSMTAP_GMR1_FACCH, 38 bytes, reported when the CRC passes), sync sequence 1 ->
+ * TCH9 9k6 (type 0x18, 60 bytes, always reported -- no CRC; gmr1_rx.c:262-353).  Their payloads do not fit
+ * the 40-byte record, so they come back as big records, ordered like the others. */
+struct gmr1_hip_rx_big_record {
+	uint16_t arfcn;
+	uint8_t  chain, type;
+	uint32_t fn;
+	uint8_t  tn, crc, len, pad;
+	int32_t  conv;
+	uint8_t  l2[64];
+};
+int gmr1_hip_rx_run_full_dev(void *stream, int n_arfcn, int sps, const float *iq, const float *tch,
+                             const float *csd, const uint64_t *offset, const uint64_t *length,
+                             const uint16_t *arfcn, const uint8_t *kc,
+                             struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                             struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
+                             int32_t *status, int32_t *n_chains);
+int gmr1_hip_rx_run_full(int n_arfcn, int sps, const float *iq, const float *tch, const float *csd, uint64_t iq_len,
+                         const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn, const uint8_t *kc,
+                         struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                         struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
+                         int32_t *status, int32_t *n_chains);
+
 /* The GSMTAP packet gmr1_gsmtap_makemsg (reference src/gsmtap.c:43-71, include/osmocom/gmr1/gsmtap.h:35-37)
  * builds for one record: 16-byte gsmtap_hdr + L2.  Returns the packet length (16 + rec->len) or
  * -EINVAL.  Host-only; works without a GPU.  with_arfcn = 0 leaves the arfcn field 0 as the reference does. */

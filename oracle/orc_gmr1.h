@@ -148,4 +148,18 @@ int orc_rx_run(const orc_cf *iq, int len, int sps, int arfcn,
 int orc_rx_run_tch(const orc_cf *iq, const orc_cf *tch, int len, int sps, int arfcn, const uint8_t *kc,
                    struct orc_rx_record *out, int max_records, int *n_records, int *n_chains);
 
+#define ORC_RX_TYPE_TCH9 0x18       /* GSMTAP_GMR1_TCH9: one 60-byte 9k6 block */
+#define ORC_RX_TYPE_TCH9_FACCH 0x1a /* GSMTAP_GMR1_TCH9 | GSMTAP_GMR1_FACCH, 38 bytes */
+struct orc_rx_big_record {          /* NT9 payloads do not fit the 24 payload bytes of orc_rx_record */
+	uint16_t arfcn;
+	uint8_t  chain, type;
+	uint32_t fn;
+	uint8_t  tn, crc, len, pad;
+	int32_t  conv;
+	uint8_t  l2[64];
+};
+int orc_rx_run_full(const orc_cf *iq, const orc_cf *tch, const orc_cf *csd, int len, int sps, int arfcn,
+                    const uint8_t *kc, struct orc_rx_record *out, int max_records, int *n_records,
+                    struct orc_rx_big_record *big, int max_big, int *n_big, int *n_chains);
+
 #endif

@@ -27,10 +27,18 @@ struct tch3_state {                 /* gmr1_rx.c:59-78 */
 	int sync_id, burst_cnt;
 };
 
+struct tch9_state {                 /* gmr1_rx.c:82-91 */
+	int active;
+	int tn;
+	struct orc_interleaver il;
+};
+
 struct chan_desc {                  /* gmr1_rx.c:93-115, the fields this scope uses */
 	const orc_cf *iq;
 	const orc_cf *tch;              /* traffic carrier, same length and timing as iq (may be NULL) */
+	const orc_cf *csd;              /* carrier of the TCH9 (circuit switched data) channel (may be NULL) */
 	struct tch3_state tch3_state;
+	struct tch9_state tch9_state;
 	uint8_t kc[8];
 	int len;
 	int sps;
@@ -45,7 +53,26 @@ struct sink {
 	struct orc_rx_record *out;
 	int max, n;
 	int arfcn, chain;
+	struct orc_rx_big_record *big;  /* NT9 payloads (38 / 60 bytes) do not fit the 40-byte record */
+	int max_big, n_big;
 };
+
+static void emit_big(struct sink *s, int type, int fn, int tn, const uint8_t *l2, int n, int conv)
+{
+	if (s->big && s->n_big < s->max_big) {
+		struct orc_rx_big_record *r = &s->big[s->n_big];
+		memset(r, 0, sizeof(*r));
+		r->arfcn = (uint16_t)s->arfcn;
+		r->chain = (uint8_t)s->chain;
+		r->type = (uint8_t)type;
+		r->fn = (uint32_t)fn;
+		r->tn = (uint8_t)tn;
+		r->len = (uint8_t)n;
+		r->conv = conv;
+		memcpy(r->l2, l2, (size_t)n);
+	}
+	s->n_big++;
+}
 
 static void emit_n(struct sink *s, int type, int fn, int tn, const uint8_t *l2, int n, int conv)
 {
@@ -130,6 +157,53 @@ static void bcch_tdma_align(struct chan_desc *cd, const uint8_t *l2)
 	cd->sa_bcch_stn = stn;
 }
 
+/* ---- TCH9 follow-up (gmr1_rx.c:248-353) ------------------------------------------------------- */
+
+static int facch3_is_ass_cmd_1(const uint8_t *l2) { return (l2[3] == 0x06) && (l2[4] == 0x2e); }
+
+static void rx_tch9_init(struct chan_desc *cd, const uint8_t *ass_cmd)
+{
+	cd->tch9_state.active = 1;
+	cd->tch9_state.tn = ((ass_cmd[5] & 0x03) << 3) | (ass_cmd[6] >> 5);      /* facch3_ass_cmd_1_parse, :254-258 */
+	orc_interleaver_init(&cd->tch9_state.il, 3, 648);
+}
+
+static int burst_map(const struct chan_desc *cd, int burst_len, int tn, int win, int *begin_o, int *len_o);
+
+/* gmr1_rx.c:276-353.  Decision D8: the reference uses sync_id / ebits even when the demodulator failed
+ * (it never looks at rv before); a failed demodulation is "no burst" here and in the product. */
+static int rx_tch9(struct chan_desc *cd, struct sink *s)
+{
+	const struct orc_burst *bt = orc_burst_get(ORC_BURST_NT9);
+	orc_sbit_t ebits[662], sacch[10], status[4];
+	orc_ubit_t ciph[658];
+	int begin, len, e_toa, rv, sync_id, crc, conv;
+	float toa;
+
+	if (!cd->tch9_state.active)
+		return 0;
+	if (!cd->csd)
+		return -EINVAL;
+	e_toa = burst_map(cd, bt->len, cd->tch9_state.tn, cd->sps + (cd->sps / 2), &begin, &len);
+	if (e_toa < 0)
+		return e_toa;
+	rv = orc_pi4cxpsk_demod(bt, cd->csd + begin, len, cd->sps, -cd->freq_err, ebits, &sync_id, &toa, NULL, NULL);
+	if (rv)
+		return rv;
+	orc_a5(1, cd->kc, (uint32_t)cd->fn, 658, ciph, NULL);
+	if (!sync_id) {     /* FACCH9 */
+		uint8_t l2[38];
+		crc = orc_facch9_decode(l2, sacch, status, ebits, ciph, &conv);
+		if (!crc)
+			emit_big(s, ORC_RX_TYPE_TCH9_FACCH, cd->fn, cd->tch9_state.tn, l2, 38, conv);
+	} else {            /* TCH9, always decoded as 9k6 (gmr1_rx.c:333) */
+		uint8_t l2[60];
+		orc_tch9_decode(l2, sacch, status, ebits, ORC_TCH9_9k6, ciph, &cd->tch9_state.il, &conv);
+		emit_big(s, ORC_RX_TYPE_TCH9, cd->fn, cd->tch9_state.tn, l2, 60, conv);
+	}
+	return rv;
+}
+
 /* ---- TCH3 follow-up (gmr1_rx.c:235-246, 355-600) -------------------------------------------- */
 
 static int ccch_is_imm_ass(const uint8_t *l2) { return (l2[1] == 0x06) && (l2[2] == 0x3f); }
@@ -179,7 +253,9 @@ static void rx_tch3_facch_flush(struct chan_desc *cd, struct sink *s)
 	}
 	if (!crc)
 		emit_n(s, ORC_RX_TYPE_TCH3_FACCH, cd->fn - 3, st->tn, l2, 10, conv);
-	/* (an ASSIGNMENT COMMAND 1 would start the TCH9 follow-up when a CSD capture is given: not in scope) */
+	/* ASSIGNMENT COMMAND 1 starts the TCH9 follow-up when a CSD capture is given (gmr1_rx.c:436-442) */
+	if (!crc && facch3_is_ass_cmd_1(l2) && cd->csd)
+		rx_tch9_init(cd, l2);
 	st->sync_id ^= 1;
 	st->burst_cnt = 0;
 	memset(st->bi_fn, 0xff, sizeof(st->bi_fn));
@@ -335,6 +411,7 @@ static void process_bcch(struct chan_desc *cd, struct sink *s)
 		if ((sirfn % 8 != 0) && (sirfn % 8 != 2))
 			rx_ccch(cd, bcch_energy / 2.0f, s);
 		rx_tch3(cd, s);
+		rx_tch9(cd, s);
 		cd->fn++;
 		cd->align += frame_len;
 		if ((cd->align + 2 * frame_len) > cd->len)
@@ -353,16 +430,26 @@ int orc_rx_run(const orc_cf *iq, int len, int sps, int arfcn,
 int orc_rx_run_tch(const orc_cf *iq, const orc_cf *tch, int len, int sps, int arfcn, const uint8_t *kc,
                    struct orc_rx_record *out, int max_records, int *n_records, int *n_chains)
 {
+	int n_big = 0;
+	return orc_rx_run_full(iq, tch, NULL, len, sps, arfcn, kc, out, max_records, n_records, NULL, 0, &n_big, n_chains);
+}
+
+/* main() with all its optional arguments: tch.cfile, key, tch_csd.cfile (gmr1_rx.c:897-975) */
+int orc_rx_run_full(const orc_cf *iq, const orc_cf *tch, const orc_cf *csd, int len, int sps, int arfcn,
+                    const uint8_t *kc, struct orc_rx_record *out, int max_records, int *n_records,
+                    struct orc_rx_big_record *big, int max_big, int *n_big, int *n_chains)
+{
 	struct chan_desc cd;
-	struct sink s = { out, max_records, 0, arfcn, 0 };
+	struct sink s = { out, max_records, 0, arfcn, 0, big, max_big, 0 };
 	int rv, toa, base_align, mtoa[16], n_fcch, i, j;
 	float ref_snr = 0.0f, ref_freq_err = 0.0f;
 	const struct orc_fcch_burst *ft = &orc_fcch_burst;
 
 	*n_records = 0;
+	if (n_big) *n_big = 0;
 	if (n_chains) *n_chains = 0;
 	memset(&cd, 0, sizeof(cd));
-	cd.iq = iq; cd.tch = tch; cd.len = len; cd.sps = sps;
+	cd.iq = iq; cd.tch = tch; cd.csd = csd; cd.len = len; cd.sps = sps;
 	if (kc)
 		memcpy(cd.kc, kc, 8);
 	cd.align = START_DISCARD;                       /* gmr1_rx.c:906-909 */
@@ -432,5 +519,6 @@ int orc_rx_run_tch(const orc_cf *iq, const orc_cf *tch, int len, int sps, int ar
 		process_bcch(&cdl, &s);
 	}
 	*n_records = s.n;
+	if (n_big) *n_big = s.n_big;
 	return 0;
 }

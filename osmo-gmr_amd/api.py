@@ -36,7 +36,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
     "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
-    "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch",
+    "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch", "gmr1_hip_rx_run_full_dev", "gmr1_hip_rx_run_full",
     "gmr1_hip_channelize_plan", "gmr1_hip_channelize_dev", "gmr1_hip_channelize",
     "gmr1_hip_facch9_decode_batch_dev", "gmr1_hip_facch9_decode_batch", "gmr1_facch9_decode",
     "gmr1_hip_tch9_decode_batch_dev", "gmr1_hip_tch9_decode_batch",
@@ -775,3 +775,46 @@ def tch9_decode_batch(ebits, mode, seq_len, ciph=None):
            sa.ctypes.data_as(C.c_void_p), stt.ctypes.data_as(C.c_void_p), conv.ctypes.data_as(C.c_void_p))
     _check(rc, "gmr1_hip_tch9_decode_batch")
     return l2, sa, stt, conv
+
+
+RX_BIG_RECORD = np.dtype([("arfcn", "<u2"), ("chain", "u1"), ("type", "u1"), ("fn", "<u4"),
+                          ("tn", "u1"), ("crc", "u1"), ("len", "u1"), ("pad", "u1"),
+                          ("conv", "<i4"), ("l2", "u1", (64,))])
+assert RX_BIG_RECORD.itemsize == 80
+
+
+def rx_run_full(iq, tch, csd, offset, length, sps=4, arfcn=None, kc=None, max_records=1 << 16, max_big=1 << 14):
+    """gmr1_hip_rx_run_full: rx_run_tch plus the CSD carriers -> (records, big records, status, n_chains)"""
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    keep = []
+
+    def opt(x):
+        if x is None:
+            return None
+        x, p = _np(np.asarray(x).reshape(-1), np.complex64)
+        assert x.size == iq.size
+        keep.append(x)
+        return p
+    p_tch, p_csd = opt(tch), opt(csd)
+    n = len(offset)
+    p_kc = None
+    if kc is not None:
+        kc, p_kc = _np(np.broadcast_to(np.asarray(kc, np.uint8).reshape(-1, 8), (n, 8)), np.uint8)
+    offset, p_off = _np(offset, np.uint64)
+    length, p_len = _np(length, np.uint64)
+    p_arfcn = None
+    if arfcn is not None:
+        arfcn, p_arfcn = _np(arfcn, np.uint16)
+    out = np.zeros(max(max_records, 1), RX_RECORD)
+    big = np.zeros(max(max_big, 1), RX_BIG_RECORD)
+    n_rec, n_big = C.c_int(0), C.c_int(0)
+    status = np.zeros(max(n, 1), np.int32)
+    chains = np.zeros(max(n, 1), np.int32)
+    f = load().gmr1_hip_rx_run_full
+    f.restype = C.c_int
+    rc = f(C.c_int(n), C.c_int(sps), p_iq, p_tch, p_csd, C.c_uint64(iq.size), p_off, p_len, p_arfcn, p_kc,
+           out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n_rec),
+           big.ctypes.data_as(C.c_void_p), C.c_int(max_big), C.byref(n_big),
+           status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_rx_run_full")
+    return (out[:min(n_rec.value, max_records)].copy(), big[:min(n_big.value, max_big)].copy(), status[:n], chains[:n])

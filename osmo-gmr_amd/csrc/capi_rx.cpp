@@ -53,6 +53,8 @@ struct RxChain {
 	std::vector<int> rec_frame;          // frame (index into log) each record belongs to
 	std::vector<FrameCtx> log;           // one entry per loop iteration of process_bcch (only with a traffic carrier)
 	std::vector<AssEvt> events;
+	std::vector<AssEvt> events9;         // ASSIGNMENT COMMAND 1 taken from a FACCH3 (frame, tn)
+	std::vector<gmr1_hip_rx_big_record> big;
 };
 
 struct Item {             // one burst of a round
@@ -152,14 +154,18 @@ size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 extern "C" {
 
-int gmr1_hip_rx_run_tch_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
-                            const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
-                            const uint8_t *kc,
-                            struct gmr1_hip_rx_record *out, int max_records, int *n_records,
-                            int32_t *status, int32_t *n_chains)
+int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
+                             const float *csd, const uint64_t *offset, const uint64_t *length,
+                             const uint16_t *arfcn, const uint8_t *kc,
+                             struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                             struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
+                             int32_t *status, int32_t *n_chains)
 {
 	hipStream_t st = (hipStream_t)stream_;
 	if (n_records) *n_records = 0;
+	if (n_big) *n_big = 0;
+	if (csd && (!tch || !n_big || max_big < 0 || (max_big > 0 && !big_out)))
+		return fail(-EINVAL, "rx_run: the CSD carrier needs the traffic carrier and the big-record outputs");
 	if (n_arfcn < 0 || !iq || !offset || !length || !n_records || (max_records > 0 && !out) || max_records < 0)
 		return fail(-EINVAL, "rx_run: iq/offset/length/n_records (and out when max_records > 0) are required");
 	if (sps < 4 || sps > 8)
@@ -724,9 +730,14 @@ int gmr1_hip_rx_run_tch_dev(void *stream_, int n_arfcn, int sps, const float *iq
 							if (!crc)
 								cf = 1;
 						}
-						if (!crc)
-							emit(c, an, 0x12 /* GSMTAP_GMR1_TCH3 | GSMTAP_GMR1_FACCH */, j.fn - 3, j.tn,
-							     &f_l2[v][(size_t)iff * 10], f_conv[v][iff], j.frame, 10);
+						if (!crc) {
+							const uint8_t *m = &f_l2[v][(size_t)iff * 10];
+							emit(c, an, 0x12 /* GSMTAP_GMR1_TCH3 | GSMTAP_GMR1_FACCH */, j.fn - 3, j.tn, m,
+							     f_conv[v][iff], j.frame, 10);
+							// ASSIGNMENT COMMAND 1 starts the TCH9 follow-up (gmr1_rx.c:248-258, 436-442)
+							if (csd && m[3] == 0x06 && m[4] == 0x2e)
+								c.events9.push_back({j.frame, ((m[5] & 0x03) << 3) | (m[6] >> 5), 0, 0.f});
+						}
 						iff++;
 					}
 				}
@@ -746,6 +757,170 @@ int gmr1_hip_rx_run_tch_dev(void *stream_, int n_arfcn, int sps, const float *iq
 		}
 	}
 
+	// ---- TCH9 follow-up (rx_tch9, gmr1_rx.c:262-353) ----------------------------------------------
+	// From the frame of a chain's first ASSIGNMENT COMMAND 1 on, every frame's NT9 burst on the assigned
+	// timeslot of the CSD carrier: demodulate (sync sequence 0 = FACCH9, 1 = TCH9), decipher with A5/1 of the
+	// frame number, decode.  Nothing feeds back, so it is one more batched pass: one demodulation launch, one
+	// keystream launch, one FACCH9 launch, one TCH9 launch per interleaver run (a run starts at every
+	// assignment; gmr1_deinterleave_inter only advances on TCH9 bursts).
+	if (csd) {
+		struct Nt9Item { int chain_idx, frame, tn; };
+		std::vector<Nt9Item> items9;
+		const int win9 = sps + (sps / 2), in_len9 = 351 * sps + win9, etoa9 = win9 >> 1;
+		for (size_t ci = 0; ci < chains.size(); ci++) {
+			RxChain &c = chains[ci];
+			if (c.events9.empty())
+				continue;
+			size_t ev = 0;
+			for (int f = c.events9[0].frame; f < (int)c.log.size(); f++) {
+				while (ev + 1 < c.events9.size() && c.events9[ev + 1].frame <= f)
+					ev++;
+				const int tn = c.events9[ev].tn;
+				const int64_t begin = (int64_t)c.log[f].align + sps * tn * 39 - etoa9;
+				if (begin < 0 || begin + in_len9 > c.len)
+					continue;
+				items9.push_back({(int)ci, f, tn});
+			}
+		}
+		const int n9 = (int)items9.size();
+		if (n9) {
+			std::vector<uint64_t> off9(n9);
+			std::vector<float> fs9(n9);
+			for (int k = 0; k < n9; k++) {
+				const RxChain &c = chains[items9[k].chain_idx];
+				const FrameCtx &x = c.log[items9[k].frame];
+				off9[k] = c.base + (uint64_t)((int64_t)x.align + sps * items9[k].tn * 39 - etoa9);
+				fs9[k] = -x.freq_err;
+			}
+			DBuf d_o, d_f, d_eb, d_sid, d_rv;
+			HIP_TRY(d_o.alloc((size_t)n9 * 8)); HIP_TRY(d_f.alloc((size_t)n9 * 4)); HIP_TRY(d_eb.alloc((size_t)n9 * 662));
+			HIP_TRY(d_sid.alloc((size_t)n9 * 4)); HIP_TRY(d_rv.alloc((size_t)n9 * 4));
+			HIP_TRY(hipMemcpyAsync(d_o.p, off9.data(), (size_t)n9 * 8, hipMemcpyHostToDevice, st));
+			HIP_TRY(hipMemcpyAsync(d_f.p, fs9.data(), (size_t)n9 * 4, hipMemcpyHostToDevice, st));
+			r = demod_dev_energy(st, GMR1_HIP_NT9, n9, sps, in_len9, csd, d_o.as<uint64_t>(), d_f.as<float>(),
+			                     d_eb.as<int8_t>(), 662, d_sid.as<int32_t>(), nullptr, nullptr, d_rv.as<int32_t>());
+			if (r) return r;
+			std::vector<int8_t> h_eb((size_t)n9 * 662);
+			std::vector<int32_t> h_sid(n9), h_rv(n9);
+			HIP_TRY(hipMemcpyAsync(h_eb.data(), d_eb.p, (size_t)n9 * 662, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_sid.data(), d_sid.p, (size_t)n9 * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipMemcpyAsync(h_rv.data(), d_rv.p, (size_t)n9 * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(hipStreamSynchronize(st));
+			// classify; TCH9 bursts are laid out run after run (one run per interleaver life)
+			std::vector<int> fj, tj;                 // item indices: FACCH9 jobs, TCH9 jobs (run-major)
+			std::vector<int> run_len;
+			{
+				int k = 0;
+				while (k < n9) {
+					const int ci = items9[k].chain_idx;
+					const RxChain &c = chains[ci];
+					size_t ev = 0;
+					int cur = 0;
+					bool open = false;
+					for (; k < n9 && items9[k].chain_idx == ci; k++) {
+						// a (re-)assignment at or before this frame restarts the interleaver (rx_tch9_init)
+						bool restart = !open;
+						while (ev < c.events9.size() && c.events9[ev].frame <= items9[k].frame) { ev++; restart = true; }
+						if (restart) {
+							if (open && cur) run_len.push_back(cur);
+							cur = 0;
+							open = true;
+						}
+						if (h_rv[k])
+							continue;                    // decision D8: a failed demodulation is no burst
+						if (h_sid[k] == 0)
+							fj.push_back(k);
+						else {
+							tj.push_back(k);
+							cur++;
+						}
+					}
+					if (cur) run_len.push_back(cur);
+				}
+			}
+			const int nf = (int)fj.size(), nt9 = (int)tj.size(), nj = nf + nt9;
+			if (nj) {
+				std::vector<int8_t> eb((size_t)nj * 662);
+				std::vector<uint8_t> keys((size_t)nj * 8, 0);
+				std::vector<uint32_t> fns(nj);
+				for (int i = 0; i < nj; i++) {
+					const int k = i < nf ? fj[i] : tj[i - nf];
+					const RxChain &c = chains[items9[k].chain_idx];
+					std::memcpy(&eb[(size_t)i * 662], &h_eb[(size_t)k * 662], 662);
+					if (kc) std::memcpy(&keys[(size_t)i * 8], kc + (size_t)c.a * 8, 8);
+					fns[i] = (uint32_t)c.log[items9[k].frame].fn;
+				}
+				DBuf d_e2, d_k, d_fn, d_ks, d_l2f, d_crc, d_cvf, d_l2t, d_cvt;
+				HIP_TRY(d_e2.alloc(eb.size())); HIP_TRY(d_k.alloc(keys.size())); HIP_TRY(d_fn.alloc((size_t)nj * 4));
+				HIP_TRY(d_ks.alloc((size_t)nj * 658));
+				HIP_TRY(d_l2f.alloc((size_t)nf * 38)); HIP_TRY(d_crc.alloc((size_t)nf * 4)); HIP_TRY(d_cvf.alloc((size_t)nf * 4));
+				HIP_TRY(d_l2t.alloc((size_t)nt9 * 60)); HIP_TRY(d_cvt.alloc((size_t)nt9 * 4));
+				HIP_TRY(hipMemcpyAsync(d_e2.p, eb.data(), eb.size(), hipMemcpyHostToDevice, st));
+				HIP_TRY(hipMemcpyAsync(d_k.p, keys.data(), keys.size(), hipMemcpyHostToDevice, st));
+				HIP_TRY(hipMemcpyAsync(d_fn.p, fns.data(), (size_t)nj * 4, hipMemcpyHostToDevice, st));
+				r = gmr1_hip_a5_batch_dev(st, nj, 1, 658, d_k.as<uint8_t>(), d_fn.as<uint32_t>(), d_ks.as<uint8_t>(), nullptr);
+				if (r) return r;
+				std::vector<uint8_t> l2f((size_t)nf * 38), l2t((size_t)nt9 * 60);
+				std::vector<int32_t> crcf(nf), cvf(nf), cvt(nt9);
+				if (nf) {
+					r = gmr1_hip_facch9_decode_batch_dev(st, nf, d_e2.as<int8_t>(), d_ks.as<uint8_t>(), d_l2f.as<uint8_t>(),
+					                                     nullptr, nullptr, d_crc.as<int32_t>(), d_cvf.as<int32_t>());
+					if (r) return r;
+					HIP_TRY(hipMemcpyAsync(l2f.data(), d_l2f.p, l2f.size(), hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipMemcpyAsync(crcf.data(), d_crc.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+					HIP_TRY(hipMemcpyAsync(cvf.data(), d_cvf.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
+				}
+				{
+					int done = 0;
+					for (int len_run : run_len) {
+						const size_t o = (size_t)(nf + done);
+						r = gmr1_hip_tch9_decode_batch_dev(st, 1, len_run, 2 /* GMR1_TCH9_9k6, gmr1_rx.c:333 */,
+						                                   d_e2.as<int8_t>() + o * 662, d_ks.as<uint8_t>() + o * 658,
+						                                   d_l2t.as<uint8_t>() + (size_t)done * 60, nullptr, nullptr,
+						                                   d_cvt.as<int32_t>() + done);
+						if (r) return r;
+						done += len_run;
+					}
+					if (nt9) {
+						HIP_TRY(hipMemcpyAsync(l2t.data(), d_l2t.p, l2t.size(), hipMemcpyDeviceToHost, st));
+						HIP_TRY(hipMemcpyAsync(cvt.data(), d_cvt.p, (size_t)nt9 * 4, hipMemcpyDeviceToHost, st));
+					}
+				}
+				HIP_TRY(hipStreamSynchronize(st));
+				// records in frame order per chain: merge the two job lists by item index
+				int a9 = 0, b9 = 0;
+				while (a9 < nf || b9 < nt9) {
+					const bool take_f = b9 >= nt9 || (a9 < nf && fj[a9] < tj[b9]);
+					const int k = take_f ? fj[a9] : tj[b9];
+					RxChain &c = chains[items9[k].chain_idx];
+					gmr1_hip_rx_big_record rec;
+					std::memset(&rec, 0, sizeof(rec));
+					rec.arfcn = arfcn ? arfcn[c.a] : (uint16_t)c.a;
+					rec.chain = (uint8_t)c.chain;
+					rec.fn = (uint32_t)c.log[items9[k].frame].fn;
+					rec.tn = (uint8_t)items9[k].tn;
+					if (take_f) {
+						if (!crcf[a9]) {
+							rec.type = 0x1a;     // GSMTAP_GMR1_TCH9 | GSMTAP_GMR1_FACCH
+							rec.len = 38;
+							rec.conv = cvf[a9];
+							std::memcpy(rec.l2, &l2f[(size_t)a9 * 38], 38);
+							c.big.push_back(rec);
+						}
+						a9++;
+					} else {
+						rec.type = 0x18;         // GSMTAP_GMR1_TCH9 (no CRC to check, gmr1_rx.c:336-339)
+						rec.len = 60;
+						rec.conv = cvt[b9];
+						std::memcpy(rec.l2, &l2t[(size_t)b9 * 60], 60);
+						c.big.push_back(rec);
+						b9++;
+					}
+				}
+			}
+		}
+	}
+
 	// ---- hand back: carriers in order, chains in order, frames in order -------------------------
 	int total = 0;
 	for (const RxChain &c : chains) {       // chains were created carrier by carrier, chain by chain
@@ -756,11 +931,63 @@ int gmr1_hip_rx_run_tch_dev(void *stream_, int n_arfcn, int sps, const float *iq
 		}
 	}
 	*n_records = total;
+	if (n_big) {
+		int tb = 0;
+		for (const RxChain &c : chains)
+			for (const gmr1_hip_rx_big_record &rec : c.big) {
+				if (tb < max_big)
+					big_out[tb] = rec;
+				tb++;
+			}
+		*n_big = tb;
+	}
 	for (int i = 0; i < A; i++) {
 		if (status) status[i] = stat[i];
 		if (n_chains) n_chains[i] = nch[i];
 	}
 	return 0;
+}
+
+int gmr1_hip_rx_run_tch_dev(void *stream, int n_arfcn, int sps, const float *iq, const float *tch,
+                            const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                            const uint8_t *kc,
+                            struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                            int32_t *status, int32_t *n_chains)
+{
+	return gmr1_hip_rx_run_full_dev(stream, n_arfcn, sps, iq, tch, nullptr, offset, length, arfcn, kc,
+	                                out, max_records, n_records, nullptr, 0, nullptr, status, n_chains);
+}
+
+int gmr1_hip_rx_run_full(int n_arfcn, int sps, const float *iq, const float *tch, const float *csd, uint64_t iq_len,
+                         const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn, const uint8_t *kc,
+                         struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                         struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
+                         int32_t *status, int32_t *n_chains)
+{
+	if (n_records) *n_records = 0;
+	if (n_big) *n_big = 0;
+	DevState *ds;
+	int r = dev_state(&ds);
+	if (r) return r;
+	if (n_arfcn < 0 || !iq || !offset || !length)
+		return fail(-EINVAL, "rx_run: iq/offset/length are required");
+	for (int i = 0; i < n_arfcn; i++)
+		if (offset[i] + length[i] > iq_len)
+			return fail(-EINVAL, "rx_run: carrier %d runs past the end of iq", i);
+	DBuf d_iq, d_tch, d_csd;
+	HIP_TRY(d_iq.alloc(iq_len * 8));
+	HIP_TRY(hipMemcpy(d_iq.p, iq, iq_len * 8, hipMemcpyHostToDevice));
+	if (tch) {
+		HIP_TRY(d_tch.alloc(iq_len * 8));
+		HIP_TRY(hipMemcpy(d_tch.p, tch, iq_len * 8, hipMemcpyHostToDevice));
+	}
+	if (csd) {
+		HIP_TRY(d_csd.alloc(iq_len * 8));
+		HIP_TRY(hipMemcpy(d_csd.p, csd, iq_len * 8, hipMemcpyHostToDevice));
+	}
+	return gmr1_hip_rx_run_full_dev(nullptr, n_arfcn, sps, d_iq.as<float>(), tch ? d_tch.as<float>() : nullptr,
+	                                csd ? d_csd.as<float>() : nullptr, offset, length, arfcn, kc, out, max_records,
+	                                n_records, big_out, max_big, n_big, status, n_chains);
 }
 
 int gmr1_hip_rx_run_dev(void *stream, int n_arfcn, int sps, const float *iq,

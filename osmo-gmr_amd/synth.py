@@ -572,13 +572,15 @@ def dkab_symbols(bits: np.ndarray, p: int) -> np.ndarray:
 def synth_tch3_carrier(fmt_speech: BurstFormat, fmt_facch: BurstFormat, n_samples: int, sps: int,
                        rng: np.random.Generator, *, t0: int, fn0: int, k_start: int, tn: int, p: int,
                        kc=None, cipher_from: int | None = None, esn0_db: float = 25.0, cfo_hz: float = 0.0,
-                       frac: float = 0.0, mix=(0.35, 0.35, 0.3), k_stop: int | None = None):
+                       frac: float = 0.0, mix=(0.35, 0.35, 0.3), k_stop: int | None = None, ass_cmd=None):
     """The traffic carrier of a TCH3 assignment, time-aligned with the BCCH carrier (same t0 / fn0):
     from frame index k_start on, timeslot tn carries per frame a DKAB, an NT3 speech burst, or -- in
     groups of four frames with fn & 3 = 0..3 -- the four bursts of a FACCH3 message (sync sequence
     alternating per message).  mix = probabilities (dkab, speech, facch group) per decision.
     Bursts from frame index `cipher_from` on are A5/1-ciphered with kc (speech: fn of the burst,
     FACCH3: fn of each of its four bursts; reference src/gmr1_rx.c:390-399, 500-503).
+    ass_cmd = (k, tn9): every FACCH3 message sent at frame index >= k is an ASSIGNMENT COMMAND 1 to
+    timeslot tn9 (facch3_is_ass_cmd_1 / facch3_ass_cmd_1_parse, gmr1_rx.c:248-258).
     Returns (stream, sent list of dicts)."""
     frame_len = 24 * 39 * sps
     sigma = np.sqrt(10.0 ** (-esn0_db / 10.0) / 2.0)
@@ -625,6 +627,10 @@ def synth_tch3_carrier(fmt_speech: BurstFormat, fmt_facch: BurstFormat, n_sample
             l2[0, 9] &= 0x0F                                  # 76 bits
             if l2[0, 3] == 0x06 and l2[0, 4] == 0x2E:
                 l2[0, 4] = 0                                  # never an ASSIGNMENT COMMAND 1 by accident
+            if ass_cmd is not None and k >= ass_cmd[0]:
+                l2[0, 3], l2[0, 4] = 0x06, 0x2E
+                l2[0, 5] = (l2[0, 5] & 0xFC) | ((ass_cmd[1] >> 3) & 0x03)
+                l2[0, 6] = ((ass_cmd[1] & 0x07) << 5) | (l2[0, 6] & 0x1F)
             sb = rng.integers(0, 2, size=(1, 32), dtype=np.uint8)
             ciph = None
             if ciphered(k):

@@ -436,3 +436,36 @@ def tch9_punct(mode):
     f.restype = C.c_int
     n = f(C.c_int(mode), idx)
     return np.array(idx[:n], np.int64)
+
+
+RX_BIG_RECORD = np.dtype([("arfcn", "<u2"), ("chain", "u1"), ("type", "u1"), ("fn", "<u4"),
+                          ("tn", "u1"), ("crc", "u1"), ("len", "u1"), ("pad", "u1"),
+                          ("conv", "<i4"), ("l2", "u1", (64,))])
+
+
+def rx_run_full(iq, tch, csd, sps=4, arfcn=0, kc=None, max_records=1 << 16, max_big=1 << 14):
+    """orc_rx_run_full: gmr1_rx with traffic carrier, key and CSD carrier -> (rv, records, big records, n_chains)"""
+    iq = np.ascontiguousarray(iq, np.complex64)
+
+    def ptr(x):
+        if x is None:
+            return None
+        x = np.ascontiguousarray(x, np.complex64)
+        assert x.size == iq.size
+        keep.append(x)
+        return _p(x, C.c_float)
+    keep = []
+    p_tch, p_csd = ptr(tch), ptr(csd)
+    p_kc = None
+    if kc is not None:
+        kc = np.ascontiguousarray(kc, np.uint8)
+        p_kc = kc.ctypes.data_as(C.c_void_p)
+    out = np.zeros(max_records, RX_RECORD)
+    big = np.zeros(max_big, RX_BIG_RECORD)
+    n, nb, nch = C.c_int(), C.c_int(), C.c_int()
+    f = lib().orc_rx_run_full
+    f.restype = C.c_int
+    rv = f(_p(iq, C.c_float), p_tch, p_csd, C.c_int(iq.size), C.c_int(sps), C.c_int(arfcn), p_kc,
+           out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n),
+           big.ctypes.data_as(C.c_void_p), C.c_int(max_big), C.byref(nb), C.byref(nch))
+    return rv, out[:min(n.value, max_records)].copy(), big[:min(nb.value, max_big)].copy(), nch.value

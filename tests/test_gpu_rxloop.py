@@ -182,3 +182,44 @@ def test_rx_loop_at_sps_8(gpu_api, orc, pkg):
     assert _key(rec) == _key(orec)
     mb, nb, mc, nc, mp = workloads.match_records(rec, sent)
     assert nb >= 5 and mp == nb and mc >= nc - 1
+
+
+def _key_big(rec):
+    return [(int(r["arfcn"]), int(r["chain"]), int(r["type"]), int(r["fn"]), int(r["tn"]), int(r["len"]),
+             bytes(r["l2"][:int(r["len"])]), int(r["conv"])) for r in rec]
+
+
+def test_rx_loop_tch9_follow_up_matches_oracle(gpu_api, orc, pkg):
+    """The whole application: IMM.ASS -> TCH3; ASSIGNMENT COMMAND 1 on its FACCH3 -> NT9 bursts on the CSD carrier,
+    FACCH9 / TCH9 9k6, A5/1 (gmr1_rx.c:262-353).  Records and big records are the oracle's, carrier by carrier."""
+    kc1 = np.arange(8, dtype=np.uint8)
+    cases = [dict(seed=2, kc=kc1, mix9=(0.0, 1.0)), dict(seed=3, kc=None, mix9=(0.3, 0.6)),
+             dict(seed=4, kc=kc1, mix9=(0.2, 0.5), tn9=17)]
+    bc, tc, cc, kcs, sents9 = [], [], [], [], []
+    for cs in cases:
+        cs = dict(cs)
+        seed = cs.pop("seed")
+        b, t, c, kc, _, _, s9 = workloads.bcch_tch_csd_triple(pkg, orc, seed, seconds=5.5, **cs)
+        bc.append(b); tc.append(t); cc.append(c); kcs.append(kc); sents9.append(s9)
+    length = np.array([x.size for x in bc], np.uint64)
+    offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.uint64)
+    rec, big, status, chains = gpu_api.rx_run_full(np.concatenate(bc), np.concatenate(tc), np.concatenate(cc),
+                                                   offset, length, sps=SPS, kc=np.stack(kcs))
+    assert not status.any()
+    n_big = 0
+    for i in range(len(bc)):
+        orv, orec, obig, och = orc.rx_run_full(bc[i], tc[i], cc[i], sps=SPS, arfcn=i, kc=kcs[i])
+        assert orv == 0 and chains[i] == och
+        assert _key_n(rec[rec["arfcn"] == i]) == _key_n(orec), f"carrier {i}: records differ"
+        assert _key_big(big[big["arfcn"] == i]) == _key_big(obig), f"carrier {i}: NT9 records differ"
+        n_big += len(obig)
+    assert n_big > 100
+    # TCH9-only carrier: a block comes out two bursts after it went in (depth-3 inter-burst interleaver)
+    sent = {s["fn"]: bytes(s["l2"]) for s in sents9[0] if s["type"] == "tch9"}
+    mine = big[(big["arfcn"] == 0) & (big["type"] == 0x18)]
+    hits = sum(sent.get(int(r["fn"]) - 2) == bytes(r["l2"][:60]) for r in mine)
+    assert hits > 0.5 * len(mine)
+    # without the CSD carrier: the same ordinary records, no big ones
+    rec2, big2, _, _ = gpu_api.rx_run_full(np.concatenate(bc), np.concatenate(tc), None, offset, length, sps=SPS,
+                                           kc=np.stack(kcs))
+    assert len(big2) == 0 and _key_n(rec2) == _key_n(rec)

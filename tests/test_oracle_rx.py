@@ -81,3 +81,19 @@ def test_rx_loop_follows_tch3_assignment(orc, pkg):
     # without the traffic carrier nothing but BCCH / CCCH comes back, and they are the same frames
     rv2, rec2, _ = orc.rx_run_tch(bcch, None)
     assert np.array_equal(rec2, rec[rec["type"] < 0x10])
+
+
+def test_rx_loop_follows_tch9_assignment(orc, pkg):
+    """ASSIGNMENT COMMAND 1 on the FACCH3 -> NT9 bursts of the CSD carrier (gmr1_rx.c:262-353): TCH9 9k6 blocks
+    come out two bursts after they went in (depth-3 inter-burst interleaver), always deciphered with A5/1."""
+    kc = np.arange(8, dtype=np.uint8)
+    bcch, tch, csd, kc, sent, sent_t, sent9 = workloads.bcch_tch_csd_triple(pkg, orc, 2, seconds=5.5, kc=kc, mix9=(0.0, 1.0))
+    rv, rec, big, n_chains = orc.rx_run_full(bcch, tch, csd, kc=kc)
+    assert rv == 0 and n_chains == 1 and len(big) > 50
+    assert np.all(big["type"] == 0x18) and np.all(big["len"] == 60) and np.all(big["tn"] == 5)
+    by_fn = {s["fn"]: bytes(s["l2"]) for s in sent9}
+    hits = sum(by_fn.get(int(r["fn"]) - 2) == bytes(r["l2"][:60]) for r in big)
+    assert hits > 0.5 * len(big)
+    # the ordinary records do not change when the CSD carrier is taken away
+    rv2, rec2, big2, _ = orc.rx_run_full(bcch, tch, None, kc=kc)
+    assert len(big2) == 0 and np.array_equal(rec2, rec)

@@ -162,3 +162,71 @@ def wideband_capture(pkg, seed, seconds=2.5, samp_rate=2.0e6, carriers=((3, {}),
         wide += (w * np.exp(2j * np.pi * (k * 31250.0 / samp_rate) * t)).astype(np.complex64)
         sents[ch] = sent
     return wide, sents
+
+
+def bcch_tch_csd_triple(pkg, orc, seed, seconds=6.0, sps=4, stn=3, delay=2, tn=11, p=20, tn9=5, k_ass=15,
+                        k_cmd=25, kc=None, esn0_db=25.0, cfo_hz=40.0, mix9=(0.3, 0.6)):
+    """BCCH carrier with an IMM.ASS, the TCH3 carrier it points to -- whose FACCH3 messages from frame k_cmd
+    on are ASSIGNMENT COMMAND 1 to timeslot tn9 -- and the CSD carrier with NT9 bursts on that timeslot:
+    FACCH9 (sync sequence 0) or TCH9 9k6 (sync sequence 1), always A5/1-ciphered with kc (gmr1_rx.c:276-353).
+    mix9 = (P(FACCH9), P(TCH9)) per frame.  The NT9 encoders are the oracle's (test data only)."""
+    from importlib import import_module
+    synth = import_module(pkg.__name__ + ".synth")
+    rng = np.random.default_rng(seed)
+    n = int(seconds * 23400 * sps)
+    frame_len = 24 * 39 * sps
+    t0 = int(rng.integers(0, frame_len))
+    fn0 = int(rng.integers(0, 1 << 18))
+    if kc is None:
+        kc = np.zeros(8, np.uint8)
+    fb, fd = pkg.api.burst_format("bcch"), pkg.api.burst_format("dc6")
+    fs, ff = pkg.api.burst_format("nt3_speech"), pkg.api.burst_format("nt3_facch")
+    f9 = pkg.api.burst_format("nt9")
+    bcch, sent = synth.synth_bcch_carrier(fb, fd, n, sps, rng, stn=stn, delay=delay, fn0=fn0, t0=t0,
+                                          esn0_db=esn0_db, cfo_hz=cfo_hz, imm_ass=[(k_ass, tn, p)])
+    ia = [s for s in sent if s["type"] == "ccch" and s.get("imm_ass")]
+    assert ia
+    k_start = ia[0]["k"]
+    tch, sent_t = synth.synth_tch3_carrier(fs, ff, n, sps, rng, t0=t0, fn0=fn0, k_start=k_start, tn=tn, p=p,
+                                           kc=None, esn0_db=esn0_db, cfo_hz=cfo_hz, mix=(0.2, 0.2, 0.6),
+                                           ass_cmd=(k_start + k_cmd, tn9))
+    # CSD carrier
+    sigma = np.sqrt(10.0 ** (-esn0_db / 10.0) / 2.0)
+    csd = (rng.standard_normal((n, 2)) * sigma).astype(np.float32).view(np.complex64).reshape(-1)
+    n_frames = (n - t0) // frame_len - 1
+    il = orc.Interleaver()
+    orc.lib().orc_interleaver_init(orc.C.byref(il), orc.C.c_int(3), orc.C.c_int(648))
+    sent9 = []
+    span = 5
+    for k in range(k_start, n_frames):
+        fn = fn0 + k
+        u = rng.random()
+        if u >= mix9[0] + mix9[1]:
+            continue
+        ciph = synth.a5_1(kc, [fn], 658)[0]
+        sacch = rng.integers(0, 2, 10, dtype=np.uint8)
+        status = rng.integers(0, 2, 4, dtype=np.uint8)
+        if u < mix9[0]:
+            l2 = rng.integers(0, 256, 38, dtype=np.uint8)
+            l2[37] &= 0x0F
+            e = orc.facch9_encode(l2, sacch, status, ciph)
+            sid = 0
+            kind = "facch9"
+        else:
+            l2 = rng.integers(0, 256, 60, dtype=np.uint8)
+            e = np.zeros(662, np.uint8)
+            orc.lib().orc_tch9_encode(e.ctypes.data_as(orc.C.c_void_p), l2.ctypes.data_as(orc.C.c_void_p),
+                                      orc.C.c_int(2), sacch.ctypes.data_as(orc.C.c_void_p),
+                                      status.ctypes.data_as(orc.C.c_void_p), ciph.ctypes.data_as(orc.C.c_void_p),
+                                      orc.C.byref(il))
+            sid = 1
+            kind = "tch9"
+        body = synth.shape_bursts(synth.map_symbols(f9, e[None, :], sync_id=sid), sps, 0.0, span)[0]
+        pos = t0 + k * frame_len + tn9 * 39 * sps - span * sps
+        if pos >= 0 and pos + body.size <= n:
+            csd[pos:pos + body.size] += body
+            sent9.append(dict(type=kind, fn=fn, k=k, l2=l2))
+    if cfo_hz:
+        ph = (2 * np.pi * cfo_hz / (23400 * sps)) * np.arange(n, dtype=np.float64)
+        csd *= np.exp(1j * ph).astype(np.complex64)
+    return bcch, tch, csd, kc, sent, sent_t, sent9
