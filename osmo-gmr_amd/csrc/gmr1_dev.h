@@ -182,7 +182,7 @@ struct A5Args {
 };
 
 // wideband -> per-ARFCN channelizer (chan_kernels.hip)
-constexpr int kPfbMaxBlocks = 12;        // prototype taps / n_chans, rounded up, + 1
+constexpr int kPfbMaxBlocks = 11;        // prototype taps / n_chans, rounded up, + 1
 struct PfbArgs {
 	int n_chans;               // 64
 	int n_blocks;              // taps per polyphase branch (<= kPfbMaxBlocks)
