@@ -1325,7 +1325,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 }
 
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
+__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
@@ -1342,9 +1342,12 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[3]);
 	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + 4 * kSteps12 * 4);
 
-	const int g0 = blockIdx.x * 4;
+	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway
+	// (the receive loop's rounds), which shortens the critical path of a wave to a quarter
+	const int g0 = blockIdx.x * bpw;
+	const int n_end = min(a.n, g0 + bpw);
 	const int g_row = g0 + row;                       // this row's burst
-	const bool row_live = g_row < a.n;
+	const bool row_live = g_row < n_end;
 
 	// per-row (lane-resident) burst parameters
 	const int kind_r = row_live ? (a.kind[g_row] ? 1 : 0) : 0;
@@ -1361,7 +1364,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 	float2 wv[NPL];
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
-		if (g >= a.n)
+		if (g >= n_end)
 			break;
 		const int kind = __builtin_amdgcn_readfirstlane(a.kind[g] ? 1 : 0);
 		const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
@@ -1410,7 +1413,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 		float avr, avi, inv;
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
 		if (row == q) { avr_r = avr; avi_r = avi; }
-		if (q + 1 < 4 && g + 1 < a.n) {
+		if (q + 1 < 4 && g + 1 < n_end) {
 			// the next burst's window travels during this burst's correlation
 			const int kind1 = __builtin_amdgcn_readfirstlane(a.kind[g + 1] ? 1 : 0);
 			window_fetch<NPL, NFULL>(a.iq + a.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
@@ -1551,7 +1554,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 		o.ok = 0;
 #pragma unroll
 		for (int r = 0; r < 4; r++) o.x[r] = make_float2(0.f, 0.f);
-		if (q >= 4 || g >= a.n)
+		if (q >= 4 || g >= n_end)
 			return;
 		const int src = 16 * q;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
@@ -1666,7 +1669,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw)
 	Sym4 cur = first, nxt = second;
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
-		if (g >= a.n)
+		if (g >= n_end)
 			break;
 		Sym4 nxt2;
 		fetch(q + 2, nxt2);             // the samples of burst q + 2 travel while q and q + 1 are worked on
@@ -1925,7 +1928,10 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 				const char *e = getenv("GMR1_HIP_LDS_PAD");
 				pad = e ? (size_t)atoi(e) : 0;
 			}
-			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw);
+			// small batches (the receive loop's rounds): one burst per wave, four times the waves
+			const int bpw = a.n <= 4096 ? 1 : 4;
+			const int grid4 = (a.n + bpw - 1) / bpw;
+			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
 		}
 	} else {
 		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
