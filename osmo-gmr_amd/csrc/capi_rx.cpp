@@ -13,8 +13,9 @@
 // step runs on the GPU; the host keeps only the per-chain integers the reference keeps in
 // struct chan_desc.  There is no CPU fallback.
 //
-// Out of scope exactly as SURVEY.md 8f says: TCH3 / TCH9 follow-up after an IMM.ASS, GSMTAP
-// transport, per-burst stderr logging.  What GSMTAP would have carried comes back as records.
+// The traffic channels never feed back into that loop, so their follow-ups run after it as batched
+// passes of their own (RxRun::tch3_pass, RxRun::tch9_pass).  GSMTAP transport and per-burst stderr
+// logging are out of scope; what GSMTAP would have carried comes back as records.
 
 #include "capi_common.h"
 
@@ -150,40 +151,33 @@ template <typename T> T *dat(DBuf &d, size_t off) { return reinterpret_cast<T *>
 
 size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-}  // namespace
 
-extern "C" {
+// One call of gmr1_hip_rx_run*: what the phases share.  The phases run in the order the reference's main()
+// runs them (gmr1_rx.c:897-975); each is one member function below.
+struct RxRun {
+	hipStream_t st;
+	int sps;
+	const float *iq, *tch, *csd;
+	const uint64_t *offset, *length;
+	const uint16_t *arfcn;
+	const uint8_t *kc;
+	int A;                                   // carriers
+	int flen;                                // samples of an FCCH burst
+	int r = 0;
+	std::vector<int32_t> stat, nch;          // per carrier: status, chains followed
+	std::vector<int> align, base_align;
+	std::vector<float> ferr;
+	std::vector<RxChain> chains;
 
-int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
-                             const float *csd, const uint64_t *offset, const uint64_t *length,
-                             const uint16_t *arfcn, const uint8_t *kc,
-                             struct gmr1_hip_rx_record *out, int max_records, int *n_records,
-                             struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
-                             int32_t *status, int32_t *n_chains)
+	int acquire();        // fcch_single_init + fcch_multi_process
+	int frame_loop();     // process_bcch: BCCH / CCCH, in rounds
+	int tch3_pass();      // rx_tch3 and its helpers
+	int tch9_pass();      // rx_tch9
+};
+
+
+int RxRun::acquire()
 {
-	hipStream_t st = (hipStream_t)stream_;
-	if (n_records) *n_records = 0;
-	if (n_big) *n_big = 0;
-	if (csd && (!tch || !n_big || max_big < 0 || (max_big > 0 && !big_out)))
-		return fail(-EINVAL, "rx_run: the CSD carrier needs the traffic carrier and the big-record outputs");
-	if (n_arfcn < 0 || !iq || !offset || !length || !n_records || (max_records > 0 && !out) || max_records < 0)
-		return fail(-EINVAL, "rx_run: iq/offset/length/n_records (and out when max_records > 0) are required");
-	if (sps < 4 || sps > 8)
-		return fail(-EINVAL, "rx_run: sps=%d unsupported (4..8)", sps);
-	DevState *ds;
-	int r = dev_state(&ds);
-	if (r) return r;
-	if (n_arfcn == 0) return 0;
-	for (int i = 0; i < n_arfcn; i++)
-		if (length[i] > 0x7fffffffull)
-			return fail(-EINVAL, "rx_run: carrier %d longer than 2^31-1 samples", i);
-
-	const int A = n_arfcn;
-	const int flen = kFcchLen * sps;
-	std::vector<int32_t> stat(A, 0), nch(A, 0);
-	std::vector<int> align(A, kStartDiscard), base_align(A, 0);
-	std::vector<float> ferr(A, 0.0f);
-
 	// ---- scratch for the acquisition sweeps: per carrier / per candidate --------------------
 	const size_t C = (size_t)A * kMaxPeaks;
 	DBuf d_off, d_fs, d_i0, d_i1, d_f0;
@@ -254,7 +248,6 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	}
 
 	// ---- fcch_multi_process (gmr1_rx.c:643-744) -----------------------------------------------
-	std::vector<RxChain> chains;
 	{
 		const int wl = (650 * kSymRate * sps) / 1000;
 		idx.clear();
@@ -364,6 +357,11 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 		}
 	}
 
+	return 0;
+}
+
+int RxRun::frame_loop()
+{
 	// ---- process_bcch (gmr1_rx.c:852-895) for every chain, in rounds ---------------------------
 	const int frame_len = sps * 24 * 39;
 	const size_t cap = std::max<size_t>(1, chains.size() * kPerRound);
@@ -470,6 +468,11 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 		}
 	}
 
+	return 0;
+}
+
+int RxRun::tch3_pass()
+{
 	// ---- TCH3 follow-up (rx_tch3, gmr1_rx.c:355-600) ----------------------------------------------
 	// Nothing the traffic channel does feeds back into the BCCH / CCCH loop, so it runs afterwards,
 	// for all chains at once, in four steps:
@@ -757,6 +760,11 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 		}
 	}
 
+	return 0;
+}
+
+int RxRun::tch9_pass()
+{
 	// ---- TCH9 follow-up (rx_tch9, gmr1_rx.c:262-353) ----------------------------------------------
 	// From the frame of a chain's first ASSIGNMENT COMMAND 1 on, every frame's NT9 burst on the assigned
 	// timeslot of the CSD carrier: demodulate (sync sequence 0 = FACCH9, 1 = TCH9), decipher with A5/1 of the
@@ -920,6 +928,53 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 			}
 		}
 	}
+
+	return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
+                             const float *csd, const uint64_t *offset, const uint64_t *length,
+                             const uint16_t *arfcn, const uint8_t *kc,
+                             struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                             struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
+                             int32_t *status, int32_t *n_chains)
+{
+	hipStream_t st = (hipStream_t)stream_;
+	if (n_records) *n_records = 0;
+	if (n_big) *n_big = 0;
+	if (csd && (!tch || !n_big || max_big < 0 || (max_big > 0 && !big_out)))
+		return fail(-EINVAL, "rx_run: the CSD carrier needs the traffic carrier and the big-record outputs");
+	if (n_arfcn < 0 || !iq || !offset || !length || !n_records || (max_records > 0 && !out) || max_records < 0)
+		return fail(-EINVAL, "rx_run: iq/offset/length/n_records (and out when max_records > 0) are required");
+	if (sps < 4 || sps > 8)
+		return fail(-EINVAL, "rx_run: sps=%d unsupported (4..8)", sps);
+	DevState *ds;
+	int r = dev_state(&ds);
+	if (r) return r;
+	if (n_arfcn == 0) return 0;
+	for (int i = 0; i < n_arfcn; i++)
+		if (length[i] > 0x7fffffffull)
+			return fail(-EINVAL, "rx_run: carrier %d longer than 2^31-1 samples", i);
+
+	RxRun run;
+	run.st = st; run.sps = sps; run.iq = iq; run.tch = tch; run.csd = csd;
+	run.offset = offset; run.length = length; run.arfcn = arfcn; run.kc = kc;
+	run.A = n_arfcn;
+	run.flen = kFcchLen * sps;
+	run.stat.assign(n_arfcn, 0); run.nch.assign(n_arfcn, 0);
+	run.align.assign(n_arfcn, kStartDiscard); run.base_align.assign(n_arfcn, 0);
+	run.ferr.assign(n_arfcn, 0.0f);
+	if ((r = run.acquire())) return r;
+	if ((r = run.frame_loop())) return r;
+	if (tch && (r = run.tch3_pass())) return r;
+	if (csd && (r = run.tch9_pass())) return r;
+	const std::vector<RxChain> &chains = run.chains;
+	const std::vector<int32_t> &stat = run.stat, &nch = run.nch;
+	const int A = n_arfcn;
 
 	// ---- hand back: carriers in order, chains in order, frames in order -------------------------
 	int total = 0;
