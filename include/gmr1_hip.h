@@ -312,6 +312,7 @@ int gmr1_hip_rx_run_full(int n_arfcn, int sps, const float *iq, const float *tch
  * builds for one record: 16-byte gsmtap_hdr + L2.  Returns the packet length (16 + rec->len) or
  * -EINVAL.  Host-only; works without a GPU.  with_arfcn = 0 leaves the arfcn field 0 as the reference does. */
 int gmr1_hip_gsmtap_pack(const struct gmr1_hip_rx_record *rec, int with_arfcn, uint8_t *buf, int buf_len);
+int gmr1_hip_gsmtap_pack_big(const struct gmr1_hip_rx_big_record *rec, int with_arfcn, uint8_t *buf, int buf_len);
 
 #ifdef __cplusplus
 }

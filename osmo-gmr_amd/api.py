@@ -36,7 +36,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
     "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
-    "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch", "gmr1_hip_rx_run_full_dev", "gmr1_hip_rx_run_full",
+    "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch", "gmr1_hip_rx_run_full_dev", "gmr1_hip_rx_run_full", "gmr1_hip_gsmtap_pack_big",
     "gmr1_hip_channelize_plan", "gmr1_hip_channelize_dev", "gmr1_hip_channelize",
     "gmr1_hip_facch9_decode_batch_dev", "gmr1_hip_facch9_decode_batch", "gmr1_facch9_decode",
     "gmr1_hip_tch9_decode_batch_dev", "gmr1_hip_tch9_decode_batch",
@@ -818,3 +818,15 @@ def rx_run_full(iq, tch, csd, offset, length, sps=4, arfcn=None, kc=None, max_re
            status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p))
     _check(rc, "gmr1_hip_rx_run_full")
     return (out[:min(n_rec.value, max_records)].copy(), big[:min(n_big.value, max_big)].copy(), status[:n], chains[:n])
+
+
+def gsmtap_pack_big(record, with_arfcn=False) -> bytes:
+    """gmr1_hip_gsmtap_pack_big: the GSMTAP packet of one RX_BIG_RECORD (FACCH9 / TCH9 payloads)."""
+    rec = np.ascontiguousarray(np.asarray(record, RX_BIG_RECORD).reshape(1))
+    buf = (C.c_uint8 * 96)()
+    f = load().gmr1_hip_gsmtap_pack_big
+    f.restype = C.c_int
+    n = f(rec.ctypes.data_as(C.c_void_p), C.c_int(1 if with_arfcn else 0), buf, C.c_int(96))
+    if n < 0:
+        _check(n, "gmr1_hip_gsmtap_pack_big")
+    return bytes(buf[:n])

@@ -1105,29 +1105,42 @@ int gmr1_hip_rx_run(int n_arfcn, int sps, const float *iq, uint64_t iq_len,
 // timeslot, arfcn BE16, signal_dbm, snr_db, frame_number BE32, sub_type, antenna_nr, sub_slot, res)
 // followed by the L2 bytes.  The reference leaves the arfcn field 0; with_arfcn != 0 fills it.
 // Host-only byte packing (the I/O sink itself -- the UDP socket -- stays with the caller).
-int gmr1_hip_gsmtap_pack(const struct gmr1_hip_rx_record *rec, int with_arfcn, uint8_t *buf, int buf_len)
+static int gsmtap_pack_any(uint16_t arfcn, uint8_t type, uint32_t fn, uint8_t tn, const uint8_t *l2, int len,
+                           int max_len, int with_arfcn, uint8_t *buf, int buf_len)
 {
-	if (!rec || !buf)
-		return fail(-EINVAL, "gsmtap_pack: rec / buf are required");
-	const int total = 16 + rec->len;
-	if (rec->len > 24 || buf_len < total)
+	const int total = 16 + len;
+	if (len > max_len || buf_len < total)
 		return fail(-EINVAL, "gsmtap_pack: need %d bytes, have %d", total, buf_len);
 	std::memset(buf, 0, 16);
 	buf[0] = 2;                       // GSMTAP_VERSION
 	buf[1] = 4;                       // sizeof(struct gsmtap_hdr) / 4
 	buf[2] = 0x0a;                    // GSMTAP_TYPE_GMR1_UM
-	buf[3] = rec->tn;
+	buf[3] = tn;
 	if (with_arfcn) {
-		buf[4] = (uint8_t)((rec->arfcn >> 8) & 0x3f);     // 14-bit ARFCN, flags clear
-		buf[5] = (uint8_t)(rec->arfcn & 0xff);
+		buf[4] = (uint8_t)((arfcn >> 8) & 0x3f);     // 14-bit ARFCN, flags clear
+		buf[5] = (uint8_t)(arfcn & 0xff);
 	}
-	buf[8] = (uint8_t)(rec->fn >> 24);                    // htonl(fn)
-	buf[9] = (uint8_t)(rec->fn >> 16);
-	buf[10] = (uint8_t)(rec->fn >> 8);
-	buf[11] = (uint8_t)rec->fn;
-	buf[12] = rec->type;              // GSMTAP_GMR1_BCCH 0x01 / GSMTAP_GMR1_CCCH 0x02
-	std::memcpy(buf + 16, rec->l2, rec->len);
+	buf[8] = (uint8_t)(fn >> 24);                    // htonl(fn)
+	buf[9] = (uint8_t)(fn >> 16);
+	buf[10] = (uint8_t)(fn >> 8);
+	buf[11] = (uint8_t)fn;
+	buf[12] = type;                   // GSMTAP_GMR1_BCCH 0x01, CCCH 0x02, TCH3 0x10 (| FACCH 0x02), TCH9 0x18 (| FACCH 0x02)
+	std::memcpy(buf + 16, l2, (size_t)len);
 	return total;
+}
+
+int gmr1_hip_gsmtap_pack(const struct gmr1_hip_rx_record *rec, int with_arfcn, uint8_t *buf, int buf_len)
+{
+	if (!rec || !buf)
+		return fail(-EINVAL, "gsmtap_pack: rec / buf are required");
+	return gsmtap_pack_any(rec->arfcn, rec->type, rec->fn, rec->tn, rec->l2, rec->len, 24, with_arfcn, buf, buf_len);
+}
+
+int gmr1_hip_gsmtap_pack_big(const struct gmr1_hip_rx_big_record *rec, int with_arfcn, uint8_t *buf, int buf_len)
+{
+	if (!rec || !buf)
+		return fail(-EINVAL, "gsmtap_pack: rec / buf are required");
+	return gsmtap_pack_any(rec->arfcn, rec->type, rec->fn, rec->tn, rec->l2, rec->len, 64, with_arfcn, buf, buf_len);
 }
 
 }  // extern "C"

@@ -133,3 +133,13 @@ def test_gsmtap_packet_layout(pkg):
     assert pkt[16:] == bytes(range(100, 124))
     pkt2 = api.gsmtap_pack(rec[0], with_arfcn=True)
     assert pkt2[4:6] == bytes([1007 >> 8, 1007 & 0xFF]) and pkt2[6:] == pkt[6:]
+
+
+def test_gsmtap_big_packet_layout(pkg):
+    api = pkg.api
+    rec = np.zeros(1, api.RX_BIG_RECORD)
+    rec["type"], rec["fn"], rec["tn"], rec["len"] = 0x18, 123456, 5, 60
+    rec["l2"][0][:60] = np.arange(60, dtype=np.uint8)
+    pkt = api.gsmtap_pack_big(rec[0])
+    assert len(pkt) == 76 and pkt[:4] == bytes([2, 4, 0x0A, 5]) and pkt[12] == 0x18
+    assert pkt[8:12] == (123456).to_bytes(4, "big") and pkt[16:] == bytes(range(60))
