@@ -195,13 +195,26 @@ def run_side_workload(args):
         toa = torch.zeros(n, dtype=torch.int32, device=dev)
         rv = torch.zeros(n, dtype=torch.int32, device=dev)
 
+        import ctypes as C
+        f_fine = api.load().gmr1_hip_fcch_fine_batch_dev
+        f_fine.restype = C.c_int
+        ftoa = torch.zeros(n, dtype=torch.int32, device=dev)
+        ferr = torch.zeros(n, dtype=torch.float32, device=dev)
+
         def step():
             api.fcch_rough_batch_dev(stream.cuda_stream, "fcch", n, 4, ns, iq.data_ptr(), offset.data_ptr(), None,
                                      toa.data_ptr(), rv.data_ptr())
+            # fine stage on the burst the rough sweep found (fcch_single_init, gmr1_rx.c:605-639); the offsets
+            # stay on the device
+            off_f = offset + torch.clamp(toa.to(torch.int64), 0, ns - 117 * 4)
+            rc = f_fine(C.c_void_p(stream.cuda_stream), C.c_int(0), C.c_int(n), C.c_int(4), C.c_void_p(iq.data_ptr()),
+                        C.c_void_p(off_f.data_ptr()), None, C.c_void_p(ftoa.data_ptr()), C.c_void_p(ferr.data_ptr()))
+            assert rc == 0
         units, unit = n * ns / 1e6, "Msamp/s"
         bytes_per_launch = n * (ns * 8 + 4)
-        kernel = "k_fcch_stats + k_fcch_corr<117> + k_fcch_pick"
-        workload = f"configs[1]: FCCH rough sweep, {n} x 1-s streams @ 93.6 ksps (23 284 lags x 117 taps each)"
+        kernel = "k_fcch_stats + k_fcch_corr<117> + k_fcch_pick (+ k_fcch_fine)"
+        workload = (f"configs[1]: FCCH rough + fine, {n} x 1-s streams @ 93.6 ksps (rough: 23 284 lags x 117 taps each; "
+                    "fine: 117-point DFT of the found burst)")
     else:
         n = args.bursts * 10
         wl = workloads.tch3_bursts(pkg, n, seed=5)
