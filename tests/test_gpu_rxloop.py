@@ -223,3 +223,33 @@ def test_rx_loop_tch9_follow_up_matches_oracle(gpu_api, orc, pkg):
     rec2, big2, _, _ = gpu_api.rx_run_full(np.concatenate(bc), np.concatenate(tc), None, offset, length, sps=SPS,
                                            kc=np.stack(kcs))
     assert len(big2) == 0 and _key_n(rec2) == _key_n(rec)
+
+
+@pytest.mark.timeout(120)
+def test_rx_loop_survives_hostile_samples(gpu_api, pkg):
+    """NaN / Inf / huge values in the capture: every loop in the path has a data-independent trip count, so
+    the call returns (with whatever it could decode) instead of hanging or faulting."""
+    x, sent = workloads.bcch_carrier(pkg, 71, seconds=2.5, sps=SPS, stn=3, delay=2)
+    rng = np.random.default_rng(0)
+    bad = x.copy()
+    idx = rng.choice(bad.size, 400, replace=False)
+    bad[idx[:100]] = np.nan
+    bad[idx[100:200]] = np.inf
+    bad[idx[200:300]] = 1e30
+    bad[idx[300:]] = -np.inf + 1j * np.nan
+    allnan = np.full(x.size, np.nan + 1j * np.nan, np.complex64)
+    streams = [bad, allnan, x]
+    length = np.array([s.size for s in streams], np.uint64)
+    offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.uint64)
+    rec, status, chains, found = gpu_api.rx_run(np.concatenate(streams), offset, length, sps=SPS)
+    clean = rec[rec["arfcn"] == 2]
+    mb, nb, mc, nc, mp = workloads.match_records(clean, sent)
+    assert nb >= 5 and mp == nb                     # the clean carrier next to them is untouched
+    assert len(rec[rec["arfcn"] == 1]) == 0
+    # the fused kernel on its own
+    n = 64
+    wl = workloads.bcch_ccch_mix(pkg, n=n, seed=2)
+    iq = wl["iq"].copy()
+    iq[rng.choice(iq.size, 2000, replace=False)] = np.nan
+    got = gpu_api.rx_bcch_ccch_batch(iq, wl["offset"], wl["kind"], sps=SPS)
+    assert got["rv"].shape == (n,)
