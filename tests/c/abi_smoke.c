@@ -1,0 +1,46 @@
+/* A C99 translation unit that uses the boundary the way a maintainer of the reference would:
+ * every public header must be plain C, the structs must have the documented sizes, and the program
+ * must link against libgmr1_hip.so and run without a GPU as far as non-compute calls go. */
+#include <stdio.h>
+#include <string.h>
+
+#include <gmr1_hip.h>
+#include <osmocom/gmr1/sdr/defs.h>
+#include <osmocom/gmr1/sdr/pi4cxpsk.h>
+#include <osmocom/gmr1/sdr/nb.h>
+#include <osmocom/gmr1/sdr/fcch.h>
+#include <osmocom/gmr1/sdr/dkab.h>
+#include <osmocom/gmr1/l1/bcch.h>
+#include <osmocom/gmr1/l1/ccch.h>
+#include <osmocom/gmr1/l1/facch3.h>
+#include <osmocom/gmr1/l1/facch9.h>
+#include <osmocom/gmr1/l1/tch3.h>
+#include <osmocom/gmr1/l1/a5.h>
+
+int main(void)
+{
+	struct gmr1_hip_rx_record rec;
+	struct gmr1_hip_rx_big_record big;
+	uint8_t pkt[96];
+	int n;
+
+	if (sizeof(rec) != 40 || sizeof(big) != 80) {
+		fprintf(stderr, "record sizes %zu / %zu\n", sizeof(rec), sizeof(big));
+		return 1;
+	}
+	/* the exported burst descriptions are ordinary data objects, as in the reference (sdr/nb.h) */
+	if (gmr1_bcch_burst.len != 234 || gmr1_dc6_burst.len != 234 || gmr1_nt3_speech_burst.len != 117 ||
+	    gmr1_nt9_burst.len != 351 || gmr1_fcch_burst.len != 117) {
+		fprintf(stderr, "burst tables\n");
+		return 2;
+	}
+	memset(&rec, 0, sizeof(rec));
+	rec.type = 1; rec.fn = 0x01020304; rec.tn = 7; rec.len = 24;
+	n = gmr1_hip_gsmtap_pack(&rec, 0, pkt, (int)sizeof(pkt));     /* host-only call */
+	if (n != 40 || pkt[0] != 2 || pkt[2] != 0x0a || pkt[3] != 7 || pkt[8] != 1 || pkt[11] != 4) {
+		fprintf(stderr, "gsmtap pack %d\n", n);
+		return 3;
+	}
+	printf("%s\n", gmr1_hip_version());
+	return 0;
+}

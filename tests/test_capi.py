@@ -143,3 +143,19 @@ def test_gsmtap_big_packet_layout(pkg):
     pkt = api.gsmtap_pack_big(rec[0])
     assert len(pkt) == 76 and pkt[:4] == bytes([2, 4, 0x0A, 5]) and pkt[12] == 0x18
     assert pkt[8:12] == (123456).to_bytes(4, "big") and pkt[16:] == bytes(range(60))
+
+
+def test_headers_are_plain_c_and_link(pkg, tmp_path):
+    """tests/c/abi_smoke.c: a C99 program over every public header, linked against the library, run without a GPU."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = os.path.join(ROOT, "tests", "c", "abi_smoke.c")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.dirname(pkg.api.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), src,
+                           "-o", exe, "-L" + libdir, "-lgmr1_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip()
