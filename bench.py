@@ -427,7 +427,10 @@ def main():
                                "sample": f"first {m} bursts of the same workload, gcc -O2 oracle, 1 thread, {tc:.1f} s"}
         out["checks"]["gpu_vs_oracle_crc_identical"] = same_crc
         out["checks"]["gpu_vs_oracle_payloads_identical"] = same_l2
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
