@@ -301,17 +301,24 @@ def main():
             print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GMR1_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices and the barrier / max-reduction run over gloo); the driver never sets it
+    backend = os.environ.get("GMR1_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = load_package()
     api = pkg.api
     api.load()
-    api.init(local_rank)
+    api.init(dev_index)
 
     n = args.bursts
     t_gen = time.time()
@@ -362,7 +369,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
