@@ -1929,7 +1929,12 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 				pad = e ? (size_t)atoi(e) : 0;
 			}
 			// small batches (the receive loop's rounds): one burst per wave, four times the waves
-			const int bpw = a.n <= 4096 ? 1 : 4;
+			static int bpw_force = -1;          // profiling only: GMR1_HIP_RX_BPW = 1 | 4
+			if (bpw_force < 0) {
+				const char *e = getenv("GMR1_HIP_RX_BPW");
+				bpw_force = e ? atoi(e) : 0;
+			}
+			const int bpw = bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4);
 			const int grid4 = (a.n + bpw - 1) / bpw;
 			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
 		}
