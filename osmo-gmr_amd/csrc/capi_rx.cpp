@@ -8,7 +8,8 @@
 // burst is independent, and different chains / carriers are independent throughout.  The driver
 // below therefore runs in ROUNDS: each live chain contributes the CCCH bursts up to and including
 // its next BCCH burst, all of them go through ONE fused k_rx4 launch, the host applies the BCCH
-// feedback (a few integers per chain) and the next round starts.  FCCH acquisition is three
+// feedback (a few integers per chain) and the next round starts.  A round's operands and results
+// (a few kilobytes) live in pinned host memory the kernel reads and writes directly.  FCCH acquisition is three
 // batched sweeps (rough / rough_multi / fine + snr) over all carriers.  The arithmetic of every
 // step runs on the GPU; the host keeps only the per-chain integers the reference keeps in
 // struct chan_desc.  There is no CPU fallback.
@@ -140,14 +141,22 @@ struct TchJob {           // a decode the walk asks for: a speech burst or a FAC
 	uint32_t bi_fn[4];
 };
 
+// pinned, coherent host memory the device reads and writes directly (zero copy): the per-round operands
+// are a few kilobytes, and a kernel that fetches them over the link is cheaper than two extra copy
+// submissions per round
 struct Pinned {
-	void *p = nullptr;
+	void *p = nullptr;      // host address
+	void *d = nullptr;      // the same memory as the device sees it
 	~Pinned() { if (p) (void)hipHostFree(p); }
-	hipError_t alloc(size_t n) { return hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault); }
+	hipError_t alloc(size_t n)
+	{
+		hipError_t e = hipHostMalloc(&p, n ? n : 1, hipHostMallocMapped | hipHostMallocCoherent);
+		if (e != hipSuccess) return e;
+		return hipHostGetDevicePointer(&d, p, 0);
+	}
 	template <typename T> T *at(size_t off) { return reinterpret_cast<T *>(static_cast<char *>(p) + off); }
+	template <typename T> T *dev(size_t off) { return reinterpret_cast<T *>(static_cast<char *>(d) + off); }
 };
-
-template <typename T> T *dat(DBuf &d, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(d.p) + off); }
 
 size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
 
@@ -370,10 +379,7 @@ int RxRun::frame_loop()
 	const size_t o_l2 = 0, o_crc = up16(o_l2 + cap * 24), o_conv = up16(o_crc + cap * 4), o_toa = up16(o_conv + cap * 4),
 	             o_fe = up16(o_toa + cap * 4), o_rv = up16(o_fe + cap * 4), o_en = up16(o_rv + cap * 4),
 	             out_bytes = up16(o_en + cap * 4);
-	DBuf d_in, d_out;
 	Pinned p_in, p_out;
-	HIP_TRY(d_in.alloc(in_bytes));
-	HIP_TRY(d_out.alloc(out_bytes));
 	HIP_TRY(p_in.alloc(in_bytes));
 	HIP_TRY(p_out.alloc(out_bytes));
 	std::vector<Item> items;
@@ -423,13 +429,11 @@ int RxRun::frame_loop()
 		const int n = (int)items.size();
 		if (!n)
 			break;
-		HIP_TRY(hipMemcpyAsync(d_in.p, p_in.p, in_bytes, hipMemcpyHostToDevice, st));
-		r = rx_bcch_ccch_dev_impl(st, n, sps, iq, dat<uint64_t>(d_in, o_off), dat<uint8_t>(d_in, o_kind),
-		                          dat<float>(d_in, o_fs), dat<uint8_t>(d_out, o_l2), dat<int32_t>(d_out, o_crc),
-		                          dat<int32_t>(d_out, o_conv), dat<float>(d_out, o_toa), dat<float>(d_out, o_fe),
-		                          dat<float>(d_out, o_en), nullptr, nullptr, dat<int32_t>(d_out, o_rv));
+		r = rx_bcch_ccch_dev_impl(st, n, sps, iq, p_in.dev<uint64_t>(o_off), p_in.dev<uint8_t>(o_kind),
+		                          p_in.dev<float>(o_fs), p_out.dev<uint8_t>(o_l2), p_out.dev<int32_t>(o_crc),
+		                          p_out.dev<int32_t>(o_conv), p_out.dev<float>(o_toa), p_out.dev<float>(o_fe),
+		                          p_out.dev<float>(o_en), nullptr, nullptr, p_out.dev<int32_t>(o_rv));
 		if (r) return r;
-		HIP_TRY(hipMemcpyAsync(p_out.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		for (int k = 0; k < n; k++) {
 			const Item &it = items[k];
