@@ -174,6 +174,20 @@ int gmr1_hip_tch9_decode_batch_dev(void *stream, int n_chan, int seq_len, int mo
 int gmr1_hip_tch9_decode_batch(int n_chan, int seq_len, int mode, const int8_t *ebits, const uint8_t *ciph,
                                uint8_t *l2, int8_t *sacch, int8_t *status, int32_t *conv);
 
+/* ---- the two layer-1 decoders gmr1_rx does not call ----------------------------------------------------
+ * xCH over DC12 (gmr1_xch_dc12_decode, include/osmocom/gmr1/l1/xch_dc12.h:38): ebits n x 432 -> l2 n x 24,
+ * crc[n] (0 = pass), conv[n] (optional).  K = 9 rate 1/3 tail-biting, 256 states.
+ * RACH (gmr1_rach_decode, include/osmocom/gmr1/l1/rach.h:38-39): ebits n x 494, sb_mask[n] -> rach n x 18,
+ * rv[n] (0 = both CRCs pass), conv[n] and crc[n x 2] = {CRC8, CRC12} (both optional).
+ * _dev: device pointers (ebits 4-byte, l2 2-byte aligned), asynchronous on `stream`. */
+int gmr1_hip_xch_dc12_decode_batch_dev(void *stream, int n, const int8_t *ebits, uint8_t *l2, int32_t *crc,
+                                       int32_t *conv);
+int gmr1_hip_xch_dc12_decode_batch(int n, const int8_t *ebits, uint8_t *l2, int32_t *crc, int32_t *conv);
+int gmr1_hip_rach_decode_batch_dev(void *stream, int n, const int8_t *ebits, const uint8_t *sb_mask,
+                                   uint8_t *rach, int32_t *rv, int32_t *conv, int32_t *crc);
+int gmr1_hip_rach_decode_batch(int n, const int8_t *ebits, const uint8_t *sb_mask, uint8_t *rach, int32_t *rv,
+                               int32_t *conv, int32_t *crc);
+
 /* ---- FCCH acquisition ------------------------------------------------------
  * fcch_type: 0 gmr1_fcch_burst, 1 gmr1_fcch3_lband_burst, 2 gmr1_fcch3_sband_burst.
  * rough: n search windows of `len` samples each -> toa[i] (samples), rv[i] (0 / -errno).

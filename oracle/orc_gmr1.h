@@ -117,6 +117,12 @@ void orc_tch9_decode(uint8_t *l2, orc_sbit_t *bits_sacch, orc_sbit_t *bits_statu
                      int mode, const orc_ubit_t *ciph, struct orc_interleaver *il, int *conv_rv);
 int  orc_tch9_punct(int mode, int *idx);
 
+/* ---- xCH over DC12 (reference include/osmocom/gmr1/l1/xch_dc12.h:37-38) and RACH (l1/rach.h:37-39) */
+void orc_xch_dc12_encode(orc_ubit_t *bits_e, const uint8_t *l2);
+int  orc_xch_dc12_decode(uint8_t *l2, const orc_sbit_t *bits_e, int *conv_rv);
+void orc_rach_encode(orc_ubit_t *bits_e, const uint8_t *rach, uint8_t sb_mask);
+int  orc_rach_decode(uint8_t *rach, const orc_sbit_t *bits_e, uint8_t sb_mask, int *conv_rv, int *crc_rv);
+
 /* ---- batch drivers used by tests and by bench.py's cpu_baseline leg only */
 
 /* kind: 0 = BCCH (orc_burst BCCH + bcch_decode), 1 = CCCH (DC6 + ccch_decode) */

@@ -42,6 +42,8 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_tch9_decode_batch_dev", "gmr1_hip_tch9_decode_batch",
     "gmr1_hip_dkab_demod_batch_dev", "gmr1_hip_dkab_demod_batch", "gmr1_dkab_demod",
     "gmr1_hip_a5_batch_dev", "gmr1_hip_a5_batch", "gmr1_a5", "gmr1_a5_1",
+    "gmr1_hip_xch_dc12_decode_batch_dev", "gmr1_hip_xch_dc12_decode_batch", "gmr1_xch_dc12_decode",
+    "gmr1_hip_rach_decode_batch_dev", "gmr1_hip_rach_decode_batch", "gmr1_rach_decode",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -755,6 +757,69 @@ def facch9_decode(ebits, ciph=None):
     if crc < 0:
         _check(crc, "gmr1_facch9_decode")
     return l2, sa, stt, crc, conv.value
+
+
+def xch_dc12_decode_batch(ebits):
+    """(n, 432) soft bits of DC12 bursts -> (l2 (n, 24), crc (n,), conv (n,))"""
+    eb, p_eb = _np(ebits, np.int8)
+    n = eb.shape[0]
+    if eb.ndim != 2 or eb.shape[1] != 432:
+        raise ValueError("xch_dc12: ebits must be (n, 432)")
+    l2 = np.zeros((n, 24), np.uint8)
+    crc = np.zeros(n, np.int32)
+    conv = np.zeros(n, np.int32)
+    f = load().gmr1_hip_xch_dc12_decode_batch
+    f.restype = C.c_int
+    rc = f(C.c_int(n), p_eb, l2.ctypes.data_as(C.c_void_p), crc.ctypes.data_as(C.c_void_p),
+           conv.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_xch_dc12_decode_batch")
+    return l2, crc, conv
+
+
+def xch_dc12_decode(ebits):
+    """gmr1_xch_dc12_decode, the reference's own call -> (l2, crc, conv)"""
+    eb, p_eb = _np(ebits, np.int8)
+    l2 = np.zeros(24, np.uint8)
+    conv = C.c_int(0)
+    f = load().gmr1_xch_dc12_decode
+    f.restype = C.c_int
+    crc = f(l2.ctypes.data_as(C.c_void_p), p_eb, C.byref(conv))
+    if crc < 0:
+        _check(crc, "gmr1_xch_dc12_decode")
+    return l2, crc, conv.value
+
+
+def rach_decode_batch(ebits, sb_mask):
+    """(n, 494) soft bits of RACH bursts, sb_mask scalar or (n,) -> (rach (n, 18), rv (n,), conv (n,), crc (n, 2))"""
+    eb, p_eb = _np(ebits, np.int8)
+    n = eb.shape[0]
+    if eb.ndim != 2 or eb.shape[1] != 494:
+        raise ValueError("rach: ebits must be (n, 494)")
+    m = np.ascontiguousarray(np.broadcast_to(np.asarray(sb_mask, np.uint8), (n,)))
+    rach = np.zeros((n, 18), np.uint8)
+    rv = np.zeros(n, np.int32)
+    conv = np.zeros(n, np.int32)
+    crc = np.zeros((n, 2), np.int32)
+    f = load().gmr1_hip_rach_decode_batch
+    f.restype = C.c_int
+    rc = f(C.c_int(n), p_eb, m.ctypes.data_as(C.c_void_p), rach.ctypes.data_as(C.c_void_p),
+           rv.ctypes.data_as(C.c_void_p), conv.ctypes.data_as(C.c_void_p), crc.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_rach_decode_batch")
+    return rach, rv, conv, crc
+
+
+def rach_decode(ebits, sb_mask):
+    """gmr1_rach_decode, the reference's own call -> (rach, rv, conv, (crc8, crc12))"""
+    eb, p_eb = _np(ebits, np.int8)
+    rach = np.zeros(18, np.uint8)
+    conv = C.c_int(0)
+    crc = (C.c_int * 2)()
+    f = load().gmr1_rach_decode
+    f.restype = C.c_int
+    rv = f(rach.ctypes.data_as(C.c_void_p), p_eb, C.c_uint8(int(sb_mask)), C.byref(conv), crc)
+    if rv < 0:
+        _check(rv, "gmr1_rach_decode")
+    return rach, rv, conv.value, (crc[0], crc[1])
 
 
 def tch9_decode_batch(ebits, mode, seq_len, ciph=None):

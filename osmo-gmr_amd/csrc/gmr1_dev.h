@@ -230,6 +230,25 @@ struct Nt9Args {
 	int32_t *conv;             // optional
 };
 hipError_t launch_nt9(const Nt9Args &a, hipStream_t stream);
+// RACH (nt9_kernels.hip, same K = 5 trellis) and xCH over DC12 (xch_kernels.hip, K = 9)
+struct RachArgs {
+	int n;
+	const int8_t *ebits;       // n x 494
+	const uint8_t *sb_mask;    // n
+	uint8_t *rach;             // n x 18
+	int32_t *rv;               // n: 0 = both CRCs pass
+	int32_t *conv;             // optional n
+	int32_t *crc;              // optional n x 2 (CRC8, CRC12)
+};
+hipError_t launch_rach(const RachArgs &a, hipStream_t stream);
+struct XchArgs {
+	int n;
+	const int8_t *ebits;       // n x 432
+	uint8_t *l2;               // n x 24
+	int32_t *crc;              // n
+	int32_t *conv;             // optional n
+};
+hipError_t launch_xch(const XchArgs &a, hipStream_t stream);
 
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
 hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);

@@ -119,6 +119,10 @@ __device__ __forceinline__ uint32_t coded_word(int N, uint32_t s, uint32_t b)
 	uint32_t o = 0;
 	if (N == 2) {
 		o = ((uint32_t)(__popc(reg & 0x19u) & 1) << 1) | (uint32_t)(__popc(reg & 0x17u) & 1);
+	} else if (N == 4) {
+		const uint32_t g4[4] = {0x19u, 0x17u, 0x15u, 0x1fu};          // conv.c:174-181
+		for (int i = 0; i < 4; i++)
+			o = (o << 1) | (uint32_t)(__popc(reg & g4[i]) & 1);
 	} else {
 		const uint32_t g[5] = {0x15u, 0x1bu, 0x1fu, 0x1du, 0x17u};
 		for (int i = 0; i < N; i++)
@@ -360,6 +364,274 @@ __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 	}
 	if (a.conv && loc == 0)
 		a.conv[g] = (int32_t)final_ae;
+}
+
+// ---------------------------------------------------------------------------
+// RACH (reference src/l1/rach.c:127-200): 494 soft bits -> 18 bytes.  K = 5 rate 1/4 over 159 bits
+// (123 class-2 bits + CRC12, then 16 class-1 bits + CRC8 xor SB mask), bits 2 and 3 of the first 135
+// steps punctured (rach.c:53-66); the class-1 part of the burst is sent twice and the two copies are
+// averaged after descrambling (rach.c:161-162).  Same packed-word trellis, four bursts per wavefront.
+// ---------------------------------------------------------------------------
+static constexpr int kRachLen = 159, kRachSteps = 163, kRachWin = 10;     // last window: 15 steps
+
+// map entry: bit 31 punctured; bits 0-9 index into the 494 e-bits, bit 10 the scrambler flips it;
+// bit 22: a second copy exists at bits 11-20 (flip: bit 21)
+struct RachMap { uint32_t m[4 * kRachSteps]; };
+static constexpr uint32_t rach_x2e(int i)      // position in the de-multiplexed burst x -> e (rach.c:150-154)
+{
+	return (uint32_t)(i < 112 ? 136 + i : (i < 248 ? i - 112 : (i < 382 ? 360 + (i - 248) : 248 + (i - 382))));
+}
+static constexpr RachMap make_rach_map()
+{
+	RachMap t{};
+	bool scr[494] = {};
+	uint32_t r = 0x4d4bu;
+	for (int i = 0; i < 494; i++) {
+		const uint32_t b = ((r >> 14) ^ r) & 1u;
+		r = ((r << 1) | b) & 0xffffu;
+		scr[i] = b != 0;
+	}
+	for (int k = 0; k < kRachSteps; k++) {
+		for (int j = 0; j < 4; j++) {
+			uint32_t e = 0;
+			if (k < 135 && j >= 2) {
+				e = kMapPunct;
+			} else if (k < 135) {
+				const int q = 2 * k + j;                                   // bits_c[0..269] = e2p (N = 33, last 6 as sent)
+				const int i2 = q < 264 ? 33 * ((5 * q) & 7) + (q >> 3) : q;
+				const int xi = 112 + i2;
+				e = rach_x2e(xi) | (scr[xi] ? 0x400u : 0u);
+			} else {
+				const int qq = 4 * (k - 135) + j;                          // bits_c[270..381] = e1p (N = 14)
+				const int i1 = 14 * ((5 * qq) & 7) + (qq >> 3);
+				const int xa = i1, xb = i1 + 382;
+				e = rach_x2e(xa) | (scr[xa] ? 0x400u : 0u) | (rach_x2e(xb) << 11) | (scr[xb] ? 0x200000u : 0u) |
+				    0x400000u;
+			}
+			t.m[4 * k + j] = e;
+		}
+	}
+	return t;
+}
+__constant__ RachMap c_rach_map = make_rach_map();
+
+// syndromes: bits 0-11 CRC12 over u[0..122] + u[123..134], bits 16-23 CRC8 over u[135..150] + u[151..158]
+// (crc.c:36-54), 10 bits per lane of a row
+struct SynRach { uint32_t s[16][10]; };
+static constexpr SynRach make_syn_rach()
+{
+	SynRach t{};
+	for (int k = 0; k < kRachLen; k++) {
+		uint32_t v = 0;
+		if (k < 123) {
+			uint32_t crc = 0x800u;
+			for (int i = k; i < 123; i++)
+				crc = (crc & 0x800u) ? (((crc << 1) ^ 0x80fu) & 0xfffu) : ((crc << 1) & 0xfffu);
+			v = crc;
+		} else if (k < 135) {
+			v = 1u << (11 - (k - 123));
+		} else if (k < 151) {
+			uint32_t crc = 0x80u;
+			for (int i = k - 135; i < 16; i++)
+				crc = (crc & 0x80u) ? (((crc << 1) ^ 0x9bu) & 0xffu) : ((crc << 1) & 0xffu);
+			v = crc << 16;
+		} else {
+			v = (1u << (7 - (k - 151))) << 16;
+		}
+		t.s[k / 10][k % 10] = v;
+	}
+	return t;
+}
+__constant__ SynRach c_syn_rach = make_syn_rach();
+
+__global__ __launch_bounds__(64) void k_rach(RachArgs a)
+{
+	__shared__ __align__(16) uint8_t s_ct[4 * kRachSteps * 8];
+	__shared__ uint16_t s_win[kRachWin * 64];
+	__shared__ uint32_t s_ub[4 * 8];
+	const int lane = threadIdx.x;
+	const int row = lane >> 4;
+	const uint32_t loc = (uint32_t)lane & 15u;
+	const int g0 = blockIdx.x * 4;
+	constexpr int stride = 8;
+
+	if (lane < 32)
+		s_ub[lane] = 0;
+	// ---- cost tables: word A = coded bits (0, 1), word B = (2, 3)
+	for (int it = lane; it < 4 * kRachSteps; it += 64) {
+		const int q = it / kRachSteps, k = it % kRachSteps;
+		const int g = g0 + q;
+		uint32_t c0[4] = {0, 0, 0, 0}, c1[4] = {0, 0, 0, 0};
+		if (g < a.n) {
+			const int8_t *e = a.ebits + (size_t)g * 494;
+			for (int j = 0; j < 4; j++) {
+				const uint32_t m = c_rach_map.m[4 * k + j];
+				if (m & kMapPunct)
+					continue;
+				int v = e[m & 0x3ffu];
+				if (m & 0x400u)
+					v = (int8_t)(-v);
+				if (m & 0x400000u) {
+					int v2 = e[(m >> 11) & 0x3ffu];
+					if (m & 0x200000u)
+						v2 = (int8_t)(-v2);
+					v = (int8_t)((v + v2) >> 1);
+				}
+				c0[j] = (uint32_t)sbit_cost(v, 0);
+				c1[j] = (uint32_t)sbit_cost(v, 1);
+			}
+		}
+		uint32_t *dst = reinterpret_cast<uint32_t *>(s_ct + ((size_t)q * kRachSteps + k) * stride);
+		dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
+		dst[1] = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
+	}
+	WSYNC();
+
+	const uint32_t stp = c_k5locs.st[loc], hit = c_k5locs.hi[loc];
+	uint32_t o_own[4][3], o_par[4][3];
+	bool hi[4];
+#pragma unroll
+	for (int ph = 0; ph < 4; ph++) {
+		const uint32_t sp = (stp >> (4 * ph)) & 15u;
+		const uint32_t b = sp >> 3;
+		hi[ph] = b != 0;
+		const uint32_t wo = coded_word(4, sp, b), wp = coded_word(4, sp ^ 8u, b);
+		o_own[ph][0] = wo >> 2; o_own[ph][1] = wo & 3u; o_own[ph][2] = 0;
+		o_par[ph][0] = wp >> 2; o_par[ph][1] = wp & 3u; o_par[ph][2] = 0;
+	}
+	uint32_t T[16];
+#pragma unroll
+	for (int j = 0; j < 16; j++)
+		T[j] = hit & (1u << j);
+
+	// ---- forward pass: 4 steps (decisions u[-4..-1]), nine windows of 16, a last one of 15 steps whose
+	// final four are the flush.  Max metric 163 * 4 * 126 does not fit 16 bits: renormalise every 4 windows.
+	const uint8_t *ct = s_ct + (size_t)row * kRachSteps * stride;
+	uint32_t off = 0;
+	uint32_t w = (loc ? kSent : 0u) | T[0];
+	w = nt9_step<0, 2>(w, ct + 0 * stride, o_own[0], o_par[0]) + T[1];
+	w = nt9_step<1, 2>(w, ct + 1 * stride, o_own[1], o_par[1]) + T[2];
+	w = nt9_step<2, 2>(w, ct + 2 * stride, o_own[2], o_par[2]) + T[3];
+	w = nt9_step<3, 2>(w, ct + 3 * stride, o_own[3], o_par[3]);
+	w = (w & 0xffff0000u) | T[0];
+#pragma unroll 1
+	for (int wm = 0; wm < kRachWin - 1; wm++) {
+		const uint8_t *c = ct + (size_t)(4 + 16 * wm) * stride;
+#pragma unroll
+		for (int j = 0; j < 16; j += 4) {
+			w = nt9_step<0, 2>(w, c + (j + 0) * stride, o_own[0], o_par[0]) + T[(j + 1) & 15];
+			w = nt9_step<1, 2>(w, c + (j + 1) * stride, o_own[1], o_par[1]) + T[(j + 2) & 15];
+			w = nt9_step<2, 2>(w, c + (j + 2) * stride, o_own[2], o_par[2]) + T[(j + 3) & 15];
+			w = nt9_step<3, 2>(w, c + (j + 3) * stride, o_own[3], o_par[3]) + (j + 4 < 16 ? T[(j + 4) & 15] : 0u);
+		}
+		s_win[wm * 64 + lane] = (uint16_t)w;
+		w = (w & 0xffff0000u) | T[0];
+		if ((wm & 3) == 3) {
+			uint32_t mn = w >> 16;
+			mn = row_xor_min<1>(mn);
+			mn = row_xor_min<2>(mn);
+			mn = row_xor_min<4>(mn);
+			mn = row_xor_min<8>(mn);
+			w -= mn << 16;
+			off += mn;
+		}
+	}
+	{
+		const uint8_t *c = ct + (size_t)(4 + 16 * (kRachWin - 1)) * stride;
+		// 11 data steps ...
+#pragma unroll
+		for (int j = 0; j < 8; j += 4) {
+			w = nt9_step<0, 2>(w, c + (j + 0) * stride, o_own[0], o_par[0]) + T[j + 1];
+			w = nt9_step<1, 2>(w, c + (j + 1) * stride, o_own[1], o_par[1]) + T[j + 2];
+			w = nt9_step<2, 2>(w, c + (j + 2) * stride, o_own[2], o_par[2]) + T[j + 3];
+			w = nt9_step<3, 2>(w, c + (j + 3) * stride, o_own[3], o_par[3]) + T[j + 4];
+		}
+		w = nt9_step<0, 2>(w, c + 8 * stride, o_own[0], o_par[0]) + T[9];
+		w = nt9_step<1, 2>(w, c + 9 * stride, o_own[1], o_par[1]) + T[10];
+		w = nt9_step<2, 2>(w, c + 10 * stride, o_own[2], o_par[2]) + T[11];
+		// ... and four flush steps (phases 3, 0, 1, 2): only b = 0 transitions survive
+		w = nt9_step<3, 2>(w, c + 11 * stride, o_own[3], o_par[3]);
+		w = hi[3] ? kSent : (w + T[12]);
+		w = nt9_step<0, 2>(w, c + 12 * stride, o_own[0], o_par[0]);
+		w = hi[0] ? kSent : (w + T[13]);
+		w = nt9_step<1, 2>(w, c + 13 * stride, o_own[1], o_par[1]);
+		w = hi[1] ? kSent : (w + T[14]);
+		w = nt9_step<2, 2>(w, c + 14 * stride, o_own[2], o_par[2]);
+		w = hi[2] ? kSent : w;
+		s_win[(kRachWin - 1) * 64 + lane] = (uint16_t)w;
+	}
+	// 163 = 3 mod 4 steps: the layout is that of phase 3, where location 0 still holds state 0
+	const uint32_t final_ae = (w >> 16) + off;
+	WSYNC();
+
+	// ---- survivor chain, one lane per row.  The last window ends in the phase-3 layout, but the walk
+	// starts from location 0 (state 0) and every window START is in the phase-0 layout.
+	if (loc == 0) {
+		constexpr unsigned long long kLocOf =
+			0x0ull | (0x8ull << 4) | (0x7ull << 8) | (0xFull << 12) | (0x2ull << 16) | (0xAull << 20) |
+			(0x5ull << 24) | (0xDull << 28) | (0x1ull << 32) | (0x9ull << 36) | (0x6ull << 40) |
+			(0xEull << 44) | (0x3ull << 48) | (0xBull << 52) | (0x4ull << 56) | (0xCull << 60);
+		const uint16_t *d16 = s_win + row * 16;
+		uint32_t L = 0, prev = 0;
+		for (int wm = kRachWin - 1; wm >= 0; wm--) {
+			const uint32_t h = d16[wm * 64 + L];
+			L = (uint32_t)(kLocOf >> (4 * (h & 15u))) & 15u;
+			if (wm & 1) {
+				prev = h;
+			} else {
+				s_ub[row * 8 + (wm >> 1)] = h | (prev << 16);
+				prev = 0;
+			}
+		}
+	}
+	WSYNC();
+
+	const int g = g0 + row;
+	if (g >= a.n)
+		return;
+	const uint32_t *u = s_ub + row * 8;
+	uint32_t syn = 0;
+	for (int q = 0; q < 10; q++) {
+		const int k = (int)loc * 10 + q;
+		if (k < kRachLen && ((u[k >> 5] >> (k & 31)) & 1u))
+			syn ^= c_syn_rach.s[loc][q];
+	}
+	syn ^= dppu<0xB1>(syn);
+	syn ^= dppu<0x4E>(syn);
+	syn ^= dppu<0x1B>(dppu<0x141>(syn));
+	syn ^= dppu<0x128>(syn);
+	// rach bits 0..15 = u[135..150], bits 16..138 = u[0..122] (rach.c:194-197), LSB first
+	for (int i = (int)loc; i < 18; i += 16) {
+		const int pos = i < 2 ? 135 + 8 * i : 8 * (i - 2);
+		const unsigned long long two = (unsigned long long)u[pos >> 5] | ((unsigned long long)u[(pos >> 5) + 1] << 32);
+		uint32_t byte = (uint32_t)(two >> (pos & 31)) & 0xffu;
+		if (i == 17)
+			byte &= 0x07u;
+		a.rach[(size_t)g * 18 + i] = (uint8_t)byte;
+	}
+	if (loc == 0) {
+		const uint32_t s12 = syn & 0xfffu, s8 = (syn >> 16) & 0xffu;
+		// CRC8 is first checked as received, then with the SB mask removed (rach.c:176-184)
+		int crc0 = s8 != 0;
+		if (crc0)
+			crc0 = (s8 ^ a.sb_mask[g]) != 0;
+		const int crc1 = s12 != 0;
+		a.rv[g] = crc0 || crc1;
+		if (a.crc) {
+			a.crc[2 * g] = crc0;
+			a.crc[2 * g + 1] = crc1;
+		}
+		if (a.conv)
+			a.conv[g] = (int32_t)final_ae;
+	}
+}
+
+hipError_t launch_rach(const RachArgs &a, hipStream_t stream)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_rach, dim3((a.n + 3) / 4), dim3(64), 0, stream, a);
+	return hipGetLastError();
 }
 
 hipError_t launch_nt9(const Nt9Args &a, hipStream_t stream)

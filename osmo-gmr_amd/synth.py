@@ -169,6 +169,40 @@ def facch3_encode(l2: np.ndarray, bits_s: np.ndarray, ciph: np.ndarray | None = 
     return out
 
 
+K9_13 = (0x1ED, 0x19B, 0x127)      # reference src/l1/conv.c:345-351
+P1213 = np.array([1, 1, 0, 1, 0, 1, 0, 1, 1] * 4 + [1, 1, 1], np.uint8)     # punct.c:1105-1125, 0 = punctured
+
+
+def xch_dc12_encode(l2: np.ndarray) -> np.ndarray:
+    """(B,24) bytes -> (B,432) encoded hard bits of a DC12 burst (reference src/l1/xch_dc12.c:64-79):
+    CRC16, K=9 rate 1/3 tail-biting, P(12;13) puncturing, intra-burst interleaver N=54, scrambler."""
+    u = unpack_lsb(l2, 192)
+    u = np.concatenate([u, crc_bits(u, 16, 0x1021)], axis=1)
+    c = conv_encode(u, K9_13, 9, tail_biting=True)
+    c = c[:, np.tile(P1213, 16) != 0]
+    ep = interleave_intra(c, 54)
+    return ep ^ scramble_mask(432)
+
+
+def rach_encode(rach: np.ndarray, sb_mask: int) -> np.ndarray:
+    """(B,18) bytes -> (B,494) encoded hard bits of a RACH burst (reference src/l1/rach.c:78-125): 16 class-1
+    bits + CRC8 (xor SB mask), 123 class-2 bits + CRC12, K=5 rate 1/4 with bits 2, 3 of the first 135 steps
+    punctured, class-1 part sent twice."""
+    rach = np.asarray(rach, np.uint8)
+    bits = unpack_lsb(rach, 144)
+    u1 = bits[:, :16]
+    u2 = bits[:, 16:139]
+    c1 = crc_bits(u1, 8, 0x9B) ^ np.array([(sb_mask >> (7 - i)) & 1 for i in range(8)], np.uint8)
+    u = np.concatenate([u2, crc_bits(u2, 12, 0x80F), u1, c1], axis=1)
+    c = conv_encode(u, K5_14, 5).reshape(-1, 163, 4)
+    c = np.concatenate([c[:, :135, :2].reshape(-1, 270), c[:, 135:, :].reshape(-1, 112)], axis=1)
+    e1p = interleave_intra(c[:, 270:], 14)
+    e2p = c[:, :270].copy()
+    e2p[:, :264] = interleave_intra(c[:, :264], 33)
+    x = np.concatenate([e1p, e2p, e1p], axis=1) ^ scramble_mask(494)
+    return np.concatenate([x[:, 112:248], x[:, :112], x[:, 382:494], x[:, 248:382]], axis=1)
+
+
 def tch3_perm() -> np.ndarray:
     kc = np.arange(104)
     ii, ij = kc % 24, kc // 24

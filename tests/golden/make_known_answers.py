@@ -10,7 +10,9 @@ Appendix D2), re-derived by this script from the formulas the reference states:
   conv_spot      reference src/l1/conv.c: generator polynomials from the comments at
                  :123-128 (k5_12), :148-154 (k5_13), :174-181 (k5_14), :201-209 (k5_15), :518-523 (tch3)
                  and rows of the next_output tables at :130-135, :155-160, :183-188, :210-215, :525-542
-                 read off the file
+                 read off the file; k9_13: polynomials :345-351, rows of the table at :353-419
+  xch_dc12       reference src/l1/xch_dc12.c:45-54 + src/l1/punct.c:1105-1125: first punctured positions
+                 of P(12;13) = mask 110 101 011 x4 + 111 (0 = punctured)
   tch9_punct     reference src/l1/tch9.c:72-78 + src/l1/punct.c:48-175: the 320 punctured positions of
                  the 9k6 mode
   fcch           reference src/sdr/fcch.c:600-613 constants
@@ -43,11 +45,15 @@ out = {
         "k5_15": {"K": 5, "polys": [0x15, 0x1B, 0x1F, 0x1D, 0x17],
                   "next_output_rows": {"0": [0, 31], "1": [13, 18], "3": [26, 5], "4": [14, 17], "8": [31, 0],
                                        "15": [11, 20]}},
+        "k9_13": {"K": 9, "polys": [0x1ED, 0x19B, 0x127],
+                  "next_output_rows": {"0": [0, 7], "1": [3, 4], "2": [5, 2], "3": [6, 1], "7": [0, 7],
+                                       "100": [4, 3], "128": [7, 0], "255": [2, 5]}},
         "tch3_k7": {"K": 7, "polys": [0x6D, 0x4F],
                     "next_output_rows": {"0": [0, 3], "1": [1, 2], "2": [3, 0], "16": [2, 1], "32": [3, 0],
                                          "63": [0, 3]}},
     },
     "fcch": {"bin_hz": 200.0, "chirp_rate_hz_per_ms": 2995.2, "bcch_period_symbols": 7488},
+    "xch_dc12_punctured_first13": [2, 4, 6, 11, 13, 15, 20, 22, 24, 29, 31, 33, 41],
     "tch9_9k6_punctured": sorted([1, 5] + [10 + 6 * k for k in range(158)] + [13 + 6 * k for k in range(158)] + [963, 967]),
 }
 # SURVEY.md Appendix D2 lists these; assert the derivation agrees with what the survey recorded

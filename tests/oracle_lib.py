@@ -438,6 +438,47 @@ def tch9_punct(mode):
     return np.array(idx[:n], np.int64)
 
 
+def xch_dc12_encode(l2):
+    l2 = np.ascontiguousarray(l2, np.uint8)
+    e = np.zeros(432, np.uint8)
+    lib().orc_xch_dc12_encode(e.ctypes.data_as(C.c_void_p), l2.ctypes.data_as(C.c_void_p))
+    return e
+
+
+def xch_dc12_decode(ebits):
+    """-> (l2[24], crc, conv)"""
+    ebits = np.ascontiguousarray(ebits, np.int8)
+    assert ebits.size == 432
+    l2 = np.zeros(24, np.uint8)
+    conv = C.c_int(0)
+    f = lib().orc_xch_dc12_decode
+    f.restype = C.c_int
+    crc = f(l2.ctypes.data_as(C.c_void_p), ebits.ctypes.data_as(C.c_void_p), C.byref(conv))
+    return l2, crc, conv.value
+
+
+def rach_encode(rach, sb_mask):
+    rach = np.ascontiguousarray(rach, np.uint8)
+    assert rach.size == 18
+    e = np.zeros(494, np.uint8)
+    lib().orc_rach_encode(e.ctypes.data_as(C.c_void_p), rach.ctypes.data_as(C.c_void_p), C.c_uint8(sb_mask))
+    return e
+
+
+def rach_decode(ebits, sb_mask):
+    """-> (rach[18], rv, conv, (crc8, crc12))"""
+    ebits = np.ascontiguousarray(ebits, np.int8)
+    assert ebits.size == 494
+    rach = np.zeros(18, np.uint8)
+    conv = C.c_int(0)
+    crc = (C.c_int * 2)()
+    f = lib().orc_rach_decode
+    f.restype = C.c_int
+    rv = f(rach.ctypes.data_as(C.c_void_p), ebits.ctypes.data_as(C.c_void_p), C.c_uint8(sb_mask),
+           C.byref(conv), crc)
+    return rach, rv, conv.value, (crc[0], crc[1])
+
+
 RX_BIG_RECORD = np.dtype([("arfcn", "<u2"), ("chain", "u1"), ("type", "u1"), ("fn", "<u4"),
                           ("tn", "u1"), ("crc", "u1"), ("len", "u1"), ("pad", "u1"),
                           ("conv", "<i4"), ("l2", "u1", (64,))])
