@@ -40,6 +40,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_channelize_plan", "gmr1_hip_channelize_dev", "gmr1_hip_channelize",
     "gmr1_hip_facch9_decode_batch_dev", "gmr1_hip_facch9_decode_batch", "gmr1_facch9_decode",
     "gmr1_hip_tch9_decode_batch_dev", "gmr1_hip_tch9_decode_batch",
+    "gmr1_tch9_decode", "gmr1_interleaver_init", "gmr1_interleaver_fini",
     "gmr1_hip_dkab_demod_batch_dev", "gmr1_hip_dkab_demod_batch", "gmr1_dkab_demod",
     "gmr1_hip_a5_batch_dev", "gmr1_hip_a5_batch", "gmr1_a5", "gmr1_a5_1",
     "gmr1_hip_xch_dc12_decode_batch_dev", "gmr1_hip_xch_dc12_decode_batch", "gmr1_xch_dc12_decode",
@@ -757,6 +758,51 @@ def facch9_decode(ebits, ciph=None):
     if crc < 0:
         _check(crc, "gmr1_facch9_decode")
     return l2, sa, stt, crc, conv.value
+
+
+class Interleaver(C.Structure):
+    """struct gmr1_interleaver (include/osmocom/gmr1/l1/interleave.h)"""
+    _fields_ = [("N", C.c_int), ("K", C.c_int), ("n", C.c_int), ("bits_cpp", C.c_void_p)]
+
+
+class Tch9Channel:
+    """One TCH9 channel decoded burst by burst with the reference's own stateful calls:
+    gmr1_interleaver_init(&il, 3, 648) once, then gmr1_tch9_decode(...) per burst (gmr1_rx.c:273, :333)."""
+
+    def __init__(self, mode: int, N: int = 3, K: int = 648):
+        self.mode = mode
+        self.il = Interleaver()
+        f = load().gmr1_interleaver_init
+        f.restype = C.c_int
+        _check(f(C.byref(self.il), C.c_int(N), C.c_int(K)), "gmr1_interleaver_init")
+
+    def decode(self, ebits, ciph=None):
+        """-> (l2, sacch (10,), status (4,), conv)"""
+        eb, p_eb = _np(ebits, np.int8)
+        if eb.size != 662:
+            raise ValueError("tch9: a burst has 662 soft bits")
+        p_c = None
+        if ciph is not None:
+            c, p_c = _np(ciph, np.uint8)
+        l2 = np.zeros((18, 30, 60)[self.mode], np.uint8)
+        sa = np.zeros(10, np.int8)
+        stt = np.zeros(4, np.int8)
+        conv = C.c_int(0)
+        f = load().gmr1_tch9_decode
+        f.restype = None
+        f(l2.ctypes.data_as(C.c_void_p), sa.ctypes.data_as(C.c_void_p), stt.ctypes.data_as(C.c_void_p), p_eb,
+          C.c_int(self.mode), p_c, C.byref(self.il), C.byref(conv))
+        return l2, sa, stt, conv.value
+
+    def close(self):
+        if self.il.bits_cpp:
+            load().gmr1_interleaver_fini(C.byref(self.il))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def xch_dc12_decode_batch(ebits):

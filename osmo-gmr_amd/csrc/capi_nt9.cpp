@@ -11,6 +11,8 @@
 
 #include "../../include/gmr1_hip.h"
 #include "../../include/osmocom/gmr1/l1/facch9.h"
+#include "../../include/osmocom/gmr1/l1/interleave.h"
+#include "../../include/osmocom/gmr1/l1/tch9.h"
 
 using namespace gmr1;
 
@@ -227,6 +229,72 @@ int gmr1_facch9_decode(uint8_t *l2, sbit_t *bits_sacch, sbit_t *bits_status,
 	if (r) return r;
 	if (conv_rv) *conv_rv = conv;
 	return crc;
+}
+
+// ---- the reference's stateful single-burst TCH9 call (tch9.h:47-50, interleave.h:40-56) -----------------
+// The history the depth-3 de-interleaver needs is kept as the previous two bursts AS RECEIVED (662 soft
+// bits + 658 key stream bits each); every call decodes the three-burst sequence on the GPU, where the
+// de-interleaving is part of the gather (nt9_kernels.hip), and returns the newest burst's outputs.
+static constexpr int kIlSlot = 662 + 658;
+
+int gmr1_interleaver_init(struct gmr1_interleaver *il, int N, int K)
+{
+	if (!il)
+		return fail(-EINVAL, "gmr1_interleaver_init: NULL");
+	std::memset(il, 0, sizeof(*il));
+	if (N != 3 || K != 648)
+		return fail(-EINVAL, "gmr1_interleaver_init: only the (3, 648) geometry of TCH9 is provided");
+	uint8_t *b = static_cast<uint8_t *>(std::calloc(2, kIlSlot));
+	if (!b)
+		return fail(-ENOMEM, "gmr1_interleaver_init: out of memory");
+	il->N = N;
+	il->K = K;
+	il->bits_cpp = b;
+	return 0;
+}
+
+void gmr1_interleaver_fini(struct gmr1_interleaver *il)
+{
+	if (!il)
+		return;
+	std::free(il->bits_cpp);
+	std::memset(il, 0, sizeof(*il));
+}
+
+void gmr1_tch9_decode(uint8_t *l2, sbit_t *bits_sacch, sbit_t *bits_status, const sbit_t *bits_e,
+                      enum gmr1_tch9_mode mode, const ubit_t *ciph, struct gmr1_interleaver *il, int *conv_rv)
+{
+	static const int kBytes[3] = {18, 30, 60};
+	if (!l2 || !bits_e || !il || !il->bits_cpp || il->N != 3 || il->K != 648 || (int)mode < 0 || (int)mode > 2) {
+		(void)fail(-EINVAL, "gmr1_tch9_decode: bad argument");
+		return;
+	}
+	const int nb = kBytes[(int)mode];
+	// sequence = [burst n-2, burst n-1, this burst]; slot (n & 1) holds burst n-2
+	uint8_t *older = il->bits_cpp + (size_t)(il->n & 1) * kIlSlot, *newer = il->bits_cpp + (size_t)((il->n + 1) & 1) * kIlSlot;
+	int8_t seq_e[3 * 662];
+	uint8_t seq_c[3 * 658];
+	std::memcpy(seq_e, older, 662);
+	std::memcpy(seq_c, older + 662, 658);
+	std::memcpy(seq_e + 662, newer, 662);
+	std::memcpy(seq_c + 658, newer + 662, 658);
+	std::memcpy(seq_e + 2 * 662, bits_e, 662);
+	if (ciph)
+		std::memcpy(seq_c + 2 * 658, ciph, 658);
+	else
+		std::memset(seq_c + 2 * 658, 0, 658);
+	uint8_t out[3 * 60] = {0};
+	int8_t sa[3 * 10] = {0}, stt[3 * 4] = {0};
+	int32_t conv[3] = {0, 0, 0};
+	(void)nt9_host((int)mode, 3, 3, seq_e, seq_c, out, sa, stt, nullptr, conv);
+	std::memcpy(l2, out + 2 * nb, (size_t)nb);
+	if (bits_sacch) std::memcpy(bits_sacch, sa + 20, 10);
+	if (bits_status) std::memcpy(bits_status, stt + 8, 4);
+	if (conv_rv) *conv_rv = conv[2];
+	// this burst replaces burst n-2
+	std::memcpy(older, seq_e + 2 * 662, 662);
+	std::memcpy(older + 662, seq_c + 2 * 658, 658);
+	il->n++;
 }
 
 }  // extern "C"

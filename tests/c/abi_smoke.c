@@ -15,6 +15,10 @@
 #include <osmocom/gmr1/l1/facch3.h>
 #include <osmocom/gmr1/l1/facch9.h>
 #include <osmocom/gmr1/l1/tch3.h>
+#include <osmocom/gmr1/l1/tch9.h>
+#include <osmocom/gmr1/l1/interleave.h>
+#include <osmocom/gmr1/l1/rach.h>
+#include <osmocom/gmr1/l1/xch_dc12.h>
 #include <osmocom/gmr1/l1/a5.h>
 
 int main(void)
@@ -40,6 +44,19 @@ int main(void)
 	if (n != 40 || pkt[0] != 2 || pkt[2] != 0x0a || pkt[3] != 7 || pkt[8] != 1 || pkt[11] != 4) {
 		fprintf(stderr, "gsmtap pack %d\n", n);
 		return 3;
+	}
+	{
+		/* the inter-burst interleaver state is a caller-owned struct of the reference's layout (gmr1_rx.c:90) */
+		struct gmr1_interleaver il;
+		if (gmr1_interleaver_init(&il, 3, 648) != 0 || il.N != 3 || il.K != 648 || il.n != 0 || !il.bits_cpp) {
+			fprintf(stderr, "interleaver init\n");
+			return 4;
+		}
+		gmr1_interleaver_fini(&il);
+		if (il.bits_cpp != NULL || gmr1_interleaver_init(&il, 4, 648) == 0)
+			return 5;
+		if (GMR1_TCH9_9k6 != 2 || sizeof(struct gmr1_interleaver) != 3 * sizeof(int) + sizeof(void *) + (sizeof(void *) - sizeof(int)))
+			return 6;
 	}
 	printf("%s\n", gmr1_hip_version());
 	return 0;

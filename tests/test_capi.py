@@ -93,6 +93,29 @@ def test_exported_struct_layout_matches_reference_abi(pkg):
     assert all(bool(sd.sync[i]) for i in range(4))       # 4 sequences, no NULL terminator
 
 
+# every gmr1_* function / data object the reference's application references (src/gmr1_rx.c), except
+# gmr1_gsmtap_makemsg, which is compiled into the program itself from src/gsmtap.c (src/Makefile.am:8)
+GMR1_RX_LINKS = [
+    "gmr1_a5", "gmr1_bcch_burst", "gmr1_bcch_decode", "gmr1_ccch_decode", "gmr1_dc6_burst", "gmr1_dkab_demod",
+    "gmr1_facch3_decode", "gmr1_facch9_decode", "gmr1_fcch_burst", "gmr1_fcch_fine", "gmr1_fcch_rough",
+    "gmr1_fcch_rough_multi", "gmr1_fcch_snr", "gmr1_interleaver_init", "gmr1_nt3_facch_burst",
+    "gmr1_nt3_speech_burst", "gmr1_nt9_burst", "gmr1_pi4cxpsk_demod", "gmr1_pi4cxpsk_detect", "gmr1_tch3_decode",
+    "gmr1_tch9_decode",
+]
+
+
+def test_library_covers_what_gmr1_rx_links_against(pkg):
+    lib = pkg.api.load()
+    for name in GMR1_RX_LINKS:
+        assert hasattr(lib, name), f"gmr1_rx.c needs {name}"
+    ref = "/root/reference/src/gmr1_rx.c"
+    if os.path.exists(ref):          # only in the build container: the list above is what the file references
+        with open(ref) as f:
+            used = set(re.findall(r"\b(gmr1_[a-z0-9_]+)\b", f.read()))
+        used -= {"gmr1_gsmtap_makemsg", "gmr1_interleaver", "gmr1_pi4cxpsk_burst"}     # own code / type names
+        assert used == set(GMR1_RX_LINKS)
+
+
 def test_no_cpu_fallback(pkg):
     """Without a usable GPU every compute entry point fails loudly (-ENODEV)."""
     import torch
@@ -105,6 +128,12 @@ def test_no_cpu_fallback(pkg):
         pkg.api.rx_bcch_ccch_batch(np.zeros(2048, np.complex64), [0], [0])
     l2, rv, _ = pkg.api.bcch_decode(eb[0])
     assert rv == -19
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.xch_dc12_decode_batch(np.zeros((2, 432), np.int8))
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.rach_decode_batch(np.zeros((2, 494), np.int8), 0)
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.xch_dc12_decode(np.zeros(432, np.int8))
 
 
 def test_product_does_not_reference_oracle():

@@ -79,6 +79,33 @@ def test_tch9_bit_exact(gpu_api, orc, mode, kind):
                 assert np.array_equal(g[0][sl][2:], sent[ch][:-2])
 
 
+@pytest.mark.parametrize("mode", [0, 2])
+def test_tch9_stateful_reference_call(gpu_api, orc, mode):
+    """gmr1_interleaver_init + gmr1_tch9_decode burst by burst, as gmr1_rx.c:273 / :333 call them, against the
+    oracle's stateful decoder (tch9.c:139-175 + interleave.c:163-186)."""
+    rng = np.random.default_rng(40 + mode)
+    seq, nb = 9, orc.TCH9_BYTES[mode]
+    l2 = rng.integers(0, 256, size=(seq, nb), dtype=np.uint8)
+    ciph = rng.integers(0, 2, size=(seq, 658), dtype=np.uint8)
+    hard = orc.tch9_encode_seq(l2, mode, rng.integers(0, 2, (seq, 10)), rng.integers(0, 2, (seq, 4)), ciph)
+    eb = _soft(rng, hard, "noisy")
+    o = orc.tch9_decode_seq(eb, mode, ciph)
+    ch = gpu_api.Tch9Channel(mode)
+    for i in range(seq):
+        g_l2, g_sa, g_st, g_conv = ch.decode(eb[i], ciph[i])
+        assert np.array_equal(g_l2, o[0][i]) and g_conv == o[3][i], (mode, i)
+        assert np.array_equal(g_sa, o[1][i]) and np.array_equal(g_st, o[2][i])
+    ch.close()
+    # without a key stream, and a geometry GMR-1 does not use
+    ch = gpu_api.Tch9Channel(mode)
+    o = orc.tch9_decode_seq(eb[:4], mode, None)
+    for i in range(4):
+        assert np.array_equal(ch.decode(eb[i])[0], o[0][i])
+    ch.close()
+    with pytest.raises(Exception):
+        gpu_api.Tch9Channel(mode, N=4, K=648)
+
+
 def test_nt9_argument_checks(gpu_api):
     eb = np.zeros((6, 662), np.int8)
     with pytest.raises(Exception):
