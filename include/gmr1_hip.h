@@ -228,8 +228,9 @@ int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
  * Channel k is the carrier k x 31.25 kHz above the centre (k >= n_chans / 2: below, freq2index :478-485).
  * rotation: optional pre-rotation in rad / sample (:444-448).  chan_idx: n_sel channel numbers (host);
  * out: n_sel streams, out_stride complex samples apart; *n_out = samples written per stream.
- * Built for sample rates that are n_chans x 31.25 kHz with n_chans = 64 (2.0 Msps); the
- * pre-resampler (:451-459) and the multi-ARFCN synthesizer (:567-576) are not.
+ * Built for sample rates that are n_chans x 31.25 kHz, n_chans even and <= 256 (64 channels / 2.0 Msps is
+ * the fast path); other rates return -EINVAL: the pre-resampler (:451-459, which cannot run in the reference
+ * either) and the multi-ARFCN synthesizer (:567-576) are not built.
  * gmr1_hip_channelize_plan reports sizes: n_mid = 2x oversampled samples per channel. */
 int gmr1_hip_channelize_plan(double samp_rate, int sps, uint64_t n_in,
                              int32_t *n_chans, uint64_t *n_mid, uint64_t *n_out);

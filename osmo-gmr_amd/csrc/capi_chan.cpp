@@ -115,12 +115,12 @@ int get_plan(double samp_rate, int sps, const ChanPlan **out)
 	const double resamp = (p.n_chans * kChanWidth) / samp_rate;
 	if (std::fabs(resamp - 1.0) >= 1e-5)
 		return fail(-EINVAL, "channelize: sample rate %.1f is not n_chans x 31250 Hz (the pre-resampler is not built)", samp_rate);
-	if (p.n_chans != 64)
-		return fail(-EINVAL, "channelize: %d channels (only the 64-channel / 2.0 Msps plan is built)", p.n_chans);
+	if (p.n_chans > kPfbMaxChans)
+		return fail(-EINVAL, "channelize: %d channels (at most %d)", p.n_chans, kPfbMaxChans);
 	const std::vector<float> taps = design_low_pass(1.0, samp_rate, kChanWidth * 0.5, kChanWidth * 0.25);
 	p.ntaps = (int)taps.size();
 	p.n_blocks = (p.ntaps + p.n_chans - 1) / p.n_chans + 1;
-	if (p.n_blocks > kPfbMaxBlocks)
+	if (p.n_chans == 64 && p.n_blocks > kPfbMaxBlocks)
 		return fail(-EINVAL, "channelize: prototype filter too long (%d taps)", p.ntaps);
 	const double chan_rate2 = kChanWidth * 2.0;                    // 2x oversampled channel rate
 	const std::vector<float> rrc = design_rrc(32.0, 32.0 * chan_rate2, kSymRate, 0.35,
@@ -206,19 +206,22 @@ int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float
 	r = dev_state(&s);
 	if (r) return r;
 	// scratch: slot table + the 2x oversampled channel streams
-	const size_t slot_bytes = 256;
+	const size_t slot_bytes = 2 * kPfbMaxChans * 4;          // slot[n_chans], then sel[n_sel]
 	void *ws;
 	r = dev_workspace(s, slot_bytes + (size_t)n_sel * T * sizeof(float2), &ws);
 	if (r) return r;
 	int32_t *d_slot = static_cast<int32_t *>(ws);
 	float2 *d_mid = reinterpret_cast<float2 *>(static_cast<char *>(ws) + slot_bytes);
+	int32_t *d_sel = d_slot + kPfbMaxChans;
 	HIP_TRY(hipMemcpyAsync(d_slot, slot.data(), (size_t)nch * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_sel, chan_idx, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st));      // slot[] is a host temporary
 	PfbArgs pa;
 	std::memset(&pa, 0, sizeof(pa));
 	pa.n_chans = nch; pa.n_blocks = p->n_blocks; pa.ntaps = p->ntaps;
 	pa.n_in = (long long)n_in; pa.T = (long long)T; pa.rotation = rotation;
 	pa.x = reinterpret_cast<const float2 *>(wide); pa.taps = p->d_taps; pa.slot = d_slot; pa.y = d_mid;
+	pa.sel = d_sel; pa.n_sel = n_sel;
 	HIP_TRY(launch_pfb(pa, st));
 	ResampArgs ra;
 	std::memset(&ra, 0, sizeof(ra));

@@ -13,6 +13,7 @@
 //                six radix-2 stages across the LANES of the wave (DPP for spans 1..8, bpermute for
 //                16 and 32); results leave bit-reversed, are transposed through a wave-private LDS tile
 //                and written as 128-byte runs per channel.  Only the channels asked for are stored.
+//   k_pfb_any  : the same filterbank for any even channel count (direct DFT of the selected channels).
 //   k_resamp   : out[n] = sum_k (b_j[k] + frac d_j[k]) y[i - k],  phase = j0 + n num/den in 1/32 input
 //                samples kept in integers (j = phase mod 32, i = phase / 32, frac = remainder / den).
 //                One output per lane; taps (b, d) pairs and the input span of the block sit in LDS.
@@ -164,10 +165,98 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 	(void)slot;
 }
 
+// ---------------------------------------------------------------------------
+// Any even channel count (the recorder derives n_chans from the sample rate: 32 at 1.0 Msps, 40 at 1.25,
+// 80 at 2.5, 128 at 4.0 ...; gmr1_rx_sdr.py:408).  Same definition, two plain stages per tile of 16
+// output instants: the polyphase sums v_t[r] = sum_b x[b M + r] h[t D - b M - r] into LDS (reads of x are
+// coalesced along r), then a direct DFT for the SELECTED channels only, Y_k[t] = sum_r v_t[r] W^{k r},
+// with the M twiddles in LDS.  O(M) per kept channel and instant instead of the lane FFT's O(log M) per
+// channel, so k_pfb64 stays the fast path of the 2.0 Msps plan; this one is the general fallback.
+// ---------------------------------------------------------------------------
+static constexpr int kAnyTile = 16;          // instants per work-group
+static constexpr int kAnyThreads = 256;
+
+template <bool ROT>
+__global__ __launch_bounds__(kAnyThreads) void k_pfb_any(PfbArgs a)
+{
+	extern __shared__ float2 lds_any[];
+	const int M = a.n_chans, D = M / 2, ld = M + 1;
+	float2 *v = lds_any;                       // kAnyTile x (M + 1)
+	float2 *tw = lds_any + kAnyTile * ld;      // M twiddles e^{-j 2 pi i / M}
+	const int tid = threadIdx.x;
+	const long long t0 = (long long)blockIdx.x * kAnyTile;
+
+	for (int i = tid; i < M; i += kAnyThreads) {
+		float sn, cs;
+		sincospif(-2.0f * (float)i / (float)M, &sn, &cs);
+		tw[i] = make_float2(cs, sn);
+	}
+	for (int e = tid; e < kAnyTile * M; e += kAnyThreads) {
+		const int u = e / M, r = e % M;
+		const long long t = t0 + u;
+		float ar = 0.f, ai = 0.f;
+		if (t < a.T) {
+			const long long td = t * D;
+			// newest sample of branch r at or before t D (floor division: t D - r may be negative)
+			long long blk = (td - r >= 0) ? (td - r) / M : -1;
+			for (int q = 0; q < a.n_blocks; q++, blk--) {
+				const long long sidx = blk * M + r;
+				const long long ti = td - sidx;
+				if (blk < 0 || ti >= a.ntaps)
+					break;
+				if (sidx >= a.n_in)
+					continue;
+				float2 x = a.x[sidx];
+				if (ROT) {
+					const double ph = (double)a.rotation * (double)sidx;
+					const float fr = (float)(ph - 6.283185307179586 * rint(ph * 0.15915494309189535));
+					float sn, cs;
+					__sincosf(fr, &sn, &cs);
+					x = make_float2(x.x * cs - x.y * sn, x.x * sn + x.y * cs);
+				}
+				const float h = a.taps[ti];
+				ar = fmaf(h, x.x, ar);
+				ai = fmaf(h, x.y, ai);
+			}
+		}
+		v[u * ld + r] = make_float2(ar, ai);
+	}
+	__syncthreads();
+	for (int e = tid; e < a.n_sel * kAnyTile; e += kAnyThreads) {
+		const int c = e / kAnyTile, u = e % kAnyTile;
+		const long long t = t0 + u;
+		if (t >= a.T)
+			continue;
+		const int k = a.sel[c];
+		const float2 *vr = v + u * ld;
+		float yr = 0.f, yi = 0.f;
+		int idx = 0;                             // (k r) mod M
+		for (int r = 0; r < M; r++) {
+			const float2 w = tw[idx], s = vr[r];
+			yr = fmaf(s.x, w.x, fmaf(-s.y, w.y, yr));
+			yi = fmaf(s.x, w.y, fmaf(s.y, w.x, yi));
+			idx += k;
+			idx = idx >= M ? idx - M : idx;
+		}
+		a.y[(long long)c * a.T + t] = make_float2(yr, yi);
+	}
+}
+
 hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream)
 {
 	if (a.T <= 0)
 		return hipSuccess;
+	if (a.n_chans != 64) {
+		if (a.n_chans < 2 || a.n_chans > kPfbMaxChans || (a.n_chans & 1) || !a.sel || a.n_sel <= 0)
+			return hipErrorInvalidValue;
+		const long long grid = (a.T + kAnyTile - 1) / kAnyTile;
+		const size_t lds = (size_t)(kAnyTile * (a.n_chans + 1) + a.n_chans) * sizeof(float2);
+		if (a.rotation != 0.0f)
+			hipLaunchKernelGGL(k_pfb_any<true>, dim3((unsigned)grid), dim3(kAnyThreads), lds, stream, a);
+		else
+			hipLaunchKernelGGL(k_pfb_any<false>, dim3((unsigned)grid), dim3(kAnyThreads), lds, stream, a);
+		return hipGetLastError();
+	}
 	const long long grid = (a.T + kPfbSteps - 1) / kPfbSteps;
 	if (a.rotation != 0.0f)
 		hipLaunchKernelGGL(k_pfb64<true>, dim3((unsigned)grid), dim3(64), 0, stream, a);

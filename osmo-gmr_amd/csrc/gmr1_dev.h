@@ -183,8 +183,9 @@ struct A5Args {
 
 // wideband -> per-ARFCN channelizer (chan_kernels.hip)
 constexpr int kPfbMaxBlocks = 11;        // prototype taps / n_chans, rounded up, + 1
+static constexpr int kPfbMaxChans = 256;
 struct PfbArgs {
-	int n_chans;               // 64
+	int n_chans;               // even; 64 runs the lane-FFT kernel, anything else (<= kPfbMaxChans) the generic one
 	int n_blocks;              // taps per polyphase branch (<= kPfbMaxBlocks)
 	int ntaps;
 	long long n_in;            // wideband samples
@@ -194,6 +195,8 @@ struct PfbArgs {
 	const float *taps;         // prototype low-pass, ntaps floats
 	const int32_t *slot;       // n_chans entries: output slot of channel k or -1
 	float2 *y;                 // n_slots x T, 2x oversampled channel streams
+	const int32_t *sel;        // n_sel selected channel indices (slot order), used by the generic kernel
+	int n_sel;
 };
 struct ResampArgs {
 	int n_slots;

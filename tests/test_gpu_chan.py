@@ -23,7 +23,7 @@ def test_plan_matches_the_reference_formulas(gpu_api):
     assert n_chans == pl.n_chans == 64 and n_mid == 200000 // 32
     assert n_out == ((n_mid * 32 - (pl.taps_resamp.size // 2) % 32) * 117) // 2500
     with pytest.raises(Exception):
-        gpu_api.channelize_plan(1.9e6, 4, 1000)            # not n_chans x 31.25 kHz: pre-resampler not built
+        gpu_api.channelize_plan(1.9e6, 4, 1000)            # not n_chans x 31.25 kHz: needs the pre-resampler (broken in the reference too)
 
 
 def test_channelizer_matches_oracle(gpu_api):
@@ -52,6 +52,41 @@ def test_channelizer_matches_oracle(gpu_api):
         assert abs(np.sqrt(np.mean(np.abs(z) ** 2)) - a) < 0.25 * a
     # pre-rotation moves everything by one raster step
     rot = gpu_api.channelize(x, FS, [6], rotation=2 * np.pi * 31250.0 / FS)
+    assert np.max(np.abs(rot[0][3000:] - got[0][3000:])) < 5e-3
+
+
+@pytest.mark.parametrize("fs", [1.0e6, 1.25e6, 2.5e6, 4.0e6])
+def test_other_channel_counts_match_oracle(gpu_api, fs):
+    """Sample rates whose channel count is not 64 (gmr1_rx_sdr.py:408: 32, 40, 80, 128 channels) run the
+    generic filterbank kernel; same oracle, same tolerance."""
+    import orc_chan
+    pl = orc_chan.Plan(fs)
+    M = pl.n_chans
+    assert M == int(round(fs / 31250.0)) and M != 64
+    rng = np.random.default_rng(int(fs) % 1000 + 5)
+    n = 40 * M * 50 + 37                                   # not a whole number of instants
+    x = (rng.standard_normal((n, 2)) * 0.3).astype(np.float32).view(np.complex64).reshape(-1)
+    s = np.arange(n)
+    tones = ((3, 1500.0, 1.0), (M - 2, -2500.0, 0.7), (M // 2 - 1, 6000.0, 1.5))
+    for k, f, a in tones:
+        kk = k if k < M // 2 else k - M
+        x += (a * np.exp(2j * np.pi * ((kk * 31250.0 + f) / fs) * s)).astype(np.complex64)
+    chans = [3, M - 2, M // 2 - 1, 0, M - 1, M // 2]
+    n_chans, n_mid, n_out = gpu_api.channelize_plan(fs, 4, n)
+    assert n_chans == M and n_mid == n // (M // 2)
+    got = gpu_api.channelize(x, fs, chans)
+    ref = orc_chan.channelize(x, pl, chans)
+    for i, k in enumerate(chans):
+        r = ref[k]
+        assert got[i].size == r.size == n_out
+        err = np.max(np.abs(got[i] - r))
+        assert err < 2e-4 * max(1.0, float(np.sqrt(np.mean(np.abs(r) ** 2)))), (fs, k, err)
+    for i, (k, f, a) in enumerate(tones):
+        z = got[i][1500:].astype(np.complex128)
+        fest = np.angle(np.mean(z[1:] * np.conj(z[:-1]))) / (2 * np.pi) * 93600.0
+        assert abs(fest - f) < 40.0, (fs, k, fest, f)
+    # pre-rotation by one raster step: channel 4 of the rotated capture = channel 3 of the plain one
+    rot = gpu_api.channelize(x, fs, [4], rotation=2 * np.pi * 31250.0 / fs)
     assert np.max(np.abs(rot[0][3000:] - got[0][3000:])) < 5e-3
 
 

@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 
@@ -41,21 +42,24 @@ def test_filter_design_properties():
         assert abs(v) < 0.02 * rc[c]
 
 
-def test_tone_lands_in_its_channel_at_its_frequency():
+@pytest.mark.parametrize("fs", [2.0e6, 1.25e6, 2.5e6])
+def test_tone_lands_in_its_channel_at_its_frequency(fs):
     import orc_chan
-    pl = orc_chan.Plan(2.0e6)
-    n = 120000
+    pl = orc_chan.Plan(fs)
+    M = pl.n_chans
+    assert M == int(round(fs / 31250.0))               # 64, 40, 80 channels (gmr1_rx_sdr.py:408)
+    n = int(0.06 * fs)
     s = np.arange(n)
-    for k, f in ((7, 2500.0), (60, -3000.0)):
-        kk = k if k < 32 else k - 64
-        x = np.exp(2j * np.pi * ((kk * 31250.0 + f) / 2.0e6) * s).astype(np.complex64)
+    for k, f in ((7, 2500.0), (M - 4, -3000.0)):
+        kk = k if k < M // 2 else k - M
+        x = np.exp(2j * np.pi * ((kk * 31250.0 + f) / fs) * s).astype(np.complex64)
         y = orc_chan.pfb_channelizer_2x(x, pl.taps, pl.n_chans)
         p = np.mean(np.abs(y[:, 100:]) ** 2, axis=1)
         assert int(np.argmax(p)) == k and p[k] > 0.9
-        others = np.delete(p, [k, (k + 1) % 64, (k - 1) % 64])
+        others = np.delete(p, [k, (k + 1) % M, (k - 1) % M])
         assert others.max() < 1e-4
         z = orc_chan.arb_resampler(y[k], pl.resamp, pl.taps_resamp)
-        assert abs(z.size - n / 2.0e6 * 93600) < 8
+        assert abs(z.size - n / fs * 93600) < 8
         zz = z[600:4000].astype(np.complex128)
         fest = np.angle(np.mean(zz[1:] * np.conj(zz[:-1]))) / (2 * np.pi) * 93600.0
         assert abs(fest - f) < 5.0 and abs(np.mean(np.abs(zz)) - 1.0) < 0.05
