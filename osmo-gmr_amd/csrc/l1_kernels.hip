@@ -405,22 +405,25 @@ __device__ __forceinline__ uint32_t k7_partner(uint32_t w)
 }
 
 // One trellis step on the packed word [metric:16 | decisions of the current 12-step window:16]
-// (see decode4_k5_12 in rx_kernels.hip): candidates = word + (cost << 16); the HIGH-predecessor
-// lane carries the tie-break / decision bit of the position, so v_min_u32 selects, breaks ties
-// towards the low predecessor and records the decision at once.
+// (see decode4_k5_12 in rx_kernels.hip).  Both generators have the D^0 and D^6 taps, so the two
+// transitions into a state carry complementary code words and their costs add up to a per-step constant K:
+// the words hold 2 * metric - sum K, a candidate is `own + m` / `partner - m` with ONE table value
+// m = (2 cost - K) << 16 (the subtraction takes the DPP operand directly), comparisons and ties are those
+// of the plain metric.  The HIGH-predecessor lane carries the tie-break / decision bit of the position, so
+// v_min_u32 selects, breaks ties towards the low predecessor and records the decision at once.
 template <int PH>
-__device__ __forceinline__ uint32_t k7_step(uint32_t w, const uint8_t *__restrict__ cost, uint32_t o_own, uint32_t o_par)
+__device__ __forceinline__ uint32_t k7_step(uint32_t w, const uint32_t *__restrict__ tab, uint32_t o_own)
 {
-	const uint32_t p = k7_partner<PH>(w);
-	const uint32_t t1 = ((uint32_t)cost[o_own] << 16) + w;
-	const uint32_t t2 = ((uint32_t)cost[o_par] << 16) + p;
+	const uint32_t m = tab[o_own];
+	const uint32_t t1 = w + m;
+	const uint32_t t2 = k7_partner<PH>(w) - m;
 	return t1 < t2 ? t1 : t2;
 }
 
 __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 {
 	__shared__ __align__(16) int8_t s_e[216];
-	__shared__ __align__(16) uint32_t s_bm[kT3Steps];
+	__shared__ __align__(16) uint32_t s_tab[kT3Steps * 4];     // (2 cost(word) - K) << 16 per step and code word
 	__shared__ uint16_t s_win[4][64];
 	const int lane = threadIdx.x;
 	const int g = blockIdx.x >> 1, fr = blockIdx.x & 1;
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 
 	// ---- branch metrics: step s has coded bits 2s (always sent) and 2s+1 (punctured when
 	// 2s+1 = 3 mod 4, i.e. s odd); the sent bits are c[idx - (idx>>2)]   (punct.c:48-133, P(1;2))
+	int ksum = 0;
 	if (lane < kT3Steps) {
 		const int s = lane;
 		const int i0 = 2 * s, i1 = 2 * s + 1;
@@ -448,36 +452,40 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 		const int v1 = (s & 1) ? 0 : tch3_c(s_e, ciph, fr, m, i1 - (i1 >> 2));
 		const int a0 = sbit_cost(v0, 0), a1 = sbit_cost(v0, 1);
 		const int b0 = sbit_cost(v1, 0), b1c = sbit_cost(v1, 1);
-		s_bm[s] = (uint32_t)(a0 + b0) | ((uint32_t)(a0 + b1c) << 8) |
-		          ((uint32_t)(a1 + b0) << 16) | ((uint32_t)(a1 + b1c) << 24);
+		const int da = a1 - a0, db = b1c - b0;
+		ksum = a0 + a1 + b0 + b1c;
+		// code word o = (g0 bit << 1) | g1 bit
+		*reinterpret_cast<uint4 *>(&s_tab[4 * s]) = make_uint4((uint32_t)(-da - db) << 16, (uint32_t)(-da + db) << 16,
+		                                                       (uint32_t)(da - db) << 16, (uint32_t)(da + db) << 16);
 	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1)
+		ksum += __shfl_xor(ksum, o);
 	WSYNC();
 
 	// ---- in-place 64-state trellis on packed words
 	const uint32_t tab = c_k7.a[lane];
-	uint32_t o_own[6], o_par[6];
+	uint32_t o_own[6];
 	uint32_t T[12];            // tie-break / decision bit of window position j, set in HIGH-predecessor lanes
 #pragma unroll
-	for (int ph = 0; ph < 6; ph++) {
+	for (int ph = 0; ph < 6; ph++)
 		o_own[ph] = (tab >> (2 * ph)) & 3u;
-		o_par[ph] = (tab >> (12 + 2 * ph)) & 3u;
-	}
 #pragma unroll
 	for (int j = 0; j < 12; j++)
 		T[j] = ((tab >> (24 + (j % 6))) & 1u) << j;
-	const uint8_t *cost = reinterpret_cast<const uint8_t *>(s_bm);
 	constexpr uint32_t kSent = 0xF0000000u;       // unreachable (libosmocore: MAX_AE)
+	constexpr uint32_t kBias = 0x4000u;           // |2 cost - K| <= 252 per step, 48 steps: stays inside 16 bits
 
 	// pass 1 (warm-up from state 0, D4): only the metrics matter
-	uint32_t w = c_k7.st[lane] ? kSent : 0u;
+	uint32_t w = c_k7.st[lane] ? kSent : (kBias << 16);
 #pragma unroll
 	for (int k = 0; k < kT3Steps; k += 6) {
-		w = k7_step<0>(w, cost + 4 * (k + 0), o_own[0], o_par[0]);
-		w = k7_step<1>(w, cost + 4 * (k + 1), o_own[1], o_par[1]);
-		w = k7_step<2>(w, cost + 4 * (k + 2), o_own[2], o_par[2]);
-		w = k7_step<3>(w, cost + 4 * (k + 3), o_own[3], o_par[3]);
-		w = k7_step<4>(w, cost + 4 * (k + 4), o_own[4], o_par[4]);
-		w = k7_step<5>(w, cost + 4 * (k + 5), o_own[5], o_par[5]);
+		w = k7_step<0>(w, s_tab + 4 * (k + 0), o_own[0]);
+		w = k7_step<1>(w, s_tab + 4 * (k + 1), o_own[1]);
+		w = k7_step<2>(w, s_tab + 4 * (k + 2), o_own[2]);
+		w = k7_step<3>(w, s_tab + 4 * (k + 3), o_own[3]);
+		w = k7_step<4>(w, s_tab + 4 * (k + 4), o_own[4]);
+		w = k7_step<5>(w, s_tab + 4 * (k + 5), o_own[5]);
 	}
 	// rewind: subtract the minimum (osmo_conv_decode_rewind)
 	{
@@ -487,25 +495,25 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 			const uint32_t ov = (uint32_t)__shfl_xor((int)mn, o);
 			mn = ov < mn ? ov : mn;
 		}
-		w = (((w >> 16) - mn) << 16) | T[0];
+		w = (((w >> 16) - mn + kBias) << 16) | T[0];
 	}
 	// pass 2: four windows of 12 steps; window m's decisions at a location are u[12m-6 .. 12m+5] of the
 	// path ending there, and the first six name the state at the start of the window
 #pragma unroll
 	for (int wm = 0; wm < 4; wm++) {
 		const int k = 12 * wm;
-		w = k7_step<0>(w, cost + 4 * (k + 0), o_own[0], o_par[0]) + T[1];
-		w = k7_step<1>(w, cost + 4 * (k + 1), o_own[1], o_par[1]) + T[2];
-		w = k7_step<2>(w, cost + 4 * (k + 2), o_own[2], o_par[2]) + T[3];
-		w = k7_step<3>(w, cost + 4 * (k + 3), o_own[3], o_par[3]) + T[4];
-		w = k7_step<4>(w, cost + 4 * (k + 4), o_own[4], o_par[4]) + T[5];
-		w = k7_step<5>(w, cost + 4 * (k + 5), o_own[5], o_par[5]) + T[6];
-		w = k7_step<0>(w, cost + 4 * (k + 6), o_own[0], o_par[0]) + T[7];
-		w = k7_step<1>(w, cost + 4 * (k + 7), o_own[1], o_par[1]) + T[8];
-		w = k7_step<2>(w, cost + 4 * (k + 8), o_own[2], o_par[2]) + T[9];
-		w = k7_step<3>(w, cost + 4 * (k + 9), o_own[3], o_par[3]) + T[10];
-		w = k7_step<4>(w, cost + 4 * (k + 10), o_own[4], o_par[4]) + T[11];
-		w = k7_step<5>(w, cost + 4 * (k + 11), o_own[5], o_par[5]);
+		w = k7_step<0>(w, s_tab + 4 * (k + 0), o_own[0]) + T[1];
+		w = k7_step<1>(w, s_tab + 4 * (k + 1), o_own[1]) + T[2];
+		w = k7_step<2>(w, s_tab + 4 * (k + 2), o_own[2]) + T[3];
+		w = k7_step<3>(w, s_tab + 4 * (k + 3), o_own[3]) + T[4];
+		w = k7_step<4>(w, s_tab + 4 * (k + 4), o_own[4]) + T[5];
+		w = k7_step<5>(w, s_tab + 4 * (k + 5), o_own[5]) + T[6];
+		w = k7_step<0>(w, s_tab + 4 * (k + 6), o_own[0]) + T[7];
+		w = k7_step<1>(w, s_tab + 4 * (k + 7), o_own[1]) + T[8];
+		w = k7_step<2>(w, s_tab + 4 * (k + 8), o_own[2]) + T[9];
+		w = k7_step<3>(w, s_tab + 4 * (k + 9), o_own[3]) + T[10];
+		w = k7_step<4>(w, s_tab + 4 * (k + 10), o_own[4]) + T[11];
+		w = k7_step<5>(w, s_tab + 4 * (k + 11), o_own[5]);
 		s_win[wm][lane] = (uint16_t)w;
 		w = (w & 0xffff0000u) | T[0];
 	}
@@ -520,7 +528,8 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 		key = ok < key ? ok : key;
 	}
 	const uint32_t end_state = (uint32_t)key & 63u;
-	const uint32_t min_ae = (uint32_t)(key >> 32);
+	// words hold 2 * ae - sum K (+ bias)
+	const uint32_t min_ae = (uint32_t)(((int)(uint32_t)(key >> 32) - (int)kBias + ksum) >> 1);
 
 	// ---- survivor chain (uniform across the wave): four dependent 16-bit reads.
 	// u[42..47] are the end state's bits (bit j = u[47 - j]); window m gives u[12m-6 .. 12m+5] LSB first
