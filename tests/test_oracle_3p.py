@@ -1,0 +1,140 @@
+"""Pins of the oracle's restatements of THIRD-PARTY arithmetic (oracle/orc_3p.c: what the reference delegates
+to libosmocore, libosmo-dsp and FFTW, none of which is in the image) against independent implementations
+that ARE in the image: numpy's FFT and correlation, Python's binascii CRC-CCITT, scipy's window-method FIR
+design, and -- for the Viterbi decoder -- exhaustive maximum-likelihood search under the stated metric.
+This does not pin libosmocore's own tie-breaking, only that the restated algorithms
+compute what their definitions say."""
+import binascii
+import ctypes as C
+import itertools
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+
+class ConvCode(C.Structure):
+    """struct orc_conv_code (oracle/orc_3p.h)"""
+    _fields_ = [("N", C.c_int), ("K", C.c_int), ("len", C.c_int), ("term", C.c_int),
+                ("next_output", (C.c_uint8 * 2) * 256), ("next_state", (C.c_uint8 * 2) * 256),
+                ("n_punct", C.c_int), ("punct", C.c_int * 1024)]
+
+
+def _cf(a):
+    a = np.ascontiguousarray(a, np.complex64)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def test_dft_is_the_plain_forward_dft(orc):
+    rng = np.random.default_rng(1)
+    for n in (117, 468, 64):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        y, p = _cf(x.copy())
+        orc.lib().orc_dft_forward(p, C.c_int(n))
+        ref = np.fft.fft(x.astype(np.complex128))                 # FFTW_FORWARD: unnormalised, e^{-j 2 pi k n / N}
+        assert np.max(np.abs(y - ref)) < 2e-4 * np.max(np.abs(ref))
+
+
+def test_correlate_matches_numpy(orc):
+    rng = np.random.default_rng(2)
+    f = (rng.standard_normal(17) + 1j * rng.standard_normal(17)).astype(np.complex64)
+    g = (rng.standard_normal(200) + 1j * rng.standard_normal(200)).astype(np.complex64)
+    out = np.zeros(200 - 17 + 1, np.complex64)
+    _, pf = _cf(f)
+    _, pg = _cf(g)
+    fn = orc.lib().orc_correlate
+    fn.restype = C.c_int
+    n = fn(pf, C.c_int(17), pg, C.c_int(200), C.c_int(1), out.ctypes.data_as(C.c_void_p))
+    assert n == out.size
+    ref = np.correlate(g.astype(np.complex128), f.astype(np.complex128), "valid")     # sum g[m + n] conj(f[n])
+    assert np.max(np.abs(out - ref)) < 1e-4
+    # step = sps: the reference correlates a symbol-rate reference against an oversampled signal
+    out4 = np.zeros(200 - 17 * 4 + 1, np.complex64)
+    n = fn(pf, C.c_int(17), pg, C.c_int(200), C.c_int(4), out4.ctypes.data_as(C.c_void_p))
+    ref4 = np.array([np.sum(np.conj(f) * g[m:m + 68:4]) for m in range(out4.size)])
+    assert n == out4.size and np.max(np.abs(out4 - ref4)) < 1e-4
+
+
+def test_crc16_is_crc_ccitt_msb_first(orc):
+    class Crc(C.Structure):
+        _fields_ = [("bits", C.c_int), ("poly", C.c_uint32), ("init", C.c_uint32), ("remainder", C.c_uint32)]
+    code = Crc(16, 0x1021, 0, 0)                                   # reference src/l1/crc.c:58-63
+    fn = orc.lib().orc_crc_compute_bits
+    fn.restype = C.c_uint32
+    rng = np.random.default_rng(3)
+    for nbytes in (1, 10, 24, 38):
+        data = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        bits = np.unpackbits(data)                                 # MSB first
+        got = fn(C.byref(code), bits.ctypes.data_as(C.c_void_p), C.c_int(bits.size))
+        assert got == binascii.crc_hqx(data.tobytes(), 0)
+
+
+def _make(orc, N, K, ln, term, polys):
+    c = ConvCode()
+    arr = (C.c_uint * len(polys))(*polys)
+    orc.lib().orc_conv_make(C.byref(c), C.c_int(N), C.c_int(K), C.c_int(ln), C.c_int(term), arr)
+    return c
+
+
+def _metric(sym, coded):
+    """libosmocore's soft metric as restated: sum over non-erased bits of ((in - (+/-127))^2) >> 9"""
+    ov = np.where(coded != 0, -127, 127)
+    e = sym.astype(np.int64) - ov
+    return int(np.sum(np.where(sym != 0, (e * e) >> 9, 0)))
+
+
+def test_viterbi_is_maximum_likelihood_under_its_metric(orc):
+    """K = 5 rate 1/2 and rate 1/4, flushed, 9 data bits: the decoder's path metric equals the minimum over all
+    512 code words, and its output is a code word that attains it."""
+    rng = np.random.default_rng(4)
+    dec = orc.lib().orc_conv_decode
+    dec.restype = C.c_int
+    enc = orc.lib().orc_conv_encode
+    for polys in ((0x19, 0x17), (0x19, 0x17, 0x15, 0x1F)):
+        N, ln = len(polys), 9
+        code = _make(orc, N, 5, ln, 0, polys)
+        words = []
+        for u in itertools.product((0, 1), repeat=ln):
+            ub = np.array(u, np.uint8)
+            cb = np.zeros((ln + 4) * N, np.uint8)
+            enc(C.byref(code), ub.ctypes.data_as(C.c_void_p), cb.ctypes.data_as(C.c_void_p))
+            words.append(cb)
+        words = np.array(words)
+        for trial in range(25):
+            sym = rng.integers(-127, 128, (ln + 4) * N).astype(np.int8)
+            if trial & 1:
+                sym[rng.random(sym.size) < 0.2] = 0               # erasures
+            out = np.zeros(ln, np.uint8)
+            rv = dec(C.byref(code), sym.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+            costs = np.array([_metric(sym, w) for w in words])
+            assert rv == costs.min(), (polys, trial)
+            idx = int("".join(map(str, out)), 2)
+            assert costs[idx] == costs.min()
+
+
+def test_normalize_and_sinc_follow_their_definitions(orc):
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal(400) * 3 + 0.7 + 1j * (rng.standard_normal(400) * 3 - 0.2)).astype(np.complex64)
+    out = np.zeros(100, np.complex64)
+    _, px = _cf(x)
+    fn = orc.lib().orc_sig_normalize
+    fn.restype = C.c_int
+    n = fn(px, C.c_int(400), C.c_int(4), C.c_float(0.0), out.ctypes.data_as(C.c_void_p))
+    xd = x.astype(np.complex128)
+    ref = ((xd - xd.mean()) / np.sqrt(np.mean(np.abs(xd - xd.mean()) ** 2)))[::4]
+    assert n == 100 and np.max(np.abs(out - ref)) < 1e-5
+    s = orc.lib().orc_sinc
+    s.restype = C.c_float
+    for v in (0.0, 0.3, -1.7, 4.0):
+        assert abs(s(C.c_float(v)) - np.sinc(v / np.pi)) < 1e-6   # osmo_sinc(x) = sin(x) / x
+
+
+def test_firdes_low_pass_matches_scipy_firwin():
+    import orc_chan
+    from scipy import signal
+    for fs in (2.0e6, 1.25e6, 4.0e6):
+        pl = orc_chan.Plan(fs)
+        ref = signal.firwin(pl.taps.size, 15625.0, window="hamming", fs=fs)
+        assert np.max(np.abs(ref - pl.taps)) < 1e-7
