@@ -138,3 +138,26 @@ def test_firdes_low_pass_matches_scipy_firwin():
         pl = orc_chan.Plan(fs)
         ref = signal.firwin(pl.taps.size, 15625.0, window="hamming", fs=fs)
         assert np.max(np.abs(ref - pl.taps)) < 1e-7
+
+
+def test_interpolation_and_peak_search_recover_a_known_pulse(orc):
+    """Truncated-sinc interpolation of a band-limited signal returns the signal; the early / late peak search
+    lands on the true maximum of a smooth pulse to well under a sample."""
+    class Cf(C.Structure):
+        _fields_ = [("re", C.c_float), ("im", C.c_float)]
+    ip = orc.lib().orc_interpolate_point
+    ip.restype = Cf
+    n = np.arange(200)
+    sig = lambda t: np.exp(2j * np.pi * 0.07 * t) + 0.5 * np.exp(-2j * np.pi * 0.11 * t + 0.3j)
+    x, px = _cf(sig(n))
+    for pos in (50.25, 99.5, 120.9):
+        v = ip(px, C.c_int(200), C.c_float(pos))
+        assert abs(complex(v.re, v.im) - sig(pos)) < 0.06          # 21 taps of a sinc: ~ 1 / (pi * 10) ripple
+    pk = orc.lib().orc_peak_energy_find
+    pk.restype = C.c_float
+    for true_pos in (80.0, 80.3, 97.77):
+        pulse, pp = _cf(np.sinc((n - true_pos) / 4.0) * np.exp(0.4j))     # band-limited to 1/4 of Nyquist
+        val = Cf()
+        for alg, tol in ((2, 0.02), (0, 0.2)):                     # early / late, weighted window
+            pos = pk(pp, C.c_int(200), C.c_int(5), C.c_int(alg), C.byref(val))
+            assert abs(pos - true_pos) < tol, (alg, pos, true_pos)
