@@ -403,6 +403,39 @@ int gmr1_ccch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv)
 }  // extern "C" (closed for the shared implementation below)
 
 namespace gmr1 {
+namespace {
+// what every burst of the fused BCCH / CCCH path shares
+int rx_base_args(int sps, const float *iq, RxArgs *out)
+{
+	if (sps < 4 || sps > 8)
+		return fail(-EINVAL, "rx_bcch_ccch: sps=%d unsupported (4..8)", sps);
+	RxArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.sps = sps;
+	a.in_len[0] = window_len(234, sps, 20 * sps);   // gmr1_rx.c:759
+	a.in_len[1] = window_len(234, sps, 10 * sps);   // gmr1_rx.c:809
+	a.fixed_type = -1;
+	a.ebits_stride = 432;
+	a.ssyms_stride = 234;
+	a.iq = reinterpret_cast<const float2 *>(iq);
+	if (a.in_len[0] > kMaxInLen)
+		return fail(-EINVAL, "rx_bcch_ccch: window too long");
+	// samples of the sync-chunk windows: sum over chunks of len*sps + w - 1
+	const int ty[2] = {GMR1_HIP_BCCH, GMR1_HIP_DC6};
+	a.stage_samples = 0;
+	for (int k = 0; k < 2; k++) {
+		const DevBurst &bt = g_host_types[ty[k]];
+		const int w = a.in_len[k] - bt.len * sps + 1;
+		int tot = 0;
+		for (int c = 0; c < bt.n_chunks[0]; c++)
+			tot += bt.sync[0][c].len * sps + w - 1;
+		if (tot > a.stage_samples) a.stage_samples = tot;
+	}
+	*out = a;
+	return 0;
+}
+}  // namespace
+
 int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           const float *iq, const uint64_t *offset, const uint8_t *kind,
                           const float *freq_shift,
@@ -412,19 +445,13 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 {
 	if (n < 0 || !iq || !offset || !kind || !l2 || !crc || !conv || !rv)
 		return fail(-EINVAL, "rx_bcch_ccch: iq/offset/kind/l2/crc/conv/rv are required");
-	if (sps < 4 || sps > 8)
-		return fail(-EINVAL, "rx_bcch_ccch: sps=%d unsupported (4..8)", sps);
 	DevState *s;
 	int r = dev_state(&s);
 	if (r) return r;
 	RxArgs a;
-	std::memset(&a, 0, sizeof(a));
-	a.n = n; a.sps = sps;
-	a.in_len[0] = window_len(234, sps, 20 * sps);   // gmr1_rx.c:759
-	a.in_len[1] = window_len(234, sps, 10 * sps);   // gmr1_rx.c:809
-	a.fixed_type = -1;
-	a.ebits_stride = 432;
-	a.ssyms_stride = 234;
+	r = rx_base_args(sps, iq, &a);
+	if (r) return r;
+	a.n = n;
 	a.dbg_stop = dbg_stop_env();
 	{
 		static int impl = -1;
@@ -434,27 +461,29 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 		}
 		a.impl = impl;
 	}
-	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.kind = kind; a.freq_shift = freq_shift;
 	a.l2 = l2; a.crc = crc; a.conv = conv; a.toa = toa; a.freq_err = freq_err;
 	a.ebits = ebits; a.ssyms = ssyms; a.rv = rv;
 	a.energy = energy;
-	if (a.in_len[0] > kMaxInLen)
-		return fail(-EINVAL, "rx_bcch_ccch: window too long");
-	{
-		// samples of the sync-chunk windows: sum over chunks of len*sps + w - 1
-		const int ty[2] = {GMR1_HIP_BCCH, GMR1_HIP_DC6};
-		a.stage_samples = 0;
-		for (int k = 0; k < 2; k++) {
-			const DevBurst &bt = g_host_types[ty[k]];
-			const int w = a.in_len[k] - bt.len * sps + 1;
-			int tot = 0;
-			for (int c = 0; c < bt.n_chunks[0]; c++)
-				tot += bt.sync[0][c].len * sps + w - 1;
-			if (tot > a.stage_samples) a.stage_samples = tot;
-		}
-	}
 	HIP_TRY(launch_rx(a, true, a.in_len[0], stream));
+	return 0;
+}
+
+// process_bcch of n_chains chains in one launch (k_rx_loop): d_state / d_log / d_nrounds are device memory
+int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopState *d_state,
+                     unsigned char *d_log_out, int max_rounds, int32_t *d_nrounds)
+{
+	if (n_chains < 0 || !iq || !d_state || !d_log_out || !d_nrounds || max_rounds < 1)
+		return fail(-EINVAL, "rx_loop: bad arguments");
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	RxArgs a;
+	r = rx_base_args(sps, iq, &a);
+	if (r) return r;
+	RxLoopArgs la;
+	la.state = d_state; la.log_out = d_log_out; la.max_rounds = max_rounds; la.n_rounds = d_nrounds;
+	HIP_TRY(launch_rx_loop(a, la, n_chains, stream));
 	return 0;
 }
 }  // namespace gmr1

@@ -5,14 +5,15 @@
 // 40 ms frame one BCCH or CCCH burst through demod + decode, feeding time / frequency / TDMA
 // position back into the next frame.  That feedback only crosses a BCCH frame (rx_bcch is the
 // only writer of align / freq_err / fn / sa_*), so between two BCCH frames of one chain every
-// burst is independent, and different chains / carriers are independent throughout.  The driver
-// below therefore runs in ROUNDS: each live chain contributes the CCCH bursts up to and including
-// its next BCCH burst, all of them go through ONE fused k_rx4 launch, the host applies the BCCH
-// feedback (a few integers per chain) and the next round starts.  A round's operands and results
-// (a few kilobytes) live in pinned host memory the kernel reads and writes directly.  FCCH acquisition is three
-// batched sweeps (rough / rough_multi / fine + snr) over all carriers.  The arithmetic of every
-// step runs on the GPU; the host keeps only the per-chain integers the reference keeps in
-// struct chan_desc.  There is no CPU fallback.
+// burst is independent, and different chains / carriers are independent throughout.  The frame
+// loop therefore runs in ROUNDS -- a chain's CCCH bursts up to and including its next BCCH burst,
+// one wavefront each, then the BCCH feedback -- and it runs them ON THE GPU: one launch of
+// k_rx_loop (rx_kernels.hip), one work-group per chain, from the first frame to the end of the
+// capture; the integer control logic is shared source (rx_loop.h).  The host replays that logic
+// over the logged burst results to emit records.  FCCH acquisition is three batched sweeps
+// (rough / rough_multi / fine + snr) over all carriers.  The arithmetic of every step runs on the
+// GPU; the host keeps only the per-chain integers the reference keeps in struct chan_desc.
+// There is no CPU fallback.
 //
 // The traffic channels never feed back into that loop, so their follow-ups run after it as batched
 // passes of their own (RxRun::tch3_pass, RxRun::tch9_pass).  GSMTAP transport and per-burst stderr
@@ -34,7 +35,6 @@ constexpr int kStartDiscard = 8000;   // gmr1_rx.c:52
 constexpr int kSymRate = 23400;
 constexpr int kFcchLen = 117;         // gmr1_fcch_burst.len, fcch.c:50-54
 constexpr int kMaxPeaks = 16;         // gmr1_rx.c:650
-constexpr int kPerRound = 8;          // bursts one chain may contribute to a round
 
 float to_hz(float f_rps) { return (kSymRate * f_rps) / (2.0f * 3.14159265358979323846f); }
 
@@ -58,45 +58,6 @@ struct RxChain {
 	std::vector<AssEvt> events9;         // ASSIGNMENT COMMAND 1 taken from a FACCH3 (frame, tn)
 	std::vector<gmr1_hip_rx_big_record> big;
 };
-
-struct Item {             // one burst of a round
-	int chain_idx;
-	int is_bcch;
-	int fn, tn, e_toa;
-	float min_energy;
-	int frame;            // index the frame has / will have in the chain's log
-};
-
-// gmr1_rx.c:149-170 (begin < 0 is an out-of-bounds read in the reference; refused here and in the oracle)
-int burst_map(const RxChain &c, int sps, int burst_len, int tn, int win, int *begin)
-{
-	const int etoa = win >> 1;
-	const int b = c.align + sps * tn * 39 - etoa;
-	const int l = burst_len * sps + win;
-	if (b < 0 || b + l > c.len)
-		return -EIO;
-	*begin = b;
-	return etoa;
-}
-
-// gmr1_rx.c:194-233: SI1 "Segment 2A bis" -> TDMA position
-void bcch_tdma_align(RxChain &c, int sps, const uint8_t *l2)
-{
-	if ((l2[0] & 0xf8) != 0x08)
-		return;
-	if ((l2[9] & 0xfc) != 0x80)
-		return;
-	const int delay = (l2[10] >> 3) & 0x0f;
-	const int stn = ((l2[10] << 2) & 0x1c) | (l2[11] >> 6);
-	const int superframe = ((l2[11] & 0x3f) << 7) | (l2[12] >> 1);
-	const int multiframe = ((l2[12] & 0x01) << 1) | (l2[13] >> 7);
-	const int mffn_hi = (l2[13] & 0x40) >> 6;
-	const int fn = (superframe << 6) | (multiframe << 4) | (mffn_hi << 3) | ((2 + delay) & 7);
-	c.align += (c.stn - stn) * 39 * sps;
-	c.fn = fn;
-	c.delay = delay;
-	c.stn = stn;
-}
 
 void emit(RxChain &c, uint16_t arfcn, int type, int fn, int tn, const uint8_t *l2, int conv, int frame, int len = 24)
 {
@@ -141,24 +102,28 @@ struct TchJob {           // a decode the walk asks for: a speech burst or a FAC
 	uint32_t bi_fn[4];
 };
 
-// pinned, coherent host memory the device reads and writes directly (zero copy): the per-round operands
-// are a few kilobytes, and a kernel that fetches them over the link is cheaper than two extra copy
-// submissions per round
-struct Pinned {
-	void *p = nullptr;      // host address
-	void *d = nullptr;      // the same memory as the device sees it
-	~Pinned() { if (p) (void)hipHostFree(p); }
-	hipError_t alloc(size_t n)
-	{
-		hipError_t e = hipHostMalloc(&p, n ? n : 1, hipHostMallocMapped | hipHostMallocCoherent);
-		if (e != hipSuccess) return e;
-		return hipHostGetDevicePointer(&d, p, 0);
-	}
-	template <typename T> T *at(size_t off) { return reinterpret_cast<T *>(static_cast<char *>(p) + off); }
-	template <typename T> T *dev(size_t off) { return reinterpret_cast<T *>(static_cast<char *>(d) + off); }
-};
-
 size_t up16(size_t x) { return (x + 15) & ~(size_t)15; }
+size_t up128(size_t x) { return (x + 127) & ~(size_t)127; }
+
+// grow-only pinned host buffer of the calling thread: the burst log of the receive loop comes back through it
+// (a fresh hipHostMalloc of some megabytes per call would cost more than the loop itself)
+int host_log(size_t bytes, unsigned char **out)
+{
+	struct Buf {                 // never freed: the runtime may be gone by the time thread-locals are destroyed
+		void *p = nullptr;
+		size_t n = 0;
+	};
+	static thread_local Buf b;
+	if (b.n < bytes) {
+		if (b.p) (void)hipHostFree(b.p);
+		b.p = nullptr;
+		b.n = 0;
+		HIP_TRY(hipHostMalloc(&b.p, bytes + bytes / 4, hipHostMallocDefault));
+		b.n = bytes + bytes / 4;
+	}
+	*out = static_cast<unsigned char *>(b.p);
+	return 0;
+}
 
 
 // One call of gmr1_hip_rx_run*: what the phases share.  The phases run in the order the reference's main()
@@ -371,107 +336,111 @@ int RxRun::acquire()
 
 int RxRun::frame_loop()
 {
-	// ---- process_bcch (gmr1_rx.c:852-895) for every chain, in rounds ---------------------------
+	// ---- process_bcch (gmr1_rx.c:852-895) for every chain ------------------------------------------
+	// One launch: k_rx_loop walks each chain through all of its frames on the GPU (rounds of CCCH bursts
+	// up to the next BCCH burst, whose result feeds back before the next round; rx_loop.h) and logs every
+	// burst's result.  The host then replays the same integer logic over the log to produce the records,
+	// the per-frame context the traffic-channel passes need, and the assignment events.
+	const int nc = (int)chains.size();
+	if (!nc)
+		return 0;
 	const int frame_len = sps * 24 * 39;
-	const size_t cap = std::max<size_t>(1, chains.size() * kPerRound);
-	// one staging block each way: [offset | freq_shift | kind] down, [l2 | crc | conv | toa | fe | rv | energy] up
-	const size_t o_off = 0, o_fs = up16(o_off + cap * 8), o_kind = up16(o_fs + cap * 4), in_bytes = up16(o_kind + cap);
-	const size_t o_l2 = 0, o_crc = up16(o_l2 + cap * 24), o_conv = up16(o_crc + cap * 4), o_toa = up16(o_conv + cap * 4),
-	             o_fe = up16(o_toa + cap * 4), o_rv = up16(o_fe + cap * 4), o_en = up16(o_rv + cap * 4),
-	             out_bytes = up16(o_en + cap * 4);
-	Pinned p_in, p_out;
-	HIP_TRY(p_in.alloc(in_bytes));
-	HIP_TRY(p_out.alloc(out_bytes));
-	std::vector<Item> items;
-	items.reserve(cap);
-
-	auto advance = [&](RxChain &c) {
-		c.fn++;
-		c.align += frame_len;
-		if (c.align + 2 * frame_len > c.len)
-			c.done = true;
-	};
-
-	for (;;) {
-		items.clear();
-		for (size_t ci = 0; ci < chains.size(); ci++) {
-			RxChain &c = chains[ci];
-			int cnt = 0;
-			while (!c.done && cnt < kPerRound - 1) {
-				const int m = ((c.fn - c.delay) & 63) % 8;
-				int begin;
-				if (m == 2) {
-					const int e = burst_map(c, sps, 234, c.stn, 20 * sps, &begin);
-					if (e >= 0) {
-						const size_t k = items.size();
-						items.push_back({(int)ci, 1, c.fn, c.stn, e, 0.f, (int)c.log.size()});
-						p_in.at<uint64_t>(o_off)[k] = c.base + (uint64_t)begin;
-						p_in.at<float>(o_fs)[k] = -c.freq_err;
-						p_in.at<uint8_t>(o_kind)[k] = 0;
-						break;          // the frame completes once the burst's result is known
-					}
-				} else if (m != 0) {
-					const int e = burst_map(c, sps, 234, c.stn, 10 * sps, &begin);
-					if (e >= 0) {
-						const size_t k = items.size();
-						items.push_back({(int)ci, 0, c.fn, c.stn, e, c.bcch_energy / 2.0f, (int)c.log.size()});
-						p_in.at<uint64_t>(o_off)[k] = c.base + (uint64_t)begin;
-						p_in.at<float>(o_fs)[k] = -c.freq_err;
-						p_in.at<uint8_t>(o_kind)[k] = 1;
-						cnt++;
-					}
-				}
-				if (tch)
-					c.log.push_back({c.align, c.freq_err, c.fn});
-				advance(c);
-			}
-		}
-		const int n = (int)items.size();
-		if (!n)
-			break;
-		r = rx_bcch_ccch_dev_impl(st, n, sps, iq, p_in.dev<uint64_t>(o_off), p_in.dev<uint8_t>(o_kind),
-		                          p_in.dev<float>(o_fs), p_out.dev<uint8_t>(o_l2), p_out.dev<int32_t>(o_crc),
-		                          p_out.dev<int32_t>(o_conv), p_out.dev<float>(o_toa), p_out.dev<float>(o_fe),
-		                          p_out.dev<float>(o_en), nullptr, nullptr, p_out.dev<int32_t>(o_rv));
-		if (r) return r;
-		HIP_TRY(hipStreamSynchronize(st));
-		for (int k = 0; k < n; k++) {
-			const Item &it = items[k];
-			RxChain &c = chains[it.chain_idx];
-			const uint16_t an = arfcn ? arfcn[c.a] : (uint16_t)c.a;
-			const int rv = p_out.at<int32_t>(o_rv)[k];
-			const int crc = p_out.at<int32_t>(o_crc)[k];
-			const float en = p_out.at<float>(o_en)[k];
-			const uint8_t *l2 = p_out.at<uint8_t>(o_l2) + (size_t)k * 24;
-			if (it.is_bcch) {
-				// rx_bcch, gmr1_rx.c:746-798
-				if (!rv) {
-					c.bcch_energy = en;
-					if (!crc) {
-						c.align += (int)roundf(p_out.at<float>(o_toa)[k]) - it.e_toa;
-						c.freq_err += p_out.at<float>(o_fe)[k];
-						bcch_tdma_align(c, sps, l2);
-						emit(c, an, 1 /* GSMTAP_GMR1_BCCH */, c.fn, c.stn, l2, p_out.at<int32_t>(o_conv)[k], it.frame);
-					}
-				}
-				if (tch)
-					c.log.push_back({c.align, c.freq_err, c.fn});     // rx_tch3 of this frame sees the updated state
-				advance(c);
-			} else {
-				// rx_ccch, gmr1_rx.c:800-850 (energy gate first, :813-816)
-				if (en < it.min_energy)
-					continue;
-				if (!rv && !crc) {
-					// IMM.ASS starts the TCH3 follow-up in this very frame (gmr1_rx.c:235-246, 836-841)
-					if (tch && l2[1] == 0x06 && l2[2] == 0x3f)
-						c.events.push_back({it.frame, ((l2[8] & 0x03) << 3) | (l2[9] >> 5), (l2[8] & 0xfc) >> 2,
-						                    it.min_energy});
-					emit(c, an, 2 /* GSMTAP_GMR1_CCCH */, it.fn, it.tn, l2, p_out.at<int32_t>(o_conv)[k], it.frame);
-				}
-			}
-		}
+	int max_frames = 0;
+	for (const RxChain &c : chains)
+		max_frames = std::max(max_frames, c.len / frame_len + 1);
+	// every round but the last covers at least seven frames (seven CCCH bursts, or fewer and the BCCH burst
+	// that closes its eight-frame cycle); burst_map only refuses windows at the very ends of the capture
+	const int max_rounds = max_frames / 7 + 8;
+	std::vector<RxLoopState> st0((size_t)nc);
+	for (int ci = 0; ci < nc; ci++) {
+		const RxChain &c = chains[ci];
+		st0[ci] = {c.base, c.len, c.align, c.freq_err, c.fn, c.delay, c.stn, c.done ? 1 : 0};
 	}
+	const size_t out_bytes = (size_t)nc * max_rounds * kLoopOutBytes;
+	const size_t st_bytes = up128((size_t)nc * sizeof(RxLoopState)), nr_bytes = up128((size_t)nc * 4);
+	DevState *ds;
+	r = dev_state(&ds);
+	if (r) return r;
+	void *ws;
+	r = dev_workspace(ds, out_bytes + st_bytes + nr_bytes + 128, &ws);
+	if (r) return r;
+	unsigned char *d_base = reinterpret_cast<unsigned char *>(((uintptr_t)ws + 127) & ~(uintptr_t)127);
+	unsigned char *d_out = d_base;
+	RxLoopState *d_state = reinterpret_cast<RxLoopState *>(d_out + out_bytes);
+	int32_t *d_nr = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_state) + st_bytes);
+	unsigned char *h_out;
+	r = host_log(out_bytes + nr_bytes, &h_out);
+	if (r) return r;
+	int32_t *h_nr = reinterpret_cast<int32_t *>(h_out + out_bytes);
+	HIP_TRY(hipMemcpyAsync(d_state, st0.data(), (size_t)nc * sizeof(RxLoopState), hipMemcpyHostToDevice, st));
+	r = rx_loop_dev_impl(st, nc, sps, iq, d_state, d_out, max_rounds, d_nr);
+	if (r) return r;
+	HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(h_nr, d_nr, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
 
+	for (int ci = 0; ci < nc; ci++) {
+		RxChain &c = chains[ci];
+		RxLoopState s = st0[ci];
+		const uint16_t an = arfcn ? arfcn[c.a] : (uint16_t)c.a;
+		auto on_frame = [&](const RxLoopState &x) {
+			if (tch)
+				c.log.push_back({x.align, x.freq_err, x.fn});
+		};
+		int frames_done = 0;
+		bool closed = false;
+		for (int round = 0; round <= h_nr[ci] && round < max_rounds; round++) {
+			RxLoopItem items[kLoopPerRound];
+			const int before = (int)c.log.size();
+			const float min_energy = c.bcch_energy / 2.0f;
+			const int n = rx_loop_build_round(s, sps, items, on_frame);
+			if (!n) {
+				closed = true;
+				break;
+			}
+			if (round == h_nr[ci])
+				return fail(-EIO, "rx loop: chain %d stopped after %d rounds with frames left", ci, round);
+			const unsigned char *ob = h_out + ((size_t)ci * max_rounds + round) * kLoopOutBytes;
+			const int32_t *o_crc = reinterpret_cast<const int32_t *>(ob + kLoopOutCrc);
+			const int32_t *o_conv = reinterpret_cast<const int32_t *>(ob + kLoopOutConv);
+			const int32_t *o_rv = reinterpret_cast<const int32_t *>(ob + kLoopOutRv);
+			const float *o_toa = reinterpret_cast<const float *>(ob + kLoopOutToa);
+			const float *o_fe = reinterpret_cast<const float *>(ob + kLoopOutFe);
+			const float *o_en = reinterpret_cast<const float *>(ob + kLoopOutEnergy);
+			for (int k = 0; k < n; k++) {
+				const RxLoopItem &it = items[k];
+				const uint8_t *l2 = ob + kLoopOutL2 + (size_t)k * 24;
+				// index the burst's frame has / will have in the chain's log
+				const int frame = tch ? before + it.frames_before : 0;
+				if (it.is_bcch) {
+					// rx_bcch, gmr1_rx.c:746-798
+					if (!o_rv[k]) {
+						c.bcch_energy = o_en[k];
+						if (rx_loop_bcch_result(s, sps, o_rv[k], o_crc[k], o_toa[k], o_fe[k], l2, it.e_toa))
+							emit(c, an, 1 /* GSMTAP_GMR1_BCCH */, s.fn, s.stn, l2, o_conv[k], frame);
+					}
+					on_frame(s);                 // rx_tch3 of this frame sees the updated state
+					rx_loop_advance(s, sps);
+				} else {
+					// rx_ccch, gmr1_rx.c:800-850 (energy gate first, :813-816)
+					if (o_en[k] < min_energy)
+						continue;
+					if (!o_rv[k] && !o_crc[k]) {
+						// IMM.ASS starts the TCH3 follow-up in this very frame (gmr1_rx.c:235-246, 836-841)
+						if (tch && l2[1] == 0x06 && l2[2] == 0x3f)
+							c.events.push_back({frame, ((l2[8] & 0x03) << 3) | (l2[9] >> 5), (l2[8] & 0xfc) >> 2, min_energy});
+						emit(c, an, 2 /* GSMTAP_GMR1_CCCH */, it.fn, it.tn, l2, o_conv[k], frame);
+					}
+				}
+			}
+			frames_done++;
+		}
+		if (!closed)
+			return fail(-EIO, "rx loop: chain %d needs more than %d rounds", ci, max_rounds);
+		c.align = s.align; c.freq_err = s.freq_err; c.fn = s.fn; c.delay = s.delay; c.stn = s.stn;
+		c.done = s.done != 0;
+		(void)frames_done;
+	}
 	return 0;
 }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "gmr1_hip.h"
+#include "rx_loop.h"
 
 namespace gmr1 {
 
@@ -62,6 +63,15 @@ struct RxArgs {
 	float *ssyms;
 	int32_t *rv;           // required
 	int32_t *sync_id;
+};
+
+// the receive loop of all chains in one launch (k_rx_loop, rx_kernels.hip); `a` carries what every burst
+// shares (iq, sps, window lengths, staging size), the per-burst arrays are set by the loop itself
+struct RxLoopArgs {
+	const RxLoopState *state;  // n_chains starting states
+	unsigned char *log_out;    // n_chains x max_rounds x kLoopOutBytes, 128-byte aligned
+	int max_rounds;
+	int32_t *n_rounds;         // n_chains: rounds each chain took
 };
 
 struct DetectArgs {
@@ -253,6 +263,7 @@ struct XchArgs {
 };
 hipError_t launch_xch(const XchArgs &a, hipStream_t stream);
 
+hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream);
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
 hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);
 

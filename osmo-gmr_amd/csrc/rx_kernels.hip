@@ -1324,11 +1324,25 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 	return o > k ? o : k;
 }
 
+// The body works on bursts g0 .. n_end-1 (at most four) of `a` with one wavefront and its own LDS slice;
+// k_rx4 is the batch kernel around it, k_rx_loop (below) the receive loop that calls it round after round.
+// per-burst arrays of a launch: the batch kernel takes them from its arguments, the receive loop points them
+// at the current round's log blocks (by value: they stay in scalar registers)
+struct RxIo {
+	const uint64_t *offset;
+	const uint8_t *kind;
+	const float *freq_shift;
+	uint8_t *l2;
+	int32_t *crc, *conv, *rv, *sync_id;
+	float *toa, *freq_err, *energy;
+	int8_t *ebits;
+	float *ssyms;
+};
+
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
+__device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
+                                         unsigned char *__restrict__ lds_raw, int lane, uint32_t *fb = nullptr)
 {
-	extern __shared__ __align__(16) unsigned char lds_raw[];
-	const int lane = threadIdx.x;
 	const int row = lane >> 4, col = lane & 15;
 	const int sps = SPS ? SPS : a.sps;
 	size_t off[4];
@@ -1342,22 +1356,18 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[3]);
 	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + 4 * kSteps12 * 4);
 
-	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway
-	// (the receive loop's rounds), which shortens the critical path of a wave to a quarter
-	const int g0 = blockIdx.x * bpw;
-	const int n_end = min(a.n, g0 + bpw);
 	const int g_row = g0 + row;                       // this row's burst
 	const bool row_live = g_row < n_end;
 
 	// per-row (lane-resident) burst parameters
-	const int kind_r = row_live ? (a.kind[g_row] ? 1 : 0) : 0;
+	const int kind_r = row_live ? (io.kind[g_row] ? 1 : 0) : 0;
 	const int type_r = kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
 	const int in_len_r = a.in_len[kind_r];
-	const float fsh_r = (row_live && a.freq_shift) ? a.freq_shift[g_row] : 0.0f;
+	const float fsh_r = (row_live && io.freq_shift) ? io.freq_shift[g_row] : 0.0f;
 	const DevBurst &bt_r = c_types[type_r];
 	const float fs_r = (fsh_r - bt_r.rotation) / (float)sps;     // pi4cxpsk.c:539
 	const int w_r = in_len_r - bt_r.len * sps + 1;
-	const float2 *__restrict__ in_r = a.iq + (row_live ? a.offset[g_row] : 0);
+	const float2 *__restrict__ in_r = a.iq + (row_live ? io.offset[g_row] : 0);
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
 
 	// =========================== pass 1: correlation magnitudes ===========================
@@ -1366,16 +1376,16 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 		const int g = g0 + q;
 		if (g >= n_end)
 			break;
-		const int kind = __builtin_amdgcn_readfirstlane(a.kind[g] ? 1 : 0);
+		const int kind = __builtin_amdgcn_readfirstlane(io.kind[g] ? 1 : 0);
 		const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
 		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
 		const DevBurst &bt = c_types[type];
 		const int nbits = bt.nbits;
 		const int w = in_len - bt.len * sps + 1;
-		const float fsh = a.freq_shift ? a.freq_shift[g] : 0.0f;
+		const float fsh = io.freq_shift ? io.freq_shift[g] : 0.0f;
 		const float fs = (fsh - bt.rotation) / (float)sps;
 
-		const float2 *__restrict__ in = a.iq + a.offset[g];
+		const float2 *__restrict__ in = a.iq + io.offset[g];
 		const int tl = bt.sync_tl[0];
 		const int nch = bt.n_chunks[0];
 		constexpr int NFULL = (SPS == 4 && NPL == 16) ? 15 : -1;
@@ -1415,13 +1425,13 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 		if (row == q) { avr_r = avr; avi_r = avi; }
 		if (q + 1 < 4 && g + 1 < n_end) {
 			// the next burst's window travels during this burst's correlation
-			const int kind1 = __builtin_amdgcn_readfirstlane(a.kind[g + 1] ? 1 : 0);
-			window_fetch<NPL, NFULL>(a.iq + a.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
+			const int kind1 = __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
+			window_fetch<NPL, NFULL>(a.iq + io.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
 		}
-		if (a.energy) {
+		if (io.energy) {
 			const float e = window_energy<NPL>(in, in_len, lane);
 			if (lane == 0)
-				a.energy[g] = e;
+				io.energy[g] = e;
 		}
 		// stage the sync-chunk windows, normalised: window c = samples [pos_c sps, pos_c sps + len_c sps + w - 1)
 		{
@@ -1561,7 +1571,7 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 		const DevBurst &bt = c_types[kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH];
 		const int in_len = __builtin_amdgcn_readlane(in_len_r, src);
 		const int d = __builtin_amdgcn_readlane(d_r, src);
-		const float2 *__restrict__ in = a.iq + a.offset[g];
+		const float2 *__restrict__ in = a.iq + io.offset[g];
 		const int blen = bt.len;
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
@@ -1658,10 +1668,15 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 	// per-burst results
 	if (col == 0 && row_live) {
 		const int rv = found_r ? 0 : -1;
-		a.rv[g_row] = rv;
-		if (a.sync_id) a.sync_id[g_row] = found_r ? 0 : -1;
-		if (a.toa) a.toa[g_row] = found_r ? toa_r : 0.f;
-		if (a.freq_err) a.freq_err[g_row] = found_r ? ffe_r : 0.f;
+		io.rv[g_row] = rv;
+		if (io.sync_id) io.sync_id[g_row] = found_r ? 0 : -1;
+		if (io.toa) io.toa[g_row] = found_r ? toa_r : 0.f;
+		if (io.freq_err) io.freq_err[g_row] = found_r ? ffe_r : 0.f;
+		if (fb && row == 0) {                  // the receive loop's feedback path (k_rx_loop): burst g0 only
+			fb[6] = (uint32_t)rv;
+			fb[8] = __float_as_uint(found_r ? toa_r : 0.f);
+			fb[9] = __float_as_uint(found_r ? ffe_r : 0.f);
+		}
 	}
 
 	// =========================== pass 2: soft symbols / soft bits ===========================
@@ -1684,13 +1699,13 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 		const float psi = lane_val(psi_r, src);
 		const float avr = lane_val(avr_r, src), avi = lane_val(avi_r, src);
 		const int blen = bt.len, nbits = bt.nbits;
-		float *gss = a.ssyms ? a.ssyms + (size_t)g * a.ssyms_stride : nullptr;
+		float *gss = io.ssyms ? io.ssyms + (size_t)g * a.ssyms_stride : nullptr;
 		int8_t *eb = L.eb + q * 432;
 		row_chain |= kind << q;
 		if (!found) {
-			if (a.ebits)
+			if (io.ebits)
 				for (int i = lane; i < a.ebits_stride; i += 64)
-					a.ebits[(size_t)g * a.ebits_stride + i] = 0;
+					io.ebits[(size_t)g * a.ebits_stride + i] = 0;
 			if (gss)
 				for (int i = lane; i < blen; i += 64)
 					gss[i] = 0.f;
@@ -1749,10 +1764,10 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 				*reinterpret_cast<uint16_t *>(eb + 2 * ord) = (uint16_t)pk2;
 			}
 		}
-		if (a.ebits) {
+		if (io.ebits) {
 			WSYNC();
 			const int neb = bt.ebits;
-			int8_t *ge = a.ebits + (size_t)g * a.ebits_stride;
+			int8_t *ge = io.ebits + (size_t)g * a.ebits_stride;
 			for (int i = lane; i < a.ebits_stride; i += 64)
 				ge[i] = i < neb ? eb[i] : (int8_t)0;
 		}
@@ -1772,18 +1787,106 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 	decode4_k5_12(L.bm, L.surv, L.ubits, lane, syn, fae);
 	if (col == 0 && row_live) {
 		if ((row_ok >> row) & 1) {
-			store_l2(a.l2 + (size_t)g_row * 24, L.ubits + row * 8);
-			a.crc[g_row] = syn ? 1 : 0;
-			a.conv[g_row] = (int32_t)fae;
+			store_l2(io.l2 + (size_t)g_row * 24, L.ubits + row * 8);
+			io.crc[g_row] = syn ? 1 : 0;
+			io.conv[g_row] = (int32_t)fae;
+			if (fb && row == 0) {
+#pragma unroll
+				for (int i = 0; i < 6; i++)
+					fb[i] = L.ubits[i];
+				fb[7] = syn ? 1u : 0u;
+			}
 		} else {
-			uint32_t *l2w = reinterpret_cast<uint32_t *>(a.l2 + (size_t)g_row * 24);
+			if (fb && row == 0)
+				fb[7] = 0xffffffffu;
+			uint32_t *l2w = reinterpret_cast<uint32_t *>(io.l2 + (size_t)g_row * 24);
 #pragma unroll
 			for (int i = 0; i < 6; i++)
 				l2w[i] = 0;
-			a.crc[g_row] = -1;
-			a.conv[g_row] = 0;
+			io.crc[g_row] = -1;
+			io.conv[g_row] = 0;
 		}
 	}
+}
+
+template <int NPL, int SPS>
+__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
+	// which shortens the critical path of a wave to a quarter
+	const int g0 = blockIdx.x * bpw;
+	const RxIo io = {a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
+	                 a.ebits, a.ssyms};
+	rx4_body<NPL, SPS>(a, io, stage_samples, cw, g0, min(a.n, g0 + bpw), lds_raw, (int)threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// k_rx_loop -- process_bcch (reference src/gmr1_rx.c:852-895) for one chain per work-group, from its first
+// frame to the end of the capture, without leaving the GPU.  The feedback of the loop only crosses a BCCH
+// frame, so it runs in rounds: wave 0 lists the chain's CCCH bursts up to and including its next BCCH burst
+// (rx_loop_build_round, rx_loop.h), up to eight wavefronts demodulate and decode one burst each (rx4_body,
+// the burst kernel itself), wave 0 applies the BCCH result (time, frequency, SI1 TDMA position) and lists
+// the next round.  Operands and feedback travel through LDS; every burst's result also goes to a log in HBM
+// that only the host reads, after the kernel, to replay the loop into records.  A round is about one wave's
+// latency instead of launch + kernel + synchronise + host (~59 us).
+// ---------------------------------------------------------------------------
+template <int NPL, int SPS>
+__global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoopArgs la, int stage_samples, int cw,
+                                                                int lds_per_wave)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	// a round's operands and the feedback of its BCCH burst never leave the CU
+	__shared__ uint64_t s_off[kLoopPerRound];
+	__shared__ float s_fs[kLoopPerRound];
+	__shared__ uint8_t s_kind[kLoopPerRound];
+	__shared__ RxLoopItem s_items[kLoopPerRound];
+	__shared__ uint32_t s_fb[kLoopPerRound][12];   // l2 words 0-5, rv, crc, toa, freq_err of each wave's burst
+	__shared__ int s_n;
+	const int chain = blockIdx.x;
+	const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+	const int sps = a.sps;
+	unsigned char *log_out = la.log_out + (size_t)chain * la.max_rounds * kLoopOutBytes;
+	RxLoopState st = la.state[chain];          // wave 0 keeps the live copy (all its lanes compute the same)
+	int round = 0, prev_bcch = 0, prev_etoa = 0;
+	for (; round < la.max_rounds; round++) {
+		unsigned char *out = log_out + (size_t)round * kLoopOutBytes;
+		if (wave == 0) {
+			if (prev_bcch) {
+				// the BCCH burst that ended the previous round
+				const uint32_t *f = s_fb[prev_bcch - 1];
+				uint32_t w[4] = {f[0], f[1], f[2], f[3]};          // SI1 needs bytes 0..13
+				rx_loop_bcch_result(st, sps, (int)f[6], (int)f[7], __uint_as_float(f[8]), __uint_as_float(f[9]),
+				                    reinterpret_cast<const uint8_t *>(w), prev_etoa);
+				rx_loop_advance(st, sps);
+			}
+			const int n = rx_loop_build_round(st, sps, s_items, [](const RxLoopState &) {});
+			if (lane < n) {
+				s_off[lane] = st.base + (uint64_t)s_items[lane].begin;
+				s_fs[lane] = -st.freq_err;
+				s_kind[lane] = s_items[lane].is_bcch ? 0 : 1;
+			}
+			if (lane == 0)
+				s_n = n;
+			prev_bcch = (n && s_items[n - 1].is_bcch) ? n : 0;
+			prev_etoa = n ? s_items[n - 1].e_toa : 0;
+		}
+		__syncthreads();
+		const int n = s_n;
+		if (n == 0)
+			break;
+		if (wave < n) {
+			const RxIo io = {s_off, s_kind, s_fs, out + kLoopOutL2,
+			                 reinterpret_cast<int32_t *>(out + kLoopOutCrc), reinterpret_cast<int32_t *>(out + kLoopOutConv),
+			                 reinterpret_cast<int32_t *>(out + kLoopOutRv), nullptr,
+			                 reinterpret_cast<float *>(out + kLoopOutToa), reinterpret_cast<float *>(out + kLoopOutFe),
+			                 reinterpret_cast<float *>(out + kLoopOutEnergy), nullptr, nullptr};
+			rx4_body<NPL, SPS>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane, s_fb[wave]);
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0)
+		la.n_rounds[chain] = round;
 }
 
 // ---------------------------------------------------------------------------
@@ -1961,6 +2064,32 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 	if (a.sps == 4)
 		return launch_rx_t<32, 4>(a, decode, max_in_len, max_len, stream);
 	return launch_rx_t<32, 0>(a, decode, max_in_len, max_len, stream);
+}
+
+hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream)
+{
+	if (n_chains <= 0)
+		return hipSuccess;
+	if (a.in_len[0] > kMaxInLen || a.dbg_stop)
+		return hipErrorInvalidValue;
+	const int max_len = 20 * a.sps + 1;
+	const int cw = (max_len + 15) & ~15;
+	size_t off4[4];
+	const size_t lds4 = (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
+	const size_t lds = lds4 * kLoopPerRound;
+	const dim3 grid((unsigned)n_chains), block(64 * kLoopPerRound);
+	if (a.in_len[0] <= 1024) {
+		if (a.sps == 4)
+			hipLaunchKernelGGL((k_rx_loop<16, 4>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+		else
+			hipLaunchKernelGGL((k_rx_loop<16, 0>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+	} else {
+		if (a.sps == 4)
+			hipLaunchKernelGGL((k_rx_loop<32, 4>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+		else
+			hipLaunchKernelGGL((k_rx_loop<32, 0>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+	}
+	return hipGetLastError();
 }
 
 hipError_t launch_detect(const DetectArgs &a, hipStream_t stream)
