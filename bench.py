@@ -138,9 +138,10 @@ def run_rx_workload(args):
     length = np.full(A, ns, np.uint64)
     stream = torch.cuda.current_stream(dev)
     res = [None]
+    rec_buf = np.zeros(1 << 18, api.RX_RECORD)       # the caller's record buffer, reused across steps
 
     def step():
-        res[0] = api.rx_run_dev(stream.cuda_stream, iq.data_ptr(), offset, length, sps=sps, max_records=1 << 20)
+        res[0] = api.rx_run_dev(stream.cuda_stream, iq.data_ptr(), offset, length, sps=sps, out=rec_buf)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

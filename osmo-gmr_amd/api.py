@@ -537,13 +537,19 @@ RX_RECORD = np.dtype([("arfcn", "<u2"), ("chain", "u1"), ("type", "u1"), ("fn", 
 assert RX_RECORD.itemsize == 40
 
 
-def _rx_run_call(fname, head_args, n, offset, length, arfcn, max_records):
+def _rx_run_call(fname, head_args, n, offset, length, arfcn, max_records, out=None):
     offset, p_off = _np(offset, np.uint64)
     length, p_len = _np(length, np.uint64)
     p_arfcn = None
     if arfcn is not None:
         arfcn, p_arfcn = _np(arfcn, np.uint16)
-    out = np.zeros(max(max_records, 1), RX_RECORD)
+    reuse = out is not None
+    if reuse:
+        if out.dtype != RX_RECORD or not out.flags.c_contiguous:
+            raise ValueError("out must be a contiguous RX_RECORD array")
+        max_records = out.size
+    else:
+        out = np.empty(max(max_records, 1), RX_RECORD)    # only the records written are handed back
     n_rec = C.c_int(0)
     status = np.zeros(max(n, 1), np.int32)
     chains = np.zeros(max(n, 1), np.int32)
@@ -552,7 +558,8 @@ def _rx_run_call(fname, head_args, n, offset, length, arfcn, max_records):
     rc = f(*head_args, p_off, p_len, p_arfcn, out.ctypes.data_as(C.c_void_p), C.c_int(max_records),
            C.byref(n_rec), status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p))
     _check(rc, fname)
-    return out[:min(n_rec.value, max_records)].copy(), status[:n], chains[:n], n_rec.value
+    got = out[:min(n_rec.value, max_records)]
+    return (got if reuse else got.copy()), status[:n], chains[:n], n_rec.value
 
 
 def rx_run(iq, offset, length, sps=4, arfcn=None, max_records=1 << 16):
@@ -564,11 +571,12 @@ def rx_run(iq, offset, length, sps=4, arfcn=None, max_records=1 << 16):
     return _rx_run_call("gmr1_hip_rx_run", head, n, offset, length, arfcn, max_records)
 
 
-def rx_run_dev(stream, iq_ptr, offset, length, sps=4, arfcn=None, max_records=1 << 16):
-    """gmr1_hip_rx_run_dev: as rx_run with the capture already in HBM (iq_ptr = device address)."""
+def rx_run_dev(stream, iq_ptr, offset, length, sps=4, arfcn=None, max_records=1 << 16, out=None):
+    """gmr1_hip_rx_run_dev: as rx_run with the capture already in HBM (iq_ptr = device address).
+    out: optional preallocated RX_RECORD array the records are written into (a view of it is returned)."""
     n = len(offset)
     head = (C.c_void_p(stream) if stream else None, C.c_int(n), C.c_int(sps), C.c_void_p(iq_ptr))
-    return _rx_run_call("gmr1_hip_rx_run_dev", head, n, offset, length, arfcn, max_records)
+    return _rx_run_call("gmr1_hip_rx_run_dev", head, n, offset, length, arfcn, max_records, out)
 
 
 def gsmtap_pack(record, with_arfcn=False) -> bytes:

@@ -22,7 +22,9 @@
 #include "capi_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "../../include/gmr1_hip.h"
@@ -142,6 +144,7 @@ struct RxRun {
 	std::vector<int> align, base_align;
 	std::vector<float> ferr;
 	std::vector<RxChain> chains;
+	double t_loop_gpu_us = 0;                // profiling: launch to log-on-host
 
 	int acquire();        // fcch_single_init + fcch_multi_process
 	int frame_loop();     // process_bcch: BCCH / CCCH, in rounds
@@ -344,6 +347,7 @@ int RxRun::frame_loop()
 	const int nc = (int)chains.size();
 	if (!nc)
 		return 0;
+	const auto t_start = std::chrono::steady_clock::now();
 	const int frame_len = sps * 24 * 39;
 	int max_frames = 0;
 	for (const RxChain &c : chains)
@@ -378,16 +382,19 @@ int RxRun::frame_loop()
 	HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipMemcpyAsync(h_nr, d_nr, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
+	t_loop_gpu_us = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count() / 1e3;
 
-	for (int ci = 0; ci < nc; ci++) {
+	// chains are independent: replayed by a few host threads (integer bookkeeping only)
+	auto replay = [&](int ci) -> int {
 		RxChain &c = chains[ci];
 		RxLoopState s = st0[ci];
+		c.rec.reserve((size_t)h_nr[ci] * (kLoopPerRound - 1));
+		c.rec_frame.reserve((size_t)h_nr[ci] * (kLoopPerRound - 1));
 		const uint16_t an = arfcn ? arfcn[c.a] : (uint16_t)c.a;
 		auto on_frame = [&](const RxLoopState &x) {
 			if (tch)
 				c.log.push_back({x.align, x.freq_err, x.fn});
 		};
-		int frames_done = 0;
 		bool closed = false;
 		for (int round = 0; round <= h_nr[ci] && round < max_rounds; round++) {
 			RxLoopItem items[kLoopPerRound];
@@ -399,7 +406,7 @@ int RxRun::frame_loop()
 				break;
 			}
 			if (round == h_nr[ci])
-				return fail(-EIO, "rx loop: chain %d stopped after %d rounds with frames left", ci, round);
+				return 1;                     // the device stopped with frames left
 			const unsigned char *ob = h_out + ((size_t)ci * max_rounds + round) * kLoopOutBytes;
 			const int32_t *o_crc = reinterpret_cast<const int32_t *>(ob + kLoopOutCrc);
 			const int32_t *o_conv = reinterpret_cast<const int32_t *>(ob + kLoopOutConv);
@@ -433,14 +440,28 @@ int RxRun::frame_loop()
 					}
 				}
 			}
-			frames_done++;
 		}
 		if (!closed)
-			return fail(-EIO, "rx loop: chain %d needs more than %d rounds", ci, max_rounds);
+			return 2;                         // more rounds than the log holds
 		c.align = s.align; c.freq_err = s.freq_err; c.fn = s.fn; c.delay = s.delay; c.stn = s.stn;
 		c.done = s.done != 0;
-		(void)frames_done;
-	}
+		return 0;
+	};
+	const int nthr = std::max(1, std::min({nc / 4, 8, (int)std::thread::hardware_concurrency()}));
+	std::vector<int> err((size_t)nc, 0);
+	auto work = [&](int t) {
+		for (int ci = t; ci < nc; ci += nthr)
+			err[ci] = replay(ci);
+	};
+	std::vector<std::thread> pool;
+	for (int t = 1; t < nthr; t++)
+		pool.emplace_back(work, t);
+	work(0);
+	for (std::thread &th : pool)
+		th.join();
+	for (int ci = 0; ci < nc; ci++)
+		if (err[ci])
+			return fail(-EIO, err[ci] == 1 ? "rx loop: chain %d stopped with frames left" : "rx loop: chain %d needs more rounds than the log holds", ci);
 	return 0;
 }
 
@@ -941,10 +962,21 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	run.stat.assign(n_arfcn, 0); run.nch.assign(n_arfcn, 0);
 	run.align.assign(n_arfcn, kStartDiscard); run.base_align.assign(n_arfcn, 0);
 	run.ferr.assign(n_arfcn, 0.0f);
+	// GMR1_HIP_RX_TIMING=1: wall time of the phases on stderr (profiling only)
+	static const bool timing = getenv("GMR1_HIP_RX_TIMING") != nullptr;
+	auto now = [] { return std::chrono::steady_clock::now(); };
+	const auto t0 = now();
 	if ((r = run.acquire())) return r;
+	const auto t1 = now();
 	if ((r = run.frame_loop())) return r;
+	const auto t2 = now();
 	if (tch && (r = run.tch3_pass())) return r;
 	if (csd && (r = run.tch9_pass())) return r;
+	if (timing) {
+		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+		fprintf(stderr, "rx_run: acquire %.0f us, frame loop %.0f us (launch+copy %.0f, replay %.0f), traffic passes %.0f us\n",
+		        us(t0, t1), us(t1, t2), run.t_loop_gpu_us, us(t1, t2) - run.t_loop_gpu_us, us(t2, now()));
+	}
 	const std::vector<RxChain> &chains = run.chains;
 	const std::vector<int32_t> &stat = run.stat, &nch = run.nch;
 	const int A = n_arfcn;
