@@ -162,7 +162,8 @@ __device__ __forceinline__ uint32_t lds_read(uint32_t addr)
 
 // One trellis step at window position J (phase J % 8).  ad[ph][r]: LDS byte address of the position's
 // table value in step 0 of the current window;  T[ph]: decision bit pattern of the lane phases.
-template <int J>
+// REC = false (the warm-up pass): no decision bits, one add less per state.
+template <int J, bool REC>
 __device__ __forceinline__ void k9_step(uint32_t (&w)[4], const uint32_t (&ad)[8][4], const uint32_t (&hi)[6])
 {
 	constexpr int PH = J & 7;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void k9_step(uint32_t (&w)[4], const uint32_t (&ad)[8
 	if constexpr (PH < 6) {
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
-			const uint32_t v = w[r] + (hi[PH] << J);
+			const uint32_t v = REC ? w[r] + (hi[PH] << J) : w[r];
 			const uint32_t t1 = v + m[r];
 			const uint32_t t2 = k9_partner<PH>(v) - m[r];
 			w[r] = t1 < t2 ? t1 : t2;
@@ -183,7 +184,7 @@ __device__ __forceinline__ void k9_step(uint32_t (&w)[4], const uint32_t (&ad)[8
 #pragma unroll
 		for (int q = 0; q < 2; q++) {
 			const int lo = PH == 6 ? q : 2 * q, h = lo + D;
-			const uint32_t vl = w[lo], vh = w[h] + (1u << J);
+			const uint32_t vl = w[lo], vh = REC ? w[h] + (1u << J) : w[h];
 			const uint32_t a1 = vl + m[lo], a2 = vh - m[lo];
 			const uint32_t b1 = vh + m[h], b2 = vl - m[h];
 			w[lo] = a1 < a2 ? a1 : a2;
@@ -214,10 +215,10 @@ __device__ __forceinline__ int k9_pass(uint32_t (&w)[4], uint32_t (&ad)[8][4], c
 	int off = 0;
 #pragma unroll 1
 	for (int wm = 0; wm < kXchWin; wm++) {
-		k9_step<0>(w, ad, hi); k9_step<1>(w, ad, hi); k9_step<2>(w, ad, hi); k9_step<3>(w, ad, hi);
-		k9_step<4>(w, ad, hi); k9_step<5>(w, ad, hi); k9_step<6>(w, ad, hi); k9_step<7>(w, ad, hi);
-		k9_step<8>(w, ad, hi); k9_step<9>(w, ad, hi); k9_step<10>(w, ad, hi); k9_step<11>(w, ad, hi);
-		k9_step<12>(w, ad, hi); k9_step<13>(w, ad, hi); k9_step<14>(w, ad, hi); k9_step<15>(w, ad, hi);
+		k9_step<0, REC>(w, ad, hi); k9_step<1, REC>(w, ad, hi); k9_step<2, REC>(w, ad, hi); k9_step<3, REC>(w, ad, hi);
+		k9_step<4, REC>(w, ad, hi); k9_step<5, REC>(w, ad, hi); k9_step<6, REC>(w, ad, hi); k9_step<7, REC>(w, ad, hi);
+		k9_step<8, REC>(w, ad, hi); k9_step<9, REC>(w, ad, hi); k9_step<10, REC>(w, ad, hi); k9_step<11, REC>(w, ad, hi);
+		k9_step<12, REC>(w, ad, hi); k9_step<13, REC>(w, ad, hi); k9_step<14, REC>(w, ad, hi); k9_step<15, REC>(w, ad, hi);
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			if (REC)
