@@ -327,15 +327,35 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 // ---------------------------------------------------------------------------
 static constexpr int kT3Steps = 48;
 
-// soft bit c[kc] of frame `fr` (tch3.c:141-172): returns the descrambled / deciphered value
+// where soft bit c[kc] of frame fr sits (tch3.c:141-172), for both multiplexing modes: index q into the
+// 208 bits of xmy (= cipher stream position), bit 8: the scrambler flips it.  The 104-bit permutation
+// (kep), the frame de-multiplexing and the scrambler are folded into one table lookup.
+struct T3Map { uint16_t q[2][2][104]; };       // [m][fr][kc]
+static constexpr T3Map make_t3map()
+{
+	T3Map t{};
+	const ScrBits scr = make_scr();
+	for (int m = 0; m < 2; m++)
+		for (int fr = 0; fr < 2; fr++)
+			for (int kc = 0; kc < 104; kc++) {
+				const int ii = kc % 24, ij = kc / 24;
+				const int kep = (ii < 8) ? (ij + 5 * ii) : (ij + 4 * ii + 8);   // bits_c[kc] = bits_ep[kep]
+				const int q = m ? (104 * fr + kep) : ((kep << 1) + fr);          // index into epp / xmy
+				const uint32_t flip = (scr.w[q >> 5] >> (q & 31)) & 1u;
+				t.q[m][fr][kc] = (uint16_t)(q | (flip << 8));
+			}
+	return t;
+}
+__constant__ T3Map c_t3map = make_t3map();
+
+// soft bit c[kc] of frame `fr`: the descrambled / deciphered value
 __device__ __forceinline__ int tch3_c(const int8_t *__restrict__ e, const uint8_t *__restrict__ ciph,
                                       int fr, int m, int kc)
 {
-	const int ii = kc % 24, ij = kc / 24;
-	const int kep = (ii < 8) ? (ij + 5 * ii) : (ij + 4 * ii + 8);   // bits_c[kc] = bits_ep[kep]
-	const int q = m ? (104 * fr + kep) : ((kep << 1) + fr);          // index into epp / xmy
+	const uint32_t me = c_t3map.q[m][fr][kc];
+	const int q = (int)(me & 0xffu);
 	int v = e[q < 52 ? q : q + 4];                                   // xmy = e[0..51] | e[56..211]
-	bool flip = (c_scr.w[q >> 5] >> (q & 31)) & 1u;
+	bool flip = (me >> 8) != 0;
 	if (ciph)
 		flip ^= ciph[q] != 0;
 	return flip ? (int)(int8_t)(-v) : v;
@@ -425,8 +445,10 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	__shared__ __align__(16) int8_t s_e[216];
 	__shared__ __align__(16) uint32_t s_tab[kT3Steps * 4];     // (2 cost(word) - K) << 16 per step and code word
 	__shared__ uint16_t s_win[4][64];
+	__shared__ uint8_t s_locof[64];            // location of a state: the survivor walk reads it four times in a row
 	const int lane = threadIdx.x;
 	const int g = blockIdx.x >> 1, fr = blockIdx.x & 1;
+	s_locof[c_k7.st[lane]] = (uint8_t)lane;
 	const int m = a.m;
 	const uint8_t *ciph = a.ciph ? a.ciph + (size_t)g * 208 : nullptr;
 
@@ -535,13 +557,13 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	// u[42..47] are the end state's bits (bit j = u[47 - j]); window m gives u[12m-6 .. 12m+5] LSB first
 	__shared__ uint32_t s_d[3];       // 80 decoded bits, bit k of the frame at word k>>5, bit k&31
 	{
-		uint32_t L = c_k7.loc_of[end_state];
+		uint32_t L = s_locof[end_state];
 		const uint32_t h3 = s_win[3][L];
-		L = c_k7.loc_of[__brev(h3 & 63u) >> 26];
+		L = s_locof[__brev(h3 & 63u) >> 26];
 		const uint32_t h2 = s_win[2][L];
-		L = c_k7.loc_of[__brev(h2 & 63u) >> 26];
+		L = s_locof[__brev(h2 & 63u) >> 26];
 		const uint32_t h1 = s_win[1][L];
-		L = c_k7.loc_of[__brev(h1 & 63u) >> 26];
+		L = s_locof[__brev(h1 & 63u) >> 26];
 		const uint32_t h0 = s_win[0][L];
 		// u[0..5] = h0 >> 6, u[6..17] = h1, u[18..29] = h2, u[30..41] = h3, u[42..47] = rev6(end_state)
 		const unsigned long long u = (unsigned long long)((h0 >> 6) & 63u) | ((unsigned long long)(h1 & 0xfffu) << 6) |
@@ -565,15 +587,9 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 		hv = tch3_c(s_e, ciph, fr, m, 72 + lane) < 0;
 	const unsigned long long m_hi = __ballot(hv != 0);            // bits 48..79 in lanes 0..31
 	if (lane < 10) {
-		// byte `lane` holds frame bits 8*lane .. 8*lane+7, first bit in the MSB
-		uint32_t byte = 0;
-#pragma unroll
-		for (int t = 0; t < 8; t++) {
-			const int k = 8 * lane + t;
-			const uint32_t bit = k < 48 ? (uint32_t)((m_lo >> k) & 1ull) : (uint32_t)((m_hi >> (k - 48)) & 1ull);
-			byte |= bit << (7 - t);
-		}
-		a.frames[((size_t)g * 2 + fr) * 10 + lane] = (uint8_t)byte;
+		// byte `lane` holds frame bits 8*lane .. 8*lane+7, first bit in the MSB: eight ballot bits, reversed
+		const uint32_t raw = lane < 6 ? (uint32_t)(m_lo >> (8 * lane)) : (uint32_t)(m_hi >> (8 * (lane - 6)));
+		a.frames[((size_t)g * 2 + fr) * 10 + lane] = (uint8_t)(__brev(raw & 0xffu) >> 24);
 	}
 	if (lane == 0 && a.conv)
 		a.conv[(size_t)g * 2 + fr] = (int32_t)min_ae;

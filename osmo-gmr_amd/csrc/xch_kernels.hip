@@ -247,8 +247,12 @@ __global__ __launch_bounds__(64) void k_xch(XchArgs a)
 	__shared__ __align__(16) uint32_t s_tab[kXchLen * 8];      // (2 cost(word) - K) << 16 per step and code word
 	__shared__ uint16_t s_win[kXchWin * 4 * 64];
 	__shared__ uint16_t s_u[kXchWin];                          // decoded bits, LSB first
+	__shared__ uint8_t s_locof[256];                           // position of a state (the survivor walk's 13 hops)
 	const int lane = threadIdx.x;
 	const int g = blockIdx.x;
+#pragma unroll
+	for (int r = 0; r < 4; r++)
+		s_locof[c_k9.st[r][lane]] = (uint8_t)(r * 64 + lane);
 
 	{
 		const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ebits + (size_t)g * 432);
@@ -348,14 +352,14 @@ __global__ __launch_bounds__(64) void k_xch(XchArgs a)
 	// ---- survivor chain (uniform): window m's decisions are u[16m-8 .. 16m+7] of the path ending at the
 	// position, LSB first; its low byte, bit-reversed, is the state the window started in
 	{
-		uint32_t P = c_k9.loc_of[end_state];
+		uint32_t P = s_locof[end_state];
 		uint32_t nxt = __brev(end_state) >> 24;              // u[200..207]
 		for (int wm = kXchWin - 1; wm >= 0; wm--) {
 			const uint32_t h = s_win[wm * 256 + P];
 			if (lane == 0)
 				s_u[wm] = (uint16_t)((h >> 8) | (nxt << 8));
 			nxt = h & 0xffu;
-			P = c_k9.loc_of[__brev(nxt) >> 24];
+			P = s_locof[__brev(nxt) >> 24];
 		}
 	}
 	WSYNC();
