@@ -10,7 +10,8 @@
 //   k_tch3   : TCH3 speech, 212 soft bits -> 2 x 10 bytes + 4 status bits
 //              (reference src/l1/tch3.c:124-183): status demux, [decipher], descramble,
 //              frame demux (m), 104-permutation, K=7 tail-biting rate-1/2 Viterbi with
-//              P(1;2) puncturing (two passes of 48 steps, 64 states = 64 lanes), 32 hard
+//              P(1;2) puncturing (two passes of 48 steps; one burst per wave, a frame per half-wave,
+//              two states per lane), 32 hard
 //              class-2 bits, MSB-first packing.  One (burst, frame) per wavefront.
 //
 // Both follow libosmocore's generic osmo_conv_decode (oracle/orc_3p.c decisions D1, D4).
@@ -362,15 +363,15 @@ __device__ __forceinline__ int tch3_c(const int8_t *__restrict__ e, const uint8_
 }
 
 // K=7 rate-1/2: g0 = 1+D^2+D^3+D^5+D^6, g1 = 1+D+D^2+D^3+D^6 (conv.c:518-571).
-// Per lane (= row location of a state) constants of the in-place 64-state butterfly.  The two
-// predecessors of a state sit in lanes that differ by the xor mask of the phase: 32, 16, 8, 7, 2, 1
-// (bpermute for the first two, one DPP control each for the rest).  With loc = c0*32 ^ c1*16 ^ c2*8 ^
-// c3*7 ^ c4*2 ^ c5*1, the predecessor state a lane holds in phase ph has bit i = c[(5 - i + ph) % 6];
-// after 6 steps the layout is back where it started.
-//   a[loc]  : bits 0-11 cost byte of the own transition per phase (2 bits each), 12-23 of the
-//             partner's, 24-29 "this lane holds the HIGH predecessor" per phase
-//   st[loc] : state held in phase 0;  loc_of[state] : its inverse
-struct K7Tab { uint32_t a[64]; uint8_t st[64]; uint8_t loc_of[64]; };
+// One burst per wavefront: its two speech frames occupy the two 32-lane halves, and the 64 trellis states of
+// a frame live two to a lane.  Position bits c0..c4 = lane within the half (xor masks 16, 8, 7, 2, 1),
+// c5 = register index; with the in-place butterfly the predecessor state a position holds in phase
+// ph = step % 6 has bit i = c[(5 - i + ph) % 6], so the two predecessors of a position differ in position bit
+// ph: lane xor 16 (ds_bpermute), 8, 7, 2, 1 (one DPP control each) for phases 0-4 and the register index for
+// phase 5 (no cross-lane traffic).  After 6 steps the layout is back where it started.
+//   o[r][p]   : code word (2 bits) of the own transition per phase
+//   st[r][p]  : state held in phase 0;  loc_of[state] = r * 32 + p
+struct K7Tab { uint16_t o[2][32]; uint8_t st[2][32]; uint8_t loc_of[64]; };
 static constexpr uint32_t k7_out(uint32_t s, uint32_t b)
 {
 	const uint32_t reg = (s << 1) | b;
@@ -382,73 +383,109 @@ static constexpr uint32_t k7_out(uint32_t s, uint32_t b)
 static constexpr K7Tab make_k7()
 {
 	K7Tab t{};
-	for (uint32_t loc = 0; loc < 64; loc++) {
-		uint32_t c[6] = {0, 0, 0, 0, 0, 0};
-		c[0] = (loc >> 5) & 1u;
-		c[1] = (loc >> 4) & 1u;
-		c[2] = (loc >> 3) & 1u;
-		uint32_t x = loc & 7u;
-		c[3] = (x >> 2) & 1u;
-		x ^= c[3] ? 7u : 0u;
-		c[4] = (x >> 1) & 1u;
-		c[5] = x & 1u;
-		uint32_t e = 0;
-		for (int ph = 0; ph < 6; ph++) {
-			uint32_t sp = 0;
-			for (int i = 0; i < 6; i++)
-				sp |= c[(5 - i + ph) % 6] << i;
-			const uint32_t b = sp >> 5;
-			e |= k7_out(sp, b) << (2 * ph);
-			e |= k7_out(sp ^ 32u, b) << (12 + 2 * ph);
-			e |= b << (24 + ph);
-			if (ph == 0) {
-				t.st[loc] = (uint8_t)sp;
-				t.loc_of[sp] = (uint8_t)loc;
+	for (uint32_t r = 0; r < 2; r++)
+		for (uint32_t p = 0; p < 32; p++) {
+			uint32_t c[6] = {0, 0, 0, 0, 0, 0};
+			c[0] = (p >> 4) & 1u;
+			c[1] = (p >> 3) & 1u;
+			uint32_t x = p & 7u;
+			c[2] = (x >> 2) & 1u;
+			x ^= c[2] ? 7u : 0u;
+			c[3] = (x >> 1) & 1u;
+			c[4] = x & 1u;
+			c[5] = r;
+			uint32_t e = 0;
+			for (int ph = 0; ph < 6; ph++) {
+				uint32_t sp = 0;
+				for (int i = 0; i < 6; i++)
+					sp |= c[(5 - i + ph) % 6] << i;
+				e |= k7_out(sp, sp >> 5) << (2 * ph);
+				if (ph == 0) {
+					t.st[r][p] = (uint8_t)sp;
+					t.loc_of[sp] = (uint8_t)(r * 32 + p);
+				}
 			}
+			t.o[r][p] = (uint16_t)e;
 		}
-		t.a[loc] = e;
-	}
 	return t;
 }
 __constant__ K7Tab c_k7 = make_k7();
 
-// partner's word in phase PH
+// the word of the position whose lane differs in position bit PH (PH < 5)
 template <int PH>
 __device__ __forceinline__ uint32_t k7_partner(uint32_t w)
 {
-	if constexpr (PH == 0) return (uint32_t)__shfl_xor((int)w, 32);
-	else if constexpr (PH == 1) return (uint32_t)__shfl_xor((int)w, 16);
-	else if constexpr (PH == 2) return dpp<0x128>(w);       // row_ror:8
-	else if constexpr (PH == 3) return dpp<0x141>(w);       // row_half_mirror: xor 7
-	else if constexpr (PH == 4) return dpp<0x4E>(w);        // quad_perm [2,3,0,1]
+	if constexpr (PH == 0) return (uint32_t)__shfl_xor((int)w, 16);
+	else if constexpr (PH == 1) return dpp<0x128>(w);       // row_ror:8
+	else if constexpr (PH == 2) return dpp<0x141>(w);       // row_half_mirror: xor 7
+	else if constexpr (PH == 3) return dpp<0x4E>(w);        // quad_perm [2,3,0,1]
 	else return dpp<0xB1>(w);                               // quad_perm [1,0,3,2]
 }
 
-// One trellis step on the packed word [metric:16 | decisions of the current 12-step window:16]
-// (see decode4_k5_12 in rx_kernels.hip).  Both generators have the D^0 and D^6 taps, so the two
-// transitions into a state carry complementary code words and their costs add up to a per-step constant K:
-// the words hold 2 * metric - sum K, a candidate is `own + m` / `partner - m` with ONE table value
-// m = (2 cost - K) << 16 (the subtraction takes the DPP operand directly), comparisons and ties are those
-// of the plain metric.  The HIGH-predecessor lane carries the tie-break / decision bit of the position, so
-// v_min_u32 selects, breaks ties towards the low predecessor and records the decision at once.
-template <int PH>
-__device__ __forceinline__ uint32_t k7_step(uint32_t w, const uint32_t *__restrict__ tab, uint32_t o_own)
+typedef __attribute__((address_space(3))) const uint32_t t3_lds_cu32;
+
+// One trellis step at window position J (phase J % 6) on the packed words [metric:16 | decisions of the
+// current 12-step window:16] (see decode4_k5_12 in rx_kernels.hip).  Both generators have the D^0 and D^6
+// taps, so the two transitions into a state carry complementary code words and their costs add up to a
+// per-step constant K: the words hold 2 * metric - sum K, a candidate is `own + m` / `partner - m` with ONE
+// table value m = (2 cost - K) << 16 (the subtraction takes the DPP operand directly), comparisons and ties
+// are those of the plain metric.  The HIGH predecessor carries the tie-break / decision bit of the position,
+// so v_min_u32 selects, breaks ties towards the low predecessor and records the decision at once (REC).
+// ad[ph][r]: LDS byte address of the position's table value in step 0.
+template <int J, int K, bool REC>
+__device__ __forceinline__ void k7_step(uint32_t (&w)[2], const uint32_t (&ad)[6][2], const uint32_t (&hi)[5])
 {
-	const uint32_t m = tab[o_own];
-	const uint32_t t1 = w + m;
-	const uint32_t t2 = k7_partner<PH>(w) - m;
-	return t1 < t2 ? t1 : t2;
+	constexpr int PH = J % 6;
+	const uint32_t m0 = *(t3_lds_cu32 *)(uintptr_t)(ad[PH][0] + 16u * K);
+	const uint32_t m1 = *(t3_lds_cu32 *)(uintptr_t)(ad[PH][1] + 16u * K);
+	if constexpr (PH < 5) {
+		const uint32_t v0 = REC ? w[0] + (hi[PH] << J) : w[0], v1 = REC ? w[1] + (hi[PH] << J) : w[1];
+		const uint32_t a1 = v0 + m0, a2 = k7_partner<PH>(v0) - m0;
+		const uint32_t b1 = v1 + m1, b2 = k7_partner<PH>(v1) - m1;
+		w[0] = a1 < a2 ? a1 : a2;
+		w[1] = b1 < b2 ? b1 : b2;
+	} else {
+		const uint32_t vl = w[0], vh = REC ? w[1] + (1u << J) : w[1];
+		const uint32_t a1 = vl + m0, a2 = vh - m0;
+		const uint32_t b1 = vh + m1, b2 = vl - m1;
+		w[0] = a1 < a2 ? a1 : a2;
+		w[1] = b1 < b2 ? b1 : b2;
+	}
+}
+
+// twelve steps starting at step K0
+template <int K0, bool REC>
+__device__ __forceinline__ void k7_window(uint32_t (&w)[2], const uint32_t (&ad)[6][2], const uint32_t (&hi)[5])
+{
+	k7_step<0, K0 + 0, REC>(w, ad, hi); k7_step<1, K0 + 1, REC>(w, ad, hi); k7_step<2, K0 + 2, REC>(w, ad, hi);
+	k7_step<3, K0 + 3, REC>(w, ad, hi); k7_step<4, K0 + 4, REC>(w, ad, hi); k7_step<5, K0 + 5, REC>(w, ad, hi);
+	k7_step<6, K0 + 6, REC>(w, ad, hi); k7_step<7, K0 + 7, REC>(w, ad, hi); k7_step<8, K0 + 8, REC>(w, ad, hi);
+	k7_step<9, K0 + 9, REC>(w, ad, hi); k7_step<10, K0 + 10, REC>(w, ad, hi); k7_step<11, K0 + 11, REC>(w, ad, hi);
+}
+
+// minimum over the 32 lanes of each half
+__device__ __forceinline__ uint32_t half_min(uint32_t v)
+{
+	uint32_t o;
+	o = dpp<0xB1>(v); v = o < v ? o : v;
+	o = dpp<0x4E>(v); v = o < v ? o : v;
+	o = dpp<0x141>(v); v = o < v ? o : v;
+	o = dpp<0x128>(v); v = o < v ? o : v;
+	o = (uint32_t)__shfl_xor((int)v, 16); v = o < v ? o : v;
+	return v;
 }
 
 __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 {
 	__shared__ __align__(16) int8_t s_e[216];
-	__shared__ __align__(16) uint32_t s_tab[kT3Steps * 4];     // (2 cost(word) - K) << 16 per step and code word
-	__shared__ uint16_t s_win[4][64];
-	__shared__ uint8_t s_locof[64];            // location of a state: the survivor walk reads it four times in a row
+	__shared__ __align__(16) uint32_t s_tab[2][kT3Steps * 4];  // per frame: (2 cost(word) - K) << 16 per step and code word
+	__shared__ uint16_t s_win[2][4][64];
+	__shared__ uint8_t s_locof[64];            // position of a state: the survivor walk reads it four times in a row
 	const int lane = threadIdx.x;
-	const int g = blockIdx.x >> 1, fr = blockIdx.x & 1;
-	s_locof[c_k7.st[lane]] = (uint8_t)lane;
+	const int fr = lane >> 5, p = lane & 31;   // the half-wave's frame, position within the half
+	const int g = blockIdx.x;
+	s_locof[c_k7.st[0][p]] = (uint8_t)p;       // (both halves write the same values)
+	s_locof[c_k7.st[1][p]] = (uint8_t)(32 + p);
 	const int m = a.m;
 	const uint8_t *ciph = a.ciph ? a.ciph + (size_t)g * 208 : nullptr;
 
@@ -460,139 +497,137 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	}
 	WSYNC();
 
-	// status bits (tch3.c:133-134), written by the frame-0 wave
-	if (fr == 0 && a.bits_s && lane < 4)
+	// status bits (tch3.c:133-134)
+	if (a.bits_s && lane < 4)
 		a.bits_s[(size_t)g * 4 + lane] = s_e[52 + lane] < 0;
 
 	// ---- branch metrics: step s has coded bits 2s (always sent) and 2s+1 (punctured when
-	// 2s+1 = 3 mod 4, i.e. s odd); the sent bits are c[idx - (idx>>2)]   (punct.c:48-133, P(1;2))
+	// 2s+1 = 3 mod 4, i.e. s odd); the sent bits are c[idx - (idx>>2)]   (punct.c:48-133, P(1;2)).
+	// 2 x 48 steps: frame 0 on lanes 0-47, then frame 1; sum of K per frame
 	int ksum = 0;
-	if (lane < kT3Steps) {
-		const int s = lane;
-		const int i0 = 2 * s, i1 = 2 * s + 1;
-		const int v0 = tch3_c(s_e, ciph, fr, m, i0 - (i0 >> 2));
-		const int v1 = (s & 1) ? 0 : tch3_c(s_e, ciph, fr, m, i1 - (i1 >> 2));
-		const int a0 = sbit_cost(v0, 0), a1 = sbit_cost(v0, 1);
-		const int b0 = sbit_cost(v1, 0), b1c = sbit_cost(v1, 1);
-		const int da = a1 - a0, db = b1c - b0;
-		ksum = a0 + a1 + b0 + b1c;
-		// code word o = (g0 bit << 1) | g1 bit
-		*reinterpret_cast<uint4 *>(&s_tab[4 * s]) = make_uint4((uint32_t)(-da - db) << 16, (uint32_t)(-da + db) << 16,
-		                                                       (uint32_t)(da - db) << 16, (uint32_t)(da + db) << 16);
-	}
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1)
-		ksum += __shfl_xor(ksum, o);
+	for (int f = 0; f < 2; f++) {
+		int ks = 0;
+		if (lane < kT3Steps) {
+			const int s = lane;
+			const int i0 = 2 * s, i1 = 2 * s + 1;
+			const int v0 = tch3_c(s_e, ciph, f, m, i0 - (i0 >> 2));
+			const int v1 = (s & 1) ? 0 : tch3_c(s_e, ciph, f, m, i1 - (i1 >> 2));
+			const int a0 = sbit_cost(v0, 0), a1 = sbit_cost(v0, 1);
+			const int b0 = sbit_cost(v1, 0), b1c = sbit_cost(v1, 1);
+			const int da = a1 - a0, db = b1c - b0;
+			ks = a0 + a1 + b0 + b1c;
+			// code word o = (g0 bit << 1) | g1 bit
+			*reinterpret_cast<uint4 *>(&s_tab[f][4 * s]) = make_uint4((uint32_t)(-da - db) << 16, (uint32_t)(-da + db) << 16,
+			                                                          (uint32_t)(da - db) << 16, (uint32_t)(da + db) << 16);
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1)
+			ks += __shfl_xor(ks, o);
+		if (fr == f)
+			ksum = ks;
+	}
 	WSYNC();
 
-	// ---- in-place 64-state trellis on packed words
-	const uint32_t tab = c_k7.a[lane];
-	uint32_t o_own[6];
-	uint32_t T[12];            // tie-break / decision bit of window position j, set in HIGH-predecessor lanes
-#pragma unroll
-	for (int ph = 0; ph < 6; ph++)
-		o_own[ph] = (tab >> (2 * ph)) & 3u;
-#pragma unroll
-	for (int j = 0; j < 12; j++)
-		T[j] = ((tab >> (24 + (j % 6))) & 1u) << j;
-	constexpr uint32_t kSent = 0xF0000000u;       // unreachable (libosmocore: MAX_AE)
-	constexpr uint32_t kBias = 0x4000u;           // |2 cost - K| <= 252 per step, 48 steps: stays inside 16 bits
-
-	// pass 1 (warm-up from state 0, D4): only the metrics matter
-	uint32_t w = c_k7.st[lane] ? kSent : (kBias << 16);
-#pragma unroll
-	for (int k = 0; k < kT3Steps; k += 6) {
-		w = k7_step<0>(w, s_tab + 4 * (k + 0), o_own[0]);
-		w = k7_step<1>(w, s_tab + 4 * (k + 1), o_own[1]);
-		w = k7_step<2>(w, s_tab + 4 * (k + 2), o_own[2]);
-		w = k7_step<3>(w, s_tab + 4 * (k + 3), o_own[3]);
-		w = k7_step<4>(w, s_tab + 4 * (k + 4), o_own[4]);
-		w = k7_step<5>(w, s_tab + 4 * (k + 5), o_own[5]);
+	// ---- per-lane constants
+	uint32_t hi[5];
+	{
+		uint32_t x = (uint32_t)p & 7u;
+		hi[0] = ((uint32_t)p >> 4) & 1u;
+		hi[1] = ((uint32_t)p >> 3) & 1u;
+		hi[2] = (x >> 2) & 1u;
+		x ^= hi[2] ? 7u : 0u;
+		hi[3] = (x >> 1) & 1u;
+		hi[4] = x & 1u;
 	}
+	const uint32_t tab_base = (uint32_t)(uintptr_t)(t3_lds_cu32 *)s_tab[fr];
+	uint32_t ad[6][2];
+	uint32_t w[2];
+	constexpr uint32_t kSent = 0xF000u;           // unreachable (libosmocore: MAX_AE)
+	constexpr uint32_t kBias = 0x4000u;           // |2 cost - K| <= 252 per step, 48 steps: stays inside 16 bits
+#pragma unroll
+	for (int r = 0; r < 2; r++) {
+		const uint32_t e = c_k7.o[r][p];
+#pragma unroll
+		for (int ph = 0; ph < 6; ph++)
+			ad[ph][r] = tab_base + 4u * ((e >> (2 * ph)) & 3u);
+		// pass 1 starts from state 0 (D4)
+		w[r] = (c_k7.st[r][p] ? kSent : kBias) << 16;
+	}
+
+	// pass 1 (warm-up): only the metrics matter
+	k7_window<0, false>(w, ad, hi);
+	k7_window<12, false>(w, ad, hi);
+	k7_window<24, false>(w, ad, hi);
+	k7_window<36, false>(w, ad, hi);
 	// rewind: subtract the minimum (osmo_conv_decode_rewind)
 	{
-		uint32_t mn = w >> 16;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
-			const uint32_t ov = (uint32_t)__shfl_xor((int)mn, o);
-			mn = ov < mn ? ov : mn;
-		}
-		w = (((w >> 16) - mn + kBias) << 16) | T[0];
+		const uint32_t mn = half_min((w[0] < w[1] ? w[0] : w[1]) >> 16);
+		w[0] = ((w[0] >> 16) - mn + kBias) << 16;
+		w[1] = ((w[1] >> 16) - mn + kBias) << 16;
 	}
-	// pass 2: four windows of 12 steps; window m's decisions at a location are u[12m-6 .. 12m+5] of the
+	// pass 2: four windows of 12 steps; window m's decisions at a position are u[12m-6 .. 12m+5] of the
 	// path ending there, and the first six name the state at the start of the window
-#pragma unroll
-	for (int wm = 0; wm < 4; wm++) {
-		const int k = 12 * wm;
-		w = k7_step<0>(w, s_tab + 4 * (k + 0), o_own[0]) + T[1];
-		w = k7_step<1>(w, s_tab + 4 * (k + 1), o_own[1]) + T[2];
-		w = k7_step<2>(w, s_tab + 4 * (k + 2), o_own[2]) + T[3];
-		w = k7_step<3>(w, s_tab + 4 * (k + 3), o_own[3]) + T[4];
-		w = k7_step<4>(w, s_tab + 4 * (k + 4), o_own[4]) + T[5];
-		w = k7_step<5>(w, s_tab + 4 * (k + 5), o_own[5]) + T[6];
-		w = k7_step<0>(w, s_tab + 4 * (k + 6), o_own[0]) + T[7];
-		w = k7_step<1>(w, s_tab + 4 * (k + 7), o_own[1]) + T[8];
-		w = k7_step<2>(w, s_tab + 4 * (k + 8), o_own[2]) + T[9];
-		w = k7_step<3>(w, s_tab + 4 * (k + 9), o_own[3]) + T[10];
-		w = k7_step<4>(w, s_tab + 4 * (k + 10), o_own[4]) + T[11];
-		w = k7_step<5>(w, s_tab + 4 * (k + 11), o_own[5]);
-		s_win[wm][lane] = (uint16_t)w;
-		w = (w & 0xffff0000u) | T[0];
-	}
+	k7_window<0, true>(w, ad, hi);
+	s_win[fr][0][p] = (uint16_t)w[0]; s_win[fr][0][32 + p] = (uint16_t)w[1];
+	w[0] &= 0xffff0000u; w[1] &= 0xffff0000u;
+	k7_window<12, true>(w, ad, hi);
+	s_win[fr][1][p] = (uint16_t)w[0]; s_win[fr][1][32 + p] = (uint16_t)w[1];
+	w[0] &= 0xffff0000u; w[1] &= 0xffff0000u;
+	k7_window<24, true>(w, ad, hi);
+	s_win[fr][2][p] = (uint16_t)w[0]; s_win[fr][2][32 + p] = (uint16_t)w[1];
+	w[0] &= 0xffff0000u; w[1] &= 0xffff0000u;
+	k7_window<36, true>(w, ad, hi);
+	s_win[fr][3][p] = (uint16_t)w[0]; s_win[fr][3][32 + p] = (uint16_t)w[1];
 	WSYNC();
 
-	// best end state: smallest metric, lowest state on ties (48 = 8 * 6 steps: every state is back in its
-	// phase-0 location)
-	unsigned long long key = ((unsigned long long)(w >> 16) << 32) | c_k7.st[lane];
+	// best end state of each frame: smallest metric, lowest state on ties (48 = 8 * 6 steps: every state is
+	// back in its phase-0 position)
+	unsigned long long key;
+	{
+		const unsigned long long k0 = ((unsigned long long)(w[0] >> 16) << 32) | c_k7.st[0][p];
+		const unsigned long long k1 = ((unsigned long long)(w[1] >> 16) << 32) | c_k7.st[1][p];
+		key = k1 < k0 ? k1 : k0;
+	}
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
+	for (int o = 16; o > 0; o >>= 1) {
 		const unsigned long long ok = __shfl_xor(key, o);
 		key = ok < key ? ok : key;
 	}
 	const uint32_t end_state = (uint32_t)key & 63u;
 	// words hold 2 * ae - sum K (+ bias)
-	const uint32_t min_ae = (uint32_t)(((int)(uint32_t)(key >> 32) - (int)kBias + ksum) >> 1);
+	const int32_t min_ae = ((int)(uint32_t)(key >> 32) - (int)kBias + ksum) >> 1;
 
-	// ---- survivor chain (uniform across the wave): four dependent 16-bit reads.
+	// ---- survivor chain (uniform across the half-wave): four dependent 16-bit reads.
 	// u[42..47] are the end state's bits (bit j = u[47 - j]); window m gives u[12m-6 .. 12m+5] LSB first
-	__shared__ uint32_t s_d[3];       // 80 decoded bits, bit k of the frame at word k>>5, bit k&31
+	unsigned long long u;
 	{
 		uint32_t L = s_locof[end_state];
-		const uint32_t h3 = s_win[3][L];
+		const uint32_t h3 = s_win[fr][3][L];
 		L = s_locof[__brev(h3 & 63u) >> 26];
-		const uint32_t h2 = s_win[2][L];
+		const uint32_t h2 = s_win[fr][2][L];
 		L = s_locof[__brev(h2 & 63u) >> 26];
-		const uint32_t h1 = s_win[1][L];
+		const uint32_t h1 = s_win[fr][1][L];
 		L = s_locof[__brev(h1 & 63u) >> 26];
-		const uint32_t h0 = s_win[0][L];
+		const uint32_t h0 = s_win[fr][0][L];
 		// u[0..5] = h0 >> 6, u[6..17] = h1, u[18..29] = h2, u[30..41] = h3, u[42..47] = rev6(end_state)
-		const unsigned long long u = (unsigned long long)((h0 >> 6) & 63u) | ((unsigned long long)(h1 & 0xfffu) << 6) |
-		                             ((unsigned long long)(h2 & 0xfffu) << 18) | ((unsigned long long)(h3 & 0xfffu) << 30) |
-		                             ((unsigned long long)(__brev(end_state) >> 26) << 42);
-		if (lane == 0) {
-			s_d[0] = (uint32_t)u;
-			s_d[1] = (uint32_t)(u >> 32);
-		}
+		u = (unsigned long long)((h0 >> 6) & 63u) | ((unsigned long long)(h1 & 0xfffu) << 6) |
+		    ((unsigned long long)(h2 & 0xfffu) << 18) | ((unsigned long long)(h3 & 0xfffu) << 30) |
+		    ((unsigned long long)(__brev(end_state) >> 26) << 42);
 	}
-	WSYNC();
 
-	// ---- class-2 bits: d[48..79] = c[72..103] < 0 (tch3.c:178-179); pack MSB first (osmo_ubit2pbit)
-	uint32_t bitv = 0;
-	if (lane < 48) {
-		bitv = (s_d[lane >> 5] >> (lane & 31)) & 1u;
+	// ---- class-2 bits: d[48..79] = c[72..103] < 0 (tch3.c:178-179): 32 per frame = one per lane of the half;
+	// pack MSB first (osmo_ubit2pbit)
+	const uint32_t hv = tch3_c(s_e, ciph, fr, m, 72 + p) < 0;
+	const unsigned long long m_all = __ballot(hv != 0);
+	const uint32_t m_hi = (uint32_t)(m_all >> (32 * fr));            // bits 48..79 of this half's frame
+	if (p < 10) {
+		// byte p holds frame bits 8p .. 8p+7, first bit in the MSB: eight bits, reversed
+		const uint32_t raw = p < 6 ? (uint32_t)(u >> (8 * p)) : (m_hi >> (8 * (p - 6)));
+		a.frames[((size_t)g * 2 + fr) * 10 + p] = (uint8_t)(__brev(raw & 0xffu) >> 24);
 	}
-	const unsigned long long m_lo = __ballot(bitv != 0);          // bits 0..47 in lanes 0..47
-	uint32_t hv = 0;
-	if (lane < 32)
-		hv = tch3_c(s_e, ciph, fr, m, 72 + lane) < 0;
-	const unsigned long long m_hi = __ballot(hv != 0);            // bits 48..79 in lanes 0..31
-	if (lane < 10) {
-		// byte `lane` holds frame bits 8*lane .. 8*lane+7, first bit in the MSB: eight ballot bits, reversed
-		const uint32_t raw = lane < 6 ? (uint32_t)(m_lo >> (8 * lane)) : (uint32_t)(m_hi >> (8 * (lane - 6)));
-		a.frames[((size_t)g * 2 + fr) * 10 + lane] = (uint8_t)(__brev(raw & 0xffu) >> 24);
-	}
-	if (lane == 0 && a.conv)
-		a.conv[(size_t)g * 2 + fr] = (int32_t)min_ae;
+	if (p == 0 && a.conv)
+		a.conv[(size_t)g * 2 + fr] = min_ae;
 }
 
 // ---------------------------------------------------------------------------
@@ -610,7 +645,7 @@ hipError_t launch_tch3(const Tch3Args &a, hipStream_t st)
 {
 	if (a.n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_tch3, dim3(2 * a.n), dim3(64), 0, st, a);
+	hipLaunchKernelGGL(k_tch3, dim3(a.n), dim3(64), 0, st, a);
 	return hipGetLastError();
 }
 
