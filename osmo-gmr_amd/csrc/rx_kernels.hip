@@ -1500,10 +1500,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 
 	// =========================== rows: peak + early/late timing ===========================
 	// osmo_cxvec_peak_energy_find(corr, 3, PEAK_EARLY_LATE, &peak), pi4cxpsk.c:240
-	const float *cr = L.corr + row * cw;
-	const int win = w_r < 3 ? w_r : 3;
+	// LAT: the one burst is row 0's; the other rows work on ITS correlation (speculative bisection below)
+	const float *cr = L.corr + (LAT ? 0 : row) * cw;
+	const int w_p = LAT ? __builtin_amdgcn_readlane(w_r, 0) : w_r;
+	const int tl_p = LAT ? c_types[__builtin_amdgcn_readlane(type_r, 0)].sync_tl[0] : bt_r.sync_tl[0];
+	const int win = w_p < 3 ? w_p : 3;
 	unsigned long long key = 0;
-	for (int m = col; m + win <= w_r; m += 16) {
+	for (int m = col; m + win <= w_p; m += 16) {
 		float e = 0.f;
 		for (int k = 0; k < win; k++) {
 			const float c = cr[m + k];
@@ -1517,7 +1520,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	key = row_max_u64<4>(key);
 	key = row_max_u64<8>(key);
 	int mi = (int)(~(uint32_t)key);
-	if (mi < 0 || mi + win > w_r)
+	if (mi < 0 || mi + win > w_p)
 		mi = 0;
 	int p = mi;
 	{
@@ -1538,7 +1541,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
 		int b = ib - 10, e = ib + 11;
 		if (b < 0) b = 0;
-		if (e >= w_r) e = w_r - 1;
+		if (e >= w_p) e = w_p - 1;
 		float acc = 0.f;
 #pragma unroll
 		for (int t = 0; t < 3; t++) {
@@ -1560,22 +1563,64 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	};
 	float early = (float)p - 1.0f, incr = 0.5f;
 	bool active = true;
+	float toa_r, pk;
+	if constexpr (LAT) {
+		// Two levels of the bisection per evaluation: row 0 evaluates the current point, rows 1 / 2 the points
+		// the search moves to if the early / the late side wins -- the same instructions on the same
+		// operands as the level-by-level walk, so the same decisions.
+		auto decide = [](float se, float sl) { const float ee = se * se, le = sl * sl; return ee > le ? -1 : (ee < le ? 1 : 0); };
 #pragma unroll 1
-	for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
-		float se, sl;
-		interp2(early, se, sl);
-		const float ee = se * se, le = sl * sl;
-		if (active) {
-			if (ee > le) early -= incr;
-			else if (ee < le) early += incr;
-			else active = false;
+		for (int it = 0; it < 8; it += 2) {       // levels it, it + 1
+			const float pos = row == 1 ? early - incr : (row == 2 ? early + incr : early);
+			float se, sl;
+			interp2(pos, se, sl);
+			const int dec = decide(se, sl);
+			const int d0 = __builtin_amdgcn_readlane(dec, 0), d1 = __builtin_amdgcn_readlane(dec, 16),
+			          d2 = __builtin_amdgcn_readlane(dec, 32);
+			if (active) {
+				if (d0 == 0) {
+					active = false;
+				} else {
+					early = d0 < 0 ? early - incr : early + incr;
+					const int dn = d0 < 0 ? d1 : d2;
+					const float half = incr * 0.5f;
+					if (dn == 0)
+						active = false;
+					else
+						early = dn < 0 ? early - half : early + half;
+				}
+			}
+			incr *= 0.25f;
 		}
-		incr *= 0.5f;
+		// level 8 on row 0; rows 1 / 2 / 3 already evaluate the peak at the three places it can end
+		{
+			const float pos = row == 0 ? early : (row == 1 ? early - incr : (row == 2 ? early + incr : early)) + 1.0f;
+			float se, sl;
+			interp2(pos, se, sl);
+			const int d0 = active ? __builtin_amdgcn_readlane(decide(se, sl), 0) : 0;
+			const float p1 = lane_val(se, 16), p2 = lane_val(se, 32), p3 = lane_val(se, 48);
+			early = d0 < 0 ? early - incr : (d0 > 0 ? early + incr : early);
+			pk = d0 < 0 ? p1 : (d0 > 0 ? p2 : p3);
+			toa_r = early + 1.0f;
+		}
+	} else {
+#pragma unroll 1
+		for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
+			float se, sl;
+			interp2(early, se, sl);
+			const float ee = se * se, le = sl * sl;
+			if (active) {
+				if (ee > le) early -= incr;
+				else if (ee < le) early += incr;
+				else active = false;
+			}
+			incr *= 0.5f;
+		}
+		toa_r = early + 1.0f;
+		float dummy;
+		interp2(toa_r, pk, dummy);
 	}
-	const float toa_r = early + 1.0f;
-	float pk, dummy;
-	interp2(toa_r, pk, dummy);
-	pk = pk * __builtin_amdgcn_rcpf((float)bt_r.sync_tl[0]);
+	pk = pk * __builtin_amdgcn_rcpf((float)tl_p);
 	const bool found_r = (pk * pk) > 0.0f;            // p_pwr starts at 0: needs strictly more
 	if (a.dbg_stop == 3) return;
 	const int d_r = (int)roundf(toa_r);
