@@ -469,11 +469,11 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 	return 0;
 }
 
-// process_bcch of n_chains chains in one launch (k_rx_loop): d_state / d_log / d_nrounds are device memory
-int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopState *d_state,
-                     unsigned char *d_log_out, int max_rounds, int32_t *d_nrounds)
+// process_bcch of n_chains chains in one launch (k_rx_loop); every pointer in `la` is device memory
+int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la)
 {
-	if (n_chains < 0 || !iq || !d_state || !d_log_out || !d_nrounds || max_rounds < 1)
+	if (n_chains < 0 || !iq || !la.state || !la.rec || !la.n_rounds || !la.n_rec || !la.n_frames || la.max_rounds < 1 ||
+	    la.rec_stride < 1 || (la.rec_frame && !la.rec_minen) || (la.flog && la.flog_stride < 1))
 		return fail(-EINVAL, "rx_loop: bad arguments");
 	DevState *s;
 	int r = dev_state(&s);
@@ -481,8 +481,6 @@ int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq,
 	RxArgs a;
 	r = rx_base_args(sps, iq, &a);
 	if (r) return r;
-	RxLoopArgs la;
-	la.state = d_state; la.log_out = d_log_out; la.max_rounds = max_rounds; la.n_rounds = d_nrounds;
 	HIP_TRY(launch_rx_loop(a, la, n_chains, stream));
 	return 0;
 }

@@ -46,10 +46,8 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           float *toa, float *freq_err, float *energy,
                           int8_t *ebits, float *ssyms, int32_t *rv);
 
-// process_bcch of n_chains chains in one launch (capi.cpp / k_rx_loop); all pointers but iq are device memory
-// this library allocated (log layout in rx_loop.h)
-int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopState *d_state,
-                     unsigned char *d_log_out, int max_rounds, int32_t *d_nrounds);
+// process_bcch of n_chains chains in one launch (capi.cpp / k_rx_loop); every pointer in `la` is device memory
+int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la);
 
 // gmr1_hip_demod_batch_dev of a built-in burst type, plus burst_energy() of each window (capi.cpp)
 int demod_dev_energy(hipStream_t st, int burst_id, int n, int sps, int in_len, const float *iq,

@@ -24,7 +24,6 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
-#include <thread>
 #include <vector>
 
 #include "../../include/gmr1_hip.h"
@@ -341,9 +340,9 @@ int RxRun::frame_loop()
 {
 	// ---- process_bcch (gmr1_rx.c:852-895) for every chain ------------------------------------------
 	// One launch: k_rx_loop walks each chain through all of its frames on the GPU (rounds of CCCH bursts
-	// up to the next BCCH burst, whose result feeds back before the next round; rx_loop.h) and logs every
-	// burst's result.  The host then replays the same integer logic over the log to produce the records,
-	// the per-frame context the traffic-channel passes need, and the assignment events.
+	// up to the next BCCH burst, whose result feeds back before the next round; rx_loop.h) and writes what
+	// the reference hands to GSMTAP -- the records, in frame order -- plus, when a traffic pass follows, the
+	// per-frame context rx_tch3 sees.  The host only collects them.
 	const int nc = (int)chains.size();
 	if (!nc)
 		return 0;
@@ -351,117 +350,91 @@ int RxRun::frame_loop()
 	const int frame_len = sps * 24 * 39;
 	int max_frames = 0;
 	for (const RxChain &c : chains)
-		max_frames = std::max(max_frames, c.len / frame_len + 1);
+		max_frames = std::max(max_frames, c.len / frame_len + 2);
 	// every round but the last covers at least seven frames (seven CCCH bursts, or fewer and the BCCH burst
 	// that closes its eight-frame cycle); burst_map only refuses windows at the very ends of the capture
 	const int max_rounds = max_frames / 7 + 8;
+	const int rec_stride = max_rounds * kLoopPerRound;
+	const bool want_ctx = tch != nullptr;
 	std::vector<RxLoopState> st0((size_t)nc);
 	for (int ci = 0; ci < nc; ci++) {
 		const RxChain &c = chains[ci];
-		st0[ci] = {c.base, c.len, c.align, c.freq_err, c.fn, c.delay, c.stn, c.done ? 1 : 0};
+		st0[ci] = {c.base, c.len, c.align, c.freq_err, c.fn, c.delay, c.stn, c.done ? 1 : 0, c.bcch_energy,
+		           (uint16_t)(arfcn ? arfcn[c.a] : (uint16_t)c.a), (uint16_t)c.chain};
 	}
-	const size_t out_bytes = (size_t)nc * max_rounds * kLoopOutBytes;
-	const size_t st_bytes = up128((size_t)nc * sizeof(RxLoopState)), nr_bytes = up128((size_t)nc * 4);
+	// one block of device memory and its mirror in pinned host memory:
+	// [records | counters (n_rounds, n_rec, n_frames) | states | frame index + gate level per record | frame log]
+	const size_t rec_bytes = up128((size_t)nc * rec_stride * sizeof(gmr1_hip_rx_record));
+	const size_t cnt_bytes = up128((size_t)nc * 3 * 4);
+	const size_t st_bytes = up128((size_t)nc * sizeof(RxLoopState));
+	const size_t rf_bytes = want_ctx ? up128((size_t)nc * rec_stride * 4) : 0;
+	const size_t fl_bytes = want_ctx ? up128((size_t)nc * max_frames * sizeof(RxLoopFrame)) : 0;
+	const size_t total = rec_bytes + cnt_bytes + st_bytes + 2 * rf_bytes + fl_bytes;
 	DevState *ds;
 	r = dev_state(&ds);
 	if (r) return r;
 	void *ws;
-	r = dev_workspace(ds, out_bytes + st_bytes + nr_bytes + 128, &ws);
+	r = dev_workspace(ds, total + 128, &ws);
 	if (r) return r;
-	unsigned char *d_base = reinterpret_cast<unsigned char *>(((uintptr_t)ws + 127) & ~(uintptr_t)127);
-	unsigned char *d_out = d_base;
-	RxLoopState *d_state = reinterpret_cast<RxLoopState *>(d_out + out_bytes);
-	int32_t *d_nr = reinterpret_cast<int32_t *>(reinterpret_cast<unsigned char *>(d_state) + st_bytes);
-	unsigned char *h_out;
-	r = host_log(out_bytes + nr_bytes, &h_out);
+	unsigned char *d = reinterpret_cast<unsigned char *>(((uintptr_t)ws + 127) & ~(uintptr_t)127);
+	unsigned char *h;
+	r = host_log(total, &h);
 	if (r) return r;
-	int32_t *h_nr = reinterpret_cast<int32_t *>(h_out + out_bytes);
-	HIP_TRY(hipMemcpyAsync(d_state, st0.data(), (size_t)nc * sizeof(RxLoopState), hipMemcpyHostToDevice, st));
-	r = rx_loop_dev_impl(st, nc, sps, iq, d_state, d_out, max_rounds, d_nr);
+	const size_t o_cnt = rec_bytes, o_st = o_cnt + cnt_bytes, o_rf = o_st + st_bytes, o_me = o_rf + rf_bytes,
+	             o_fl = o_me + rf_bytes;
+	RxLoopArgs la;
+	std::memset(&la, 0, sizeof(la));
+	la.state = reinterpret_cast<RxLoopState *>(d + o_st);
+	la.rec = reinterpret_cast<gmr1_hip_rx_record *>(d);
+	la.rec_stride = rec_stride;
+	la.max_rounds = max_rounds;
+	la.n_rounds = reinterpret_cast<int32_t *>(d + o_cnt);
+	la.n_rec = la.n_rounds + nc;
+	la.n_frames = la.n_rec + nc;
+	if (want_ctx) {
+		la.rec_frame = reinterpret_cast<int32_t *>(d + o_rf);
+		la.rec_minen = reinterpret_cast<float *>(d + o_me);
+		la.flog = reinterpret_cast<RxLoopFrame *>(d + o_fl);
+		la.flog_stride = max_frames;
+	}
+	HIP_TRY(hipMemcpyAsync(la.state, st0.data(), (size_t)nc * sizeof(RxLoopState), hipMemcpyHostToDevice, st));
+	r = rx_loop_dev_impl(st, nc, sps, iq, la);
 	if (r) return r;
-	HIP_TRY(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipMemcpyAsync(h_nr, d_nr, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	t_loop_gpu_us = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count() / 1e3;
 
-	// chains are independent: replayed by a few host threads (integer bookkeeping only)
-	auto replay = [&](int ci) -> int {
+	const int32_t *h_nr = reinterpret_cast<const int32_t *>(h + o_cnt), *h_nrec = h_nr + nc, *h_nfr = h_nrec + nc;
+	const RxLoopState *h_st = reinterpret_cast<const RxLoopState *>(h + o_st);
+	for (int ci = 0; ci < nc; ci++) {
 		RxChain &c = chains[ci];
-		RxLoopState s = st0[ci];
-		c.rec.reserve((size_t)h_nr[ci] * (kLoopPerRound - 1));
-		c.rec_frame.reserve((size_t)h_nr[ci] * (kLoopPerRound - 1));
-		const uint16_t an = arfcn ? arfcn[c.a] : (uint16_t)c.a;
-		auto on_frame = [&](const RxLoopState &x) {
-			if (tch)
-				c.log.push_back({x.align, x.freq_err, x.fn});
-		};
-		bool closed = false;
-		for (int round = 0; round <= h_nr[ci] && round < max_rounds; round++) {
-			RxLoopItem items[kLoopPerRound];
-			const int before = (int)c.log.size();
-			const float min_energy = c.bcch_energy / 2.0f;
-			const int n = rx_loop_build_round(s, sps, items, on_frame);
-			if (!n) {
-				closed = true;
-				break;
+		if (h_nr[ci] >= max_rounds || h_nrec[ci] > rec_stride || (want_ctx && h_nfr[ci] > max_frames))
+			return fail(-EIO, "rx loop: chain %d outgrew its buffers (%d rounds, %d records, %d frames)", ci, h_nr[ci],
+			            h_nrec[ci], h_nfr[ci]);
+		const gmr1_hip_rx_record *rp = reinterpret_cast<const gmr1_hip_rx_record *>(h) + (size_t)ci * rec_stride;
+		c.rec.assign(rp, rp + h_nrec[ci]);
+		if (want_ctx) {
+			const int32_t *fp = reinterpret_cast<const int32_t *>(h + o_rf) + (size_t)ci * rec_stride;
+			const float *mp = reinterpret_cast<const float *>(h + o_me) + (size_t)ci * rec_stride;
+			const RxLoopFrame *lp = reinterpret_cast<const RxLoopFrame *>(h + o_fl) + (size_t)ci * max_frames;
+			c.rec_frame.assign(fp, fp + h_nrec[ci]);
+			c.log.resize((size_t)h_nfr[ci]);
+			for (int f = 0; f < h_nfr[ci]; f++)
+				c.log[f] = {lp[f].align, lp[f].freq_err, lp[f].fn};
+			// IMM.ASS on the CCCH starts the TCH3 follow-up in that very frame (gmr1_rx.c:235-246, 836-841)
+			for (int k = 0; k < h_nrec[ci]; k++) {
+				const uint8_t *l2 = rp[k].l2;
+				if (rp[k].type == 2 && l2[1] == 0x06 && l2[2] == 0x3f)
+					c.events.push_back({fp[k], ((l2[8] & 0x03) << 3) | (l2[9] >> 5), (l2[8] & 0xfc) >> 2, mp[k]});
 			}
-			if (round == h_nr[ci])
-				return 1;                     // the device stopped with frames left
-			const unsigned char *ob = h_out + ((size_t)ci * max_rounds + round) * kLoopOutBytes;
-			const int32_t *o_crc = reinterpret_cast<const int32_t *>(ob + kLoopOutCrc);
-			const int32_t *o_conv = reinterpret_cast<const int32_t *>(ob + kLoopOutConv);
-			const int32_t *o_rv = reinterpret_cast<const int32_t *>(ob + kLoopOutRv);
-			const float *o_toa = reinterpret_cast<const float *>(ob + kLoopOutToa);
-			const float *o_fe = reinterpret_cast<const float *>(ob + kLoopOutFe);
-			const float *o_en = reinterpret_cast<const float *>(ob + kLoopOutEnergy);
-			for (int k = 0; k < n; k++) {
-				const RxLoopItem &it = items[k];
-				const uint8_t *l2 = ob + kLoopOutL2 + (size_t)k * 24;
-				// index the burst's frame has / will have in the chain's log
-				const int frame = tch ? before + it.frames_before : 0;
-				if (it.is_bcch) {
-					// rx_bcch, gmr1_rx.c:746-798
-					if (!o_rv[k]) {
-						c.bcch_energy = o_en[k];
-						if (rx_loop_bcch_result(s, sps, o_rv[k], o_crc[k], o_toa[k], o_fe[k], l2, it.e_toa))
-							emit(c, an, 1 /* GSMTAP_GMR1_BCCH */, s.fn, s.stn, l2, o_conv[k], frame);
-					}
-					on_frame(s);                 // rx_tch3 of this frame sees the updated state
-					rx_loop_advance(s, sps);
-				} else {
-					// rx_ccch, gmr1_rx.c:800-850 (energy gate first, :813-816)
-					if (o_en[k] < min_energy)
-						continue;
-					if (!o_rv[k] && !o_crc[k]) {
-						// IMM.ASS starts the TCH3 follow-up in this very frame (gmr1_rx.c:235-246, 836-841)
-						if (tch && l2[1] == 0x06 && l2[2] == 0x3f)
-							c.events.push_back({frame, ((l2[8] & 0x03) << 3) | (l2[9] >> 5), (l2[8] & 0xfc) >> 2, min_energy});
-						emit(c, an, 2 /* GSMTAP_GMR1_CCCH */, it.fn, it.tn, l2, o_conv[k], frame);
-					}
-				}
-			}
+		} else {
+			c.rec_frame.assign((size_t)h_nrec[ci], 0);
 		}
-		if (!closed)
-			return 2;                         // more rounds than the log holds
+		const RxLoopState &s = h_st[ci];
 		c.align = s.align; c.freq_err = s.freq_err; c.fn = s.fn; c.delay = s.delay; c.stn = s.stn;
+		c.bcch_energy = s.bcch_energy;
 		c.done = s.done != 0;
-		return 0;
-	};
-	const int nthr = std::max(1, std::min({nc / 4, 8, (int)std::thread::hardware_concurrency()}));
-	std::vector<int> err((size_t)nc, 0);
-	auto work = [&](int t) {
-		for (int ci = t; ci < nc; ci += nthr)
-			err[ci] = replay(ci);
-	};
-	std::vector<std::thread> pool;
-	for (int t = 1; t < nthr; t++)
-		pool.emplace_back(work, t);
-	work(0);
-	for (std::thread &th : pool)
-		th.join();
-	for (int ci = 0; ci < nc; ci++)
-		if (err[ci])
-			return fail(-EIO, err[ci] == 1 ? "rx loop: chain %d stopped with frames left" : "rx loop: chain %d needs more rounds than the log holds", ci);
+	}
 	return 0;
 }
 
@@ -974,7 +947,7 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	if (csd && (r = run.tch9_pass())) return r;
 	if (timing) {
 		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
-		fprintf(stderr, "rx_run: acquire %.0f us, frame loop %.0f us (launch+copy %.0f, replay %.0f), traffic passes %.0f us\n",
+		fprintf(stderr, "rx_run: acquire %.0f us, frame loop %.0f us (launch+copy %.0f, collect %.0f), traffic passes %.0f us\n",
 		        us(t0, t1), us(t1, t2), run.t_loop_gpu_us, us(t1, t2) - run.t_loop_gpu_us, us(t2, now()));
 	}
 	const std::vector<RxChain> &chains = run.chains;

@@ -66,12 +66,16 @@ struct RxArgs {
 };
 
 // the receive loop of all chains in one launch (k_rx_loop, rx_kernels.hip); `a` carries what every burst
-// shares (iq, sps, window lengths, staging size), the per-burst arrays are set by the loop itself
+// shares (iq, sps, window lengths, staging size), the per-burst arrays are the loop's own (LDS)
 struct RxLoopArgs {
-	const RxLoopState *state;  // n_chains starting states
-	unsigned char *log_out;    // n_chains x max_rounds x kLoopOutBytes, 128-byte aligned
+	RxLoopState *state;            // n_chains: starting states in, final states out
+	gmr1_hip_rx_record *rec;       // n_chains x rec_stride records, frame order per chain
+	int32_t *rec_frame;            // optional, parallel to rec: index of the record's frame in the chain's frame log
+	float *rec_minen;              // optional, parallel to rec: the CCCH energy gate level of the record's round
+	RxLoopFrame *flog;             // optional, n_chains x flog_stride: (align, freq_err, fn) of every frame
+	int rec_stride, flog_stride;
 	int max_rounds;
-	int32_t *n_rounds;         // n_chains: rounds each chain took
+	int32_t *n_rounds, *n_rec, *n_frames;   // n_chains each
 };
 
 struct DetectArgs {

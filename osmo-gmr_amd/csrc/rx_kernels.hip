@@ -1358,7 +1358,7 @@ struct RxIo {
 // LAT: the caller cares about the latency of ONE burst (the receive loop), not about throughput
 template <int NPL, int SPS, bool LAT = false>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
-                                         unsigned char *__restrict__ lds_raw, int lane, uint32_t *fb = nullptr)
+                                         unsigned char *__restrict__ lds_raw, int lane)
 {
 	const int row = lane >> 4, col = lane & 15;
 	const int sps = SPS ? SPS : a.sps;
@@ -1741,11 +1741,6 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		if (io.sync_id) io.sync_id[g_row] = found_r ? 0 : -1;
 		if (io.toa) io.toa[g_row] = found_r ? toa_r : 0.f;
 		if (io.freq_err) io.freq_err[g_row] = found_r ? ffe_r : 0.f;
-		if (fb && row == 0) {                  // the receive loop's feedback path (k_rx_loop): burst g0 only
-			fb[6] = (uint32_t)rv;
-			fb[8] = __float_as_uint(found_r ? toa_r : 0.f);
-			fb[9] = __float_as_uint(found_r ? ffe_r : 0.f);
-		}
 	}
 
 	// =========================== pass 2: soft symbols / soft bits ===========================
@@ -1859,15 +1854,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			store_l2(io.l2 + (size_t)g_row * 24, L.ubits + row * 8);
 			io.crc[g_row] = syn ? 1 : 0;
 			io.conv[g_row] = (int32_t)fae;
-			if (fb && row == 0) {
-#pragma unroll
-				for (int i = 0; i < 6; i++)
-					fb[i] = L.ubits[i];
-				fb[7] = syn ? 1u : 0u;
-			}
 		} else {
-			if (fb && row == 0)
-				fb[7] = 0xffffffffu;
+
 			uint32_t *l2w = reinterpret_cast<uint32_t *>(io.l2 + (size_t)g_row * 24);
 #pragma unroll
 			for (int i = 0; i < 6; i++)
@@ -1895,42 +1883,95 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 // frame to the end of the capture, without leaving the GPU.  The feedback of the loop only crosses a BCCH
 // frame, so it runs in rounds: wave 0 lists the chain's CCCH bursts up to and including its next BCCH burst
 // (rx_loop_build_round, rx_loop.h), up to eight wavefronts demodulate and decode one burst each (rx4_body,
-// the burst kernel itself), wave 0 applies the BCCH result (time, frequency, SI1 TDMA position) and lists
-// the next round.  Operands and feedback travel through LDS; every burst's result also goes to a log in HBM
-// that only the host reads, after the kernel, to replay the loop into records.  A round is about one wave's
-// latency instead of launch + kernel + synchronise + host (~59 us).
+// the burst kernel itself), wave 0 turns the results into records exactly as rx_bcch / rx_ccch do (energy
+// gate, CRC, BCCH feedback: time, frequency, SI1 TDMA position) and lists the next round.  A round's operands
+// and results never leave LDS; what goes to HBM is what the reference hands to GSMTAP: the 40-byte records, in
+// frame order, plus -- when a traffic pass follows -- the per-frame context rx_tch3 sees.  A round is about
+// one wave's latency instead of launch + kernel + synchronise + host (~59 us).
 // ---------------------------------------------------------------------------
 template <int NPL, int SPS>
 __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoopArgs la, int stage_samples, int cw,
                                                                 int lds_per_wave)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
-	// a round's operands and the feedback of its BCCH burst never leave the CU
+	// operands and results of the round's bursts
 	__shared__ uint64_t s_off[kLoopPerRound];
 	__shared__ float s_fs[kLoopPerRound];
 	__shared__ uint8_t s_kind[kLoopPerRound];
 	__shared__ RxLoopItem s_items[kLoopPerRound];
-	__shared__ uint32_t s_fb[kLoopPerRound][12];   // l2 words 0-5, rv, crc, toa, freq_err of each wave's burst
+	__shared__ __align__(8) uint8_t s_l2[kLoopPerRound][24];
+	__shared__ int32_t s_crc[kLoopPerRound], s_conv[kLoopPerRound], s_rv[kLoopPerRound];
+	__shared__ float s_toa[kLoopPerRound], s_fe[kLoopPerRound], s_en[kLoopPerRound];
 	__shared__ int s_n;
 	const int chain = blockIdx.x;
 	const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
 	const int sps = a.sps;
-	unsigned char *log_out = la.log_out + (size_t)chain * la.max_rounds * kLoopOutBytes;
 	RxLoopState st = la.state[chain];          // wave 0 keeps the live copy (all its lanes compute the same)
 	const uint64_t lim = st.base + (uint64_t)st.len;
-	int round = 0, prev_bcch = 0, prev_etoa = 0;
+	gmr1_hip_rx_record *rec = la.rec + (size_t)chain * la.rec_stride;
+	int32_t *rec_frame = la.rec_frame ? la.rec_frame + (size_t)chain * la.rec_stride : nullptr;
+	float *rec_minen = la.rec_minen ? la.rec_minen + (size_t)chain * la.rec_stride : nullptr;
+	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
+	int n_rec = 0, n_frames = 0;               // records emitted / frames completed so far
+	int prev_n = 0, frames_at_round = 0;
+	auto on_frame = [&](const RxLoopState &x) {
+		if (flog && lane == 0 && n_frames < la.flog_stride)
+			flog[n_frames] = {x.align, x.freq_err, x.fn};
+		n_frames++;
+	};
+	int round = 0;
 	for (; round < la.max_rounds; round++) {
-		unsigned char *out = log_out + (size_t)round * kLoopOutBytes;
 		if (wave == 0) {
-			if (prev_bcch) {
-				// the BCCH burst that ended the previous round
-				const uint32_t *f = s_fb[prev_bcch - 1];
-				uint32_t w[4] = {f[0], f[1], f[2], f[3]};          // SI1 needs bytes 0..13
-				rx_loop_bcch_result(st, sps, (int)f[6], (int)f[7], __uint_as_float(f[8]), __uint_as_float(f[9]),
-				                    reinterpret_cast<const uint8_t *>(w), prev_etoa);
-				rx_loop_advance(st, sps);
+			if (prev_n) {
+				// ---- the previous round's results -> records (rx_ccch gmr1_rx.c:800-850, rx_bcch :746-798)
+				const float min_energy = st.bcch_energy / 2.0f;     // the level the round started with
+				const int k = lane < prev_n ? lane : 0;
+				const RxLoopItem it = s_items[k];
+				const bool is_b = it.is_bcch != 0;
+				const int rv = s_rv[k], crc = s_crc[k];
+				bool emit = false;
+				int fn = it.fn, tn = it.tn;
+				if (lane < prev_n && !is_b)
+					emit = !(s_en[k] < min_energy) && !rv && !crc;         // energy gate first (:813-816)
+				const int kb = prev_n - 1;                              // a BCCH burst is the round's last
+				if (s_items[kb].is_bcch) {
+					bool moved = false;
+					if (!s_rv[kb]) {
+						st.bcch_energy = s_en[kb];
+						moved = rx_loop_bcch_result(st, sps, s_rv[kb], s_crc[kb], s_toa[kb], s_fe[kb], s_l2[kb],
+						                            s_items[kb].e_toa) != 0;
+					}
+					if (lane == kb) {
+						emit = moved;
+						fn = st.fn;                                      // after the SI1 alignment (:789-795)
+						tn = st.stn;
+					}
+					on_frame(st);                                        // rx_tch3 of this frame sees the updated state
+					rx_loop_advance(st, sps);
+				}
+				const unsigned long long mask = __ballot(emit);
+				if (emit) {
+					const int slot = n_rec + __popcll(mask & ((1ull << lane) - 1ull));
+					if (slot < la.rec_stride) {
+						uint32_t *d = reinterpret_cast<uint32_t *>(rec + slot);
+						const uint32_t *l2w = reinterpret_cast<const uint32_t *>(s_l2[k]);
+						d[0] = (uint32_t)st.arfcn | ((uint32_t)st.chain << 16) | ((is_b ? 1u : 2u) << 24);
+						d[1] = (uint32_t)fn;
+						d[2] = ((uint32_t)tn & 0xffu) | (24u << 16);         // crc = 0, len = 24
+						d[3] = (uint32_t)s_conv[k];
+#pragma unroll
+						for (int i = 0; i < 6; i++)
+							d[4 + i] = l2w[i];
+						if (rec_frame) {
+							rec_frame[slot] = frames_at_round + it.frames_before;
+							rec_minen[slot] = min_energy;
+						}
+					}
+				}
+				n_rec += __popcll(mask);
 			}
-			const int n = rx_loop_build_round(st, sps, s_items, [](const RxLoopState &) {});
+			frames_at_round = n_frames;
+			const int n = rx_loop_build_round(st, sps, s_items, on_frame);
 			if (lane < n) {
 				s_off[lane] = st.base + (uint64_t)s_items[lane].begin;
 				s_fs[lane] = -st.freq_err;
@@ -1938,8 +1979,7 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 			}
 			if (lane == 0)
 				s_n = n;
-			prev_bcch = (n && s_items[n - 1].is_bcch) ? n : 0;
-			prev_etoa = n ? s_items[n - 1].e_toa : 0;
+			prev_n = n;
 		}
 		__syncthreads();
 		const int n = s_n;
@@ -1954,19 +1994,19 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 				if (nxt >= 64 && nxt + 1100 < lim)
 					sink = reinterpret_cast<const float *>(a.iq + nxt - 64)[lane * 32];
 			}
-			const RxIo io = {s_off, s_kind, s_fs, out + kLoopOutL2,
-			                 reinterpret_cast<int32_t *>(out + kLoopOutCrc), reinterpret_cast<int32_t *>(out + kLoopOutConv),
-			                 reinterpret_cast<int32_t *>(out + kLoopOutRv), nullptr,
-			                 reinterpret_cast<float *>(out + kLoopOutToa), reinterpret_cast<float *>(out + kLoopOutFe),
-			                 reinterpret_cast<float *>(out + kLoopOutEnergy), nullptr, nullptr};
-			rx4_body<NPL, SPS, true>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane, s_fb[wave]);
+			const RxIo io = {s_off, s_kind, s_fs, &s_l2[0][0], s_crc, s_conv, s_rv, nullptr, s_toa, s_fe, s_en, nullptr, nullptr};
+			rx4_body<NPL, SPS, true>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane);
 			if (sink == 1.2345678e-30f)
-				s_fb[wave][11] = 1;              // keeps the touch alive
+				s_en[wave] = 0.f;                  // keeps the touch alive
 		}
 		__syncthreads();
 	}
-	if (threadIdx.x == 0)
+	if (threadIdx.x == 0) {
 		la.n_rounds[chain] = round;
+		la.n_rec[chain] = n_rec;
+		la.n_frames[chain] = n_frames;
+		la.state[chain] = st;
+	}
 }
 
 // ---------------------------------------------------------------------------

@@ -1,8 +1,7 @@
 // rx_loop.h -- the integer control logic of process_bcch (reference src/gmr1_rx.c:852-895) with its helpers
-// burst_map (:149-170) and bcch_tdma_align (:194-233), written once for both sides of the receive loop:
-// the device runs it inside k_rx_loop (one work-group walks one chain through ALL of its frames, no host
-// round trip between them), the host replays it afterwards over the logged burst results to produce records,
-// per-frame context for the traffic-channel passes and the assignment events.  No signal arithmetic here.
+// burst_map (:149-170) and bcch_tdma_align (:194-233).  The device runs it inside k_rx_loop (one work-group
+// walks one chain through ALL of its frames, no host round trip between them); it is host-callable too
+// (tests, sizing).  No signal arithmetic here.
 #pragma once
 
 #include <math.h>
@@ -17,16 +16,6 @@
 namespace gmr1 {
 
 constexpr int kLoopPerRound = 8;           // bursts one chain contributes to a round: <= 7 CCCH, then its BCCH
-// One round's block in the device log the host replays: the results of its (up to eight) bursts
-constexpr int kLoopOutL2 = 0;              // uint8 l2[8][24]
-constexpr int kLoopOutCrc = 192;           // int32 crc[8], conv[8], rv[8] ; float toa[8], freq_err[8], energy[8]
-constexpr int kLoopOutConv = 224;
-constexpr int kLoopOutRv = 256;
-constexpr int kLoopOutToa = 288;
-constexpr int kLoopOutFe = 320;
-constexpr int kLoopOutEnergy = 352;
-constexpr int kLoopOutBytes = 384;
-
 struct RxLoopState {                       // the part of struct chan_desc the frame loop reads and writes
 	uint64_t base;                         // first sample of the carrier in iq
 	int len;                               // samples of the carrier
@@ -34,7 +23,12 @@ struct RxLoopState {                       // the part of struct chan_desc the f
 	float freq_err;
 	int fn, delay, stn;
 	int done;
+	float bcch_energy;                     // burst_energy() of the last BCCH burst found (NaN: none yet)
+	uint16_t arfcn;                        // what the chain's records carry
+	uint16_t chain;
 };
+
+struct RxLoopFrame { int align; float freq_err; int fn; };     // what rx_tch3 sees in a frame
 
 struct RxLoopItem {                        // one burst of a round
 	int begin;                             // window start, samples from the carrier's first
