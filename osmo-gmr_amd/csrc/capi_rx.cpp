@@ -9,8 +9,8 @@
 // loop therefore runs in ROUNDS -- a chain's CCCH bursts up to and including its next BCCH burst,
 // one wavefront each, then the BCCH feedback -- and it runs them ON THE GPU: one launch of
 // k_rx_loop (rx_kernels.hip), one work-group per chain, from the first frame to the end of the
-// capture; the integer control logic is shared source (rx_loop.h).  The host replays that logic
-// over the logged burst results to emit records.  FCCH acquisition is three batched sweeps
+// capture; it writes the records itself (the integer control logic is in rx_loop.h) and the host
+// only collects them.  FCCH acquisition is three batched sweeps
 // (rough / rough_multi / fine + snr) over all carriers.  The arithmetic of every step runs on the
 // GPU; the host keeps only the per-chain integers the reference keeps in struct chan_desc.
 // There is no CPU fallback.
