@@ -168,7 +168,7 @@ def run_rx_workload(args):
         mine = rec[rec["arfcn"] == 0]
         key = lambda r: [(int(x["chain"]), int(x["type"]), int(x["fn"]), int(x["tn"]), bytes(x["l2"])) for x in r]
         out["cpu_baseline"] = {"value": ns / tc / 1e6, "unit": "Msamp/s", "cores": 1, "kind": "port",
-                               "sample": f"carrier 0 ({args.seconds:g} s), gcc -O2 oracle, 1 thread, {tc:.1f} s"}
+                               "sample": f"carrier 0 ({args.seconds:g} s), gcc -O2 oracle, 1 thread, {tc * 1e3:.0f} ms"}
         out["checks"] = {"frames_identical_to_oracle": bool(key(mine) == key(orec)), "oracle_frames": int(len(orec))}
     print(json.dumps(out))
 
