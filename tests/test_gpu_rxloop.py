@@ -95,6 +95,29 @@ def test_rx_loop_device_resident_and_record_limit(gpu_api, orc, pkg):
     assert found2 == found and len(rec2) == 5 and _key(rec2) == _key(rec[:5])
 
 
+def test_rx_loop_more_chains_than_compute_units(gpu_api, orc, pkg):
+    """300 carriers = more work-groups than the 256 CUs hold at once (each walks its whole capture): late
+    work-groups start when early ones finish; every carrier must still yield exactly its own frames."""
+    import torch
+    distinct = [workloads.bcch_carrier(pkg, 90 + a, seconds=1.6, sps=SPS, stn=(7 * a) % 24, delay=a + 1, cfo_hz=25.0 * a)[0]
+                for a in range(3)]
+    n = distinct[0].size
+    A = 300
+    t = torch.from_numpy(np.concatenate(distinct).view(np.float32)).cuda()
+    big = torch.cat([t] * (A // 3)).contiguous()
+    offset = np.arange(A, dtype=np.uint64) * np.uint64(n)
+    length = np.full(A, n, np.uint64)
+    rec, status, chains, found = gpu_api.rx_run_dev(None, big.data_ptr(), offset, length, sps=SPS, max_records=1 << 17)
+    assert not status.any() and found == len(rec)
+    refs = [_key(orc.rx_run(distinct[a], sps=SPS, arfcn=0)[1]) for a in range(3)]
+    assert all(len(r) > 20 for r in refs)
+    # records come back carrier by carrier
+    bounds = np.searchsorted(rec["arfcn"], np.arange(A + 1))
+    for a in range(A):
+        got = [k[1:] for k in _key(rec[bounds[a]:bounds[a + 1]])]
+        assert got == [k[1:] for k in refs[a % 3]], a
+
+
 def test_rx_loop_rejects_bad_arguments(gpu_api):
     x = np.zeros(1000, np.complex64)
     with pytest.raises(Exception):
