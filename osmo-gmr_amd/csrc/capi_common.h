@@ -49,6 +49,10 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 // process_bcch of n_chains chains in one launch (capi.cpp / k_rx_loop); every pointer in `la` is device memory
 int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la);
 
+// TCH9 bursts of several interleaver runs of unequal length in one launch (capi_nt9.cpp)
+int tch9_runs_dev_impl(hipStream_t st, int mode, int n, const int32_t *seq_pos, const int8_t *ebits, const uint8_t *ciph,
+                       uint8_t *l2, int32_t *conv);
+
 // gmr1_hip_demod_batch_dev of a built-in burst type, plus burst_energy() of each window (capi.cpp)
 int demod_dev_energy(hipStream_t st, int burst_id, int n, int sps, int in_len, const float *iq,
                      const uint64_t *offset, const float *freq_shift, int8_t *ebits, int ebits_stride,

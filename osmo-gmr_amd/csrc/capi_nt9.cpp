@@ -141,6 +141,33 @@ int nt9_dev(hipStream_t st, int kind, int n, int seq_len, const int8_t *ebits, c
 	return 0;
 }
 
+}  // namespace
+
+namespace gmr1 {
+// TCH9 bursts of several interleaver runs of unequal length, run after run, in one launch: seq_pos[i] (device)
+// = position of burst i in its run (the receive loop's TCH9 follow-up, capi_rx.cpp)
+int tch9_runs_dev_impl(hipStream_t st, int mode, int n, const int32_t *seq_pos, const int8_t *ebits, const uint8_t *ciph,
+                       uint8_t *l2, int32_t *conv)
+{
+	if (n < 0 || mode < 0 || mode > 2 || !seq_pos || !ebits || !l2)
+		return fail(-EINVAL, "tch9 runs: bad arguments");
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	const uint32_t *map;
+	r = get_map(mode, &map);
+	if (r) return r;
+	Nt9Args a;
+	std::memset(&a, 0, sizeof(a));
+	a.n = n; a.seq_len = 1; a.seq_pos = seq_pos; a.kind = mode; a.N = kKinds[mode].N; a.len = kKinds[mode].len;
+	a.map = map; a.ebits = ebits; a.ciph = ciph; a.l2 = l2; a.l2_bytes = kKinds[mode].l2_bytes; a.conv = conv;
+	HIP_TRY(launch_nt9(a, st));
+	return 0;
+}
+}  // namespace gmr1
+
+namespace {
+
 int nt9_host(int kind, int n, int seq_len, const int8_t *ebits, const uint8_t *ciph,
              uint8_t *l2, int8_t *sacch, int8_t *status, int32_t *crc, int32_t *conv)
 {

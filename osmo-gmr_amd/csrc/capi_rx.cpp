@@ -127,6 +127,45 @@ int host_log(size_t bytes, unsigned char **out)
 }
 
 
+// Device scratch of a traffic pass: one carve-up of the grow-only device workspace (none of the kernels the
+// passes launch uses it) instead of dozens of hipMalloc / hipFree pairs per call.
+struct Arena {
+	unsigned char *base = nullptr;
+	size_t cap = 0, off = 0;
+	int init(size_t bytes)
+	{
+		DevState *ds;
+		int r = dev_state(&ds);
+		if (r) return r;
+		void *ws;
+		r = dev_workspace(ds, bytes + 256, &ws);
+		if (r) return r;
+		base = reinterpret_cast<unsigned char *>(((uintptr_t)ws + 127) & ~(uintptr_t)127);
+		cap = bytes;
+		off = 0;
+		return 0;
+	}
+	void *take(size_t n)
+	{
+		n = up128(n ? n : 1);
+		if (off + n > cap)
+			return nullptr;
+		void *p = base + off;
+		off += n;
+		return p;
+	}
+};
+thread_local Arena *g_arena = nullptr;
+struct ABuf {                      // DBuf's interface on the current arena
+	void *p = nullptr;
+	hipError_t alloc(size_t n)
+	{
+		p = g_arena ? g_arena->take(n) : nullptr;
+		return p ? hipSuccess : hipErrorOutOfMemory;
+	}
+	template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
 // One call of gmr1_hip_rx_run*: what the phases share.  The phases run in the order the reference's main()
 // runs them (gmr1_rx.c:897-975); each is one member function below.
 struct RxRun {
@@ -472,6 +511,11 @@ int RxRun::tch3_pass()
 		}
 		const int nt = (int)titems.size();
 		if (nt) {
+			// step A needs 376 B per frame, the decodes of step C at most 866 B per frame
+			Arena arena;
+			if ((r = arena.init((size_t)nt * 1300 + 64 * 1024))) return r;
+			g_arena = &arena;
+			struct Reset { ~Reset() { g_arena = nullptr; } } reset;
 			std::vector<uint64_t> t_off(nt);
 			std::vector<float> t_fs(nt), t_et(nt);
 			std::vector<int32_t> t_p(nt);
@@ -483,7 +527,7 @@ int RxRun::tch3_pass()
 				t_et[k] = (float)t_etoa;
 				t_p[k] = titems[k].p;
 			}
-			DBuf d_off2, d_fs2, d_et, d_pp, d_feb, d_fsid, d_frv, d_en, d_seb, d_srv, d_bt, d_dsid, d_dtoa, d_drv, d_krv, d_ftoa;
+			ABuf d_off2, d_fs2, d_et, d_pp, d_feb, d_fsid, d_frv, d_en, d_seb, d_srv, d_bt, d_dsid, d_dtoa, d_drv, d_krv, d_ftoa;
 			HIP_TRY(d_off2.alloc((size_t)nt * 8)); HIP_TRY(d_fs2.alloc((size_t)nt * 4)); HIP_TRY(d_et.alloc((size_t)nt * 4));
 			HIP_TRY(d_pp.alloc((size_t)nt * 4)); HIP_TRY(d_feb.alloc((size_t)nt * 104)); HIP_TRY(d_fsid.alloc((size_t)nt * 4));
 			HIP_TRY(d_frv.alloc((size_t)nt * 4)); HIP_TRY(d_en.alloc((size_t)nt * 4)); HIP_TRY(d_seb.alloc((size_t)nt * 212));
@@ -494,6 +538,7 @@ int RxRun::tch3_pass()
 			HIP_TRY(hipMemcpyAsync(d_fs2.p, t_fs.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
 			HIP_TRY(hipMemcpyAsync(d_et.p, t_et.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
 			HIP_TRY(hipMemcpyAsync(d_pp.p, t_p.data(), (size_t)nt * 4, hipMemcpyHostToDevice, st));
+
 			// A. speculative per-frame work
 			r = demod_dev_energy(st, GMR1_HIP_NT3_FACCH, nt, sps, t_in_len, tch, d_off2.as<uint64_t>(), d_fs2.as<float>(),
 			                     d_feb.as<int8_t>(), 104, d_fsid.as<int32_t>(), d_ftoa.as<float>(), d_en.as<float>(),
@@ -525,6 +570,7 @@ int RxRun::tch3_pass()
 			HIP_TRY(hipMemcpyAsync(h_krv.data(), d_krv.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipMemcpyAsync(h_en.data(), d_en.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
 			HIP_TRY(hipStreamSynchronize(st));
+
 
 			// B. the state machine of rx_tch3 (gmr1_rx.c:531-600) and its helpers, chain by chain
 			std::vector<TchJob> jobs;
@@ -621,7 +667,7 @@ int RxRun::tch3_pass()
 					if (kc) std::memcpy(&keys[(size_t)i * 8], kc + (size_t)chains[j.chain_idx].a * 8, 8);
 					fns[i] = (uint32_t)j.fn;
 				}
-				DBuf d_eb, d_k, d_fn, d_ks, d_fr, d_cv;
+				ABuf d_eb, d_k, d_fn, d_ks, d_fr, d_cv;
 				HIP_TRY(d_eb.alloc(eb.size())); HIP_TRY(d_k.alloc(keys.size())); HIP_TRY(d_fn.alloc((size_t)ns * 4));
 				HIP_TRY(d_ks.alloc((size_t)ns * 208)); HIP_TRY(d_fr.alloc((size_t)ns * 20)); HIP_TRY(d_cv.alloc((size_t)ns * 8));
 				HIP_TRY(hipMemcpyAsync(d_eb.p, eb.data(), eb.size(), hipMemcpyHostToDevice, st));
@@ -652,7 +698,7 @@ int RxRun::tch3_pass()
 						fns[(size_t)i * 4 + b] = j.bi_fn[b];
 					}
 				}
-				DBuf d_eb, d_k, d_fn, d_ks, d_l2, d_crc, d_cv;
+				ABuf d_eb, d_k, d_fn, d_ks, d_l2, d_crc, d_cv;
 				HIP_TRY(d_eb.alloc(eb.size())); HIP_TRY(d_k.alloc(keys.size())); HIP_TRY(d_fn.alloc((size_t)nf * 16));
 				HIP_TRY(d_ks.alloc((size_t)nf * 384)); HIP_TRY(d_l2.alloc((size_t)nf * 10)); HIP_TRY(d_crc.alloc((size_t)nf * 4));
 				HIP_TRY(d_cv.alloc((size_t)nf * 4));
@@ -675,6 +721,7 @@ int RxRun::tch3_pass()
 					HIP_TRY(hipStreamSynchronize(st));
 				}
 			}
+
 
 			// D. ciphering state and records, in the order things happened
 			{
@@ -712,6 +759,7 @@ int RxRun::tch3_pass()
 					}
 				}
 			}
+
 			// frame order within each chain: BCCH / CCCH of a frame come before its TCH records
 			for (RxChain &c : chains) {
 				if (c.events.empty())
@@ -759,6 +807,11 @@ int RxRun::tch9_pass()
 		}
 		const int n9 = (int)items9.size();
 		if (n9) {
+			// demodulation 682 B per frame, keystreams and decodes at most 662 + 8 + 4 + 658 + 64 B per frame
+			Arena arena;
+			if ((r = arena.init((size_t)n9 * 2300 + 64 * 1024))) return r;
+			g_arena = &arena;
+			struct Reset { ~Reset() { g_arena = nullptr; } } reset;
 			std::vector<uint64_t> off9(n9);
 			std::vector<float> fs9(n9);
 			for (int k = 0; k < n9; k++) {
@@ -767,7 +820,7 @@ int RxRun::tch9_pass()
 				off9[k] = c.base + (uint64_t)((int64_t)x.align + sps * items9[k].tn * 39 - etoa9);
 				fs9[k] = -x.freq_err;
 			}
-			DBuf d_o, d_f, d_eb, d_sid, d_rv;
+			ABuf d_o, d_f, d_eb, d_sid, d_rv;
 			HIP_TRY(d_o.alloc((size_t)n9 * 8)); HIP_TRY(d_f.alloc((size_t)n9 * 4)); HIP_TRY(d_eb.alloc((size_t)n9 * 662));
 			HIP_TRY(d_sid.alloc((size_t)n9 * 4)); HIP_TRY(d_rv.alloc((size_t)n9 * 4));
 			HIP_TRY(hipMemcpyAsync(d_o.p, off9.data(), (size_t)n9 * 8, hipMemcpyHostToDevice, st));
@@ -825,7 +878,7 @@ int RxRun::tch9_pass()
 					if (kc) std::memcpy(&keys[(size_t)i * 8], kc + (size_t)c.a * 8, 8);
 					fns[i] = (uint32_t)c.log[items9[k].frame].fn;
 				}
-				DBuf d_e2, d_k, d_fn, d_ks, d_l2f, d_crc, d_cvf, d_l2t, d_cvt;
+				ABuf d_e2, d_k, d_fn, d_ks, d_l2f, d_crc, d_cvf, d_l2t, d_cvt;
 				HIP_TRY(d_e2.alloc(eb.size())); HIP_TRY(d_k.alloc(keys.size())); HIP_TRY(d_fn.alloc((size_t)nj * 4));
 				HIP_TRY(d_ks.alloc((size_t)nj * 658));
 				HIP_TRY(d_l2f.alloc((size_t)nf * 38)); HIP_TRY(d_crc.alloc((size_t)nf * 4)); HIP_TRY(d_cvf.alloc((size_t)nf * 4));
@@ -845,16 +898,21 @@ int RxRun::tch9_pass()
 					HIP_TRY(hipMemcpyAsync(crcf.data(), d_crc.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
 					HIP_TRY(hipMemcpyAsync(cvf.data(), d_cvf.p, (size_t)nf * 4, hipMemcpyDeviceToHost, st));
 				}
+				std::vector<int32_t> pos((size_t)nt9);       // lives until the synchronisation below
 				{
-					int done = 0;
-					for (int len_run : run_len) {
-						const size_t o = (size_t)(nf + done);
-						r = gmr1_hip_tch9_decode_batch_dev(st, 1, len_run, 2 /* GMR1_TCH9_9k6, gmr1_rx.c:333 */,
-						                                   d_e2.as<int8_t>() + o * 662, d_ks.as<uint8_t>() + o * 658,
-						                                   d_l2t.as<uint8_t>() + (size_t)done * 60, nullptr, nullptr,
-						                                   d_cvt.as<int32_t>() + done);
+					// all runs in one launch: every burst knows its position in its own run
+					if (nt9) {
+						size_t i = 0;
+						for (int len_run : run_len)
+							for (int q = 0; q < len_run; q++)
+								pos[i++] = q;
+						ABuf d_pos;
+						HIP_TRY(d_pos.alloc((size_t)nt9 * 4));
+						HIP_TRY(hipMemcpyAsync(d_pos.p, pos.data(), (size_t)nt9 * 4, hipMemcpyHostToDevice, st));
+						r = tch9_runs_dev_impl(st, 2 /* GMR1_TCH9_9k6, gmr1_rx.c:333 */, nt9, d_pos.as<int32_t>(),
+						                       d_e2.as<int8_t>() + (size_t)nf * 662, d_ks.as<uint8_t>() + (size_t)nf * 658,
+						                       d_l2t.as<uint8_t>(), d_cvt.as<int32_t>());
 						if (r) return r;
-						done += len_run;
 					}
 					if (nt9) {
 						HIP_TRY(hipMemcpyAsync(l2t.data(), d_l2t.p, l2t.size(), hipMemcpyDeviceToHost, st));

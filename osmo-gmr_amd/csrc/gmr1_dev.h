@@ -233,6 +233,7 @@ hipError_t launch_a5(const A5Args &a, hipStream_t stream);
 struct Nt9Args {
 	int n;                     // bursts
 	int seq_len;               // TCH9: consecutive bursts per channel (inter-burst de-interleaver), FACCH9: 1
+	const int32_t *seq_pos;    // optional: position of every burst in its run (runs of unequal length, back to back)
 	int kind;                  // 0 2k4, 1 4k8, 2 9k6 (enum gmr1_tch9_mode), 3 FACCH9
 	int N;                     // coded bits per input bit (5, 3, 2, 2)
 	int len;                   // data bits (144, 240, 480, 316)

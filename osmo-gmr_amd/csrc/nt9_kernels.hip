@@ -175,7 +175,8 @@ __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 		const int g = g0 + q;
 		uint32_t c0[5] = {0, 0, 0, 0, 0}, c1[5] = {0, 0, 0, 0, 0};
 		if (g < a.n) {
-			const int pos = g % a.seq_len;               // position of the burst in its channel's sequence
+			// position of the burst in its channel's sequence (runs of unequal length: given per burst)
+			const int pos = a.seq_pos ? a.seq_pos[g] : g % a.seq_len;
 			for (int j = 0; j < N; j++) {
 				const uint32_t m = a.map[k * N + j];
 				if (m & kMapPunct)
