@@ -1883,8 +1883,9 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 // frame to the end of the capture, without leaving the GPU.  The feedback of the loop only crosses a BCCH
 // frame, so it runs in rounds: wave 0 lists the chain's CCCH bursts up to and including its next BCCH burst
 // (rx_loop_build_round, rx_loop.h), up to eight wavefronts demodulate and decode one burst each (rx4_body,
-// the burst kernel itself), wave 0 turns the results into records exactly as rx_bcch / rx_ccch do (energy
-// gate, CRC, BCCH feedback: time, frequency, SI1 TDMA position) and lists the next round.  A round's operands
+// the burst kernel itself), wave 0 applies the BCCH feedback (time, frequency, SI1 TDMA position), lists the next
+// round and, while that one is already running, turns the finished round's results into records exactly as
+// rx_bcch / rx_ccch do (energy gate, CRC).  A round's operands
 // and results never leave LDS; what goes to HBM is what the reference hands to GSMTAP: the 40-byte records, in
 // frame order, plus -- when a traffic pass follows -- the per-frame context rx_tch3 sees.  A round is about
 // one wave's latency instead of launch + kernel + synchronise + host (~59 us).
@@ -1894,14 +1895,15 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
                                                                 int lds_per_wave)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
-	// operands and results of the round's bursts
+	// operands of the round's bursts; items and results double-buffered by round parity, so that the records of
+	// round r - 1 can be written while round r is already running
 	__shared__ uint64_t s_off[kLoopPerRound];
 	__shared__ float s_fs[kLoopPerRound];
 	__shared__ uint8_t s_kind[kLoopPerRound];
-	__shared__ RxLoopItem s_items[kLoopPerRound];
-	__shared__ __align__(8) uint8_t s_l2[kLoopPerRound][24];
-	__shared__ int32_t s_crc[kLoopPerRound], s_conv[kLoopPerRound], s_rv[kLoopPerRound];
-	__shared__ float s_toa[kLoopPerRound], s_fe[kLoopPerRound], s_en[kLoopPerRound];
+	__shared__ RxLoopItem s_items[2][kLoopPerRound];
+	__shared__ __align__(8) uint8_t s_l2[2][kLoopPerRound][24];
+	__shared__ int32_t s_crc[2][kLoopPerRound], s_conv[2][kLoopPerRound], s_rv[2][kLoopPerRound];
+	__shared__ float s_toa[2][kLoopPerRound], s_fe[2][kLoopPerRound], s_en[2][kLoopPerRound];
 	__shared__ int s_n;
 	const int chain = blockIdx.x;
 	const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -1914,68 +1916,74 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
 	int n_rec = 0, n_frames = 0;               // records emitted / frames completed so far
 	int prev_n = 0, frames_at_round = 0;
+	// what the deferred record writer of the previous round needs (wave 0)
+	int e_n = 0, e_frames = 0, e_fn = 0, e_tn = 0;
+	bool e_moved = false;
+	float e_minen = 0.f;
 	auto on_frame = [&](const RxLoopState &x) {
 		if (flog && lane == 0 && n_frames < la.flog_stride)
 			flog[n_frames] = {x.align, x.freq_err, x.fn};
 		n_frames++;
 	};
+	// records of a finished round (rx_ccch gmr1_rx.c:800-850, rx_bcch :746-798), compacted in burst order
+	auto write_records = [&](int pb) {
+		const int k = lane < e_n ? lane : 0;
+		const RxLoopItem it = s_items[pb][k];
+		const bool is_b = it.is_bcch != 0;
+		bool emit = false;
+		if (lane < e_n)
+			emit = is_b ? e_moved                                          // found, CRC passed (:782-795)
+			            : (!(s_en[pb][k] < e_minen) && !s_rv[pb][k] && !s_crc[pb][k]);   // energy gate first (:813-816)
+		const unsigned long long mask = __ballot(emit);
+		if (emit) {
+			const int slot = n_rec + __popcll(mask & ((1ull << lane) - 1ull));
+			if (slot < la.rec_stride) {
+				uint32_t *d = reinterpret_cast<uint32_t *>(rec + slot);
+				const uint32_t *l2w = reinterpret_cast<const uint32_t *>(s_l2[pb][k]);
+				d[0] = (uint32_t)st.arfcn | ((uint32_t)st.chain << 16) | ((is_b ? 1u : 2u) << 24);
+				d[1] = (uint32_t)(is_b ? e_fn : it.fn);                    // BCCH: after the SI1 alignment
+				d[2] = ((uint32_t)(is_b ? e_tn : it.tn) & 0xffu) | (24u << 16);     // crc = 0, len = 24
+				d[3] = (uint32_t)s_conv[pb][k];
+#pragma unroll
+				for (int i = 0; i < 6; i++)
+					d[4 + i] = l2w[i];
+				if (rec_frame) {
+					rec_frame[slot] = e_frames + it.frames_before;
+					rec_minen[slot] = e_minen;
+				}
+			}
+		}
+		n_rec += __popcll(mask);
+	};
 	int round = 0;
 	for (; round < la.max_rounds; round++) {
+		const int cb = round & 1, pb = cb ^ 1;
 		if (wave == 0) {
+			e_n = prev_n;
 			if (prev_n) {
-				// ---- the previous round's results -> records (rx_ccch gmr1_rx.c:800-850, rx_bcch :746-798)
-				const float min_energy = st.bcch_energy / 2.0f;     // the level the round started with
-				const int k = lane < prev_n ? lane : 0;
-				const RxLoopItem it = s_items[k];
-				const bool is_b = it.is_bcch != 0;
-				const int rv = s_rv[k], crc = s_crc[k];
-				bool emit = false;
-				int fn = it.fn, tn = it.tn;
-				if (lane < prev_n && !is_b)
-					emit = !(s_en[k] < min_energy) && !rv && !crc;         // energy gate first (:813-816)
-				const int kb = prev_n - 1;                              // a BCCH burst is the round's last
-				if (s_items[kb].is_bcch) {
-					bool moved = false;
-					if (!s_rv[kb]) {
-						st.bcch_energy = s_en[kb];
-						moved = rx_loop_bcch_result(st, sps, s_rv[kb], s_crc[kb], s_toa[kb], s_fe[kb], s_l2[kb],
-						                            s_items[kb].e_toa) != 0;
+				// ---- the previous round's BCCH burst (always its last) feeds back before the next round is listed
+				e_minen = st.bcch_energy / 2.0f;                        // the gate level the round started with
+				e_frames = frames_at_round;
+				e_moved = false;
+				const int kb = prev_n - 1;
+				if (s_items[pb][kb].is_bcch) {
+					if (!s_rv[pb][kb]) {
+						st.bcch_energy = s_en[pb][kb];
+						e_moved = rx_loop_bcch_result(st, sps, s_rv[pb][kb], s_crc[pb][kb], s_toa[pb][kb], s_fe[pb][kb],
+						                              s_l2[pb][kb], s_items[pb][kb].e_toa) != 0;
 					}
-					if (lane == kb) {
-						emit = moved;
-						fn = st.fn;                                      // after the SI1 alignment (:789-795)
-						tn = st.stn;
-					}
+					e_fn = st.fn;
+					e_tn = st.stn;
 					on_frame(st);                                        // rx_tch3 of this frame sees the updated state
 					rx_loop_advance(st, sps);
 				}
-				const unsigned long long mask = __ballot(emit);
-				if (emit) {
-					const int slot = n_rec + __popcll(mask & ((1ull << lane) - 1ull));
-					if (slot < la.rec_stride) {
-						uint32_t *d = reinterpret_cast<uint32_t *>(rec + slot);
-						const uint32_t *l2w = reinterpret_cast<const uint32_t *>(s_l2[k]);
-						d[0] = (uint32_t)st.arfcn | ((uint32_t)st.chain << 16) | ((is_b ? 1u : 2u) << 24);
-						d[1] = (uint32_t)fn;
-						d[2] = ((uint32_t)tn & 0xffu) | (24u << 16);         // crc = 0, len = 24
-						d[3] = (uint32_t)s_conv[k];
-#pragma unroll
-						for (int i = 0; i < 6; i++)
-							d[4 + i] = l2w[i];
-						if (rec_frame) {
-							rec_frame[slot] = frames_at_round + it.frames_before;
-							rec_minen[slot] = min_energy;
-						}
-					}
-				}
-				n_rec += __popcll(mask);
 			}
 			frames_at_round = n_frames;
-			const int n = rx_loop_build_round(st, sps, s_items, on_frame);
+			const int n = rx_loop_build_round(st, sps, s_items[cb], on_frame);
 			if (lane < n) {
-				s_off[lane] = st.base + (uint64_t)s_items[lane].begin;
+				s_off[lane] = st.base + (uint64_t)s_items[cb][lane].begin;
 				s_fs[lane] = -st.freq_err;
-				s_kind[lane] = s_items[lane].is_bcch ? 0 : 1;
+				s_kind[lane] = s_items[cb][lane].is_bcch ? 0 : 1;
 			}
 			if (lane == 0)
 				s_n = n;
@@ -1983,6 +1991,8 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 		}
 		__syncthreads();
 		const int n = s_n;
+		if (wave == 0 && e_n)
+			write_records(pb);                     // off the critical path: the round's BCCH burst runs on the last wave
 		if (n == 0)
 			break;
 		if (wave < n) {
@@ -1994,10 +2004,11 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 				if (nxt >= 64 && nxt + 1100 < lim)
 					sink = reinterpret_cast<const float *>(a.iq + nxt - 64)[lane * 32];
 			}
-			const RxIo io = {s_off, s_kind, s_fs, &s_l2[0][0], s_crc, s_conv, s_rv, nullptr, s_toa, s_fe, s_en, nullptr, nullptr};
+			const RxIo io = {s_off, s_kind, s_fs, &s_l2[cb][0][0], s_crc[cb], s_conv[cb], s_rv[cb], nullptr,
+			                 s_toa[cb], s_fe[cb], s_en[cb], nullptr, nullptr};
 			rx4_body<NPL, SPS, true>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane);
 			if (sink == 1.2345678e-30f)
-				s_en[wave] = 0.f;                  // keeps the touch alive
+				s_fs[wave] = 0.f;                  // keeps the touch alive
 		}
 		__syncthreads();
 	}
