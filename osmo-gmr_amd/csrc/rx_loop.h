@@ -86,7 +86,7 @@ GMR1_HD int rx_loop_build_round(RxLoopState &c, int sps, RxLoopItem *items, F on
 {
 	int n = 0, cnt = 0, frames = 0;
 	while (!c.done && cnt < kLoopPerRound - 1) {
-		const int m = ((c.fn - c.delay) & 63) % 8;
+		const int m = (c.fn - c.delay) & 7;          // sirfn % 8 with sirfn = (fn - delay) & 63, gmr1_rx.c:870-877
 		int begin = 0;
 		if (m == 2) {
 			const int e = rx_loop_burst_map(c, sps, 234, c.stn, 20 * sps, &begin);
