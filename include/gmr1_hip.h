@@ -70,7 +70,11 @@ struct gmr1_hip_burst_flat {
 	struct gmr1_hip_chunk data[GMR1_HIP_MAX_CHUNKS];
 };
 
-/* ---- library / device ---------------------------------------------------- */
+/* ---- library / device ----------------------------------------------------
+ * Threads: gmr1_hip_last_error() is per thread; the burst-level _batch / _batch_dev calls keep no state
+ * between calls and may run from several threads on different streams.  The calls that use the library's
+ * grow-only device workspace -- gmr1_hip_fcch_rough*_batch*, gmr1_hip_channelize*, gmr1_hip_rx_run* -- must not
+ * run concurrently on the same device (one receiver per GPU, as in the reference: one process per capture). */
 int         gmr1_hip_init(int device);          /* optional; selects the HIP device     */
 const char *gmr1_hip_last_error(void);
 const char *gmr1_hip_version(void);
