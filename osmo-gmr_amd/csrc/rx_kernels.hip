@@ -1979,7 +1979,41 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 				}
 			}
 			frames_at_round = n_frames;
-			const int n = rx_loop_build_round(st, sps, s_items[cb], on_frame);
+			// ---- the next round: what rx_loop_build_round does frame after frame, for the usual case (the next
+			// sixteen frames all lie inside the capture) with one frame per lane
+			int n;
+			{
+				const int frame_len = sps * 24 * 39;
+				const int j = lane & 15;
+				const int fn_j = st.fn + j, align_j = st.align + j * frame_len;
+				const bool inside = !st.done && st.align + 17 * frame_len <= st.len;   // frames 0..15 are all reached
+				const int m = (fn_j - st.delay) & 7;
+				const int tn_off = sps * st.stn * 39;
+				const int b_b = align_j + tn_off - 10 * sps, b_c = align_j + tn_off - 5 * sps;   // burst_map, e_toa = win / 2
+				const bool ok_b = b_b >= 0 && b_b + 234 * sps + 20 * sps <= st.len;
+				const bool ok_c = b_c >= 0 && b_c + 234 * sps + 10 * sps <= st.len;
+				const uint32_t mb = (uint32_t)__ballot(lane < 16 && m == 2 && ok_b) & 0xffffu;
+				const uint32_t mc = (uint32_t)__ballot(lane < 16 && m != 0 && m != 2 && ok_c) & 0xffffu;
+				const int jb = mb ? __builtin_ctz(mb) : 16;             // the first BCCH burst
+				const uint32_t before = mc & ((1u << jb) - 1u);
+				if (inside && mb && __popc(before) < kLoopPerRound - 1) {
+					// CCCH bursts of frames 0 .. jb-1, then the BCCH burst of frame jb (which stays the current frame)
+					const uint32_t items = before | (1u << jb);
+					if (lane < 16 && ((items >> j) & 1u)) {
+						const int idx = __popc(items & ((1u << j) - 1u));
+						const bool is_b = j == jb;
+						s_items[cb][idx] = {is_b ? b_b : b_c, is_b ? 1 : 0, fn_j, st.stn, is_b ? 10 * sps : 5 * sps, j};
+					}
+					if (flog && lane < jb && n_frames + lane < la.flog_stride)
+						flog[n_frames + lane] = {align_j, st.freq_err, fn_j};
+					n_frames += jb;
+					st.fn += jb;
+					st.align += jb * frame_len;
+					n = __popc(items);
+				} else {
+					n = rx_loop_build_round(st, sps, s_items[cb], on_frame);
+				}
+			}
 			if (lane < n) {
 				s_off[lane] = st.base + (uint64_t)s_items[cb][lane].begin;
 				s_fs[lane] = -st.freq_err;
