@@ -1506,7 +1506,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const int tl_p = LAT ? c_types[__builtin_amdgcn_readlane(type_r, 0)].sync_tl[0] : bt_r.sync_tl[0];
 	const int win = w_p < 3 ? w_p : 3;
 	unsigned long long key = 0;
-	for (int m = col; m + win <= w_p; m += 16) {
+	for (int m = LAT ? lane : col; m + win <= w_p; m += LAT ? 64 : 16) {
 		float e = 0.f;
 		for (int k = 0; k < win; k++) {
 			const float c = cr[m + k];
@@ -1519,6 +1519,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	key = row_max_u64<2>(key);
 	key = row_max_u64<4>(key);
 	key = row_max_u64<8>(key);
+	if (LAT) {                                        // the four rows searched the one burst's lags together
+		unsigned long long o = __shfl_xor(key, 16);
+		key = o > key ? o : key;
+		o = __shfl_xor(key, 32);
+		key = o > key ? o : key;
+	}
 	int mi = (int)(~(uint32_t)key);
 	if (mi < 0 || mi + win > w_p)
 		mi = 0;
@@ -1672,19 +1678,25 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			chn[h] = -1;
 			spos[h] = 0;
 			if (n < tl_r && row_live) {
-				int ch = 0, base = 0, cum = 0;
+				int ch = 0, base = 0, cum = 0, wb = 0;
 				for (int c = 0; c < nch_r - 1; c++) {
 					cum += bt_r.sync[0][c].len;
-					if (n >= cum) { base = cum; ch = c + 1; }
+					if (n >= cum) { base = cum; ch = c + 1; wb += bt_r.sync[0][c].len * sps + w_r - 1; }
 				}
 				const int nn = n - base;
 				const int sp = bt_r.sync[0][ch].pos + nn;
 				const int idx = sp * sps + d_r;
 				float2 x = make_float2(0.f, 0.f);
 				if (idx >= 0 && idx < in_len_r) {
-					x = in_r[idx];
-					x.x -= avr_r;
-					x.y -= avi_r;
+					if (LAT) {
+						// the wave's one burst: its sync-chunk windows are still staged (normalised, which no angle
+						// below notices) -- no second trip to L2
+						x = L.x[wb + nn * sps + d_r];
+					} else {
+						x = in_r[idx];
+						x.x -= avr_r;
+						x.y -= avi_r;
+					}
 				}
 				float s, c;
 				sincos_fast(fs_r * (float)idx, s, c);
