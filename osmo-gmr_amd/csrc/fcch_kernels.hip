@@ -342,6 +342,7 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 {
 	constexpr int PER = (N + 63) / 64;       // bins / symbols per lane
 	__shared__ float2 s_up[N], s_dn[N];
+	__shared__ float2 s_tw[N];               // the DFT's twiddles: read N times per bin, so from LDS, not from memory
 	__shared__ float s_e[2][N];
 	const int b = blockIdx.x, lane = threadIdx.x;
 	const int sps = a.sps, nraw = N * sps;
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 
 	// normalise, shift, mix
 	for (int i = lane; i < N; i += 64) {
+		s_tw[i] = c_fcch.twid[a.tab][i];
 		float2 v = in[i * sps];
 		v.x = (v.x - avr) * inv;
 		v.y = (v.y - avi) * inv;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 		if (k < N) {
 			int idx = 0;
 			for (int n = 0; n < N; n++) {
-				const float2 tw = c_fcch.twid[tab][idx];
+				const float2 tw = s_tw[idx];
 				const float2 u = s_up[n];
 				au.x = fmaf(u.x, tw.x, fmaf(-u.y, tw.y, au.x));
 				au.y = fmaf(u.x, tw.y, fmaf(u.y, tw.x, au.y));
