@@ -12,12 +12,15 @@
 //   k_rx4                  : the default fused BCCH / CCCH kernel: the same arithmetic with the
 //                            serial phases (timing bisection, sync-symbol terms) done once for
 //                            the four bursts of a wave, one burst per 16-lane row.
+//   k_rx_loop              : the frame loop of gmr1_rx (process_bcch, src/gmr1_rx.c:852-895) for one chain
+//                            per work-group of eight waves, all frames of the capture in one launch: the
+//                            body of k_rx4 (rx4_body) per burst, BCCH feedback, records written in place.
 //   k_detect, k_mod_order  : gmr1_pi4cxpsk_detect / _mod_order (pi4cxpsk.c:617-729).
 //   k_l1                   : the layer-1 chain alone on soft bits read from HBM.
 //
 // Design notes (DESIGN.md has the long form):
 //   * Work-groups are single 64-lane wavefronts: every hand-off goes through the
-//     wave's own LDS slice and needs no s_barrier.
+//     wave's own LDS slice and needs no s_barrier (k_rx_loop: eight of them, two barriers per round).
 //   * Samples are loaded once from HBM with coalesced 8-byte-per-lane loads, DC /
 //     power normalised in registers and parked in LDS; everything else reads LDS.
 //   * Burst formats live in __constant__ memory and are read with scalar loads.
