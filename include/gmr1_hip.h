@@ -192,6 +192,53 @@ int gmr1_hip_rach_decode_batch_dev(void *stream, int n, const int8_t *ebits, con
 int gmr1_hip_rach_decode_batch(int n, const int8_t *ebits, const uint8_t *sb_mask, uint8_t *rach, int32_t *rv,
                                int32_t *conv, int32_t *crc);
 
+/* ---- transmit direction: channel encoders and modulator -------------------------------------------------
+ * Batch forms of gmr1_{bcch,ccch,xch_dc12,facch3,tch3,facch9,tch9,rach}_encode (the headers under include/osmocom/gmr1/l1) and
+ * of gmr1_pi4cxpsk_mod (sdr/pi4cxpsk.h:115-117).  Payloads are packed bytes, everything else one ubit per byte:
+ *   bcch / xch_dc12: l2 n x 24 -> ebits n x 424 / 432;  ccch: l2 n x 24 -> n x 432
+ *   facch3: l2 n x 10, bits_s n x 32, ciph n x 384 (optional) -> ebits n x 416 (four bursts of 104)
+ *   tch3:   frames n x 2 x 10, bits_s n x 4, ciph n x 208 (optional), m -> ebits n x 212
+ *   facch9: l2 n x 38, sacch n x 10, status n x 4, ciph n x 658 (optional) -> ebits n x 662
+ *   tch9:   l2 n x 18 / 30 / 60 by mode; n = whole runs of seq_len consecutive bursts of one channel, the
+ *           inter-burst interleaver starts empty at every run (as after gmr1_interleaver_init)
+ *   rach:   rach n x 18, sb_mask n -> ebits n x 494
+ *   mod:    ebits n x (ebits of the burst format) -> out n x len complex float32 symbols, sync sequence sync_id
+ * _dev: device pointers, asynchronous on `stream` (mod_dev returns after its launch has finished). */
+int gmr1_hip_bcch_encode_batch_dev(void *stream, int n, const uint8_t *l2, uint8_t *ebits);
+int gmr1_hip_bcch_encode_batch(int n, const uint8_t *l2, uint8_t *ebits);
+int gmr1_hip_ccch_encode_batch_dev(void *stream, int n, const uint8_t *l2, uint8_t *ebits);
+int gmr1_hip_ccch_encode_batch(int n, const uint8_t *l2, uint8_t *ebits);
+int gmr1_hip_xch_dc12_encode_batch_dev(void *stream, int n, const uint8_t *l2, uint8_t *ebits);
+int gmr1_hip_xch_dc12_encode_batch(int n, const uint8_t *l2, uint8_t *ebits);
+int gmr1_hip_facch3_encode_batch_dev(void *stream, int n, const uint8_t *l2, const uint8_t *bits_s, const uint8_t *ciph,
+                                     uint8_t *ebits);
+int gmr1_hip_facch3_encode_batch(int n, const uint8_t *l2, const uint8_t *bits_s, const uint8_t *ciph, uint8_t *ebits);
+int gmr1_hip_tch3_encode_batch_dev(void *stream, int n, int m, const uint8_t *frames, const uint8_t *bits_s,
+                                   const uint8_t *ciph, uint8_t *ebits);
+int gmr1_hip_tch3_encode_batch(int n, int m, const uint8_t *frames, const uint8_t *bits_s, const uint8_t *ciph,
+                               uint8_t *ebits);
+int gmr1_hip_facch9_encode_batch_dev(void *stream, int n, const uint8_t *l2, const uint8_t *sacch, const uint8_t *status,
+                                     const uint8_t *ciph, uint8_t *ebits);
+int gmr1_hip_facch9_encode_batch(int n, const uint8_t *l2, const uint8_t *sacch, const uint8_t *status,
+                                 const uint8_t *ciph, uint8_t *ebits);
+int gmr1_hip_tch9_encode_batch_dev(void *stream, int mode, int n, int seq_len, const uint8_t *l2, const uint8_t *sacch,
+                                   const uint8_t *status, const uint8_t *ciph, uint8_t *ebits);
+int gmr1_hip_tch9_encode_batch(int mode, int n, int seq_len, const uint8_t *l2, const uint8_t *sacch,
+                               const uint8_t *status, const uint8_t *ciph, uint8_t *ebits);
+int gmr1_hip_rach_encode_batch_dev(void *stream, int n, const uint8_t *rach, const uint8_t *sb_mask, uint8_t *ebits);
+int gmr1_hip_rach_encode_batch(int n, const uint8_t *rach, const uint8_t *sb_mask, uint8_t *ebits);
+int gmr1_hip_mod_batch_dev(void *stream, int burst_id, int sync_id, int n, const uint8_t *ebits, float *out);
+int gmr1_hip_mod_batch(int burst_id, int sync_id, int n, const uint8_t *ebits, float *out);
+/* The position map (payload bits -> burst bits) the encoder kernel evaluates for one chain, copied into buf as
+ * struct EncPlan of osmo-gmr_amd/csrc/gmr1_dev.h; returns its size (buf may be NULL) or -EINVAL.  Host-only,
+ * works without a GPU: tests/test_tx_plan.py evaluates it bit by bit against the CPU oracle. */
+enum gmr1_hip_enc_chain {
+	GMR1_HIP_ENC_BCCH = 0, GMR1_HIP_ENC_CCCH, GMR1_HIP_ENC_FACCH3, GMR1_HIP_ENC_TCH3_M0, GMR1_HIP_ENC_TCH3_M1,
+	GMR1_HIP_ENC_FACCH9, GMR1_HIP_ENC_TCH9_2K4, GMR1_HIP_ENC_TCH9_4K8, GMR1_HIP_ENC_TCH9_9K6, GMR1_HIP_ENC_RACH,
+	GMR1_HIP_ENC_XCH_DC12, GMR1_HIP_ENC__COUNT
+};
+int gmr1_hip_encoder_plan(int chain, void *buf, int buf_len);
+
 /* ---- FCCH acquisition ------------------------------------------------------
  * fcch_type: 0 gmr1_fcch_burst, 1 gmr1_fcch3_lband_burst, 2 gmr1_fcch3_sband_burst.
  * rough: n search windows of `len` samples each -> toa[i] (samples), rv[i] (0 / -errno).

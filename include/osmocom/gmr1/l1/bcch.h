@@ -12,6 +12,10 @@ extern "C" {
 /* 424 soft bits -> 24 bytes; returns 0 when the CRC16 matches; *conv_rv (optional) = Viterbi metric */
 int gmr1_bcch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv);
 
+/* bcch.h:37: 24 bytes -> 424 burst bits (CRC16, K=5 rate 1/2, intra-burst interleaver, scrambler).  The bits are
+ * computed on the GPU; a device failure leaves bits_e untouched and is reported by gmr1_hip_last_error(). */
+void gmr1_bcch_encode(ubit_t *bits_e, const uint8_t *l2);
+
 #ifdef __cplusplus
 }
 #endif

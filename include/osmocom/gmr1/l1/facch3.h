@@ -14,6 +14,9 @@ extern "C" {
 int gmr1_facch3_decode(uint8_t *l2, ubit_t *bits_s,
                        const sbit_t *bits_e, const ubit_t *ciph, int *conv_rv);
 
+/* facch3.h:37-38: 10 bytes (76 bits) -> 4 x 104 burst bits; bits_s: 4 x 8 status bits; ciph: optional 4 x 96 keystream bits */
+void gmr1_facch3_encode(ubit_t *bits_e, const uint8_t *l2, const ubit_t *bits_s, const ubit_t *ciph);
+
 #ifdef __cplusplus
 }
 #endif

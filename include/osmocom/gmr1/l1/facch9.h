@@ -15,6 +15,10 @@ extern "C" {
 int gmr1_facch9_decode(uint8_t *l2, sbit_t *bits_sacch, sbit_t *bits_status,
                        const sbit_t *bits_e, const ubit_t *ciph, int *conv_rv);
 
+/* facch9.h:37-39: 38 bytes (300 bits) -> 662 burst bits; bits_sacch 10, bits_status 4, ciph optional 658 */
+void gmr1_facch9_encode(ubit_t *bits_e, const uint8_t *l2, const ubit_t *bits_sacch, const ubit_t *bits_status,
+                        const ubit_t *ciph);
+
 #ifdef __cplusplus
 }
 #endif

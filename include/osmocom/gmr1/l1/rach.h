@@ -14,6 +14,9 @@ extern "C" {
  * *conv_rv = Viterbi path metric, crc_rv[0] / crc_rv[1] = CRC8 / CRC12 verdicts (both optional). */
 int gmr1_rach_decode(uint8_t *rach, const sbit_t *bits_e, uint8_t sb_mask, int *conv_rv, int *crc_rv);
 
+/* rach.h:37: 18 bytes -> 494 burst bits (CRC8 ^ sb_mask, CRC12, K=5 rate 1/4, class-1 part sent twice) */
+void gmr1_rach_encode(ubit_t *bits_e, const uint8_t *rach, uint8_t sb_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,12 @@ void gmr1_tch3_decode(uint8_t *frame0, uint8_t *frame1, ubit_t *bits_s,
                       const sbit_t *bits_e, const ubit_t *ciph, int m,
                       int *conv0_rv, int *conv1_rv);
 
+/* tch3.h:37-39: two 10-byte speech frames -> 212 burst bits.  NOTE: the reference's encoder calls osmo_conv_encode with
+ * input and output swapped (src/l1/tch3.c:81), so its own output is not a TCH3 burst; this is the encoder
+ * gmr1_tch3_decode inverts (48 class-1 bits through the tail-biting K=7 code, 32 class-2 bits as they are). */
+void gmr1_tch3_encode(ubit_t *bits_e, const uint8_t *frame0, const uint8_t *frame1,
+                      const ubit_t *bits_s, const ubit_t *ciph, int m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,12 @@ void gmr1_tch9_decode(uint8_t *l2, sbit_t *bits_sacch, sbit_t *bits_status,
                       const ubit_t *ciph, struct gmr1_interleaver *il,
                       int *conv_rv);
 
+/* tch9.h:47-49: 18 / 30 / 60 bytes -> 662 burst bits through the depth-3 inter-burst interleaver `il`
+ * (gmr1_interleaver_init(il, 3, 648); one object per direction and channel) */
+void gmr1_tch9_encode(ubit_t *bits_e, const uint8_t *l2, enum gmr1_tch9_mode mode,
+                      const ubit_t *bits_sacch, const ubit_t *bits_status,
+                      const ubit_t *ciph, struct gmr1_interleaver *il);
+
 #ifdef __cplusplus
 }
 #endif

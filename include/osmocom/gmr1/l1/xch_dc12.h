@@ -13,6 +13,9 @@ extern "C" {
  * (0 = pass); *conv_rv = Viterbi path metric (optional). */
 int gmr1_xch_dc12_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv);
 
+/* xch_dc12.h:37: 24 bytes -> 432 burst bits (CRC16, K=9 rate 1/3 tail-biting, P(12;13)); 0 or -errno */
+int gmr1_xch_dc12_encode(ubit_t *bits_e, const uint8_t *l2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,11 @@ int gmr1_pi4cxpsk_detect(struct gmr1_pi4cxpsk_burst **burst_types, float e_toa,
 /* 2 for BPSK, 4 for QPSK (x^2 vs x^4 line power), < 0 on error */
 int gmr1_pi4cxpsk_mod_order(struct osmo_cxvec *burst_in, int sps, float freq_shift);
 
+/* pi4cxpsk.h:115-117: burst bits -> burst_type->len symbols at one sample per symbol (guard = 0, training sequence
+ * sync_id, pi/4 rotation applied); -ENOMEM when burst_out->max_len is too short, 0 on success */
+int gmr1_pi4cxpsk_mod(struct gmr1_pi4cxpsk_burst *burst_type,
+                      ubit_t *ebits, int sync_id, struct osmo_cxvec *burst_out);
+
 #ifdef __cplusplus
 }
 #endif

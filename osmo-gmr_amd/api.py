@@ -45,6 +45,15 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_a5_batch_dev", "gmr1_hip_a5_batch", "gmr1_a5", "gmr1_a5_1",
     "gmr1_hip_xch_dc12_decode_batch_dev", "gmr1_hip_xch_dc12_decode_batch", "gmr1_xch_dc12_decode",
     "gmr1_hip_rach_decode_batch_dev", "gmr1_hip_rach_decode_batch", "gmr1_rach_decode",
+    "gmr1_hip_bcch_encode_batch_dev", "gmr1_hip_bcch_encode_batch", "gmr1_bcch_encode",
+    "gmr1_hip_ccch_encode_batch_dev", "gmr1_hip_ccch_encode_batch", "gmr1_ccch_encode",
+    "gmr1_hip_xch_dc12_encode_batch_dev", "gmr1_hip_xch_dc12_encode_batch", "gmr1_xch_dc12_encode",
+    "gmr1_hip_facch3_encode_batch_dev", "gmr1_hip_facch3_encode_batch", "gmr1_facch3_encode",
+    "gmr1_hip_tch3_encode_batch_dev", "gmr1_hip_tch3_encode_batch", "gmr1_tch3_encode",
+    "gmr1_hip_facch9_encode_batch_dev", "gmr1_hip_facch9_encode_batch", "gmr1_facch9_encode",
+    "gmr1_hip_tch9_encode_batch_dev", "gmr1_hip_tch9_encode_batch", "gmr1_tch9_encode",
+    "gmr1_hip_rach_encode_batch_dev", "gmr1_hip_rach_encode_batch", "gmr1_rach_encode",
+    "gmr1_hip_mod_batch_dev", "gmr1_hip_mod_batch", "gmr1_pi4cxpsk_mod", "gmr1_hip_encoder_plan",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -949,3 +958,189 @@ def gsmtap_pack_big(record, with_arfcn=False) -> bytes:
     if n < 0:
         _check(n, "gmr1_hip_gsmtap_pack_big")
     return bytes(buf[:n])
+
+
+# ---- transmit direction: channel encoders and modulator (csrc/capi_tx.cpp, tx_kernels.hip) ----------------
+ENC_CHAINS = ("bcch", "ccch", "facch3", "tch3_m0", "tch3_m1", "facch9", "tch9_2k4", "tch9_4k8", "tch9_9k6", "rach",
+              "xch_dc12")
+
+
+def encoder_plan(chain):
+    """The position map of one encoder chain (struct EncPlan of csrc/gmr1_dev.h) as a dict of numpy arrays.
+    Host-only: works without a GPU."""
+    cid = ENC_CHAINS.index(chain) if isinstance(chain, str) else int(chain)
+    size = load().gmr1_hip_encoder_plan(C.c_int(cid), None, C.c_int(0))
+    if size < 0:
+        _check(size, "gmr1_hip_encoder_plan")
+    buf = np.zeros(size, np.uint8)
+    rc = load().gmr1_hip_encoder_plan(C.c_int(cid), buf.ctypes.data_as(C.c_void_p), C.c_int(size))
+    if rc < 0:
+        _check(rc, "gmr1_hip_encoder_plan")
+    head = buf[:32].view(np.int32)
+    o = 32
+    poly = buf[o:o + 32].view(np.uint32); o += 32
+    n_tab = 64 * 8
+    crc_tab = buf[o:o + 2 * n_tab].view(np.uint16); o += 2 * n_tab
+    crc_tab2 = buf[o:o + 2 * n_tab].view(np.uint16); o += 2 * n_tab
+    ext_src = buf[o:o + 2 * 512].view(np.uint16); o += 2 * 512
+    out = buf[o:o + 4 * 672].view(np.uint32); o += 4 * 672
+    assert o == size, (o, size)
+    names = ("n_in0", "n_in1", "n_ext", "n_out", "n_aux0", "n_aux1", "n_ciph", "depth")
+    d = {k: int(v) for k, v in zip(names, head)}
+    d.update(poly=poly.copy(), crc_tab=crc_tab.copy(), crc_tab2=crc_tab2.copy(), ext_src=ext_src[:d["n_ext"]].copy(),
+             out=out[:d["n_out"]].copy())
+    return d
+
+
+def _opt(a, dtype=np.uint8):
+    if a is None:
+        return None, None
+    return _np(a, dtype)
+
+
+def _encode_batch(fname, n_out, n, head, arrays):
+    """arrays: list of (array or None); -> (n, n_out) uint8"""
+    keep, ptrs = [], []
+    for a in arrays:
+        k, p = _opt(a)
+        keep.append(k)
+        ptrs.append(p)
+    e = np.zeros((n, n_out), np.uint8)
+    _check(getattr(load(), fname)(*head, *ptrs, e.ctypes.data_as(C.c_void_p)), fname)
+    return e
+
+
+def bcch_encode_batch(l2):
+    l2 = np.ascontiguousarray(l2, np.uint8).reshape(-1, 24)
+    return _encode_batch("gmr1_hip_bcch_encode_batch", 424, l2.shape[0], [C.c_int(l2.shape[0])], [l2])
+
+
+def ccch_encode_batch(l2):
+    l2 = np.ascontiguousarray(l2, np.uint8).reshape(-1, 24)
+    return _encode_batch("gmr1_hip_ccch_encode_batch", 432, l2.shape[0], [C.c_int(l2.shape[0])], [l2])
+
+
+def xch_dc12_encode_batch(l2):
+    l2 = np.ascontiguousarray(l2, np.uint8).reshape(-1, 24)
+    return _encode_batch("gmr1_hip_xch_dc12_encode_batch", 432, l2.shape[0], [C.c_int(l2.shape[0])], [l2])
+
+
+def facch3_encode_batch(l2, bits_s, ciph=None):
+    """l2 (n, 10), bits_s (n, 32), ciph (n, 384) optional -> (n, 4, 104)"""
+    l2 = np.ascontiguousarray(l2, np.uint8).reshape(-1, 10)
+    n = l2.shape[0]
+    return _encode_batch("gmr1_hip_facch3_encode_batch", 416, n, [C.c_int(n)], [l2, bits_s, ciph]).reshape(n, 4, 104)
+
+
+def tch3_encode_batch(frames, bits_s, m=0, ciph=None):
+    """frames (n, 2, 10), bits_s (n, 4), ciph (n, 208) optional -> (n, 212)"""
+    frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, 20)
+    n = frames.shape[0]
+    return _encode_batch("gmr1_hip_tch3_encode_batch", 212, n, [C.c_int(n), C.c_int(m)], [frames, bits_s, ciph])
+
+
+def facch9_encode_batch(l2, sacch, status, ciph=None):
+    l2 = np.ascontiguousarray(l2, np.uint8).reshape(-1, 38)
+    n = l2.shape[0]
+    return _encode_batch("gmr1_hip_facch9_encode_batch", 662, n, [C.c_int(n)], [l2, sacch, status, ciph])
+
+
+def tch9_encode_batch(l2, mode, seq_len, sacch, status, ciph=None):
+    """l2 (n, 18 | 30 | 60): whole runs of seq_len consecutive bursts of one channel each -> (n, 662)"""
+    l2 = np.ascontiguousarray(l2, np.uint8)
+    l2 = l2.reshape(-1, (18, 30, 60)[mode] if 0 <= mode < 3 else l2.shape[-1])
+    n = l2.shape[0]
+    return _encode_batch("gmr1_hip_tch9_encode_batch", 662, n, [C.c_int(mode), C.c_int(n), C.c_int(seq_len)],
+                         [l2, sacch, status, ciph])
+
+
+def rach_encode_batch(rach, sb_mask):
+    rach = np.ascontiguousarray(rach, np.uint8).reshape(-1, 18)
+    n = rach.shape[0]
+    return _encode_batch("gmr1_hip_rach_encode_batch", 494, n, [C.c_int(n)], [rach, np.asarray(sb_mask, np.uint8).reshape(n)])
+
+
+def mod_batch(burst, ebits, sync_id=0):
+    """ebits (n, burst.ebits) ubits -> (n, burst.len) complex64 symbols at one sample per symbol"""
+    bid = BURST_IDS.index(burst) if isinstance(burst, str) else int(burst)
+    b = burst_info(bid)
+    eb, p_eb = _np(ebits, np.uint8)
+    eb = eb.reshape(-1, b.ebits)
+    out = np.zeros((eb.shape[0], b.len), np.complex64)
+    _check(load().gmr1_hip_mod_batch(C.c_int(bid), C.c_int(sync_id), C.c_int(eb.shape[0]), p_eb,
+                                     out.ctypes.data_as(C.c_void_p)), "gmr1_hip_mod_batch")
+    return out
+
+
+def encode_single(chain, *args):
+    """The reference's own single calls gmr1_<chain>_encode (void unless xch_dc12): returns the burst bits.
+    bcch / ccch / xch_dc12: (l2); facch3: (l2, bits_s, ciph | None); tch3: (frame0, frame1, bits_s, ciph | None, m);
+    facch9: (l2, sacch, status, ciph | None); rach: (rach, sb_mask)."""
+    n_out = {"bcch": 424, "ccch": 432, "xch_dc12": 432, "facch3": 416, "tch3": 212, "facch9": 662, "rach": 494}[chain]
+    e = np.full(n_out, 255, np.uint8)
+    f = getattr(load(), "gmr1_%s_encode" % chain)
+    f.restype = C.c_int if chain == "xch_dc12" else None
+    cargs, keep = [], []
+    for a in args:
+        if a is None:
+            cargs.append(None)
+        elif isinstance(a, (int, np.integer)):
+            cargs.append(C.c_uint8(int(a)) if chain == "rach" else C.c_int(int(a)))
+        else:
+            k, p = _np(a, np.uint8)
+            keep.append(k)
+            cargs.append(p)
+    rc = f(e.ctypes.data_as(C.c_void_p), *cargs)
+    if chain == "xch_dc12":
+        _check(rc, "gmr1_xch_dc12_encode")
+    if (e == 255).any():
+        raise Gmr1HipError("gmr1_%s_encode: %s" % (chain, load().gmr1_hip_last_error().decode(errors="replace")))
+    return e
+
+
+class Tch9Encoder:
+    """One TCH9 channel encoded burst by burst with the reference's stateful calls (tch9.h:47-49)."""
+
+    def __init__(self, mode: int):
+        self.mode = mode
+        self.il = Interleaver()
+        f = load().gmr1_interleaver_init
+        f.restype = C.c_int
+        _check(f(C.byref(self.il), C.c_int(3), C.c_int(648)), "gmr1_interleaver_init")
+
+    def encode(self, l2, sacch, status, ciph=None):
+        l2, p_l2 = _np(l2, np.uint8)
+        sa, p_sa = _np(sacch, np.uint8)
+        stt, p_st = _np(status, np.uint8)
+        c, p_c = _opt(ciph)
+        e = np.full(662, 255, np.uint8)
+        f = load().gmr1_tch9_encode
+        f.restype = None
+        f(e.ctypes.data_as(C.c_void_p), p_l2, C.c_int(self.mode), p_sa, p_st, p_c, C.byref(self.il))
+        if (e == 255).any():
+            raise Gmr1HipError("gmr1_tch9_encode: %s" % load().gmr1_hip_last_error().decode(errors="replace"))
+        return e
+
+    def close(self):
+        if self.il.bits_cpp:
+            load().gmr1_interleaver_fini(C.byref(self.il))
+            self.il.bits_cpp = None
+
+
+def pi4cxpsk_mod(burst_name: str, ebits, sync_id=0, max_len=None):
+    """The reference's gmr1_pi4cxpsk_mod on one of the exported burst objects -> (rc, symbols)"""
+    lib_ = load()
+    bt = C.c_void_p.in_dll(lib_, "gmr1_%s_burst" % burst_name)   # address of the exported struct
+    b = burst_info(burst_name)
+    n = b.len if max_len is None else max_len
+    data = np.zeros(max(n, 1), np.complex64)
+    v = CxVec()
+    v.len = 0
+    v.max_len = n
+    v.flags = 0
+    v.data = data.ctypes.data_as(C.c_void_p)
+    eb, p_eb = _np(ebits, np.uint8)
+    f = lib_.gmr1_pi4cxpsk_mod
+    f.restype = C.c_int
+    rc = f(C.c_void_p(C.addressof(bt)), p_eb, C.c_int(sync_id), C.byref(v))
+    return rc, data[:v.len].copy()

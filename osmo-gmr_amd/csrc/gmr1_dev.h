@@ -268,6 +268,47 @@ struct XchArgs {
 };
 hipError_t launch_xch(const XchArgs &a, hipStream_t stream);
 
+// ---- transmit direction (tx_kernels.hip): the channel encoders and the 1-sample-per-symbol modulator ------
+// Every GMR-1 channel coder is a fixed GF(2)-linear map from payload bits to burst bits (CRC, feed-forward
+// convolutional code, puncturing, interleavers, scrambler, multiplexing).  The host writes that map down once
+// per channel as an EncPlan (capi_tx.cpp); one generic kernel evaluates it, one unit (burst, or group of four
+// FACCH3 bursts) per wave.
+constexpr int kEncMaxIn = 64;          // payload bytes of one unit (TCH9 9k6: 60)
+constexpr int kEncMaxExt = 512;        // bits of the extended information word (TCH9 9k6: 480 + 8)
+constexpr int kEncMaxOut = 672;        // burst bits of one unit (NT9: 662)
+struct EncPlan {
+	int32_t n_in0, n_in1;              // payload bytes per unit: first / second input array
+	int32_t n_ext;                     // extended information word: [K-1 preset bits | info + CRC | flush zeros] ...
+	int32_t n_out;                     // burst bits written per unit
+	int32_t n_aux0, n_aux1;            // multiplexed-in bits per unit (status / SACCH): first / second array
+	int32_t n_ciph;                    // keystream bits per unit
+	int32_t depth;                     // 1, or 3: inter-burst interleaver (bursts n, n-1, n-2 of a run)
+	uint32_t poly[8];                  // window masks over K consecutive bits of the extended word
+	uint16_t crc_tab[kEncMaxIn * 8];   // what payload bit b adds to CRC register A (the CRCs are linear: init 0, no final xor)
+	uint16_t crc_tab2[kEncMaxIn * 8];  // the same for CRC register B (RACH: CRC12), else zeros
+	uint16_t ext_src[kEncMaxExt];      // where every bit of the extended word comes from (see tx_kernels.hip)
+	uint32_t out[kEncMaxOut];          // descriptor of every burst bit (see tx_kernels.hip)
+};
+struct EncArgs {
+	int n;                             // units
+	int seq_len;                       // depth 3: units per interleaver run (state starts empty at each run)
+	const EncPlan *plan;               // device
+	const uint8_t *in0, *in1;          // n x n_in0, n x n_in1 payload bytes
+	const uint8_t *aux0, *aux1;        // n x n_aux0, n x n_aux1 ubits
+	const uint8_t *ciph;               // optional n x n_ciph ubits
+	uint8_t *ebits;                    // n x n_out ubits
+};
+hipError_t launch_encode(const EncArgs &a, hipStream_t stream);
+
+struct ModArgs {
+	int n, len, nbits, n_ebits;
+	float rotation;
+	const int16_t *plan;               // len entries: -1 guard, 0..3 sync symbol, 4 + k: data symbol from ebits[k ...]
+	const uint8_t *ebits;              // n x n_ebits ubits
+	float2 *out;                       // n x len symbols
+};
+hipError_t launch_mod(const ModArgs &a, hipStream_t stream);
+
 hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream);
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
 hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);

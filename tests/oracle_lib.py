@@ -124,12 +124,15 @@ def ccch_decode(ebits):
     return _dec24("orc_ccch_decode", ebits)
 
 
-def facch3_encode(l2, bits_s):
+def facch3_encode(l2, bits_s, ciph=None):
     l2 = np.ascontiguousarray(l2, np.uint8)
     bits_s = np.ascontiguousarray(bits_s, np.uint8)
+    if ciph is not None:
+        ciph = np.ascontiguousarray(ciph, np.uint8)
     out = np.zeros((l2.shape[0], 4, 104), np.uint8)
     for i in range(l2.shape[0]):
-        lib().orc_facch3_encode(_p(out[i], C.c_uint8), _p(l2[i], C.c_uint8), _p(bits_s[i], C.c_uint8), None)
+        lib().orc_facch3_encode(_p(out[i], C.c_uint8), _p(l2[i], C.c_uint8), _p(bits_s[i], C.c_uint8),
+                                None if ciph is None else _p(ciph[i], C.c_uint8))
     return out
 
 
@@ -149,14 +152,16 @@ def facch3_decode(ebits):
     return l2, s, crc, conv
 
 
-def tch3_encode(f0, f1, bits_s, m=0):
+def tch3_encode(f0, f1, bits_s, m=0, ciph=None):
     f0 = np.ascontiguousarray(f0, np.uint8)
     f1 = np.ascontiguousarray(f1, np.uint8)
     bits_s = np.ascontiguousarray(bits_s, np.uint8)
+    if ciph is not None:
+        ciph = np.ascontiguousarray(ciph, np.uint8)
     out = np.zeros((f0.shape[0], 212), np.uint8)
     for i in range(f0.shape[0]):
         lib().orc_tch3_encode(_p(out[i], C.c_uint8), _p(f0[i], C.c_uint8), _p(f1[i], C.c_uint8),
-                              _p(bits_s[i], C.c_uint8), None, C.c_int(m))
+                              _p(bits_s[i], C.c_uint8), None if ciph is None else _p(ciph[i], C.c_uint8), C.c_int(m))
     return out
 
 

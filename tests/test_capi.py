@@ -134,6 +134,17 @@ def test_no_cpu_fallback(pkg):
         pkg.api.rach_decode_batch(np.zeros((2, 494), np.int8), 0)
     with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
         pkg.api.xch_dc12_decode(np.zeros(432, np.int8))
+    # transmit direction: encoders and modulator
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.bcch_encode_batch(np.zeros((2, 24), np.uint8))
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.tch9_encode_batch(np.zeros((3, 18), np.uint8), 0, 3, np.zeros((3, 10), np.uint8), np.zeros((3, 4), np.uint8))
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.mod_batch("bcch", np.zeros((1, 424), np.uint8))
+    with pytest.raises(pkg.api.Gmr1HipError):
+        pkg.api.encode_single("bcch", np.zeros(24, np.uint8))          # void call: bits_e untouched, error recorded
+    rc, _ = pkg.api.pi4cxpsk_mod("bcch", np.zeros(424, np.uint8))
+    assert rc == -19
 
 
 def test_product_does_not_reference_oracle():
