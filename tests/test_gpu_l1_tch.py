@@ -56,3 +56,41 @@ def test_tch3_bit_exact(gpu_api, orc, pkg):
                 assert np.array_equal(g[0], f0) and np.array_equal(g[1], f1) and np.array_equal(g[2], s)
     a0, a1, sb, c0, c1 = gpu_api.tch3_decode(_soft(pkg.synth.tch3_encode(f0[:1], f1[:1], s[:1], 0)[0]), 0)
     assert np.array_equal(a0, f0[0]) and np.array_equal(a1, f1[0]) and np.array_equal(sb, s[0]) and c0 == 0 == c1
+
+
+def test_nt3_mix_from_samples_matches_oracle(gpu_api, orc, pkg):
+    """BASELINE configs[4] from samples (the bench's `--workload nt3`, small): 90 % NT3 speech + 10 % FACCH3 groups,
+    window 474, the carrier offset handed over as freq_shift like rx_tch3 does.  Demodulated soft bits within 1 LSB of
+    the oracle's, decoded frames / messages identical to the oracle's on the same soft bits, and what was sent comes
+    back wherever the channel allows (speech class-1 bits; FACCH3 groups whose CRC passes)."""
+    import workloads
+    wl = workloads.nt3_mix(pkg, 800, seed=51)
+    iq = wl["iq"].reshape(-1, wl["stride"])
+    sp, fa = wl["speech"], wl["facch"]
+    d = gpu_api.demod_batch("nt3_speech", wl["iq"], wl["offset"][sp], 474, sps=4, freq_shift=wl["freq_shift"][sp],
+                            want_ssyms=False)
+    assert not d["rv"].any()
+    for k in range(0, sp.size, 7):
+        r = orc.demod("nt3_speech", iq[sp[k], :474], 4, float(wl["freq_shift"][sp[k]]))
+        assert np.max(np.abs(r["ebits"].astype(int) - d["ebits"][k].astype(int))) <= 1
+        assert abs(r["toa"] - d["toa"][k]) < 0.02
+    f0, f1, st, c0, c1 = gpu_api.tch3_decode_batch(d["ebits"], m=0)
+    r0, r1, rs, rc0, rc1 = orc.tch3_decode(d["ebits"], 0)
+    assert np.array_equal(f0, r0) and np.array_equal(f1, r1) and np.array_equal(st, rs)
+    assert np.array_equal(c0, rc0) and np.array_equal(c1, rc1)
+    hi = wl["esn0"][sp] >= 10.0 if "esn0" in wl else np.ones(sp.size, bool)
+    ok = (f0[:, :6] == wl["frames"][:, 0, :6]).all(axis=1) & (f1[:, :6] == wl["frames"][:, 1, :6]).all(axis=1)
+    assert ok[hi].mean() > 0.9
+
+    df = gpu_api.demod_batch("nt3_facch", wl["iq"], wl["offset"][fa], 474, sps=4, freq_shift=wl["freq_shift"][fa],
+                             want_ssyms=False)
+    assert not df["rv"].any()
+    for k in range(0, fa.size, 3):
+        r = orc.demod("nt3_facch", iq[fa[k], :474], 4, float(wl["freq_shift"][fa[k]]))
+        assert r["sync_id"] == df["sync_id"][k]
+        assert np.max(np.abs(r["ebits"].astype(int) - df["ebits"][k].astype(int))) <= 1
+    l2, bs, crc, conv = gpu_api.facch3_decode_batch(df["ebits"].reshape(-1, 416))
+    rl2, rbs, rcrc, rconv = orc.facch3_decode(df["ebits"].reshape(-1, 416))
+    assert np.array_equal(crc, rcrc) and np.array_equal(conv, rconv) and np.array_equal(l2, rl2) and np.array_equal(bs, rbs)
+    good = crc == 0
+    assert good.any() and np.array_equal(l2[good], wl["l2"][good])

@@ -88,6 +88,53 @@ def tch3_bursts(pkg, n, seed, m=0, sigma=40.0):
     return dict(ebits=eb, frame0=f0, frame1=f1, status=s, m=m)
 
 
+def nt3_mix(pkg, n, seed, esn0_db=(6.0, 10.0, 20.0), sps=4, m=0, stride_align=16):
+    """BASELINE.md config 5 from samples: n NT3 bursts (n a multiple of 40), 90 % speech (two random 80-bit frames
+    each) and 10 % FACCH3 in groups of four consecutive bursts (sync sequence alternating per group), window 474
+    samples, impairments as config 3 with the timing jitter the 7-lag window of rx_tch3 allows (gmr1_rx.c:549-550: win = 1.5 sps; +-1 sample + fraction), CFO, phase, AWGN, gain.  An NT3 burst has one short training sequence, so the demodulator cannot estimate a frequency
+    error itself: as in rx_tch3 (gmr1_rx.c:509-512, -cd->freq_err from the BCCH tracking) the carrier offset is handed
+    to it, here as `freq_shift` = minus the offset the generator applied (rad / symbol).
+
+    Layout: iq[burst][480] complex64 (474 + padding to 16 samples).  Returns dict(iq flat, offset, kind (0 speech,
+    1 FACCH3), speech (indices), facch (indices, groups of 4), frames (n_s, 2, 10), status (n_s, 4), l2 (n_f / 4, 10),
+    bits_s (n_f / 4, 32), sync_id (n_f / 4), freq_shift (n,))."""
+    assert n % 40 == 0
+    synth = pkg.synth
+    rng = np.random.default_rng(seed)
+    kind = ((np.arange(n) % 40) >= 36).astype(np.uint8)
+    speech = np.nonzero(kind == 0)[0]
+    facch = np.nonzero(kind == 1)[0]
+    fmt_s, fmt_f = pkg.api.burst_format("nt3_speech"), pkg.api.burst_format("nt3_facch")
+    win = 6
+    in_len = 117 * sps + win
+    stride = -(-in_len // stride_align) * stride_align
+    offset = np.arange(n, dtype=np.uint64) * np.uint64(stride)
+    iq = np.zeros((n, stride), np.complex64)
+    esn0 = rng.choice(np.asarray(esn0_db, dtype=np.float64), size=n)
+    # speech
+    frames = rng.integers(0, 256, (speech.size, 2, 10), dtype=np.uint8)
+    status = rng.integers(0, 2, (speech.size, 4), dtype=np.uint8)
+    eb = synth.tch3_encode(frames[:, 0], frames[:, 1], status, m)
+    bb = synth.synth_windows(fmt_s, synth.map_symbols(fmt_s, eb), sps, win, rng, toa_jitter=1, frac=True, cfo_hz_std=50.0,
+                             esn0_db=esn0[speech], gain_db_std=6.0, stride=stride)
+    iq[speech] = bb.iq
+    freq_shift = np.zeros(n, np.float32)
+    freq_shift[speech] = -bb.cfo * sps
+    # FACCH3: one 10-byte message over four bursts
+    ng = facch.size // 4
+    l2 = rng.integers(0, 256, (ng, 10), dtype=np.uint8)
+    l2[:, 9] &= 0x0f                                          # 76 bits
+    bits_s = rng.integers(0, 2, (ng, 32), dtype=np.uint8)
+    ebf = synth.facch3_encode(l2, bits_s).reshape(ng * 4, 104)
+    sync_id = (np.arange(ng) & 1).astype(np.int32)
+    bb = synth.synth_windows(fmt_f, synth.map_symbols(fmt_f, ebf, np.repeat(sync_id, 4)), sps, win, rng, toa_jitter=1,
+                             frac=True, cfo_hz_std=50.0, esn0_db=esn0[facch], gain_db_std=6.0, stride=stride)
+    iq[facch] = bb.iq
+    freq_shift[facch] = -bb.cfo * sps
+    return dict(iq=iq.reshape(-1), offset=offset, kind=kind, speech=speech, facch=facch, frames=frames, status=status,
+                l2=l2, bits_s=bits_s, sync_id=sync_id, freq_shift=freq_shift, esn0=esn0, in_len=in_len, stride=stride, m=m)
+
+
 def bcch_carrier(pkg, seed, seconds=2.0, sps=4, **kw):
     """One BCCH carrier (one ARFCN): FCCH + SI1 BCCH + CCCH on the TDMA grid."""
     from importlib import import_module
