@@ -623,16 +623,74 @@ __device__ int sync_search(int type, int in_len, int sps_rt, float fs, const Lds
 			return lane_val(v, 32 * half) + lane_val(v, 32 * half + 16);
 		};
 
-		float early = (float)p - 1.0f, late = (float)p + 1.0f, incr = 0.5f;
-		while (incr > (1.0f / 1024.0f)) {
-			const float term = row_sum(interp_term(lane < 32 ? early : late));
-			const float ev = lane_val(term, 0) + lane_val(term, 16);
-			const float lv = lane_val(term, 32) + lane_val(term, 48);
-			const float ee = ev * ev, le = lv * lv;
-			if (ee > le)      { early -= incr; late -= incr; }
-			else if (ee < le) { early += incr; late += incr; }
-			else break;
-			incr *= 0.5f;
+		// Early / late bisection (incr = 1/2 ... 1/512), THREE levels per evaluation: each group of 8 lanes
+		// interpolates the correlation at one candidate position and two samples later (same fractional part,
+		// so the same 21 weights; lane sub holds taps k = 3 sub - 10 + {0,1,2}) -- group 0 at the current point,
+		// groups 1 / 2 where the search goes if the early / late side wins, groups 3..6 one level further down.
+		// The candidates are formed by the same float operations the level-by-level walk performs, so it takes
+		// the same decisions; the walk itself is scalar work on two ballots.
+		const int grp = lane >> 3, isub = lane & 7;
+		auto interp_pair = [&](float pos, float &se, float &sl) {
+			const float fl = floorf(pos);
+			const int ib = (int)fl;
+			const float f = pos - fl;
+			const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
+			int be = ib - 10, ee = ib + 11, bl = ib - 8, el = ib + 13;
+			if (be < 0) be = 0;
+			if (bl < 0) bl = 0;
+			if (ee >= w) ee = w - 1;
+			if (el >= w) el = w - 1;
+			float ae = 0.f, al = 0.f;
+#pragma unroll
+			for (int tt = 0; tt < 3; tt++) {
+				const int k = 3 * isub - 10 + tt;
+				const float sg = ((isub + tt) & 1) ? S : -S;
+				const float xx = kPif * ((float)k - f);
+				const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
+				const int ie = ib + k, il = ib + 2 + k;
+				const bool ve = k <= 10 && ie >= be && ie < ee;
+				const bool vl = k <= 10 && il >= bl && il < el;
+				const float ce = L.corr[ve ? ie : 0], cl = L.corr[vl ? il : 0];
+				ae += ve ? ce * wgt : 0.0f;
+				al += vl ? cl * wgt : 0.0f;
+			}
+			ae += row_xorf<1>(ae);
+			ae += row_xorf<2>(ae);
+			ae += row_xorf<4>(ae);
+			al += row_xorf<1>(al);
+			al += row_xorf<2>(al);
+			al += row_xorf<4>(al);
+			se = ae;
+			sl = al;
+		};
+		float early = (float)p - 1.0f, incr = 0.5f;
+#pragma unroll 1
+		for (int it = 0; it < 3; it++) {
+			const float half = incr * 0.5f, quarter = incr * 0.25f;
+			float pos = early;
+			if (grp == 1) {
+				pos = early - incr;
+			} else if (grp == 2) {
+				pos = early + incr;
+			} else if (grp >= 3 && grp <= 6) {
+				const float a1 = grp < 5 ? early - incr : early + incr;
+				pos = (grp & 1) ? a1 - half : a1 + half;           // 3: - -, 4: - +, 5: + -, 6: + +
+			}
+			float se, sl;
+			interp_pair(pos, se, sl);
+			const float ee = se * se, le = sl * sl;
+			const unsigned long long m_neg = __ballot(ee > le), m_pos = __ballot(ee < le);
+			auto dec = [&](int g) -> int { return ((m_neg >> (8 * g)) & 1ull) ? -1 : (((m_pos >> (8 * g)) & 1ull) ? 1 : 0); };
+			const int d0 = dec(0);
+			if (d0 == 0) break;
+			early = d0 < 0 ? early - incr : early + incr;
+			const int d1 = dec(d0 < 0 ? 1 : 2);
+			if (d1 == 0) break;
+			early = d1 < 0 ? early - half : early + half;
+			const int d2 = dec(3 + (d0 > 0 ? 2 : 0) + (d1 > 0 ? 1 : 0));
+			if (d2 == 0) break;
+			early = d2 < 0 ? early - quarter : early + quarter;
+			incr *= 0.125f;
 		}
 		const float s_toa = early + 1.0f;
 		float pk = half_total(interp_term(s_toa), 0);
