@@ -54,6 +54,8 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_tch9_encode_batch_dev", "gmr1_hip_tch9_encode_batch", "gmr1_tch9_encode",
     "gmr1_hip_rach_encode_batch_dev", "gmr1_hip_rach_encode_batch", "gmr1_rach_encode",
     "gmr1_hip_mod_batch_dev", "gmr1_hip_mod_batch", "gmr1_pi4cxpsk_mod", "gmr1_hip_encoder_plan",
+    "gmr1_scramble_sbit", "gmr1_scramble_ubit", "gmr1_interleave_intra", "gmr1_deinterleave_intra",
+    "gmr1_interleave_inter", "gmr1_deinterleave_inter",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -1144,3 +1146,61 @@ def pi4cxpsk_mod(burst_name: str, ebits, sync_id=0, max_len=None):
     f.restype = C.c_int
     rc = f(C.c_void_p(C.addressof(bt)), p_eb, C.c_int(sync_id), C.byref(v))
     return rc, data[:v.len].copy()
+
+
+# ---- stand-alone layer-1 primitives (reference scramb.h / interleave.h), each one blocking GPU call ----------
+def _prim(fname, x, dtype, *lead):
+    x, p = _np(x, dtype)
+    out = np.full(x.shape, 77, dtype)
+    f = getattr(load(), fname)
+    f.restype = None
+    f(*lead, out.ctypes.data_as(C.c_void_p), p, *([C.c_int(x.size)] if "scramble" in fname else []))
+    return out
+
+
+def scramble_sbit(x):
+    return _prim("gmr1_scramble_sbit", x, np.int8)
+
+
+def scramble_ubit(x):
+    return _prim("gmr1_scramble_ubit", x, np.uint8)
+
+
+def interleave_intra(x, N, inverse=False):
+    x, p = _np(x, np.uint8)
+    assert x.size == 8 * N
+    out = np.full(8 * N, 77, np.uint8)
+    f = getattr(load(), "gmr1_deinterleave_intra" if inverse else "gmr1_interleave_intra")
+    f.restype = None
+    f(out.ctypes.data_as(C.c_void_p), p, C.c_int(N))
+    return out
+
+
+class InterBurstInterleaver:
+    """gmr1_interleaver_init(il, 3, 648) + gmr1_interleave_inter / gmr1_deinterleave_inter on that object."""
+
+    def __init__(self):
+        self.il = Interleaver()
+        f = load().gmr1_interleaver_init
+        f.restype = C.c_int
+        _check(f(C.byref(self.il), C.c_int(3), C.c_int(648)), "gmr1_interleaver_init")
+
+    def _call(self, fname, x):
+        x, p = _np(x, np.uint8)
+        assert x.size == 648
+        out = np.full(648, 77, np.uint8)
+        f = getattr(load(), fname)
+        f.restype = None
+        f(C.byref(self.il), out.ctypes.data_as(C.c_void_p), p)
+        return out
+
+    def interleave(self, bits_ep):
+        return self._call("gmr1_interleave_inter", bits_ep)
+
+    def deinterleave(self, bits_epp):
+        return self._call("gmr1_deinterleave_inter", bits_epp)
+
+    def close(self):
+        if self.il.bits_cpp:
+            load().gmr1_interleaver_fini(C.byref(self.il))
+            self.il.bits_cpp = None

@@ -19,6 +19,7 @@
 #include "../../include/osmocom/gmr1/l1/facch9.h"
 #include "../../include/osmocom/gmr1/l1/interleave.h"
 #include "../../include/osmocom/gmr1/l1/rach.h"
+#include "../../include/osmocom/gmr1/l1/scramb.h"
 #include "../../include/osmocom/gmr1/l1/tch3.h"
 #include "../../include/osmocom/gmr1/l1/tch9.h"
 #include "../../include/osmocom/gmr1/l1/xch_dc12.h"
@@ -640,6 +641,53 @@ int builtin_flat(int burst_id, gmr1_hip_burst_flat *f)
 	return flatten(kBuiltin[burst_id], f, kBuiltinName[burst_id]);
 }
 
+// ---- stand-alone primitives -------------------------------------------------------------------------------------
+// one blocking H2D -> k_bitmap -> D2H; perm / mask are position tables the host writes down (no data passes through them)
+int bitmap_host(int n_in, int n_out, int soft, const void *in, const std::vector<int32_t> *perm,
+                const std::vector<uint8_t> *mask, void *out, const char *what)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n_out < 0 || n_in < 0 || (n_out > 0 && (!in || !out)))
+		return fail(-EINVAL, "%s: bad argument", what);
+	if (n_out == 0)
+		return 0;
+	DBuf d_in, d_out, d_perm, d_mask;
+	HIP_TRY(d_in.alloc((size_t)n_in));
+	HIP_TRY(d_out.alloc((size_t)n_out));
+	HIP_TRY(hipMemcpy(d_in.p, in, (size_t)n_in, hipMemcpyHostToDevice));
+	BitMapArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.n = n_out; a.soft = soft; a.in = d_in.as<uint8_t>(); a.out = d_out.as<uint8_t>();
+	if (perm) {
+		HIP_TRY(d_perm.alloc((size_t)n_out * 4));
+		HIP_TRY(hipMemcpy(d_perm.p, perm->data(), (size_t)n_out * 4, hipMemcpyHostToDevice));
+		a.perm = d_perm.as<int32_t>();
+	}
+	if (mask) {
+		HIP_TRY(d_mask.alloc((size_t)n_out));
+		HIP_TRY(hipMemcpy(d_mask.p, mask->data(), (size_t)n_out, hipMemcpyHostToDevice));
+		a.mask = d_mask.as<uint8_t>();
+	}
+	HIP_TRY(launch_bitmap(a, nullptr));
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n_out, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+std::vector<uint8_t> scramble_mask(int len)         // scramb.c:39-52: 15-bit LFSR, seed 0x4d4b
+{
+	std::vector<uint8_t> m((size_t)(len > 0 ? len : 0));
+	uint16_t r = 0x4d4b;
+	for (int i = 0; i < len; i++) {
+		const int b = ((r >> 14) ^ r) & 1;
+		r = (uint16_t)((r << 1) | b);
+		m[i] = (uint8_t)b;
+	}
+	return m;
+}
+
 }  // namespace
 
 extern "C" {
@@ -834,6 +882,82 @@ int gmr1_pi4cxpsk_mod(struct gmr1_pi4cxpsk_burst *burst_type, ubit_t *ebits, int
 	if (r) return fail(r, "gmr1_pi4cxpsk_mod: unsupported burst description");
 	burst_out->len = burst_type->len;
 	return mod_host(f, sync_id, 1, ebits, reinterpret_cast<float *>(burst_out->data));
+}
+
+// ---- the stand-alone layer-1 primitives (scramb.h:36-37, interleave.h:36-56); each is one blocking call to the GPU ----
+void gmr1_scramble_sbit(sbit_t *out, const sbit_t *in, int len)
+{
+	const std::vector<uint8_t> m = scramble_mask(len);
+	(void)bitmap_host(len, len, 1, in, nullptr, &m, out, "gmr1_scramble_sbit");
+}
+
+void gmr1_scramble_ubit(ubit_t *out, const ubit_t *in, int len)
+{
+	const std::vector<uint8_t> m = scramble_mask(len);
+	(void)bitmap_host(len, len, 0, in, nullptr, &m, out, "gmr1_scramble_ubit");
+}
+
+void gmr1_interleave_intra(void *out, const void *in, int N)
+{
+	if (N < 0) { (void)fail(-EINVAL, "gmr1_interleave_intra: N < 0"); return; }
+	std::vector<int32_t> perm((size_t)8 * N);
+	for (int kc = 0; kc < 8 * N; kc++)
+		perm[N * ((5 * kc) & 7) + (kc >> 3)] = kc;                 // interleave.c:48-61
+	(void)bitmap_host(8 * N, 8 * N, 0, in, &perm, nullptr, out, "gmr1_interleave_intra");
+}
+
+void gmr1_deinterleave_intra(void *out, const void *in, int N)
+{
+	if (N < 0) { (void)fail(-EINVAL, "gmr1_deinterleave_intra: N < 0"); return; }
+	std::vector<int32_t> perm((size_t)8 * N);
+	for (int kc = 0; kc < 8 * N; kc++)
+		perm[kc] = N * ((5 * kc) & 7) + (kc >> 3);                 // interleave.c:73-87
+	(void)bitmap_host(8 * N, 8 * N, 0, in, &perm, nullptr, out, "gmr1_deinterleave_intra");
+}
+
+// interleave.c:128-158.  The state is the reference's: N rows of K bits in il->bits_cpp (an object used with these two
+// calls must not also be handed to gmr1_tch9_encode / gmr1_tch9_decode, which keep their own history there).
+void gmr1_interleave_inter(struct gmr1_interleaver *il, void *bits_epp, void *bits_ep)
+{
+	if (!il || !il->bits_cpp || il->N != 3 || il->K != 648 || !bits_epp || !bits_ep) {
+		(void)fail(-EINVAL, "gmr1_interleave_inter: bad argument");
+		return;
+	}
+	const int N = il->N, K = il->K, cur = il->n % N;
+	// staging = [state with this burst in row cur]: the row copy is the upload itself
+	std::vector<uint8_t> stage(il->bits_cpp, il->bits_cpp + (size_t)N * K);
+	std::memcpy(stage.data() + (size_t)cur * K, bits_ep, (size_t)K);
+	std::vector<int32_t> perm((size_t)K);
+	for (int jk = 0; jk < K; jk++)
+		perm[jk] = ((cur - (jk % N) + N) % N) * K + jk;
+	if (bitmap_host(N * K, K, 0, stage.data(), &perm, nullptr, bits_epp, "gmr1_interleave_inter"))
+		return;
+	std::memcpy(il->bits_cpp + (size_t)cur * K, stage.data() + (size_t)cur * K, (size_t)K);
+	il->n++;
+}
+
+// interleave.c:163-190
+void gmr1_deinterleave_inter(struct gmr1_interleaver *il, void *bits_ep, void *bits_epp)
+{
+	if (!il || !il->bits_cpp || il->N != 3 || il->K != 648 || !bits_ep || !bits_epp) {
+		(void)fail(-EINVAL, "gmr1_deinterleave_inter: bad argument");
+		return;
+	}
+	const int N = il->N, K = il->K, cur = il->n % N;
+	// source = [state | received burst]; the new state takes bit jk of row (cur - jk mod N) from the burst
+	std::vector<uint8_t> src((size_t)(N + 1) * K);
+	std::memcpy(src.data(), il->bits_cpp, (size_t)N * K);
+	std::memcpy(src.data() + (size_t)N * K, bits_epp, (size_t)K);
+	std::vector<int32_t> perm((size_t)N * K);
+	for (int i = 0; i < N; i++)
+		for (int jk = 0; jk < K; jk++)
+			perm[(size_t)i * K + jk] = (i == (cur - (jk % N) + N) % N) ? N * K + jk : i * K + jk;
+	std::vector<uint8_t> state((size_t)N * K);
+	if (bitmap_host((N + 1) * K, N * K, 0, src.data(), &perm, nullptr, state.data(), "gmr1_deinterleave_inter"))
+		return;
+	std::memcpy(il->bits_cpp, state.data(), (size_t)N * K);
+	std::memcpy(bits_ep, state.data() + (size_t)((il->n + 1) % N) * K, (size_t)K);
+	il->n++;
 }
 
 }  // extern "C"

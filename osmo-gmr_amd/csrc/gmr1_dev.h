@@ -309,6 +309,18 @@ struct ModArgs {
 };
 hipError_t launch_mod(const ModArgs &a, hipStream_t stream);
 
+// the stand-alone layer-1 primitives (scrambler, intra- / inter-burst interleaver) as one gather kernel:
+// out[i] = in[perm ? perm[i] : i], then xor (ubits) or negate (sbits) where mask[i] is set
+struct BitMapArgs {
+	int n;
+	int soft;                          // 1: int8 soft bits (mask negates), 0: ubits / bytes (mask xors bit 0)
+	const uint8_t *in;
+	const int32_t *perm;               // optional
+	const uint8_t *mask;               // optional
+	uint8_t *out;
+};
+hipError_t launch_bitmap(const BitMapArgs &a, hipStream_t stream);
+
 hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream);
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
 hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);

@@ -158,4 +158,25 @@ hipError_t launch_mod(const ModArgs &a, hipStream_t stream)
 	return hipGetLastError();
 }
 
+// ---- stand-alone primitives: gmr1_scramble_{sbit,ubit} (scramb.c:62-93), gmr1_{de,}interleave_intra
+// (interleave.c:48-87), gmr1_{de,}interleave_inter (interleave.c:128-190): a gather plus an optional sign / bit flip
+__global__ __launch_bounds__(256) void k_bitmap(BitMapArgs a)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= a.n)
+		return;
+	uint8_t v = a.in[a.perm ? a.perm[i] : i];
+	if (a.mask && a.mask[i])
+		v = a.soft ? (uint8_t)(int8_t)(-(int)(int8_t)v) : (uint8_t)(v ^ 1u);
+	a.out[i] = v;
+}
+
+hipError_t launch_bitmap(const BitMapArgs &a, hipStream_t stream)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	hipLaunchKernelGGL(k_bitmap, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
 }  // namespace gmr1

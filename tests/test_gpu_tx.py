@@ -217,3 +217,50 @@ def test_encode_rejects_bad_arguments(gpu_api):
     l2 = np.zeros(10, np.uint8)
     assert L.gmr1_hip_facch3_encode_batch(C.c_int(1), l2.ctypes.data_as(C.c_void_p), None, None,
                                           e.ctypes.data_as(C.c_void_p)) == -22       # status bits are required
+
+
+def test_standalone_primitives_match_oracle(gpu_api, orc):
+    """gmr1_scramble_{sbit,ubit}, gmr1_{de,}interleave_intra, gmr1_{de,}interleave_inter as stand-alone calls (each one
+    trip to the GPU) against the oracle's restatement of the same reference functions."""
+    import ctypes as C
+    O = orc.lib()
+    rng = np.random.default_rng(77)
+
+    def ocall(fn, out, *args):
+        getattr(O, fn)(out.ctypes.data_as(C.c_void_p), *args)
+        return out
+
+    for n in (1, 96, 432, 1000):
+        sb = rng.integers(-128, 128, n, dtype=np.int8)
+        ub = rng.integers(0, 2, n, dtype=np.uint8)
+        assert np.array_equal(gpu_api.scramble_sbit(sb), ocall("orc_scramble_sbit", np.zeros(n, np.int8),
+                                                               sb.ctypes.data_as(C.c_void_p), C.c_int(n)))
+        assert np.array_equal(gpu_api.scramble_ubit(ub), ocall("orc_scramble_ubit", np.zeros(n, np.uint8),
+                                                               ub.ctypes.data_as(C.c_void_p), C.c_int(n)))
+        assert np.array_equal(gpu_api.scramble_ubit(gpu_api.scramble_ubit(ub)), ub)
+    for N in (12, 53, 81):
+        x = rng.integers(0, 256, 8 * N, dtype=np.uint8)
+        y = gpu_api.interleave_intra(x, N)
+        assert np.array_equal(y, ocall("orc_interleave_intra", np.zeros(8 * N, np.uint8), x.ctypes.data_as(C.c_void_p), C.c_int(N)))
+        assert np.array_equal(gpu_api.interleave_intra(y, N, inverse=True), x)
+        assert np.array_equal(gpu_api.interleave_intra(x, N, inverse=True),
+                              ocall("orc_deinterleave_intra", np.zeros(8 * N, np.uint8), x.ctypes.data_as(C.c_void_p), C.c_int(N)))
+    # inter-burst: a run of bursts through the interleaver, then through the de-interleaver: block n comes back at n + 2
+    oil, odl = orc.Interleaver(), orc.Interleaver()
+    O.orc_interleaver_init(C.byref(oil), C.c_int(3), C.c_int(648))
+    O.orc_interleaver_init(C.byref(odl), C.c_int(3), C.c_int(648))
+    gi, gd = gpu_api.InterBurstInterleaver(), gpu_api.InterBurstInterleaver()
+    blocks = rng.integers(0, 256, (7, 648), dtype=np.uint8)
+    for i in range(7):
+        ref = np.zeros(648, np.uint8)
+        O.orc_interleave_inter(C.byref(oil), ref.ctypes.data_as(C.c_void_p), blocks[i].ctypes.data_as(C.c_void_p))
+        got = gi.interleave(blocks[i])
+        assert np.array_equal(got, ref), i
+        ref2 = np.zeros(648, np.uint8)
+        O.orc_deinterleave_inter(C.byref(odl), ref2.ctypes.data_as(C.c_void_p), ref.ctypes.data_as(C.c_void_p))
+        got2 = gd.deinterleave(got)
+        assert np.array_equal(got2, ref2), i
+        if i >= 2:
+            assert np.array_equal(got2, blocks[i - 2])
+    gi.close()
+    gd.close()
