@@ -178,6 +178,30 @@ static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
 	a.offset = offset; a.freq_shift = freq_shift;
 	a.ebits = ebits; a.sync_id = sync_id; a.toa = toa; a.freq_err = freq_err; a.ssyms = ssyms; a.rv = rv;
 	a.energy = energy;
+	// Large batches of a simple format (one training sequence, QPSK, <= 3 sync chunks of <= 128 window samples,
+	// <= 18 sync symbols, <= 256 symbols; sps 4: NT3 speech, DC2, BCCH, DC6) take the four-bursts-per-wave kernel, where the
+	// serial phases of four bursts share their instructions (k_rx4g); everything else, and small batches, one burst per wave.
+	static int gen_off = -1;                    // profiling only: GMR1_HIP_RX_GEN=0 keeps every batch on k_rx
+	if (gen_off < 0) {
+		const char *e = getenv("GMR1_HIP_RX_GEN");
+		gen_off = (e && atoi(e) == 0) ? 1 : 0;
+	}
+	if (!gen_off && n > 4096 && sps == 4 && a.dbg_stop == 0 && ht.n_sync == 1 && ht.nbits == 2 && ht.n_chunks[0] >= 1 &&
+	    ht.n_chunks[0] <= 3 && ht.sync_tl[0] <= 18 && ht.len <= 256 && in_len <= 1024 && w <= 128 && ht.ebits <= 432) {
+		bool fits = true;
+		int stage = 0;
+		for (int c = 0; c < ht.n_chunks[0]; c++) {
+			const int wl = ht.sync[0][c].len * sps + w - 1;
+			fits &= wl <= 128;
+			stage += wl;
+		}
+		if (fits) {
+			// short formats with a single sync chunk (NT3 speech, DC2) have their own instantiation
+			const bool small = in_len <= 512 && ht.len <= 128 && ht.n_chunks[0] == 1 && ht.sync_tl[0] <= 16 && stage <= 64;
+			a.impl = small ? 3 : 2;
+			a.stage_samples = stage;
+		}
+	}
 	HIP_TRY(launch_rx(a, false, in_len, st));
 	return 0;
 }

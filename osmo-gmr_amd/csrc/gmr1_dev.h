@@ -49,7 +49,8 @@ struct RxArgs {
 	int ssyms_stride;
 	int dbg_stop;          // profiling aid: 0 = run everything, N = stop after phase N
 	int stage_samples;     // fused path: LDS samples for the sync-chunk windows (max over BCCH / DC6)
-	int impl;              // fused path: 0 = k_rx4 (row-batched serial phases), 1 = k_rx (one burst at a time)
+	int impl;              // fused path: 0 = k_rx4 (row-batched serial phases), 1 = k_rx (one burst at a time);
+	                       // demod only: 2 / 3 = k_rx4g (four bursts per wave; 3: its small-format variant), else k_rx
 	const float2 *iq;
 	const uint64_t *offset;
 	const uint8_t *kind;

@@ -1417,12 +1417,20 @@ struct RxIo {
 };
 
 // LAT: the caller cares about the latency of ONE burst (the receive loop), not about throughput
-template <int NPL, int SPS, bool LAT = false>
+// GEN: demodulation only, every burst of the one format a.fixed_type (one training sequence, QPSK, <= 3 sync chunks,
+// <= 18 sync symbols, <= 256 symbols: NT3 speech, DC2, BCCH, DC6) -- the batch form of gmr1_pi4cxpsk_demod for large n
+template <int NPL, int SPS, bool LAT = false, bool GEN = false>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
                                          unsigned char *__restrict__ lds_raw, int lane)
 {
 	const int row = lane >> 4, col = lane & 15;
 	const int sps = SPS ? SPS : a.sps;
+	// the small generic variant (NPL = 8; the host launches it for formats of <= 128 symbols with one sync chunk of
+	// <= 16 symbols whose window is <= 64 samples: NT3 speech, DC2) drops the unrolled work the long bursts need
+	constexpr bool SMALL = GEN && NPL == 8;
+	constexpr int NSYM = SMALL ? 2 : 4;               // 64-symbol pieces of a burst
+	constexpr int NCHK = SMALL ? 1 : 3;               // sync chunks
+	constexpr int NSH = SMALL ? 1 : 2;                // 16-symbol pieces of the sync sequence
 	size_t off[4];
 	lds4_layout(stage_samples, cw, off);
 	Lds4 L;
@@ -1438,8 +1446,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const bool row_live = g_row < n_end;
 
 	// per-row (lane-resident) burst parameters
-	const int kind_r = row_live ? (io.kind[g_row] ? 1 : 0) : 0;
-	const int type_r = kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
+	const int kind_r = (!GEN && row_live) ? (io.kind[g_row] ? 1 : 0) : 0;
+	const int type_r = GEN ? a.fixed_type : (kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 	const int in_len_r = a.in_len[kind_r];
 	const float fsh_r = (row_live && io.freq_shift) ? io.freq_shift[g_row] : 0.0f;
 	const DevBurst &bt_r = c_types[type_r];
@@ -1454,8 +1462,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int g = g0 + q;
 		if (g >= n_end)
 			break;
-		const int kind = __builtin_amdgcn_readfirstlane(io.kind[g] ? 1 : 0);
-		const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
+		const int kind = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g] ? 1 : 0);
+		const int type = GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
 		const DevBurst &bt = c_types[type];
 		const int nbits = bt.nbits;
@@ -1466,17 +1474,17 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const float2 *__restrict__ in = a.iq + io.offset[g];
 		const int tl = bt.sync_tl[0];
 		const int nch = bt.n_chunks[0];
-		constexpr int NFULL = (SPS == 4 && NPL == 16) ? 15 : -1;
+		constexpr int NFULL = (!GEN && SPS == 4 && NPL == 16) ? 15 : -1;
 		// everything that needs memory is asked for first -- the whole window (statistics) and, again,
 		// the ~300 samples under the sync chunks (they go to LDS; the second request hits the lines the
 		// first one is fetching) -- and what needs no data (the rotated reference) is computed while it
 		// travels
 		if (q == 0)
 			window_fetch<NPL, NFULL>(in, in_len, lane, wv);
-		constexpr int SIT = SPS == 4 ? 2 : 4;            // 64-sample pieces per chunk window
-		float2 sv[3][SIT];
+		constexpr int SIT = SMALL ? 1 : (SPS == 4 ? 2 : 4);   // 64-sample pieces per chunk window
+		float2 sv[NCHK][SIT];
 #pragma unroll
-		for (int c = 0; c < 3; c++) {
+		for (int c = 0; c < NCHK; c++) {
 			const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
 			const float2 *__restrict__ src = in + (c < nch ? bt.sync[0][c].pos * sps : 0);
 #pragma unroll
@@ -1509,7 +1517,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 		if (q + 1 < 4 && g + 1 < n_end) {
 			// the next burst's window travels during this burst's correlation
-			const int kind1 = __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
+			const int kind1 = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
 			window_fetch<NPL, NFULL>(a.iq + io.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
 		}
 		if (!LAT && io.energy) {
@@ -1522,7 +1530,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		{
 			int wb = 0;
 #pragma unroll
-			for (int c = 0; c < 3; c++) {
+			for (int c = 0; c < NCHK; c++) {
 				const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
 #pragma unroll
 				for (int h = 0; h < SIT; h++) {
@@ -1694,23 +1702,23 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 
 	// pass-2 operands of a burst (its 234 symbols at stride sps from sample d, re-read from
 	// L2 / Infinity Cache): fetched two bursts ahead of their use
-	struct Sym4 { float2 x[4]; int ok; };
+	struct Sym4 { float2 x[NSYM]; int ok; };
 	auto fetch = [&](int q, Sym4 &o) {
 		const int g = g0 + q;
 		o.ok = 0;
 #pragma unroll
-		for (int r = 0; r < 4; r++) o.x[r] = make_float2(0.f, 0.f);
+		for (int r = 0; r < NSYM; r++) o.x[r] = make_float2(0.f, 0.f);
 		if (q >= 4 || g >= n_end)
 			return;
 		const int src = 16 * q;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
-		const DevBurst &bt = c_types[kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH];
+		const DevBurst &bt = c_types[GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH)];
 		const int in_len = __builtin_amdgcn_readlane(in_len_r, src);
 		const int d = __builtin_amdgcn_readlane(d_r, src);
 		const float2 *__restrict__ in = a.iq + io.offset[g];
 		const int blen = bt.len;
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
+		for (int r = 0; r < NSYM; r++) {
 			const int i = lane + 64 * r;
 			const int j = i * sps + d;
 			if (i < blen && j >= 0 && j < in_len) {
@@ -1730,10 +1738,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	float ffe_r = 0.f, psi_r = 0.f;
 	{
 		// lane col holds sync symbols n = col and n = col + 16 (< tl <= 32)
-		float2 t0[2];
-		int chn[2], spos[2];
+		float2 t0[NSH];
+		int chn[NSH], spos[NSH];
 #pragma unroll
-		for (int h = 0; h < 2; h++) {
+		for (int h = 0; h < NSH; h++) {
 			const int n = col + 16 * h;
 			t0[h] = make_float2(0.f, 0.f);
 			chn[h] = -1;
@@ -1768,7 +1776,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 		// chunk sums (pi4cxpsk.c:381-389); the window scale 1/sigma is irrelevant to every angle
-		if (nch_r > 1) {
+		if constexpr (!SMALL) if (nch_r > 1) {
 			float sumr[4], sumi[4];
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
@@ -1793,7 +1801,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		// carrier phase of the frequency-corrected sync symbols (pi4cxpsk.c:415-433,574-575)
 		float tr = 0.f, ti = 0.f;
 #pragma unroll
-		for (int h = 0; h < 2; h++) {
+		for (int h = 0; h < NSH; h++) {
 			float2 tt = t0[h];
 			if (ffe_r != 0.0f) {
 				float s, c;
@@ -1828,7 +1836,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int src = 16 * q;
 		const bool found = __builtin_amdgcn_readlane((int)found_r, src) != 0;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
-		const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
+		const int type = GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 		const DevBurst &bt = c_types[type];
 		const int d = __builtin_amdgcn_readlane(d_r, src);
 		const float fs = lane_val(fs_r, src);
@@ -1852,9 +1860,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 		row_ok |= 1 << q;
 		// where the soft bits of symbol i go (position of the symbol's bits among the e-bits, -1: sync / guard)
-		int ordv[4];
+		int ordv[NSYM];
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
+		for (int r = 0; r < NSYM; r++) {
 			const int i = lane + 64 * r;
 			ordv[r] = i < blen ? bt.ord_of_sym[i] : -1;
 		}
@@ -1866,7 +1874,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		Bt -= rintf(Bt);
 		const float scale = (float)(1 << nbits);
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
+		for (int r = 0; r < NSYM; r++) {
 			const int i = lane + 64 * r;
 			if (i >= blen)
 				continue;
@@ -1911,7 +1919,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		cur = nxt;
 		nxt = nxt2;
 	}
-	if (a.dbg_stop && a.dbg_stop < 7)
+	if (GEN || (a.dbg_stop && a.dbg_stop < 7))
 		return;
 
 	// =========================== rows: layer 1 ===========================
@@ -1949,6 +1957,17 @@ __global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw,
 	const RxIo io = {a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
 	rx4_body<NPL, SPS>(a, io, stage_samples, cw, g0, min(a.n, g0 + bpw), lds_raw, (int)threadIdx.x);
+}
+
+// demodulation only, one burst format per launch, four bursts per wavefront (rx4_body<..., GEN>)
+template <int NPL, int SPS>
+__global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const int g0 = blockIdx.x * 4;
+	const RxIo io = {a.offset, nullptr, a.freq_shift, nullptr, nullptr, nullptr, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
+	                 a.ebits, a.ssyms};
+	rx4_body<NPL, SPS, false, true>(a, io, stage_samples, cw, g0, min(a.n, g0 + 4), lds_raw, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -2294,6 +2313,19 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 	// symbols per burst: fused path is BCCH/DC6 (234); generic path sizes for the longest format
 	// third kernel argument: lags the correlation accumulator must hold (fused path: 20*sps + 1)
 	const int max_len = decode ? (20 * a.sps + 1) : kMaxWindow;
+	if (!decode && (a.impl == 2 || a.impl == 3) && a.sps == 4 && max_in_len <= 1024) {
+		// large batch of one simple burst format (the host checked what rx4_body<GEN> assumes; impl 3: also what its
+		// small variant assumes): four bursts per wave
+		const int cw = (a.in_len[0] - a.ssyms_stride * 4 + 1 + 15) & ~15;       // lags (ssyms_stride = symbols per burst)
+		size_t off4[4];
+		const size_t lds4 = lds4_layout(a.stage_samples, cw, off4);
+		const int grid4 = (a.n + 3) / 4;
+		if (a.impl == 3)
+			hipLaunchKernelGGL((k_rx4g<8, 4>), dim3(grid4), dim3(64), lds4, stream, a, a.stage_samples, cw);
+		else
+			hipLaunchKernelGGL((k_rx4g<16, 4>), dim3(grid4), dim3(64), lds4, stream, a, a.stage_samples, cw);
+		return hipGetLastError();
+	}
 	if (max_in_len <= 1024) {
 		if (a.sps == 4)
 			return launch_rx_t<16, 4>(a, decode, max_in_len, max_len, stream);

@@ -94,3 +94,44 @@ def test_nt3_mix_from_samples_matches_oracle(gpu_api, orc, pkg):
     assert np.array_equal(crc, rcrc) and np.array_equal(conv, rconv) and np.array_equal(l2, rl2) and np.array_equal(bs, rbs)
     good = crc == 0
     assert good.any() and np.array_equal(l2[good], wl["l2"][good])
+
+
+def test_demod_large_batch_four_bursts_per_wave(gpu_api, orc, pkg):
+    """Batches above 4096 bursts of a simple format take k_rx4g (four bursts per wave); smaller ones k_rx (one per wave).
+    Both against the oracle, and against each other, on NT3 speech (one 6-symbol sync chunk, 7 lags) and DC6 (three
+    chunks, 41 lags)."""
+    import workloads
+    wl = workloads.nt3_mix(pkg, 8000, seed=52)
+    iq = wl["iq"].reshape(-1, wl["stride"])
+    sp = wl["speech"]
+    assert sp.size > 4096
+    big = gpu_api.demod_batch("nt3_speech", wl["iq"], wl["offset"][sp], 474, sps=4, freq_shift=wl["freq_shift"][sp])
+    small = gpu_api.demod_batch("nt3_speech", wl["iq"], wl["offset"][sp[:2000]], 474, sps=4, freq_shift=wl["freq_shift"][sp[:2000]])
+    assert not big["rv"].any() and not (big["sync_id"] != 0).any()
+    assert np.max(np.abs(big["ebits"][:2000].astype(int) - small["ebits"].astype(int))) <= 1
+    assert np.max(np.abs(big["toa"][:2000] - small["toa"])) < 0.02
+    assert np.max(np.abs(big["ssyms"][:2000] - small["ssyms"])) < 1e-4
+    for k in list(range(0, sp.size, 97)) + [sp.size - 1, sp.size - 2, sp.size - 3]:
+        r = orc.demod("nt3_speech", iq[sp[k], :474], 4, float(wl["freq_shift"][sp[k]]))
+        assert r["rv"] == 0
+        assert np.max(np.abs(r["ebits"].astype(int) - big["ebits"][k].astype(int))) <= 1, k
+        assert abs(r["toa"] - big["toa"][k]) < 0.02
+        assert np.max(np.abs(r["ssyms"] - big["ssyms"][k])) < 1e-4
+    # a batch that is not a multiple of four, and one window of silence in it (no sync found: rv = -1, zeros out)
+    m = 4099
+    iq2 = wl["iq"].copy().reshape(-1, wl["stride"])
+    iq2[sp[4098]] = 0
+    odd = gpu_api.demod_batch("nt3_speech", iq2, wl["offset"][sp[:m]], 474, sps=4, freq_shift=wl["freq_shift"][sp[:m]])
+    assert odd["rv"][4098] == -1 and not odd["ebits"][4098].any() and not odd["rv"][:4098].any()
+    assert np.array_equal(odd["ebits"][:4098], big["ebits"][:4098])
+
+    mix = workloads.bcch_ccch_mix(pkg, 7000, seed=53)
+    cc = np.nonzero(mix["kind"] == 1)[0]
+    assert cc.size > 4096
+    d = gpu_api.demod_batch("dc6", mix["iq"], mix["offset"][cc], 976, sps=4)
+    for k in range(0, cc.size, 211):
+        o = int(mix["offset"][cc[k]])
+        r = orc.demod("dc6", mix["iq"][o:o + 976], 4)
+        assert r["rv"] == d["rv"][k] == 0
+        assert np.max(np.abs(r["ebits"].astype(int) - d["ebits"][k].astype(int))) <= 1
+        assert abs(r["toa"] - d["toa"][k]) < 0.02 and abs(r["freq_err"] - d["freq_err"][k]) < 1e-5
