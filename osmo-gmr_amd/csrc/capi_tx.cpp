@@ -9,6 +9,7 @@
 
 #include "capi_common.h"
 
+#include <cmath>
 #include <mutex>
 #include <vector>
 
@@ -603,12 +604,20 @@ int mod_dev(hipStream_t st, const gmr1_hip_burst_flat &f, int sync_id, int n, co
 	if (r) return fail(r, "mod: unsupported burst description or sync_id %d", sync_id);
 	if (n == 0)
 		return 0;
-	DBuf d_p;
+	// osmo_cxvec_rotate: sample i times e^{j (rotation * i)}, phase and phasor in single precision
+	std::vector<float2> rot((size_t)f.len);
+	for (int i = 0; i < f.len; i++) {
+		const float ph = f.rotation * (float)i;
+		rot[i] = make_float2(cosf(ph), sinf(ph));
+	}
+	DBuf d_p, d_r;
 	HIP_TRY(d_p.alloc(plan.size() * 2));
+	HIP_TRY(d_r.alloc(rot.size() * 8));
 	HIP_TRY(hipMemcpyAsync(d_p.p, plan.data(), plan.size() * 2, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_r.p, rot.data(), rot.size() * 8, hipMemcpyHostToDevice, st));
 	ModArgs a;
 	a.n = n; a.len = f.len; a.nbits = f.nbits; a.n_ebits = f.ebits; a.rotation = f.rotation;
-	a.plan = d_p.as<int16_t>(); a.ebits = ebits; a.out = reinterpret_cast<float2 *>(out);
+	a.plan = d_p.as<int16_t>(); a.rot = d_r.as<float2>(); a.ebits = ebits; a.out = reinterpret_cast<float2 *>(out);
 	HIP_TRY(launch_mod(a, st));
 	HIP_TRY(hipStreamSynchronize(st));         // the plan buffer is released on return
 	return 0;

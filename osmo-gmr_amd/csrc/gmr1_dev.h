@@ -305,6 +305,7 @@ struct ModArgs {
 	int n, len, nbits, n_ebits;
 	float rotation;
 	const int16_t *plan;               // len entries: -1 guard, 0..3 sync symbol, 4 + k: data symbol from ebits[k ...]
+	const float2 *rot;                 // len entries: e^{j rotation i}, evaluated on the host as osmo_cxvec_rotate does
 	const uint8_t *ebits;              // n x n_ebits ubits
 	float2 *out;                       // n x len symbols
 };

@@ -116,45 +116,47 @@ hipError_t launch_encode(const EncArgs &a, hipStream_t stream)
 	return hipGetLastError();
 }
 
-// ---- modulator: pi4cxpsk.c:741-799.  One thread per symbol; the constellation points are +-1 / +-j exactly,
+// ---- modulator: pi4cxpsk.c:741-799.  One wave per burst; the constellation points are +-1 / +-j exactly,
 // so the "multiply by the rotation" of osmo_cxvec_rotate is written out as the complex product the CPU computes
-// (the zeros of the operand matter only for the sign of a zero).
+// (the zeros of the operand matter only for the sign of a zero); the rotation phasors e^{j rotation i} are a
+// per-format table the host evaluates with the CPU's own cosf / sinf, so the symbols match a CPU build bit for bit.
 __global__ __launch_bounds__(256) void k_mod(ModArgs a)
 {
-	const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-	if (idx >= (long long)a.n * a.len)
+	const long long u = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one burst per wave, symbols strided over its lanes
+	if (u >= a.n)
 		return;
-	const long long u = idx / a.len;
-	const int i = (int)(idx - u * a.len);
-	const int p = a.plan[i];
-	float2 v = make_float2(0.f, 0.f);
-	if (p >= 0) {
-		int sym = p;
-		if (p >= 4) {
-			const uint8_t *eb = a.ebits + u * a.n_ebits + (p - 4);
-			if (a.nbits == 2) {
-				const int bv = ((eb[0] & 1) << 1) | (eb[1] & 1);
-				sym = bv ^ (bv >> 1);             // 00 01 10 11 -> 0 1 3 2 (the '.bits' table of pi4cxpsk.c:87-107)
-			} else {
-				sym = eb[0] & 1;
+	const uint8_t *ebu = a.ebits + u * a.n_ebits;
+	float2 *outu = a.out + u * a.len;
+	for (int i = threadIdx.x & 63; i < a.len; i += 64) {
+		const int p = a.plan[i];
+		float2 v = make_float2(0.f, 0.f);
+		if (p >= 0) {
+			int sym = p;
+			if (p >= 4) {
+				const uint8_t *eb = ebu + (p - 4);
+				if (a.nbits == 2) {
+					const int bv = ((eb[0] & 1) << 1) | (eb[1] & 1);
+					sym = bv ^ (bv >> 1);             // 00 01 10 11 -> 0 1 3 2 (the '.bits' table of pi4cxpsk.c:87-107)
+				} else {
+					sym = eb[0] & 1;
+				}
 			}
+			if (a.nbits == 2)
+				v = make_float2((sym & 1) ? 0.f : ((sym & 2) ? -1.f : 1.f), (sym & 1) ? ((sym & 2) ? -1.f : 1.f) : 0.f);
+			else
+				v = make_float2((sym & 1) ? -1.f : 1.f, 0.f);
 		}
-		if (a.nbits == 2)
-			v = make_float2((sym & 1) ? 0.f : ((sym & 2) ? -1.f : 1.f), (sym & 1) ? ((sym & 2) ? -1.f : 1.f) : 0.f);
-		else
-			v = make_float2((sym & 1) ? -1.f : 1.f, 0.f);
+		const float2 r = a.rot[i];
+		const float c = r.x, s = r.y;
+		outu[i] = make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
 	}
-	const float ph = a.rotation * (float)i;
-	const float c = cosf(ph), s = sinf(ph);
-	a.out[u * a.len + i] = make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
 }
 
 hipError_t launch_mod(const ModArgs &a, hipStream_t stream)
 {
 	if (a.n <= 0 || a.len <= 0)
 		return hipSuccess;
-	const long long total = (long long)a.n * a.len;
-	hipLaunchKernelGGL(k_mod, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(k_mod, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 
