@@ -135,3 +135,42 @@ def test_demod_large_batch_four_bursts_per_wave(gpu_api, orc, pkg):
         assert r["rv"] == d["rv"][k] == 0
         assert np.max(np.abs(r["ebits"].astype(int) - d["ebits"][k].astype(int))) <= 1
         assert abs(r["toa"] - d["toa"][k]) < 0.02 and abs(r["freq_err"] - d["freq_err"][k]) < 1e-5
+
+
+@pytest.mark.parametrize("name,win", [("dc2", 12), ("bcch", 80), ("nt3_speech", 6)])
+def test_demod_four_per_wave_equals_one_per_wave(gpu_api, orc, pkg, name, win):
+    """The same bursts through both demodulation kernels: 4097+ bursts in one call (k_rx4g) and in calls of <= 4096
+    (k_rx): decisions identical (rv, sync_id), toa within a bisection step, soft symbols within 1e-4, soft bits within
+    1 LSB except the rare midpoint symbols; and a sample against the oracle."""
+    synth = pkg.synth
+    rng = np.random.default_rng(len(name) + win)
+    fmt = pkg.api.burst_format(name)
+    info = gpu_api.burst_info(name)
+    n = 4500
+    eb = rng.integers(0, 2, (n, info.ebits), dtype=np.uint8)
+    jit = max(0, min(8, win // 2 - 2))
+    bb = synth.synth_windows(fmt, synth.map_symbols(fmt, eb), 4, win, rng, toa_jitter=jit, frac=True, cfo_hz_std=20.0,
+                             esn0_db=rng.choice([8.0, 15.0], n), gain_db_std=3.0)
+    in_len = bb.in_len
+    off = np.arange(n, dtype=np.uint64) * np.uint64(bb.stride)
+    big = gpu_api.demod_batch(name, bb.iq, off, in_len, sps=4)
+    parts = [gpu_api.demod_batch(name, bb.iq, off[i:i + 2250], in_len, sps=4) for i in (0, 2250)]
+    small = {k: np.concatenate([p[k] for p in parts]) for k in ("rv", "sync_id", "toa", "freq_err", "ebits", "ssyms")}
+    assert np.array_equal(big["rv"], small["rv"]) and np.array_equal(big["sync_id"], small["sync_id"])
+    assert not big["rv"].any()
+    assert np.max(np.abs(big["toa"] - small["toa"])) <= 16 / 1024 + 1e-6
+    same_pick = np.rint(big["toa"]) == np.rint(small["toa"])
+    assert same_pick.mean() > 0.995
+    assert np.max(np.abs(big["freq_err"] - small["freq_err"])) < 1e-5
+    d = np.abs(big["ebits"].astype(int) - small["ebits"].astype(int))[same_pick]
+    assert (d.max(axis=1) <= 1).mean() > 0.999
+    ds = np.abs(big["ssyms"] - small["ssyms"])[same_pick]
+    ds = np.minimum(ds, 2 ** info.nbits - ds)                    # soft symbols live on a circle of 2^nbits
+    assert ds.max() < 1e-4
+    # the payload bits come back (hard decisions) at these signal levels
+    assert ((big["ebits"] < 0) == eb.astype(bool)).mean() > 0.97
+    for k in range(0, n, 450):
+        r = orc.demod(name, bb.iq[k, :in_len], 4)
+        assert r["rv"] == 0 and abs(r["toa"] - big["toa"][k]) <= 16 / 1024 + 1e-6
+        if np.rint(r["toa"]) == np.rint(big["toa"][k]):
+            assert np.max(np.abs(r["ebits"].astype(int) - big["ebits"][k].astype(int))) <= 1
