@@ -8,7 +8,11 @@ symbol and impaired (timing, CFO, phase, gain, AWGN).  Also the FCCH
 dual-chirp streams of config 2.
 
 Nothing here touches ``oracle/``: tests cross-check these encoders against the
-oracle's, and bench.py uses this module to fill HBM with its workload.
+oracle's, and bench.py uses this module to fill HBM with its workload.  It is
+test-data generation, not a product path: the product's own encoders and
+modulator are the GPU ones (csrc/tx_kernels.hip, ``api.*_encode_batch``,
+``api.mod_batch``); these numpy ones are a third, independent implementation
+that both the oracle and the GPU path are checked against.
 
 Pulse: the reference demodulator samples symbols directly (no matched filter,
 pi4cxpsk.c:286-297) because the channelizer in utils/gmr1_rx_sdr.py:523-529
