@@ -1361,7 +1361,7 @@ struct Lds4 {
 	uint32_t *ubits;
 };
 
-__host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t *off)
+__host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t *off, bool gen = false)
 {
 	// pass 1 keeps only the sync-chunk windows of the burst in LDS (everything else it needs is in
 	// registers; pass 2 re-reads from L2).  Decode-time data overlays all of it:
@@ -1376,6 +1376,12 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
 	off[1] = stage_bytes;
 	off[2] = stage_bytes + corr_bytes;
 	off[3] = dec_bytes;            // soft-bit rows
+	if (gen) {
+		// demodulation only (k_rx4g): no layer-1 data; the soft-bit rows overlay the pass-1 data, which is dead by then
+		off[3] = 0;
+		const size_t p1 = stage_bytes + corr_bytes + 18 * 8;
+		return align16(p1 > 4 * 432 ? p1 : (size_t)(4 * 432));
+	}
 	size_t total = stage_bytes + corr_bytes + 18 * 8;
 	if (total < dec_bytes + 4 * 432)
 		total = dec_bytes + 4 * 432;
@@ -1432,7 +1438,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	constexpr int NCHK = SMALL ? 1 : 3;               // sync chunks
 	constexpr int NSH = SMALL ? 1 : 2;                // 16-symbol pieces of the sync sequence
 	size_t off[4];
-	lds4_layout(stage_samples, cw, off);
+	lds4_layout(stage_samples, cw, off, GEN);
 	Lds4 L;
 	L.x = reinterpret_cast<float2 *>(lds_raw + off[0]);
 	L.corr = reinterpret_cast<float *>(lds_raw + off[1]);
@@ -1825,6 +1831,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 
 	// =========================== pass 2: soft symbols / soft bits ===========================
+	if (GEN)
+		WSYNC();        // the soft-bit rows overlay the correlation the rows above were reading
 	int row_ok = 0, row_chain = 0;
 	Sym4 cur = first, nxt = second;
 	for (int q = 0; q < 4; q++) {
@@ -2318,7 +2326,7 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 		// small variant assumes): four bursts per wave
 		const int cw = (a.in_len[0] - a.ssyms_stride * 4 + 1 + 15) & ~15;       // lags (ssyms_stride = symbols per burst)
 		size_t off4[4];
-		const size_t lds4 = lds4_layout(a.stage_samples, cw, off4);
+		const size_t lds4 = lds4_layout(a.stage_samples, cw, off4, true);
 		const int grid4 = (a.n + 3) / 4;
 		if (a.impl == 3)
 			hipLaunchKernelGGL((k_rx4g<8, 4>), dim3(grid4), dim3(64), lds4, stream, a, a.stage_samples, cw);
