@@ -1955,35 +1955,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 }
 
-// Blocks [0, n_quads) take bpw bursts each from the first n_main bursts; the blocks after them take ONE burst each of
-// the rest: a short tail of short-lived waves that fills the SIMDs while the last four-burst waves drain (the launch is
-// only a few wave lifetimes long, so how it ends matters).
 template <int NPL, int SPS>
-__device__ __forceinline__ void rx4_entry(const RxArgs &a, int stage_samples, int cw, int bpw, int n_main, int n_quads)
+__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
 	// which shortens the critical path of a wave to a quarter
-	const int b = (int)blockIdx.x;
-	const int g0 = b < n_quads ? b * bpw : n_main + (b - n_quads);
-	const int n_end = b < n_quads ? min(n_main, g0 + bpw) : g0 + 1;
+	const int g0 = blockIdx.x * bpw;
 	const RxIo io = {a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
-	rx4_body<NPL, SPS>(a, io, stage_samples, cw, g0, n_end, lds_raw, (int)threadIdx.x);
-}
-
-template <int NPL, int SPS>
-__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw, int n_main, int n_quads)
-{
-	rx4_entry<NPL, SPS>(a, stage_samples, cw, bpw, n_main, n_quads);
-}
-
-// the benchmark's instantiation (1016 / 976-sample windows at sps 4) held to 80 VGPRs: six waves per SIMD instead of
-// five for six spilled registers in cold code (the other instantiations would spill hundreds)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void k_rx4_16_4(RxArgs a, int stage_samples, int cw,
-                                                                                          int bpw, int n_main, int n_quads)
-{
-	rx4_entry<16, 4>(a, stage_samples, cw, bpw, n_main, n_quads);
+	rx4_body<NPL, SPS>(a, io, stage_samples, cw, g0, min(a.n, g0 + bpw), lds_raw, (int)threadIdx.x);
 }
 
 // demodulation only, one burst format per launch, four bursts per wavefront (rx4_body<..., GEN>)
@@ -2297,8 +2278,6 @@ __global__ __launch_bounds__(64) void k_l1(L1Args a)
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-constexpr int kRx4Tail = 0;           // bursts at the end of a large fused batch that run one per wave (sweep: 0 is best)
-
 template <int NPL, int SPS>
 static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int max_len, hipStream_t stream)
 {
@@ -2324,28 +2303,8 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 				bpw_force = e ? atoi(e) : 0;
 			}
 			const int bpw = bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4);
-			// large batches end in a tail of one-burst waves (see rx4_entry); GMR1_HIP_RX_TAIL overrides its length
-			static int tail_force = -2;
-			if (tail_force == -2) {
-				const char *e = getenv("GMR1_HIP_RX_TAIL");
-				tail_force = e ? atoi(e) : -1;
-			}
-			int tail = bpw == 4 ? (tail_force >= 0 ? tail_force : kRx4Tail) : 0;
-			if (tail > a.n / 8)
-				tail = 0;
-			const int n_main = a.n - tail;
-			const int n_quads = (n_main + bpw - 1) / bpw;
-			const int grid4 = n_quads + tail;
-			static int occ6 = -1;               // profiling only: GMR1_HIP_RX_OCC6=0 runs the 88-VGPR build of the same body
-			if (occ6 < 0) {
-				const char *e = getenv("GMR1_HIP_RX_OCC6");
-				occ6 = (e && atoi(e) == 0) ? 0 : 1;
-			}
-			if (NPL == 16 && SPS == 4 && occ6)
-				hipLaunchKernelGGL(k_rx4_16_4, dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw, n_main, n_quads);
-			else
-				hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw, n_main,
-				                   n_quads);
+			const int grid4 = (a.n + bpw - 1) / bpw;
+			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
 		}
 	} else {
 		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
