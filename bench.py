@@ -620,7 +620,7 @@ def main():
         # the same port on all host cores (the reference itself is single-threaded: one process per capture): threads over
         # contiguous burst ranges, each calling the C oracle (ctypes releases the GIL for the call)
         from concurrent.futures import ThreadPoolExecutor
-        cores = max(1, min(os.cpu_count() or 1, 64))
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))       # a one-GPU box's CPU share is 16 cores
         reps = 12                                    # every thread walks its slice `reps` times: a few seconds in total
         bounds = np.linspace(0, m, cores + 1).astype(int)
 
