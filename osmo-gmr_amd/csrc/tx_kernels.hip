@@ -89,8 +89,7 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode(EncArgs a)
 	WAVE_SYNC();
 
 	uint8_t *dst = a.ebits + u * P.n_out;
-	for (int e = lane; e < P.n_out; e += 64) {
-		const uint32_t ds = P.out[e];
+	auto burst_bit = [&](uint32_t ds) -> uint32_t {
 		const uint32_t t = ds & 1023u, kind = (ds >> 13) & 3u, ci = (ds >> 16) & 1023u, d = (ds >> 26) & 3u;
 		uint32_t bit = 0;
 		if (kind == 0) {
@@ -103,7 +102,19 @@ __global__ __launch_bounds__(64 * kEncWaves) void k_encode(EncArgs a)
 		bit ^= (ds >> 15) & 1u;
 		if (ci && a.ciph)
 			bit ^= a.ciph[u * P.n_ciph + (ci - 1)] & 1u;
-		dst[e] = (uint8_t)bit;
+		return bit;
+	};
+	if ((P.n_out & 3) == 0 && (reinterpret_cast<uintptr_t>(a.ebits) & 3u) == 0) {
+		// four burst bits per lane, one dword store (every unit starts on a dword when n_out is a multiple of four)
+		const uint4 *dsc = reinterpret_cast<const uint4 *>(P.out);
+		uint32_t *dst4 = reinterpret_cast<uint32_t *>(dst);
+		for (int e4 = lane; e4 < (P.n_out >> 2); e4 += 64) {
+			const uint4 d4 = dsc[e4];
+			dst4[e4] = burst_bit(d4.x) | (burst_bit(d4.y) << 8) | (burst_bit(d4.z) << 16) | (burst_bit(d4.w) << 24);
+		}
+	} else {
+		for (int e = lane; e < P.n_out; e += 64)
+			dst[e] = (uint8_t)burst_bit(P.out[e]);
 	}
 }
 
