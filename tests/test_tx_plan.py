@@ -141,3 +141,36 @@ def test_plan_rach():
     assert (P["n_in0"], P["n_in1"]) == (18, 1)
     ref = np.stack([oracle_lib.rach_encode(rach[i], int(sb[i])) for i in range(40)])
     assert np.array_equal(eval_plan(P, rach, in1=sb), ref)
+
+
+def test_plan_call_rejects_bad_arguments():
+    import ctypes as C
+    L = pkg.api.load()
+    size = L.gmr1_hip_encoder_plan(C.c_int(0), None, C.c_int(0))
+    assert size > 0
+    assert L.gmr1_hip_encoder_plan(C.c_int(-1), None, C.c_int(0)) == -22
+    assert L.gmr1_hip_encoder_plan(C.c_int(len(pkg.api.ENC_CHAINS)), None, C.c_int(0)) == -22
+    buf = np.zeros(size, np.uint8)
+    assert L.gmr1_hip_encoder_plan(C.c_int(0), buf.ctypes.data_as(C.c_void_p), C.c_int(size - 1)) == -22
+    assert L.gmr1_hip_encoder_plan(C.c_int(0), buf.ctypes.data_as(C.c_void_p), C.c_int(size)) == size
+
+
+def test_plans_are_linear_maps():
+    """Every chain is GF(2)-linear in (payload, status bits, keystream) up to its scrambler constant: the map of the xor of
+    two inputs is the xor of the maps, xor the map of the all-zero input.  (What lets one kernel evaluate all of them.)"""
+    rng = np.random.default_rng(5)
+    for chain in pkg.api.ENC_CHAINS:
+        P = pkg.api.encoder_plan(chain)
+        n = 6
+        def draw():
+            in0 = rng.integers(0, 256, (n, P["n_in0"]), dtype=np.uint8)
+            in1 = rng.integers(0, 256, (n, P["n_in1"]), dtype=np.uint8) if P["n_in1"] else None
+            a0 = rng.integers(0, 2, (n, P["n_aux0"]), dtype=np.uint8) if P["n_aux0"] else None
+            a1 = rng.integers(0, 2, (n, P["n_aux1"]), dtype=np.uint8) if P["n_aux1"] else None
+            c = rng.integers(0, 2, (n, P["n_ciph"]), dtype=np.uint8) if P["n_ciph"] else None
+            return [in0, in1, a0, a1, c]
+        x, y = draw(), draw()
+        z = [None if a is None else a ^ b for a, b in zip(x, y)]
+        zero = [None if a is None else np.zeros_like(a) for a in x]
+        f = lambda v: eval_plan(P, v[0], v[1], v[2], v[3], v[4], seq_len=3)
+        assert np.array_equal(f(z), f(x) ^ f(y) ^ f(zero)), chain
