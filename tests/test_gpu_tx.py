@@ -263,3 +263,29 @@ def test_standalone_primitives_match_oracle(gpu_api, orc):
             assert np.array_equal(got2, blocks[i - 2])
     gi.close()
     gd.close()
+
+
+def test_encoders_linear_at_full_size(gpu_api):
+    """Size-independent property at the benchmark's batch size: every channel coder is GF(2)-affine, so over 100 000
+    random payload pairs encode(x ^ y) = encode(x) ^ encode(y) ^ encode(0) bit for bit (BCCH, xCH / DC12, RACH incl. the
+    SB mask, TCH9 with its inter-burst interleaver in runs of 50)."""
+    n = 100_000
+    rng = np.random.default_rng(41)
+    x = rng.integers(0, 256, (n, 24), dtype=np.uint8)
+    y = rng.integers(0, 256, (n, 24), dtype=np.uint8)
+    z0 = np.zeros((1, 24), np.uint8)
+    for enc in (gpu_api.bcch_encode_batch, gpu_api.xch_dc12_encode_batch):
+        assert np.array_equal(enc(x ^ y), enc(x) ^ enc(y) ^ enc(z0))
+    rx, ry = x[:, :18], y[:, :18]
+    mx, my = x[:, 18], y[:, 19]
+    e0 = gpu_api.rach_encode_batch(np.zeros((1, 18), np.uint8), np.zeros(1, np.uint8))
+    assert np.array_equal(gpu_api.rach_encode_batch(rx ^ ry, mx ^ my),
+                          gpu_api.rach_encode_batch(rx, mx) ^ gpu_api.rach_encode_batch(ry, my) ^ e0)
+    m = 20_000
+    px = rng.integers(0, 256, (m, 60), dtype=np.uint8)
+    py = rng.integers(0, 256, (m, 60), dtype=np.uint8)
+    sa = rng.integers(0, 2, (m, 10), dtype=np.uint8)
+    st = rng.integers(0, 2, (m, 4), dtype=np.uint8)
+    zs, zt = np.zeros((m, 10), np.uint8), np.zeros((m, 4), np.uint8)
+    f = lambda p, a, b: gpu_api.tch9_encode_batch(p, 2, 50, a, b)
+    assert np.array_equal(f(px ^ py, sa, st), f(px, sa, st) ^ f(py, zs, zt) ^ f(np.zeros((m, 60), np.uint8), zs, zt))
