@@ -52,6 +52,12 @@ def parse():
     ap.add_argument("--arfcns", type=int, default=64, help="rx workload: BCCH carriers per GPU")
     ap.add_argument("--seconds", type=float, default=60.0, help="rx workload: capture length")
     ap.add_argument("--streams", type=int, default=1024, help="fcch workload: 1-s streams per GPU")
+    ap.add_argument("--shard-arfcns", type=int, default=64, help="N > 1: carriers of the sharded config-4 run (extra keys)")
+    ap.add_argument("--shard-seconds", type=float, default=60.0, help="N > 1: capture length of the sharded config-4 run")
+    ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the sharded config-4 run")
+    ap.add_argument("--shard-timeout", type=float, default=240.0,
+                    help="N > 1: if the sharded config-4 run has not finished after this many seconds, the headline line is "
+                         "printed without it (with the reason) instead of hanging the job")
     return ap.parse_args()
 
 
@@ -470,8 +476,139 @@ def run_nt3_workload(args):
     print(json.dumps(out))
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv=None, script=None, extra_env=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher: the parent starts N fresh interpreters (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, the same command line) and waits for them.  The
+    parent never imports torch and never makes a HIP call (a process that has touched the GPU must not fork / exec
+    others on this pool); children inherit stdout, rank 0 prints the one JSON line.  Returns the worst exit code."""
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    script = script or os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(free_port()), "GMR1_BENCH_SPAWNED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=e))
+    t_end = None if timeout is None else time.time() + timeout
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    # a rank that died leaves the others waiting in a collective: end exactly those children
+                    for q in pending:
+                        q.terminate()
+            if t_end is not None and time.time() > t_end:
+                rc = rc or 124
+                for q in pending:
+                    q.terminate()
+                t_end = None
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def sharded_rx_extra(args, pkg, dev, backend, rank, world):
+    """The north star's config-4 exchange, measured next to the headline (N > 1 only; keys outside `value`):
+    rank 0 holds the channelised capture (--shard-arfcns carriers x --shard-seconds, device-resident), carrier a goes
+    to rank a mod N point to point (RCCL send / recv over xGMI under backend nccl), every rank runs the receive loop
+    (gmr1_hip_rx_run_dev) on its carriers, the 40-byte frame records come back to rank 0 (SURVEY.md 8e;
+    independence per gmr1_rx.c:732-741).  Returns the dict for the JSON line on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    import workloads
+    sh, api = pkg.shard, pkg.api
+    A, sps, seconds = args.shard_arfcns, 4, args.shard_seconds
+    ns = int(seconds * 23400 * sps)
+    distinct = min(A, 8)
+    host, slices = None, None
+    cdev = dev if backend == "nccl" else None            # gloo moves host tensors
+    if rank == 0:
+        host = [workloads.bcch_carrier(pkg, 700 + a, seconds=seconds, sps=sps, stn=(5 * a) % 24, delay=a % 8,
+                                       cfo_hz=40.0 * (a - 3), esn0_db=10.0 + a)[0] for a in range(distinct)]
+        base = [torch.from_numpy(h) for h in host]
+        if cdev is not None:
+            base = [b.to(cdev) for b in base]
+        slices = [base[a % distinct] for a in range(A)]
+    t = {}
+    out = None
+    for it in range(2):                                  # pass 0 warms the communicator and the kernels
+        dist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mine = sh.scatter_iq(slices, A, ns, src=0, device=cdev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        rec, key = sh.rx_run_on_slices(api, mine, ns, sps=sps, device=dev, with_key=True,
+                                           max_records=max(len(mine), 1) * 4096)
+        dist.barrier()
+        t2 = time.perf_counter()
+        out = sh.gather_records(rec, dst=0, device=cdev, order_key=key)
+        dist.barrier()
+        t3 = time.perf_counter()
+        t = {"scatter_ms": (t1 - t0) * 1e3, "rx_loop_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3}
+    tt = torch.tensor([t["scatter_ms"], t["rx_loop_ms"], t["gather_ms"]], dtype=torch.float64,
+                      device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank != 0:
+        return None
+    res = {"workload": f"configs[3] sharded: {A} carriers x {seconds:g} s @ 93.6 ksps ({distinct} distinct, tiled) held by "
+                       f"rank 0, carrier a -> rank a mod {world}, p2p scatter, gmr1_rx loop per rank, 40-byte records gathered",
+           "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+           "scatter_ms": float(tt[0]), "rx_loop_ms": float(tt[1]), "gather_ms": float(tt[2]),
+           "scatter_bytes": int(sum(1 for a in range(A) if a % world != 0) * ns * 8),
+           "frames": int(out.size), "carriers_with_frames": int(np.unique(out["arfcn"]).size)}
+    res["scatter_GBps"] = res["scatter_bytes"] / max(res["scatter_ms"], 1e-9) / 1e6
+    res["samples_per_s"] = A * ns / ((res["scatter_ms"] + res["rx_loop_ms"] + res["gather_ms"]) * 1e-3)
+    if not args.no_cpu:
+        import oracle_lib                                  # checker only: carrier 0's frames against the CPU loop
+        oracle_lib.lib()
+        _, orec, _ = oracle_lib.rx_run(host[0], sps=sps, arfcn=0)
+        mine0 = out[out["arfcn"] == 0]
+        key = lambda r: [(int(x["chain"]), int(x["type"]), int(x["fn"]), int(x["tn"]), bytes(x["l2"])) for x in r]
+        res["frames_identical_to_oracle"] = bool(key(mine0) == key(orec))
+        res["oracle_frames_carrier0"] = int(len(orec))
+        # every tile of carrier 0 (a, a + distinct, ...) was decoded on a different rank: they must agree with it
+        same = all(key(out[out["arfcn"] == a]) == key(mine0) for a in range(0, A, distinct))
+        res["tiles_of_carrier0_identical_across_ranks"] = bool(same)
+    return res
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no launcher: start the N ranks ourselves, before anything in this process touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}: refusing to report a line for the "
+                         "wrong number of GPUs (start it as `python bench.py --gpus N`, or with a launcher whose world "
+                         "size equals N)")
     if args.workload == "nt3":
         return run_nt3_workload(args)
     if args.workload == "rx":
@@ -486,16 +623,17 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    world = int(env_world or "1")
     # GMR1_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
-    # (ranks then share devices and the barrier / max-reduction run over gloo); the driver never sets it
+    # (ranks then share devices and the exchanges run over gloo on host tensors); the driver never sets it
     backend = os.environ.get("GMR1_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    n_dev = torch.cuda.device_count()                      # does not initialise the GPU
+    if n_dev == 0:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: --gpus {world} but this node shows {n_dev} GPU(s); RCCL needs one device per rank "
+                         "(GMR1_BENCH_BACKEND=gloo rehearses the rank logic on fewer devices)")
+    dev_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -572,10 +710,38 @@ def main():
     payload_ok = bool(np.array_equal(h_l2[good], wl["l2"][good]))
     decoded_frac = float(good.mean())
 
-    if rank != 0:
+    # ---- N > 1: the north star's exchange (scatter of IQ slices, receive loop, gather of frames) ----
+    # Extra keys only, after the timed region.  A watchdog prints the headline line without them if the exchange
+    # does not come back (a collective that hangs must not cost the measurement that is already taken).
+    sharded = None
+    line = {}
+    if world > 1 and not args.no_shard:
+        import threading
+
+        def give_up():
+            if rank == 0 and line:
+                line["sharded_rx"] = {"error": f"not finished after {args.shard_timeout:g} s"}
+                print(json.dumps(line), flush=True)
+            os._exit(0 if line or rank != 0 else 1)
+        dog = threading.Timer(args.shard_timeout, give_up)
+        dog.daemon = True
+    else:
+        dog = None
+
+    def finish():
         if world > 1:
             import torch.distributed as dist
             dist.destroy_process_group()
+
+    if rank != 0:
+        if dog is not None:
+            dog.start()
+            try:
+                sharded_rx_extra(args, pkg, dev, backend, rank, world)
+            except Exception as e:                      # rank 0 reports; this rank has nothing to print
+                print(f"rank {rank}: sharded config-4 run failed: {e!r}", file=sys.stderr)
+            dog.cancel()
+        finish()
         return
 
     n_bcch = int((wl["kind"] == 0).sum())
@@ -650,10 +816,16 @@ def main():
                                          "sample": f"{reps} passes over the same {m} bursts split over {cores} threads, {ta:.1f} s"}
         out["checks"]["gpu_vs_oracle_crc_identical"] = same_crc
         out["checks"]["gpu_vs_oracle_payloads_identical"] = same_l2
+    if dog is not None:
+        line.update(out)
+        dog.start()
+        try:
+            out["sharded_rx"] = sharded_rx_extra(args, pkg, dev, backend, rank, world)
+        except Exception as e:
+            out["sharded_rx"] = {"error": repr(e)}
+        dog.cancel()
     print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

@@ -77,34 +77,74 @@ def scatter_iq(slices, n_arfcn: int, n_samples: int, src: int = 0, device=None):
     return out
 
 
-def gather_records(records: np.ndarray, dst: int = 0, device=None):
+def gather_records(records: np.ndarray, dst: int = 0, device=None, order_key=None):
     """Gather variable-length record arrays (RECORD_DTYPE) on rank `dst`.
 
-    Counts travel by all_gather (world x 8 bytes), payloads as padded fixed-size blocks.
-    Returns the concatenation ordered by (arfcn, fn, tn, chain) on `dst`, None elsewhere."""
+    Counts travel by all_gather (world x 8 bytes), payloads as padded fixed-size blocks (40-byte records plus an
+    8-byte ordering key each).  The result on `dst` has the order a single gmr1_hip_rx_run over ALL carriers
+    produces: carrier, then chain, then the order the chain emitted its frames in (frame numbers jump when a chain
+    decodes its first SI1, gmr1_rx.c:194-233, so sorting by fn would be wrong).  `order_key[i]` =
+    (global carrier index << 32) | position of record i in this rank's output; when it is not given the
+    records' `arfcn` field is taken as the global carrier index (true when carriers are named 0..A-1).
+    None on ranks other than `dst`."""
     import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
     records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+    if order_key is None:
+        order_key = (records["arfcn"].astype(np.uint64) << np.uint64(32)) | np.arange(records.size, dtype=np.uint64)
+    order_key = np.ascontiguousarray(order_key, dtype=np.uint64)
+    assert order_key.size == records.size
     cnt = torch.tensor([records.size], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(counts, cnt)
     counts = [int(c.item()) for c in counts]
     cap = max(max(counts), 1)
-    buf = np.zeros(cap, dtype=RECORD_DTYPE)
-    buf[:records.size] = records
-    payload = torch.from_numpy(buf.view(np.uint8).reshape(cap, RECORD_DTYPE.itemsize).copy())
+    row = RECORD_DTYPE.itemsize + 8
+    buf = np.zeros((cap, row), dtype=np.uint8)
+    buf[:records.size, :RECORD_DTYPE.itemsize] = records.view(np.uint8).reshape(records.size, RECORD_DTYPE.itemsize)
+    buf[:records.size, RECORD_DTYPE.itemsize:] = order_key.view(np.uint8).reshape(records.size, 8)
+    payload = torch.from_numpy(buf)
     if device is not None:
         payload = payload.to(device)
     blocks = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(blocks, payload)      # < 0.5 MB in total for an ARFCN-minute: latency bound
     if rank != dst:
         return None
-    parts = [blocks[r].cpu().numpy().reshape(-1).view(RECORD_DTYPE)[:counts[r]] for r in range(world)]
-    allr = np.concatenate(parts) if parts else np.zeros(0, RECORD_DTYPE)
-    order = np.lexsort((allr["chain"], allr["tn"], allr["fn"], allr["arfcn"]))
-    return allr[order]
+    rows = np.concatenate([blocks[r].cpu().numpy()[:counts[r]] for r in range(world)])
+    allr = np.ascontiguousarray(rows[:, :RECORD_DTYPE.itemsize]).reshape(-1).view(RECORD_DTYPE)
+    keys = np.ascontiguousarray(rows[:, RECORD_DTYPE.itemsize:]).reshape(-1).view(np.uint64)
+    return allr[np.argsort(keys, kind="stable")]
+
+
+def rx_run_on_slices(api, mine, n_samples: int, sps: int = 4, device=None, max_records: int = 1 << 16, arfcn_ids=None,
+                     with_key: bool = False):
+    """The receive loop (gmr1_hip_rx_run_dev, reference src/gmr1_rx.c:605-895) over the carriers this rank owns:
+    `mine` = {global carrier index: complex64 tensor of n_samples}.  Returns the records (and, with `with_key`, the
+    ordering key gather_records wants)."""
+    import torch
+
+    ids = sorted(mine)
+    if not ids:
+        rec = np.zeros(0, RECORD_DTYPE)
+        return (rec, np.zeros(0, np.uint64)) if with_key else rec
+    parts = [torch.view_as_real(mine[a]).reshape(-1) for a in ids]
+    if device is not None:
+        parts = [p.to(device) for p in parts]
+    iq = torch.cat(parts).contiguous()
+    offset = np.arange(len(ids), dtype=np.uint64) * np.uint64(n_samples)
+    length = np.full(len(ids), n_samples, np.uint64)
+    stream = torch.cuda.current_stream(iq.device).cuda_stream
+    # the loop labels records with what it is given: the global carrier index, renamed afterwards if asked
+    names = np.asarray(ids, np.uint16)
+    rec, status, chains, found = api.rx_run_dev(stream, iq.data_ptr(), offset, length, sps=sps,
+                                                arfcn=names, max_records=max_records)
+    rec = np.array(rec, dtype=RECORD_DTYPE)
+    key = (rec["arfcn"].astype(np.uint64) << np.uint64(32)) | np.arange(rec.size, dtype=np.uint64)
+    if arfcn_ids is not None:
+        rec["arfcn"] = np.asarray(arfcn_ids, np.uint16)[rec["arfcn"]]
+    return (rec, key) if with_key else rec
 
 
 def rx_capture_sharded(api, slices, n_arfcn: int, n_samples: int, sps: int = 4, src: int = 0, device=None,
@@ -112,22 +152,12 @@ def rx_capture_sharded(api, slices, n_arfcn: int, n_samples: int, sps: int = 4, 
     """BASELINE.md config 4 end to end on the ranks of one node: rank `src` holds the channelised
     capture (`slices[a]`, complex64 tensors of n_samples), every rank receives the ARFCNs it owns,
     runs the receive loop on them (gmr1_hip_rx_run_dev, reference src/gmr1_rx.c:605-895) and the
-    decoded-frame records come back to `src`.  No collective touches the data path."""
-    import torch
-
+    decoded-frame records come back to `src`, in the order one gmr1_hip_rx_run over all carriers gives.
+    No collective touches the data path."""
     mine = scatter_iq(slices, n_arfcn, n_samples, src=src, device=device)
-    ids = sorted(mine)
-    if ids:
-        iq = torch.cat([torch.view_as_real(mine[a]).reshape(-1) for a in ids]).contiguous()
-        offset = np.arange(len(ids), dtype=np.uint64) * np.uint64(n_samples)
-        length = np.full(len(ids), n_samples, np.uint64)
-        stream = torch.cuda.current_stream(iq.device).cuda_stream
-        names = np.asarray(ids if arfcn_ids is None else [arfcn_ids[a] for a in ids], np.uint16)
-        rec, status, chains, found = api.rx_run_dev(stream, iq.data_ptr(), offset, length, sps=sps,
-                                                    arfcn=names, max_records=max_records)
-    else:
-        rec = np.zeros(0, RECORD_DTYPE)
-    return gather_records(rec, dst=src, device=device)
+    rec, key = rx_run_on_slices(api, mine, n_samples, sps=sps, device=device, max_records=max_records,
+                                arfcn_ids=arfcn_ids, with_key=True)
+    return gather_records(rec, dst=src, device=device, order_key=key)
 
 
 def rx_wideband_sharded(api, wide, n_in: int, samp_rate: float, channels, sps: int = 4, src: int = 0,

@@ -90,13 +90,15 @@ def test_scatter_gather_world2(pkg):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    # every ARFCN's records arrived once, ordered by (arfcn, fn)
+    # every ARFCN's records arrived once, ordered by carrier and, inside a carrier, in the order the owning rank
+    # emitted them (the stand-in emits descending frame numbers: a sort by fn would have reversed them) -- the order
+    # one gmr1_hip_rx_run over all carriers produces
     exp_n = sum((a % 3) + 1 for a in range(n_arfcn))
     assert out.size == exp_n
     assert list(out["arfcn"]) == sorted(out["arfcn"])
     for a in range(n_arfcn):
         m = out[out["arfcn"] == a]
         assert m.size == (a % 3) + 1
-        assert list(m["fn"]) == sorted(m["fn"])
+        assert list(m["fn"]) == list(range((a % 3) + 1))[::-1]
         assert (m["l2"][:, 0] == a).all()
         assert (m["conv"] == (int(np.abs(_slice(a, n_samples)).sum()) & 0x7fffffff)).all()
