@@ -123,6 +123,11 @@ int  orc_xch_dc12_decode(uint8_t *l2, const orc_sbit_t *bits_e, int *conv_rv);
 void orc_rach_encode(orc_ubit_t *bits_e, const uint8_t *rach, uint8_t sb_mask);
 int  orc_rach_decode(uint8_t *rach, const orc_sbit_t *bits_e, uint8_t sb_mask, int *conv_rv, int *crc_rv);
 
+/* ---- the specialised convolutional code (trellis + punctured positions) each chain uses, for the table tests */
+const struct orc_conv_code *orc_l1_code(int which);    /* 0 BCCH / CCCH, 1 FACCH3, 2 TCH3 speech */
+const struct orc_conv_code *orc_nt9_code(int which);   /* 0 FACCH9, 1 TCH9 2k4, 2 TCH9 4k8, 3 TCH9 9k6 */
+const struct orc_conv_code *orc_xch_code(int which);   /* 0 xCH over DC12, 1 RACH */
+
 /* ---- batch drivers used by tests and by bench.py's cpu_baseline leg only */
 
 /* kind: 0 = BCCH (orc_burst BCCH + bcch_decode), 1 = CCCH (DC6 + ccch_decode) */

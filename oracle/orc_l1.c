@@ -76,6 +76,13 @@ static void codes_init(void)
 	codes_ready = 1;
 }
 
+/* for the tests: the specialised code a chain decodes with (0 = BCCH / CCCH, 1 = FACCH3, 2 = TCH3 speech) */
+const struct orc_conv_code *orc_l1_code(int which)
+{
+	codes_init();
+	return which == 0 ? &code_bcch : which == 1 ? &code_facch3 : which == 2 ? &code_tch3 : NULL;
+}
+
 /* ---- BCCH: reference src/l1/bcch.c:60-103 ------------------------------- */
 void orc_bcch_encode(orc_ubit_t *bits_e, const uint8_t *l2)
 {

@@ -75,6 +75,13 @@ static void codes_init(void)
 	ready = 1;
 }
 
+/* for the tests: 0 = FACCH9, 1 + mode = TCH9 */
+const struct orc_conv_code *orc_nt9_code(int which)
+{
+	codes_init();
+	return which == 0 ? &code_facch9 : (which >= 1 && which <= 3) ? &code_tch9[which - 1] : NULL;
+}
+
 int orc_tch9_punct(int mode, int *idx)      /* for the tests: the punctured positions of a mode */
 {
 	codes_init();

@@ -46,6 +46,13 @@ static void codes_init(void)
 	ready = 1;
 }
 
+/* for the tests: 0 = xCH over DC12, 1 = RACH */
+const struct orc_conv_code *orc_xch_code(int which)
+{
+	codes_init();
+	return which == 0 ? &code_xch : which == 1 ? &code_rach : NULL;
+}
+
 /* osmo_pbit2ubit_ext / osmo_ubit2pbit_ext in lsb mode with bit offsets on the packed side */
 static void p2u_lsb(orc_ubit_t *out, const uint8_t *in, int in_ofs, int n)
 {
