@@ -45,6 +45,7 @@ namespace gmr1 {
 	} while (0)
 
 static constexpr float kPif = 3.14159265358979323846f;
+typedef float v2f __attribute__((ext_vector_type(2)));   // (re, im) in a register pair: v_pk_add / v_pk_mul / v_pk_fma_f32
 static constexpr int kSteps12 = 212;              // 208 data + 4 flush steps (BCCH/CCCH)
 static constexpr int kEbRow = 448;                // LDS bytes per soft-bit row (>= 432, /16)
 static constexpr int kEbitsLds = 704;             // single-burst soft-bit buffer (>= 662)
@@ -54,11 +55,6 @@ static constexpr int kEbitsLds = 704;             // single-burst soft-bit buffe
 // ---------------------------------------------------------------------------
 __constant__ DevBurst c_types[kNumTypes];
 
-hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream)
-{
-	return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_types), host, sizeof(DevBurst) * (size_t)count,
-	                              sizeof(DevBurst) * (size_t)first, hipMemcpyHostToDevice, stream);
-}
 
 // Per trellis step of the BCCH / CCCH chain: where the two soft bits of the step
 // sit in the burst's e-bit order and whether the scrambler flips them
@@ -149,6 +145,42 @@ static constexpr SynRows make_syn_rows()
 	return r;
 }
 __constant__ __attribute__((aligned(16))) SynRows c_syn_rows = make_syn_rows();
+
+// Soft bits of a pi/4-CQPSK symbol by table (pi4cxpsk.c:452-507): the two soft bits are a function of the symbol's
+// phase quantised to 1/128 symbol (dq = round(|sv - round(sv)| * 128)) -- piecewise constant with every boundary on a
+// multiple of 1/256 symbol.  Cell k of the table covers phases [k, k + 1) / 1024 turns (1 turn = 4 symbols) and holds
+// what the arithmetic gives at the cell's midpoint (no ties there): nearest symbol sp (Gray bits p0 p1), its neighbour
+// on the side of the phase, distance dq; the bit that differs between the two gets 127 - dq, the other 127 - dq/2.
+// Entry = soft bit 0 | soft bit 1 << 8.  The arithmetic form and the table differ only for phases that are exactly a
+// cell boundary in binary floating point.
+struct SbLut { uint16_t v[1024]; };
+static constexpr SbLut make_sb_lut()
+{
+	SbLut t{};
+	for (int k = 0; k < 1024; k++) {
+		int q = 2 * k + 1;                    // cell midpoint in 1/512 symbol; a turn is 2048
+		if (q > 1024)
+			q -= 2048;                        // (-2, 2] symbols
+		const int n = (q + 256 + 2048) / 512 - 4;   // nearest symbol, floor((q + 256) / 512)
+		const int dlq = 512 * n - q;          // round(sv) - sv, odd: never zero
+		const int adl = dlq < 0 ? -dlq : dlq;
+		const int dq = (adl + 2) / 4;         // round(|dl| * 128): adl / 4 = m + 1/4 or m + 3/4
+		const unsigned sp = (unsigned)n & 3u;
+		const unsigned neg = dlq < 0 ? 1u : 0u;
+		const bool f0 = ((sp ^ neg ^ 1u) & 1u) != 0;
+		const int m_near = 127 - dq, m_far = 127 - (dq >> 1);
+		int v0 = f0 ? m_near : m_far;
+		int v1 = f0 ? m_far : m_near;
+		if (sp >> 1)
+			v0 = -v0;
+		if ((sp ^ (sp >> 1)) & 1u)
+			v1 = -v1;
+		t.v[k] = (uint16_t)(((unsigned)v0 & 0xffu) | (((unsigned)v1 & 0xffu) << 8));
+	}
+	return t;
+}
+__device__ __attribute__((aligned(16))) const SbLut g_sb_lut = make_sb_lut();
+constexpr int kSbLutBytes = 2048;
 
 // ---------------------------------------------------------------------------
 // cross-lane helpers (DPP: no LDS traffic)
@@ -425,27 +457,28 @@ template <int NPL, int NFULL = -1>
 __device__ __forceinline__ void window_stats(const float2 (&v)[NPL], int in_len, int lane,
                                              float &avr_o, float &avi_o, float &inv_o)
 {
-	float sr = 0.f, si = 0.f;
+	// (re, im) pairs through the packed FP32 pipe: one v_pk_add_f32 per sample for the sums, one v_pk_add_f32 and
+	// one v_pk_fma_f32 for the variance (re and im are summed in separate chains, as they are in the mean)
+	v2f s2 = {0.f, 0.f};
 	const int nfull = NFULL >= 0 ? NFULL : (in_len >> 6);
 	const bool tail = (lane + 64 * nfull) < in_len;
 #pragma unroll
-	for (int k = 0; k < NPL; k++) {
-		sr += v[k].x;
-		si += v[k].y;
-	}
-	sr = wave_sum(sr);
-	si = wave_sum(si);
+	for (int k = 0; k < NPL; k++)
+		s2 += (v2f){v[k].x, v[k].y};
+	const float sr = wave_sum(s2.x);
+	const float si = wave_sum(s2.y);
 	const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
 	const float avr = sr / (float)in_len, avi = si / (float)in_len;     // true division, see load_normalise
-	float acc = 0.f;
+	const v2f av = {avr, avi};
+	v2f acc2 = {0.f, 0.f};
 #pragma unroll
 	for (int k = 0; k < NPL; k++) {
 		if (k < nfull || (k == nfull && tail)) {
-			const float dx = v[k].x - avr, dy = v[k].y - avi;
-			acc = fmaf(dx, dx, fmaf(dy, dy, acc));
+			const v2f d = (v2f){v[k].x, v[k].y} - av;
+			acc2 = __builtin_elementwise_fma(d, d, acc2);
 		}
 	}
-	float stddev = __builtin_amdgcn_sqrtf(wave_sum(acc) * inv_n);
+	float stddev = __builtin_amdgcn_sqrtf(wave_sum(acc2.x + acc2.y) * inv_n);
 	if (stddev == 0.0f)
 		stddev = 1.0f;
 	avr_o = avr;
@@ -1351,6 +1384,51 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 // L2 / Infinity Cache; it buys back ~650 VALU instructions per burst.
 // Single-sequence burst formats only (BCCH, DC6), which is all the fused path handles.
 // ---------------------------------------------------------------------------
+// rotated reference value of sync symbol n of a format's first training sequence: conj(ref_n) e^{j fs (n' sps)},
+// n' = position of the symbol inside its chunk (pi4cxpsk.c:125-171 + the derotation of :539 folded in)
+__device__ __forceinline__ float2 sync_coef0(const DevBurst &bt, int n, int sps, float fs)
+{
+	const int nch = bt.n_chunks[0];
+	int ch = 0, base = 0, cum = 0;
+	for (int c = 0; c < nch - 1; c++) {
+		cum += bt.sync[0][c].len;
+		if (n >= cum) { base = cum; ch = c + 1; }
+	}
+	const int nn = n - base;
+	float s, c;
+	sincos_fast(fs * (float)(nn * sps), s, c);
+	return conj_ref_mul(bt.nbits, bt.sync[0][ch].syms[nn], make_float2(c, s));
+}
+
+// the same for freq_shift = 0, every burst format, sps 1..16: [sps][type][n < 32]
+constexpr int kCoef0MaxSps = 16;
+__device__ float2 g_coef0[kCoef0MaxSps + 1][kNumTypes][32];
+
+__global__ __launch_bounds__(64) void k_coef0(int first, int count)
+{
+	const int type = first + (int)blockIdx.x, sps = (int)blockIdx.y + 1, n = (int)threadIdx.x;
+	if (type >= first + count || n >= 32)
+		return;
+	const DevBurst &bt = c_types[type];
+	float2 v = make_float2(0.f, 0.f);
+	if (bt.n_sync > 0 && n < bt.sync_tl[0]) {
+		const float fs = (0.0f - bt.rotation) / (float)sps;               // pi4cxpsk.c:539 with freq_shift = 0
+		v = sync_coef0(bt, n, sps, fs);
+	}
+	g_coef0[sps][type][n] = v;
+}
+
+hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream)
+{
+	hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_types), host, sizeof(DevBurst) * (size_t)count,
+	                                      sizeof(DevBurst) * (size_t)first, hipMemcpyHostToDevice, stream);
+	if (e != hipSuccess)
+		return e;
+	// the zero-shift sync references of the uploaded formats (same stream: ordered before any burst kernel)
+	hipLaunchKernelGGL(k_coef0, dim3((unsigned)count, kCoef0MaxSps), dim3(64), 0, stream, first, count);
+	return hipGetLastError();
+}
+
 struct Lds4 {
 	float2 *x;        // normalised sync-chunk windows of the burst being correlated [stage_samples]
 	float *corr;      // 4 x cw correlation magnitudes
@@ -1366,7 +1444,8 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
 	// pass 1 keeps only the sync-chunk windows of the burst in LDS (everything else it needs is in
 	// registers; pass 2 re-reads from L2).  Decode-time data overlays all of it:
 	//   [stage | corr 4 x cw | coef]   during pass 1 and the timing rows
-	//   [bm | ubits | 4 soft-bit rows / window decisions]   from pass 2 on
+	//   [bm | ubits | 4 soft-bit rows / window decisions]   from pass 2 on; during pass 2 itself the soft-bit
+	//   table (2 KB, g_sb_lut) sits where the branch metrics will go
 	// (the 13 x 64 halfwords of window decisions overlay the soft-bit rows, which are dead once the
 	// branch metrics exist)
 	const size_t dec_bytes = 4 * kSteps12 * 4 + 4 * 8 * 4;
@@ -1380,7 +1459,8 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
 		// demodulation only (k_rx4g): no layer-1 data; the soft-bit rows overlay the pass-1 data, which is dead by then
 		off[3] = 0;
 		const size_t p1 = stage_bytes + corr_bytes + 18 * 8;
-		return align16(p1 > 4 * 432 ? p1 : (size_t)(4 * 432));
+		const size_t p2 = 4 * 432 + kSbLutBytes;      // pass 2: soft-bit rows, then the soft-bit table
+		return align16(p1 > p2 ? p1 : p2);
 	}
 	size_t total = stage_bytes + corr_bytes + 18 * 8;
 	if (total < dec_bytes + 4 * 432)
@@ -1472,7 +1552,6 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int type = GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
 		const DevBurst &bt = c_types[type];
-		const int nbits = bt.nbits;
 		const int w = in_len - bt.len * sps + 1;
 		const float fsh = io.freq_shift ? io.freq_shift[g] : 0.0f;
 		const float fs = (fsh - bt.rotation) / (float)sps;
@@ -1499,18 +1578,15 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
 			}
 		}
-		// rotated reference of the (single) sync sequence
+		// rotated reference of the (single) sync sequence: without a caller-supplied frequency shift it only depends on
+		// the burst format and sps -- a table built once with this same arithmetic (g_coef0)
 		WSYNC();
-		for (int n = lane; n < tl; n += 64) {
-			int ch = 0, base = 0, cum = 0;
-			for (int c = 0; c < nch - 1; c++) {
-				cum += bt.sync[0][c].len;
-				if (n >= cum) { base = cum; ch = c + 1; }
-			}
-			const int nn = n - base;
-			float s, c;
-			sincos_fast(fs * (float)(nn * sps), s, c);
-			L.coef[n] = conj_ref_mul(nbits, bt.sync[0][ch].syms[nn], make_float2(c, s));
+		if (io.freq_shift == nullptr) {
+			if (lane < tl)
+				L.coef[lane] = g_coef0[sps][type][lane];
+		} else {
+			for (int n = lane; n < tl; n += 64)
+				L.coef[n] = sync_coef0(bt, n, sps, fs);
 		}
 		float avr, avi, inv;
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
@@ -1541,8 +1617,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 #pragma unroll
 				for (int h = 0; h < SIT; h++) {
 					const int sidx = lane + 64 * h;
-					if (sidx < wl)
-						L.x[wb + sidx] = make_float2((sv[c][h].x - avr) * inv, (sv[c][h].y - avi) * inv);
+					if (sidx < wl) {
+						const v2f nv = ((v2f){sv[c][h].x, sv[c][h].y} - (v2f){avr, avi}) * (v2f){inv, inv};
+						L.x[wb + sidx] = make_float2(nv.x, nv.y);
+					}
 				}
 				wb += wl;
 			}
@@ -1556,13 +1634,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const int len = bt.sync[0][ch].len;
 				const float2 *xp = L.x + wb + j;          // staged window of this chunk
 				const float2 *cp = L.coef + base;
-				float ar = 0.f, ai = 0.f;
+				// (ar, ai) += c x as two packed FMAs: (-c.im x.im, c.im x.re) first, then c.re (x.re, x.im) -- the order the
+				// scalar chains ar = fma(c.re, x.re, fma(-c.im, x.im, ar)), ai = fma(c.re, x.im, fma(c.im, x.re, ai)) had
+				v2f acc = {0.f, 0.f};
 				for (int n = 0; n < len; n++) {
 					const float2 x = xp[n * sps];
 					const float2 cf = cp[n];
-					ar = fmaf(cf.x, x.x, fmaf(-cf.y, x.y, ar));
-					ai = fmaf(cf.x, x.y, fmaf(cf.y, x.x, ai));
+					acc = __builtin_elementwise_fma((v2f){-cf.y, cf.y}, (v2f){x.y, x.x}, acc);
+					acc = __builtin_elementwise_fma((v2f){cf.x, cf.x}, (v2f){x.x, x.y}, acc);
 				}
+				const float ar = acc.x, ai = acc.y;
 				base += len;
 				wb += len * sps + w - 1;
 				cj += sqrtf(fmaf(ar, ar, ai * ai));
@@ -1714,7 +1795,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		o.ok = 0;
 #pragma unroll
 		for (int r = 0; r < NSYM; r++) o.x[r] = make_float2(0.f, 0.f);
-		if (q >= 4 || g >= n_end)
+		if (q >= 4 || g >= n_end || a.dbg_stop == 100)     // 100: timing experiment, pass 2 without its re-read
 			return;
 		const int src = 16 * q;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
@@ -1736,6 +1817,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	Sym4 first, second;
 	fetch(0, first);
 	fetch(1, second);
+
+	// the soft-bit table of pass 2 (2 KB, L2-resident) starts travelling now; it goes to LDS once the rows are done
+	// with the pass-1 data it overlays
+	const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(g_sb_lut.v);
+	const uint4 lut_a = lut_src[lane], lut_b = lut_src[lane + 64];
 
 	// =========================== rows: sync symbols, frequency, phase ===========================
 	const int nbits_r = bt_r.nbits;
@@ -1831,8 +1917,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 
 	// =========================== pass 2: soft symbols / soft bits ===========================
-	if (GEN)
-		WSYNC();        // the soft-bit rows overlay the correlation the rows above were reading
+	// the soft-bit table overlays the pass-1 data (fused: where the branch metrics go after pass 2; demodulation
+	// only: behind the soft-bit rows, which themselves overlay the correlation the rows above were reading)
+	unsigned char *const lut = lds_raw + (GEN ? 4 * 432 : 0);
+	WSYNC();
+	reinterpret_cast<uint4 *>(lut)[lane] = lut_a;
+	reinterpret_cast<uint4 *>(lut)[lane + 64] = lut_b;
+	WSYNC();
 	int row_ok = 0, row_chain = 0;
 	Sym4 cur = first, nxt = second;
 	for (int q = 0; q < 4; q++) {
@@ -1875,11 +1966,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			ordv[r] = i < blen ? bt.ord_of_sym[i] : -1;
 		}
 		// phase of symbol i in TURNS: arg(x_i) + fs (i sps + d) + rps i - psi  =  arg(x_i) + A i + B
-		// (pi4cxpsk.c:351-371 derotation, :574-588 frequency / phase correction, folded into one fma)
+		// (pi4cxpsk.c:351-371 derotation, :574-588 frequency / phase correction, folded into one fma), carried
+		// scaled by 2048 (exact): floor(2048 th) & 2046 is the byte offset of the phase's cell in the soft-bit table
 		const float kInv2Pi = 0.159154943091895336f;
 		const float At = (fs * (float)sps + rps) * kInv2Pi;
 		float Bt = (fs * (float)d - psi) * kInv2Pi;
 		Bt -= rintf(Bt);
+		const float A2 = At * 2048.0f, B2 = Bt * 2048.0f;
 		const float scale = (float)(1 << nbits);
 #pragma unroll
 		for (int r = 0; r < NSYM; r++) {
@@ -1891,30 +1984,19 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				x.x -= avr;
 				x.y -= avi;
 			}
-			float th = fmaf(At, (float)i, atan2_turns(x.y, x.x) + Bt);
-			th -= rintf(th);
-			const float sv = (x.x == 0.0f && x.y == 0.0f) ? 0.0f : th * scale;   // cargf(0) = 0
-			if (gss)
-				gss[i] = sv;
+			const float th2 = fmaf(A2, (float)i, fmaf(atan2_turns(x.y, x.x), 2048.0f, B2));
+			const bool zero = x.x == 0.0f && x.y == 0.0f;                   // cargf(0) = 0
+			if (gss) {
+				float th = th2 * (1.0f / 2048.0f);
+				th -= rintf(th);
+				gss[i] = zero ? 0.0f : th * scale;
+			}
 			const int ord = ordv[r];
 			if (ord >= 0) {
-				// soft bits of a pi/4-CQPSK symbol (pi4cxpsk.c:452-507): nearest symbol sp (Gray bits
-				// p0 p1), its neighbour on the side of sv, distance dq in 1/128 symbol; the bit that
-				// differs between the two gets 127 - dq, the other 127 - dq/2
-				const float svr = rintf(sv);
-				const float dl = svr - sv;
-				const int dq = (int)rintf(fabsf(dl) * 128.0f);   // roundf up to exact .5 ties
-				const uint32_t sp = (uint32_t)(int)svr & 3u;
-				const uint32_t neg = __builtin_bit_cast(uint32_t, dl) >> 31;    // neighbour is sp + 1
-				const bool f0 = ((sp ^ neg ^ 1u) & 1u) != 0;                    // boundary 1|2 or 3|0: p0 differs
-				const int m_near = 127 - dq, m_far = 127 - (dq >> 1);
-				int v0 = f0 ? m_near : m_far;
-				int v1 = f0 ? m_far : m_near;
-				const int s0 = -(int)(sp >> 1), s1 = -(int)((sp ^ (sp >> 1)) & 1u);
-				v0 = (v0 ^ s0) - s0;
-				v1 = (v1 ^ s1) - s1;
-				const uint32_t pk2 = ((uint32_t)v0 & 0xffu) | (((uint32_t)v1 & 0xffu) << 8);
-				*reinterpret_cast<uint16_t *>(eb + 2 * ord) = (uint16_t)pk2;
+				int cell;
+				asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(cell) : "v"(th2));
+				cell = zero ? 0 : (cell & 2046);
+				*reinterpret_cast<uint16_t *>(eb + 2 * ord) = *reinterpret_cast<const uint16_t *>(lut + cell);
 			}
 		}
 		if (io.ebits) {
