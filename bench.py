@@ -30,6 +30,17 @@ BYTES_CCCH = 976 * 8 + 24 + 16
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
+def kernel_sources_hash():
+    """sha256 over the sources the headline kernel is compiled from: profiles/hbm_traffic.json names the build its
+    PMC counters were taken on, and a traffic figure from another build is not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("rx_kernels.hip", "gmr1_dev.h", "rx_loop.h"):
+        with open(os.path.join(ROOT, "osmo-gmr_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -747,13 +758,20 @@ def main():
     n_bcch = int((wl["kind"] == 0).sum())
     bytes_per_launch = n_bcch * BYTES_BCCH + (n - n_bcch) * BYTES_CCCH
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_note = None, "profiles/hbm_traffic.json missing"
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("k_rx_bytes_per_launch_100k")
-        except Exception:
-            traffic = None
+            tj = json.load(open(tf))
+            if tj.get("kernel_sources_sha256") != kernel_sources_hash():
+                traffic_note = "profiles/hbm_traffic.json was taken on other kernel sources: not reported"
+            elif n != 100_000:
+                traffic_note = "profiles/hbm_traffic.json is per 100000 bursts"
+            else:
+                traffic = tj.get("k_rx_bytes_per_launch_100k")
+                traffic_note = f"PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, build {tj.get('tag')}"
+        except Exception as e:
+            traffic_note = f"profiles/hbm_traffic.json unreadable: {e!r}"
 
     out = {
         "metric": "Mbursts/s demod+Viterbi (and IQ Msamp/s), 1/2/4/8 MI355X",
@@ -770,7 +788,7 @@ def main():
         "iq_msamp_per_s": world * (n_bcch * 1016 + (n - n_bcch) * 976) * args.steps / wall / 1e6,
         "roofline": {"bound": "hbm", "kernel": "k_rx4<16,4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "traffic_source": traffic_note, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         "checks": {"crc_pass_frac": decoded_frac, "payloads_match_sent": payload_ok,
                    "workload_gen_s": round(t_gen, 1)},
     }

@@ -41,10 +41,19 @@ int fail(int code, const char *fmt, ...)
 
 const char *last_error() { return t_err; }
 
+static int host_types_build();
+
 int host_types()
 {
-	if (g_host_types_ready)
-		return 0;
+	// first use may come from several threads at once (the legacy one-burst calls take no lock)
+	static std::once_flag once;
+	static int rv_once = 0;
+	std::call_once(once, [] { rv_once = host_types_build(); });
+	return rv_once;
+}
+
+static int host_types_build()
+{
 	tables_init();
 	std::memset(g_host_types, 0, sizeof(g_host_types));
 	for (int i = 0; i < GMR1_HIP_N_BURSTS; i++) {
@@ -447,8 +456,13 @@ int rx_base_args(int sps, const float *iq, RxArgs *out)
 	// samples of the sync-chunk windows: sum over chunks of len*sps + w - 1
 	const int ty[2] = {GMR1_HIP_BCCH, GMR1_HIP_DC6};
 	a.stage_samples = 0;
+	// the fused kernels unroll the sync correlation for these two formats (corr_fixed, rx_kernels.hip)
+	static const int kTaps[2][3] = {{11, 3, 3}, {7, 3, 3}};
 	for (int k = 0; k < 2; k++) {
 		const DevBurst &bt = g_host_types[ty[k]];
+		if (bt.n_sync != 1 || bt.n_chunks[0] != 3 || bt.sync[0][0].len != kTaps[k][0] ||
+		    bt.sync[0][1].len != kTaps[k][1] || bt.sync[0][2].len != kTaps[k][2])
+			return fail(-EINVAL, "rx_bcch_ccch: burst table %d does not have the training layout the kernel is built for", ty[k]);
 		const int w = a.in_len[k] - bt.len * sps + 1;
 		int tot = 0;
 		for (int c = 0; c < bt.n_chunks[0]; c++)

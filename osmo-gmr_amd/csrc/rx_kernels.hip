@@ -1429,6 +1429,46 @@ hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t 
 	return hipGetLastError();
 }
 
+// Sync correlation of the fused path's two formats with everything static: chunks of T0, T1, T2 training symbols
+// (BCCH 11 + 3 + 3, DC6 7 + 3 + 3; nb.c:36-41, 94-99).  Lane n holds rotated reference value n; the taps are read
+// out into scalar registers once per burst (v_readlane) and feed the packed FMAs as scalar operands, so a tap costs one
+// LDS read and two v_pk_fma_f32, all reads of a lag issued back to back.  xs: the staged chunk windows, window c =
+// samples [pos_c sps, pos_c sps + T_c sps + w - 1).  corr[j] = sum over chunks of |sum_n c_n x[j + n sps]|.
+template <int SPS, int T0, int T1, int T2>
+__device__ __forceinline__ void corr_fixed(const float2 *__restrict__ xs, int sps_rt, int w, int lane, float2 cfl,
+                                           float *__restrict__ corr)
+{
+	constexpr int T[3] = {T0, T1, T2};
+	constexpr int NT = T0 + T1 + T2;
+	const int sps = SPS ? SPS : sps_rt;
+	v2f cf[NT];
+#pragma unroll
+	for (int n = 0; n < NT; n++)
+		cf[n] = (v2f){lane_val(cfl.x, n), lane_val(cfl.y, n)};
+	for (int j = lane; j < w; j += 64) {
+		float cj = 0.f;
+		int wb = 0, base = 0;
+#pragma unroll
+		for (int ch = 0; ch < 3; ch++) {
+			const float2 *xp = xs + wb + j;
+			// (ar, ai) += c x as two packed FMAs: (-c.im x.im, c.im x.re) first, then c.re (x.re, x.im) -- the order of the
+			// scalar chains ar = fma(c.re, x.re, fma(-c.im, x.im, ar)), ai = fma(c.re, x.im, fma(c.im, x.re, ai))
+			v2f acc = {0.f, 0.f};
+#pragma unroll
+			for (int n = 0; n < T[ch]; n++) {
+				const float2 x = xp[n * sps];
+				const v2f c = cf[base + n];
+				acc = __builtin_elementwise_fma((v2f){-c.y, c.y}, (v2f){x.y, x.x}, acc);
+				acc = __builtin_elementwise_fma((v2f){c.x, c.x}, (v2f){x.x, x.y}, acc);
+			}
+			base += T[ch];
+			wb += T[ch] * sps + w - 1;
+			cj += __builtin_amdgcn_sqrtf(fmaf(acc.x, acc.x, acc.y * acc.y));
+		}
+		corr[j] = cj;
+	}
+}
+
 struct Lds4 {
 	float2 *x;        // normalised sync-chunk windows of the burst being correlated [stage_samples]
 	float *corr;      // 4 x cw correlation magnitudes
@@ -1580,14 +1620,17 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 		// rotated reference of the (single) sync sequence: without a caller-supplied frequency shift it only depends on
 		// the burst format and sps -- a table built once with this same arithmetic (g_coef0)
-		WSYNC();
+		// (lane n keeps value n: tl <= 32 for every format this body is launched for)
+		float2 cfl = make_float2(0.f, 0.f);
 		if (io.freq_shift == nullptr) {
-			if (lane < tl)
-				L.coef[lane] = g_coef0[sps][type][lane];
-		} else {
-			for (int n = lane; n < tl; n += 64)
-				L.coef[n] = sync_coef0(bt, n, sps, fs);
+			if (lane < 32)
+				cfl = g_coef0[sps][type][lane];
+		} else if (lane < tl) {
+			cfl = sync_coef0(bt, lane, sps, fs);
 		}
+		WSYNC();
+		if (GEN && lane < tl)
+			L.coef[lane] = cfl;
 		float avr, avi, inv;
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
 		if (row == q) { avr_r = avr; avi_r = avi; }
@@ -1627,6 +1670,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 		WSYNC();
 		float *corr = L.corr + q * cw;
+		if constexpr (!GEN) {
+			// BCCH / DC6: static tap structure (the host refuses to start this kernel if the tables say otherwise)
+			if (kind == 0)
+				corr_fixed<SPS, 11, 3, 3>(L.x, sps, w, lane, cfl, corr);
+			else
+				corr_fixed<SPS, 7, 3, 3>(L.x, sps, w, lane, cfl, corr);
+		} else
 		for (int j = lane; j < w; j += 64) {
 			float cj = 0.f;
 			int base = 0, wb = 0;
@@ -1795,7 +1845,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		o.ok = 0;
 #pragma unroll
 		for (int r = 0; r < NSYM; r++) o.x[r] = make_float2(0.f, 0.f);
-		if (q >= 4 || g >= n_end || a.dbg_stop == 100)     // 100: timing experiment, pass 2 without its re-read
+		if (q < 0 || q >= 4 || g >= n_end || a.dbg_stop == 100)     // 100: timing experiment, pass 2 without its re-read
 			return;
 		const int src = 16 * q;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
@@ -1814,9 +1864,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 	};
-	Sym4 first, second;
-	fetch(0, first);
-	fetch(1, second);
+	// pass 2 takes the bursts last-read first: burst 3's window was streamed in a few microseconds ago and may still be
+	// in this XCD's L2, burst 0's is long gone from it
+	// ... and all four are asked for now, while the sync terms below are worked out: every microsecond sooner is a
+	// better chance that the lines are still in L2 (the window registers of pass 1 are free to receive them)
+	Sym4 psym[4];
 
 	// the soft-bit table of pass 2 (2 KB, L2-resident) starts travelling now; it goes to LDS once the rows are done
 	// with the pass-1 data it overlays
@@ -1829,15 +1881,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const int tl_r = bt_r.sync_tl[0];
 	float ffe_r = 0.f, psi_r = 0.f;
 	{
-		// lane col holds sync symbols n = col and n = col + 16 (< tl <= 32)
-		float2 t0[NSH];
-		int chn[NSH], spos[NSH];
+		// lane col holds sync symbols n = col and n = col + 16 (< tl <= 32); their samples are asked for first (loads
+		// come back in order), then pass 2's
+		float2 t0[NSH], xr[NSH];
+		int chn[NSH], spos[NSH], idxv[NSH], nnv[NSH];
 #pragma unroll
 		for (int h = 0; h < NSH; h++) {
 			const int n = col + 16 * h;
-			t0[h] = make_float2(0.f, 0.f);
+			t0[h] = xr[h] = make_float2(0.f, 0.f);
 			chn[h] = -1;
-			spos[h] = 0;
+			spos[h] = idxv[h] = nnv[h] = 0;
 			if (n < tl_r && row_live) {
 				int ch = 0, base = 0, cum = 0, wb = 0;
 				for (int c = 0; c < nch_r - 1; c++) {
@@ -1847,17 +1900,28 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const int nn = n - base;
 				const int sp = bt_r.sync[0][ch].pos + nn;
 				const int idx = sp * sps + d_r;
-				float2 x = make_float2(0.f, 0.f);
 				if (idx >= 0 && idx < in_len_r) {
-					if (LAT) {
-						// the wave's one burst: its sync-chunk windows are still staged (normalised, which no angle
-						// below notices) -- no second trip to L2
-						x = L.x[wb + nn * sps + d_r];
-					} else {
-						x = in_r[idx];
-						x.x -= avr_r;
-						x.y -= avi_r;
-					}
+					// LAT, the wave's one burst: its sync-chunk windows are still staged (normalised, which no angle
+					// below notices) -- no second trip to L2
+					xr[h] = LAT ? L.x[wb + nn * sps + d_r] : in_r[idx];
+				}
+				chn[h] = ch;
+				spos[h] = sp;
+				idxv[h] = idx;
+				nnv[h] = nn;
+			}
+		}
+#pragma unroll
+		for (int q = 3; q >= 0; q--)
+			fetch(q, psym[q]);
+#pragma unroll
+		for (int h = 0; h < NSH; h++) {
+			if (chn[h] >= 0) {
+				const int idx = idxv[h], ch = chn[h], nn = nnv[h], sp = spos[h];
+				float2 x = xr[h];
+				if (!LAT && idx >= 0 && idx < in_len_r) {
+					x.x -= avr_r;
+					x.y -= avi_r;
 				}
 				float s, c;
 				sincos_fast(fs_r * (float)idx, s, c);
@@ -1925,13 +1989,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	reinterpret_cast<uint4 *>(lut)[lane + 64] = lut_b;
 	WSYNC();
 	int row_ok = 0, row_chain = 0;
-	Sym4 cur = first, nxt = second;
-	for (int q = 0; q < 4; q++) {
+#pragma unroll
+	for (int q = 3; q >= 0; q--) {
 		const int g = g0 + q;
+		const Sym4 &cur = psym[q];
 		if (g >= n_end)
-			break;
-		Sym4 nxt2;
-		fetch(q + 2, nxt2);             // the samples of burst q + 2 travel while q and q + 1 are worked on
+			continue;
 		const int src = 16 * q;
 		const bool found = __builtin_amdgcn_readlane((int)found_r, src) != 0;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
@@ -1953,8 +2016,6 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (gss)
 				for (int i = lane; i < blen; i += 64)
 					gss[i] = 0.f;
-			cur = nxt;
-			nxt = nxt2;
 			continue;
 		}
 		row_ok |= 1 << q;
@@ -2006,8 +2067,6 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			for (int i = lane; i < a.ebits_stride; i += 64)
 				ge[i] = i < neb ? eb[i] : (int8_t)0;
 		}
-		cur = nxt;
-		nxt = nxt2;
 	}
 	if (GEN || (a.dbg_stop && a.dbg_stop < 7))
 		return;
@@ -2038,7 +2097,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 }
 
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
