@@ -137,6 +137,8 @@ static int conv_scan(const struct orc_conv_code *c, const orc_sbit_t *in,
 
 int orc_conv_decode(const struct orc_conv_code *c, const orc_sbit_t *in, orc_ubit_t *out)
 {
+	if (orc_conv_acc_applies(c))               /* decision D1b, orc_3p_acc.c: only when a test switches it on */
+		return orc_conv_decode_acc(c, in, out);
 	int ns = 1 << (c->K - 1);
 	int total = c->len + (c->term == ORC_TERM_FLUSH ? c->K - 1 : 0);
 	unsigned ae[256];
@@ -313,6 +315,11 @@ orc_cf orc_interpolate_point(const orc_cf *cv, int len, float pos)
 	return val;
 }
 
+/* decision D3, the stop criterion of the early/late bisection: incr > 1/1024 by default; tests shift it by whole steps
+ * (orc_peak_set_stop_shift(+1): one halving more, -1: one less) to show what the choice can and cannot change */
+static int g_peak_stop_shift;
+void orc_peak_set_stop_shift(int steps) { g_peak_stop_shift = steps; }
+
 float orc_peak_energy_find(const orc_cf *cv, int len, int win, enum orc_peak_alg alg, orc_cf *peak_val)
 {
 	int mi = 0;
@@ -344,7 +351,8 @@ float orc_peak_energy_find(const orc_cf *cv, int len, int win, enum orc_peak_alg
 		}
 		early = (float)p - 1.0f;
 		late  = (float)p + 1.0f;
-		while (incr > (1.0f / 1024.0f)) {
+		const float stop = ldexpf(1.0f, -10 - g_peak_stop_shift);
+		while (incr > stop) {
 			float ee = normsq(orc_interpolate_point(cv, len, early));
 			float le = normsq(orc_interpolate_point(cv, len, late));
 			if (ee > le)      { early -= incr; late -= incr; }

@@ -53,6 +53,12 @@ void orc_conv_make(struct orc_conv_code *c, int N, int K, int len,
 int  orc_conv_output_length(const struct orc_conv_code *c);
 void orc_conv_encode(const struct orc_conv_code *c, const orc_ubit_t *in, orc_ubit_t *out);
 int  orc_conv_decode(const struct orc_conv_code *c, const orc_sbit_t *in, orc_ubit_t *out);
+/* decision D1b (orc_3p_acc.c): libosmocore's accelerated decoder for K in {5,7}, N in {2,3,4}.  orc_conv_set_mode(1)
+ * makes orc_conv_decode use it for those codes (process-wide, tests only); the default 0 is D1 for every code. */
+void orc_conv_set_mode(int mode);
+int  orc_conv_get_mode(void);
+int  orc_conv_acc_applies(const struct orc_conv_code *c);
+int  orc_conv_decode_acc(const struct orc_conv_code *c, const orc_sbit_t *in, orc_ubit_t *out);
 
 /* ---- CRC / bit packing ------------------------------------------------- */
 
@@ -76,6 +82,7 @@ int   orc_sig_normalize(const orc_cf *sig, int len, int decim, float freq_shift,
 /* out has g_len - f_len*step + 1 entries; returns that count */
 int   orc_correlate(const orc_cf *f, int f_len, const orc_cf *g, int g_len, int step, orc_cf *out);
 orc_cf orc_interpolate_point(const orc_cf *cv, int len, float pos);
+void  orc_peak_set_stop_shift(int steps);   /* tests only: D3's bisection runs `steps` halvings longer (< 0: shorter) */
 float orc_peak_energy_find(const orc_cf *cv, int len, int win, enum orc_peak_alg alg, orc_cf *peak_val);
 void  orc_peaks_scan(const orc_cf *cv, int len, int *idx, int N);
 void  orc_rotate(orc_cf *v, int len, float rps);

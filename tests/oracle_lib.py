@@ -58,6 +58,32 @@ def lib():
     return _lib
 
 
+class conv_mode:
+    """with oracle_lib.conv_mode(1): ...  -- decision D1b (libosmocore's accelerated Viterbi decoder for K in {5, 7},
+    N in {2, 3, 4}; oracle/orc_3p_acc.c) instead of D1 (the generic decoder) inside the block."""
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = lib().orc_conv_get_mode()
+        lib().orc_conv_set_mode(C.c_int(self.mode))
+
+    def __exit__(self, *exc):
+        lib().orc_conv_set_mode(C.c_int(self.prev))
+
+
+class peak_stop_shift:
+    """with oracle_lib.peak_stop_shift(+1): ... -- decision D3's early/late bisection one halving longer (-1: shorter)."""
+    def __init__(self, steps):
+        self.steps = steps
+
+    def __enter__(self):
+        lib().orc_peak_set_stop_shift(C.c_int(self.steps))
+
+    def __exit__(self, *exc):
+        lib().orc_peak_set_stop_shift(C.c_int(0))
+
+
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
