@@ -56,6 +56,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_mod_batch_dev", "gmr1_hip_mod_batch", "gmr1_pi4cxpsk_mod", "gmr1_hip_encoder_plan",
     "gmr1_scramble_sbit", "gmr1_scramble_ubit", "gmr1_interleave_intra", "gmr1_deinterleave_intra",
     "gmr1_interleave_inter", "gmr1_deinterleave_inter",
+    "gmr1_puncturer_generate",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -63,7 +64,17 @@ EXPORTED_DATA = [
     "gmr1_nt3_speech_burst", "gmr1_nt3_facch_burst", "gmr1_nt6_burst", "gmr1_nt9_burst",
     "gmr1_rach_burst", "gmr1_sdcch_burst",
     "gmr1_fcch_burst", "gmr1_fcch3_lband_burst", "gmr1_fcch3_sband_burst",
-]
+    # code descriptions for libosmocore's own codec (l1/conv.h, l1/crc.h, l1/punct.h): host data, not used by the kernels
+    "gmr1_conv_k5_12", "gmr1_conv_k5_13", "gmr1_conv_k5_14", "gmr1_conv_k5_15", "gmr1_conv_k6_14", "gmr1_conv_k9_12",
+    "gmr1_conv_k9_13", "gmr1_conv_k9_14", "gmr1_conv_tch3", "gmr1_crc8", "gmr1_crc12", "gmr1_crc16",
+] + ["gmr1_punct_" + _n for _n in """
+    k5_12_P23 k5_12_P25 k5_12_Ps25 k5_12_P311 k5_12_P412 k5_12_Ps412 k5_12_P12 k5_12_Ps12 k5_12_A k5_12_B
+    k5_12_C k5_12_D k5_12_E k5_12_P38 k5_12_P26 k5_12_P37 k5_13_P16 k5_13_P25 k5_13_P15 k5_13_Ps15 k5_13_P78
+    k5_15_P23 k5_15_P53 k5_15_Ps53 k7_12_P23 k7_12_P410 k7_12_P512 k7_12_P116 k7_12_P148 k7_12_P184
+    k7_12_P1152 k7_12_P45 k7_12_P245 k9_12_P13 k9_12_P47 k9_12_P34 k9_12_P17 k9_12_P19 k9_12_P26 k9_12_P110
+    k9_12_P14 k9_12_P45 k9_12_P234 k6_14_P45 k9_14_P148 k9_14_P65 k9_13_P12 k9_13_P1213 k9_13_P44 k9_13_P33
+    k9_13_P65
+""".split()]
 
 
 class Chunk(C.Structure):

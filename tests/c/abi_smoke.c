@@ -20,6 +20,12 @@
 #include <osmocom/gmr1/l1/rach.h>
 #include <osmocom/gmr1/l1/xch_dc12.h>
 #include <osmocom/gmr1/l1/a5.h>
+#include <osmocom/gmr1/l1/scramb.h>
+#include <osmocom/gmr1/l1/conv.h>
+#include <osmocom/gmr1/l1/punct.h>
+#include <osmocom/gmr1/l1/crc.h>
+#include <osmocom/gmr1/gsmtap.h>
+#include <stdlib.h>
 
 int main(void)
 {
@@ -57,6 +63,25 @@ int main(void)
 			return 5;
 		if (GMR1_TCH9_9k6 != 2 || sizeof(struct gmr1_interleaver) != 3 * sizeof(int) + sizeof(void *) + (sizeof(void *) - sizeof(int)))
 			return 6;
+	}
+	{
+		/* the way the reference's tch3.c:42-49 specialises a code: copy the description, set len, attach the
+		 * puncturing of P(1;2) -- plain C, flexible array member and all */
+		struct osmo_conv_code code;
+		int k = 0;
+		memcpy(&code, &gmr1_conv_tch3, sizeof(code));
+		code.len = 48;
+		if (gmr1_puncturer_generate(&code, NULL, &gmr1_punct_k5_12_P12, NULL, 0) != 0 || !code.puncture)
+			return 7;
+		while (code.puncture[k] >= 0) {
+			if (code.puncture[k] != 4 * k + 3)
+				return 8;
+			k++;
+		}
+		if (k != 24 || code.K != 7 || code.term != CONV_TERM_TAIL_BITING || code.next_output[1][0] != 1 ||
+		    gmr1_punct_k5_12_P12.mask[3] != 0 || gmr1_crc16.poly != 0x1021 || gmr1_crc8.bits != 8)
+			return 9;
+		free((void *)code.puncture);
 	}
 	printf("%s\n", gmr1_hip_version());
 	return 0;

@@ -246,3 +246,73 @@ def test_crc_parameters_equal_crc_c(orc):
                 reg ^= poly
         c = Crc(bits, poly, init, rem)
         assert f(C.byref(c), msg.ctypes.data_as(C.c_void_p), C.c_int(200)) == (reg ^ rem), name
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the description objects the library exports (l1/conv.h, l1/punct.h, l1/crc.h) against the reference files
+# ---------------------------------------------------------------------------------------------------------------
+class ConvCode(C.Structure):      # struct osmo_conv_code, include/osmocom/gmr1/compat.h
+    _fields_ = [("N", C.c_int), ("K", C.c_int), ("len", C.c_int), ("term", C.c_int),
+                ("next_output", C.POINTER(C.c_uint8 * 2)), ("next_state", C.POINTER(C.c_uint8 * 2)),
+                ("next_term_output", C.c_void_p), ("next_term_state", C.c_void_p), ("puncture", C.POINTER(C.c_int))]
+
+
+class PunctHead(C.Structure):     # struct gmr1_puncturer up to its flexible mask[]
+    _fields_ = [("r", C.c_int), ("L", C.c_int), ("N", C.c_int)]
+
+
+def _exported_mask(lib, name):
+    h = PunctHead.in_dll(lib, name)
+    m = (C.c_uint8 * (h.L * h.N)).from_address(C.addressof(h) + C.sizeof(PunctHead))
+    return h, list(m)
+
+
+def test_exported_conv_objects_equal_conv_c(pkg):
+    lib = pkg.api.load()
+    for name, c in ref_parse.parse_conv().items():
+        e = ConvCode.in_dll(lib, name)
+        ns = 1 << (c["K"] - 1)
+        assert (e.N, e.K, e.len, e.term) == (c["N"], c["K"], 0, TERM[c["term"]]), name
+        assert [[e.next_output[s][0], e.next_output[s][1]] for s in range(ns)] == c["next_output"], name
+        assert [[e.next_state[s][0], e.next_state[s][1]] for s in range(ns)] == c["next_state"], name
+        assert not e.next_term_output and not e.next_term_state and not e.puncture, name
+
+
+def test_exported_puncturers_and_crcs_equal_the_reference(pkg):
+    lib = pkg.api.load()
+    for name, m in ref_parse.parse_punct().items():
+        h, mask = _exported_mask(lib, name)
+        assert (h.r, h.L, h.N) == (m["r"], m["L"], m["N"]), name
+        assert mask == m["mask"], name
+
+    class Crc8(C.Structure):
+        _fields_ = [("bits", C.c_int), ("poly", C.c_uint8), ("init", C.c_uint8), ("remainder", C.c_uint8)]
+
+    class Crc16(C.Structure):
+        _fields_ = [("bits", C.c_int), ("poly", C.c_uint16), ("init", C.c_uint16), ("remainder", C.c_uint16)]
+    for name, T, exp in (("gmr1_crc8", Crc8, (8, 0x9b, 0, 0)), ("gmr1_crc12", Crc16, (12, 0x80f, 0, 0)),
+                         ("gmr1_crc16", Crc16, (16, 0x1021, 0, 0))):
+        c = T.in_dll(lib, name)
+        assert (c.bits, c.poly, c.init, c.remainder) == exp, name
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(CHAINS) if CHAINS[n][5] not in (None, "rach")])
+def test_exported_puncturer_generate_reproduces_the_reference_lists(pkg, name):
+    """gmr1_puncturer_generate on the exported schemes, called the way the reference's constructors call it
+    (tch3.c:46-48, tch9.c:59-78, xch_dc12.c:49-52), against the reference's generator run over the parsed masks."""
+    lib = pkg.api.load()
+    _, _, base, length, term, (pre, main, post, rep) = CHAINS[name]
+    code = ConvCode()
+    C.memmove(C.byref(code), C.addressof(ConvCode.in_dll(lib, base)), C.sizeof(ConvCode))
+    code.len, code.term = length, TERM[term]
+    ptr = lambda n: C.c_void_p(C.addressof(PunctHead.in_dll(lib, n))) if n else None
+    lib.gmr1_puncturer_generate.restype = C.c_int
+    assert lib.gmr1_puncturer_generate(C.byref(code), ptr(pre), ptr(main), ptr(post), C.c_int(rep)) == 0
+    got = []
+    while code.puncture[len(got)] >= 0:
+        got.append(code.puncture[len(got)])
+    assert got == _ref_chain(name)[4]
+    C.CDLL(None).free(code.puncture)
+    # a scheme for another code rate is refused
+    wrong = "gmr1_punct_k5_13_P16" if code.N != 3 else "gmr1_punct_k5_12_P23"
+    assert lib.gmr1_puncturer_generate(C.byref(code), None, ptr(wrong), None, 0) == -22
