@@ -498,12 +498,71 @@ def mod_order_batch(iq, offset, in_len, sps=4, freq_shift=None):
     return order
 
 
+class _RefMod(C.Structure):       # struct gmr1_pi4cxpsk_modulation (sdr/pi4cxpsk.h)
+    _fields_ = [("rotation", C.c_float), ("nbits", C.c_int), ("syms", C.c_void_p), ("bits", C.c_void_p)]
+
+
+class _RefSync(C.Structure):      # struct gmr1_pi4cxpsk_sync
+    _fields_ = [("pos", C.c_int), ("len", C.c_int), ("syms", C.c_uint8 * 32), ("_ref", C.c_void_p)]
+
+
+class _RefData(C.Structure):      # struct gmr1_pi4cxpsk_data
+    _fields_ = [("pos", C.c_int), ("len", C.c_int)]
+
+
+class _RefBurst(C.Structure):     # struct gmr1_pi4cxpsk_burst
+    _fields_ = [("mod", C.POINTER(_RefMod)), ("guard_pre", C.c_int), ("guard_post", C.c_int),
+                ("len", C.c_int), ("ebits", C.c_int), ("sync", C.POINTER(_RefSync) * 4),
+                ("data", C.POINTER(_RefData))]
+
+
+class CallerBurst:
+    """A caller-defined `struct gmr1_pi4cxpsk_burst` (the reference lets applications describe their own burst formats
+    and pass them to gmr1_pi4cxpsk_demod / _detect): a deep copy of an exported one in memory of our own, optionally
+    edited.  `.address` is what goes where `&gmr1_xyz_burst` would."""
+
+    def __init__(self, like: str):
+        src = _RefBurst.in_dll(load(), f"gmr1_{like}_burst")
+        self.burst = _RefBurst()
+        self.burst.mod = src.mod                       # the modulation objects are the library's (as in the reference)
+        self.burst.guard_pre, self.burst.guard_post = src.guard_pre, src.guard_post
+        self.burst.len, self.burst.ebits = src.len, src.ebits
+        self._keep = []
+        for k in range(4):
+            if not src.sync[k]:
+                break
+            n = 0
+            while src.sync[k][n].pos >= 0:
+                n += 1
+            arr = (_RefSync * (n + 1))()
+            for i in range(n):
+                arr[i].pos, arr[i].len = src.sync[k][i].pos, src.sync[k][i].len
+                C.memmove(arr[i].syms, src.sync[k][i].syms, 32)
+            arr[n].pos = -1
+            self._keep.append(arr)
+            self.burst.sync[k] = C.cast(arr, C.POINTER(_RefSync))
+        n = 0
+        while src.data[n].pos >= 0:
+            n += 1
+        d = (_RefData * (n + 1))()
+        for i in range(n):
+            d[i].pos, d[i].len = src.data[i].pos, src.data[i].len
+        d[n].pos = -1
+        self._keep.append(d)
+        self.burst.data = C.cast(d, C.POINTER(_RefData))
+
+    @property
+    def address(self):
+        return C.addressof(self.burst)
+
+
 def pi4cxpsk_detect(burst_names, e_toa, iq, sps=4, freq_shift=0.0):
-    """gmr1_pi4cxpsk_detect({&gmr1_a_burst, &gmr1_b_burst, NULL}, e_toa, cxvec, ...) as C callers use it."""
+    """gmr1_pi4cxpsk_detect({&gmr1_a_burst, &gmr1_b_burst, NULL}, e_toa, cxvec, ...) as C callers use it; an entry
+    may also be a CallerBurst (a description of the caller's own)."""
     L = load()
     arr = (C.c_void_p * (len(burst_names) + 1))()
     for i, nm in enumerate(burst_names):
-        arr[i] = C.addressof(C.c_void_p.in_dll(L, f"gmr1_{nm}_burst"))
+        arr[i] = nm.address if isinstance(nm, CallerBurst) else C.addressof(C.c_void_p.in_dll(L, f"gmr1_{nm}_burst"))
     arr[len(burst_names)] = None
     iq = np.ascontiguousarray(iq, np.complex64)
     vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))

@@ -41,6 +41,12 @@ int fail(int code, const char *fmt, ...)
 
 const char *last_error() { return t_err; }
 
+std::mutex &custom_slots_mutex()
+{
+	static std::mutex mu;
+	return mu;
+}
+
 static int host_types_build();
 
 int host_types()
@@ -265,8 +271,13 @@ static int demod_host_impl(int type, const DevBurst &ht, const DevBurst *custom,
 		if (offset[i] + (uint64_t)in_len > iq_len)
 			return fail(-EINVAL, "burst %d runs past the end of iq", i);
 	hipStream_t st = nullptr;
-	if (custom)
+	// a caller-defined description occupies the one spare table slot for the duration of the call: two threads
+	// demodulating different custom formats must not interleave upload and launch
+	std::unique_lock<std::mutex> lk(custom_slots_mutex(), std::defer_lock);
+	if (custom) {
+		lk.lock();
 		HIP_TRY(upload_types(custom, kCustomSlot, 1, st));
+	}
 	DBuf d_iq, d_off, d_fs, d_eb, d_sid, d_toa, d_fe, d_ss, d_rv;
 	HIP_TRY(d_iq.alloc(iq_len * 8));
 	HIP_TRY(d_off.alloc((size_t)n * 8));

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <hip/hip_runtime.h>
 
@@ -32,6 +33,9 @@ struct DevState {
 };
 
 extern DevBurst g_host_types[kNumTypes];
+// guards the descriptor-table slots caller-defined burst types are uploaded into (one demodulator slot, four detector
+// slots): held from the upload until the kernel that reads them has finished
+std::mutex &custom_slots_mutex();
 int host_types();
 // state of the CURRENT device; uploads the constant tables on first use
 int dev_state(DevState **out);

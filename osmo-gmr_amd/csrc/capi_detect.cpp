@@ -1,15 +1,22 @@
 // capi_detect.cpp -- C-ABI entry points of burst-type detection and modulation-order estimation.
 #include "capi_common.h"
 
+#include <mutex>
+
 using namespace gmr1;
 
 extern "C" {
 
-int gmr1_hip_detect_batch_dev(void *stream, int n_types, const int *burst_ids, int n, int sps, int in_len,
-                              const float *iq, const uint64_t *offset, const float *freq_shift,
-                              const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv)
+// descriptor-table slots of caller-defined candidate types (gmr1_pi4cxpsk_detect); kCustomSlot stays the demodulator's
+static constexpr int kDetectSlot0 = kCustomSlot - 4;
+static_assert(kDetectSlot0 >= GMR1_HIP_N_BURSTS, "descriptor table too small");
+
+// slots[i]: descriptor-table slot of candidate i (a built-in id or kDetectSlot0 + i), hts[i]: its host copy
+static int detect_dev_impl(hipStream_t stream, int n_types, const int *slots, const DevBurst *const *hts, int n, int sps,
+                           int in_len, const float *iq, const uint64_t *offset, const float *freq_shift,
+                           const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv)
 {
-	if (n < 0 || !burst_ids || !iq || !offset || !rv)
+	if (n < 0 || !slots || !iq || !offset || !rv)
 		return fail(-EINVAL, "detect: NULL argument");
 	if (n_types < 1 || n_types > 4)
 		return fail(-EINVAL, "detect: 1..4 candidate burst types");
@@ -22,10 +29,8 @@ int gmr1_hip_detect_batch_dev(void *stream, int n_types, const int *burst_ids, i
 	std::memset(&a, 0, sizeof(a));
 	a.n = n; a.sps = sps; a.in_len = in_len; a.n_types = n_types;
 	for (int i = 0; i < n_types; i++) {
-		if (burst_ids[i] < 0 || burst_ids[i] >= GMR1_HIP_N_BURSTS)
-			return fail(-EINVAL, "detect: bad burst id %d", burst_ids[i]);
-		a.types[i] = burst_ids[i];
-		const DevBurst &ht = g_host_types[burst_ids[i]];
+		a.types[i] = slots[i];
+		const DevBurst &ht = *hts[i];
 		const int w = in_len - ht.len * sps + 1;
 		if (w < 1 || w > kMaxWindow || in_len > kMaxInLen)
 			return fail(-EINVAL, "detect: window of %d samples gives %d lags (1..%d supported)", in_len, w, kMaxWindow);
@@ -33,13 +38,40 @@ int gmr1_hip_detect_batch_dev(void *stream, int n_types, const int *burst_ids, i
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.freq_shift = freq_shift; a.e_toa = e_toa;
 	a.bt_id = bt_id; a.sync_id = sync_id; a.toa = toa; a.rv = rv;
-	HIP_TRY(launch_detect(a, (hipStream_t)stream));
+	HIP_TRY(launch_detect(a, stream));
 	return 0;
 }
 
-int gmr1_hip_detect_batch(int n_types, const int *burst_ids, int n, int sps, int in_len,
-                          const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
-                          const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv)
+static int builtin_slots(int n_types, const int *burst_ids, const DevBurst **hts)
+{
+	if (!burst_ids || n_types < 1 || n_types > 4)
+		return fail(-EINVAL, "detect: 1..4 candidate burst types");
+	int r = host_types();
+	if (r) return r;
+	for (int i = 0; i < n_types; i++) {
+		if (burst_ids[i] < 0 || burst_ids[i] >= GMR1_HIP_N_BURSTS)
+			return fail(-EINVAL, "detect: bad burst id %d", burst_ids[i]);
+		hts[i] = &g_host_types[burst_ids[i]];
+	}
+	return 0;
+}
+
+int gmr1_hip_detect_batch_dev(void *stream, int n_types, const int *burst_ids, int n, int sps, int in_len,
+                              const float *iq, const uint64_t *offset, const float *freq_shift,
+                              const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv)
+{
+	const DevBurst *hts[4];
+	int r = builtin_slots(n_types, burst_ids, hts);
+	if (r) return r;
+	return detect_dev_impl((hipStream_t)stream, n_types, burst_ids, hts, n, sps, in_len, iq, offset, freq_shift, e_toa,
+	                       bt_id, sync_id, toa, rv);
+}
+
+// host-pointer staging; customs[i] != nullptr: candidate i is caller-defined and is uploaded into its slot first
+static int detect_host_impl(int n_types, const int *slots, const DevBurst *const *hts, const DevBurst *const *customs,
+                            int n, int sps, int in_len, const float *iq, uint64_t iq_len, const uint64_t *offset,
+                            const float *freq_shift, const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa,
+                            int32_t *rv)
 {
 	DevState *s;
 	int r = dev_state(&s);
@@ -67,16 +99,37 @@ int gmr1_hip_detect_batch(int n_types, const int *burst_ids, int n, int sps, int
 		HIP_TRY(d_et.alloc((size_t)n * 4));
 		HIP_TRY(hipMemcpy(d_et.p, e_toa, (size_t)n * 4, hipMemcpyHostToDevice));
 	}
-	r = gmr1_hip_detect_batch_dev(nullptr, n_types, burst_ids, n, sps, in_len, d_iq.as<float>(), d_off.as<uint64_t>(),
-	                              freq_shift ? d_fs.as<float>() : nullptr, e_toa ? d_et.as<float>() : nullptr,
-	                              d_bt.as<int32_t>(), d_sid.as<int32_t>(), d_toa.as<float>(), d_rv.as<int32_t>());
+	// caller-defined descriptors share the table slots process-wide: upload, launch and completion under one lock
+	std::unique_lock<std::mutex> lk(custom_slots_mutex(), std::defer_lock);
+	for (int i = 0; i < n_types; i++)
+		if (customs && customs[i]) {
+			if (!lk.owns_lock())
+				lk.lock();
+			HIP_TRY(upload_types(customs[i], slots[i], 1, nullptr));
+		}
+	r = detect_dev_impl(nullptr, n_types, slots, hts, n, sps, in_len, d_iq.as<float>(), d_off.as<uint64_t>(),
+	                    freq_shift ? d_fs.as<float>() : nullptr, e_toa ? d_et.as<float>() : nullptr,
+	                    d_bt.as<int32_t>(), d_sid.as<int32_t>(), d_toa.as<float>(), d_rv.as<int32_t>());
 	if (r) return r;
 	HIP_TRY(hipStreamSynchronize(nullptr));
+	if (lk.owns_lock())
+		lk.unlock();
 	HIP_TRY(hipMemcpy(rv, d_rv.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	if (bt_id) HIP_TRY(hipMemcpy(bt_id, d_bt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	if (sync_id) HIP_TRY(hipMemcpy(sync_id, d_sid.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	if (toa) HIP_TRY(hipMemcpy(toa, d_toa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	return 0;
+}
+
+int gmr1_hip_detect_batch(int n_types, const int *burst_ids, int n, int sps, int in_len,
+                          const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
+                          const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv)
+{
+	const DevBurst *hts[4];
+	int r = builtin_slots(n_types, burst_ids, hts);
+	if (r) return r;
+	return detect_host_impl(n_types, burst_ids, hts, nullptr, n, sps, in_len, iq, iq_len, offset, freq_shift, e_toa,
+	                        bt_id, sync_id, toa, rv);
 }
 
 int gmr1_hip_mod_order_batch_dev(void *stream, int n, int sps, int in_len,
@@ -137,7 +190,12 @@ int gmr1_pi4cxpsk_detect(struct gmr1_pi4cxpsk_burst **burst_types, float e_toa,
 		return fail(-EINVAL, "gmr1_pi4cxpsk_detect: NULL argument");
 	int r = host_types();
 	if (r) return r;
-	int ids[4], nt = 0;
+	// any NULL-terminated list of burst descriptions, as in the reference (pi4cxpsk.c:617-682): the built-in ones by
+	// their table slot, caller-defined ones flattened and uploaded into spare slots for the call; the index returned
+	// in *bt_id_p is the position in the caller's list either way
+	int slots[4], nt = 0;
+	DevBurst custom[4];
+	const DevBurst *hts[4], *cps[4];
 	for (; burst_types[nt]; nt++) {
 		if (nt >= 4)
 			return fail(-EINVAL, "gmr1_pi4cxpsk_detect: at most 4 candidate types");
@@ -145,15 +203,23 @@ int gmr1_pi4cxpsk_detect(struct gmr1_pi4cxpsk_burst **burst_types, float e_toa,
 		for (int i = 0; i < GMR1_HIP_N_BURSTS; i++)
 			if (burst_types[nt] == kBuiltin[i])
 				id = i;
-		if (id < 0)
-			return fail(-EINVAL, "gmr1_pi4cxpsk_detect: only the built-in burst types are supported");
-		ids[nt] = id;
+		cps[nt] = nullptr;
+		if (id < 0) {
+			gmr1_hip_burst_flat f;
+			r = flatten(burst_types[nt], &f, "custom");
+			if (r == 0) r = to_dev(f, &custom[nt]);
+			if (r) return fail(r, "gmr1_pi4cxpsk_detect: unsupported burst description (candidate %d)", nt);
+			id = kDetectSlot0 + nt;
+			cps[nt] = &custom[nt];
+		}
+		slots[nt] = id;
+		hts[nt] = cps[nt] ? &custom[nt] : &g_host_types[id];
 	}
 	const uint64_t off = 0;
 	int32_t bt = -1, sid = -1, rv = 0;
 	float toa = 0.f;
-	r = gmr1_hip_detect_batch(nt, ids, 1, sps, burst_in->len, reinterpret_cast<const float *>(burst_in->data),
-	                          (uint64_t)burst_in->len, &off, &freq_shift, &e_toa, &bt, &sid, &toa, &rv);
+	r = detect_host_impl(nt, slots, hts, cps, 1, sps, burst_in->len, reinterpret_cast<const float *>(burst_in->data),
+	                     (uint64_t)burst_in->len, &off, &freq_shift, &e_toa, &bt, &sid, &toa, &rv);
 	if (r) return r;
 	if (rv) return rv;
 	if (bt_id_p) *bt_id_p = bt;

@@ -229,6 +229,22 @@ def test_detect_and_mod_order(gpu_api, orc, pkg):
     d = gpu_api.pi4cxpsk_detect(["nt3_facch", "nt3_speech"], 3.0, iq[0], sps)
     o = orc.detect(["nt3_facch", "nt3_speech"], 3.0, iq[0], sps)
     assert d["rv"] == 0 and d["bt_id"] == o["bt_id"] and d["sync_id"] == o["sync_id"]
+    # caller-defined burst descriptions (the reference takes any struct gmr1_pi4cxpsk_burst **, pi4cxpsk.c:617-682):
+    # copies of the two formats in the caller's memory, alone and mixed with a built-in one, decide like the built-ins;
+    # one with a training symbol changed is a different format and loses against the right one
+    c_fa, c_sp = gpu_api.CallerBurst("nt3_facch"), gpu_api.CallerBurst("nt3_speech")
+    for i in range(0, n, 7):
+        o = orc.detect(["nt3_facch", "nt3_speech"], 3.0, iq[i], sps)
+        for cand in ([c_fa, c_sp], [c_fa, "nt3_speech"], ["nt3_facch", c_sp]):
+            d = gpu_api.pi4cxpsk_detect(cand, 3.0, iq[i], sps)
+            assert (d["rv"], d["bt_id"], d["sync_id"]) == (0, o["bt_id"], o["sync_id"]), (i, cand)
+            assert abs(d["toa"] - o["toa"]) < 16 / 1024
+    i_sp = int(np.nonzero(truth == 1)[0][0])
+    odd = gpu_api.CallerBurst("nt3_speech")
+    for k in range(1, odd.burst.sync[0][0].len, 2):
+        odd.burst.sync[0][0].syms[k] ^= 2            # every other training symbol turned by 180 degrees
+    assert gpu_api.pi4cxpsk_detect([odd, c_sp], 3.0, iq[i_sp], sps)["bt_id"] == 1
+    assert gpu_api.pi4cxpsk_detect([c_sp, odd], 3.0, iq[i_sp], sps)["bt_id"] == 0
     order = gpu_api.mod_order_batch(iq, offset, in_len, sps=sps)
     for i in range(n):
         assert order[i] == orc.mod_order(iq[i], sps), i
