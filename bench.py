@@ -487,6 +487,54 @@ def run_nt3_workload(args):
     print(json.dumps(out))
 
 
+def time_legacy_calls(api, wl, oracle_lib, m=600):
+    """The path an UNCHANGED gmr1_rx.c takes: per burst one blocking gmr1_pi4cxpsk_demod and one gmr1_bcch_decode /
+    gmr1_ccch_decode (reference rx_bcch / rx_ccch, gmr1_rx.c:746-850), host pointers in, host pointers out -- timed over
+    the first `m` bursts of the workload through ctypes (its ~2 us per call are in the figure), next to the CPU oracle
+    making the same two calls.  tools/legacy_loop.c measures the same from a C program."""
+    import ctypes as C
+    L = api.load()
+    f_demod, f_dec = L.gmr1_pi4cxpsk_demod, (L.gmr1_bcch_decode, L.gmr1_ccch_decode)
+    for f in (f_demod,) + f_dec:
+        f.restype = C.c_int
+    bt = [C.addressof(C.c_void_p.in_dll(L, "gmr1_bcch_burst")), C.addressof(C.c_void_p.in_dll(L, "gmr1_dc6_burst"))]
+    eb = (C.c_int8 * 432)()
+    l2 = np.zeros((m, 24), np.uint8)
+    crc = np.zeros(m, np.int32)
+    sid, conv, toa, fe = C.c_int(), C.c_int(), C.c_float(), C.c_float()
+    vecs = []
+    for i in range(m):
+        k = int(wl["kind"][i])
+        ln = 976 if k else 1016
+        o = int(wl["offset"][i])
+        vecs.append((k, api.CxVec(ln, ln, 0, wl["iq"][o:o + ln].ctypes.data_as(C.c_void_p)), l2[i].ctypes.data_as(C.c_void_p)))
+
+    def loop():
+        for i, (k, v, pl2) in enumerate(vecs):
+            rc = f_demod(C.c_void_p(bt[k]), C.byref(v), C.c_int(4), C.c_float(0.0), eb, C.byref(sid), C.byref(toa), C.byref(fe))
+            crc[i] = f_dec[k](pl2, eb, C.byref(conv)) if rc == 0 else -100
+    loop()                                                  # one-time set-up (pinned block, stream)
+    t0 = time.perf_counter()
+    loop()
+    t_gpu = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref_l2 = np.zeros((m, 24), np.uint8)
+    ref_crc = np.zeros(m, np.int32)
+    for i, (k, v, _) in enumerate(vecs):
+        o = int(wl["offset"][i])
+        r = oracle_lib.demod("dc6" if k else "bcch", wl["iq"][o:o + (976 if k else 1016)], 4)
+        if r["rv"] == 0:
+            d = (oracle_lib.ccch_decode if k else oracle_lib.bcch_decode)(r["ebits"][None, :432 if k else 424])
+            ref_l2[i], ref_crc[i] = d[0][0], d[1][0]
+        else:
+            ref_crc[i] = -100
+    t_cpu = time.perf_counter() - t0
+    ok = (crc == 0) | (ref_crc == 0)
+    return {"us_per_demod_decode_pair": t_gpu / m * 1e6, "oracle_us_per_pair": t_cpu / m * 1e6, "bursts": m,
+            "identical_to_oracle": bool(np.array_equal(crc, ref_crc) and np.array_equal(l2[ok], ref_l2[ok])),
+            "note": "blocking one-burst calls with host pointers, through ctypes on both sides; a carrier-minute is about 1300 pairs"}
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -834,6 +882,7 @@ def main():
                                          "sample": f"{reps} passes over the same {m} bursts split over {cores} threads, {ta:.1f} s"}
         out["checks"]["gpu_vs_oracle_crc_identical"] = same_crc
         out["checks"]["gpu_vs_oracle_payloads_identical"] = same_l2
+        out["legacy_one_burst_calls"] = time_legacy_calls(api, wl, oracle_lib)
     if dog is not None:
         line.update(out)
         dog.start()

@@ -325,6 +325,67 @@ int gmr1_hip_demod_batch(int burst_id, int n, int sps, int in_len,
 // ---------------------------------------------------------------------------
 // reference-compatible single burst demodulation (pi4cxpsk.h:101-105)
 // ---------------------------------------------------------------------------
+}  // extern "C" (closed for the one-burst machinery)
+
+namespace {
+
+// ---- the reference's one-burst calls without per-call allocations -----------------------------------------------
+// An unchanged gmr1_rx.c makes ~1300 blocking calls per carrier-minute (gmr1_pi4cxpsk_demod, then gmr1_bcch_decode /
+// gmr1_ccch_decode on what it returned).  Each used to cost a handful of hipMalloc / pageable hipMemcpy / hipFree
+// round trips; now operands and results live in ONE pinned, device-mapped host block created on first use: the call
+// copies its input there (<= 16 KB), launches on a private stream, the kernel reads and writes the block over the
+// link (zero copy), and the call returns when the stream has drained.  For the BCCH and DC6 formats the demodulator
+// call runs the fused kernel (the layer-1 chain on the soft bits it has just produced costs nothing extra) and
+// remembers (soft bits -> L2, CRC, metric); the decode call that follows with those very soft bits -- compared byte
+// by byte -- is answered from that memo, anything else is decoded on the GPU as before.  Process-wide, one call at a
+// time (the reference's calls are not re-entrant either).
+struct OneBurst {
+	std::mutex mu;
+	int dev = -1;
+	hipStream_t st = nullptr;
+	unsigned char *h = nullptr, *d = nullptr;      // the block: host address, device address
+	bool memo = false;
+	int memo_chain = 0, memo_n = 0;
+	int8_t memo_eb[432];
+	uint8_t memo_l2[24];
+	int32_t memo_crc = 0, memo_conv = 0;
+};
+OneBurst g_one;
+
+constexpr size_t kOneIq = 0;                        // kMaxInLen complex samples
+constexpr size_t kOneOff = (size_t)kMaxInLen * 8;   // uint64 offset (0), uint8 kind, float freq_shift
+constexpr size_t kOneOut = kOneOff + 64;            // rv, sync_id, toa, freq_err, crc, conv | l2[24] at +32 | soft bits at +64
+constexpr size_t kOneEb = kOneOut + 64;
+constexpr size_t kOneBytes = kOneEb + 1024;
+
+// g_one.mu held.  0, or -errno; *usable = false when the context belongs to another device (caller takes the slow path)
+int one_ready(bool *usable)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	if (!g_one.h) {
+		HIP_TRY(hipStreamCreateWithFlags(&g_one.st, hipStreamNonBlocking));
+		void *h = nullptr, *d = nullptr;
+		HIP_TRY(hipHostMalloc(&h, kOneBytes, hipHostMallocMapped));
+		HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+		g_one.h = static_cast<unsigned char *>(h);
+		g_one.d = static_cast<unsigned char *>(d);
+		g_one.dev = dev;
+	}
+	*usable = g_one.dev == dev;
+	return 0;
+}
+
+template <typename T> T *one_h(size_t off) { return reinterpret_cast<T *>(g_one.h + off); }
+template <typename T> T *one_d(size_t off) { return reinterpret_cast<T *>(g_one.d + off); }
+
+}  // namespace
+
+extern "C" {
+
 int gmr1_pi4cxpsk_demod(struct gmr1_pi4cxpsk_burst *burst_type,
                         struct osmo_cxvec *burst_in, int sps, float freq_shift,
                         sbit_t *ebits, int *sync_id_p, float *toa_p, float *freq_err_p)
@@ -348,6 +409,54 @@ int gmr1_pi4cxpsk_demod(struct gmr1_pi4cxpsk_burst *burst_type,
 		cp = &custom;
 	}
 	const DevBurst &ht = cp ? custom : g_host_types[type];
+	if (!cp && burst_in->len >= 1 && burst_in->len <= kMaxInLen) {
+		std::lock_guard<std::mutex> lk(g_one.mu);
+		bool usable = false;
+		r = one_ready(&usable);
+		if (r) return r;
+		if (usable) {
+			const int in_len = burst_in->len;
+			std::memcpy(one_h<unsigned char>(kOneIq), burst_in->data, (size_t)in_len * 8);
+			*one_h<uint64_t>(kOneOff) = 0;
+			*one_h<float>(kOneOff + 12) = freq_shift;
+			int32_t *o = one_h<int32_t>(kOneOut);
+			float *of = one_h<float>(kOneOut);
+			g_one.memo = false;
+			// the fused kernel takes the two formats of rx_bcch / rx_ccch at the window lengths they use (gmr1_rx.c:759, 809)
+			const int kind = type == GMR1_HIP_BCCH ? 0 : (type == GMR1_HIP_DC6 ? 1 : -1);
+			const bool fused = kind >= 0 && sps >= 4 && sps <= 8 && in_len == window_len(234, sps, (kind ? 10 : 20) * sps);
+			if (fused) {
+				*one_h<uint8_t>(kOneOff + 8) = (uint8_t)kind;
+				r = rx_bcch_ccch_dev_impl(g_one.st, 1, sps, one_d<float>(kOneIq), one_d<uint64_t>(kOneOff),
+				                          one_d<uint8_t>(kOneOff + 8), one_d<float>(kOneOff + 12), one_d<uint8_t>(kOneOut + 32),
+				                          one_d<int32_t>(kOneOut + 16), one_d<int32_t>(kOneOut + 20), one_d<float>(kOneOut + 8),
+				                          one_d<float>(kOneOut + 12), nullptr, one_d<int8_t>(kOneEb), nullptr,
+				                          one_d<int32_t>(kOneOut));
+				o[1] = 0;                                      // one training sequence: sync_id 0 when found
+			} else {
+				r = demod_dev_impl(g_one.st, type, ht, 1, sps, in_len, one_d<float>(kOneIq), one_d<uint64_t>(kOneOff),
+				                   one_d<float>(kOneOff + 12), one_d<int8_t>(kOneEb), ht.ebits, one_d<int32_t>(kOneOut + 4),
+				                   one_d<float>(kOneOut + 8), one_d<float>(kOneOut + 12), nullptr, one_d<int32_t>(kOneOut));
+			}
+			if (r) return r;
+			HIP_TRY(hipStreamSynchronize(g_one.st));
+			if (o[0]) return o[0];
+			std::memcpy(ebits, one_h<int8_t>(kOneEb), (size_t)ht.ebits);
+			if (sync_id_p) *sync_id_p = o[1];
+			if (toa_p) *toa_p = of[2];
+			if (freq_err_p) *freq_err_p = of[3];
+			if (fused) {
+				g_one.memo = true;
+				g_one.memo_chain = kind ? kChainCcch : kChainBcch;
+				g_one.memo_n = ht.ebits;
+				std::memcpy(g_one.memo_eb, one_h<int8_t>(kOneEb), (size_t)ht.ebits);
+				std::memcpy(g_one.memo_l2, one_h<uint8_t>(kOneOut + 32), 24);
+				g_one.memo_crc = o[4];
+				g_one.memo_conv = o[5];
+			}
+			return 0;
+		}
+	}
 	const uint64_t off = 0;
 	int32_t rv = 0, sid = -1;
 	float toa = 0.f, fe = 0.f;
@@ -423,23 +532,43 @@ int gmr1_hip_ccch_decode_batch(int n, const int8_t *ebits, uint8_t *l2, int32_t 
 // reference-compatible single-burst decoders (bcch.h:38, ccch.h:38).  A device
 // failure cannot be reported through the reference's "crc result" return value
 // without being mistaken for a CRC verdict, so it is returned as -errno (< 0).
-int gmr1_bcch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv)
+static int decode_one(int chain, uint8_t *l2, const sbit_t *bits_e, int *conv_rv)
 {
+	if (!l2 || !bits_e)
+		return fail(-EINVAL, "decode: NULL argument");
+	const int neb = chain == kChainCcch ? 432 : 424;
 	int32_t crc = 0, conv = 0;
-	int r = l1_host(kChainBcch, 1, reinterpret_cast<const int8_t *>(bits_e), l2, &crc, &conv);
+	{
+		std::lock_guard<std::mutex> lk(g_one.mu);
+		bool usable = false;
+		int r = one_ready(&usable);
+		if (r) return r;
+		if (usable) {
+			if (g_one.memo && g_one.memo_chain == chain && g_one.memo_n == neb && !std::memcmp(g_one.memo_eb, bits_e, (size_t)neb)) {
+				// these very soft bits were decoded by the demodulator call that produced them
+				std::memcpy(l2, g_one.memo_l2, 24);
+				if (conv_rv) *conv_rv = g_one.memo_conv;
+				return g_one.memo_crc;
+			}
+			std::memcpy(one_h<int8_t>(kOneEb), bits_e, (size_t)neb);
+			r = l1_dev(g_one.st, chain, 1, one_d<int8_t>(kOneEb), one_d<uint8_t>(kOneOut + 32), one_d<int32_t>(kOneOut + 16),
+			           one_d<int32_t>(kOneOut + 20));
+			if (r) return r;
+			HIP_TRY(hipStreamSynchronize(g_one.st));
+			std::memcpy(l2, one_h<uint8_t>(kOneOut + 32), 24);
+			if (conv_rv) *conv_rv = one_h<int32_t>(kOneOut)[5];
+			return one_h<int32_t>(kOneOut)[4];
+		}
+	}
+	int r = l1_host(chain, 1, reinterpret_cast<const int8_t *>(bits_e), l2, &crc, &conv);
 	if (r) return r;
 	if (conv_rv) *conv_rv = conv;
 	return crc;
 }
 
-int gmr1_ccch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv)
-{
-	int32_t crc = 0, conv = 0;
-	int r = l1_host(kChainCcch, 1, reinterpret_cast<const int8_t *>(bits_e), l2, &crc, &conv);
-	if (r) return r;
-	if (conv_rv) *conv_rv = conv;
-	return crc;
-}
+int gmr1_bcch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv) { return decode_one(kChainBcch, l2, bits_e, conv_rv); }
+
+int gmr1_ccch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv) { return decode_one(kChainCcch, l2, bits_e, conv_rv); }
 
 // ---------------------------------------------------------------------------
 // fused BCCH / CCCH receive

@@ -205,6 +205,8 @@ int gmr1_hip_fcch_rough_multi_batch_dev(void *stream, int fcch_type, int n, int 
 {
 	if (fcch_type < 0 || fcch_type >= kFcchTabs || !peaks_toa || !count || N < 1 || N > 32)
 		return fail(-EINVAL, "fcch_rough_multi: bad argument");
+	if (sps < 1 || sps > 16)                                      // before any arithmetic that divides by it
+		return fail(-EINVAL, "fcch_rough_multi: sps=%d out of range (1..16)", sps);
 	if (len < ((650 * 23400 * sps) / 1000))                       // fcch.c:355-356
 		return fail(-EINVAL, "fcch_rough_multi: needs at least 650 ms of signal");
 	DevState *s;

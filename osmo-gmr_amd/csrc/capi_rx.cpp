@@ -447,9 +447,14 @@ int RxRun::frame_loop()
 	const RxLoopState *h_st = reinterpret_cast<const RxLoopState *>(h + o_st);
 	for (int ci = 0; ci < nc; ci++) {
 		RxChain &c = chains[ci];
-		if (h_nr[ci] >= max_rounds || h_nrec[ci] > rec_stride || (want_ctx && h_nfr[ci] > max_frames))
-			return fail(-EIO, "rx loop: chain %d outgrew its buffers (%d rounds, %d records, %d frames)", ci, h_nr[ci],
-			            h_nrec[ci], h_nfr[ci]);
+		if (h_nr[ci] >= max_rounds || h_nrec[ci] > rec_stride || (want_ctx && h_nfr[ci] > max_frames)) {
+			// this chain outgrew its buffers: its carrier's status says so, its records are dropped, the others go on
+			fail(-EIO, "rx loop: chain %d of carrier %d outgrew its buffers (%d rounds, %d records, %d frames)", c.chain,
+			     c.a, h_nr[ci], h_nrec[ci], h_nfr[ci]);
+			stat[c.a] = -EIO;
+			c.done = true;
+			continue;
+		}
 		const gmr1_hip_rx_record *rp = reinterpret_cast<const gmr1_hip_rx_record *>(h) + (size_t)ci * rec_stride;
 		c.rec.assign(rp, rp + h_nrec[ci]);
 		if (want_ctx) {

@@ -2196,29 +2196,32 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 		}
 		n_rec += __popcll(mask);
 	};
+	// the finished round's BCCH burst (always its last) feeds back before the next round is listed (wave 0)
+	auto feedback = [&](int pb) {
+		e_n = prev_n;
+		if (!prev_n)
+			return;
+		e_minen = st.bcch_energy / 2.0f;                        // the gate level the round started with
+		e_frames = frames_at_round;
+		e_moved = false;
+		const int kb = prev_n - 1;
+		if (s_items[pb][kb].is_bcch) {
+			if (!s_rv[pb][kb]) {
+				st.bcch_energy = s_en[pb][kb];
+				e_moved = rx_loop_bcch_result(st, sps, s_rv[pb][kb], s_crc[pb][kb], s_toa[pb][kb], s_fe[pb][kb],
+				                              s_l2[pb][kb], s_items[pb][kb].e_toa) != 0;
+			}
+			e_fn = st.fn;
+			e_tn = st.stn;
+			on_frame(st);                                        // rx_tch3 of this frame sees the updated state
+			rx_loop_advance(st, sps);
+		}
+	};
 	int round = 0;
 	for (; round < la.max_rounds; round++) {
 		const int cb = round & 1, pb = cb ^ 1;
 		if (wave == 0) {
-			e_n = prev_n;
-			if (prev_n) {
-				// ---- the previous round's BCCH burst (always its last) feeds back before the next round is listed
-				e_minen = st.bcch_energy / 2.0f;                        // the gate level the round started with
-				e_frames = frames_at_round;
-				e_moved = false;
-				const int kb = prev_n - 1;
-				if (s_items[pb][kb].is_bcch) {
-					if (!s_rv[pb][kb]) {
-						st.bcch_energy = s_en[pb][kb];
-						e_moved = rx_loop_bcch_result(st, sps, s_rv[pb][kb], s_crc[pb][kb], s_toa[pb][kb], s_fe[pb][kb],
-						                              s_l2[pb][kb], s_items[pb][kb].e_toa) != 0;
-					}
-					e_fn = st.fn;
-					e_tn = st.stn;
-					on_frame(st);                                        // rx_tch3 of this frame sees the updated state
-					rx_loop_advance(st, sps);
-				}
-			}
+			feedback(pb);
 			frames_at_round = n_frames;
 			// ---- the next round: what rx_loop_build_round does frame after frame, for the usual case (the next
 			// sixteen frames all lie inside the capture) with one frame per lane
@@ -2286,6 +2289,13 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 				s_fs[wave] = 0.f;                  // keeps the touch alive
 		}
 		__syncthreads();
+	}
+	if (round == la.max_rounds && wave == 0 && prev_n) {
+		// the bound on the rounds was reached with a round still pending (never with the host's sizing; the host
+		// reports it as this chain's failure): its feedback and records are not lost
+		const int pb = (round & 1) ^ 1;
+		feedback(pb);
+		write_records(pb);
 	}
 	if (threadIdx.x == 0) {
 		la.n_rounds[chain] = round;
