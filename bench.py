@@ -589,7 +589,7 @@ def spawn_ranks(n, argv=None, script=None, extra_env=None, timeout=None):
     return rc
 
 
-def sharded_rx_extra(args, pkg, dev, backend, rank, world):
+def sharded_rx_extra(args, pkg, dev, backend, rank, world, partial):
     """The north star's config-4 exchange, measured next to the headline (N > 1 only; keys outside `value`):
     rank 0 holds the channelised capture (--shard-arfcns carriers x --shard-seconds, device-resident), carrier a goes
     to rank a mod N point to point (RCCL send / recv over xGMI under backend nccl), every rank runs the receive loop
@@ -634,8 +634,48 @@ def sharded_rx_extra(args, pkg, dev, backend, rank, world):
     tt = torch.tensor([t["scatter_ms"], t["rx_loop_ms"], t["gather_ms"]], dtype=torch.float64,
                       device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    if rank != 0:
-        return None
+    res = None
+    if rank == 0:
+        res = _sharded_summary(args, dist, host, out, tt, A, ns, seconds, distinct, world, sps)
+        partial["sharded_rx"] = res                  # what the watchdog prints if the native leg below never returns
+    if backend == "nccl":
+        nat = _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base if rank == 0 else None, out)
+        if rank == 0:
+            res["native"] = nat
+    return res
+
+
+def _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base, torch_records):
+    """The same exchange through the library's own C entry point (gmr1_hip_rx_run_sharded, include/gmr1_hip_shard.h):
+    ncclSend / ncclRecv posted from C++, no Python between scatter, receive loop and gather."""
+    import torch
+    api = pkg.api
+    ids = [api.Shard.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    sh = api.Shard(ids[0], rank, world)
+    try:
+        iq_all = torch.cat([torch.view_as_real(b).reshape(-1) for b in base]).contiguous() if rank == 0 else None
+        offset = (np.arange(A, dtype=np.uint64) % np.uint64(distinct)) * np.uint64(ns)      # tiles share their samples
+        length = np.full(A, ns, np.uint64)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        rec = tim = None
+        for _ in range(2):                               # the first pass warms the communicator
+            dist.barrier()
+            rec, status, chains, tim = sh.rx_run(st, iq_all.data_ptr() if rank == 0 else 0, offset, length, sps=sps,
+                                                 arfcn=np.arange(A, dtype=np.uint16), max_records=A * 4096)
+        tt = torch.tensor(tim.astype(np.float64), device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rank != 0:
+            return None
+        key = lambda r: [(int(x["arfcn"]), int(x["chain"]), int(x["type"]), int(x["fn"]), int(x["tn"]), bytes(x["l2"])) for x in r]
+        return {"entry_point": "gmr1_hip_rx_run_sharded (RCCL from C++)", "scatter_ms": float(tt[0]), "rx_loop_ms": float(tt[1]),
+                "gather_ms": float(tt[2]), "frames": int(rec.size),
+                "records_identical_to_torch_distributed_path": bool(key(rec) == key(torch_records))}
+    finally:
+        sh.close()
+
+
+def _sharded_summary(args, dist, host, out, tt, A, ns, seconds, distinct, world, sps):
     res = {"workload": f"configs[3] sharded: {A} carriers x {seconds:g} s @ 93.6 ksps ({distinct} distinct, tiled) held by "
                        f"rank 0, carrier a -> rank a mod {world}, p2p scatter, gmr1_rx loop per rank, 40-byte records gathered",
            "backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
@@ -779,7 +819,9 @@ def main():
 
         def give_up():
             if rank == 0 and line:
-                line["sharded_rx"] = {"error": f"not finished after {args.shard_timeout:g} s"}
+                part = line.get("sharded_rx") or {}
+                part["error"] = f"not finished after {args.shard_timeout:g} s"
+                line["sharded_rx"] = part
                 print(json.dumps(line), flush=True)
             os._exit(0 if line or rank != 0 else 1)
         dog = threading.Timer(args.shard_timeout, give_up)
@@ -796,7 +838,7 @@ def main():
         if dog is not None:
             dog.start()
             try:
-                sharded_rx_extra(args, pkg, dev, backend, rank, world)
+                sharded_rx_extra(args, pkg, dev, backend, rank, world, partial={})
             except Exception as e:                      # rank 0 reports; this rank has nothing to print
                 print(f"rank {rank}: sharded config-4 run failed: {e!r}", file=sys.stderr)
             dog.cancel()
@@ -887,9 +929,9 @@ def main():
         line.update(out)
         dog.start()
         try:
-            out["sharded_rx"] = sharded_rx_extra(args, pkg, dev, backend, rank, world)
+            out["sharded_rx"] = sharded_rx_extra(args, pkg, dev, backend, rank, world, partial=line)
         except Exception as e:
-            out["sharded_rx"] = {"error": repr(e)}
+            out["sharded_rx"] = dict(line.get("sharded_rx") or {}, error=repr(e))
         dog.cancel()
     print(json.dumps(out), flush=True)
     finish()

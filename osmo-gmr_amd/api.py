@@ -57,6 +57,8 @@ EXPORTED_FUNCTIONS = [
     "gmr1_scramble_sbit", "gmr1_scramble_ubit", "gmr1_interleave_intra", "gmr1_deinterleave_intra",
     "gmr1_interleave_inter", "gmr1_deinterleave_inter",
     "gmr1_puncturer_generate",
+    "gmr1_hip_shard_unique_id", "gmr1_hip_shard_create", "gmr1_hip_shard_adopt", "gmr1_hip_shard_destroy",
+    "gmr1_hip_rx_run_sharded",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -1274,3 +1276,58 @@ class InterBurstInterleaver:
         if self.il.bits_cpp:
             load().gmr1_interleaver_fini(C.byref(self.il))
             self.il.bits_cpp = None
+
+
+# ---- gmr1_hip_shard.h: the receive loop over the ranks of a node, RCCL exchanges inside the library ------------------
+class Shard:
+    """One rank's end of the node-wide communicator (gmr1_hip_shard_create).  `id_bytes`: the 128-byte id made by
+    Shard.unique_id() on one rank and handed to the others by the host program (here: torch.distributed)."""
+
+    def __init__(self, id_bytes: bytes, rank: int, world: int):
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(id_bytes)
+        _check(load().gmr1_hip_shard_create(C.byref(self._h), buf, C.c_int(rank), C.c_int(world)), "gmr1_hip_shard_create")
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(load().gmr1_hip_shard_unique_id(buf), "gmr1_hip_shard_unique_id")
+        return bytes(buf)
+
+    def rx_run(self, stream, iq_ptr, offset, length, sps=4, arfcn=None, root=0, max_records=1 << 17):
+        """gmr1_hip_rx_run_sharded.  Returns (records, status, n_chains, timing_ms) on root, (None, None, None, timing_ms)
+        elsewhere."""
+        offset, p_off = _np(offset, np.uint64)
+        length, p_len = _np(length, np.uint64)
+        n = len(offset)
+        p_arfcn = None
+        if arfcn is not None:
+            arfcn, p_arfcn = _np(arfcn, np.uint16)
+        is_root = self.rank == root
+        out = np.empty(max(max_records, 1), RX_RECORD) if is_root else None
+        n_rec = C.c_int(0)
+        status = np.zeros(max(n, 1), np.int32)
+        chains = np.zeros(max(n, 1), np.int32)
+        timing = np.zeros(3, np.float32)
+        f = load().gmr1_hip_rx_run_sharded
+        f.restype = C.c_int
+        rc = f(self._h, C.c_void_p(stream) if stream else None, C.c_int(root), C.c_int(n), C.c_int(sps),
+               C.c_void_p(iq_ptr) if iq_ptr else None, p_off, p_len, p_arfcn,
+               out.ctypes.data_as(C.c_void_p) if is_root else None, C.c_int(max_records), C.byref(n_rec),
+               status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p), timing.ctypes.data_as(C.c_void_p))
+        _check(rc, "gmr1_hip_rx_run_sharded")
+        if not is_root:
+            return None, None, None, timing
+        return out[:min(n_rec.value, max_records)].copy(), status[:n], chains[:n], timing
+
+    def close(self):
+        if self._h:
+            load().gmr1_hip_shard_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -136,6 +136,8 @@ def test_no_cpu_fallback(pkg):
     l2, rv, _ = pkg.api.bcch_decode(eb[0])
     assert rv == -19
     with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.Shard(bytes(128), 0, 1)
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
         pkg.api.xch_dc12_decode_batch(np.zeros((2, 432), np.int8))
     with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
         pkg.api.rach_decode_batch(np.zeros((2, 494), np.int8), 0)

@@ -143,9 +143,35 @@ def test_rx_capture_sharded_single_rank(gpu_api, orc, pkg):
         rec = shard.rx_capture_sharded(gpu_api, slices, 3, n, sps=SPS, device=None)
     finally:
         dist.destroy_process_group()
+    # the order one receive loop over all carriers gives: carrier, chain, order of emission
     ref = np.concatenate([orc.rx_run(xs[a], sps=SPS, arfcn=a)[1] for a in range(3)])
-    order = np.lexsort((ref["chain"], ref["tn"], ref["fn"], ref["arfcn"]))
-    assert _key(rec) == _key(ref[order])
+    assert _key(rec) == _key(ref)
+
+
+def test_native_sharded_entry_world_of_one(gpu_api, orc, pkg):
+    """gmr1_hip_rx_run_sharded (gmr1_hip_shard.h) on a communicator of one rank: RCCL is found and initialised
+    (ncclGetUniqueId, ncclCommInitRank), the exchanges degenerate, and what comes back is gmr1_hip_rx_run_dev's output --
+    records, status and chain counts -- with the caller's carrier labels, also when two carriers share a label."""
+    import torch
+    n = int(2.5 * 23400 * SPS)
+    xs = [workloads.bcch_carrier(pkg, 50 + a, seconds=2.5, sps=SPS, stn=2 * a, delay=a % 8, cfo_hz=-25.0 * a)[0]
+          for a in range(3)]
+    iq = torch.from_numpy(np.concatenate(xs).view(np.float32)).cuda()
+    offset = np.arange(3, dtype=np.uint64) * np.uint64(n)
+    length = np.full(3, n, np.uint64)
+    st = torch.cuda.current_stream().cuda_stream
+    sh = gpu_api.Shard(gpu_api.Shard.unique_id(), 0, 1)
+    try:
+        for labels in ([700, 701, 702], [9, 9, 11]):
+            rec, status, chains, timing = sh.rx_run(st, iq.data_ptr(), offset, length, sps=SPS, arfcn=labels)
+            one, st1, ch1, _ = gpu_api.rx_run_dev(st, iq.data_ptr(), offset, length, sps=SPS, arfcn=np.array(labels, np.uint16))
+            assert _key(rec) == _key(one) and len(rec) > 0
+            assert np.array_equal(status, st1) and np.array_equal(chains, ch1)
+            assert (timing >= 0).all() and timing[1] > 0
+    finally:
+        sh.close()
+    ref = np.concatenate([orc.rx_run(xs[a], sps=SPS, arfcn=[9, 9, 11][a])[1] for a in range(3)])
+    assert _key(rec) == _key(ref)
 
 
 def _key_n(rec):
