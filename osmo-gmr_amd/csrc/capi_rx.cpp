@@ -191,187 +191,183 @@ struct RxRun {
 };
 
 
+// grow-only device scratch of the acquisition (its sweeps use the library's shared workspace themselves)
+static int acq_scratch(size_t bytes, unsigned char **out)
+{
+	struct Buf { void *p = nullptr; size_t n = 0; };
+	static thread_local Buf b;
+	if (b.n < bytes) {
+		if (b.p) (void)hipFree(b.p);
+		b.p = nullptr;
+		b.n = 0;
+		HIP_TRY(hipMalloc(&b.p, bytes + bytes / 4));
+		b.n = bytes + bytes / 4;
+	}
+	*out = static_cast<unsigned char *>(b.p);
+	return 0;
+}
+
 int RxRun::acquire()
 {
-	// ---- scratch for the acquisition sweeps: per carrier / per candidate --------------------
-	const size_t C = (size_t)A * kMaxPeaks;
-	DBuf d_off, d_fs, d_i0, d_i1, d_f0;
-	HIP_TRY(d_off.alloc(C * 8));
-	HIP_TRY(d_fs.alloc(C * 4));
-	HIP_TRY(d_i0.alloc(C * 4));
-	HIP_TRY(d_i1.alloc(C * 4));
-	HIP_TRY(d_f0.alloc(C * 4));
-	std::vector<uint64_t> h_off(C);
-	std::vector<float> h_fs(C), h_f0(C);
-	std::vector<int32_t> h_i0(C), h_i1(C);
-	std::vector<int> idx;            // carriers (or candidates) of the current sweep
-	idx.reserve(C);
-
-	auto push_inputs = [&](size_t n, bool with_fs) -> int {
-		HIP_TRY(hipMemcpyAsync(d_off.p, h_off.data(), n * 8, hipMemcpyHostToDevice, st));
-		if (with_fs)
-			HIP_TRY(hipMemcpyAsync(d_fs.p, h_fs.data(), n * 4, hipMemcpyHostToDevice, st));
+	// The five sweeps of fcch_single_init / fcch_multi_process (gmr1_rx.c:605-744) follow each other on the stream
+	// without the host: k_acq_glue (fcch_kernels.hip) does the additions and bound checks between them on the device
+	// and lays out each next sweep's windows; candidate stages run over all kMaxPeaks slots of every carrier (a slot
+	// without a candidate gets a harmless window).  One copy brings every raw sweep result back, and the decisions are
+	// then taken here exactly as before, from those numbers.
+	static_assert(kMaxPeaks == kAcqPeaks, "candidate slots");
+	const int wl1 = (330 * kSymRate * sps) / 1000, wl3 = (650 * kSymRate * sps) / 1000;
+	std::vector<int> idx;
+	for (int i = 0; i < A; i++) {
+		if ((uint64_t)align[i] + wl1 > length[i]) { stat[i] = -1; continue; }
+		idx.push_back(i);
+	}
+	const int n = (int)idx.size();
+	if (!n)
 		return 0;
-	};
+	const size_t S = (size_t)n * kMaxPeaks;
+	// one block, device and pinned host mirror: [per carrier ... | per slot ...]
+	size_t o = 0;
+	auto take = [&](size_t bytes) { const size_t at = o; o += up128(bytes); return at; };
+	const size_t o_base = take(n * 8), o_len = take(n * 8), o_stat = take(n * 4), o_align = take(n * 4), o_ba = take(n * 4),
+	             o_ferr = take(n * 4), o_can3 = take(n * 4), o_toa1 = take(n * 4), o_rv1 = take(n * 4), o_ftoa = take(n * 4),
+	             o_fe = take(n * 4), o_count = take(n * 4), o_peaks = take(S * 4), o_ctoa = take(S * 4), o_cfe = take(S * 4),
+	             o_snr = take(S * 4), o_live = take(S * 4), o_off = take(S * 8), o_fs = take(S * 4);
+	const size_t total = o;
+	unsigned char *d, *h;
+	if ((r = acq_scratch(total, &d))) return r;
+	if ((r = host_log(total, &h))) return r;
+	auto H = [&](size_t at) { return h + at; };
+	auto D = [&](size_t at) { return d + at; };
+	for (int k = 0; k < n; k++) {
+		const int i = idx[k];
+		reinterpret_cast<uint64_t *>(H(o_base))[k] = offset[i];
+		reinterpret_cast<uint64_t *>(H(o_len))[k] = length[i];
+		reinterpret_cast<int32_t *>(H(o_stat))[k] = 0;
+		reinterpret_cast<int32_t *>(H(o_align))[k] = align[i];
+		reinterpret_cast<int32_t *>(H(o_ba))[k] = 0;
+		reinterpret_cast<float *>(H(o_ferr))[k] = 0.f;
+		reinterpret_cast<int32_t *>(H(o_can3))[k] = length[i] >= (uint64_t)wl3 ? 1 : 0;
+		reinterpret_cast<uint64_t *>(H(o_off))[k] = offset[i] + (uint64_t)align[i];
+	}
+	// inputs: everything up to can3, and the first sweep's windows
+	HIP_TRY(hipMemcpyAsync(d, h, o_toa1, hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(D(o_off), H(o_off), (size_t)n * 8, hipMemcpyHostToDevice, st));
+	// rough_multi leaves slots past `count` unwritten: the copy back must not carry stale numbers
+	HIP_TRY(hipMemsetAsync(D(o_peaks), 0, S * 4, st));
 
-	// ---- fcch_single_init (gmr1_rx.c:605-639): rough over 330 ms, then fine ------------------
-	{
-		const int wl = (330 * kSymRate * sps) / 1000;
-		idx.clear();
-		for (int i = 0; i < A; i++) {
-			if ((uint64_t)align[i] + wl > length[i]) { stat[i] = -1; continue; }
-			h_off[idx.size()] = offset[i] + align[i];
-			idx.push_back(i);
-		}
-		const int n = (int)idx.size();
-		if (n) {
-			if ((r = push_inputs(n, false))) return r;
-			r = gmr1_hip_fcch_rough_batch_dev(st, 0, n, sps, wl, iq, d_off.as<uint64_t>(), nullptr,
-			                                  d_i0.as<int32_t>(), d_i1.as<int32_t>());
-			if (r) return r;
-			HIP_TRY(hipMemcpyAsync(h_i0.data(), d_i0.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipMemcpyAsync(h_i1.data(), d_i1.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
-			for (int k = 0; k < n; k++) {
-				const int i = idx[k];
-				if (h_i1[k]) { stat[i] = h_i1[k]; continue; }
-				align[i] += h_i0[k];
-				if ((uint64_t)align[i] + flen > length[i]) stat[i] = -1;
-			}
-		}
-		idx.clear();
-		for (int i = 0; i < A; i++) {
-			if (stat[i]) continue;
-			h_off[idx.size()] = offset[i] + align[i];
-			idx.push_back(i);
-		}
-		const int m = (int)idx.size();
-		if (m) {
-			if ((r = push_inputs(m, false))) return r;
-			r = gmr1_hip_fcch_fine_batch_dev(st, 0, m, sps, iq, d_off.as<uint64_t>(), nullptr,
-			                                 d_i0.as<int32_t>(), d_f0.as<float>());
-			if (r) return r;
-			HIP_TRY(hipMemcpyAsync(h_i0.data(), d_i0.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipMemcpyAsync(h_f0.data(), d_f0.p, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
-			for (int k = 0; k < m; k++) {
-				const int i = idx[k];
-				align[i] += h_i0[k];
-				ferr[i] = h_f0[k];
-			}
+	AcqArgs g;
+	std::memset(&g, 0, sizeof(g));
+	g.n = n; g.sps = sps; g.flen = flen; g.wl3 = wl3;
+	g.base = reinterpret_cast<const uint64_t *>(D(o_base));
+	g.len = reinterpret_cast<const uint64_t *>(D(o_len));
+	g.stat = reinterpret_cast<int32_t *>(D(o_stat));
+	g.align = reinterpret_cast<int32_t *>(D(o_align));
+	g.base_align = reinterpret_cast<int32_t *>(D(o_ba));
+	g.ferr = reinterpret_cast<float *>(D(o_ferr));
+	g.can3 = reinterpret_cast<const int32_t *>(D(o_can3));
+	g.toa1 = reinterpret_cast<const int32_t *>(D(o_toa1));
+	g.rv1 = reinterpret_cast<const int32_t *>(D(o_rv1));
+	g.ftoa = reinterpret_cast<const int32_t *>(D(o_ftoa));
+	g.fe = reinterpret_cast<const float *>(D(o_fe));
+	g.peaks = reinterpret_cast<const int32_t *>(D(o_peaks));
+	g.count = reinterpret_cast<const int32_t *>(D(o_count));
+	g.ctoa = reinterpret_cast<const int32_t *>(D(o_ctoa));
+	g.cfe = reinterpret_cast<const float *>(D(o_cfe));
+	g.off = reinterpret_cast<uint64_t *>(D(o_off));
+	g.fs = reinterpret_cast<float *>(D(o_fs));
+	g.live = reinterpret_cast<int32_t *>(D(o_live));
+	uint64_t *d_off = g.off;
+	float *d_fs = g.fs;
+
+	// fcch_single_init (gmr1_rx.c:605-639): rough over 330 ms, then fine
+	if ((r = gmr1_hip_fcch_rough_batch_dev(st, 0, n, sps, wl1, iq, d_off, nullptr, reinterpret_cast<int32_t *>(D(o_toa1)),
+	                                       reinterpret_cast<int32_t *>(D(o_rv1))))) return r;
+	HIP_TRY(launch_acq_glue(1, g, st));
+	if ((r = gmr1_hip_fcch_fine_batch_dev(st, 0, n, sps, iq, d_off, nullptr, reinterpret_cast<int32_t *>(D(o_ftoa)),
+	                                      reinterpret_cast<float *>(D(o_fe))))) return r;
+	HIP_TRY(launch_acq_glue(2, g, st));
+	// fcch_multi_process (gmr1_rx.c:643-744); a carrier shorter than 650 ms can only fail here, its dummy window would
+	// not fit either: the sweep runs over the others
+	std::vector<int> k3;
+	for (int k = 0; k < n; k++)
+		if (length[idx[k]] >= (uint64_t)wl3)
+			k3.push_back(k);
+	const bool all3 = (int)k3.size() == n;
+	if (!k3.empty()) {
+		if (all3) {
+			if ((r = gmr1_hip_fcch_rough_multi_batch_dev(st, 0, n, sps, wl3, iq, d_off, d_fs, reinterpret_cast<int32_t *>(D(o_peaks)),
+			                                             kMaxPeaks, reinterpret_cast<int32_t *>(D(o_count))))) return r;
+		} else {
+			// mixed lengths: the long-enough carriers one by one at their own slots (rare; captures come in equal lengths)
+			for (int k : k3)
+				if ((r = gmr1_hip_fcch_rough_multi_batch_dev(st, 0, 1, sps, wl3, iq, d_off + k, d_fs + k,
+				                                             reinterpret_cast<int32_t *>(D(o_peaks)) + (size_t)k * kMaxPeaks, kMaxPeaks,
+				                                             reinterpret_cast<int32_t *>(D(o_count)) + k))) return r;
 		}
 	}
+	HIP_TRY(launch_acq_glue(3, g, st));
+	if ((r = gmr1_hip_fcch_fine_batch_dev(st, 0, (int)S, sps, iq, d_off, d_fs, reinterpret_cast<int32_t *>(D(o_ctoa)),
+	                                      reinterpret_cast<float *>(D(o_cfe))))) return r;
+	HIP_TRY(launch_acq_glue(4, g, st));
+	if ((r = gmr1_hip_fcch_snr_batch_dev(st, 0, (int)S, sps, iq, d_off, d_fs, reinterpret_cast<float *>(D(o_snr))))) return r;
+	HIP_TRY(hipMemcpyAsync(H(o_toa1), D(o_toa1), o_live - o_toa1, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
 
-	// ---- fcch_multi_process (gmr1_rx.c:643-744) -----------------------------------------------
-	{
-		const int wl = (650 * kSymRate * sps) / 1000;
-		idx.clear();
-		for (int i = 0; i < A; i++) {
-			if (stat[i]) continue;
-			base_align[i] = std::max(0, align[i] - flen);
-			if ((uint64_t)base_align[i] + wl > length[i]) { stat[i] = -1; continue; }
-			h_off[idx.size()] = offset[i] + base_align[i];
-			h_fs[idx.size()] = -ferr[i];
-			idx.push_back(i);
+	// ---- the decisions, from the raw sweep results, in the reference's order ------------------------------------
+	const int32_t *toa1 = reinterpret_cast<const int32_t *>(H(o_toa1)), *rv1 = reinterpret_cast<const int32_t *>(H(o_rv1)),
+	              *ftoa = reinterpret_cast<const int32_t *>(H(o_ftoa)), *count = reinterpret_cast<const int32_t *>(H(o_count)),
+	              *peaks = reinterpret_cast<const int32_t *>(H(o_peaks)), *ctoa = reinterpret_cast<const int32_t *>(H(o_ctoa));
+	const float *fe = reinterpret_cast<const float *>(H(o_fe)), *cfe = reinterpret_cast<const float *>(H(o_cfe)),
+	            *snr = reinterpret_cast<const float *>(H(o_snr));
+	for (int k = 0; k < n; k++) {
+		const int i = idx[k];
+		if (rv1[k]) { stat[i] = rv1[k]; continue; }
+		align[i] += toa1[k];
+		if ((uint64_t)align[i] + flen > length[i]) { stat[i] = -1; continue; }
+		align[i] += ftoa[k];
+		ferr[i] = fe[k];
+		base_align[i] = std::max(0, align[i] - flen);
+		if ((uint64_t)base_align[i] + wl3 > length[i]) { stat[i] = -1; continue; }
+		if (count[k] < 0) { stat[i] = count[k]; continue; }
+		// candidates; a carrier with any candidate out of its samples is dropped as a whole (the oracle's early
+		// return, see orc_rx.c), before or after the refinement
+		bool ok = true;
+		for (int q = 0; q < count[k]; q++) {
+			const int64_t p = (int64_t)base_align[i] + peaks[(size_t)k * kMaxPeaks + q];
+			if (p < 0 || p + flen > (int64_t)length[i]) ok = false;
 		}
-		const int n = (int)idx.size();
-		std::vector<int32_t> peaks((size_t)std::max(n, 1) * kMaxPeaks), count(std::max(n, 1));
-		DBuf d_peaks, d_count;
-		HIP_TRY(d_peaks.alloc((size_t)std::max(n, 1) * kMaxPeaks * 4));
-		HIP_TRY(d_count.alloc((size_t)std::max(n, 1) * 4));
-		if (n) {
-			if ((r = push_inputs(n, true))) return r;
-			r = gmr1_hip_fcch_rough_multi_batch_dev(st, 0, n, sps, wl, iq, d_off.as<uint64_t>(), d_fs.as<float>(),
-			                                        d_peaks.as<int32_t>(), kMaxPeaks, d_count.as<int32_t>());
-			if (r) return r;
-			HIP_TRY(hipMemcpyAsync(peaks.data(), d_peaks.p, (size_t)n * kMaxPeaks * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipMemcpyAsync(count.data(), d_count.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
+		if (!ok) { stat[i] = -1; continue; }
+		for (int q = 0; q < count[k]; q++) {
+			const size_t sl = (size_t)k * kMaxPeaks + q;
+			const int64_t p = (int64_t)base_align[i] + peaks[sl] + ctoa[sl];
+			if (p < 0 || p + flen > (int64_t)length[i]) stat[i] = -1;
 		}
-		// candidates of every carrier, flattened; a carrier with any candidate out of its
-		// samples is dropped as a whole (the oracle's early return, see orc_rx.c)
-		struct Cand { int i, k, mtoa, ftoa; float fe, snr; };
-		std::vector<Cand> cand;
-		for (int q = 0; q < n; q++) {
-			const int i = idx[q];
-			if (count[q] < 0) { stat[i] = count[q]; continue; }
-			bool ok = true;
-			for (int k = 0; k < count[q]; k++) {
-				const int64_t p = (int64_t)base_align[i] + peaks[(size_t)q * kMaxPeaks + k];
-				if (p < 0 || p + flen > (int64_t)length[i]) ok = false;
+		if (stat[i]) continue;
+		// survivor selection, candidate order, first one is the reference (gmr1_rx.c:704-733)
+		float ref_snr = 0.f, ref_fe = 0.f;
+		for (int q = 0; q < count[k]; q++) {
+			const size_t sl = (size_t)k * kMaxPeaks + q;
+			if (q == 0) {
+				ref_snr = snr[sl];
+				ref_fe = cfe[sl];
+			} else {
+				if (snr[sl] < 2.0f) continue;
+				if (snr[sl] < ref_snr / 6.0f) continue;
+				if (to_hz(std::fabs(ref_fe - cfe[sl])) > 500.0f) continue;
 			}
-			if (!ok) { stat[i] = -1; continue; }
-			for (int k = 0; k < count[q]; k++)
-				cand.push_back({i, k, peaks[(size_t)q * kMaxPeaks + k], 0, 0.f, 0.f});
-		}
-		const int nc = (int)cand.size();
-		if (nc) {
-			for (int k = 0; k < nc; k++) {
-				h_off[k] = offset[cand[k].i] + base_align[cand[k].i] + cand[k].mtoa;
-				h_fs[k] = -ferr[cand[k].i];
-			}
-			if ((r = push_inputs(nc, true))) return r;
-			r = gmr1_hip_fcch_fine_batch_dev(st, 0, nc, sps, iq, d_off.as<uint64_t>(), d_fs.as<float>(),
-			                                 d_i0.as<int32_t>(), d_f0.as<float>());
-			if (r) return r;
-			HIP_TRY(hipMemcpyAsync(h_i0.data(), d_i0.p, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipMemcpyAsync(h_f0.data(), d_f0.p, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
-			for (int k = 0; k < nc; k++) {
-				cand[k].ftoa = h_i0[k];
-				cand[k].fe = h_f0[k];
-				const int i = cand[k].i;
-				const int64_t p = (int64_t)base_align[i] + cand[k].mtoa + cand[k].ftoa;
-				if (p < 0 || p + flen > (int64_t)length[i]) stat[i] = -1;
-			}
-			// SNR at the refined position, with the refined frequency (gmr1_rx.c:693-702)
-			std::vector<int> live;
-			for (int k = 0; k < nc; k++) {
-				if (stat[cand[k].i]) continue;
-				const int i = cand[k].i;
-				h_off[live.size()] = offset[i] + base_align[i] + cand[k].mtoa + cand[k].ftoa;
-				h_fs[live.size()] = -(ferr[i] + cand[k].fe);
-				live.push_back(k);
-			}
-			const int nl = (int)live.size();
-			if (nl) {
-				if ((r = push_inputs(nl, true))) return r;
-				r = gmr1_hip_fcch_snr_batch_dev(st, 0, nl, sps, iq, d_off.as<uint64_t>(), d_fs.as<float>(), d_f0.as<float>());
-				if (r) return r;
-				HIP_TRY(hipMemcpyAsync(h_f0.data(), d_f0.p, (size_t)nl * 4, hipMemcpyDeviceToHost, st));
-				HIP_TRY(hipStreamSynchronize(st));
-				for (int q = 0; q < nl; q++)
-					cand[live[q]].snr = h_f0[q];
-			}
-			// survivor selection, candidate order, first one is the reference (gmr1_rx.c:704-733)
-			float ref_snr = 0.f, ref_fe = 0.f;
-			for (int k = 0; k < nc; k++) {
-				const Cand &cd = cand[k];
-				const int i = cd.i;
-				if (stat[i]) continue;
-				if (cd.k == 0) {
-					ref_snr = cd.snr;
-					ref_fe = cd.fe;
-				} else {
-					if (cd.snr < 2.0f) continue;
-					if (cd.snr < ref_snr / 6.0f) continue;
-					if (to_hz(std::fabs(ref_fe - cd.fe)) > 500.0f) continue;
-				}
-				RxChain c;
-				c.a = i;
-				c.chain = nch[i]++;
-				c.base = offset[i];
-				c.len = (int)length[i];
-				c.align = base_align[i] + cd.mtoa + cd.ftoa;
-				c.freq_err = ferr[i];
-				c.fn = 0; c.delay = 0; c.stn = 0;
-				c.bcch_energy = std::nanf("inf");
-				c.done = false;
-				chains.push_back(std::move(c));
-			}
+			RxChain c;
+			c.a = i;
+			c.chain = nch[i]++;
+			c.base = offset[i];
+			c.len = (int)length[i];
+			c.align = base_align[i] + peaks[sl] + ctoa[sl];
+			c.freq_err = ferr[i];
+			c.fn = 0; c.delay = 0; c.stn = 0;
+			c.bcch_energy = std::nanf("inf");
+			c.done = false;
+			chains.push_back(std::move(c));
 		}
 	}
-
 	return 0;
 }
 

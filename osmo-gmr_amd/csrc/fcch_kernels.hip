@@ -693,4 +693,104 @@ hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t st)
 	return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// k_acq_glue -- the arithmetic gmr1_rx's acquisition does between two sweeps (fcch_single_init gmr1_rx.c:605-639,
+// fcch_multi_process :643-702), on the device so that the sweeps follow each other without the host:
+//   step 1  after the 330 ms rough sweep : align += toa, bounds, window of the fine stage
+//   step 2  after the fine stage         : align += toa, freq_err, base_align, window + shift of the 650 ms sweep
+//   step 3  after rough_multi            : one window per candidate slot (bounds: a candidate outside drops the carrier)
+//   step 4  after fine over the slots    : refined window + shift of the SNR stage
+// ---------------------------------------------------------------------------
+__global__ void k_acq_glue(int step, AcqArgs a)
+{
+	const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+	if (step == 1 || step == 2) {
+		if (t >= a.n)
+			return;
+		const int k = t;
+		const int64_t len = (int64_t)a.len[k];
+		int stat = a.stat[k];
+		if (step == 1) {
+			if (!stat) {
+				if (a.rv1[k]) {
+					stat = a.rv1[k];
+				} else {
+					a.align[k] += a.toa1[k];
+					if ((int64_t)a.align[k] + a.flen > len)
+						stat = -1;
+				}
+			}
+			a.stat[k] = stat;
+			a.off[k] = a.base[k] + (uint64_t)(stat ? 0 : a.align[k]);
+		} else {
+			float fs = 0.f;
+			if (!stat) {
+				a.align[k] += a.ftoa[k];
+				a.ferr[k] = a.fe[k];
+				int ba = a.align[k] - a.flen;
+				if (ba < 0) ba = 0;
+				a.base_align[k] = ba;
+				if (!a.can3[k] || (int64_t)ba + a.wl3 > len)
+					stat = -1;
+				fs = -a.fe[k];
+			}
+			a.stat[k] = stat;
+			a.off[k] = a.base[k] + (uint64_t)((stat || !a.can3[k]) ? 0 : a.base_align[k]);
+			a.fs[k] = fs;
+		}
+		return;
+	}
+	if (t >= a.n * kAcqPeaks)
+		return;
+	const int k = t / kAcqPeaks, j = t % kAcqPeaks;
+	const int64_t len = (int64_t)a.len[k];
+	if (step == 3) {
+		int stat = a.stat[k];
+		bool live = false;
+		int64_t p = 0;
+		if (!stat) {
+			const int cnt = a.count[k];
+			if (cnt < 0) {
+				stat = cnt;
+			} else {
+				// a carrier with any candidate outside its samples is dropped as a whole
+				bool ok = true;
+				for (int q = 0; q < cnt; q++) {
+					const int64_t pq = (int64_t)a.base_align[k] + a.peaks[(size_t)k * kAcqPeaks + q];
+					if (pq < 0 || pq + a.flen > len) ok = false;
+				}
+				if (!ok)
+					stat = -1;
+				else if (j < cnt) {
+					live = true;
+					p = (int64_t)a.base_align[k] + a.peaks[(size_t)k * kAcqPeaks + j];
+				}
+			}
+		}
+		a.live[t] = live ? 1 : 0;
+		a.off[t] = a.base[k] + (uint64_t)(live ? p : 0);
+		a.fs[t] = live ? -a.ferr[k] : 0.f;
+		if (j == 0 && stat)
+			a.stat[k] = stat;          // (every thread of the carrier computed the same verdict; the others only read)
+		return;
+	}
+	// step 4
+	const bool live = a.live[t] != 0;
+	int64_t p = 0;
+	if (live)
+		p = (int64_t)a.base_align[k] + a.peaks[(size_t)k * kAcqPeaks + j] + a.ctoa[t];
+	const bool inside = live && p >= 0 && p + a.flen <= len;
+	a.off[t] = a.base[k] + (uint64_t)(inside ? p : 0);
+	a.fs[t] = inside ? -(a.ferr[k] + a.cfe[t]) : 0.f;
+}
+
+hipError_t launch_acq_glue(int step, const AcqArgs &a, hipStream_t st)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	const int n = (step <= 2) ? a.n : a.n * kAcqPeaks;
+	hipLaunchKernelGGL(k_acq_glue, dim3((n + 255) / 256), dim3(256), 0, st, step, a);
+	return hipGetLastError();
+}
+
 }  // namespace gmr1

@@ -156,6 +156,33 @@ hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t stre
 hipError_t launch_fcch_multi(const FcchMultiArgs &a, hipStream_t stream);
 hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t stream);
 
+// Acquisition of the receive loop (gmr1_rx.c:605-744) as ONE dependent chain on the stream: what the host used to do
+// between two sweeps (add the found offset, check the bounds, lay out the next sweep's windows) runs in k_acq_glue, so
+// the five sweeps need no host round trip between them.  Entries are per carrier of the sweep list (`k`), candidate
+// slots per carrier are kAcqPeaks wide; a slot that is not live gets the carrier's first sample as a harmless window.
+constexpr int kAcqPeaks = 16;
+struct AcqArgs {
+	int n;                       // carriers in the list
+	int sps, flen;               // samples of an FCCH burst
+	int wl3;                     // samples of the 650 ms sweep
+	const uint64_t *base;        // n: first sample of the carrier
+	const uint64_t *len;         // n: samples of the carrier
+	int32_t *stat;               // n: 0 alive, else the status the carrier ends with
+	int32_t *align, *base_align; // n
+	float *ferr;                 // n
+	const int32_t *can3;         // n: the carrier is long enough for the 650 ms sweep at all
+	// sweep outputs the glue reads
+	const int32_t *toa1, *rv1;   // rough
+	const int32_t *ftoa; const float *fe;           // fine
+	const int32_t *peaks, *count;                   // rough_multi: n x kAcqPeaks, n
+	const int32_t *ctoa; const float *cfe;          // fine over the candidate slots
+	// next sweep's inputs the glue writes
+	uint64_t *off;               // n or n x kAcqPeaks
+	float *fs;
+	int32_t *live;               // n x kAcqPeaks: the slot holds a candidate
+};
+hipError_t launch_acq_glue(int step, const AcqArgs &a, hipStream_t stream);
+
 // ---- traffic-channel layer 1 (l1_kernels.hip) -------------------------------
 struct Facch3Args {
 	int n;                     // frames (each = 4 bursts x 104 soft bits)

@@ -64,8 +64,14 @@ def test_rx_loop_matches_oracle_per_carrier(gpu_api, orc, pkg):
         assert chains[i] == och, (i, chains[i], och)
         assert _key(mine) == _key(orec), f"carrier {i}: decoded frames differ from the oracle's"
         if len(orec):
-            same = mine["conv"] == orec["conv"]
-            assert same.mean() >= 0.8, (i, same.mean())
+            # the Viterbi metric of a frame is a function of its soft bits, and those may differ from the oracle's by
+            # one LSB on about 4e-4 of the bits (tests/test_gpu_rx.py: an fp32 phase of ~30 turns quantises at ~1e-3 of
+            # a soft-bit step on both sides): a burst of ~430 soft bits has all of them identical about 85 % of the time,
+            # and one LSB moves a bit's cost ((v -+ 127)^2 >> 9) by at most 1 -- so most metrics are equal and none is
+            # off by more than a few units
+            d = np.abs(mine["conv"].astype(int) - orec["conv"].astype(int))
+            assert (d == 0).mean() >= 0.75, (i, (d == 0).mean())
+            assert d.max() <= 3, (i, d.max())
         n_multi += och > 1
         # and they are what was transmitted
         mb, nb, mc, nc, mp = workloads.match_records(mine, sents[i])
