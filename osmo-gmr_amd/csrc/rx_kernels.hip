@@ -1571,15 +1571,6 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const int g_row = g0 + row;                       // this row's burst
 	const bool row_live = g_row < n_end;
 
-	// per-row (lane-resident) burst parameters
-	const int kind_r = (!GEN && row_live) ? (io.kind[g_row] ? 1 : 0) : 0;
-	const int type_r = GEN ? a.fixed_type : (kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
-	const int in_len_r = a.in_len[kind_r];
-	const float fsh_r = (row_live && io.freq_shift) ? io.freq_shift[g_row] : 0.0f;
-	const DevBurst &bt_r = c_types[type_r];
-	const float fs_r = (fsh_r - bt_r.rotation) / (float)sps;     // pi4cxpsk.c:539
-	const int w_r = in_len_r - bt_r.len * sps + 1;
-	const float2 *__restrict__ in_r = a.iq + (row_live ? io.offset[g_row] : 0);
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
 
 	// =========================== pass 1: correlation magnitudes ===========================
@@ -1703,6 +1694,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 	WSYNC();
 	if (a.dbg_stop == 2) return;
+
+	// per-row (lane-resident) burst parameters: looked up here, not before pass 1, which has no register to spare for them
+	const int kind_r = (!GEN && row_live) ? (io.kind[g_row] ? 1 : 0) : 0;
+	const int type_r = GEN ? a.fixed_type : (kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
+	const int in_len_r = a.in_len[kind_r];
+	const float fsh_r = (row_live && io.freq_shift) ? io.freq_shift[g_row] : 0.0f;
+	const DevBurst &bt_r = c_types[type_r];
+	const float fs_r = (fsh_r - bt_r.rotation) / (float)sps;     // pi4cxpsk.c:539
+	const int w_r = in_len_r - bt_r.len * sps + 1;
+	const float2 *__restrict__ in_r = a.iq + (row_live ? io.offset[g_row] : 0);
 
 	// =========================== rows: peak + early/late timing ===========================
 	// osmo_cxvec_peak_energy_find(corr, 3, PEAK_EARLY_LATE, &peak), pi4cxpsk.c:240
@@ -1866,14 +1867,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	};
 	// pass 2 takes the bursts last-read first: burst 3's window was streamed in a few microseconds ago and may still be
 	// in this XCD's L2, burst 0's is long gone from it
-	// ... and all four are asked for now, while the sync terms below are worked out: every microsecond sooner is a
-	// better chance that the lines are still in L2 (the window registers of pass 1 are free to receive them)
-	Sym4 psym[4];
-
-	// the soft-bit table of pass 2 (2 KB, L2-resident) starts travelling now; it goes to LDS once the rows are done
-	// with the pass-1 data it overlays
-	const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(g_sb_lut.v);
-	const uint4 lut_a = lut_src[lane], lut_b = lut_src[lane + 64];
+	// (two bursts ahead of their use: asking for all four at once was measured and is no faster)
+	Sym4 first, second;
 
 	// =========================== rows: sync symbols, frequency, phase ===========================
 	const int nbits_r = bt_r.nbits;
@@ -1911,9 +1906,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				nnv[h] = nn;
 			}
 		}
-#pragma unroll
-		for (int q = 3; q >= 0; q--)
-			fetch(q, psym[q]);
+		fetch(3, first);
+		fetch(2, second);
 #pragma unroll
 		for (int h = 0; h < NSH; h++) {
 			if (chn[h] >= 0) {
@@ -1984,15 +1978,21 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// the soft-bit table overlays the pass-1 data (fused: where the branch metrics go after pass 2; demodulation
 	// only: behind the soft-bit rows, which themselves overlay the correlation the rows above were reading)
 	unsigned char *const lut = lds_raw + (GEN ? 4 * 432 : 0);
+	// the soft-bit table (2 KB, L2-resident) goes to LDS now that the rows are done with the pass-1 data it overlays
+	const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(g_sb_lut.v);
+	const uint4 lut_a = lut_src[lane], lut_b = lut_src[lane + 64];
 	WSYNC();
 	reinterpret_cast<uint4 *>(lut)[lane] = lut_a;
 	reinterpret_cast<uint4 *>(lut)[lane + 64] = lut_b;
 	WSYNC();
 	int row_ok = 0, row_chain = 0;
+	Sym4 nxt1 = first, nxt2 = second;
 #pragma unroll
 	for (int q = 3; q >= 0; q--) {
 		const int g = g0 + q;
-		const Sym4 &cur = psym[q];
+		const Sym4 cur = nxt1;
+		nxt1 = nxt2;
+		fetch(q - 2, nxt2);             // the samples of burst q - 2 travel while q and q - 1 are worked on
 		if (g >= n_end)
 			continue;
 		const int src = 16 * q;
