@@ -271,6 +271,20 @@ int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
                             const float *iq, uint64_t iq_len, const uint64_t *offset,
                             const float *freq_shift, float *snr);
 
+/* Direct mode of the recorder script (utils/gmr1_rx_sdr.py:605-807, DirectOutputParameters / DirectOutputBranch): a few
+ * carriers straight from the wideband stream, no filterbank.  Per carrier at freq_hz[i] from the centre:
+ * filter.freq_xlating_fir_filter_ccc(decim1, low_pass(1, 1, .3 / decim1, .3 / decim1), f, fs), filter.fir_filter_ccc(decim2,
+ * low_pass(1, 1, .45 / decim2, .1 / decim2)), pfb.arb_resampler_ccf(resamp, root_raised_cosine(32, ..., 0.35), 32) -- the
+ * split chosen as the script's _select_decim does (2.0 Msps: 7, 6, 1.9656).  out: n_sel streams of *n_out complex64 at
+ * 23400 x sps, out_stride complex samples apart.  -EINVAL for rates the reference itself cannot run (an exact multiple
+ * of 23400 x sps) or whose resampler is longer than the kernel holds (e.g. 1.0 Msps: rate 0.468). */
+int gmr1_hip_ddc_plan(double samp_rate, int sps, uint64_t n_in, int32_t *decim1, int32_t *decim2, double *resamp,
+                      uint64_t *n_out);
+int gmr1_hip_ddc_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in, int n_sel,
+                     const double *freq_hz, float *out, uint64_t out_stride, uint64_t *n_out);
+int gmr1_hip_ddc(double samp_rate, int sps, const float *wide, uint64_t n_in, int n_sel, const double *freq_hz,
+                 float *out, uint64_t out_stride, uint64_t *n_out);
+
 /* ------------------------------------------------------------------------
  * Wideband capture -> per-ARFCN streams at sym_rate x sps (reference utils/gmr1_rx_sdr.py:391-602:
  * PFBBase = 2x oversampled polyphase channelizer over n_chans = (ceil(fs / 31.25 kHz) + 1) & ~1 channels

@@ -186,3 +186,94 @@ def channelize(x: np.ndarray, plan: Plan, channels, rotation: float = 0.0, n_out
     """Wideband capture -> {channel index: stream at sym_rate * sps}."""
     y = pfb_channelizer_2x(x, plan.taps, plan.n_chans, rotation)
     return {int(k): arb_resampler(y[int(k)], plan.resamp, plan.taps_resamp, plan.nfilt, n_out) for k in channels}
+
+
+# =========================================================================== direct mode (gmr1_rx_sdr.py:605-807)
+# A few ARFCNs straight from the wideband stream, no filterbank: per ARFCN a frequency-translating decimating FIR, a
+# second decimating FIR and the same 32-phase arbitrary resampler (DirectOutputParameters :609-749, DirectOutputBranch
+# :752-807).  The blocks are GNU Radio's (filter.freq_xlating_fir_filter_ccc, filter.fir_filter_ccc,
+# pfb.arb_resampler_ccf); their published algorithms:
+#   freq_xlating_fir_filter_ccc(D, taps, f, fs)  y[m] = sum_k taps[k] z[m D - k],  z[n] = x[n] exp(-j 2 pi f n / fs)
+#   fir_filter_ccc(D, taps)                      y[m] = sum_k taps[k] x[m D - k]
+# (samples before the stream are zero; the script's optional `delay` block is left out, as every block-internal delay is).
+class DirectPlan:
+    """DirectOutputParameters.__init__ :611-628: the decimation split and the three filters.
+
+    Reference quirk: for a sample rate that is an exact multiple of sym_rate * sps `_select_decim` RETURNS its
+    factors instead of storing them (:652-655), so `decim1` is never set and `_generate_taps` raises -- the exact
+    case cannot run in the reference and is refused here as well."""
+
+    def __init__(self, samp_rate: float, sps: int = 4, sym_rate: int = SYM_RATE):
+        self.samp_rate, self.sym_rate, self.sps = float(samp_rate), sym_rate, sps
+        if samp_rate % (sym_rate * sps) == 0:
+            raise ValueError("exact multiple of sym_rate * sps: the reference's own direct mode fails there")
+        # :657-680
+        decim_max = int(math.floor(samp_rate / (2 * sym_rate)))
+        decim_min = int(math.ceil(samp_rate / (3 * sym_rate)))
+        factors = [self._factor(i) for i in range(decim_min, decim_max + 1)]
+        best = sorted(factors, key=lambda x: -self._score(x))[0]          # (Python's sort is stable: first best wins)
+        best = (best + [1])[0:2]
+        decim = best[0] * best[1]
+        resamp = (1.0 * sym_rate * sps * decim) / samp_rate
+        if best[1] <= 4:                                                  # a small second stage is left to the resampler
+            resamp /= best[1]
+            best[1] = 1
+        self.decim1, self.decim2, self.resamp = best[0], best[1], resamp
+        # :682-749, in the script's order: the root-raised cosine goes into the LAST stage that exists
+        need_rrc = True
+        fs2 = samp_rate / (self.decim1 * self.decim2)
+        self.nfilt = 32
+        if self.resamp != 1:
+            self.taps_resamp = firdes_rrc(32.0, 32.0 * fs2, sym_rate, 0.35, int(11.0 * 32 * fs2 / sym_rate))
+            need_rrc = False
+        else:
+            self.taps_resamp = np.zeros(0, np.float32)
+        if self.decim2 != 1:
+            if need_rrc:
+                self.taps2 = firdes_rrc(1.0, samp_rate / self.decim1, sym_rate, 0.35,
+                                        int(11.0 * samp_rate / (self.decim1 * sym_rate)))
+                need_rrc = False
+            else:
+                self.taps2 = firdes_low_pass(1.0, 1.0, 0.45 / self.decim2, 0.10 / self.decim2)
+        else:
+            self.taps2 = np.zeros(0, np.float32)
+        if need_rrc:
+            self.taps1 = firdes_rrc(1.0, samp_rate, sym_rate, 0.35, int(11.0 * samp_rate / sym_rate))
+        else:
+            self.taps1 = firdes_low_pass(1.0, 1.0, 0.3 / self.decim1, 0.3 / self.decim1)
+
+    @staticmethod
+    def _factor(decim):                                                   # :637-642
+        d_ideal = int(round(math.sqrt(decim)))
+        for i in range(d_ideal, 1, -1):
+            if decim % i == 0:
+                return [decim // i, i]
+        return [decim]
+
+    @staticmethod
+    def _score(f):                                                        # :644-650
+        if len(f) == 1:
+            return f[0]
+        return (f[0] * f[0] * f[1]) / (1 + (1.0 * f[0] / f[1]))
+
+
+def fir_decimate(x: np.ndarray, taps: np.ndarray, decim: int) -> np.ndarray:
+    """y[m] = sum_k taps[k] x[m decim - k], m = 0 .. len(x) // decim - 1, zeros before the stream."""
+    x = np.asarray(x, np.complex128)
+    n_out = x.size // decim
+    y = np.convolve(x, np.asarray(taps, np.float64))[:n_out * decim:decim]
+    return y[:n_out]
+
+
+def direct_ddc(x: np.ndarray, plan: DirectPlan, freq_hz: float, n_out: int | None = None) -> np.ndarray:
+    """One ARFCN `freq_hz` from the centre of the wideband stream -> its stream at sym_rate * sps."""
+    x = np.asarray(x, np.complex128)
+    y = x
+    if plan.decim1 > 1:
+        z = x * np.exp(-2j * np.pi * (freq_hz / plan.samp_rate) * np.arange(x.size))
+        y = fir_decimate(z, plan.taps1, plan.decim1)
+    if plan.decim2 > 1:
+        y = fir_decimate(y, plan.taps2, plan.decim2)
+    if plan.resamp != 1:
+        y = arb_resampler(y, plan.resamp, plan.taps_resamp, plan.nfilt, n_out)
+    return y.astype(np.complex64)

@@ -57,6 +57,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_scramble_sbit", "gmr1_scramble_ubit", "gmr1_interleave_intra", "gmr1_deinterleave_intra",
     "gmr1_interleave_inter", "gmr1_deinterleave_inter",
     "gmr1_puncturer_generate",
+    "gmr1_hip_ddc_plan", "gmr1_hip_ddc_dev", "gmr1_hip_ddc",
     "gmr1_hip_shard_unique_id", "gmr1_hip_shard_create", "gmr1_hip_shard_adopt", "gmr1_hip_shard_destroy",
     "gmr1_hip_rx_run_sharded",
 ]
@@ -792,6 +793,35 @@ def channelize(wide, samp_rate, channels, sps=4, rotation=0.0):
            out.ctypes.data_as(C.c_void_p), C.c_uint64(n_out), C.byref(no))
     _check(rc, "gmr1_hip_channelize")
     return out
+
+
+def ddc_plan(samp_rate, sps, n_in):
+    """gmr1_hip_ddc_plan -> (decim1, decim2, resamp, n_out) of the recorder script's direct mode."""
+    d1, d2, rs, n_out = C.c_int32(), C.c_int32(), C.c_double(), C.c_uint64()
+    _check(load().gmr1_hip_ddc_plan(C.c_double(samp_rate), C.c_int(sps), C.c_uint64(n_in), C.byref(d1), C.byref(d2),
+                                    C.byref(rs), C.byref(n_out)), "gmr1_hip_ddc_plan")
+    return d1.value, d2.value, rs.value, n_out.value
+
+
+def ddc(wide, samp_rate, freqs_hz, sps=4):
+    """gmr1_hip_ddc: wide (complex64, host) -> array (len(freqs_hz), n_out) complex64."""
+    wide, p_w = _np(np.asarray(wide).reshape(-1), np.complex64)
+    freqs, p_f = _np(freqs_hz, np.float64)
+    _, _, _, n_out = ddc_plan(samp_rate, sps, wide.size)
+    out = np.zeros((freqs.size, max(n_out, 1)), np.complex64)
+    got = C.c_uint64()
+    _check(load().gmr1_hip_ddc(C.c_double(samp_rate), C.c_int(sps), p_w, C.c_uint64(wide.size), C.c_int(freqs.size), p_f,
+                               out.ctypes.data_as(C.c_void_p), C.c_uint64(out.shape[1]), C.byref(got)), "gmr1_hip_ddc")
+    return out[:, :got.value]
+
+
+def ddc_dev(stream, wide_ptr, n_in, samp_rate, freqs_hz, out_ptr, out_stride, sps=4):
+    freqs, p_f = _np(freqs_hz, np.float64)
+    got = C.c_uint64()
+    _check(load().gmr1_hip_ddc_dev(C.c_void_p(stream) if stream else None, C.c_double(samp_rate), C.c_int(sps),
+                                   C.c_void_p(wide_ptr), C.c_uint64(n_in), C.c_int(freqs.size), p_f, C.c_void_p(out_ptr),
+                                   C.c_uint64(out_stride), C.byref(got)), "gmr1_hip_ddc_dev")
+    return got.value
 
 
 def channelize_dev(stream, wide_ptr, n_in, samp_rate, channels, out_ptr, out_stride, sps=4, rotation=0.0):

@@ -83,6 +83,7 @@ std::vector<float> design_rrc(double gain, double fs, double sym_rate, double al
 }
 
 long long gcdll(long long a, long long b) { return b ? gcdll(b, a % b) : a; }
+size_t up_to(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ChanPlan {
 	double samp_rate = 0;
@@ -149,9 +150,244 @@ int get_plan(double samp_rate, int sps, const ChanPlan **out)
 	return 0;
 }
 
+// ---- direct mode (utils/gmr1_rx_sdr.py:605-807) ------------------------------------------------------------------
+struct DdcPlan {
+	double samp_rate = 0;
+	int sps = 0, device = -1;
+	int d1 = 1, d2 = 1;
+	double resamp = 1.0;
+	std::vector<float> taps1, taps2;         // host copies (stage 1 taps are turned per carrier at call time)
+	int tpf = 0, j0 = 0;
+	long long num = 0, den = 1;
+	float2 *d_taps2 = nullptr;               // real taps as (t, 0)
+	float2 *d_bank = nullptr;                // resampler bank, rows padded to the kernel's 30 taps
+};
+std::deque<DdcPlan> g_ddc_plans;
+
+// DirectOutputParameters._factor / _score :637-650
+std::vector<int> ddc_factor(int decim)
+{
+	const int d_ideal = (int)std::lround(std::sqrt((double)decim));
+	for (int i = d_ideal; i > 1; i--)
+		if (decim % i == 0)
+			return {decim / i, i};
+	return {decim};
+}
+double ddc_score(const std::vector<int> &f)
+{
+	if (f.size() == 1)
+		return f[0];
+	return ((double)f[0] * f[0] * f[1]) / (1.0 + (double)f[0] / f[1]);
+}
+
+int get_ddc_plan(double samp_rate, int sps, const DdcPlan **out)
+{
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	std::lock_guard<std::mutex> lk(g_plan_mu);
+	for (const DdcPlan &p : g_ddc_plans)
+		if (p.samp_rate == samp_rate && p.sps == sps && p.device == dev) {
+			*out = &p;
+			return 0;
+		}
+	DdcPlan p;
+	p.samp_rate = samp_rate; p.sps = sps; p.device = dev;
+	const double out_rate = (double)kSymRate * sps;
+	if (std::fmod(samp_rate, out_rate) == 0.0)
+		return fail(-EINVAL, "ddc: %.1f is an exact multiple of %d x %d: the reference's own direct mode cannot run there "
+		                     "(_select_decim returns its factors without storing them, gmr1_rx_sdr.py:652-655)", samp_rate, kSymRate, sps);
+	// _select_decim :657-680
+	const int decim_max = (int)std::floor(samp_rate / (2.0 * kSymRate));
+	const int decim_min = (int)std::ceil(samp_rate / (3.0 * kSymRate));
+	std::vector<int> best;
+	double best_score = -1.0;
+	for (int i = decim_min; i <= decim_max; i++) {
+		const std::vector<int> f = ddc_factor(i);
+		const double sc = ddc_score(f);
+		if (sc > best_score) { best_score = sc; best = f; }     // the first of equal scores, like Python's stable sort
+	}
+	if (best.empty())
+		return fail(-EINVAL, "ddc: sample rate %.1f too low for a direct branch", samp_rate);
+	if (best.size() == 1)
+		best.push_back(1);
+	const int decim = best[0] * best[1];
+	double resamp = (out_rate * decim) / samp_rate;
+	if (best[1] <= 4) {
+		resamp /= best[1];
+		best[1] = 1;
+	}
+	p.d1 = best[0]; p.d2 = best[1]; p.resamp = resamp;
+	if (resamp == 1.0)
+		return fail(-EINVAL, "ddc: resampling rate 1 (no resampler stage) is not built");
+	// _generate_taps :682-749: root-raised cosine in the resampler, plain low-passes before it
+	const double fs2 = samp_rate / (p.d1 * p.d2);
+	const std::vector<float> rrc = design_rrc(32.0, 32.0 * fs2, kSymRate, 0.35, (int)(11.0 * 32 * fs2 / kSymRate));
+	if (p.d2 != 1)
+		p.taps2 = design_low_pass(1.0, 1.0, 0.45 / p.d2, 0.10 / p.d2);
+	p.taps1 = design_low_pass(1.0, 1.0, 0.3 / p.d1, 0.3 / p.d1);
+	if ((int)p.taps1.size() > kDdcMaxTaps || (int)p.taps2.size() > kDdcMaxTaps)
+		return fail(-EINVAL, "ddc: filters of %zu / %zu taps (at most %d)", p.taps1.size(), p.taps2.size(), kDdcMaxTaps);
+	const int nt = (int)rrc.size();
+	p.tpf = (nt + kNfilt - 1) / kNfilt;
+	constexpr int kBankTaps = 30;            // what k_resamp keeps in registers per phase
+	if (p.tpf > kBankTaps)
+		return fail(-EINVAL, "ddc: the resampler of this plan (rate %.4f, %d taps per phase) is longer than the %d the kernel "
+		                     "holds", resamp, p.tpf, kBankTaps);
+	p.j0 = (nt / 2) % kNfilt;
+	// phase step nfilt / rate = nfilt * samp_rate / (d1 d2 out_rate), as a reduced fraction
+	long long num = (long long)kNfilt * (long long)std::llround(samp_rate), den = (long long)p.d1 * p.d2 * (long long)out_rate;
+	if ((double)std::llround(samp_rate) != samp_rate)
+		return fail(-EINVAL, "ddc: the sample rate must be a whole number of Hz");
+	const long long g = gcdll(num, den);
+	p.num = num / g; p.den = den / g;
+	std::vector<float2> bank((size_t)kNfilt * kBankTaps, make_float2(0.f, 0.f));
+	for (int j = 0; j < kNfilt; j++)
+		for (int k = 0; k < p.tpf; k++) {
+			const int i = j + k * kNfilt;
+			const float b = i < nt ? rrc[i] : 0.0f;
+			const float d = (i + 1 < nt) ? (rrc[i + 1] - rrc[i]) : 0.0f;
+			bank[(size_t)j * kBankTaps + k] = make_float2(b, d);
+		}
+	std::vector<float2> t2(p.taps2.size());
+	for (size_t i = 0; i < t2.size(); i++)
+		t2[i] = make_float2(p.taps2[i], 0.f);
+	if (!t2.empty()) {
+		HIP_TRY(hipMalloc(&p.d_taps2, t2.size() * sizeof(float2)));
+		HIP_TRY(hipMemcpy(p.d_taps2, t2.data(), t2.size() * sizeof(float2), hipMemcpyHostToDevice));
+	}
+	HIP_TRY(hipMalloc(&p.d_bank, bank.size() * sizeof(float2)));
+	HIP_TRY(hipMemcpy(p.d_bank, bank.data(), bank.size() * sizeof(float2), hipMemcpyHostToDevice));
+	g_ddc_plans.push_back(p);
+	*out = &g_ddc_plans.back();
+	return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int gmr1_hip_ddc_plan(double samp_rate, int sps, uint64_t n_in, int32_t *decim1, int32_t *decim2, double *resamp,
+                      uint64_t *n_out)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (sps < 1 || sps > 16)
+		return fail(-EINVAL, "ddc: sps=%d out of range (1..16)", sps);
+	const DdcPlan *p;
+	r = get_ddc_plan(samp_rate, sps, &p);
+	if (r) return r;
+	if (decim1) *decim1 = p->d1;
+	if (decim2) *decim2 = p->d2;
+	if (resamp) *resamp = p->resamp;
+	if (n_out) {
+		const uint64_t n2 = n_in / (uint64_t)p->d1 / (uint64_t)p->d2;
+		const long long v = ((long long)n2 * kNfilt - p->j0) * p->den;
+		*n_out = v > 0 ? (uint64_t)(v / p->num) : 0;
+	}
+	return 0;
+}
+
+int gmr1_hip_ddc_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in, int n_sel,
+                     const double *freq_hz, float *out, uint64_t out_stride, uint64_t *n_out_p)
+{
+	if (!wide || n_sel < 0 || (n_sel && (!freq_hz || !out)))
+		return fail(-EINVAL, "ddc: wide / freq_hz / out are required");
+	uint64_t n_out;
+	int r = gmr1_hip_ddc_plan(samp_rate, sps, n_in, nullptr, nullptr, nullptr, &n_out);
+	if (r) return r;
+	if (n_out_p) *n_out_p = n_out;
+	if (n_sel == 0 || n_out == 0)
+		return 0;
+	if (out_stride < n_out)
+		return fail(-EINVAL, "ddc: out_stride %llu < %llu output samples per carrier", (unsigned long long)out_stride,
+		            (unsigned long long)n_out);
+	const DdcPlan *p;
+	r = get_ddc_plan(samp_rate, sps, &p);
+	if (r) return r;
+	hipStream_t st = (hipStream_t)stream;
+	DevState *s;
+	r = dev_state(&s);
+	if (r) return r;
+	const long long n1 = (long long)(n_in / (uint64_t)p->d1), n2 = n1 / p->d2;
+	const int nt1 = (int)p->taps1.size();
+	// scratch: per-carrier stage-1 taps and rotation steps, then the two intermediate streams
+	const size_t b_t1 = up_to(sizeof(float2) * (size_t)n_sel * nt1, 256), b_rot = up_to(sizeof(double) * (size_t)n_sel, 256);
+	const size_t b_y1 = up_to(sizeof(float2) * (size_t)n_sel * (size_t)n1, 256);
+	const size_t b_y2 = p->d2 > 1 ? up_to(sizeof(float2) * (size_t)n_sel * (size_t)n2, 256) : 0;
+	void *ws;
+	r = dev_workspace(s, b_t1 + b_rot + b_y1 + b_y2, &ws);
+	if (r) return r;
+	char *w = static_cast<char *>(ws);
+	float2 *d_t1 = reinterpret_cast<float2 *>(w);
+	double *d_rot = reinterpret_cast<double *>(w + b_t1);
+	float2 *d_y1 = reinterpret_cast<float2 *>(w + b_t1 + b_rot);
+	float2 *d_y2 = p->d2 > 1 ? reinterpret_cast<float2 *>(w + b_t1 + b_rot + b_y1) : d_y1;
+	// freq_xlating_fir_filter_ccc: the low-pass turned up to the carrier, taps[k] e^{+j 2 pi f k / fs}; the output is
+	// turned back by e^{-j 2 pi f m d1 / fs}
+	std::vector<float2> t1((size_t)n_sel * nt1);
+	std::vector<double> rot((size_t)n_sel);
+	for (int c = 0; c < n_sel; c++) {
+		const double fn = freq_hz[c] / samp_rate;
+		for (int k = 0; k < nt1; k++) {
+			const double ph = 2.0 * M_PI * std::fmod(fn * k, 1.0);
+			t1[(size_t)c * nt1 + k] = make_float2((float)(p->taps1[k] * std::cos(ph)), (float)(p->taps1[k] * std::sin(ph)));
+		}
+		rot[c] = fn * p->d1;
+	}
+	HIP_TRY(hipMemcpyAsync(d_t1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipMemcpyAsync(d_rot, rot.data(), rot.size() * sizeof(double), hipMemcpyHostToDevice, st));
+	HIP_TRY(hipStreamSynchronize(st));       // t1 / rot are host temporaries
+	DdcFirArgs f1;
+	std::memset(&f1, 0, sizeof(f1));
+	f1.n_sel = n_sel; f1.decim = p->d1; f1.ntaps = nt1; f1.n_in = (long long)n_in; f1.n_out = n1; f1.in_stride = 0;
+	f1.x = reinterpret_cast<const float2 *>(wide); f1.taps = d_t1; f1.rot = d_rot; f1.y = d_y1;
+	HIP_TRY(launch_ddc_fir(f1, st));
+	if (p->d2 > 1) {
+		// the same real taps for every carrier: a stride of zero taps rows is not expressible, so the row is repeated
+		// by launching carrier by carrier on the one row
+		for (int c = 0; c < n_sel; c++) {
+			DdcFirArgs f2;
+			std::memset(&f2, 0, sizeof(f2));
+			f2.n_sel = 1; f2.decim = p->d2; f2.ntaps = (int)p->taps2.size(); f2.n_in = n1; f2.n_out = n2; f2.in_stride = 0;
+			f2.x = d_y1 + (size_t)c * n1; f2.taps = p->d_taps2; f2.rot = nullptr; f2.y = d_y2 + (size_t)c * n2;
+			HIP_TRY(launch_ddc_fir(f2, st));
+		}
+	}
+	ResampArgs ra;
+	std::memset(&ra, 0, sizeof(ra));
+	ra.n_slots = n_sel; ra.nfilt = kNfilt; ra.tpf = 30; ra.j0 = p->j0; ra.num = p->num; ra.den = p->den;
+	ra.T = n2; ra.n_out = (long long)n_out; ra.out_stride = (long long)out_stride;
+	ra.y = d_y2; ra.bank = p->d_bank; ra.out = reinterpret_cast<float2 *>(out);
+	HIP_TRY(launch_resamp(ra, st));
+	return 0;
+}
+
+int gmr1_hip_ddc(double samp_rate, int sps, const float *wide, uint64_t n_in, int n_sel, const double *freq_hz,
+                 float *out, uint64_t out_stride, uint64_t *n_out_p)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (!wide || n_sel < 0 || (n_sel && (!freq_hz || !out)))
+		return fail(-EINVAL, "ddc: wide / freq_hz / out are required");
+	uint64_t n_out;
+	r = gmr1_hip_ddc_plan(samp_rate, sps, n_in, nullptr, nullptr, nullptr, &n_out);
+	if (r) return r;
+	if (n_out_p) *n_out_p = n_out;
+	if (!n_sel || !n_out) return 0;
+	if (out_stride < n_out)
+		return fail(-EINVAL, "ddc: out_stride too small");
+	DBuf d_w, d_o;
+	HIP_TRY(d_w.alloc(n_in * 8));
+	HIP_TRY(d_o.alloc((size_t)n_sel * out_stride * 8));
+	HIP_TRY(hipMemcpy(d_w.p, wide, n_in * 8, hipMemcpyHostToDevice));
+	r = gmr1_hip_ddc_dev(nullptr, samp_rate, sps, d_w.as<float>(), n_in, n_sel, freq_hz, d_o.as<float>(), out_stride, nullptr);
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(out, d_o.p, (size_t)n_sel * out_stride * 8, hipMemcpyDeviceToHost));
+	return 0;
+}
 
 int gmr1_hip_channelize_plan(double samp_rate, int sps, uint64_t n_in,
                              int32_t *n_chans, uint64_t *n_mid, uint64_t *n_out)

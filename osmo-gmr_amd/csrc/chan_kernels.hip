@@ -343,6 +343,72 @@ __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long l
 	}
 }
 
+// ---------------------------------------------------------------------------
+// k_ddc_fir -- decimating FIR of the direct mode: y[s][m] = rot_s(m) * sum_k taps[s][k] x_s[m D - k].
+// One work-group = 256 consecutive outputs of one carrier: the 256 D + ntaps input samples they span are staged in
+// LDS with coalesced loads (the windows of neighbouring outputs overlap by ntaps - D samples), the carrier's taps too;
+// every thread then runs its own dot product out of LDS.  Stage 1 reads the one wideband stream for every carrier
+// with that carrier's complex taps  taps[k] exp(+j 2 pi f k / fs)  and turns the output by exp(-j 2 pi f m D / fs)
+// (freq_xlating_fir_filter_ccc: the same as mixing x down by f first), the angle reduced in double so that a minute
+// of capture keeps its phase; stage 2 has real taps and no rotation.
+// ---------------------------------------------------------------------------
+static constexpr int kDdcOut = 256;
+
+__global__ __launch_bounds__(256) void k_ddc_fir(DdcFirArgs a)
+{
+	extern __shared__ __align__(16) unsigned char ddc_lds[];
+	float2 *tp = reinterpret_cast<float2 *>(ddc_lds);                     // ntaps
+	float2 *xs = tp + a.ntaps;                                           // kDdcOut * decim + ntaps
+	const int s = blockIdx.y, tid = threadIdx.x;
+	const long long m0 = (long long)blockIdx.x * kDdcOut;
+	const float2 *__restrict__ x = a.x + (long long)s * a.in_stride;
+	const int span = kDdcOut * a.decim + a.ntaps;
+	const long long first = m0 * a.decim - (a.ntaps - 1);                 // oldest sample the block touches
+	for (int i = tid; i < a.ntaps; i += 256)
+		tp[i] = a.taps[(long long)s * a.ntaps + i];
+	for (int i = tid; i < span; i += 256) {
+		const long long n = first + i;
+		xs[i] = (n >= 0 && n < a.n_in) ? x[n] : make_float2(0.f, 0.f);
+	}
+	__syncthreads();
+	const long long m = m0 + tid;
+	if (m >= a.n_out)
+		return;
+	// x[m D - k] = xs[tid D + ntaps - 1 - k]
+	const float2 *w = xs + tid * a.decim + a.ntaps - 1;
+	float ar = 0.f, ai = 0.f;
+	for (int k = 0; k < a.ntaps; k++) {
+		const float2 h = tp[k], v = w[-k];
+		ar = fmaf(h.x, v.x, fmaf(-h.y, v.y, ar));
+		ai = fmaf(h.x, v.y, fmaf(h.y, v.x, ai));
+	}
+	if (a.rot) {
+		double ph = (double)m * a.rot[s];
+		ph -= floor(ph);
+		float sn, cs;
+		__sincosf(-2.0f * kPif * (float)ph, &sn, &cs);
+		const float r = ar * cs - ai * sn, q = ar * sn + ai * cs;
+		ar = r;
+		ai = q;
+	}
+	a.y[(long long)s * a.n_out + m] = make_float2(ar, ai);
+}
+
+hipError_t launch_ddc_fir(const DdcFirArgs &a, hipStream_t stream)
+{
+	if (a.n_out <= 0 || a.n_sel <= 0)
+		return hipSuccess;
+	if (a.ntaps < 1 || a.ntaps > kDdcMaxTaps || a.decim < 1 || a.decim > 64)
+		return hipErrorInvalidValue;
+	const size_t lds = ((size_t)a.ntaps + (size_t)kDdcOut * a.decim + a.ntaps) * sizeof(float2);
+	if (lds > 150 * 1024)
+		return hipErrorInvalidValue;
+	if (lds > 64 * 1024)
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ddc_fir), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(k_ddc_fir, dim3((unsigned)((a.n_out + kDdcOut - 1) / kDdcOut), (unsigned)a.n_sel), dim3(256), lds, stream, a);
+	return hipGetLastError();
+}
+
 hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 {
 	if (a.n_out <= 0 || a.n_slots <= 0)

@@ -255,6 +255,21 @@ struct ResampArgs {
 hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream);
 hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream);
 
+// direct mode of the recorder script (utils/gmr1_rx_sdr.py:605-807): per selected carrier a frequency-translating
+// decimating FIR, then a second decimating FIR (k_ddc_fir, chan_kernels.hip); the arbitrary resampler above follows
+constexpr int kDdcMaxTaps = 256;
+struct DdcFirArgs {
+	int n_sel;                 // carriers
+	int decim, ntaps;
+	long long n_in, n_out;     // samples per stream in / out (n_out = n_in / decim)
+	long long in_stride;       // complex samples between input streams; 0: every carrier reads the same (wideband) stream
+	const float2 *x;
+	const float2 *taps;        // n_sel x ntaps complex taps (stage 1: the low-pass turned to the carrier; stage 2: real taps, im = 0)
+	const double *rot;         // optional, n_sel: output m is multiplied by exp(-j 2 pi frac(m rot[s])) (stage 1)
+	float2 *y;                 // n_sel x n_out
+};
+hipError_t launch_ddc_fir(const DdcFirArgs &a, hipStream_t stream);
+
 hipError_t launch_dkab(const DkabArgs &a, hipStream_t stream);
 hipError_t launch_a5(const A5Args &a, hipStream_t stream);
 // NT9 bursts: FACCH9 and the three TCH9 modes share one decoder kernel (nt9_kernels.hip)

@@ -151,3 +151,58 @@ def test_wideband_sharded_single_rank(gpu_api, pkg):
         mine = rec[rec["arfcn"] == ch]
         mb, nbc, mc, nc, mp = workloads.match_records(mine, sents[ch])
         assert nbc >= 3 and mp == nbc and mc >= nc - 1
+
+
+# ---- direct mode (gmr1_rx_sdr.py:605-807): gmr1_hip_ddc* -----------------------------------------------------------
+@pytest.mark.parametrize("fs", [2.0e6, 1.25e6, 2.5e6, 4.0e6])
+def test_direct_mode_matches_oracle(gpu_api, fs):
+    """Frequency-translating FIR, second FIR, arbitrary resampler against the numpy restatement, at the decimation
+    splits the script picks for these rates (7 x 6, 5 x 5, 7 x 7, 12 x 7), carriers on and off the 31.25 kHz raster."""
+    import orc_chan
+    pl = orc_chan.DirectPlan(fs)
+    d1, d2, rs, n_out = gpu_api.ddc_plan(fs, 4, 200000)
+    assert (d1, d2) == (pl.decim1, pl.decim2) and abs(rs - pl.resamp) < 1e-12
+    rng = np.random.default_rng(int(fs) % 97)
+    n = 200000
+    x = (rng.standard_normal((n, 2)) * 0.3).astype(np.float32).view(np.complex64).reshape(-1)
+    s = np.arange(n)
+    freqs = [3 * 31250.0, -7 * 31250.0 + 400.0, 0.0]
+    for f, a in zip(freqs, (1.0, 0.6, 1.5)):
+        x += (a * np.exp(2j * np.pi * ((f + 900.0) / fs) * s)).astype(np.complex64)
+    got = gpu_api.ddc(x, fs, freqs)
+    assert got.shape == (3, n_out)
+    for i, f in enumerate(freqs):
+        ref = orc_chan.direct_ddc(x, pl, f, n_out=n_out)
+        err = np.max(np.abs(got[i] - ref))
+        assert err < 2e-4 * max(1.0, float(np.sqrt(np.mean(np.abs(ref) ** 2)))), (fs, f, err)
+        z = got[i][1000:9000].astype(np.complex128)
+        fest = np.angle(np.mean(z[1:] * np.conj(z[:-1]))) / (2 * np.pi) * 93600.0
+        assert abs(fest - 900.0) < 40.0, (fs, f, fest)
+
+
+def test_direct_mode_refusals(gpu_api):
+    with pytest.raises(gpu_api.Gmr1HipError, match="-22"):
+        gpu_api.ddc_plan(93600.0 * 20, 4, 1000)           # the reference's own exact case cannot run
+    with pytest.raises(gpu_api.Gmr1HipError, match="-22"):
+        gpu_api.ddc_plan(1.0e6, 4, 1000)                  # rate 0.468: 95 taps per resampler phase
+
+
+def test_direct_mode_decodes_end_to_end(gpu_api, pkg):
+    """Wideband capture -> direct branches of its three carriers -> receive loop: the frames that were sent (the same
+    capture the filterbank test decodes)."""
+    wide, sents = workloads.wideband_capture(pkg, 21, seconds=2.5)
+    chans = sorted(sents)
+    freqs = [(c if c < 32 else c - 64) * 31250.0 for c in chans]
+    streams = gpu_api.ddc(wide, FS, freqs)
+    n = streams.shape[1]
+    iq = streams.reshape(-1)
+    rec, status, chains, found = gpu_api.rx_run(iq, np.arange(len(chans), dtype=np.uint64) * n, np.full(len(chans), n, np.uint64),
+                                                sps=4, arfcn=np.array(chans, np.uint16))
+    assert list(status) == [0] * len(chans)
+    for c in chans:
+        mine = rec[rec["arfcn"] == c]
+        mb, nbc, mc, nc, mp = workloads.match_records(mine, sents[c])
+        n_b = sum(s["type"] == "bcch" for s in sents[c])
+        n_c = sum(s["type"] == "ccch" for s in sents[c])
+        assert nbc >= n_b - 3 and mp == nbc, (c, nbc, n_b, mp)
+        assert nc >= 0.7 * n_c and mc >= nc - 1, (c, nc, n_c, mc)     # (the three filters' start-up costs the first frames)

@@ -63,3 +63,36 @@ def test_tone_lands_in_its_channel_at_its_frequency(fs):
         zz = z[600:4000].astype(np.complex128)
         fest = np.angle(np.mean(zz[1:] * np.conj(zz[:-1]))) / (2 * np.pi) * 93600.0
         assert abs(fest - f) < 5.0 and abs(np.mean(np.abs(zz)) - 1.0) < 0.05
+
+
+def test_direct_mode_plan_numbers_of_the_reference_script():
+    """DirectOutputParameters (gmr1_rx_sdr.py:609-749) at the rates a recorder would use."""
+    import orc_chan
+    p = orc_chan.DirectPlan(2.0e6)
+    # candidates 29..42: 42 = 7 x 6 scores 7*7*6 / (1 + 7/6) = 135.7, the best
+    assert (p.decim1, p.decim2) == (7, 6) and abs(p.resamp - 1.9656) < 1e-12
+    assert (p.taps1.size, p.taps2.size, p.taps_resamp.size) == (57, 145, 717)
+    assert abs(p.taps1.astype(np.float64).sum() - 1.0) < 1e-5 and abs(p.taps2.astype(np.float64).sum() - 1.0) < 1e-5
+    q = orc_chan.DirectPlan(1.25e6)
+    assert (q.decim1, q.decim2) == (5, 5) and abs(q.resamp - 1.872) < 1e-12
+    z = orc_chan.DirectPlan(1.0e6)                      # a second stage of <= 4 is merged into the resampler (:674-677)
+    assert (z.decim1, z.decim2) == (5, 1) and abs(z.resamp - 0.468) < 1e-12
+    with pytest.raises(ValueError):
+        orc_chan.DirectPlan(93600.0 * 20)                # the reference's own exact case does not run (:652-655)
+
+
+def test_direct_mode_brings_a_tone_to_baseband():
+    import orc_chan
+    fs = 2.0e6
+    p = orc_chan.DirectPlan(fs)
+    f_c, df = 5 * 31250.0, 1700.0
+    n = 84000
+    t = np.arange(n)
+    x = np.exp(2j * np.pi * (f_c + df) / fs * t) + 0.5 * np.exp(2j * np.pi * (f_c + 9 * 31250.0) / fs * t)   # + a far carrier
+    y = orc_chan.direct_ddc(x.astype(np.complex64), p, f_c)
+    assert abs(y.size - n / fs * 93600.0) < 40
+    seg = y[400:-50].astype(np.complex128)
+    ph = np.unwrap(np.angle(seg))
+    f_est = (ph[-1] - ph[0]) / (2 * np.pi * (seg.size - 1)) * 93600.0
+    assert abs(f_est - df) < 1.0                          # the wanted tone at its offset ...
+    assert abs(np.abs(seg).mean() - 1.0) < 0.02 and np.abs(seg).std() < 0.02      # ... alone (the far carrier is gone)
