@@ -77,6 +77,12 @@ def preroll(step, seconds):
     only under sustained load, and a measurement of K short launches right after an idle period sees the ramp, not the
     kernel.  Nothing is skipped or cached by this: it is the same step on the same data."""
     import torch
+    # the first timing event recorded on a stream makes the runtime re-arm the queue for timestamps, and the dispatch
+    # that follows waits for it (tens of milliseconds, once per process): that belongs to no step
+    arm = torch.cuda.Event(enable_timing=True)
+    arm.record(torch.cuda.current_stream())
+    step()
+    torch.cuda.synchronize()
     if seconds <= 0:
         return 0
     t_end = time.perf_counter() + seconds
