@@ -541,3 +541,48 @@ def rx_run_full(iq, tch, csd, sps=4, arfcn=0, kc=None, max_records=1 << 16, max_
            out.ctypes.data_as(C.c_void_p), C.c_int(max_records), C.byref(n),
            big.ctypes.data_as(C.c_void_p), C.c_int(max_big), C.byref(nb), C.byref(nch))
     return rv, out[:min(n.value, max_records)].copy(), big[:min(nb.value, max_big)].copy(), nch.value
+
+
+# ---- AMBE speech decoder (oracle/orc_ambe.c) ----
+
+def ambe_state_size():
+    f = lib().orc_ambe_state_size
+    f.restype = C.c_size_t
+    return f()
+
+
+class AmbeDecoder:
+    """One oracle decoder; `cleared=True` selects the other reading of decision D9 (voicing entries above L are 0)."""
+
+    def __init__(self, cleared=False):
+        self.buf = C.create_string_buffer(ambe_state_size())
+        lib().orc_ambe_init(self.buf)
+        lib().orc_ambe_set_cleared(self.buf, C.c_int(1 if cleared else 0))
+
+    def decode(self, frames):
+        """frames [n, 10] uint8 -> (pcm [n, 160] int16, rv [n] int32)"""
+        frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, 10)
+        n = len(frames)
+        pcm = np.zeros((n, 160), np.int16)
+        rv = np.zeros(n, np.int32)
+        lib().orc_ambe_decode_stream(self.buf, _p(frames, C.c_uint8), C.c_int(n), _p(pcm, C.c_int16), _p(rv, C.c_int32))
+        return pcm, rv
+
+    def decode_frame(self, frame, N=160):
+        frame = np.ascontiguousarray(frame, np.uint8)
+        pcm = np.zeros(max(N, 160), np.int16)
+        rv = lib().orc_ambe_decode_frame(self.buf, _p(pcm, C.c_int16), C.c_int(N), _p(frame, C.c_uint8), C.c_int(0))
+        return pcm[:max(N, 160)], rv
+
+    def state_words(self):
+        return np.frombuffer(self.buf.raw, np.uint32).copy()
+
+
+def ambe_decode(frames, cleared=False):
+    return AmbeDecoder(cleared).decode(frames)
+
+
+def ambe_unpack(frame):
+    out = (C.c_uint * 14)()
+    lib().orc_ambe_unpack(_p(np.ascontiguousarray(frame, np.uint8), C.c_uint8), out)
+    return list(out)
