@@ -34,6 +34,7 @@
 #ifndef GMR1_HIP_H
 #define GMR1_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -387,6 +388,29 @@ int gmr1_hip_rx_run_full(int n_arfcn, int sps, const float *iq, const float *tch
                          struct gmr1_hip_rx_record *out, int max_records, int *n_records,
                          struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
                          int32_t *status, int32_t *n_chains);
+
+/* ---- AMBE speech decoder over many voice channels (reference: one `struct gmr1_codec` per channel, frames one call
+ * at a time: include/osmocom/gmr1/codec/codec.h:37-45, src/codec) ----
+ * frames [n_ch][n_frames][10] bytes, pcm [n_ch][n_frames][160] samples, rv (optional) [n_ch][n_frames]: 0, or -EINVAL
+ * for a tone frame with an unassigned code.  One wavefront per channel walks that channel's frames in order.
+ * `state`: gmr1_hip_codec_state_bytes() per channel, 16-byte aligned, opaque, carried between calls so a channel can
+ * be decoded piecewise; gmr1_hip_codec_init_dev makes fresh decoders (the reference's gmr1_codec_alloc).
+ * GMR1_HIP_CODEC_CLEARED: per-harmonic voicing above the harmonic count reads 0 instead of what the same subframe of
+ * an earlier frame left there (DESIGN.md decision D9: the reference leaves it to its stack; the default is what its
+ * own program gmr1_ambe_decode computes).
+ * The host form copies frames in and samples out; state == NULL or GMR1_HIP_CODEC_FRESH: fresh decoders; otherwise
+ * `state` (host memory) is read before and written after. */
+#define GMR1_HIP_CODEC_CLEARED 1
+#define GMR1_HIP_CODEC_FRESH   2
+size_t gmr1_hip_codec_state_bytes(void);
+int gmr1_hip_codec_init_dev(void *stream, int n_ch, void *state, int flags);
+int gmr1_hip_codec_decode_batch_dev(void *stream, int n_ch, int n_frames, const uint8_t *frames, int16_t *pcm,
+                                    int32_t *rv, void *state);
+int gmr1_hip_codec_decode_batch(int n_ch, int n_frames, const uint8_t *frames, int16_t *pcm, int32_t *rv, void *state,
+                                int flags);
+/* The tables the library computes with the host's libm when it loads (cosine table, 2^f0log per pitch history, ...):
+ * for tests; works without a GPU. */
+int gmr1_hip_codec_host_tables(const void **image, size_t *bytes);
 
 /* The GSMTAP packet gmr1_gsmtap_makemsg (reference src/gsmtap.c:43-71, include/osmocom/gmr1/gsmtap.h:35-37)
  * builds for one record: 16-byte gsmtap_hdr + L2.  Returns the packet length (16 + rec->len) or

@@ -613,3 +613,13 @@ float orc_ambe_cos_entry(int i)
 	tables_once();
 	return g_cos[i & 1023];
 }
+
+float orc_ambe_pow2(float x)
+{
+	return powf(2.0f, x);                       /* as frame.c:301, 305 call it */
+}
+
+float orc_ambe_log2_int(int L)
+{
+	return log2f(L);                            /* frame.c:238 */
+}

@@ -41,3 +41,5 @@ float orc_ambe_f0log_sf1(int pitch);
 int orc_ambe_harmonics(float f0);
 int orc_ambe_tone_ampl(int log_ampl);
 float orc_ambe_cos_entry(int i);
+float orc_ambe_pow2(float x);
+float orc_ambe_log2_int(int L);

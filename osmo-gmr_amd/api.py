@@ -60,6 +60,9 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_ddc_plan", "gmr1_hip_ddc_dev", "gmr1_hip_ddc",
     "gmr1_hip_shard_unique_id", "gmr1_hip_shard_create", "gmr1_hip_shard_adopt", "gmr1_hip_shard_destroy",
     "gmr1_hip_rx_run_sharded",
+    "gmr1_codec_alloc", "gmr1_codec_release", "gmr1_codec_decode_frame", "gmr1_codec_decode_dtx",
+    "gmr1_hip_codec_state_bytes", "gmr1_hip_codec_init_dev", "gmr1_hip_codec_decode_batch_dev",
+    "gmr1_hip_codec_decode_batch", "gmr1_hip_codec_host_tables",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -1361,3 +1364,97 @@ class Shard:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------
+# AMBE speech decoder (include/osmocom/gmr1/codec/codec.h, gmr1_hip_codec_*)
+# ---------------------------------------------------------------------------
+CODEC_CLEARED, CODEC_FRESH = 1, 2
+
+
+def codec_state_bytes() -> int:
+    f = load().gmr1_hip_codec_state_bytes
+    f.restype = C.c_size_t
+    return f()
+
+
+def codec_decode_batch(frames, state=None, flags=0):
+    """frames (n_ch, n_frames, 10) uint8 -> (pcm (n_ch, n_frames, 160) int16, rv (n_ch, n_frames) int32, state).
+    state: None = fresh decoders, or the uint8 array a previous call returned (continues those channels)."""
+    frames, p_f = _np(frames, np.uint8)
+    assert frames.ndim == 3 and frames.shape[2] == 10
+    n_ch, n_fr = frames.shape[:2]
+    pcm = np.zeros((n_ch, n_fr, 160), np.int16)
+    rv = np.zeros((n_ch, n_fr), np.int32)
+    if state is None:
+        state = np.zeros((n_ch, codec_state_bytes()), np.uint8)
+        flags |= CODEC_FRESH
+    else:
+        state = np.ascontiguousarray(state, np.uint8).copy()
+        assert state.shape == (n_ch, codec_state_bytes())
+    _check(load().gmr1_hip_codec_decode_batch(C.c_int(n_ch), C.c_int(n_fr), p_f, pcm.ctypes.data_as(C.c_void_p),
+                                              rv.ctypes.data_as(C.c_void_p), state.ctypes.data_as(C.c_void_p),
+                                              C.c_int(flags)), "gmr1_hip_codec_decode_batch")
+    return pcm, rv, state
+
+
+def codec_init_dev(stream, n_ch, state_ptr, flags=0):
+    _check(load().gmr1_hip_codec_init_dev(C.c_void_p(stream) if stream else None, C.c_int(n_ch), C.c_void_p(state_ptr),
+                                          C.c_int(flags)), "gmr1_hip_codec_init_dev")
+
+
+def codec_decode_batch_dev(stream, n_ch, n_frames, frames_ptr, pcm_ptr, rv_ptr, state_ptr):
+    _check(load().gmr1_hip_codec_decode_batch_dev(C.c_void_p(stream) if stream else None, C.c_int(n_ch), C.c_int(n_frames),
+                                                  C.c_void_p(frames_ptr), C.c_void_p(pcm_ptr),
+                                                  C.c_void_p(rv_ptr) if rv_ptr else None, C.c_void_p(state_ptr)),
+           "gmr1_hip_codec_decode_batch_dev")
+
+
+class Codec:
+    """The reference's one-channel object: gmr1_codec_alloc / decode_frame / decode_dtx / release."""
+
+    def __init__(self):
+        f = load().gmr1_codec_alloc
+        f.restype = C.c_void_p
+        self.h = f()
+        if not self.h:
+            raise Gmr1HipError("gmr1_codec_alloc returned NULL: " + load().gmr1_hip_last_error().decode(errors="replace"))
+
+    def decode_frame(self, frame, N=160, bad=0):
+        frame, p_f = _np(frame, np.uint8)
+        audio = np.zeros(max(N, 160), np.int16)
+        rc = load().gmr1_codec_decode_frame(C.c_void_p(self.h), audio.ctypes.data_as(C.c_void_p), C.c_int(N), p_f, C.c_int(bad))
+        return audio, rc
+
+    def decode_dtx(self, N=160):
+        audio = np.ones(N, np.int16)
+        rc = load().gmr1_codec_decode_dtx(C.c_void_p(self.h), audio.ctypes.data_as(C.c_void_p), C.c_int(N))
+        return audio, rc
+
+    def release(self):
+        if self.h:
+            load().gmr1_codec_release(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+# layout of the host table image (csrc/ambe_dev.h: struct AmbeTab), for the tests that check it without a GPU
+CODEC_TAB_DTYPE = np.dtype([
+    ("cosv", "<f4", 1024), ("win", "<f4", 128), ("f0_sf1", "<f4", 128), ("log2_L", "<f4", 64), ("tone_ampl", "<i4", 256),
+    ("lcg_mul", "<u4", 128), ("lcg_add", "<u4", 128), ("gain", "<f4", 512), ("prba12", "<f4", 256), ("prba34", "<f4", 128),
+    ("prba57", "<f4", 384), ("hoc", "<f4", (4, 512)), ("interp", "<f4", 4), ("perr14", "<f4", 256), ("perr58", "<f4", 128),
+    ("rho", "<f4", 56), ("vuv", "<u2", 64), ("hpg", "u1", 192), ("f0_sf0", "<f4", (129, 128, 4)),
+])
+
+
+def codec_host_tables():
+    img, n = C.c_void_p(), C.c_size_t()
+    _check(load().gmr1_hip_codec_host_tables(C.byref(img), C.byref(n)), "gmr1_hip_codec_host_tables")
+    assert n.value == CODEC_TAB_DTYPE.itemsize, (n.value, CODEC_TAB_DTYPE.itemsize)
+    raw = C.string_at(img.value, n.value)
+    return np.frombuffer(raw, CODEC_TAB_DTYPE)[0]

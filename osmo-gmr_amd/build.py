@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgmr1_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["rx_kernels.hip", "fcch_kernels.hip", "l1_kernels.hip", "tch_kernels.hip", "chan_kernels.hip", "nt9_kernels.hip", "xch_kernels.hip", "tx_kernels.hip"]
-CXX_SOURCES = ["capi.cpp", "capi_fcch.cpp", "capi_l1.cpp", "capi_detect.cpp", "capi_rx.cpp", "capi_tch.cpp", "capi_chan.cpp", "capi_nt9.cpp", "capi_xch.cpp", "capi_tx.cpp", "host_tables.cpp", "l1_tables.cpp", "l1_punct.cpp", "capi_shard.cpp"]
+HIP_SOURCES = ["rx_kernels.hip", "fcch_kernels.hip", "l1_kernels.hip", "tch_kernels.hip", "chan_kernels.hip", "nt9_kernels.hip", "xch_kernels.hip", "tx_kernels.hip", "ambe_kernels.hip"]
+CXX_SOURCES = ["capi.cpp", "capi_fcch.cpp", "capi_l1.cpp", "capi_detect.cpp", "capi_rx.cpp", "capi_tch.cpp", "capi_chan.cpp", "capi_nt9.cpp", "capi_xch.cpp", "capi_tx.cpp", "host_tables.cpp", "l1_tables.cpp", "l1_punct.cpp", "capi_shard.cpp", "capi_ambe.cpp", "ambe_tables.cpp"]
 
 COMMON = [
     "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
