@@ -19,6 +19,8 @@ REF = "/root/reference"
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 LIB = os.path.join(REF_DIR, "libgmr1_codec_ref.so")
 TOOL = os.path.join(REF_DIR, "gmr1_ambe_decode")
+TOOL_HIP = os.path.join(REF_DIR, "gmr1_ambe_decode_hip")      # the same main(), linked against libgmr1_hip.so instead
+HIP_LIB = os.path.join(ROOT, "osmo-gmr_amd", "libgmr1_hip.so")
 CODEC_FILES = ["ambe", "codec", "frame", "math", "synth", "tables", "tone"]
 
 
@@ -34,7 +36,23 @@ def build():
             os.path.join(REF, "src", "codec", f + ".c") for f in CODEC_FILES]
         if not os.path.exists(TOOL) or any(os.path.getmtime(s) > os.path.getmtime(TOOL) for s in srcs):
             subprocess.check_call(["gcc", "-O2", "-g", "-I" + os.path.join(REF, "include"), "-o", TOOL] + srcs + ["-lm"])
+        build_program_on_product()
     return os.path.exists(LIB) and os.path.exists(TOOL)
+
+
+def build_program_on_product():
+    """The reference's src/gmr1_ambe_decode.c, unchanged, compiled against THIS repo's include/ and linked against
+    libgmr1_hip.so (no other object): the drop-in check for the codec calls.  Returns the path or None."""
+    main_c = os.path.join(REF, "src", "gmr1_ambe_decode.c")
+    if not (os.path.isfile(main_c) and os.path.exists(HIP_LIB)):
+        return TOOL_HIP if os.path.exists(TOOL_HIP) else None
+    if not os.path.exists(TOOL_HIP) or max(os.path.getmtime(main_c), os.path.getmtime(HIP_LIB)) > os.path.getmtime(TOOL_HIP):
+        os.makedirs(REF_DIR, exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror=implicit-function-declaration",
+                               "-I" + os.path.join(ROOT, "include"), "-o", TOOL_HIP, main_c,
+                               "-Wl,--no-undefined", "-L" + os.path.dirname(HIP_LIB), "-l:" + os.path.basename(HIP_LIB),
+                               "-Wl,-rpath,$ORIGIN/../../osmo-gmr_amd"])
+    return TOOL_HIP
 
 
 def available():
@@ -68,11 +86,14 @@ def decode_clean_stack(frames):
     return pcm, rv
 
 
-def decode_with_program(frames):
+def decode_with_program(frames, tool=None, wav=False):
     """The reference's program on a file of frames -> pcm [m, 160] (m < n if it stopped at a frame it rejects)."""
     frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, 10)
     with tempfile.TemporaryDirectory() as d:
-        fin, fout = os.path.join(d, "in.dat"), os.path.join(d, "out.raw")
+        fin, fout = os.path.join(d, "in.dat"), os.path.join(d, "out.wav" if wav else "out.raw")
         frames.tofile(fin)
-        subprocess.run([TOOL, fin, fout], check=True, stderr=subprocess.DEVNULL)
-        return np.fromfile(fout, np.int16).reshape(-1, 160)
+        subprocess.run([tool or TOOL, fin, fout], check=True, stderr=subprocess.DEVNULL, timeout=300)
+        raw = np.fromfile(fout, np.uint8)
+        if wav:
+            raw = raw[44:]
+        return raw.view(np.int16).reshape(-1, 160)

@@ -139,3 +139,23 @@ def test_device_pointers_and_streams(api):
     st.synchronize()
     host, hrv, _ = api.codec_decode_batch(fr)
     assert np.array_equal(d_pcm.cpu().numpy(), host) and not d_rv.cpu().numpy().any()
+
+
+def test_the_reference_program_running_on_this_library(gold):
+    """src/gmr1_ambe_decode.c, unchanged, linked against libgmr1_hip.so (built in the container, where the reference's
+    sources are: oracle/_ref/gmr1_ambe_decode_hip) reads a file of frames and writes the file the reference writes.
+    It is a second GPU process started from this one, so it only runs on request and on its own, before this process
+    has touched the GPU:  GMR1_RUN_REF_PROGRAM=1 python -m pytest tests/test_gpu_ambe.py -m gpu -k running_on_this_library
+    (profiles/r02r_ref_program_on_hip.log is such a run)."""
+    import ref_codec
+    if os.environ.get("GMR1_RUN_REF_PROGRAM") != "1":
+        pytest.skip("set GMR1_RUN_REF_PROGRAM=1 and select this test alone")
+    exe = ref_codec.build_program_on_product()
+    if not exe:
+        pytest.skip("the program was not built (no reference sources on the machine that made this snapshot)")
+    fr = gold["mixed_frames"]
+    got = ref_codec.decode_with_program(fr, tool=exe)
+    assert got.shape == gold["mixed_pcm"].shape
+    compare(got, gold["mixed_pcm"], "reference main() on libgmr1_hip.so")
+    wav = ref_codec.decode_with_program(fr[:50], tool=exe, wav=True)
+    assert np.array_equal(wav, got[:50])

@@ -144,3 +144,15 @@ def test_gmr1_rx_compiles_and_links_unchanged(pkg, tmp_path):
     # it loads and runs up to its argument check (reference gmr1_rx.c:912-915: usage, exit code != 0)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert "Usage:" in r.stderr and "bcch.cfile" in r.stderr
+
+
+def test_gmr1_ambe_decode_compiles_and_links_unchanged(pkg):
+    """The vocoder's program needs nothing third-party: src/gmr1_ambe_decode.c + include/ + libgmr1_hip.so is a
+    complete link (--no-undefined), and the only gmr1_* symbols it takes are the three codec calls."""
+    import ref_codec
+    exe = ref_codec.build_program_on_product()
+    assert exe and os.path.exists(exe)
+    undef = _nm(exe, "-u")
+    gmr1 = {x.split("@")[0] for x in undef if x.startswith("gmr1_")}
+    assert gmr1 == {"gmr1_codec_alloc", "gmr1_codec_release", "gmr1_codec_decode_frame"}
+    assert gmr1 <= _nm(pkg.build.LIB, "-D", "--defined-only")
