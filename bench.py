@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--cpu-passes", type=int, default=3,
                     help="bursts workload: passes of the CPU oracle over its sample (3 x 100k bursts = about 11 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--workload", default="bursts", choices=["bursts", "fcch", "tch3", "nt3", "rx", "chan"],
+    ap.add_argument("--workload", default="bursts", choices=["bursts", "fcch", "tch3", "nt3", "rx", "chan", "ambe"],
                     help="bursts = configs[2] (default, the headline metric); fcch = configs[1] rough sweep "
                          "over 1-s streams; tch3 = configs[4] l1-only TCH3 decode; nt3 = configs[4] from samples (90 %% speech + 10 %% FACCH3: demod + "
                          "layer 1); rx = configs[3] the whole "
@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--arfcns", type=int, default=64, help="rx workload: BCCH carriers per GPU")
     ap.add_argument("--seconds", type=float, default=60.0, help="rx workload: capture length")
     ap.add_argument("--streams", type=int, default=1024, help="fcch workload: 1-s streams per GPU")
+    ap.add_argument("--channels", type=int, default=8192, help="ambe workload: voice channels per GPU")
+    ap.add_argument("--frames", type=int, default=100, help="ambe workload: 20 ms frames per channel and step")
     ap.add_argument("--shard-arfcns", type=int, default=64, help="N > 1: carriers of the sharded config-4 run (extra keys)")
     ap.add_argument("--shard-seconds", type=float, default=60.0, help="N > 1: capture length of the sharded config-4 run")
     ap.add_argument("--no-shard", action="store_true", help="N > 1: skip the sharded config-4 run")
@@ -158,6 +160,95 @@ def run_chan_workload(args):
         outj["cpu_baseline"] = {"value": m / tc / 1e6, "unit": "Msamp/s", "cores": 1, "kind": "port",
                                 "sample": f"first {m} wideband samples, 3 of 64 output branches, numpy oracle, {tc:.1f} s"}
         outj["checks"] = {"max_abs_err_vs_oracle": err}
+    print(json.dumps(outj))
+
+
+def run_ambe_workload(args):
+    """SURVEY.md 8 row f4, last part: the AMBE vocoder (reference src/codec, gmr1_ambe_decode).  One step = `frames`
+    consecutive 20 ms frames of each of `channels` voice channels -> PCM, decoder states carried in HBM from step to
+    step like a running call (gmr1_hip_codec_decode_batch_dev)."""
+    import torch
+    from __graft_entry__ import load_package
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    pkg = load_package()
+    api = pkg.api
+    api.load()
+    api.init(0)
+    n_ch, n_fr = args.channels, args.frames
+    t_gen = time.perf_counter()
+    host = pkg.synth.ambe_speech_frames(n_ch, n_fr, seed=9)
+    t_gen = time.perf_counter() - t_gen
+    frames = torch.from_numpy(host).to(dev)
+    pcm = torch.empty((n_ch, n_fr, 160), dtype=torch.int16, device=dev)
+    rv = torch.empty((n_ch, n_fr), dtype=torch.int32, device=dev)
+    state = torch.zeros((n_ch, api.codec_state_bytes()), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    api.codec_init_dev(stream.cuda_stream, n_ch, state.data_ptr())
+    # the first step from fresh decoders is the one that is checked
+    api.codec_decode_batch_dev(stream.cuda_stream, n_ch, n_fr, frames.data_ptr(), pcm.data_ptr(), rv.data_ptr(), state.data_ptr())
+    torch.cuda.synchronize()
+    first = pcm[:16].cpu().numpy()
+
+    def step():
+        api.codec_decode_batch_dev(stream.cuda_stream, n_ch, n_fr, frames.data_ptr(), pcm.data_ptr(), rv.data_ptr(),
+                                   state.data_ptr())
+    preroll(step, args.preroll_s)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps
+    total = n_ch * n_fr
+    # algorithmic bytes: 10 in + 320 out per frame, the decoder state read and written once per channel and launch
+    alg = total * (10 + 320 + 4) + 2 * n_ch * api.codec_state_bytes()
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+    outj = {"metric": "Mbursts/s demod+Viterbi (and IQ Msamp/s), 1/2/4/8 MI355X", "value": total * args.steps / wall / 1e6,
+            "unit": "Mframes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"AMBE speech decoder: {n_ch} voice channels x {n_fr} frames of 20 ms per step, "
+                                   "10-byte frames -> 160 samples of 8 kHz PCM, decoder states resident",
+                       "realtime_factor": total * 0.02 * args.steps / wall, "pcm_msamp_per_s": total * 160 * args.steps / wall / 1e6},
+            "roofline": {"bound": "hbm", "kernel": "k_ambe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg,
+                         "note": "330 bytes per frame against tens of thousands of table-cosine multiply-adds: the kernel is "
+                                 "VALU / LDS bound by construction (DESIGN.md 4.6), the HBM fraction is reported for form"},
+            "checks": {"workload_gen_s": round(t_gen, 2), "rejected_frames": int((rv != 0).sum().item())}}
+    if not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        import ref_codec
+        m_ch = min(n_ch, 2048)
+        have_ref = os.path.exists(ref_codec.LIB)
+        tc = time.perf_counter()
+        differ = 0
+        for c in range(m_ch):
+            if have_ref:
+                got, _ = ref_codec.decode_clean_stack(host[c])
+            else:
+                got, _ = oracle_lib.ambe_decode(host[c])
+            if c < 16 and not have_ref:
+                differ += int((got != first[c]).sum())
+        tc = time.perf_counter() - tc
+        if have_ref:      # the check is against the oracle's default reading (what the reference's program computes)
+            differ = sum(int((oracle_lib.ambe_decode(host[c])[0] != first[c]).sum()) for c in range(16))
+        outj["cpu_baseline"] = {"value": m_ch * n_fr / tc / 1e6, "unit": "Mframes/s", "cores": 1,
+                                "kind": "reference" if have_ref else "port",
+                                "sample": f"the first {m_ch} channels x {n_fr} frames of the same workload, "
+                                          + ("the reference's src/codec compiled from its sources (oracle/_ref), one call "
+                                             "per frame through oracle/ref_codec_shim.c" if have_ref else "gcc -O2 oracle")
+                                          + f", 1 thread, {tc:.1f} s"}
+        outj["checks"]["samples_differing_from_oracle_first_16_channels"] = differ
+        outj["checks"]["samples_compared"] = int(first.size)
     print(json.dumps(outj))
 
 
@@ -720,6 +811,8 @@ def main():
         return run_rx_workload(args)
     if args.workload == "chan":
         return run_chan_workload(args)
+    if args.workload == "ambe":
+        return run_ambe_workload(args)
     if args.workload != "bursts":
         return run_side_workload(args)
     import torch

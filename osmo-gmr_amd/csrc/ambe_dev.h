@@ -58,6 +58,20 @@ struct AmbeTab {
 	float f0_sf0[129 * 128 * 4];       // powf(2, interpolated f0log) by (previous pitch index, pitch, rule), frame.c:303-305
 };
 
+// Two more tables, too large for AmbeTab and built on the device itself (k_ambe_noise_table, k_ambe_cs_table) with
+// the very operations the synthesiser would otherwise repeat for every subframe:
+//  * noise_dft[x][bin] = (re, im) of the 128-point DFT of the windowed noise sequence the generator produces from
+//    state x (synth.c:127-134, math.c:118-138).  The generator has 53125 states (x -> 171 x + 11213 mod 53125, full
+//    period) and nothing else enters that spectrum, so it is a table: 53125 x 65 x 8 bytes = 27.6 MB of HBM.
+//  * cs[bin][n] = (cos, sin) table values the inverse DFT multiplies with (math.c:142-163): the table index is a
+//    truncated float product of constants, the same for every frame.
+constexpr int kAmbeNoiseStates = 53125;
+constexpr int kAmbeBins = 65;
+struct AmbeBig {
+	float2 noise_dft[kAmbeNoiseStates][kAmbeBins];
+	float2 cs[kAmbeBins][128];
+};
+
 struct AmbeArgs {
 	int n_ch, n_frames;
 	const uint8_t *frames;             // [n_ch][n_frames][10]
@@ -66,10 +80,13 @@ struct AmbeArgs {
 	int32_t *rv;                       // optional [n_ch][n_frames]: 0 or -EINVAL (tone.c:197-201)
 	AmbeState *state;                  // [n_ch], read and written
 	const AmbeTab *tab;
+	const AmbeBig *big;
 	int tone_n;                        // the N of gmr1_codec_decode_frame: samples a tone frame covers (160 in batches)
+	int dbg;                           // timing experiments only (GMR1_HIP_AMBE_DBG): 1 no noise path, 2 no oscillators, 4 no parameter decode
 };
 
 hipError_t launch_ambe(const AmbeArgs &a, hipStream_t stream);
 hipError_t launch_ambe_init(AmbeState *state, int n_ch, int flags, hipStream_t stream);
+hipError_t launch_ambe_big(const AmbeTab *tab, AmbeBig *big, hipStream_t stream);
 
 }  // namespace gmr1

@@ -17,6 +17,8 @@
 // cosf): within one unit in the last place of glibc's float results, which moves a PCM sample by one step at most
 // and only when the sum sits on an integer boundary (tests/test_gpu_ambe.py counts them).
 
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include "ambe_dev.h"
@@ -178,6 +180,52 @@ __global__ __launch_bounds__(64) void k_ambe_init(AmbeState *state, int n_ch, in
 	}
 }
 
+// AmbeBig::noise_dft, one generator state per work-group: the noise sequence (synth.c:98-110), its window
+// (synth.c:130-131) and the forward DFT (math.c:118-138), one bin per lane, samples in order
+__global__ __launch_bounds__(64) void k_ambe_noise_table(const AmbeTab *tab, AmbeBig *big)
+{
+	__shared__ float cosv[1024];
+	__shared__ float t[128];
+	const int lane = (int)threadIdx.x;
+	const uint32_t x0 = blockIdx.x;
+	const AmbeTab &T = *tab;
+	for (int i = lane; i < 1024; i += 64)
+		cosv[i] = T.cosv[i];
+	for (int i = lane; i < 128; i += 64) {
+		const uint32_t u = (T.lcg_mul[i] * x0 + T.lcg_add[i]) % 53125u;
+		t[i] = i < 121 ? (float)u * T.win[i] : 0.0f;
+	}
+	__syncthreads();
+	const float c1 = (-2.0f * kPi / 128.0f);
+	const float sc = 512.0f / kPi;
+	for (int r = 0; r < 2; r++) {
+		const int bin = lane + 64 * r;
+		if (bin > 64)
+			break;
+		const float cb = c1 * (float)bin;
+		float ar = 0.0f, ai = 0.0f;
+		for (int n = 0; n < 121; n++) {
+			const float ang = cb * (float)n;
+			const int idx = (int)(ang * sc);
+			const float x = t[n];
+			ar += x * cosv[idx & 1023];
+			ai += x * cosv[(idx + 768) & 1023];
+		}
+		big->noise_dft[x0][bin] = make_float2(ar, ai);
+	}
+}
+
+// AmbeBig::cs: the table entries cosf_fast / sinf_fast return for the angle (-2 pi / 128) bin n (math.c:152-156)
+__global__ __launch_bounds__(128) void k_ambe_cs_table(const AmbeTab *tab, AmbeBig *big)
+{
+	const int n = (int)threadIdx.x, bin = (int)blockIdx.x;
+	const float c1 = (-2.0f * kPi / 128.0f);
+	const float sc = 512.0f / kPi;
+	const float ang = (c1 * (float)bin) * (float)n;
+	const int idx = (int)(ang * sc);
+	big->cs[bin][n] = make_float2(tab->cosv[idx & 1023], tab->cosv[(idx + 768) & 1023]);
+}
+
 __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 {
 	__shared__ AmbeLds s;
@@ -333,7 +381,7 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 			const int Lp = uni(prev_L);
 
 			// -- second subframe's log magnitudes (frame.c:175-242) --
-			{
+			if (!(a.dbg & 4)) {
 				const int L = Ls[1];
 				float v = regrid(s.mlog_prev, Lp, L, lane) * 0.65f;
 				// PRBA vector -> 8 points (lanes 0..7)
@@ -385,7 +433,7 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 			}
 			WSYNC();
 			// -- first subframe's (frame.c:246-286) --
-			{
+			if (!(a.dbg & 4)) {
 				const int L = Ls[0];
 				const float from_before = regrid(s.mlog_prev, Lp, L, lane);
 				const float from_after = regrid(s.mlog[1], Ls[1], L, lane);
@@ -486,41 +534,24 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 				const int last_edge = uni(s.edge[L]);
 
 				float nu0 = 0.0f, nu1 = 0.0f;      // new unvoiced samples n = lane, lane + 64
-				// noise generator: 121 values, continuing 80 further on (synth.c:98-110, 127-128)
-				{
-					const uint32_t x0 = u_last & 0xffffu;
-					const uint32_t ua = (T.lcg_mul[lane] * x0 + T.lcg_add[lane]) % 53125u;
-					const uint32_t ub = (T.lcg_mul[(lane + 64) & 127] * x0 + T.lcg_add[(lane + 64) & 127]) % 53125u;
-					s.t[lane] = (float)ua * s.win[lane];
-					s.t[lane + 64] = lane + 64 < 121 ? (float)ub * s.win[lane + 64] : 0.0f;
-					u_last = (uint32_t)__builtin_amdgcn_readlane((int)ub, 79 - 64);
-				}
-				WSYNC();
-				if (any_noise) {
-					// forward DFT, one bin per lane (math.c:118-138); bin 64 only when a band reaches it (D10 inputs)
-					const bool need64 = last_edge > 64;
-					const float c1 = (-2.0f * kPi / 128.0f);
-					const float sc = 512.0f / kPi;
-					for (int r = 0; r < (need64 ? 2 : 1); r++) {
-						const int bin = lane + 64 * r;
-						const float cb = c1 * (float)bin;
-						float ar = 0.0f, ai = 0.0f;
-						for (int n = 0; n < 121; n++) {
-							const float ang = cb * (float)n;
-							const int idx = (int)(ang * sc);
-							const float x = s.t[n];
-							ar += x * ct[idx & 1023];
-							ai += x * ct[(idx + 768) & 1023];
+				// noise generator: this subframe's 121 values start from u_last, the next one's 80 further on
+				// (synth.c:98-110, 127-128); their windowed spectrum is a function of u_last alone: AmbeBig::noise_dft
+				const uint32_t x0 = u_last & 0xffffu;
+				u_last = (T.lcg_mul[79] * x0 + T.lcg_add[79]) % 53125u;
+				if (any_noise && !(a.dbg & 1)) {
+					const bool need64 = last_edge > 64;        // a band reaches the last bin: decision D10 inputs only
+					const float2 *row = a.big->noise_dft[x0 < (uint32_t)kAmbeNoiseStates ? x0 : 0];
+					{
+						const float2 v = row[lane];
+						s.re[lane] = v.x;
+						s.im[lane] = v.y;
+						s.pw[lane] = v.x * v.x + v.y * v.y;
+						if (lane == 0) {
+							const float2 w = need64 ? row[64] : make_float2(0.0f, 0.0f);
+							s.re[64] = w.x;
+							s.im[64] = w.y;
+							s.pw[64] = w.x * w.x + w.y * w.y;
 						}
-						if (bin <= 64) {
-							s.re[bin] = ar;
-							s.im[bin] = ai;
-							s.pw[bin] = ar * ar + ai * ai;
-						}
-					}
-					if (!need64 && lane == 0) {
-						s.re[64] = 0.0f;
-						s.im[64] = 0.0f;
 					}
 					WSYNC();
 					// per harmonic: energy of its bins -> scale factor
@@ -555,25 +586,22 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 					WSYNC();
 					const bool live64 = need64 && (s.re[64] != 0.0f || s.im[64] != 0.0f);
 					// inverse DFT, samples n = lane and lane + 64 (math.c:142-163); zero bins add nothing
-					const float n0f = (float)lane, n1f = (float)(lane + 64);
 					float a0 = 0.0f, a1 = 0.0f;
 					uint64_t todo = live;
 					while (todo) {
 						const int k = __builtin_ctzll(todo);
 						todo &= todo - 1;
-						const float ck = c1 * (float)k;
 						const float twice = k == 0 ? 1.0f : 2.0f;
 						const float br = s.re[k], bi = s.im[k];
-						const int ia = (int)((ck * n0f) * sc), ib = (int)((ck * n1f) * sc);
-						a0 += twice * (br * ct[ia & 1023] + bi * ct[(ia + 768) & 1023]);
-						a1 += twice * (br * ct[ib & 1023] + bi * ct[(ib + 768) & 1023]);
+						const float2 ca = a.big->cs[k][lane], cb = a.big->cs[k][lane + 64];
+						a0 += twice * (br * ca.x + bi * ca.y);
+						a1 += twice * (br * cb.x + bi * cb.y);
 					}
 					if (live64) {
-						const float ck = c1 * 64.0f;
 						const float br = s.re[64], bi = s.im[64];
-						const int ia = (int)((ck * n0f) * sc), ib = (int)((ck * n1f) * sc);
-						a0 += 1.0f * (br * ct[ia & 1023] + bi * ct[(ia + 768) & 1023]);
-						a1 += 1.0f * (br * ct[ib & 1023] + bi * ct[(ib + 768) & 1023]);
+						const float2 ca = a.big->cs[64][lane], cb = a.big->cs[64][lane + 64];
+						a0 += 1.0f * (br * ca.x + bi * ca.y);
+						a1 += 1.0f * (br * cb.x + bi * cb.y);
 					}
 					nu0 = a0 / 128.0f;
 					nu1 = a1 / 128.0f;
@@ -637,7 +665,7 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 				const float wc0 = i0 >= 21 ? s.win[i0 - 20] : 0.0f;         // current subframe fades in from sample 21
 				const float wc1 = i1 < 80 ? s.win[i1 - 20] : 0.0f;
 				const float wo0 = i0 < 60 ? s.win[i0 + 60] : 0.0f;          // previous one fades out until sample 59
-				for (int l = 0; l < Lmax; l++) {
+				for (int l = 0; l < ((a.dbg & 2) ? 0 : Lmax); l++) {
 					const uint64_t bit = 1ull << l;
 					if (m_smooth & bit) {
 						const float a_m = lane_get(mg_was, l), a_dm = lane_get(dm, l), a_ph = lane_get(ph_was, l);
@@ -714,7 +742,21 @@ hipError_t launch_ambe(const AmbeArgs &a, hipStream_t stream)
 {
 	if (a.n_ch <= 0 || a.n_frames <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_ambe, dim3(a.n_ch), dim3(64), 0, stream, a);
+	static int dbg = -1;
+	if (dbg < 0) {
+		const char *e = getenv("GMR1_HIP_AMBE_DBG");
+		dbg = e ? atoi(e) : 0;
+	}
+	AmbeArgs b = a;
+	b.dbg = dbg;
+	hipLaunchKernelGGL(k_ambe, dim3(a.n_ch), dim3(64), 0, stream, b);
+	return hipGetLastError();
+}
+
+hipError_t launch_ambe_big(const AmbeTab *tab, AmbeBig *big, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_ambe_noise_table, dim3(kAmbeNoiseStates), dim3(64), 0, stream, tab, big);
+	hipLaunchKernelGGL(k_ambe_cs_table, dim3(kAmbeBins), dim3(128), 0, stream, tab, big);
 	return hipGetLastError();
 }
 

@@ -123,8 +123,9 @@ const AmbeTab *host_tab()
 constexpr int kMaxDev = 16;
 std::mutex g_mu;
 AmbeTab *g_dev_tab[kMaxDev];
+AmbeBig *g_dev_big[kMaxDev];
 
-int dev_tab(const AmbeTab **out)
+int dev_tab(const AmbeTab **out, const AmbeBig **big)
 {
 	DevState *s;
 	int r = dev_state(&s);
@@ -142,8 +143,15 @@ int dev_tab(const AmbeTab **out)
 		HIP_TRY(hipMalloc(&d, sizeof(AmbeTab)));
 		HIP_TRY(hipMemcpy(d, h, sizeof(AmbeTab), hipMemcpyHostToDevice));
 		g_dev_tab[dev] = static_cast<AmbeTab *>(d);
+		// the two tables the device builds for itself (ambe_dev.h: AmbeBig), once per device
+		void *b = nullptr;
+		HIP_TRY(hipMalloc(&b, sizeof(AmbeBig)));
+		HIP_TRY(launch_ambe_big(g_dev_tab[dev], static_cast<AmbeBig *>(b), nullptr));
+		HIP_TRY(hipStreamSynchronize(nullptr));
+		g_dev_big[dev] = static_cast<AmbeBig *>(b);
 	}
 	*out = g_dev_tab[dev];
+	*big = g_dev_big[dev];
 	return 0;
 }
 
@@ -153,7 +161,8 @@ int decode_dev(hipStream_t st, int n_ch, int n_frames, const uint8_t *frames, in
 	if (n_ch < 0 || n_frames < 0)
 		return fail(-EINVAL, "codec: negative channel or frame count");
 	const AmbeTab *t;
-	int r = dev_tab(&t);
+	const AmbeBig *big;
+	int r = dev_tab(&t, &big);
 	if (r) return r;
 	if (n_ch == 0 || n_frames == 0)
 		return 0;
@@ -170,7 +179,9 @@ int decode_dev(hipStream_t st, int n_ch, int n_frames, const uint8_t *frames, in
 	a.rv = rv;
 	a.state = static_cast<AmbeState *>(state);
 	a.tab = t;
+	a.big = big;
 	a.tone_n = tone_n;
+	a.dbg = 0;
 	HIP_TRY(launch_ambe(a, st));
 	return 0;
 }

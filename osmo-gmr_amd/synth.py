@@ -685,3 +685,44 @@ def synth_tch3_carrier(fmt_speech: BurstFormat, fmt_facch: BurstFormat, n_sample
         n = np.arange(n_samples, dtype=np.float64)
         x *= np.exp(1j * (2 * np.pi * cfo_hz / (SYM_RATE * sps)) * n).astype(np.complex64)
     return x, sent
+
+
+# ---------------------------------------------------------------------------
+# AMBE speech frames (the vocoder's input): bit layout of reference src/codec/frame.c:56-75
+# ---------------------------------------------------------------------------
+AMBE_LAYOUT = {   # field -> [(first bit, bits)], most significant part first
+    "pitch": [(0, 7)], "gain": [(7, 6), (50, 2)], "vuv": [(13, 6)], "prba12": [(19, 6), (52, 1)],
+    "prba34": [(25, 3), (53, 3)], "prba57": [(28, 3), (56, 4)], "hoc0": [(31, 3), (60, 4)],
+    "hoc1": [(34, 3), (64, 3)], "hoc2": [(37, 2), (67, 4)], "hoc3": [(39, 2), (71, 3)],
+    "perr14": [(41, 3), (74, 3)], "perr58": [(44, 2), (77, 3)], "mag_rule": [(46, 2)], "pitch_rule": [(48, 2)],
+}
+
+
+def ambe_pack(fields, shape):
+    """fields: name -> integer array of `shape` -> frames shape + (10,) uint8."""
+    bits = np.zeros(tuple(shape) + (80,), np.uint8)
+    for name, parts in AMBE_LAYOUT.items():
+        v = np.asarray(fields.get(name, 0), np.int64) + np.zeros(shape, np.int64)
+        left = sum(n for _, n in parts)
+        for first, n in parts:
+            left -= n
+            for k in range(n):
+                bits[..., first + k] = (v >> (left + n - 1 - k)) & 1
+    return np.packbits(bits, axis=-1)
+
+
+def ambe_speech_frames(n_ch, n_frames, seed=0):
+    """(n_ch, n_frames, 10) speech frames: pitch and gain wander slowly and the pitch repeats now and then (voiced
+    speech keeps its pitch for a few frames), every other quantiser index is uniform.  The first frame of a channel
+    does not ask for pitch interpolation (there is nothing to interpolate from)."""
+    rng = np.random.default_rng(seed)
+    shape = (n_ch, n_frames)
+    step = rng.integers(-6, 7, shape)
+    step[rng.random(shape) < 0.3] = 0
+    start = rng.integers(10, 110, (n_ch, 1))
+    pitch = np.clip(start + np.cumsum(step, axis=1), 0, 123)       # 124..127 mark silence / tone frames
+    gain = np.clip(rng.integers(60, 200, (n_ch, 1)) + np.cumsum(rng.integers(-25, 26, shape), axis=1), 0, 255)
+    f = {k: rng.integers(0, 1 << sum(n for _, n in parts), shape) for k, parts in AMBE_LAYOUT.items()}
+    f["pitch"], f["gain"] = pitch, gain
+    f["pitch_rule"][:, 0] = 0
+    return ambe_pack(f, shape)
