@@ -45,8 +45,7 @@ struct AmbeLds {
 	float mlog_prev[64];    // previous frame, second subframe
 	float mlog[2][64];
 	float m[3][64];         // [0] previous subframe of the running pair, [1] / [2] alternate
-	float tmp[64];
-	float scale[64];
+	float scale[72];        // per bin: what its harmonic multiplies it with
 	int edge[64];           // edge[l] .. edge[l + 1]: bins of harmonic l
 	float phi[64];
 };
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(128) void k_ambe_cs_table(const AmbeTab *tab, AmbeB
 	big->cs[bin][n] = make_float2(tab->cosv[idx & 1023], tab->cosv[(idx + 768) & 1023]);
 }
 
-__global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ambe(AmbeArgs a)
 {
 	__shared__ AmbeLds s;
 	const int lane = (int)threadIdx.x;
@@ -463,6 +462,13 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 				const float w0 = f0 * (2.0f * kPi);                     // frame.c:342-359
 				const float w0q = sub == 0 ? prev_w0 : f0s[0] * (2.0f * kPi);
 				const int m_now = m_prev == 0 ? 1 : (m_prev == 1 ? 2 : 1);
+				// noise generator: this subframe's 121 values start from u_last, the next one's 80 further on
+				// (synth.c:98-110, 127-128); their windowed spectrum is a function of u_last alone: AmbeBig::noise_dft.
+				// Asked for here, used after the enhancement.
+				const uint32_t x0 = u_last & 0xffffu;
+				u_last = (T.lcg_mul[79] * x0 + T.lcg_add[79]) % 53125u;
+				const float2 *row = a.big->noise_dft[x0 < (uint32_t)kAmbeNoiseStates ? x0 : 0];
+				const float2 spec = row[lane];
 
 				// per-harmonic voicing and linear magnitude
 				const unsigned bands = sub == 0 ? (pat & 0xff) : (pat >> 8);       // MSB = lowest band (frame.c:313-318)
@@ -534,15 +540,10 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 				const int last_edge = uni(s.edge[L]);
 
 				float nu0 = 0.0f, nu1 = 0.0f;      // new unvoiced samples n = lane, lane + 64
-				// noise generator: this subframe's 121 values start from u_last, the next one's 80 further on
-				// (synth.c:98-110, 127-128); their windowed spectrum is a function of u_last alone: AmbeBig::noise_dft
-				const uint32_t x0 = u_last & 0xffffu;
-				u_last = (T.lcg_mul[79] * x0 + T.lcg_add[79]) % 53125u;
 				if (any_noise && !(a.dbg & 1)) {
 					const bool need64 = last_edge > 64;        // a band reaches the last bin: decision D10 inputs only
-					const float2 *row = a.big->noise_dft[x0 < (uint32_t)kAmbeNoiseStates ? x0 : 0];
 					{
-						const float2 v = row[lane];
+						const float2 v = spec;
 						s.re[lane] = v.x;
 						s.im[lane] = v.y;
 						s.pw[lane] = v.x * v.x + v.y * v.y;
@@ -554,48 +555,52 @@ __global__ __launch_bounds__(64) void k_ambe(AmbeArgs a)
 						}
 					}
 					WSYNC();
-					// per harmonic: energy of its bins -> scale factor
+					// per harmonic: energy of its bins -> the factor its bins are multiplied with (zero: voiced band)
+					s.scale[lane] = 0.0f;                      // bins no harmonic covers are cleared (synth.c:141-144, 184-187)
+					if (lane == 0)
+						s.scale[64] = 0.0f;
+					WSYNC();
 					if (lane < L) {
 						float e = 0.0f;
 						for (int k = lo; k < hi; k++)
 							e += s.pw[k];
-						s.scale[lane] = 76.89f * M / sqrtf(e / (float)(hi - lo));
+						const float f = voiced_l ? 0.0f : 76.89f * M / sqrtf(e / (float)(hi - lo));
+						for (int k = lo; k < hi; k++)
+							s.scale[k] = f;
 					}
 					WSYNC();
-					// per bin: its harmonic's factor, or zero (voiced band, below the first edge, above the last)
 					uint64_t live = 0;
-					for (int r = 0; r < (need64 ? 2 : 1); r++) {
-						const int bin = lane + 64 * r;
-						int l = -1;
-						for (int q = 0; q < L; q++)
-							if (bin >= s.edge[q] && bin < s.edge[q + 1])
-								l = q;
-						float vr = 0.0f, vi = 0.0f;
-						if (bin <= 64 && l >= 0 && !((Vmask >> l) & 1)) {
-							vr = s.re[bin] * s.scale[l];
-							vi = s.im[bin] * s.scale[l];
+					{
+						const float f = s.scale[lane];
+						const float vr = f == 0.0f ? 0.0f : s.re[lane] * f, vi = f == 0.0f ? 0.0f : s.im[lane] * f;
+						s.re[lane] = vr;
+						s.im[lane] = vi;
+						live = __ballot(vr != 0.0f || vi != 0.0f);
+						if (lane == 0) {
+							const float g = s.scale[64];
+							s.re[64] = (need64 && g != 0.0f) ? s.re[64] * g : 0.0f;
+							s.im[64] = (need64 && g != 0.0f) ? s.im[64] * g : 0.0f;
 						}
-						if (bin <= 64) {
-							s.re[bin] = vr;
-							s.im[bin] = vi;
-						}
-						const uint64_t nz = __ballot(vr != 0.0f || vi != 0.0f);
-						if (r == 0)
-							live = nz;      // bin 64 is looked at separately below
 					}
 					WSYNC();
 					const bool live64 = need64 && (s.re[64] != 0.0f || s.im[64] != 0.0f);
 					// inverse DFT, samples n = lane and lane + 64 (math.c:142-163); zero bins add nothing
 					float a0 = 0.0f, a1 = 0.0f;
 					uint64_t todo = live;
+					// the table values of the next live bin are requested while the current one is added
+					int k = todo ? __builtin_ctzll(todo) : 0;
+					float2 ca = a.big->cs[k][lane], cb = a.big->cs[k][lane + 64];
 					while (todo) {
-						const int k = __builtin_ctzll(todo);
 						todo &= todo - 1;
+						const int kn = todo ? __builtin_ctzll(todo) : k;
+						const float2 na = a.big->cs[kn][lane], nb = a.big->cs[kn][lane + 64];
 						const float twice = k == 0 ? 1.0f : 2.0f;
 						const float br = s.re[k], bi = s.im[k];
-						const float2 ca = a.big->cs[k][lane], cb = a.big->cs[k][lane + 64];
 						a0 += twice * (br * ca.x + bi * ca.y);
 						a1 += twice * (br * cb.x + bi * cb.y);
+						k = kn;
+						ca = na;
+						cb = nb;
 					}
 					if (live64) {
 						const float br = s.re[64], bi = s.im[64];
