@@ -221,7 +221,7 @@ def run_ambe_workload(args):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg,
                          "note": "330 bytes per frame against tens of thousands of table-cosine multiply-adds: the kernel is "
-                                 "VALU / LDS bound by construction (DESIGN.md 4.6), the HBM fraction is reported for form"},
+                                 "VALU / LDS bound by construction (DESIGN.md 4.7), the HBM fraction is reported for form"},
             "checks": {"workload_gen_s": round(t_gen, 2), "rejected_frames": int((rv != 0).sum().item())}}
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -25,6 +25,7 @@
 #include <osmocom/gmr1/l1/punct.h>
 #include <osmocom/gmr1/l1/crc.h>
 #include <osmocom/gmr1/gsmtap.h>
+#include <osmocom/gmr1/codec/codec.h>
 #include <stdlib.h>
 
 int main(void)
@@ -82,6 +83,24 @@ int main(void)
 		    gmr1_punct_k5_12_P12.mask[3] != 0 || gmr1_crc16.poly != 0x1021 || gmr1_crc8.bits != 8)
 			return 9;
 		free((void *)code.puncture);
+	}
+	{
+		/* the vocoder object as src/gmr1_ambe_decode.c uses it; without a device the allocation fails like a calloc would */
+		struct gmr1_codec *codec = gmr1_codec_alloc();
+		int16_t audio[160];
+		const void *img = NULL;
+		size_t bytes = 0;
+		memset(audio, 0x55, sizeof(audio));
+		if (codec) {
+			uint8_t silence[10] = {0xf8};
+			if (gmr1_codec_decode_frame(codec, audio, 160, silence, 0) != 0 || audio[0] != 0 || audio[159] != 0)
+				return 10;
+			if (gmr1_codec_decode_dtx(codec, audio, 160) != 0)
+				return 11;
+		}
+		gmr1_codec_release(codec);                  /* NULL is allowed (src/codec/codec.c:64-66) */
+		if (gmr1_hip_codec_state_bytes() % 16 || gmr1_hip_codec_host_tables(&img, &bytes) != 0 || !img || bytes < 200000)
+			return 12;
 	}
 	printf("%s\n", gmr1_hip_version());
 	return 0;
