@@ -159,3 +159,32 @@ def test_the_reference_program_running_on_this_library(gold):
     compare(got, gold["mixed_pcm"], "reference main() on libgmr1_hip.so")
     wav = ref_codec.decode_with_program(fr[:50], tool=exe, wav=True)
     assert np.array_equal(wav, got[:50])
+
+
+def test_traffic_channel_to_pcm_end_to_end(api, orc, pkg):
+    """What a user of the reference does in two programs - gmr1_rx writes the speech frames of a TCH3 assignment to a
+    file (gmr1_rx.c:560-577), gmr1_ambe_decode turns the file into audio - as two GPU calls: samples of a BCCH carrier and
+    its traffic carrier -> records (gmr1_hip_rx_run_tch) -> the 20 bytes of every speech burst, in order -> PCM.
+    Checked against the same chain on the CPU oracle."""
+    import workloads
+    b, t, _, sent_t = workloads.bcch_tch_pair(pkg, 21, seconds=6.0, mix=(0.15, 0.75, 0.10))
+    length = np.array([b.size], np.uint64)
+    offset = np.zeros(1, np.uint64)
+    rec, status, chains, found = api.rx_run_tch(b, t, offset, length, sps=4)
+    assert not status.any()
+    speech = rec[rec["type"] == 0x10]
+    assert len(speech) > 60
+    frames = np.stack([r["l2"][:20] for r in speech]).reshape(-1, 10)        # frame 0, frame 1 of each burst
+    pcm, rv, _ = api.codec_decode_batch(frames[None])
+    # the oracle's chain
+    orv, orec, _ = orc.rx_run_tch(b, t, sps=4, arfcn=0)
+    ospeech = orec[orec["type"] == 0x10]
+    oframes = np.stack([r["l2"][:20] for r in ospeech]).reshape(-1, 10)
+    assert np.array_equal(frames, oframes)
+    want, wrv = oracle_lib.ambe_decode(oframes)
+    assert np.array_equal(rv[0], wrv)
+    compare(pcm[0], want, "TCH3 bursts -> PCM", limit=1e-4)
+    # and the frames are the ones that were sent
+    sent = [bytes(s["frame0"]) + bytes(s["frame1"]) for s in sent_t if s["type"] == "speech" and not s["ciph"]]
+    got = {bytes(r["l2"][:20]) for r in speech}
+    assert sum(s in got for s in sent) >= 0.9 * len(sent)
