@@ -58,7 +58,7 @@ struct AmbeTab {
 	float f0_sf0[129 * 128 * 4];       // powf(2, interpolated f0log) by (previous pitch index, pitch, rule), frame.c:303-305
 };
 
-// Two more tables, too large for AmbeTab and built on the device itself (k_ambe_noise_table, k_ambe_cs_table) with
+// Three more tables, too large for AmbeTab and built on the device itself (k_ambe_noise_table, k_ambe_cs_table, k_ambe_grid_table) with
 // the very operations the synthesiser would otherwise repeat for every subframe:
 //  * noise_dft[x][bin] = (re, im) of the 128-point DFT of the windowed noise sequence the generator produces from
 //    state x (synth.c:127-134, math.c:118-138).  The generator has 53125 states (x -> 171 x + 11213 mod 53125, full
@@ -67,9 +67,13 @@ struct AmbeTab {
 //    truncated float product of constants, the same for every frame.
 constexpr int kAmbeNoiseStates = 53125;
 constexpr int kAmbeBins = 65;
+//  * grid[Ls - 9][Ld - 9][i] = the position ambe_resample_mag reaches at destination harmonic i when it maps Ls
+//    harmonics onto Ld (frame.c:147-166): a running float sum of Ls / Ld, the same for every frame with that pair.
+constexpr int kAmbeLs = 48;            // harmonic counts 9 .. 56
 struct AmbeBig {
 	float2 noise_dft[kAmbeNoiseStates][kAmbeBins];
 	float2 cs[kAmbeBins][128];
+	float grid[kAmbeLs][kAmbeLs][64];
 };
 
 struct AmbeArgs {

@@ -48,6 +48,8 @@ struct AmbeLds {
 	float scale[72];        // per bin: what its harmonic multiplies it with
 	int edge[64];           // edge[l] .. edge[l + 1]: bins of harmonic l
 	float phi[64];
+	alignas(16) float sum_a[64];
+	alignas(16) float sum_b[64];
 };
 
 __device__ __forceinline__ float tcos(const float *ct, float a)
@@ -71,12 +73,22 @@ __device__ __forceinline__ float unif(float v)
 	return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
-// v of lanes 0 .. n-1 added in that order, starting from 0 (the reference's `sum = 0; for (...) sum += x[i];`)
-__device__ __forceinline__ float seq_sum(float v, int n)
+// The values of lanes 0 .. 55 added in that order, starting from 0 (the reference's `sum = 0; for (...) sum += x[i];`).
+// Lanes past the end of the reference's loop must hold 0: adding +0 changes nothing.  Through LDS, four per read.
+__device__ __forceinline__ float seq_sum(float *buf, float v, int lane)
 {
+	buf[lane] = v;
+	WSYNC();
 	float acc = 0.0f;
-	for (int i = 0; i < n; i++)
-		acc += lane_get(v, i);
+#pragma unroll
+	for (int i = 0; i < kAmbeMaxHarm; i += 4) {
+		const float4 x = *reinterpret_cast<const float4 *>(buf + i);
+		acc += x.x;
+		acc += x.y;
+		acc += x.z;
+		acc += x.w;
+	}
+	WSYNC();
 	return acc;
 }
 
@@ -122,16 +134,11 @@ __device__ __forceinline__ int harmonics(float f0)
 }
 
 // frame.c:140-171 for destination harmonic `lane` (< Ld): src (Ls values, in LDS) seen on a grid of Ld harmonics,
-// mean removed.  The grid position is a running float sum in the reference, so it is run here as well.
-__device__ __forceinline__ float regrid(const float *src, int Ls, int Ld, int lane)
+// mean removed.  The grid position is a running float sum in the reference: AmbeBig::grid holds it.
+__device__ __forceinline__ float regrid(const AmbeBig *big, float *buf, const float *src, int Ls, int Ld, int lane)
 {
-	const float step = (float)Ls / (float)Ld;
-	float at = step, mine = step;
-	for (int i = 0; i < Ld; i++) {
-		if (i == lane)
-			mine = at;
-		at += step;
-	}
+	const int a = min(max(Ls, 9), 56) - 9, b = min(max(Ld, 9), 56) - 9;
+	const float mine = big->grid[a][b][lane];
 	float v = 0.0f;
 	if (lane < Ld) {
 		const int k = (int)floorf(mine);
@@ -144,7 +151,7 @@ __device__ __forceinline__ float regrid(const float *src, int Ls, int Ld, int la
 			v = src[k - 1] * (1.0f - frac) + src[k] * frac;
 		}
 	}
-	float mean = seq_sum(v, Ld);
+	float mean = seq_sum(buf, v, lane);
 	mean /= (float)Ld;
 	return v - mean;
 }
@@ -212,6 +219,21 @@ __global__ __launch_bounds__(64) void k_ambe_noise_table(const AmbeTab *tab, Amb
 		}
 		big->noise_dft[x0][bin] = make_float2(ar, ai);
 	}
+}
+
+// AmbeBig::grid: the running sum of frame.c:147-166 for one (Ls, Ld) pair per work-group
+__global__ __launch_bounds__(64) void k_ambe_grid_table(AmbeBig *big)
+{
+	const int Ls = 9 + (int)blockIdx.x / kAmbeLs, Ld = 9 + (int)blockIdx.x % kAmbeLs;
+	const int lane = (int)threadIdx.x;
+	const float step = (float)Ls / (float)Ld;
+	float at = step, mine = step;
+	for (int i = 0; i < kAmbeMaxHarm; i++) {
+		if (i == lane)
+			mine = at;
+		at += step;
+	}
+	big->grid[Ls - 9][Ld - 9][lane] = mine;
 }
 
 // AmbeBig::cs: the table entries cosf_fast / sinf_fast return for the angle (-2 pi / 128) bin n (math.c:152-156)
@@ -382,7 +404,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			// -- second subframe's log magnitudes (frame.c:175-242) --
 			if (!(a.dbg & 4)) {
 				const int L = Ls[1];
-				float v = regrid(s.mlog_prev, Lp, L, lane) * 0.65f;
+				float v = regrid(a.big, s.sum_a, s.mlog_prev, Lp, L, lane) * 0.65f;
 				// PRBA vector -> 8 points (lanes 0..7)
 				float g[8];
 				g[0] = 0.0f;
@@ -434,8 +456,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 			// -- first subframe's (frame.c:246-286) --
 			if (!(a.dbg & 4)) {
 				const int L = Ls[0];
-				const float from_before = regrid(s.mlog_prev, Lp, L, lane);
-				const float from_after = regrid(s.mlog[1], Ls[1], L, lane);
+				const float from_before = regrid(a.big, s.sum_a, s.mlog_prev, Lp, L, lane);
+				const float from_after = regrid(a.big, s.sum_a, s.mlog[1], Ls[1], L, lane);
 				const float al = T.interp[mag_rule];
 				float e[9];
 				e[0] = 0.0f;
@@ -492,11 +514,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				{
 					const float p = M * M;
 					const float q = p * cw;
+					s.sum_a[lane] = p;                     // lanes >= L hold M = 0
+					s.sum_b[lane] = q;
+					WSYNC();
 					float r0 = 0.0f, r1 = 0.0f;
-					for (int i = 0; i < L; i++) {
-						r0 += lane_get(p, i);
-						r1 += lane_get(q, i);
+#pragma unroll
+					for (int i = 0; i < kAmbeMaxHarm; i += 4) {
+						const float4 x = *reinterpret_cast<const float4 *>(s.sum_a + i);
+						const float4 y = *reinterpret_cast<const float4 *>(s.sum_b + i);
+						r0 += x.x; r0 += x.y; r0 += x.z; r0 += x.w;
+						r1 += y.x; r1 += y.y; r1 += y.z; r1 += y.w;
 					}
+					WSYNC();
 					const float k1 = 0.96f * kPi / (w0 * r0 * (r0 * r0 - r1 * r1));
 					const float k2 = r0 * r0 + r1 * r1;
 					const float k3 = 2.0f * r0 * r1;
@@ -510,7 +539,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 							w = 0.5f;
 					}
 					M *= w;
-					const float after = seq_sum(M * M, L);
+					if (lane >= L)
+						M = 0.0f;
+					const float after = seq_sum(s.sum_a, M * M, lane);
 					const float norm = sqrtf(r0 / after);
 					M *= norm;
 					if (lane >= L)
@@ -762,6 +793,7 @@ hipError_t launch_ambe_big(const AmbeTab *tab, AmbeBig *big, hipStream_t stream)
 {
 	hipLaunchKernelGGL(k_ambe_noise_table, dim3(kAmbeNoiseStates), dim3(64), 0, stream, tab, big);
 	hipLaunchKernelGGL(k_ambe_cs_table, dim3(kAmbeBins), dim3(128), 0, stream, tab, big);
+	hipLaunchKernelGGL(k_ambe_grid_table, dim3(kAmbeLs * kAmbeLs), dim3(64), 0, stream, big);
 	return hipGetLastError();
 }
 
