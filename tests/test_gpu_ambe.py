@@ -188,3 +188,29 @@ def test_traffic_channel_to_pcm_end_to_end(api, orc, pkg):
     sent = [bytes(s["frame0"]) + bytes(s["frame1"]) for s in sent_t if s["type"] == "speech" and not s["ciph"]]
     got = {bytes(r["l2"][:20]) for r in speech}
     assert sum(s in got for s in sent) >= 0.9 * len(sent)
+
+
+def test_bench_sized_batch_properties(api, pkg):
+    """At the bench's channel count: channels do not influence each other (a permutation of the channels permutes the
+    output), a run repeats bit for bit, and a random sample of channels equals the oracle."""
+    n_ch, n_fr = 8192, 24
+    fr = pkg.synth.ambe_speech_frames(n_ch, n_fr, seed=31)
+    # sprinkle silence and tone frames
+    rng = np.random.default_rng(32)
+    for c in rng.integers(0, n_ch, 600):
+        f = int(rng.integers(1, n_fr))
+        fr[c, f] = S.silence_frame() if rng.random() < 0.5 else S.tone_frame(int(rng.integers(0x80, 0xa4)), 230, int(rng.integers(0, 4)))
+    pcm, rv, st = api.codec_decode_batch(fr)
+    pcm2, rv2, st2 = api.codec_decode_batch(fr)
+    assert np.array_equal(pcm, pcm2) and np.array_equal(st, st2) and not rv.any()
+    perm = rng.permutation(n_ch)
+    pcm3, _, st3 = api.codec_decode_batch(fr[perm])
+    assert np.array_equal(pcm3, pcm[perm]) and np.array_equal(st3, st[perm])
+    differ = 0
+    for c in rng.integers(0, n_ch, 48):
+        want, _ = oracle_lib.ambe_decode(fr[c])
+        d = np.abs(pcm[c].astype(np.int32) - want.astype(np.int32))
+        assert d.max() <= 1
+        differ += int((d != 0).sum())
+    print("bench-sized batch: %d of %d sampled samples differ from the oracle" % (differ, 48 * n_fr * 160))
+    assert differ <= 20
