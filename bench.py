@@ -834,9 +834,13 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # GMR1_BENCH_FORCE_GROUP=1: a single rank goes through everything the N > 1 ranks go through (RCCL group, barriers,
+    # max-over-ranks, the sharded exchange with itself) - the only way to touch RCCL on a one-GPU box
+    grouped = world > 1 or os.environ.get("GMR1_BENCH_FORCE_GROUP") == "1"
+    if grouped:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -870,7 +874,7 @@ def main():
                                    ferr.data_ptr(), None, None, rv.data_ptr())
 
     def barrier():
-        if world > 1:
+        if grouped:
             import torch.distributed as dist
             dist.barrier()
 
@@ -895,7 +899,7 @@ def main():
     wall = t1 - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # one launch per step
 
-    if world > 1:
+    if grouped:
         import torch.distributed as dist
         tt = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -913,7 +917,7 @@ def main():
     # does not come back (a collective that hangs must not cost the measurement that is already taken).
     sharded = None
     line = {}
-    if world > 1 and not args.no_shard:
+    if grouped and not args.no_shard:
         import threading
 
         def give_up():
@@ -929,7 +933,7 @@ def main():
         dog = None
 
     def finish():
-        if world > 1:
+        if grouped:
             import torch.distributed as dist
             dist.destroy_process_group()
 
