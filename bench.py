@@ -798,6 +798,9 @@ def _sharded_summary(args, dist, host, out, tt, A, ns, seconds, distinct, world,
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
+    if args.workload != "bursts" and (args.gpus > 1 or int(env_world or "1") > 1):
+        raise SystemExit(f"bench.py: --workload {args.workload} is a one-GPU side measurement; the N-GPU line is the "
+                         "headline workload's (drop --workload)")
     if env_world is None and args.gpus > 1:
         # no launcher: start the N ranks ourselves, before anything in this process touches the GPU
         raise SystemExit(spawn_ranks(args.gpus))

@@ -269,7 +269,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 	float tone_ph1 = S.tone_ph1, tone_ph2 = S.tone_ph2;
 	float prev_f0log = S.f0log, prev_w0 = S.w0, prev_gain = S.gain, psi1 = S.psi1, SE = S.SE;
-	int prev_idx = S.pitch_idx, prev_L = S.L;
+	// (a state the caller damaged must not turn into an out-of-range table index: clamp what is used as one)
+	int prev_idx = min(max(S.pitch_idx, 0), 128), prev_L = min(max(S.L, 9), kAmbeMaxHarm);
 	uint64_t prev_V = ((uint64_t)S.V[1] << 32) | S.V[0];
 	uint32_t u_last = S.u_last;
 	uint64_t slot[2] = {((uint64_t)S.slot[0][1] << 32) | S.slot[0][0], ((uint64_t)S.slot[1][1] << 32) | S.slot[1][0]};
