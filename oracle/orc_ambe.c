@@ -623,3 +623,10 @@ float orc_ambe_log2_int(int L)
 {
 	return log2f(L);                            /* frame.c:238 */
 }
+
+/* libm as the reference calls it, over arrays: the product's restatement of glibc's powf is checked against these */
+void orc_ambe_powf_array(int n, const float *x, float y, int x_is_base, float *out)
+{
+	for (int i = 0; i < n; i++)
+		out[i] = x_is_base ? powf(x[i], y) : powf(y, x[i]);
+}

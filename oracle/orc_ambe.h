@@ -43,3 +43,4 @@ int orc_ambe_tone_ampl(int log_ampl);
 float orc_ambe_cos_entry(int i);
 float orc_ambe_pow2(float x);
 float orc_ambe_log2_int(int L);
+void orc_ambe_powf_array(int n, const float *x, float y, int x_is_base, float *out);

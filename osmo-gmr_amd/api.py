@@ -62,7 +62,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_rx_run_sharded",
     "gmr1_codec_alloc", "gmr1_codec_release", "gmr1_codec_decode_frame", "gmr1_codec_decode_dtx",
     "gmr1_hip_codec_state_bytes", "gmr1_hip_codec_init_dev", "gmr1_hip_codec_decode_batch_dev",
-    "gmr1_hip_codec_decode_batch", "gmr1_hip_codec_host_tables",
+    "gmr1_hip_codec_decode_batch", "gmr1_hip_codec_host_tables", "gmr1_hip_codec_libm_check",
 ]
 EXPORTED_DATA = [
     "gmr1_pi2cbpsk", "gmr1_pi4cbpsk", "gmr1_pi4cqpsk",
@@ -1458,3 +1458,11 @@ def codec_host_tables():
     assert n.value == CODEC_TAB_DTYPE.itemsize, (n.value, CODEC_TAB_DTYPE.itemsize)
     raw = C.string_at(img.value, n.value)
     return np.frombuffer(raw, CODEC_TAB_DTYPE)[0]
+
+
+def codec_libm_check(which, x):
+    x, p_x = _np(x, np.float32)
+    out = np.zeros(x.size, np.float32)
+    _check(load().gmr1_hip_codec_libm_check(C.c_int(which), C.c_int(x.size), p_x, out.ctypes.data_as(C.c_void_p)),
+           "gmr1_hip_codec_libm_check")
+    return out

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "ambe_libm.h"
+
 namespace gmr1 {
 
 constexpr int kAmbeFrameBytes = 10;
@@ -85,6 +87,7 @@ struct AmbeArgs {
 	AmbeState *state;                  // [n_ch], read and written
 	const AmbeTab *tab;
 	const AmbeBig *big;
+	const ambe_libm::LibmTab *libm;    // glibc's powf tables (ambe_libm.h)
 	int tone_n;                        // the N of gmr1_codec_decode_frame: samples a tone frame covers (160 in batches)
 	int dbg;                           // timing experiments only (GMR1_HIP_AMBE_DBG): 1 no noise path, 2 no oscillators, 4 no parameter decode
 };

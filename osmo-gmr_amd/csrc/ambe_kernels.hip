@@ -13,9 +13,10 @@
 // Hence: -ffp-contract=off, sums over harmonics added lane after lane in index order (seq_sum), the DFT / inverse DFT /
 // oscillator sums run serially inside the lane that owns the bin / sample.  What libm computes in the reference is
 // either tabulated by the host's libm (cosine table, 2^f0log for every reachable pitch history, log2 L, tone
-// amplitudes: exact by construction) or evaluated in double precision and rounded once (2^Mlog, x^(1/4), the tone's
-// cosf): within one unit in the last place of glibc's float results, which moves a PCM sample by one step at most
-// and only when the sum sits on an integer boundary (tests/test_gpu_ambe.py counts them).
+// amplitudes: exact by construction) or computed the way glibc computes it (ambe_libm.h: powf for 2^Mlog and x^(1/4),
+// checked bit for bit against the host's libm), or -- the tone frames' cosf -- evaluated in double precision and rounded
+// once: within one unit in the last place of glibc's float result, which moves a sample by one step at most and only
+// when the product sits on an integer boundary (tests/test_gpu_ambe.py counts them).
 
 #include <cstdlib>
 
@@ -505,7 +506,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				float M = 0.0f;
 				if (lane < L) {
 					const float unv = 0.2046f / sqrtf(w0);
-					M = (float)exp2((double)s.mlog[sub][lane]) / 6.0f;
+					bool ok;
+					float two_to = ambe_libm::pow2f(*a.libm, s.mlog[sub][lane], &ok);       // powf(2.0, Mlog), frame.c:355
+					if (!ok)
+						two_to = (float)exp2((double)s.mlog[sub][lane]);
+					M = two_to / 6.0f;
 					if (!voiced_l)
 						M *= unv;
 				}
@@ -533,7 +538,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					float w = 1.0f;
 					if ((lane + 1) * 8 > L) {
 						const float x = k1 * (k2 - k3 * cw);
-						w = sqrtf(M) * (float)sqrt(sqrt((double)x));
+						bool ok;
+						float root4 = ambe_libm::powf_pos(*a.libm, x, 0.25f, &ok);            // powf(x, 0.25f), synth.c:352-355
+						if (!ok)
+							root4 = (float)sqrt(sqrt((double)x));
+						w = sqrtf(M) * root4;
 						if (w > 1.2f)
 							w = 1.2f;
 						else if (w < 0.5f)

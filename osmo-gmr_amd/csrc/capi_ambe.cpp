@@ -124,8 +124,24 @@ constexpr int kMaxDev = 16;
 std::mutex g_mu;
 AmbeTab *g_dev_tab[kMaxDev];
 AmbeBig *g_dev_big[kMaxDev];
+ambe_libm::LibmTab *g_dev_libm[kMaxDev];
 
-int dev_tab(const AmbeTab **out, const AmbeBig **big)
+long double (*volatile p_exp2l)(long double) = exp2l;
+
+const ambe_libm::LibmTab *host_libm()
+{
+	static ambe_libm::LibmTab t;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		for (int i = 0; i < 32; i++)
+			t.exp2_tab[i] = ambe_libm::bits_of((double)p_exp2l((long double)i / 32.0L)) - ((uint64_t)i << 47);
+		for (int i = 0; i < 16; i++)
+			ambe_libm::log2_entry(i, t.invc[i], t.logc[i]);
+	});
+	return &t;
+}
+
+int dev_tab(const AmbeTab **out, const AmbeBig **big, const ambe_libm::LibmTab **libm)
 {
 	DevState *s;
 	int r = dev_state(&s);
@@ -149,9 +165,14 @@ int dev_tab(const AmbeTab **out, const AmbeBig **big)
 		HIP_TRY(launch_ambe_big(g_dev_tab[dev], static_cast<AmbeBig *>(b), nullptr));
 		HIP_TRY(hipStreamSynchronize(nullptr));
 		g_dev_big[dev] = static_cast<AmbeBig *>(b);
+		void *l = nullptr;
+		HIP_TRY(hipMalloc(&l, sizeof(ambe_libm::LibmTab)));
+		HIP_TRY(hipMemcpy(l, host_libm(), sizeof(ambe_libm::LibmTab), hipMemcpyHostToDevice));
+		g_dev_libm[dev] = static_cast<ambe_libm::LibmTab *>(l);
 	}
 	*out = g_dev_tab[dev];
 	*big = g_dev_big[dev];
+	*libm = g_dev_libm[dev];
 	return 0;
 }
 
@@ -162,7 +183,8 @@ int decode_dev(hipStream_t st, int n_ch, int n_frames, const uint8_t *frames, in
 		return fail(-EINVAL, "codec: negative channel or frame count");
 	const AmbeTab *t;
 	const AmbeBig *big;
-	int r = dev_tab(&t, &big);
+	const ambe_libm::LibmTab *libm;
+	int r = dev_tab(&t, &big, &libm);
 	if (r) return r;
 	if (n_ch == 0 || n_frames == 0)
 		return 0;
@@ -180,6 +202,7 @@ int decode_dev(hipStream_t st, int n_ch, int n_frames, const uint8_t *frames, in
 	a.state = static_cast<AmbeState *>(state);
 	a.tab = t;
 	a.big = big;
+	a.libm = libm;
 	a.tone_n = tone_n;
 	a.dbg = 0;
 	HIP_TRY(launch_ambe(a, st));
@@ -250,6 +273,21 @@ int gmr1_hip_codec_host_tables(const void **image, size_t *bytes)
 		return fail(-ENOMEM, "codec: no memory for the tables");
 	if (image) *image = t;
 	if (bytes) *bytes = sizeof(AmbeTab);
+	return 0;
+}
+
+int gmr1_hip_codec_libm_check(int which, int n, const float *x, float *out)
+{
+	// the device's restatement of glibc's powf (ambe_libm.h), run on the host: which = 0: powf(2, x[i]); 1: powf(x[i], 0.25f).
+	// out[i] = the result, or NaN where the argument is outside what is restated (the kernel then evaluates in double)
+	if (n < 0 || (n > 0 && (!x || !out)) || which < 0 || which > 1)
+		return fail(-EINVAL, "gmr1_hip_codec_libm_check: bad argument");
+	const ambe_libm::LibmTab &T = *host_libm();
+	for (int i = 0; i < n; i++) {
+		bool ok;
+		const float v = which == 0 ? ambe_libm::pow2f(T, x[i], &ok) : ambe_libm::powf_pos(T, x[i], 0.25f, &ok);
+		out[i] = ok ? v : std::nanf("");
+	}
 	return 0;
 }
 

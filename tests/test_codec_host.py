@@ -110,3 +110,34 @@ def test_state_size_and_calls_without_a_device(api):
         api.codec_decode_batch(fr)
     rc = api.load().gmr1_codec_decode_frame(None, None, 160, None, 0)
     assert rc == -22
+
+
+def _orc_powf(x, y, x_is_base):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros_like(x)
+    oracle_lib.lib().orc_ambe_powf_array(C.c_int(x.size), x.ctypes.data_as(C.c_void_p), C.c_float(y), C.c_int(x_is_base),
+                                         out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def test_restated_powf_returns_libms_bits(api):
+    """ambe_libm.h (glibc's powf algorithm as the kernel evaluates it) against the libm the reference calls: identical
+    bits for powf(2, y) over the log-magnitude range and far beyond it, and for powf(x, 0.25f) over 60 octaves."""
+    rng = np.random.default_rng(8)
+    n = 5_000_000
+    for lo, hi in ((-20.0, 20.0), (-124.0, 124.0)):
+        y = rng.uniform(lo, hi, n).astype(np.float32)
+        got = api.codec_libm_check(0, y)
+        assert not np.isnan(got).any()
+        assert np.array_equal(got.view(np.uint32), _orc_powf(y, 2.0, 0).view(np.uint32))
+    x = (np.exp2(rng.uniform(-30, 30, n)) * rng.uniform(1, 2, n)).astype(np.float32)
+    got = api.codec_libm_check(1, x)
+    assert not np.isnan(got).any()
+    assert np.array_equal(got.view(np.uint32), _orc_powf(x, 0.25, 1).view(np.uint32))
+    # every float in a stretch around 1 (where the log table's entries meet), consecutively
+    x = (np.arange(0x3f000000, 0x3f000000 + 4_000_000, dtype=np.uint32)).view(np.float32)
+    assert np.array_equal(api.codec_libm_check(1, x).view(np.uint32), _orc_powf(x, 0.25, 1).view(np.uint32))
+    # outside what is restated the check says so (the kernel then evaluates in double precision)
+    bad = api.codec_libm_check(1, np.array([0.0, -1.0, np.inf, np.nan, 1e-45], np.float32))
+    assert np.isnan(bad).all()
+    assert np.isnan(api.codec_libm_check(0, np.array([130.0, -130.0, np.nan], np.float32))).all()
