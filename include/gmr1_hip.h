@@ -411,8 +411,8 @@ int gmr1_hip_codec_decode_batch(int n_ch, int n_frames, const uint8_t *frames, i
 /* The tables the library computes with the host's libm when it loads (cosine table, 2^f0log per pitch history, ...):
  * for tests; works without a GPU. */
 int gmr1_hip_codec_host_tables(const void **image, size_t *bytes);
-/* The kernel's restatement of glibc's powf, evaluated on the host (for tests; works without a GPU): which = 0:
- * out[i] = powf(2, x[i]); 1: powf(x[i], 0.25f); NaN where the kernel would fall back to double precision. */
+/* The kernel's restatement of glibc's powf and cosf, evaluated on the host (for tests; works without a GPU): which = 0:
+ * out[i] = powf(2, x[i]); 1: powf(x[i], 0.25f) (NaN where the kernel would fall back to double precision); 2: cosf(x[i]). */
 int gmr1_hip_codec_libm_check(int which, int n, const float *x, float *out);
 
 /* The GSMTAP packet gmr1_gsmtap_makemsg (reference src/gsmtap.c:43-71, include/osmocom/gmr1/gsmtap.h:35-37)

@@ -630,3 +630,9 @@ void orc_ambe_powf_array(int n, const float *x, float y, int x_is_base, float *o
 	for (int i = 0; i < n; i++)
 		out[i] = x_is_base ? powf(x[i], y) : powf(y, x[i]);
 }
+
+void orc_ambe_cosf_array(int n, const float *x, float *out)
+{
+	for (int i = 0; i < n; i++)
+		out[i] = cosf(x[i]);                    /* tone.c:104 */
+}

@@ -44,3 +44,4 @@ float orc_ambe_cos_entry(int i);
 float orc_ambe_pow2(float x);
 float orc_ambe_log2_int(int L);
 void orc_ambe_powf_array(int n, const float *x, float y, int x_is_base, float *out);
+void orc_ambe_cosf_array(int n, const float *x, float *out);

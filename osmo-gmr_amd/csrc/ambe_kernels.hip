@@ -14,9 +14,7 @@
 // oscillator sums run serially inside the lane that owns the bin / sample.  What libm computes in the reference is
 // either tabulated by the host's libm (cosine table, 2^f0log for every reachable pitch history, log2 L, tone
 // amplitudes: exact by construction) or computed the way glibc computes it (ambe_libm.h: powf for 2^Mlog and x^(1/4),
-// checked bit for bit against the host's libm), or -- the tone frames' cosf -- evaluated in double precision and rounded
-// once: within one unit in the last place of glibc's float result, which moves a sample by one step at most and only
-// when the product sits on an integer boundary (tests/test_gpu_ambe.py counts them).
+// cosf for the tone frames; checked bit for bit against the host's libm by tests/test_codec_host.py).
 
 #include <cstdlib>
 
@@ -364,9 +362,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				}
 				int v = 0;
 				if (any && i >= start && i < start + n) {
-					v = (int)(int16_t)(int)((float)ampl * (float)cos((double)my1));
+					v = (int)(int16_t)(int)((float)ampl * ambe_libm::cosf_glibc(my1));
 					if (two)
-						v = (int)(int16_t)(v + (int)(int16_t)(int)((float)ampl * (float)cos((double)my2)));
+						v = (int)(int16_t)(v + (int)(int16_t)(int)((float)ampl * ambe_libm::cosf_glibc(my2)));
 				}
 				if (i < N)
 					out[i] = (int16_t)v;

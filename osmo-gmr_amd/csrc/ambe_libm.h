@@ -147,5 +147,86 @@ AMBE_HD float powf_pos(const LibmTab &T, float x, float y, bool *ok)
 	return *ok ? exp2_of(T, ylogx) : 0.0f;
 }
 
+// ---- cosf (s_cosf.c, s_sincosf.h, s_sincosf_data.c) ----
+// glibc picks its FMA build of this source on every x86-64 CPU that has FMA (sysdeps/x86_64/fpu/multiarch): the
+// multiply-adds below are fused where that build fuses them.  (The plain build differs in about one argument in 10^7.)
+
+AMBE_HD double fmadd(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __fma_rn(a, b, c);
+#else
+	return __builtin_fma(a, b, c);
+#endif
+}
+
+// polynomial for sin (n even) or cos (n odd) of a reduced argument; `neg`: the negated cosine coefficients (__sincosf_table[1])
+AMBE_HD float sincos_poly(double x, double x2, bool neg, int n)
+{
+	const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+	if ((n & 1) == 0) {
+		const double x3 = x * x2;
+		const double t = fmadd(x2, s3, s2);
+		const double x7 = x3 * x2;
+		const double s = fmadd(x3, s1, x);
+		return (float)fmadd(x7, t, s);
+	}
+	const double sg = neg ? -1.0 : 1.0;
+	const double c0 = sg * 0x1p0, c1 = sg * -0x1.ffffffd0c621cp-2, c2 = sg * 0x1.55553e1068f19p-5,
+	             c3 = sg * -0x1.6c087e89a359dp-10, c4 = sg * 0x1.99343027bf8c3p-16;
+	const double x4 = x2 * x2;
+	const double u = fmadd(x2, c4, c3);
+	const double v = fmadd(x2, c1, c0);
+	const double x6 = x4 * x2;
+	const double c = fmadd(x4, c2, v);
+	return (float)fmadd(x6, u, c);
+}
+
+AMBE_HD uint32_t inv_pio4_word(int i)
+{
+	// 4 / pi = 0x0.a2f9836e4e441529fc2757d1f534ddc0db6295993c439041..., one byte further per entry (__inv_pio4)
+	const uint32_t w[24] = {0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+	                        0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+	                        0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+	return w[i];
+}
+
+AMBE_HD float cosf_glibc(float y)
+{
+	const uint32_t xi0 = bits_of(y);
+	const uint32_t top = (xi0 >> 20) & 0x7ffu;                 // abstop12
+	double x = (double)y;
+	const double sign4[4] = {1.0, -1.0, -1.0, 1.0};
+	if (top < 0x3f4u) {                                        // |y| < pi/4
+		if (top < 0x398u)                                      // |y| < 2^-12
+			return 1.0f;
+		return sincos_poly(x, x * x, false, 1);
+	}
+	if (top < 0x42fu) {                                        // |y| < 120: one multiply finds the quadrant
+		const double r = x * 0x1.45F306DC9C883p+23;
+		const int n = ((int32_t)r + 0x800000) >> 24;
+		x = fmadd(-(double)n, 0x1.921FB54442D18p0, x);
+		return sincos_poly(x * sign4[n & 3], x * x, (n & 2) != 0, n ^ 1);
+	}
+	if (top < 0x7f8u) {                                        // finite: 96 bits of 4 / pi
+		const int sign = (int)(xi0 >> 31);
+		const int at = (int)((xi0 >> 26) & 15u);
+		const int shift = (int)((xi0 >> 23) & 7u);
+		uint32_t xi = (xi0 & 0xffffffu) | 0x800000u;
+		xi <<= shift;
+		uint64_t res0 = (uint64_t)(uint32_t)(xi * inv_pio4_word(at));
+		const uint64_t res1 = (uint64_t)xi * inv_pio4_word(at + 4);
+		const uint64_t res2 = (uint64_t)xi * inv_pio4_word(at + 8);
+		res0 = (res2 >> 32) | (res0 << 32);
+		res0 += res1;
+		const uint64_t n64 = (res0 + (1ull << 61)) >> 62;
+		res0 -= n64 << 62;
+		const int n = (int)n64;
+		x = (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+		return sincos_poly(x * sign4[(n + sign) & 3], x * x, ((n + sign) & 2) != 0, n ^ 1);
+	}
+	return y - y;                                              // inf, NaN -> NaN
+}
+
 }  // namespace ambe_libm
 }  // namespace gmr1

@@ -278,13 +278,18 @@ int gmr1_hip_codec_host_tables(const void **image, size_t *bytes)
 
 int gmr1_hip_codec_libm_check(int which, int n, const float *x, float *out)
 {
-	// the device's restatement of glibc's powf (ambe_libm.h), run on the host: which = 0: powf(2, x[i]); 1: powf(x[i], 0.25f).
+	// the device's restatement of glibc's powf / cosf (ambe_libm.h), run on the host: which = 0: powf(2, x[i]);
+	// 1: powf(x[i], 0.25f); 2: cosf(x[i]).
 	// out[i] = the result, or NaN where the argument is outside what is restated (the kernel then evaluates in double)
-	if (n < 0 || (n > 0 && (!x || !out)) || which < 0 || which > 1)
+	if (n < 0 || (n > 0 && (!x || !out)) || which < 0 || which > 2)
 		return fail(-EINVAL, "gmr1_hip_codec_libm_check: bad argument");
 	const ambe_libm::LibmTab &T = *host_libm();
 	for (int i = 0; i < n; i++) {
 		bool ok;
+		if (which == 2) {
+			out[i] = ambe_libm::cosf_glibc(x[i]);
+			continue;
+		}
 		const float v = which == 0 ? ambe_libm::pow2f(T, x[i], &ok) : ambe_libm::powf_pos(T, x[i], 0.25f, &ok);
 		out[i] = ok ? v : std::nanf("");
 	}

@@ -141,3 +141,21 @@ def test_restated_powf_returns_libms_bits(api):
     bad = api.codec_libm_check(1, np.array([0.0, -1.0, np.inf, np.nan, 1e-45], np.float32))
     assert np.isnan(bad).all()
     assert np.isnan(api.codec_libm_check(0, np.array([130.0, -130.0, np.nan], np.float32))).all()
+
+
+def test_restated_cosf_returns_libms_bits(api):
+    """The tone frames' cosf (tone.c:104) runs on a phase that grows without bound: all three ranges of glibc's routine
+    (no reduction, one-multiply reduction below 120, 96 bits of 4 / pi above), and every float bit pattern class."""
+    rng = np.random.default_rng(9)
+    n = 4_000_000
+    sets = [rng.uniform(-1, 1, n), rng.uniform(-120, 120, n), rng.uniform(0, 2e6, n), rng.uniform(-1e9, 1e9, n),
+            np.arange(0x3f400000, 0x3f400000 + n, dtype=np.uint32).view(np.float32),           # around pi / 4
+            rng.integers(0, 0x7f800000, n, dtype=np.uint32).view(np.float32)]                   # any finite magnitude
+    for x in sets:
+        x = np.ascontiguousarray(x, np.float32)
+        want = np.zeros_like(x)
+        oracle_lib.lib().orc_ambe_cosf_array(C.c_int(x.size), x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p))
+        got = api.codec_libm_check(2, x)
+        differ = int((got.view(np.uint32) != want.view(np.uint32)).sum())
+        assert differ == 0, differ
+    assert np.isnan(api.codec_libm_check(2, np.array([np.inf, -np.inf, np.nan], np.float32))).all()
