@@ -10,7 +10,7 @@ bash tools/measure_traffic.sh $t > $o/traffic.log 2>&1
 cp gpurun_out/hbm_traffic.json $o/hbm_traffic.json
 bash tools/pmc_rx4.sh $t > /dev/null 2>&1; cp gpurun_out/pmc_$t.txt $o/pmc_sq_k_rx4.txt
 python3 tools/phase_times.py > $o/phase_times.txt 2>&1
-for w in nt3 tch3 fcch rx chan; do python3 bench.py --workload $w > $o/bench_$w.json 2> $o/bench_$w.err; done
+for w in nt3 tch3 fcch rx chan ambe; do python3 bench.py --workload $w > $o/bench_$w.json 2> $o/bench_$w.err; done
 python3 bench.py --workload rx --arfcns 512 --seconds 20 --no-cpu > $o/bench_rx_512x20s.json 2> $o/bench_rx_512.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_nt3 -- python3 bench.py --workload nt3 --no-cpu --steps 20 > /dev/null 2> $o/stats_nt3.err
 cp $(ls $o/stats_nt3/*/*kernel_stats.csv | head -1) $o/kernel_stats_nt3_1M.csv
@@ -20,7 +20,7 @@ python3 tools/time_legacy.py > $o/legacy_one_burst_calls.json 2> $o/legacy.err
 GMR1_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 --shard-arfcns 16 --shard-seconds 20 > $o/bench_gloo2_one_gpu.json 2> $o/bench_gloo2.err
 rm -rf $o/stats_bench $o/stats_nt3 $o/stats_rx
 ls -la $o | head -40
-for f in bench_100k bench_nt3 bench_tch3 bench_fcch bench_rx bench_chan bench_rx_512x20s; do echo "== $f"; python3 -c "
+for f in bench_100k bench_nt3 bench_tch3 bench_fcch bench_rx bench_chan bench_ambe bench_rx_512x20s; do echo "== $f"; python3 -c "
 import json,sys
 d=json.load(open('$o/$f.json'))
 print(d['value'], d['unit'], 'ms/step', d['ms_per_step'], 'roofline', (d.get('roofline') or {}).get('frac'), (d.get('roofline') or {}).get('kernel_ms'))
