@@ -411,6 +411,23 @@ static constexpr K7Tab make_k7()
 }
 __constant__ K7Tab c_k7 = make_k7();
 
+// The two states of a lane differ in position bit c5, which is state bit `ph` in phase ph: by linearity their own code
+// words differ by the code word of that unit state, whatever the lane.  The packed warm-up pass (k7_step_pk) builds on it.
+static constexpr uint32_t k7_pair_mask(int ph)
+{
+	return k7_out(1u << ph, (1u << ph) >> 5);
+}
+static constexpr bool k7_pair_mask_holds()
+{
+	const K7Tab t = make_k7();
+	for (int p = 0; p < 32; p++)
+		for (int ph = 0; ph < 6; ph++)
+			if ((((uint32_t)t.o[1][p] >> (2 * ph)) & 3u) != ((((uint32_t)t.o[0][p] >> (2 * ph)) & 3u) ^ k7_pair_mask(ph)))
+				return false;
+	return true;
+}
+static_assert(k7_pair_mask_holds(), "code words of a lane's two states must differ by a per-phase constant");
+
 // the word of the position whose lane differs in position bit PH (PH < 5)
 template <int PH>
 __device__ __forceinline__ uint32_t k7_partner(uint32_t w)
@@ -463,6 +480,37 @@ __device__ __forceinline__ void k7_window(uint32_t (&w)[2], const uint32_t (&ad)
 	k7_step<9, K0 + 9, REC>(w, ad, hi); k7_step<10, K0 + 10, REC>(w, ad, hi); k7_step<11, K0 + 11, REC>(w, ad, hi);
 }
 
+// The warm-up pass needs metrics only, and a metric is 16 bits: both states of a lane in ONE register, low half the
+// r = 0 state.  v_pk_add_u16 / v_pk_sub_u16 / v_pk_min_u16 do the two add-compare-selects at once and the partner costs
+// one DPP move for both (VOP3P takes no DPP operand) - 4 VALU and one table read per step where the word form takes
+// 6 and two.  The arithmetic is the word form's high half: sums wrap modulo 2^16 there as well, the minimum is unsigned.
+// The table holds, per step and own code word c, (m[c ^ pair_mask] << 16) | m[c]  (TAB_DELTA bytes after the word table).
+typedef unsigned short k7_us2 __attribute__((ext_vector_type(2)));
+template <int J, int K, int TAB_DELTA>
+__device__ __forceinline__ void k7_step_pk(uint32_t &P, const uint32_t (&ad)[6][2])
+{
+	constexpr int PH = J % 6;
+	const uint32_t pm = *(t3_lds_cu32 *)(uintptr_t)(ad[PH][0] + 16u * K + (uint32_t)TAB_DELTA);
+	uint32_t other;
+	if constexpr (PH < 5)
+		other = k7_partner<PH>(P);
+	else
+		other = __builtin_amdgcn_alignbit(P, P, 16);           // the lane's two states swap halves
+	const k7_us2 m2 = __builtin_bit_cast(k7_us2, pm);
+	const k7_us2 a = __builtin_bit_cast(k7_us2, P) + m2;
+	const k7_us2 b = __builtin_bit_cast(k7_us2, other) - m2;
+	P = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(a, b));
+}
+
+template <int K0, int TAB_DELTA>
+__device__ __forceinline__ void k7_window_pk(uint32_t &P, const uint32_t (&ad)[6][2])
+{
+	k7_step_pk<0, K0 + 0, TAB_DELTA>(P, ad); k7_step_pk<1, K0 + 1, TAB_DELTA>(P, ad); k7_step_pk<2, K0 + 2, TAB_DELTA>(P, ad);
+	k7_step_pk<3, K0 + 3, TAB_DELTA>(P, ad); k7_step_pk<4, K0 + 4, TAB_DELTA>(P, ad); k7_step_pk<5, K0 + 5, TAB_DELTA>(P, ad);
+	k7_step_pk<6, K0 + 6, TAB_DELTA>(P, ad); k7_step_pk<7, K0 + 7, TAB_DELTA>(P, ad); k7_step_pk<8, K0 + 8, TAB_DELTA>(P, ad);
+	k7_step_pk<9, K0 + 9, TAB_DELTA>(P, ad); k7_step_pk<10, K0 + 10, TAB_DELTA>(P, ad); k7_step_pk<11, K0 + 11, TAB_DELTA>(P, ad);
+}
+
 // minimum over the 32 lanes of each half
 __device__ __forceinline__ uint32_t half_min(uint32_t v)
 {
@@ -478,7 +526,11 @@ __device__ __forceinline__ uint32_t half_min(uint32_t v)
 __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 {
 	__shared__ __align__(16) int8_t s_e[216];
-	__shared__ __align__(16) uint32_t s_tab[2][kT3Steps * 4];  // per frame: (2 cost(word) - K) << 16 per step and code word
+	// per frame: (2 cost(word) - K) << 16 per step and code word; behind both frames' tables the same again in the packed
+	// form of the warm-up pass (k7_step_pk), at a fixed distance so that one address register serves both
+	__shared__ __align__(16) uint32_t s_tab_all[4][kT3Steps * 4];
+	uint32_t (*s_tab)[kT3Steps * 4] = s_tab_all;
+	constexpr int kPkDelta = 2 * kT3Steps * 4 * 4;
 	__shared__ uint16_t s_win[2][4][64];
 	__shared__ uint8_t s_locof[64];            // position of a state: the survivor walk reads it four times in a row
 	const int lane = threadIdx.x;
@@ -518,8 +570,14 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 			const int da = a1 - a0, db = b1c - b0;
 			ks = a0 + a1 + b0 + b1c;
 			// code word o = (g0 bit << 1) | g1 bit
-			*reinterpret_cast<uint4 *>(&s_tab[f][4 * s]) = make_uint4((uint32_t)(-da - db) << 16, (uint32_t)(-da + db) << 16,
-			                                                          (uint32_t)(da - db) << 16, (uint32_t)(da + db) << 16);
+			const uint32_t t[4] = {(uint32_t)(-da - db) << 16, (uint32_t)(-da + db) << 16, (uint32_t)(da - db) << 16,
+			                       (uint32_t)(da + db) << 16};
+			*reinterpret_cast<uint4 *>(&s_tab[f][4 * s]) = make_uint4(t[0], t[1], t[2], t[3]);
+			// packed form: high half the lane's r = 1 state, whose code word is the own one xor the phase's constant
+			const uint32_t mk = (s % 6 == 0) ? k7_pair_mask(0) : (s % 6 == 1) ? k7_pair_mask(1) : (s % 6 == 2) ? k7_pair_mask(2)
+			                  : (s % 6 == 3) ? k7_pair_mask(3) : (s % 6 == 4) ? k7_pair_mask(4) : k7_pair_mask(5);
+			*reinterpret_cast<uint4 *>(&s_tab_all[2 + f][4 * s]) =
+			    make_uint4(t[0 ^ mk] | (t[0] >> 16), t[1 ^ mk] | (t[1] >> 16), t[2 ^ mk] | (t[2] >> 16), t[3 ^ mk] | (t[3] >> 16));
 		}
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1)
@@ -555,11 +613,16 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 		w[r] = (c_k7.st[r][p] ? kSent : kBias) << 16;
 	}
 
-	// pass 1 (warm-up): only the metrics matter
-	k7_window<0, false>(w, ad, hi);
-	k7_window<12, false>(w, ad, hi);
-	k7_window<24, false>(w, ad, hi);
-	k7_window<36, false>(w, ad, hi);
+	// pass 1 (warm-up): only the metrics matter - both states of the lane in one register (k7_step_pk)
+	{
+		uint32_t P = (w[1] & 0xffff0000u) | (w[0] >> 16);
+		k7_window_pk<0, kPkDelta>(P, ad);
+		k7_window_pk<12, kPkDelta>(P, ad);
+		k7_window_pk<24, kPkDelta>(P, ad);
+		k7_window_pk<36, kPkDelta>(P, ad);
+		w[0] = P << 16;
+		w[1] = P & 0xffff0000u;
+	}
 	// rewind: subtract the minimum (osmo_conv_decode_rewind)
 	{
 		const uint32_t mn = half_min((w[0] < w[1] ? w[0] : w[1]) >> 16);
