@@ -1554,6 +1554,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// the small generic variant (NPL = 8; the host launches it for formats of <= 128 symbols with one sync chunk of
 	// <= 16 symbols whose window is <= 64 samples: NT3 speech, DC2) drops the unrolled work the long bursts need
 	constexpr bool SMALL = GEN && NPL == 8;
+	// The next burst's window in flight during this burst's correlation costs 32 registers at the body's peak.  The fused
+	// kernel does without: 78 instead of 87 VGPRs is the step from five to six waves per SIMD, and the sixth wave hides more
+	// latency than the prefetch did (0.288 -> 0.274 ms per 100 k bursts).  The other instantiations keep it.
+	constexpr bool PREFETCH_NEXT = GEN || LAT;
 	constexpr int NSYM = SMALL ? 2 : 4;               // 64-symbol pieces of a burst
 	constexpr int NCHK = SMALL ? 1 : 3;               // sync chunks
 	constexpr int NSH = SMALL ? 1 : 2;                // 16-symbol pieces of the sync sequence
@@ -1595,7 +1599,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		// the ~300 samples under the sync chunks (they go to LDS; the second request hits the lines the
 		// first one is fetching) -- and what needs no data (the rotated reference) is computed while it
 		// travels
-		if (q == 0)
+		if (q == 0 || !PREFETCH_NEXT)
 			window_fetch<NPL, NFULL>(in, in_len, lane, wv);
 		constexpr int SIT = SMALL ? 1 : (SPS == 4 ? 2 : 4);   // 64-sample pieces per chunk window
 		float2 sv[NCHK][SIT];
@@ -1631,7 +1635,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (lane == 0)
 				io.energy[g] = e;
 		}
-		if (q + 1 < 4 && g + 1 < n_end) {
+		if (PREFETCH_NEXT && q + 1 < 4 && g + 1 < n_end) {
 			// the next burst's window travels during this burst's correlation
 			const int kind1 = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
 			window_fetch<NPL, NFULL>(a.iq + io.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
@@ -2097,7 +2101,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 }
 
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
