@@ -2100,8 +2100,14 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 }
 
+// resident waves per SIMD each instantiation is compiled for: the headline one (windows <= 1024 samples at sps 4) fits six
+// without spilling, the run-time-sps one five; the long windows (sps 8: 32 samples per lane) need the registers of three
 template <int NPL, int SPS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
+constexpr int kRx4Waves = NPL > 16 ? 3 : (SPS == 4 ? 6 : 5);
+
+template <int NPL, int SPS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS>, kRx4Waves<NPL, SPS>)))
+void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
