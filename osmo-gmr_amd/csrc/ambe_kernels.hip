@@ -163,6 +163,27 @@ __device__ __forceinline__ int pcm16(float v)
 	return (int)(int16_t)x;
 }
 
+// glibc's routines work in double precision and want many registers for a short time; kept out of line, they do not
+// raise the register count of the frame loop (the tone frames' cosine is on a rare path anyway)
+__device__ __noinline__ float tone_cosf(float x)
+{
+	return ambe_libm::cosf_glibc(x);
+}
+
+__device__ __noinline__ float pow2_of_mlog(const ambe_libm::LibmTab *T, float y)
+{
+	bool ok;
+	const float v = ambe_libm::pow2f(*T, y, &ok);              // powf(2.0, Mlog), frame.c:355
+	return ok ? v : (float)exp2((double)y);
+}
+
+__device__ __noinline__ float fourth_root(const ambe_libm::LibmTab *T, float x)
+{
+	bool ok;
+	const float v = ambe_libm::powf_pos(*T, x, 0.25f, &ok);    // powf(x, 0.25f), synth.c:352-355
+	return ok ? v : (float)sqrt(sqrt((double)x));
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64) void k_ambe_init(AmbeState *state, int n_ch, int flags)
@@ -362,9 +383,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				}
 				int v = 0;
 				if (any && i >= start && i < start + n) {
-					v = (int)(int16_t)(int)((float)ampl * ambe_libm::cosf_glibc(my1));
+					v = (int)(int16_t)(int)((float)ampl * tone_cosf(my1));
 					if (two)
-						v = (int)(int16_t)(v + (int)(int16_t)(int)((float)ampl * ambe_libm::cosf_glibc(my2)));
+						v = (int)(int16_t)(v + (int)(int16_t)(int)((float)ampl * tone_cosf(my2)));
 				}
 				if (i < N)
 					out[i] = (int16_t)v;
@@ -504,10 +525,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 				float M = 0.0f;
 				if (lane < L) {
 					const float unv = 0.2046f / sqrtf(w0);
-					bool ok;
-					float two_to = ambe_libm::pow2f(*a.libm, s.mlog[sub][lane], &ok);       // powf(2.0, Mlog), frame.c:355
-					if (!ok)
-						two_to = (float)exp2((double)s.mlog[sub][lane]);
+					const float two_to = pow2_of_mlog(a.libm, s.mlog[sub][lane]);
 					M = two_to / 6.0f;
 					if (!voiced_l)
 						M *= unv;
@@ -536,10 +554,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 					float w = 1.0f;
 					if ((lane + 1) * 8 > L) {
 						const float x = k1 * (k2 - k3 * cw);
-						bool ok;
-						float root4 = ambe_libm::powf_pos(*a.libm, x, 0.25f, &ok);            // powf(x, 0.25f), synth.c:352-355
-						if (!ok)
-							root4 = (float)sqrt(sqrt((double)x));
+						const float root4 = fourth_root(a.libm, x);
 						w = sqrtf(M) * root4;
 						if (w > 1.2f)
 							w = 1.2f;
