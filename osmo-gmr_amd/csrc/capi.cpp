@@ -217,6 +217,17 @@ static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
 			a.stage_samples = stage;
 		}
 	}
+	// The same kernel's variant for two training sequences of one chunk each at the same place, one bit per symbol (NT3 FACCH)
+	if (!gen_off && a.impl == 0 && n > 4096 && sps == 4 && a.dbg_stop == 0 && ht.n_sync == 2 && ht.nbits == 1 &&
+	    ht.n_chunks[0] == 1 && ht.n_chunks[1] == 1 && ht.sync[0][0].pos == ht.sync[1][0].pos &&
+	    ht.sync[0][0].len == ht.sync[1][0].len && ht.sync_tl[0] <= 8 && ht.sync_tl[0] == ht.sync_tl[1] && in_len <= 512 &&
+	    ht.len <= 128 && w <= 64 && ht.ebits <= 432) {
+		const int stage = ht.sync[0][0].len * sps + w - 1;
+		if (stage <= 64) {
+			a.impl = 4;
+			a.stage_samples = stage;
+		}
+	}
 	HIP_TRY(launch_rx(a, false, in_len, st));
 	return 0;
 }

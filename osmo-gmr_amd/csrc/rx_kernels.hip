@@ -182,6 +182,28 @@ static constexpr SbLut make_sb_lut()
 __device__ __attribute__((aligned(16))) const SbLut g_sb_lut = make_sb_lut();
 constexpr int kSbLutBytes = 2048;
 
+// The same for pi/4-CBPSK (one bit per symbol, a turn is two symbols; pi4cxpsk.c:452-507 with nbits = 1): the symbol's
+// one soft bit is 127 - dq (its neighbour always differs in that bit), negative for symbol 1.  Entry = the soft bit in
+// the low byte; cells and boundaries as above (dq steps at odd multiples of 1/256 symbol, cell edges at multiples of 1/512).
+static constexpr SbLut make_sb_lut1()
+{
+	SbLut t{};
+	for (int k = 0; k < 1024; k++) {
+		int q = 2 * k + 1;                    // cell midpoint in 1/1024 symbol; a turn is 2048
+		if (q > 1024)
+			q -= 2048;                        // (-1, 1] symbols
+		const int n = (q + 512 + 2048) / 1024 - 2;  // nearest symbol, floor((q + 512) / 1024)
+		const int dlq = 1024 * n - q;         // round(sv) - sv, odd: never zero
+		const int adl = dlq < 0 ? -dlq : dlq;
+		const int dq = (adl + 4) / 8;         // round(|dl| * 128): adl / 8 is never half an integer
+		const unsigned sp = (unsigned)n & 1u;
+		const int v0 = sp ? -(127 - dq) : (127 - dq);
+		t.v[k] = (uint16_t)((unsigned)v0 & 0xffu);
+	}
+	return t;
+}
+__device__ __attribute__((aligned(16))) const SbLut g_sb_lut1 = make_sb_lut1();
+
 // ---------------------------------------------------------------------------
 // cross-lane helpers (DPP: no LDS traffic)
 // ---------------------------------------------------------------------------
@@ -1400,6 +1422,14 @@ __device__ __forceinline__ float2 sync_coef0(const DevBurst &bt, int n, int sps,
 	return conj_ref_mul(bt.nbits, bt.sync[0][ch].syms[nn], make_float2(c, s));
 }
 
+// the same for symbol n of training sequence sq of a format whose sequences have ONE chunk each (NT3 FACCH)
+__device__ __forceinline__ float2 sync_coef_seq1(const DevBurst &bt, int sq, int n, int sps, float fs)
+{
+	float s, c;
+	sincos_fast(fs * (float)(n * sps), s, c);
+	return conj_ref_mul(bt.nbits, bt.sync[sq][0].syms[n], make_float2(c, s));
+}
+
 // the same for freq_shift = 0, every burst format, sps 1..16: [sps][type][n < 32]
 constexpr int kCoef0MaxSps = 16;
 __device__ float2 g_coef0[kCoef0MaxSps + 1][kNumTypes][32];
@@ -1545,7 +1575,11 @@ struct RxIo {
 // LAT: the caller cares about the latency of ONE burst (the receive loop), not about throughput
 // GEN: demodulation only, every burst of the one format a.fixed_type (one training sequence, QPSK, <= 3 sync chunks,
 // <= 18 sync symbols, <= 256 symbols: NT3 speech, DC2, BCCH, DC6) -- the batch form of gmr1_pi4cxpsk_demod for large n
-template <int NPL, int SPS, bool LAT = false, bool GEN = false>
+// FAC (with GEN, NPL = 8): a format with TWO training sequences of one chunk each at the same place, BPSK - NT3 FACCH.
+// Both sequences are correlated over the one staged window; the second is ranked and timed on the SUM of both
+// correlations, as the reference's uncleared accumulator has it (pi4cxpsk.c:207-237); the timing rows run once per
+// sequence; `cw` holds both correlation arrays of a burst (first cw / 2 lags: sequence 0, then the sum).
+template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
                                          unsigned char *__restrict__ lds_raw, int lane)
 {
@@ -1554,6 +1588,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// the small generic variant (NPL = 8; the host launches it for formats of <= 128 symbols with one sync chunk of
 	// <= 16 symbols whose window is <= 64 samples: NT3 speech, DC2) drops the unrolled work the long bursts need
 	constexpr bool SMALL = GEN && NPL == 8;
+	static_assert(!FAC || SMALL, "the two-sequence variant builds on the small generic one");
+	const int cwh = FAC ? cw / 2 : cw;                // lags per correlation array
 	// The next burst's window in flight during this burst's correlation costs 32 registers at the body's peak.  The fused
 	// kernel does without: 78 instead of 87 VGPRs is the step from five to six waves per SIMD, and the sixth wave hides more
 	// latency than the prefetch did (0.288 -> 0.274 ms per 100 k bursts).  The other instantiations keep it.
@@ -1624,7 +1660,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			cfl = sync_coef0(bt, lane, sps, fs);
 		}
 		WSYNC();
-		if (GEN && lane < tl)
+		if constexpr (FAC) {
+			if (lane < 2 * tl)
+				L.coef[lane] = sync_coef_seq1(bt, lane >= tl ? 1 : 0, lane >= tl ? lane - tl : lane, sps, fs);
+		} else if (GEN && lane < tl)
 			L.coef[lane] = cfl;
 		float avr, avi, inv;
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
@@ -1671,6 +1710,25 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				corr_fixed<SPS, 11, 3, 3>(L.x, sps, w, lane, cfl, corr);
 			else
 				corr_fixed<SPS, 7, 3, 3>(L.x, sps, w, lane, cfl, corr);
+		} else if constexpr (FAC) {
+			const int len = bt.sync[0][0].len;
+			for (int j = lane; j < w; j += 64) {
+				const float2 *xp = L.x + j;
+				v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+				for (int n = 0; n < len; n++) {
+					const float2 x = xp[n * sps];
+					const float2 c0 = L.coef[n], c1 = L.coef[tl + n];
+					acc0 = __builtin_elementwise_fma((v2f){-c0.y, c0.y}, (v2f){x.y, x.x}, acc0);
+					acc0 = __builtin_elementwise_fma((v2f){c0.x, c0.x}, (v2f){x.x, x.y}, acc0);
+					acc1 = __builtin_elementwise_fma((v2f){-c1.y, c1.y}, (v2f){x.y, x.x}, acc1);
+					acc1 = __builtin_elementwise_fma((v2f){c1.x, c1.x}, (v2f){x.x, x.y}, acc1);
+				}
+				float cj = 0.f;
+				cj += sqrtf(fmaf(acc0.x, acc0.x, acc0.y * acc0.y));
+				corr[j] = cj;                               // sequence 0
+				cj += sqrtf(fmaf(acc1.x, acc1.x, acc1.y * acc1.y));
+				corr[cwh + j] = cj;                         // what sequence 1 is ranked and timed on
+			}
 		} else
 		for (int j = lane; j < w; j += 64) {
 			float cj = 0.f;
@@ -1712,133 +1770,144 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// =========================== rows: peak + early/late timing ===========================
 	// osmo_cxvec_peak_energy_find(corr, 3, PEAK_EARLY_LATE, &peak), pi4cxpsk.c:240
 	// LAT: the one burst is row 0's; the other rows work on ITS correlation (speculative bisection below)
-	const float *cr = L.corr + (LAT ? 0 : row) * cw;
+	const float *cr = L.corr + (LAT ? 0 : row) * cw;          // FAC: moved to the second array for the second sequence
 	const int w_p = LAT ? __builtin_amdgcn_readlane(w_r, 0) : w_r;
 	const int tl_p = LAT ? c_types[__builtin_amdgcn_readlane(type_r, 0)].sync_tl[0] : bt_r.sync_tl[0];
 	const int win = w_p < 3 ? w_p : 3;
-	unsigned long long key = 0;
-	for (int m = LAT ? lane : col; m + win <= w_p; m += LAT ? 64 : 16) {
-		float e = 0.f;
-		for (int k = 0; k < win; k++) {
-			const float c = cr[m + k];
-			e += c * c;
-		}
-		const unsigned long long kk = ((unsigned long long)__builtin_bit_cast(uint32_t, e) << 32) | (uint32_t)(~m);
-		key = kk > key ? kk : key;
-	}
-	key = row_max_u64<1>(key);
-	key = row_max_u64<2>(key);
-	key = row_max_u64<4>(key);
-	key = row_max_u64<8>(key);
-	if (LAT) {                                        // the four rows searched the one burst's lags together
-		unsigned long long o = __shfl_xor(key, 16);
-		key = o > key ? o : key;
-		o = __shfl_xor(key, 32);
-		key = o > key ? o : key;
-	}
-	int mi = (int)(~(uint32_t)key);
-	if (mi < 0 || mi + win > w_p)
-		mi = 0;
-	int p = mi;
-	{
-		float pe = -1.f;
-		for (int k = 0; k < win; k++) {
-			const float c = cr[mi + k];
-			const float e = c * c;
-			if (e > pe) { pe = e; p = mi + k; }
-		}
-	}
-	// interpolated correlation at `pos` (lanes 0-7 of the row) and at `pos + 2` (lanes 8-15): same
-	// fractional part, so the same 21 weights; lane sub = col & 7 holds taps k = 3 sub - 10 + {0,1,2}
-	const int ipt = col >> 3, isub = col & 7;
-	auto interp2 = [&](float pos, float &se, float &sl) {
-		const float fl = floorf(pos);
-		const int ib = (int)fl + 2 * ipt;
-		const float f = pos - fl;
-		const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
-		int b = ib - 10, e = ib + 11;
-		if (b < 0) b = 0;
-		if (e >= w_p) e = w_p - 1;
-		float acc = 0.f;
-#pragma unroll
-		for (int t = 0; t < 3; t++) {
-			const int k = 3 * isub - 10 + t;
-			const float sg = ((isub + t) & 1) ? S : -S;
-			const float xx = kPif * ((float)k - f);
-			const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
-			const int i = ib + k;
-			const bool valid = k <= 10 && i >= b && i < e;
-			const float c = cr[valid ? i : 0];
-			acc += valid ? c * wgt : 0.0f;
-		}
-		acc += row_xorf<1>(acc);
-		acc += row_xorf<2>(acc);
-		acc += row_xorf<4>(acc);
-		const float oth = row_xorf<8>(acc);
-		se = ipt ? oth : acc;
-		sl = ipt ? acc : oth;
-	};
-	float early = (float)p - 1.0f, incr = 0.5f;
-	bool active = true;
-	float toa_r, pk;
-	if constexpr (LAT) {
-		// Two levels of the bisection per evaluation: row 0 evaluates the current point, rows 1 / 2 the points
-		// the search moves to if the early / the late side wins -- the same instructions on the same
-		// operands as the level-by-level walk, so the same decisions.
-		auto decide = [](float se, float sl) { const float ee = se * se, le = sl * sl; return ee > le ? -1 : (ee < le ? 1 : 0); };
-#pragma unroll 1
-		for (int it = 0; it < 8; it += 2) {       // levels it, it + 1
-			const float pos = row == 1 ? early - incr : (row == 2 ? early + incr : early);
-			float se, sl;
-			interp2(pos, se, sl);
-			const int dec = decide(se, sl);
-			const int d0 = __builtin_amdgcn_readlane(dec, 0), d1 = __builtin_amdgcn_readlane(dec, 16),
-			          d2 = __builtin_amdgcn_readlane(dec, 32);
-			if (active) {
-				if (d0 == 0) {
-					active = false;
-				} else {
-					early = d0 < 0 ? early - incr : early + incr;
-					const int dn = d0 < 0 ? d1 : d2;
-					const float half = incr * 0.5f;
-					if (dn == 0)
-						active = false;
-					else
-						early = dn < 0 ? early - half : early + half;
-				}
+	float toa_r = 0.f, p_pwr = 0.f;                    // pi4cxpsk.c:227-237: the best sequence so far
+	int sid_r = -1;
+	for (int sq = 0; sq < (FAC ? 2 : 1); sq++) {
+		if (FAC)
+			cr = L.corr + row * cw + sq * cwh;
+		unsigned long long key = 0;
+		for (int m = LAT ? lane : col; m + win <= w_p; m += LAT ? 64 : 16) {
+			float e = 0.f;
+			for (int k = 0; k < win; k++) {
+				const float c = cr[m + k];
+				e += c * c;
 			}
-			incr *= 0.25f;
+			const unsigned long long kk = ((unsigned long long)__builtin_bit_cast(uint32_t, e) << 32) | (uint32_t)(~m);
+			key = kk > key ? kk : key;
 		}
-		// level 8 on row 0; rows 1 / 2 / 3 already evaluate the peak at the three places it can end
+		key = row_max_u64<1>(key);
+		key = row_max_u64<2>(key);
+		key = row_max_u64<4>(key);
+		key = row_max_u64<8>(key);
+		if (LAT) {                                        // the four rows searched the one burst's lags together
+			unsigned long long o = __shfl_xor(key, 16);
+			key = o > key ? o : key;
+			o = __shfl_xor(key, 32);
+			key = o > key ? o : key;
+		}
+		int mi = (int)(~(uint32_t)key);
+		if (mi < 0 || mi + win > w_p)
+			mi = 0;
+		int p = mi;
 		{
-			const float pos = row == 0 ? early : (row == 1 ? early - incr : (row == 2 ? early + incr : early)) + 1.0f;
-			float se, sl;
-			interp2(pos, se, sl);
-			const int d0 = active ? __builtin_amdgcn_readlane(decide(se, sl), 0) : 0;
-			const float p1 = lane_val(se, 16), p2 = lane_val(se, 32), p3 = lane_val(se, 48);
-			early = d0 < 0 ? early - incr : (d0 > 0 ? early + incr : early);
-			pk = d0 < 0 ? p1 : (d0 > 0 ? p2 : p3);
-			toa_r = early + 1.0f;
-		}
-	} else {
-#pragma unroll 1
-		for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
-			float se, sl;
-			interp2(early, se, sl);
-			const float ee = se * se, le = sl * sl;
-			if (active) {
-				if (ee > le) early -= incr;
-				else if (ee < le) early += incr;
-				else active = false;
+			float pe = -1.f;
+			for (int k = 0; k < win; k++) {
+				const float c = cr[mi + k];
+				const float e = c * c;
+				if (e > pe) { pe = e; p = mi + k; }
 			}
-			incr *= 0.5f;
 		}
-		toa_r = early + 1.0f;
-		float dummy;
-		interp2(toa_r, pk, dummy);
+		// interpolated correlation at `pos` (lanes 0-7 of the row) and at `pos + 2` (lanes 8-15): same
+		// fractional part, so the same 21 weights; lane sub = col & 7 holds taps k = 3 sub - 10 + {0,1,2}
+		const int ipt = col >> 3, isub = col & 7;
+		auto interp2 = [&](float pos, float &se, float &sl) {
+			const float fl = floorf(pos);
+			const int ib = (int)fl + 2 * ipt;
+			const float f = pos - fl;
+			const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
+			int b = ib - 10, e = ib + 11;
+			if (b < 0) b = 0;
+			if (e >= w_p) e = w_p - 1;
+			float acc = 0.f;
+	#pragma unroll
+			for (int t = 0; t < 3; t++) {
+				const int k = 3 * isub - 10 + t;
+				const float sg = ((isub + t) & 1) ? S : -S;
+				const float xx = kPif * ((float)k - f);
+				const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
+				const int i = ib + k;
+				const bool valid = k <= 10 && i >= b && i < e;
+				const float c = cr[valid ? i : 0];
+				acc += valid ? c * wgt : 0.0f;
+			}
+			acc += row_xorf<1>(acc);
+			acc += row_xorf<2>(acc);
+			acc += row_xorf<4>(acc);
+			const float oth = row_xorf<8>(acc);
+			se = ipt ? oth : acc;
+			sl = ipt ? acc : oth;
+		};
+		float early = (float)p - 1.0f, incr = 0.5f;
+		bool active = true;
+		float toa_s, pk_s;
+		if constexpr (LAT) {
+			// Two levels of the bisection per evaluation: row 0 evaluates the current point, rows 1 / 2 the points
+			// the search moves to if the early / the late side wins -- the same instructions on the same
+			// operands as the level-by-level walk, so the same decisions.
+			auto decide = [](float se, float sl) { const float ee = se * se, le = sl * sl; return ee > le ? -1 : (ee < le ? 1 : 0); };
+	#pragma unroll 1
+			for (int it = 0; it < 8; it += 2) {       // levels it, it + 1
+				const float pos = row == 1 ? early - incr : (row == 2 ? early + incr : early);
+				float se, sl;
+				interp2(pos, se, sl);
+				const int dec = decide(se, sl);
+				const int d0 = __builtin_amdgcn_readlane(dec, 0), d1 = __builtin_amdgcn_readlane(dec, 16),
+				          d2 = __builtin_amdgcn_readlane(dec, 32);
+				if (active) {
+					if (d0 == 0) {
+						active = false;
+					} else {
+						early = d0 < 0 ? early - incr : early + incr;
+						const int dn = d0 < 0 ? d1 : d2;
+						const float half = incr * 0.5f;
+						if (dn == 0)
+							active = false;
+						else
+							early = dn < 0 ? early - half : early + half;
+					}
+				}
+				incr *= 0.25f;
+			}
+			// level 8 on row 0; rows 1 / 2 / 3 already evaluate the peak at the three places it can end
+			{
+				const float pos = row == 0 ? early : (row == 1 ? early - incr : (row == 2 ? early + incr : early)) + 1.0f;
+				float se, sl;
+				interp2(pos, se, sl);
+				const int d0 = active ? __builtin_amdgcn_readlane(decide(se, sl), 0) : 0;
+				const float p1 = lane_val(se, 16), p2 = lane_val(se, 32), p3 = lane_val(se, 48);
+				early = d0 < 0 ? early - incr : (d0 > 0 ? early + incr : early);
+				pk_s = d0 < 0 ? p1 : (d0 > 0 ? p2 : p3);
+				toa_s = early + 1.0f;
+			}
+		} else {
+	#pragma unroll 1
+			for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
+				float se, sl;
+				interp2(early, se, sl);
+				const float ee = se * se, le = sl * sl;
+				if (active) {
+					if (ee > le) early -= incr;
+					else if (ee < le) early += incr;
+					else active = false;
+				}
+				incr *= 0.5f;
+			}
+			toa_s = early + 1.0f;
+			float dummy;
+			interp2(toa_s, pk_s, dummy);
+		}
+		pk_s = pk_s * __builtin_amdgcn_rcpf((float)tl_p);
+		if (pk_s * pk_s > p_pwr) {                      // needs strictly more than what is there (0 at first)
+			p_pwr = pk_s * pk_s;
+			toa_r = toa_s;
+			sid_r = sq;
+		}
 	}
-	pk = pk * __builtin_amdgcn_rcpf((float)tl_p);
-	const bool found_r = (pk * pk) > 0.0f;            // p_pwr starts at 0: needs strictly more
+	const bool found_r = sid_r >= 0;
 	if (a.dbg_stop == 3) return;
 	const int d_r = (int)roundf(toa_r);
 
@@ -1924,7 +1993,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				float s, c;
 				sincos_fast(fs_r * (float)idx, s, c);
 				x = cmul(x, make_float2(c, s));
-				t0[h] = conj_ref_mul(nbits_r, bt_r.sync[0][ch].syms[nn], x);
+				t0[h] = conj_ref_mul(nbits_r, bt_r.sync[FAC ? (sid_r > 0 ? 1 : 0) : 0][ch].syms[nn], x);
 				chn[h] = ch;
 				spos[h] = sp;
 			}
@@ -1973,7 +2042,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	if (col == 0 && row_live) {
 		const int rv = found_r ? 0 : -1;
 		io.rv[g_row] = rv;
-		if (io.sync_id) io.sync_id[g_row] = found_r ? 0 : -1;
+		if (io.sync_id) io.sync_id[g_row] = found_r ? sid_r : -1;
 		if (io.toa) io.toa[g_row] = found_r ? toa_r : 0.f;
 		if (io.freq_err) io.freq_err[g_row] = found_r ? ffe_r : 0.f;
 	}
@@ -1983,7 +2052,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// only: behind the soft-bit rows, which themselves overlay the correlation the rows above were reading)
 	unsigned char *const lut = lds_raw + (GEN ? 4 * 432 : 0);
 	// the soft-bit table (2 KB, L2-resident) goes to LDS now that the rows are done with the pass-1 data it overlays
-	const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(g_sb_lut.v);
+	const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(FAC ? g_sb_lut1.v : g_sb_lut.v);
 	const uint4 lut_a = lut_src[lane], lut_b = lut_src[lane + 64];
 	WSYNC();
 	reinterpret_cast<uint4 *>(lut)[lane] = lut_a;
@@ -2061,7 +2130,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				int cell;
 				asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(cell) : "v"(th2));
 				cell = zero ? 0 : (cell & 2046);
-				*reinterpret_cast<uint16_t *>(eb + 2 * ord) = *reinterpret_cast<const uint16_t *>(lut + cell);
+				if constexpr (FAC)
+					eb[ord] = (int8_t)lut[cell];                   // one soft bit per symbol
+				else
+					*reinterpret_cast<uint16_t *>(eb + 2 * ord) = *reinterpret_cast<const uint16_t *>(lut + cell);
 			}
 		}
 		if (io.ebits) {
@@ -2119,14 +2191,14 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 }
 
 // demodulation only, one burst format per launch, four bursts per wavefront (rx4_body<..., GEN>)
-template <int NPL, int SPS>
+template <int NPL, int SPS, bool FAC = false>
 __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int g0 = blockIdx.x * 4;
 	const RxIo io = {a.offset, nullptr, a.freq_shift, nullptr, nullptr, nullptr, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
-	rx4_body<NPL, SPS, false, true>(a, io, stage_samples, cw, g0, min(a.n, g0 + 4), lds_raw, (int)threadIdx.x);
+	rx4_body<NPL, SPS, false, true, FAC>(a, io, stage_samples, cw, g0, min(a.n, g0 + 4), lds_raw, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -2482,14 +2554,17 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 	// symbols per burst: fused path is BCCH/DC6 (234); generic path sizes for the longest format
 	// third kernel argument: lags the correlation accumulator must hold (fused path: 20*sps + 1)
 	const int max_len = decode ? (20 * a.sps + 1) : kMaxWindow;
-	if (!decode && (a.impl == 2 || a.impl == 3) && a.sps == 4 && max_in_len <= 1024) {
+	if (!decode && (a.impl == 2 || a.impl == 3 || a.impl == 4) && a.sps == 4 && max_in_len <= 1024) {
 		// large batch of one simple burst format (the host checked what rx4_body<GEN> assumes; impl 3: also what its
-		// small variant assumes): four bursts per wave
-		const int cw = (a.in_len[0] - a.ssyms_stride * 4 + 1 + 15) & ~15;       // lags (ssyms_stride = symbols per burst)
+		// small variant assumes; impl 4: the small variant for two training sequences and BPSK): four bursts per wave
+		const int cw1 = (a.in_len[0] - a.ssyms_stride * 4 + 1 + 15) & ~15;      // lags (ssyms_stride = symbols per burst)
+		const int cw = a.impl == 4 ? 2 * cw1 : cw1;                            // impl 4: two correlation arrays per burst
 		size_t off4[4];
 		const size_t lds4 = lds4_layout(a.stage_samples, cw, off4, true);
 		const int grid4 = (a.n + 3) / 4;
-		if (a.impl == 3)
+		if (a.impl == 4)
+			hipLaunchKernelGGL((k_rx4g<8, 4, true>), dim3(grid4), dim3(64), lds4, stream, a, a.stage_samples, cw);
+		else if (a.impl == 3)
 			hipLaunchKernelGGL((k_rx4g<8, 4>), dim3(grid4), dim3(64), lds4, stream, a, a.stage_samples, cw);
 		else
 			hipLaunchKernelGGL((k_rx4g<16, 4>), dim3(grid4), dim3(64), lds4, stream, a, a.stage_samples, cw);

@@ -137,7 +137,7 @@ def test_demod_large_batch_four_bursts_per_wave(gpu_api, orc, pkg):
         assert abs(r["toa"] - d["toa"][k]) < 0.02 and abs(r["freq_err"] - d["freq_err"][k]) < 1e-5
 
 
-@pytest.mark.parametrize("name,win", [("dc2", 12), ("bcch", 80), ("nt3_speech", 6)])
+@pytest.mark.parametrize("name,win", [("dc2", 12), ("bcch", 80), ("nt3_speech", 6), ("nt3_facch", 6)])
 def test_demod_four_per_wave_equals_one_per_wave(gpu_api, orc, pkg, name, win):
     """The same bursts through both demodulation kernels: 4097+ bursts in one call (k_rx4g) and in calls of <= 4096
     (k_rx): decisions identical (rv, sync_id), toa within a bisection step, soft symbols within 1e-4, soft bits within
@@ -149,7 +149,9 @@ def test_demod_four_per_wave_equals_one_per_wave(gpu_api, orc, pkg, name, win):
     n = 4500
     eb = rng.integers(0, 2, (n, info.ebits), dtype=np.uint8)
     jit = max(0, min(8, win // 2 - 2))
-    bb = synth.synth_windows(fmt, synth.map_symbols(fmt, eb), 4, win, rng, toa_jitter=jit, frac=True, cfo_hz_std=20.0,
+    # formats with two training sequences (NT3 FACCH: the kernel's two-sequence variant): both in the batch
+    sid = rng.integers(0, len(fmt.sync), n) if len(fmt.sync) > 1 else 0
+    bb = synth.synth_windows(fmt, synth.map_symbols(fmt, eb, sync_id=sid), 4, win, rng, toa_jitter=jit, frac=True, cfo_hz_std=20.0,
                              esn0_db=rng.choice([8.0, 15.0], n), gain_db_std=3.0)
     in_len = bb.in_len
     off = np.arange(n, dtype=np.uint64) * np.uint64(bb.stride)
@@ -158,6 +160,10 @@ def test_demod_four_per_wave_equals_one_per_wave(gpu_api, orc, pkg, name, win):
     small = {k: np.concatenate([p[k] for p in parts]) for k in ("rv", "sync_id", "toa", "freq_err", "ebits", "ssyms")}
     assert np.array_equal(big["rv"], small["rv"]) and np.array_equal(big["sync_id"], small["sync_id"])
     assert not big["rv"].any()
+    if len(fmt.sync) > 1:
+        # the sequence that was sent is the one that is found (the second one is ranked on the sum of both correlations,
+        # the reference's quirk: it wins whenever it is there, and mostly when it is not - what matters is GPU == oracle)
+        assert (big["sync_id"][np.asarray(sid) == 1] == 1).all() and set(np.unique(big["sync_id"])) <= {0, 1}
     assert np.max(np.abs(big["toa"] - small["toa"])) <= 16 / 1024 + 1e-6
     same_pick = np.rint(big["toa"]) == np.rint(small["toa"])
     assert same_pick.mean() > 0.995
@@ -168,9 +174,13 @@ def test_demod_four_per_wave_equals_one_per_wave(gpu_api, orc, pkg, name, win):
     ds = np.minimum(ds, 2 ** info.nbits - ds)                    # soft symbols live on a circle of 2^nbits
     assert ds.max() < 1e-4
     # the payload bits come back (hard decisions) at these signal levels
-    assert ((big["ebits"] < 0) == eb.astype(bool)).mean() > 0.97
+    # (with two training sequences only where the second was sent: the reference's ranking takes the second one anyway,
+    # and a burst sent with the first is then read against the wrong phase reference - DESIGN.md, reference quirks)
+    sent_ok = np.asarray(sid) == len(fmt.sync) - 1 if len(fmt.sync) > 1 else np.ones(n, bool)
+    assert ((big["ebits"][sent_ok] < 0) == eb[sent_ok].astype(bool)).mean() > 0.97
     for k in range(0, n, 450):
         r = orc.demod(name, bb.iq[k, :in_len], 4)
+        assert r["sync_id"] == big["sync_id"][k]
         assert r["rv"] == 0 and abs(r["toa"] - big["toa"][k]) <= 16 / 1024 + 1e-6
         if np.rint(r["toa"]) == np.rint(big["toa"][k]):
             assert np.max(np.abs(r["ebits"].astype(int) - big["ebits"][k].astype(int))) <= 1
