@@ -81,6 +81,22 @@ const char *gmr1_hip_last_error(void);
 const char *gmr1_hip_version(void);
 int         gmr1_hip_burst_info(int burst_id, struct gmr1_hip_burst_flat *out);
 
+/* ---- which Viterbi decoder of libosmocore the layer-1 chains reproduce ------
+ * The reference hands every channel to osmo_conv_decode() (src/l1/bcch.c:94, ccch.c:98, facch3.c:160, tch3.c:174,
+ * facch9.c:134, tch9.c:170, rach.c:167, xch_dc12.c:97).  Which arithmetic that is depends on the libosmocore the
+ * integrator links: its generic decoder (every version; src/conv.c), or -- since 2017, for codes with K in {5, 7} and
+ * N in {2, 3, 4}: every chain above except xCH (K = 9) and TCH9 2k4 (N = 5) -- osmo_conv_decode_acc (src/conv_acc.c).
+ * The two differ in metric quantisation, start states, flush steps and the tail-biting end state, so near the decoding
+ * threshold they return different frames, and the accelerated one returns 0 where the generic one returns the path
+ * metric (`conv_rv`).  Pick the one the replaced build used.  Process-wide; takes effect with the next call; the
+ * default is GMR1_HIP_CONV_GENERIC unless the environment says GMR1_HIP_CONV_DECODER=acc when the library is first used. */
+enum gmr1_hip_conv_decoder {
+	GMR1_HIP_CONV_GENERIC = 0,   /* osmo_conv_decode's generic path for every code */
+	GMR1_HIP_CONV_ACC     = 1,   /* osmo_conv_decode_acc where libosmocore >= 0.10 dispatches to it, generic elsewhere */
+};
+int gmr1_hip_set_conv_decoder(int decoder);     /* 0, or -EINVAL */
+int gmr1_hip_get_conv_decoder(void);
+
 /* ---- normal-burst demodulation (any burst type, one type per call) ------- */
 /* iq: interleaved float32 I/Q; burst i occupies iq[offset[i] .. offset[i]+in_len) (complex samples).
  * Optional outputs may be NULL.  ebits is n x ebits_stride int8, ssyms n x bt.len float. */

@@ -19,6 +19,7 @@ BURST_IDS = ["bcch", "dc2", "dc6", "dc12", "nt3_speech", "nt3_facch", "nt6", "nt
 # every symbol include/gmr1_hip.h and include/osmocom/gmr1/**.h declare
 EXPORTED_FUNCTIONS = [
     "gmr1_hip_init", "gmr1_hip_last_error", "gmr1_hip_version", "gmr1_hip_burst_info",
+    "gmr1_hip_set_conv_decoder", "gmr1_hip_get_conv_decoder",
     "gmr1_hip_demod_batch_dev", "gmr1_hip_demod_batch",
     "gmr1_hip_bcch_decode_batch_dev", "gmr1_hip_ccch_decode_batch_dev",
     "gmr1_hip_bcch_decode_batch", "gmr1_hip_ccch_decode_batch",
@@ -160,6 +161,34 @@ def burst_format(name_or_id):
                      for c in range(b.n_sync_chunks[s])])
     data = [(b.data[c].pos, b.data[c].len) for c in range(b.n_data)]
     return synth.BurstFormat(b.name.decode(), float(b.rotation), b.nbits, b.len, b.ebits, sync, data)
+
+
+CONV_GENERIC, CONV_ACC = 0, 1
+
+
+def set_conv_decoder(decoder: int):
+    """gmr1_hip_set_conv_decoder: which libosmocore Viterbi decoder the layer-1 chains reproduce (process-wide)."""
+    _check(load().gmr1_hip_set_conv_decoder(C.c_int(int(decoder))), "gmr1_hip_set_conv_decoder")
+
+
+def get_conv_decoder() -> int:
+    return int(load().gmr1_hip_get_conv_decoder())
+
+
+class conv_decoder:
+    """with api.conv_decoder(api.CONV_ACC): ...  -- switch the decoder for a block (tests, bench)."""
+
+    def __init__(self, decoder):
+        self.decoder = int(decoder)
+
+    def __enter__(self):
+        self.prev = get_conv_decoder()
+        set_conv_decoder(self.decoder)
+        return self
+
+    def __exit__(self, *exc):
+        set_conv_decoder(self.prev)
+        return False
 
 
 def init(device: int = 0):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -40,6 +41,22 @@ int fail(int code, const char *fmt, ...)
 }
 
 const char *last_error() { return t_err; }
+
+namespace {
+std::atomic<int> g_conv_decoder{-1};       // -1: not chosen yet (the environment decides on first use)
+}
+int conv_acc()
+{
+	int v = g_conv_decoder.load(std::memory_order_relaxed);
+	if (v < 0) {
+		const char *e = getenv("GMR1_HIP_CONV_DECODER");
+		v = (e && (!strcmp(e, "acc") || !strcmp(e, "1"))) ? GMR1_HIP_CONV_ACC : GMR1_HIP_CONV_GENERIC;
+		int expect = -1;
+		if (!g_conv_decoder.compare_exchange_strong(expect, v))
+			v = expect;
+	}
+	return v == GMR1_HIP_CONV_ACC;
+}
 
 std::mutex &custom_slots_mutex()
 {
@@ -133,6 +150,16 @@ extern "C" {
 // ---------------------------------------------------------------------------
 const char *gmr1_hip_version(void) { return "gmr1-hip 0.1 (gfx950)"; }
 const char *gmr1_hip_last_error(void) { return last_error(); }
+
+int gmr1_hip_set_conv_decoder(int decoder)
+{
+	if (decoder != GMR1_HIP_CONV_GENERIC && decoder != GMR1_HIP_CONV_ACC)
+		return fail(-EINVAL, "gmr1_hip_set_conv_decoder: %d is neither GMR1_HIP_CONV_GENERIC nor GMR1_HIP_CONV_ACC", decoder);
+	g_conv_decoder.store(decoder);
+	return 0;
+}
+
+int gmr1_hip_get_conv_decoder(void) { return conv_acc() ? GMR1_HIP_CONV_ACC : GMR1_HIP_CONV_GENERIC; }
 
 int gmr1_hip_init(int device)
 {
@@ -356,7 +383,7 @@ struct OneBurst {
 	hipStream_t st = nullptr;
 	unsigned char *h = nullptr, *d = nullptr;      // the block: host address, device address
 	bool memo = false;
-	int memo_chain = 0, memo_n = 0;
+	int memo_chain = 0, memo_n = 0, memo_acc = 0;
 	int8_t memo_eb[432];
 	uint8_t memo_l2[24];
 	int32_t memo_crc = 0, memo_conv = 0;
@@ -459,6 +486,7 @@ int gmr1_pi4cxpsk_demod(struct gmr1_pi4cxpsk_burst *burst_type,
 			if (fused) {
 				g_one.memo = true;
 				g_one.memo_chain = kind ? kChainCcch : kChainBcch;
+				g_one.memo_acc = conv_acc();
 				g_one.memo_n = ht.ebits;
 				std::memcpy(g_one.memo_eb, one_h<int8_t>(kOneEb), (size_t)ht.ebits);
 				std::memcpy(g_one.memo_l2, one_h<uint8_t>(kOneOut + 32), 24);
@@ -493,7 +521,7 @@ static int l1_dev(hipStream_t st, int chain, int n, const int8_t *ebits, uint8_t
 	int r = dev_state(&s);
 	if (r) return r;
 	L1Args a;
-	a.n = n; a.chain = chain; a.ebits = ebits; a.l2 = l2; a.crc = crc; a.conv = conv;
+	a.n = n; a.chain = chain; a.conv_acc = conv_acc(); a.ebits = ebits; a.l2 = l2; a.crc = crc; a.conv = conv;
 	HIP_TRY(launch_l1(a, st));
 	return 0;
 }
@@ -555,7 +583,8 @@ static int decode_one(int chain, uint8_t *l2, const sbit_t *bits_e, int *conv_rv
 		int r = one_ready(&usable);
 		if (r) return r;
 		if (usable) {
-			if (g_one.memo && g_one.memo_chain == chain && g_one.memo_n == neb && !std::memcmp(g_one.memo_eb, bits_e, (size_t)neb)) {
+			if (g_one.memo && g_one.memo_chain == chain && g_one.memo_n == neb && g_one.memo_acc == conv_acc() &&
+			    !std::memcmp(g_one.memo_eb, bits_e, (size_t)neb)) {
 				// these very soft bits were decoded by the demodulator call that produced them
 				std::memcpy(l2, g_one.memo_l2, 24);
 				if (conv_rv) *conv_rv = g_one.memo_conv;
@@ -596,6 +625,7 @@ int rx_base_args(int sps, const float *iq, RxArgs *out)
 	RxArgs a;
 	std::memset(&a, 0, sizeof(a));
 	a.sps = sps;
+	a.conv_acc = conv_acc();
 	a.in_len[0] = window_len(234, sps, 20 * sps);   // gmr1_rx.c:759
 	a.in_len[1] = window_len(234, sps, 10 * sps);   // gmr1_rx.c:809
 	a.fixed_type = -1;

@@ -17,6 +17,8 @@ namespace gmr1 {
 
 int fail(int code, const char *fmt, ...);
 const char *last_error();
+// 1 when the layer-1 chains follow libosmocore's accelerated Viterbi decoder (gmr1_hip_set_conv_decoder), else 0
+int conv_acc();
 
 #define HIP_TRY(expr)                                                                  \
 	do {                                                                               \

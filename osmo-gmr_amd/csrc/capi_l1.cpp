@@ -17,7 +17,7 @@ int gmr1_hip_facch3_decode_batch_dev(void *stream, int n, const int8_t *ebits, c
 	int r = dev_state(&s);
 	if (r) return r;
 	Facch3Args a;
-	a.n = n; a.ebits = ebits; a.ciph = ciph; a.l2 = l2; a.bits_s = bits_s; a.crc = crc; a.conv = conv;
+	a.n = n; a.conv_acc = conv_acc(); a.ebits = ebits; a.ciph = ciph; a.l2 = l2; a.bits_s = bits_s; a.crc = crc; a.conv = conv;
 	HIP_TRY(launch_facch3(a, (hipStream_t)stream));
 	return 0;
 }
@@ -62,7 +62,7 @@ int gmr1_hip_tch3_decode_batch_dev(void *stream, int n, int m, const int8_t *ebi
 	int r = dev_state(&s);
 	if (r) return r;
 	Tch3Args a;
-	a.n = n; a.m = m ? 1 : 0; a.ebits = ebits; a.ciph = ciph; a.frames = frames; a.bits_s = bits_s; a.conv = conv;
+	a.n = n; a.m = m ? 1 : 0; a.conv_acc = conv_acc(); a.ebits = ebits; a.ciph = ciph; a.frames = frames; a.bits_s = bits_s; a.conv = conv;
 	HIP_TRY(launch_tch3(a, (hipStream_t)stream));
 	return 0;
 }

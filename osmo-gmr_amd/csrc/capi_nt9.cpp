@@ -134,7 +134,7 @@ int nt9_dev(hipStream_t st, int kind, int n, int seq_len, const int8_t *ebits, c
 	if (r) return r;
 	Nt9Args a;
 	std::memset(&a, 0, sizeof(a));
-	a.n = n; a.seq_len = seq_len; a.kind = kind; a.N = kKinds[kind].N; a.len = kKinds[kind].len;
+	a.n = n; a.seq_len = seq_len; a.kind = kind; a.conv_acc = conv_acc(); a.N = kKinds[kind].N; a.len = kKinds[kind].len;
 	a.map = map; a.ebits = ebits; a.ciph = ciph; a.l2 = l2; a.l2_bytes = kKinds[kind].l2_bytes;
 	a.sacch = sacch; a.status = status; a.crc = crc; a.conv = conv;
 	HIP_TRY(launch_nt9(a, st));
@@ -159,7 +159,7 @@ int tch9_runs_dev_impl(hipStream_t st, int mode, int n, const int32_t *seq_pos, 
 	if (r) return r;
 	Nt9Args a;
 	std::memset(&a, 0, sizeof(a));
-	a.n = n; a.seq_len = 1; a.seq_pos = seq_pos; a.kind = mode; a.N = kKinds[mode].N; a.len = kKinds[mode].len;
+	a.n = n; a.seq_len = 1; a.seq_pos = seq_pos; a.kind = mode; a.conv_acc = conv_acc(); a.N = kKinds[mode].N; a.len = kKinds[mode].len;
 	a.map = map; a.ebits = ebits; a.ciph = ciph; a.l2 = l2; a.l2_bytes = kKinds[mode].l2_bytes; a.conv = conv;
 	HIP_TRY(launch_nt9(a, st));
 	return 0;

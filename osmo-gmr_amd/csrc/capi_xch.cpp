@@ -36,7 +36,7 @@ int rach_dev(hipStream_t st, int n, const int8_t *ebits, const uint8_t *sb_mask,
 	int r = dev_state(&s);
 	if (r) return r;
 	RachArgs a;
-	a.n = n; a.ebits = ebits; a.sb_mask = sb_mask; a.rach = rach; a.rv = rv; a.conv = conv; a.crc = crc;
+	a.n = n; a.conv_acc = conv_acc(); a.ebits = ebits; a.sb_mask = sb_mask; a.rach = rach; a.rv = rv; a.conv = conv; a.crc = crc;
 	HIP_TRY(launch_rach(a, st));
 	return 0;
 }

@@ -51,6 +51,7 @@ struct RxArgs {
 	int stage_samples;     // fused path: LDS samples for the sync-chunk windows (max over BCCH / DC6)
 	int impl;              // fused path: 0 = k_rx4 (row-batched serial phases), 1 = k_rx (one burst at a time);
 	                       // demod only: 2 / 3 = k_rx4g (four bursts per wave; 3: its small-format variant), else k_rx
+	int conv_acc;          // fused path: 1 = libosmocore's accelerated Viterbi decoder (GMR1_HIP_CONV_ACC), 0 = its generic one
 	const float2 *iq;
 	const uint64_t *offset;
 	const uint8_t *kind;
@@ -102,6 +103,7 @@ struct ModOrderArgs {
 struct L1Args {
 	int n;
 	int chain;             // kChainBcch / kChainCcch
+	int conv_acc;          // 1 = libosmocore's accelerated decoder, 0 = its generic one
 	const int8_t *ebits;   // n x (424|432)
 	uint8_t *l2;
 	int32_t *crc, *conv;
@@ -186,6 +188,7 @@ hipError_t launch_acq_glue(int step, const AcqArgs &a, hipStream_t stream);
 // ---- traffic-channel layer 1 (l1_kernels.hip) -------------------------------
 struct Facch3Args {
 	int n;                     // frames (each = 4 bursts x 104 soft bits)
+	int conv_acc;              // 1 = libosmocore's accelerated decoder, 0 = its generic one
 	const int8_t *ebits;       // n x 416
 	const uint8_t *ciph;       // optional n x 384 keystream bits
 	uint8_t *l2;               // n x 10
@@ -196,6 +199,7 @@ struct Facch3Args {
 struct Tch3Args {
 	int n;                     // bursts (212 soft bits each, two speech frames)
 	int m;                     // multiplexing mode 0 / 1
+	int conv_acc;              // 1 = libosmocore's accelerated decoder, 0 = its generic one
 	const int8_t *ebits;       // n x 212
 	const uint8_t *ciph;       // optional n x 208 keystream bits
 	uint8_t *frames;           // n x 2 x 10
@@ -279,6 +283,7 @@ struct Nt9Args {
 	const int32_t *seq_pos;    // optional: position of every burst in its run (runs of unequal length, back to back)
 	int kind;                  // 0 2k4, 1 4k8, 2 9k6 (enum gmr1_tch9_mode), 3 FACCH9
 	int N;                     // coded bits per input bit (5, 3, 2, 2)
+	int conv_acc;              // 1 = libosmocore's accelerated decoder where it applies (N <= 4), 0 = its generic one
 	int len;                   // data bits (144, 240, 480, 316)
 	const uint32_t *map;       // (len + 4) x N descriptors of the coded bits (see nt9_kernels.hip)
 	const int8_t *ebits;       // n x 662
@@ -294,6 +299,7 @@ hipError_t launch_nt9(const Nt9Args &a, hipStream_t stream);
 // RACH (nt9_kernels.hip, same K = 5 trellis) and xCH over DC12 (xch_kernels.hip, K = 9)
 struct RachArgs {
 	int n;
+	int conv_acc;              // 1 = libosmocore's accelerated decoder, 0 = its generic one
 	const int8_t *ebits;       // n x 494
 	const uint8_t *sb_mask;    // n
 	uint8_t *rach;             // n x 18

@@ -14,7 +14,13 @@
 //              two states per lane), 32 hard
 //              class-2 bits, MSB-first packing.  One (burst, frame) per wavefront.
 //
-// Both follow libosmocore's generic osmo_conv_decode (oracle/orc_3p.c decisions D1, D4).
+// Both follow libosmocore's generic osmo_conv_decode (oracle/orc_3p.c decisions D1, D4) or, instantiated with ACC, its
+// accelerated decoder osmo_conv_decode_acc (decision D1b, oracle/orc_3p_acc.c): correlation metric -- here as the
+// equivalent non-negative cost  sum of |in| over the coded bits that contradict the soft bit's sign  --, every start
+// state allowed (flushed codes: state 0 leads by 127 * N * K; tail-biting: all equal), full butterflies in the flush
+// steps, tail-biting end state = best sum, first in the decoder's own (bit-reversed) state numbering, no metric returned.
+#include <type_traits>
+
 #include "gmr1_dev.h"
 
 namespace gmr1 {
@@ -70,11 +76,17 @@ __device__ __forceinline__ uint32_t row_xor(uint32_t v)
 	else if constexpr (X == 2) return dpp<0x4E>(v);
 	else return dpp<0xB1>(v);
 }
+template <bool ACC = false>
 __device__ __forceinline__ int sbit_cost(int v, int bit)
 {
-	// ((in - (+-127))^2 >> 9), erasures cost nothing (libosmocore conv.c, generic decoder)
-	const int e = bit ? v + 127 : v - 127;
-	return v ? (__mul24(e, e) >> 9) : 0;
+	if constexpr (ACC) {
+		// conv_acc.c maximises sum in * (+-1): the cost of contradicting the soft bit is |in| (half the correlation lost)
+		return bit ? (v > 0 ? v : 0) : (v < 0 ? -v : 0);
+	} else {
+		// ((in - (+-127))^2 >> 9), erasures cost nothing (libosmocore conv.c, generic decoder)
+		const int e = bit ? v + 127 : v - 127;
+		return v ? (__mul24(e, e) >> 9) : 0;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -137,8 +149,8 @@ __device__ __forceinline__ uint32_t k5_partner(uint32_t w)
 
 // one rate-1/4 trellis step on the packed word [metric:16 | window decisions:16]; the cost of a coded
 // 4-bit word is A[word >> 2] + B[word & 3] (two byte tables per step: coded bits 0-1 and 2-3)
-template <int PH>
-__device__ __forceinline__ uint32_t k5r4_step(uint32_t w, const uint8_t *__restrict__ ab, uint32_t ov_own, uint32_t ov_par)
+template <int PH, typename CT>
+__device__ __forceinline__ uint32_t k5r4_step(uint32_t w, const CT *__restrict__ ab, uint32_t ov_own, uint32_t ov_par)
 {
 	const uint32_t p = k5_partner<PH>(w);
 	const uint32_t c_own = (uint32_t)ab[ov_own >> 2] + (uint32_t)ab[4 + (ov_own & 3u)];
@@ -148,10 +160,14 @@ __device__ __forceinline__ uint32_t k5r4_step(uint32_t w, const uint8_t *__restr
 	return t1 < t2 ? t1 : t2;
 }
 
+// ACC: two soft bits of -128 in one table entry cost 256 -- 16-bit table entries in that mode
+template <bool ACC>
 __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 {
+	typedef typename std::conditional<ACC, uint16_t, uint8_t>::type CT;
+	typedef typename std::conditional<ACC, uint4, uint2>::type CW;
 	__shared__ __align__(16) int8_t s_eb[4][416];
-	__shared__ __align__(16) uint2 s_cst[4][kF3Steps];      // per step: A[4] (coded bits 0-1), B[4] (coded bits 2-3)
+	__shared__ __align__(16) CW s_cst[4][kF3Steps];         // per step: A[4] (coded bits 0-1), B[4] (coded bits 2-3)
 	__shared__ uint16_t s_win[6][64];                       // window decisions per row location
 	__shared__ __align__(16) uint32_t s_ub[4][4];
 	const int lane = threadIdx.x;
@@ -201,13 +217,18 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 				flip ^= a.ciph[(size_t)(f0 + q) * 384 + 96 * burst + p] != 0;
 			if (flip)
 				v = (int8_t)(-v);
-			c0[j] = (uint32_t)sbit_cost(v, 0);
-			c1[j] = (uint32_t)sbit_cost(v, 1);
+			c0[j] = (uint32_t)sbit_cost<ACC>(v, 0);
+			c1[j] = (uint32_t)sbit_cost<ACC>(v, 1);
 		}
-		// byte x of A = cost of coded bits (0, 1) = (x >> 1, x & 1); B likewise for coded bits (2, 3)
-		const uint32_t aw = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
-		const uint32_t bw = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
-		s_cst[q][k] = make_uint2(aw, bw);
+		// entry x of A = cost of coded bits (0, 1) = (x >> 1, x & 1); B likewise for coded bits (2, 3)
+		if constexpr (ACC) {
+			s_cst[q][k] = make_uint4((c0[0] + c0[1]) | ((c0[0] + c1[1]) << 16), (c1[0] + c0[1]) | ((c1[0] + c1[1]) << 16),
+			                         (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 16), (c1[2] + c0[3]) | ((c1[2] + c1[3]) << 16));
+		} else {
+			const uint32_t aw = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
+			const uint32_t bw = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
+			s_cst[q][k] = make_uint2(aw, bw);
+		}
 	}
 	WSYNC();
 
@@ -227,8 +248,9 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 #pragma unroll
 	for (int j = 0; j < 16; j++)
 		T[j] = hit & (1u << j);
-	constexpr uint32_t kSent = 0xF0000000u;
-	const uint8_t *cb = reinterpret_cast<const uint8_t *>(&s_cst[row][0]);
+	// every other start state: unreachable (generic decoder) / behind state 0 by 127 * N * K, halved like the costs (ACC)
+	constexpr uint32_t kSent = ACC ? (127u * 4u * 5u / 2u) << 16 : 0xF0000000u;
+	const CT *cb = reinterpret_cast<const CT *>(&s_cst[row][0]);
 	uint32_t w = (loc ? kSent : 0u) | T[0];
 	w = k5r4_step<0>(w, cb + 8 * 0, ov_own[0], ov_par[0]) + T[1];
 	w = k5r4_step<1>(w, cb + 8 * 1, ov_own[1], ov_par[1]) + T[2];
@@ -237,7 +259,7 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 	w = (w & 0xffff0000u) | T[0];
 #pragma unroll 1
 	for (int wm = 0; wm < 5; wm++) {
-		const uint8_t *c = cb + 8 * (4 + 16 * wm);
+		const CT *c = cb + 8 * (4 + 16 * wm);
 #pragma unroll
 		for (int j = 0; j < 16; j += 4) {
 			w = k5r4_step<0>(w, c + 8 * (j + 0), ov_own[0], ov_par[0]) + T[(j + 1) & 15];
@@ -249,7 +271,7 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 		w = (w & 0xffff0000u) | T[0];
 	}
 	{
-		const uint8_t *c = cb + 8 * 84;
+		const CT *c = cb + 8 * 84;
 #pragma unroll
 		for (int j = 0; j < 8; j += 4) {
 			w = k5r4_step<0>(w, c + 8 * (j + 0), ov_own[0], ov_par[0]) + T[j + 1];
@@ -258,16 +280,16 @@ __global__ __launch_bounds__(64) void k_facch3(Facch3Args a)
 			w = k5r4_step<3>(w, c + 8 * (j + 3), ov_own[3], ov_par[3]) + T[j + 4];
 		}
 		w = k5r4_step<0>(w, c + 8 * 8, ov_own[0], ov_par[0]);
-		w = hi[0] ? kSent : (w + T[9]);
+		w = !ACC && hi[0] ? kSent : (w + T[9]);
 		w = k5r4_step<1>(w, c + 8 * 9, ov_own[1], ov_par[1]);
-		w = hi[1] ? kSent : (w + T[10]);
+		w = !ACC && hi[1] ? kSent : (w + T[10]);
 		w = k5r4_step<2>(w, c + 8 * 10, ov_own[2], ov_par[2]);
-		w = hi[2] ? kSent : (w + T[11]);
+		w = !ACC && hi[2] ? kSent : (w + T[11]);
 		w = k5r4_step<3>(w, c + 8 * 11, ov_own[3], ov_par[3]);
-		w = hi[3] ? kSent : w;
+		w = !ACC && hi[3] ? kSent : w;
 		s_win[5][lane] = (uint16_t)w;
 	}
-	const uint32_t final_ae = w >> 16;        // state 0 ends in location 0 of the row
+	const uint32_t final_ae = ACC ? 0u : w >> 16;        // state 0 ends in location 0 of the row; osmo_conv_decode_acc returns 0
 	WSYNC();
 
 	// ---- survivor chain, one lane per row: six dependent 16-bit reads
@@ -523,6 +545,7 @@ __device__ __forceinline__ uint32_t half_min(uint32_t v)
 	return v;
 }
 
+template <bool ACC>
 __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 {
 	__shared__ __align__(16) int8_t s_e[216];
@@ -565,8 +588,8 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 			const int i0 = 2 * s, i1 = 2 * s + 1;
 			const int v0 = tch3_c(s_e, ciph, f, m, i0 - (i0 >> 2));
 			const int v1 = (s & 1) ? 0 : tch3_c(s_e, ciph, f, m, i1 - (i1 >> 2));
-			const int a0 = sbit_cost(v0, 0), a1 = sbit_cost(v0, 1);
-			const int b0 = sbit_cost(v1, 0), b1c = sbit_cost(v1, 1);
+			const int a0 = sbit_cost<ACC>(v0, 0), a1 = sbit_cost<ACC>(v0, 1);
+			const int b0 = sbit_cost<ACC>(v1, 0), b1c = sbit_cost<ACC>(v1, 1);
 			const int da = a1 - a0, db = b1c - b0;
 			ks = a0 + a1 + b0 + b1c;
 			// code word o = (g0 bit << 1) | g1 bit
@@ -602,15 +625,15 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	uint32_t ad[6][2];
 	uint32_t w[2];
 	constexpr uint32_t kSent = 0xF000u;           // unreachable (libosmocore: MAX_AE)
-	constexpr uint32_t kBias = 0x4000u;           // |2 cost - K| <= 252 per step, 48 steps: stays inside 16 bits
+	constexpr uint32_t kBias = 0x4000u;           // |2 cost - K| <= 252 (ACC: 256) per step, 48 steps: stays inside 16 bits
 #pragma unroll
 	for (int r = 0; r < 2; r++) {
 		const uint32_t e = c_k7.o[r][p];
 #pragma unroll
 		for (int ph = 0; ph < 6; ph++)
 			ad[ph][r] = tab_base + 4u * ((e >> (2 * ph)) & 3u);
-		// pass 1 starts from state 0 (D4)
-		w[r] = (c_k7.st[r][p] ? kSent : kBias) << 16;
+		// pass 1 starts from state 0 (D4); conv_acc.c: from every state alike
+		w[r] = (!ACC && c_k7.st[r][p] ? kSent : kBias) << 16;
 	}
 
 	// pass 1 (warm-up): only the metrics matter - both states of the lane in one register (k7_step_pk)
@@ -646,10 +669,12 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 
 	// best end state of each frame: smallest metric, lowest state on ties (48 = 8 * 6 steps: every state is
 	// back in its phase-0 position)
+	// (ACC: best sum, the first in conv_acc.c's own state numbering -- newest bit on top, i.e. bit-reversed -- on ties)
 	unsigned long long key;
 	{
-		const unsigned long long k0 = ((unsigned long long)(w[0] >> 16) << 32) | c_k7.st[0][p];
-		const unsigned long long k1 = ((unsigned long long)(w[1] >> 16) << 32) | c_k7.st[1][p];
+		const uint32_t s0 = c_k7.st[0][p], s1 = c_k7.st[1][p];
+		const unsigned long long k0 = ((unsigned long long)(w[0] >> 16) << 32) | (ACC ? __brev(s0) >> 26 : s0);
+		const unsigned long long k1 = ((unsigned long long)(w[1] >> 16) << 32) | (ACC ? __brev(s1) >> 26 : s1);
 		key = k1 < k0 ? k1 : k0;
 	}
 #pragma unroll
@@ -657,9 +682,9 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 		const unsigned long long ok = __shfl_xor(key, o);
 		key = ok < key ? ok : key;
 	}
-	const uint32_t end_state = (uint32_t)key & 63u;
-	// words hold 2 * ae - sum K (+ bias)
-	const int32_t min_ae = ((int)(uint32_t)(key >> 32) - (int)kBias + ksum) >> 1;
+	const uint32_t end_state = ACC ? __brev((uint32_t)key & 63u) >> 26 : (uint32_t)key & 63u;
+	// words hold 2 * ae - sum K (+ bias); osmo_conv_decode_acc returns 0
+	const int32_t min_ae = ACC ? 0 : ((int)(uint32_t)(key >> 32) - (int)kBias + ksum) >> 1;
 
 	// ---- survivor chain (uniform across the half-wave): four dependent 16-bit reads.
 	// u[42..47] are the end state's bits (bit j = u[47 - j]); window m gives u[12m-6 .. 12m+5] LSB first
@@ -700,7 +725,10 @@ hipError_t launch_facch3(const Facch3Args &a, hipStream_t st)
 {
 	if (a.n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_facch3, dim3((a.n + 3) / 4), dim3(64), 0, st, a);
+	if (a.conv_acc)
+		hipLaunchKernelGGL(k_facch3<true>, dim3((a.n + 3) / 4), dim3(64), 0, st, a);
+	else
+		hipLaunchKernelGGL(k_facch3<false>, dim3((a.n + 3) / 4), dim3(64), 0, st, a);
 	return hipGetLastError();
 }
 
@@ -708,7 +736,10 @@ hipError_t launch_tch3(const Tch3Args &a, hipStream_t st)
 {
 	if (a.n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_tch3, dim3(a.n), dim3(64), 0, st, a);
+	if (a.conv_acc)
+		hipLaunchKernelGGL(k_tch3<true>, dim3(a.n), dim3(64), 0, st, a);
+	else
+		hipLaunchKernelGGL(k_tch3<false>, dim3(a.n), dim3(64), 0, st, a);
 	return hipGetLastError();
 }
 

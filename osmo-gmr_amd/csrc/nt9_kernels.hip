@@ -16,6 +16,13 @@
 //
 // The metric of 320 ... 484 steps does not fit 16 bits, so every 64 steps the row minimum is subtracted
 // (and added back into conv_rv at the end); comparisons never see the difference.
+//
+// Instantiated with ACC the kernels follow libosmocore's accelerated decoder (osmo_conv_decode_acc: K = 5, N <= 4, so
+// not the rate-1/5 TCH9 2k4 code) instead of its generic one -- decision D1b, oracle/orc_3p_acc.c; see l1_kernels.hip.
+// The cost of contradicting a soft bit is |in| (N even) or 2 |in| (N = 3: state 0's lead of 127 * N * K correlation units
+// is odd there, so costs stay in correlation units), table entries are 16 bits wide (two soft bits of -128 cost 256).
+#include <type_traits>
+
 #include "gmr1_dev.h"
 
 namespace gmr1 {
@@ -131,18 +138,23 @@ __device__ __forceinline__ uint32_t coded_word(int N, uint32_t s, uint32_t b)
 	return o;
 }
 
+template <bool ACC = false, int SCALE = 1>
 __device__ __forceinline__ int sbit_cost(int v, int bit)
 {
-	const int e = bit ? v + 127 : v - 127;
-	return v ? (__mul24(e, e) >> 9) : 0;      // erasures (and punctured bits) cost nothing
+	if constexpr (ACC) {
+		return SCALE * (bit ? (v > 0 ? v : 0) : (v < 0 ? -v : 0));
+	} else {
+		const int e = bit ? v + 127 : v - 127;
+		return v ? (__mul24(e, e) >> 9) : 0;      // erasures (and punctured bits) cost nothing
+	}
 }
 
 static constexpr int kNt9MaxSteps = 484;
 static constexpr int kNt9MaxWin = 31;
 constexpr uint32_t kSent = 0xF0000000u;
 
-template <int PH, int NW>
-__device__ __forceinline__ uint32_t nt9_step(uint32_t w, const uint8_t *__restrict__ ct, const uint32_t (&o_own)[3],
+template <int PH, int NW, typename CT>
+__device__ __forceinline__ uint32_t nt9_step(uint32_t w, const CT *__restrict__ ct, const uint32_t (&o_own)[3],
                                              const uint32_t (&o_par)[3])
 {
 	const uint32_t p = partner<PH>(w);
@@ -154,18 +166,20 @@ __device__ __forceinline__ uint32_t nt9_step(uint32_t w, const uint8_t *__restri
 	return t1 < t2 ? t1 : t2;
 }
 
-template <int NW>
+template <int NW, bool ACC>
 __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 {
+	typedef typename std::conditional<ACC, uint16_t, uint8_t>::type CT;
+	constexpr int SC = NW == 2 ? 2 : 1;              // ACC cost unit (see the head of the file)
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
 	const int row = lane >> 4;
 	const uint32_t loc = (uint32_t)lane & 15u;
 	const int S = a.len + 4;                         // trellis steps
 	const int N = a.N;
-	const int stride = 4 * NW;                       // bytes of cost tables per step
-	uint8_t *ct_all = lds_raw;                                                     // 4 x S x stride
-	uint16_t *win = reinterpret_cast<uint16_t *>(lds_raw + (size_t)4 * kNt9MaxSteps * stride);   // kNt9MaxWin x 64
+	const int stride = 4 * NW;                       // entries of cost tables per step
+	CT *ct_all = reinterpret_cast<CT *>(lds_raw);                                  // 4 x S x stride
+	uint16_t *win = reinterpret_cast<uint16_t *>(lds_raw + (size_t)4 * kNt9MaxSteps * stride * sizeof(CT));   // kNt9MaxWin x 64
 	uint32_t *ub = reinterpret_cast<uint32_t *>(win + kNt9MaxWin * 64);            // 4 x 16 words
 	const int g0 = blockIdx.x * 4;
 
@@ -191,18 +205,22 @@ __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 					flip ^= a.ciph[src * 658 + ((m >> 11) & 0x3ffu)] != 0;
 				if (flip)
 					v = (int8_t)(-v);
-				c0[j] = (uint32_t)sbit_cost(v, 0);
-				c1[j] = (uint32_t)sbit_cost(v, 1);
+				c0[j] = (uint32_t)sbit_cost<ACC, SC>(v, 0);
+				c1[j] = (uint32_t)sbit_cost<ACC, SC>(v, 1);
 			}
 		}
+		// entries: costs of the coded bit pairs (0, 1), (2, 3) and of coded bit 4, `SH` bits wide
+		constexpr int SH = 8 * (int)sizeof(CT);
 		uint32_t *dst = reinterpret_cast<uint32_t *>(ct_all + ((size_t)q * S + k) * stride);
-		if (N == 2) {
-			dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
+		const uint32_t a00 = c0[0] + c0[1], a01 = c0[0] + c1[1], a10 = c1[0] + c0[1], a11 = c1[0] + c1[1];
+		if constexpr (ACC) {
+			dst[0] = a00 | (a01 << SH); dst[1] = a10 | (a11 << SH);
+			if (NW == 2) { dst[2] = c0[2] | (c1[2] << SH); dst[3] = 0; }           // N = 3 (N = 5 never runs with ACC)
 		} else {
-			dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
-			if (N == 3) {
+			dst[0] = a00 | (a01 << 8) | (a10 << 16) | (a11 << 24);
+			if (NW == 2) {
 				dst[1] = c0[2] | (c1[2] << 8);
-			} else {
+			} else if (NW == 3) {
 				dst[1] = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
 				dst[2] = c0[4] | (c1[4] << 8);
 			}
@@ -238,11 +256,13 @@ __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 
 	// ---- forward pass: 4 steps (decisions u[-4..-1]), full windows of 16, a last window of `tail`
 	// steps (16 or 12) whose final four are the flush
-	const uint8_t *ct = ct_all + (size_t)row * S * stride;
+	const CT *ct = ct_all + (size_t)row * S * stride;
 	const int n_win = (a.len + 15) / 16;             // windows after the first four steps
 	const int tail = a.len - 16 * (n_win - 1);       // 16 or 12
 	uint32_t off = 0;                                // what has been subtracted from the metrics so far
-	uint32_t w = (loc ? kSent : 0u) | T[0];
+	// every other start state: unreachable / (ACC) behind state 0 by 127 * N * K correlation units = SC / 2 cost units each
+	constexpr uint32_t kOther = ACC ? (uint32_t)(127 * (NW == 2 ? 3 : 2) * 5 * SC / 2) << 16 : kSent;
+	uint32_t w = (loc ? kOther : 0u) | T[0];
 	w = nt9_step<0, NW>(w, ct + 0 * stride, o_own[0], o_par[0]) + T[1];
 	w = nt9_step<1, NW>(w, ct + 1 * stride, o_own[1], o_par[1]) + T[2];
 	w = nt9_step<2, NW>(w, ct + 2 * stride, o_own[2], o_par[2]) + T[3];
@@ -250,7 +270,7 @@ __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 	w = (w & 0xffff0000u) | T[0];
 #pragma unroll 1
 	for (int wm = 0; wm < n_win - 1; wm++) {
-		const uint8_t *c = ct + (size_t)(4 + 16 * wm) * stride;
+		const CT *c = ct + (size_t)(4 + 16 * wm) * stride;
 #pragma unroll
 		for (int j = 0; j < 16; j += 4) {
 			w = nt9_step<0, NW>(w, c + (j + 0) * stride, o_own[0], o_par[0]) + T[(j + 1) & 15];
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 		}
 	}
 	{
-		const uint8_t *c = ct + (size_t)(4 + 16 * (n_win - 1)) * stride;
+		const CT *c = ct + (size_t)(4 + 16 * (n_win - 1)) * stride;
 		const int body = tail - 4;                   // steps of the last window before the flush (12 or 8)
 #pragma unroll
 		for (int j = 0; j < 8; j += 4) {
@@ -289,17 +309,18 @@ __global__ __launch_bounds__(64) void k_nt9(Nt9Args a)
 		}
 		// flush: only b = 0 transitions survive (lanes whose new state ends in 1 become unreachable)
 		const uint32_t t1 = body == 12 ? T[13] : T[9], t2 = body == 12 ? T[14] : T[10], t3 = body == 12 ? T[15] : T[11];
+		// (ACC: ordinary butterflies)
 		w = nt9_step<0, NW>(w, c + (body + 0) * stride, o_own[0], o_par[0]);
-		w = hi[0] ? kSent : (w + t1);
+		w = !ACC && hi[0] ? kSent : (w + t1);
 		w = nt9_step<1, NW>(w, c + (body + 1) * stride, o_own[1], o_par[1]);
-		w = hi[1] ? kSent : (w + t2);
+		w = !ACC && hi[1] ? kSent : (w + t2);
 		w = nt9_step<2, NW>(w, c + (body + 2) * stride, o_own[2], o_par[2]);
-		w = hi[2] ? kSent : (w + t3);
+		w = !ACC && hi[2] ? kSent : (w + t3);
 		w = nt9_step<3, NW>(w, c + (body + 3) * stride, o_own[3], o_par[3]);
-		w = hi[3] ? kSent : w;
+		w = !ACC && hi[3] ? kSent : w;
 		win[(n_win - 1) * 64 + lane] = (uint16_t)w;
 	}
-	const uint32_t final_ae = (w >> 16) + off;       // state 0 ends in location 0 of the row
+	const uint32_t final_ae = ACC ? 0u : (w >> 16) + off;       // state 0 ends in location 0 of the row; osmo_conv_decode_acc returns 0
 	WSYNC();
 
 	// ---- survivor chain, one lane per row: window m's decisions at the survivor's location are decoded
@@ -445,9 +466,11 @@ static constexpr SynRach make_syn_rach()
 }
 __constant__ SynRach c_syn_rach = make_syn_rach();
 
+template <bool ACC>
 __global__ __launch_bounds__(64) void k_rach(RachArgs a)
 {
-	__shared__ __align__(16) uint8_t s_ct[4 * kRachSteps * 8];
+	typedef typename std::conditional<ACC, uint16_t, uint8_t>::type CT;
+	__shared__ __align__(16) CT s_ct[4 * kRachSteps * 8];
 	__shared__ uint16_t s_win[kRachWin * 64];
 	__shared__ uint32_t s_ub[4 * 8];
 	const int lane = threadIdx.x;
@@ -478,13 +501,18 @@ __global__ __launch_bounds__(64) void k_rach(RachArgs a)
 						v2 = (int8_t)(-v2);
 					v = (int8_t)((v + v2) >> 1);
 				}
-				c0[j] = (uint32_t)sbit_cost(v, 0);
-				c1[j] = (uint32_t)sbit_cost(v, 1);
+				c0[j] = (uint32_t)sbit_cost<ACC>(v, 0);
+				c1[j] = (uint32_t)sbit_cost<ACC>(v, 1);
 			}
 		}
 		uint32_t *dst = reinterpret_cast<uint32_t *>(s_ct + ((size_t)q * kRachSteps + k) * stride);
-		dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
-		dst[1] = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
+		if constexpr (ACC) {
+			dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 16); dst[1] = (c1[0] + c0[1]) | ((c1[0] + c1[1]) << 16);
+			dst[2] = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 16); dst[3] = (c1[2] + c0[3]) | ((c1[2] + c1[3]) << 16);
+		} else {
+			dst[0] = (c0[0] + c0[1]) | ((c0[0] + c1[1]) << 8) | ((c1[0] + c0[1]) << 16) | ((c1[0] + c1[1]) << 24);
+			dst[1] = (c0[2] + c0[3]) | ((c0[2] + c1[3]) << 8) | ((c1[2] + c0[3]) << 16) | ((c1[2] + c1[3]) << 24);
+		}
 	}
 	WSYNC();
 
@@ -507,9 +535,10 @@ __global__ __launch_bounds__(64) void k_rach(RachArgs a)
 
 	// ---- forward pass: 4 steps (decisions u[-4..-1]), nine windows of 16, a last one of 15 steps whose
 	// final four are the flush.  Max metric 163 * 4 * 126 does not fit 16 bits: renormalise every 4 windows.
-	const uint8_t *ct = s_ct + (size_t)row * kRachSteps * stride;
+	const CT *ct = s_ct + (size_t)row * kRachSteps * stride;
 	uint32_t off = 0;
-	uint32_t w = (loc ? kSent : 0u) | T[0];
+	constexpr uint32_t kOther = ACC ? (127u * 4u * 5u / 2u) << 16 : kSent;     // see k_nt9
+	uint32_t w = (loc ? kOther : 0u) | T[0];
 	w = nt9_step<0, 2>(w, ct + 0 * stride, o_own[0], o_par[0]) + T[1];
 	w = nt9_step<1, 2>(w, ct + 1 * stride, o_own[1], o_par[1]) + T[2];
 	w = nt9_step<2, 2>(w, ct + 2 * stride, o_own[2], o_par[2]) + T[3];
@@ -517,7 +546,7 @@ __global__ __launch_bounds__(64) void k_rach(RachArgs a)
 	w = (w & 0xffff0000u) | T[0];
 #pragma unroll 1
 	for (int wm = 0; wm < kRachWin - 1; wm++) {
-		const uint8_t *c = ct + (size_t)(4 + 16 * wm) * stride;
+		const CT *c = ct + (size_t)(4 + 16 * wm) * stride;
 #pragma unroll
 		for (int j = 0; j < 16; j += 4) {
 			w = nt9_step<0, 2>(w, c + (j + 0) * stride, o_own[0], o_par[0]) + T[(j + 1) & 15];
@@ -538,7 +567,7 @@ __global__ __launch_bounds__(64) void k_rach(RachArgs a)
 		}
 	}
 	{
-		const uint8_t *c = ct + (size_t)(4 + 16 * (kRachWin - 1)) * stride;
+		const CT *c = ct + (size_t)(4 + 16 * (kRachWin - 1)) * stride;
 		// 11 data steps ...
 #pragma unroll
 		for (int j = 0; j < 8; j += 4) {
@@ -552,17 +581,17 @@ __global__ __launch_bounds__(64) void k_rach(RachArgs a)
 		w = nt9_step<2, 2>(w, c + 10 * stride, o_own[2], o_par[2]) + T[11];
 		// ... and four flush steps (phases 3, 0, 1, 2): only b = 0 transitions survive
 		w = nt9_step<3, 2>(w, c + 11 * stride, o_own[3], o_par[3]);
-		w = hi[3] ? kSent : (w + T[12]);
+		w = !ACC && hi[3] ? kSent : (w + T[12]);
 		w = nt9_step<0, 2>(w, c + 12 * stride, o_own[0], o_par[0]);
-		w = hi[0] ? kSent : (w + T[13]);
+		w = !ACC && hi[0] ? kSent : (w + T[13]);
 		w = nt9_step<1, 2>(w, c + 13 * stride, o_own[1], o_par[1]);
-		w = hi[1] ? kSent : (w + T[14]);
+		w = !ACC && hi[1] ? kSent : (w + T[14]);
 		w = nt9_step<2, 2>(w, c + 14 * stride, o_own[2], o_par[2]);
-		w = hi[2] ? kSent : w;
+		w = !ACC && hi[2] ? kSent : w;
 		s_win[(kRachWin - 1) * 64 + lane] = (uint16_t)w;
 	}
 	// 163 = 3 mod 4 steps: the layout is that of phase 3, where location 0 still holds state 0
-	const uint32_t final_ae = (w >> 16) + off;
+	const uint32_t final_ae = ACC ? 0u : (w >> 16) + off;
 	WSYNC();
 
 	// ---- survivor chain, one lane per row.  The last window ends in the phase-3 layout, but the walk
@@ -631,7 +660,10 @@ hipError_t launch_rach(const RachArgs &a, hipStream_t stream)
 {
 	if (a.n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_rach, dim3((a.n + 3) / 4), dim3(64), 0, stream, a);
+	if (a.conv_acc)
+		hipLaunchKernelGGL(k_rach<true>, dim3((a.n + 3) / 4), dim3(64), 0, stream, a);
+	else
+		hipLaunchKernelGGL(k_rach<false>, dim3((a.n + 3) / 4), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 
@@ -640,14 +672,19 @@ hipError_t launch_nt9(const Nt9Args &a, hipStream_t stream)
 	if (a.n <= 0)
 		return hipSuccess;
 	const int nw = a.N == 2 ? 1 : (a.N == 3 ? 2 : 3);
-	const size_t lds = (size_t)4 * kNt9MaxSteps * 4 * nw + (size_t)kNt9MaxWin * 64 * 2 + 4 * 16 * 4;
+	const bool acc = a.conv_acc && a.N <= 4;         // osmo_conv_decode sends N = 5 to the generic decoder
+	const size_t lds = (size_t)4 * kNt9MaxSteps * 4 * nw * (acc ? 2 : 1) + (size_t)kNt9MaxWin * 64 * 2 + 4 * 16 * 4;
 	const dim3 grid((a.n + 3) / 4);
-	if (nw == 1)
-		hipLaunchKernelGGL(k_nt9<1>, grid, dim3(64), lds, stream, a);
+	if (nw == 1 && acc)
+		hipLaunchKernelGGL((k_nt9<1, true>), grid, dim3(64), lds, stream, a);
+	else if (nw == 1)
+		hipLaunchKernelGGL((k_nt9<1, false>), grid, dim3(64), lds, stream, a);
+	else if (nw == 2 && acc)
+		hipLaunchKernelGGL((k_nt9<2, true>), grid, dim3(64), lds, stream, a);
 	else if (nw == 2)
-		hipLaunchKernelGGL(k_nt9<2>, grid, dim3(64), lds, stream, a);
+		hipLaunchKernelGGL((k_nt9<2, false>), grid, dim3(64), lds, stream, a);
 	else
-		hipLaunchKernelGGL(k_nt9<3>, grid, dim3(64), lds, stream, a);
+		hipLaunchKernelGGL((k_nt9<3, false>), grid, dim3(64), lds, stream, a);
 	return hipGetLastError();
 }
 

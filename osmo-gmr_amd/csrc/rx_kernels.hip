@@ -112,6 +112,30 @@ static constexpr CostTable make_cost()
 }
 __constant__ CostTable c_cost = make_cost();
 
+// The same for libosmocore's accelerated decoder (osmo_conv_decode_acc, decision D1b: oracle/orc_3p_acc.c).  It MAXIMISES
+// the correlation sum in * (+-1); minimising  sum over the coded bits that contradict the soft bit's sign of |in|  ranks
+// every pair of paths identically ((sum |in| - correlation) / 2, an integer) and is non-negative, so the packed
+// [metric | decisions] words and v_min_u32 serve both decoders.  |in| <= 127 on the fused path (the demodulator's soft
+// bits); two soft bits of -128 in one step would overflow a byte lane -- k_l1 takes 16-bit lanes in this mode.
+static constexpr CostTable make_cost_acc()
+{
+	CostTable t{};
+	for (int idx = 0; idx < 512; idx++) {
+		int v = (int)(int8_t)(uint8_t)(idx & 255);
+		if (idx & 256)
+			v = (int)(int8_t)(uint8_t)(-v);
+		const uint32_t c0 = v < 0 ? (uint32_t)(-v) : 0u;
+		const uint32_t c1 = v > 0 ? (uint32_t)v : 0u;
+		t.a[idx] = c0 | (c0 << 8) | (c1 << 16) | (c1 << 24);
+		t.b[idx] = c0 | (c1 << 8) | (c0 << 16) | (c1 << 24);
+	}
+	return t;
+}
+__constant__ CostTable c_cost_acc = make_cost_acc();
+// what the accelerated decoder gives state 0 as a start: 127 * N * K in correlation units (conv_acc.c reset_decoder),
+// halved like the costs
+constexpr uint32_t kAccLeadK5r2 = 127u * 2u * 5u / 2u;
+
 struct SynTable { uint16_t s[208]; };
 static constexpr SynTable make_syn()
 {
@@ -973,24 +997,28 @@ __device__ int demod_one(int type, const float2 *__restrict__ in, int in_len, in
 // (descramble + de-interleave folded into the gather via c_steps)
 //   bcch.c:91-92 / ccch.c:95-96, interleave.c:73-87, scramb.c:63-73
 // ---------------------------------------------------------------------------
+template <bool ACC = false>
 __device__ __forceinline__ void branch_metrics_k5_12(const int8_t *__restrict__ eb, int chain,
                                                      uint32_t *__restrict__ bm, int lane)
 {
+	const CostTable &ct = ACC ? c_cost_acc : c_cost;
 	for (int k = lane; k < kSteps12; k += 64) {
 		const uint32_t st = c_steps.w[chain][k];
 		// the four byte sums c(a) + c(b) of a step come out of one add of two table words
 		const uint32_t ia = (uint32_t)(uint8_t)eb[st & 0x3ffu] | ((st >> 2) & 0x100u);
 		const uint32_t ib = (uint32_t)(uint8_t)eb[(st >> 16) & 0x3ffu] | ((st >> 18) & 0x100u);
-		bm[k] = c_cost.a[ia] + c_cost.b[ib];
+		bm[k] = ct.a[ia] + ct.b[ib];
 	}
 }
 
 // the four bursts of a fused wave at once: every lane owns steps lane + 64 it of each burst, and the
 // three dependent fetches (step descriptor -> soft bits -> cost words) are each issued for all 16
 // (burst, step) pairs before anything waits -- three memory round trips per wave instead of 48
+template <bool ACC = false>
 __device__ __forceinline__ void branch_metrics4_k5_12(const int8_t *__restrict__ eb, int eb_stride, int row_ok,
                                                       int row_chain, uint32_t *__restrict__ bm, int lane)
 {
+	const CostTable &ct = ACC ? c_cost_acc : c_cost;
 	uint32_t st[2][4];
 #pragma unroll
 	for (int c = 0; c < 2; c++)
@@ -1016,8 +1044,8 @@ __device__ __forceinline__ void branch_metrics4_k5_12(const int8_t *__restrict__
 	for (int q = 0; q < 4; q++)
 #pragma unroll
 		for (int it = 0; it < 4; it++) {
-			va[q][it] = c_cost.a[ia[q][it]];
-			vb[q][it] = c_cost.b[ib[q][it]];
+			va[q][it] = ct.a[ia[q][it]];
+			vb[q][it] = ct.b[ib[q][it]];
 		}
 #pragma unroll
 	for (int q = 0; q < 4; q++) {
@@ -1147,8 +1175,17 @@ __constant__ DecTable c_dec = make_dec();
 	             : [rn] "+v"(R[J]), [qn] "+v"(Q[J])                                                  \
 	             : [ao] "v"(ao[PH]), [ap] "v"(ap[PH]), [off] "i"(4 * (K)))
 
+__device__ __forceinline__ void k5_12_survivors_crc(uint64_t *__restrict__ surv, uint32_t *__restrict__ ubits, int lane,
+                                                    uint32_t &syn_o);
+
 // bm: 4 rows x 212 words; surv: 13 x 64 halfwords of window decisions; ubits: 4 rows x 8 words
 // (decoded bits, LSB first)
+//
+// ACC = libosmocore's accelerated decoder instead of its generic one (decision D1b, oracle/orc_3p_acc.c; costs from
+// c_cost_acc): every start state is allowed, state 0 leading by 127 * N * K; the four flush steps are ordinary
+// butterflies (the survivor walk still starts in state 0); no path metric is returned.  Ties between the two paths into
+// a state fall to the same (lower) predecessor in both decoders.
+template <bool ACC = false>
 __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restrict__ surv,
                               uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae)
 {
@@ -1173,7 +1210,7 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 #pragma unroll
 	for (int j = 0; j < 16; j++)
 		T[j] = (dc >> 16) & (1u << j);
-	uint32_t w = (loc ? kSentinel : 0u) | T[0];
+	uint32_t w = (loc ? (ACC ? kAccLeadK5r2 << 16 : kSentinel) : 0u) | T[0];
 	uint32_t t1, t2;
 	uint16_t *dump = reinterpret_cast<uint16_t *>(surv) + lane;
 
@@ -1209,17 +1246,31 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 	ACS_PF(0, 0, 14, T[1]); ACS_PF(1, 1, 14, T[2]); ACS_PF(2, 2, 14, T[3]); ACS_PF(3, 3, 14, T[4]);
 	ACS_PF(4, 0, 14, T[5]); ACS_PF(5, 1, 14, T[6]); ACS_PF(6, 2, 14, T[7]); ACS_PF(7, 3, 14, T[8]);
 	ACS_NP(8, 0, 14, T[9]); ACS_NP(9, 1, 12, T[10]); ACS_NP(10, 2, 10, T[11]); ACS_NP(11, 3, 8, T[12]);
-	ACS_NP_END(12, 0, 6);
-	w = hi[0] ? kSentinel : (w + T[13]);
-	ACS_NP_END(13, 1, 4);
-	w = hi[1] ? kSentinel : (w + T[14]);
-	ACS_NP_END(14, 2, 2);
-	w = hi[2] ? kSentinel : (w + T[15]);
-	ACS_NP_END(15, 3, 0);
-	w = hi[3] ? kSentinel : w;
+	if constexpr (ACC) {
+		ACS_NP(12, 0, 6, T[13]); ACS_NP(13, 1, 4, T[14]); ACS_NP(14, 2, 2, T[15]); ACS_NP_END(15, 3, 0);
+		(void)hi;
+	} else {
+		ACS_NP_END(12, 0, 6);
+		w = hi[0] ? kSentinel : (w + T[13]);
+		ACS_NP_END(13, 1, 4);
+		w = hi[1] ? kSentinel : (w + T[14]);
+		ACS_NP_END(14, 2, 2);
+		w = hi[2] ? kSentinel : (w + T[15]);
+		ACS_NP_END(15, 3, 0);
+		w = hi[3] ? kSentinel : w;
+	}
 	dump[12 * 64] = (uint16_t)w;
-	// state 0 ends in location 0 of the row
-	final_ae = w >> 16;
+	// state 0 ends in location 0 of the row; osmo_conv_decode_acc returns 0, not a metric
+	final_ae = ACC ? 0u : w >> 16;
+	k5_12_survivors_crc(surv, ubits, lane, syn_o);
+}
+
+// second half of the decoder: survivor chain and CRC16 of the four rows (shared with the 16-bit-lane forward pass below)
+__device__ __forceinline__ void k5_12_survivors_crc(uint64_t *__restrict__ surv, uint32_t *__restrict__ ubits, int lane,
+                                                    uint32_t &syn_o)
+{
+	const int row = lane >> 4;
+	const uint32_t loc = (uint32_t)lane & 15u;
 	// this lane's CRC syndrome words travel while the survivor chain is walked
 	const uint4 sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][0]);
 	const uint4 sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][4]);
@@ -1285,7 +1336,7 @@ __device__ __forceinline__ void store_l2(uint8_t *l2, const uint32_t *ub)
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
-template <int NPL, int SPS, bool DECODE>
+template <int NPL, int SPS, bool DECODE, bool ACC = false>
 __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -1355,7 +1406,7 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 		WSYNC();     // x is dead from here on: bm / surv / ubits overlay it
 		for (int q = 0; q < 4; q++) {
 			if ((row_ok >> q) & 1) {
-				branch_metrics_k5_12(L.eb + q * kEbRow, (row_chain >> q) & 1, L.bm + q * kSteps12, lane);
+				branch_metrics_k5_12<ACC>(L.eb + q * kEbRow, (row_chain >> q) & 1, L.bm + q * kSteps12, lane);
 			} else {
 				for (int k = lane; k < kSteps12; k += 64)
 					L.bm[q * kSteps12 + k] = 0;
@@ -1365,7 +1416,7 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 		if (a.dbg_stop == 7)
 			return;
 		uint32_t syn, fae;
-		decode4_k5_12(L.bm, L.surv, L.ubits, lane, syn, fae);
+		decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae);
 		const int row = lane >> 4;
 		const int g = g0 + row;
 		if ((lane & 15) == 0 && g < a.n) {
@@ -1579,7 +1630,7 @@ struct RxIo {
 // Both sequences are correlated over the one staged window; the second is ranked and timed on the SUM of both
 // correlations, as the reference's uncleared accumulator has it (pi4cxpsk.c:207-237); the timing rows run once per
 // sequence; `cw` holds both correlation arrays of a burst (first cw / 2 lags: sequence 0, then the sum).
-template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false>
+template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
                                          unsigned char *__restrict__ lds_raw, int lane)
 {
@@ -2149,12 +2200,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 
 	// =========================== rows: layer 1 ===========================
 	WSYNC();     // the window is dead: bm / surv / ubits overlay it
-	branch_metrics4_k5_12(L.eb, 432, row_ok, row_chain, L.bm, lane);
+	branch_metrics4_k5_12<ACC>(L.eb, 432, row_ok, row_chain, L.bm, lane);
 	WSYNC();
 	if (a.dbg_stop == 7)
 		return;
 	uint32_t syn, fae;
-	decode4_k5_12(L.bm, L.surv, L.ubits, lane, syn, fae);
+	decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae);
 	if (col == 0 && row_live) {
 		if ((row_ok >> row) & 1) {
 			store_l2(io.l2 + (size_t)g_row * 24, L.ubits + row * 8);
@@ -2177,7 +2228,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 template <int NPL, int SPS>
 constexpr int kRx4Waves = NPL > 16 ? 3 : (SPS == 4 ? 6 : 5);
 
-template <int NPL, int SPS>
+template <int NPL, int SPS, bool ACC = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS>, kRx4Waves<NPL, SPS>)))
 void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
@@ -2187,7 +2238,7 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 	const int g0 = blockIdx.x * bpw;
 	const RxIo io = {a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
-	rx4_body<NPL, SPS>(a, io, stage_samples, cw, g0, min(a.n, g0 + bpw), lds_raw, (int)threadIdx.x);
+	rx4_body<NPL, SPS, false, false, false, ACC>(a, io, stage_samples, cw, g0, min(a.n, g0 + bpw), lds_raw, (int)threadIdx.x);
 }
 
 // demodulation only, one burst format per launch, four bursts per wavefront (rx4_body<..., GEN>)
@@ -2213,7 +2264,7 @@ __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw
 // frame order, plus -- when a traffic pass follows -- the per-frame context rx_tch3 sees.  A round is about
 // one wave's latency instead of launch + kernel + synchronise + host (~59 us).
 // ---------------------------------------------------------------------------
-template <int NPL, int SPS>
+template <int NPL, int SPS, bool ACC = false>
 __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoopArgs la, int stage_samples, int cw,
                                                                 int lds_per_wave)
 {
@@ -2366,7 +2417,7 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 			}
 			const RxIo io = {s_off, s_kind, s_fs, &s_l2[cb][0][0], s_crc[cb], s_conv[cb], s_rv[cb], nullptr,
 			                 s_toa[cb], s_fe[cb], s_en[cb], nullptr, nullptr};
-			rx4_body<NPL, SPS, true>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane);
+			rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane);
 			if (sink == 1.2345678e-30f)
 				s_fs[wave] = 0.f;                  // keeps the touch alive
 		}
@@ -2466,6 +2517,105 @@ __global__ __launch_bounds__(64) void k_mod_order(ModOrderArgs a, int max_in_len
 	}
 }
 
+// ---------------------------------------------------------------------------
+// The layer-1 chain under libosmocore's accelerated decoder on soft bits from OUTSIDE (they may hold -128, and two of
+// those in one trellis step cost 256: one more than a byte lane of the branch-metric word takes).  Same packed-word
+// butterfly, same windows, same survivor walk as decode4_k5_12<true>; the four costs of a step are 16-bit lanes of two
+// words, formed here from the soft bits themselves.
+// ---------------------------------------------------------------------------
+template <int PH>
+__device__ __forceinline__ uint32_t k5w_step(uint32_t w, const uint16_t *__restrict__ c4, uint32_t oo, uint32_t op)
+{
+	uint32_t p;
+	if constexpr (PH == 0) p = dpp<0x128>(w);                // row_ror:8
+	else if constexpr (PH == 1) p = dpp<0x141>(w);           // row_half_mirror: xor 7
+	else if constexpr (PH == 2) p = dpp<0x4E>(w);            // quad_perm [2,3,0,1]
+	else p = dpp<0xB1>(w);                                   // quad_perm [1,0,3,2]
+	const uint32_t t1 = ((uint32_t)c4[oo] << 16) + w;
+	const uint32_t t2 = ((uint32_t)c4[op] << 16) + p;
+	return t1 < t2 ? t1 : t2;
+}
+
+__global__ __launch_bounds__(64) void k_l1_acc(L1Args a)
+{
+	__shared__ __align__(16) int8_t s_eb[4 * kEbRow];
+	__shared__ __align__(16) uint2 s_bmw[4 * kSteps12];        // per step: costs of the coded words 00, 01 | 10, 11
+	__shared__ __align__(16) uint64_t s_surv[kSteps12];
+	__shared__ __align__(16) uint32_t s_ub[4 * 8];
+	const int lane = threadIdx.x;
+	const int row = lane >> 4;
+	const uint32_t loc = (uint32_t)lane & 15u;
+	const int g0 = blockIdx.x * 4;
+	const int neb = a.chain == kChainCcch ? 432 : 424;
+	const int chain = a.chain == kChainCcch ? 1 : 0;
+
+	for (int q = 0; q < 4; q++) {
+		const int g = g0 + q;
+		if (g < a.n) {
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(a.ebits + (size_t)g * neb);
+			uint32_t *dst = reinterpret_cast<uint32_t *>(s_eb + q * kEbRow);
+			for (int i = lane; i < neb / 4; i += 64)
+				dst[i] = src[i];
+		}
+	}
+	WSYNC();
+	for (int it = lane; it < 4 * kSteps12; it += 64) {
+		const int q = it / kSteps12, k = it % kSteps12;
+		uint2 v = make_uint2(0u, 0u);
+		if (g0 + q < a.n) {
+			const uint32_t st = c_steps.w[chain][k];
+			int va = s_eb[q * kEbRow + (st & 0x3ffu)], vb = s_eb[q * kEbRow + ((st >> 16) & 0x3ffu)];
+			if (st & 0x400u) va = (int8_t)(-va);                  // gmr1_scramble_sbit: -128 stays -128
+			if (st & 0x4000000u) vb = (int8_t)(-vb);
+			const uint32_t a0 = va < 0 ? (uint32_t)(-va) : 0u, a1 = va > 0 ? (uint32_t)va : 0u;
+			const uint32_t b0 = vb < 0 ? (uint32_t)(-vb) : 0u, b1 = vb > 0 ? (uint32_t)vb : 0u;
+			v = make_uint2((a0 + b0) | ((a0 + b1) << 16), (a1 + b0) | ((a1 + b1) << 16));
+		}
+		s_bmw[it] = v;
+	}
+	WSYNC();
+
+	const uint32_t dc = c_dec.v[loc];
+	uint32_t oo[4], op[4], T[16];
+#pragma unroll
+	for (int ph = 0; ph < 4; ph++) {
+		oo[ph] = (dc >> (2 * ph)) & 3u;
+		op[ph] = (dc >> (8 + 2 * ph)) & 3u;
+	}
+#pragma unroll
+	for (int j = 0; j < 16; j++)
+		T[j] = (dc >> 16) & (1u << j);
+	const uint16_t *c = reinterpret_cast<const uint16_t *>(s_bmw + row * kSteps12);
+	uint16_t *dump = reinterpret_cast<uint16_t *>(s_surv) + lane;
+	uint32_t w = (loc ? kAccLeadK5r2 << 16 : 0u) | T[0];
+	w = k5w_step<0>(w, c + 0, oo[0], op[0]) + T[1];
+	w = k5w_step<1>(w, c + 4, oo[1], op[1]) + T[2];
+	w = k5w_step<2>(w, c + 8, oo[2], op[2]) + T[3];
+	w = k5w_step<3>(w, c + 12, oo[3], op[3]);
+	w = (w & 0xffff0000u) | T[0];
+#pragma unroll 1
+	for (int m = 0; m < 13; m++) {
+		const uint16_t *cm = c + 4 * (4 + 16 * m);
+#pragma unroll
+		for (int j = 0; j < 16; j += 4) {
+			w = k5w_step<0>(w, cm + 4 * (j + 0), oo[0], op[0]) + T[(j + 1) & 15];
+			w = k5w_step<1>(w, cm + 4 * (j + 1), oo[1], op[1]) + T[(j + 2) & 15];
+			w = k5w_step<2>(w, cm + 4 * (j + 2), oo[2], op[2]) + T[(j + 3) & 15];
+			w = k5w_step<3>(w, cm + 4 * (j + 3), oo[3], op[3]) + (j + 4 < 16 ? T[(j + 4) & 15] : 0u);
+		}
+		dump[m * 64] = (uint16_t)w;
+		w = (w & 0xffff0000u) | T[0];
+	}
+	uint32_t syn;
+	k5_12_survivors_crc(s_surv, s_ub, lane, syn);
+	const int g = g0 + row;
+	if (loc == 0 && g < a.n) {
+		store_l2(a.l2 + (size_t)g * 24, s_ub + row * 8);
+		a.crc[g] = syn ? 1 : 0;
+		a.conv[g] = 0;
+	}
+}
+
 __global__ __launch_bounds__(64) void k_l1(L1Args a)
 {
 	__shared__ __align__(16) int8_t s_eb[4 * kEbRow];
@@ -2519,7 +2669,10 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 	if (decode) {
 		const int grid = (a.n + 3) / 4;
 		if (a.impl == 1) {
-			hipLaunchKernelGGL((k_rx<NPL, SPS, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
+			if (a.conv_acc)
+				hipLaunchKernelGGL((k_rx<NPL, SPS, true, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
+			else
+				hipLaunchKernelGGL((k_rx<NPL, SPS, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
 		} else {
 			const int cw = (max_len + 15) & ~15;
 			size_t off4[4];
@@ -2537,7 +2690,10 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 			}
 			const int bpw = bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4);
 			const int grid4 = (a.n + bpw - 1) / bpw;
-			hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+			if (a.conv_acc)
+				hipLaunchKernelGGL((k_rx4<NPL, SPS, true>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+			else
+				hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
 		}
 	} else {
 		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
@@ -2592,17 +2748,25 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	const size_t lds4 = (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
 	const size_t lds = lds4 * kLoopPerRound;
 	const dim3 grid((unsigned)n_chains), block(64 * kLoopPerRound);
+#define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                      \
+	do {                                                                                                               \
+		if (a.conv_acc)                                                                                                \
+			hipLaunchKernelGGL((k_rx_loop<NPL, SPS, true>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4); \
+		else                                                                                                           \
+			hipLaunchKernelGGL((k_rx_loop<NPL, SPS>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);  \
+	} while (0)
 	if (a.in_len[0] <= 1024) {
 		if (a.sps == 4)
-			hipLaunchKernelGGL((k_rx_loop<16, 4>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+			GMR1_LOOP_LAUNCH(16, 4);
 		else
-			hipLaunchKernelGGL((k_rx_loop<16, 0>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+			GMR1_LOOP_LAUNCH(16, 0);
 	} else {
 		if (a.sps == 4)
-			hipLaunchKernelGGL((k_rx_loop<32, 4>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+			GMR1_LOOP_LAUNCH(32, 4);
 		else
-			hipLaunchKernelGGL((k_rx_loop<32, 0>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);
+			GMR1_LOOP_LAUNCH(32, 0);
 	}
+#undef GMR1_LOOP_LAUNCH
 	return hipGetLastError();
 }
 
@@ -2647,7 +2811,10 @@ hipError_t launch_l1(const L1Args &a, hipStream_t stream)
 {
 	if (a.n <= 0)
 		return hipSuccess;
-	hipLaunchKernelGGL(k_l1, dim3((a.n + 3) / 4), dim3(64), 0, stream, a);
+	if (a.conv_acc)
+		hipLaunchKernelGGL(k_l1_acc, dim3((a.n + 3) / 4), dim3(64), 0, stream, a);
+	else
+		hipLaunchKernelGGL(k_l1, dim3((a.n + 3) / 4), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 

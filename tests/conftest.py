@@ -44,3 +44,12 @@ def gpu_api(pkg):
     pkg.api.load()
     pkg.api.init(0)
     return pkg.api
+
+
+@pytest.fixture(params=["generic", "acc"])
+def decoder(request, gpu_api, orc):
+    """Runs a GPU parity test once per libosmocore Viterbi decoder (decisions D1 / D1b): the product in
+    the mode gmr1_hip_set_conv_decoder selects against the oracle restating the same decoder."""
+    acc = request.param == "acc"
+    with gpu_api.conv_decoder(gpu_api.CONV_ACC if acc else gpu_api.CONV_GENERIC), orc.conv_mode(1 if acc else 0):
+        yield request.param

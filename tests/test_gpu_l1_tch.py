@@ -18,7 +18,7 @@ def _variants(rng, bits):
     return (("clean", clean), ("noisy", noisy), ("junk", junk), ("coarse", coarse))
 
 
-def test_facch3_bit_exact(gpu_api, orc, pkg):
+def test_facch3_bit_exact(gpu_api, orc, pkg, decoder):
     rng = np.random.default_rng(31)
     n = 403                                     # ragged: not a multiple of 4 frames
     l2 = rng.integers(0, 256, (n, 10), dtype=np.uint8)
@@ -39,7 +39,7 @@ def test_facch3_bit_exact(gpu_api, orc, pkg):
     assert rv == 0 and np.array_equal(out, l2[3]) and np.array_equal(sb, s[3]) and conv == 0
 
 
-def test_tch3_bit_exact(gpu_api, orc, pkg):
+def test_tch3_bit_exact(gpu_api, orc, pkg, decoder):
     rng = np.random.default_rng(32)
     n = 301
     f0 = rng.integers(0, 256, (n, 10), dtype=np.uint8)
@@ -58,7 +58,7 @@ def test_tch3_bit_exact(gpu_api, orc, pkg):
     assert np.array_equal(a0, f0[0]) and np.array_equal(a1, f1[0]) and np.array_equal(sb, s[0]) and c0 == 0 == c1
 
 
-def test_nt3_mix_from_samples_matches_oracle(gpu_api, orc, pkg):
+def test_nt3_mix_from_samples_matches_oracle(gpu_api, orc, pkg, decoder):
     """BASELINE configs[4] from samples (the bench's `--workload nt3`, small): 90 % NT3 speech + 10 % FACCH3 groups,
     window 474, the carrier offset handed over as freq_shift like rx_tch3 does.  Demodulated soft bits within 1 LSB of
     the oracle's, decoded frames / messages identical to the oracle's on the same soft bits, and what was sent comes

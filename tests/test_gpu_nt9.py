@@ -26,7 +26,7 @@ def _soft(rng, hard, kind):
 
 
 @pytest.mark.parametrize("kind", ["clean", "noisy", "erased", "noise", "ties"])
-def test_facch9_bit_exact(gpu_api, orc, kind):
+def test_facch9_bit_exact(gpu_api, orc, kind, decoder):
     rng = np.random.default_rng(3)
     n = 37
     hard = np.zeros((n, 662), np.uint8)
@@ -53,7 +53,7 @@ def test_facch9_bit_exact(gpu_api, orc, kind):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("kind", ["clean", "noisy", "erased", "noise", "ties"])
-def test_tch9_bit_exact(gpu_api, orc, mode, kind):
+def test_tch9_bit_exact(gpu_api, orc, mode, kind, decoder):
     rng = np.random.default_rng(10 * mode + 1)
     n_chan, seq = 3, 7
     nb = orc.TCH9_BYTES[mode]
@@ -80,7 +80,7 @@ def test_tch9_bit_exact(gpu_api, orc, mode, kind):
 
 
 @pytest.mark.parametrize("mode", [0, 2])
-def test_tch9_stateful_reference_call(gpu_api, orc, mode):
+def test_tch9_stateful_reference_call(gpu_api, orc, mode, decoder):
     """gmr1_interleaver_init + gmr1_tch9_decode burst by burst, as gmr1_rx.c:273 / :333 call them, against the
     oracle's stateful decoder (tch9.c:139-175 + interleave.c:163-186)."""
     rng = np.random.default_rng(40 + mode)

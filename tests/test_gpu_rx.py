@@ -64,7 +64,7 @@ def _compare_fused(got, ref, wl, *, label):
                 crc_fail=int((got["crc"] != 0).sum()))
 
 
-def test_l1_bcch_ccch_bit_exact(gpu_api, orc, pkg):
+def test_l1_bcch_ccch_bit_exact(gpu_api, orc, pkg, decoder):
     """Hard-decision l1 chain: same soft bits in -> identical L2 / crc / conv (bit-exact)."""
     rng = np.random.default_rng(11)
     n = 1003   # not a multiple of 4: exercises the ragged last wavefront
@@ -89,7 +89,7 @@ def test_l1_bcch_ccch_bit_exact(gpu_api, orc, pkg):
                 assert np.array_equal(g[0], l2) and not g[1].any()
 
 
-def test_l1_legacy_single_call(gpu_api, orc, pkg):
+def test_l1_legacy_single_call(gpu_api, orc, pkg, decoder):
     """gmr1_bcch_decode / gmr1_ccch_decode: the reference's own one-burst calls."""
     rng = np.random.default_rng(12)
     l2 = rng.integers(0, 256, size=(3, 24), dtype=np.uint8)
@@ -105,7 +105,7 @@ def test_l1_legacy_single_call(gpu_api, orc, pkg):
         assert crc == 0 and np.array_equal(out, l2[i]) and conv == o[2][0]
 
 
-def test_fused_rx_parity_small(gpu_api, orc, pkg):
+def test_fused_rx_parity_small(gpu_api, orc, pkg, decoder):
     wl = workloads.bcch_ccch_mix(pkg, n=2001, seed=3)
     got = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4)
     ref = orc.demod_decode_batch(wl["iq"], wl["offset"], wl["kind"], sps=4)
@@ -114,7 +114,7 @@ def test_fused_rx_parity_small(gpu_api, orc, pkg):
     assert (got["crc"] == 0).mean() > 0.9
 
 
-def test_fused_rx_clean_exact_payload(gpu_api, orc, pkg):
+def test_fused_rx_clean_exact_payload(gpu_api, orc, pkg, decoder):
     """Config 1 flavour: noiseless bursts, integer TOA -> every payload recovered, toa == 40 / 20."""
     wl = workloads.bcch_ccch_mix(pkg, n=70, seed=1, esn0_db=(200.0,), toa_jitter=0, frac=False,
                                  cfo_hz_std=0.0, gain_db_std=0.0)
@@ -309,7 +309,7 @@ def test_demod_low_oversampling(gpu_api, orc, pkg):
 
 
 @pytest.mark.parametrize("sps", [5, 8])
-def test_fused_rx_other_oversampling(gpu_api, orc, pkg, sps):
+def test_fused_rx_other_oversampling(gpu_api, orc, pkg, sps, decoder):
     """The fused path at sps != 4 (generic k_rx4 instantiation; windows of 234 sps + 20 sps / 10 sps samples)."""
     wl = workloads.bcch_ccch_mix(pkg, n=403, seed=7, sps=sps, toa_jitter=2 * sps)
     got = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=sps)

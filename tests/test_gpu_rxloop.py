@@ -45,7 +45,7 @@ def _capture(pkg):
     return streams, sents
 
 
-def test_rx_loop_matches_oracle_per_carrier(gpu_api, orc, pkg):
+def test_rx_loop_matches_oracle_per_carrier(gpu_api, orc, pkg, decoder):
     streams, sents = _capture(pkg)
     length = np.array([s.size for s in streams], np.uint64)
     offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.uint64)
@@ -185,7 +185,7 @@ def _key_n(rec):
              bytes(r["l2"][:int(r["len"])])) for r in rec]
 
 
-def test_rx_loop_tch3_follow_up_matches_oracle(gpu_api, orc, pkg):
+def test_rx_loop_tch3_follow_up_matches_oracle(gpu_api, orc, pkg, decoder):
     """IMM.ASS -> DKAB / speech / FACCH3 on the traffic carrier, plain and A5/1-ciphered (gmr1_rx.c:355-600):
     the record sequence is the oracle's, carrier by carrier."""
     rng = np.random.default_rng(77)
@@ -244,7 +244,7 @@ def _key_big(rec):
              bytes(r["l2"][:int(r["len"])]), int(r["conv"])) for r in rec]
 
 
-def test_rx_loop_tch9_follow_up_matches_oracle(gpu_api, orc, pkg):
+def test_rx_loop_tch9_follow_up_matches_oracle(gpu_api, orc, pkg, decoder):
     """The whole application: IMM.ASS -> TCH3; ASSIGNMENT COMMAND 1 on its FACCH3 -> NT9 bursts on the CSD carrier,
     FACCH9 / TCH9 9k6, A5/1 (gmr1_rx.c:262-353).  Records and big records are the oracle's, carrier by carrier."""
     kc1 = np.arange(8, dtype=np.uint8)

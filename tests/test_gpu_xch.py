@@ -32,7 +32,7 @@ def _xch_batch(pkg, n, seed):
     return l2, sb
 
 
-def test_xch_dc12_matches_oracle(gpu_api, orc, pkg):
+def test_xch_dc12_matches_oracle(gpu_api, orc, pkg, decoder):
     l2, sb = _xch_batch(pkg, 600, 11)
     g_l2, g_crc, g_conv = gpu_api.xch_dc12_decode_batch(sb)
     n_pass = 0
@@ -50,7 +50,7 @@ def test_xch_dc12_matches_oracle(gpu_api, orc, pkg):
     assert r_crc == g_crc[5] and r_conv == g_conv[5] and np.array_equal(r_l2, g_l2[5])
 
 
-def test_rach_matches_oracle(gpu_api, orc, pkg):
+def test_rach_matches_oracle(gpu_api, orc, pkg, decoder):
     synth = importlib.import_module(pkg.__name__ + ".synth")
     rng = np.random.default_rng(12)
     n = 803                                        # not a multiple of the four bursts per wavefront
