@@ -71,7 +71,21 @@ def parse():
     ap.add_argument("--shard-timeout", type=float, default=240.0,
                     help="N > 1: if the sharded config-4 run has not finished after this many seconds, the headline line is "
                          "printed without it (with the reason) instead of hanging the job")
-    return ap.parse_args()
+    ap.add_argument("--conv-decoder", default="generic", choices=["generic", "acc"],
+                    help="which libosmocore Viterbi decoder the layer-1 chains reproduce (gmr1_hip_set_conv_decoder): its generic "
+                         "one (default) or osmo_conv_decode_acc; the CPU oracle beside it runs the same one")
+    args = ap.parse_args()
+    # read by the library on first use and by tests/oracle_lib.py when it loads the oracle; inherited by spawned ranks
+    os.environ["GMR1_HIP_CONV_DECODER"] = args.conv_decoder
+    os.environ["ORC_CONV_MODE"] = "1" if args.conv_decoder == "acc" else "0"
+    return args
+
+
+def emit(out, **kw):
+    """Print the one JSON line; every line names the Viterbi decoder the run reproduced."""
+    if isinstance(out.get("config"), dict):
+        out["config"]["conv_decoder"] = os.environ.get("GMR1_HIP_CONV_DECODER", "generic")
+    print(json.dumps(out), **kw)
 
 
 def preroll(step, seconds):
@@ -160,7 +174,7 @@ def run_chan_workload(args):
         outj["cpu_baseline"] = {"value": m / tc / 1e6, "unit": "Msamp/s", "cores": 1, "kind": "port",
                                 "sample": f"first {m} wideband samples, 3 of 64 output branches, numpy oracle, {tc:.1f} s"}
         outj["checks"] = {"max_abs_err_vs_oracle": err}
-    print(json.dumps(outj))
+    emit(outj)
 
 
 def run_ambe_workload(args):
@@ -249,7 +263,7 @@ def run_ambe_workload(args):
                                           + f", 1 thread, {tc:.1f} s"}
         outj["checks"]["samples_differing_from_oracle_first_16_channels"] = differ
         outj["checks"]["samples_compared"] = int(first.size)
-    print(json.dumps(outj))
+    emit(outj)
 
 
 def run_rx_workload(args):
@@ -319,7 +333,7 @@ def run_rx_workload(args):
         out["cpu_baseline"] = {"value": ns / tc / 1e6, "unit": "Msamp/s", "cores": 1, "kind": "port",
                                "sample": f"carrier 0 ({args.seconds:g} s), gcc -O2 oracle, 1 thread, {tc * 1e3:.0f} ms"}
         out["checks"] = {"frames_identical_to_oracle": bool(key(mine) == key(orec)), "oracle_frames": int(len(orec))}
-    print(json.dumps(out))
+    emit(out)
 
 
 def run_side_workload(args):
@@ -429,7 +443,7 @@ def run_side_workload(args):
             out["checks"] = {"frames_identical_to_oracle": bool(np.array_equal(g0[:, 0], ref[0]) and
                                                                  np.array_equal(g0[:, 1], ref[1])),
                              "conv_identical": bool(np.array_equal(conv.cpu().numpy()[:m, 0], ref[3]))}
-    print(json.dumps(out))
+    emit(out)
 
 
 def run_nt3_workload(args):
@@ -581,7 +595,7 @@ def run_nt3_workload(args):
                              speech_frames_identical_to_oracle=bool(np.array_equal(h_fr[:m_s], ref_fr)),
                              facch3_identical_to_oracle=bool(np.array_equal(h_crc[:m_g], ref_crc) and
                                                              np.array_equal(h_l2[:m_g][ref_crc == 0], ref_l2[ref_crc == 0])))
-    print(json.dumps(out))
+    emit(out)
 
 
 def time_legacy_calls(api, wl, oracle_lib, m=600):
@@ -928,7 +942,7 @@ def main():
                 part = line.get("sharded_rx") or {}
                 part["error"] = f"not finished after {args.shard_timeout:g} s"
                 line["sharded_rx"] = part
-                print(json.dumps(line), flush=True)
+                emit(line, flush=True)
             os._exit(0 if line or rank != 0 else 1)
         dog = threading.Timer(args.shard_timeout, give_up)
         dog.daemon = True
@@ -1039,7 +1053,7 @@ def main():
         except Exception as e:
             out["sharded_rx"] = dict(line.get("sharded_rx") or {}, error=repr(e))
         dog.cancel()
-    print(json.dumps(out), flush=True)
+    emit(out, flush=True)
     finish()
 
 

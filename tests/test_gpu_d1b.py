@@ -1,7 +1,9 @@
 """The decoder-choice sensitivity (decision D1 vs D1b, tests/test_oracle_d1b.py) on the benchmark workloads at full
 size, from the soft bits the GPU demodulator produced: configs[2] (100 000 BCCH / CCCH bursts) and configs[4]'s NT3 mix
 (100 000 bursts: 90 000 speech + 2 500 FACCH3 groups).  The GPU decodes with D1 (bit-exact with the oracle's D1, other
-tests); here the oracle decodes the SAME soft bits with D1b and the differences are counted."""
+tests); here the oracle decodes the SAME soft bits with D1b and the differences are counted.  Round 3: the product decodes
+with D1b too (gmr1_hip_set_conv_decoder(GMR1_HIP_CONV_ACC)), and at these sizes it must return exactly what the oracle's D1b
+returns -- from the fused kernel and from the stand-alone layer-1 kernels."""
 import numpy as np
 import pytest
 
@@ -22,6 +24,17 @@ def test_bench_bursts_100k_decoder_choice(gpu_api, orc, pkg):
             rows = np.nonzero((wl["kind"] == k) & found)[0]
             o = dec(got["ebits"][rows][:, :neb])
             l2[rows], crc[rows] = o[0], o[1]
+    # the product in the accelerated decoder's mode: the fused kernel (same demodulator, so the same soft bits) and the
+    # stand-alone layer-1 kernel on those soft bits both return the oracle's D1b frames, verdicts, and conv_rv = 0
+    with gpu_api.conv_decoder(gpu_api.CONV_ACC):
+        acc = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4, want_ssyms=False)
+        assert np.array_equal(acc["ebits"], got["ebits"]) and np.array_equal(acc["rv"], got["rv"])
+        assert np.array_equal(acc["crc"][found], crc[found]) and np.array_equal(acc["l2"][found], l2[found])
+        assert not acc["conv"].any()
+        for k, dec, neb in ((0, gpu_api.bcch_decode_batch, 424), (1, gpu_api.ccch_decode_batch, 432)):
+            rows = np.nonzero((wl["kind"] == k) & found)[0]
+            g = dec(got["ebits"][rows][:, :neb])
+            assert np.array_equal(g[0], l2[rows]) and np.array_equal(g[1], crc[rows]) and not g[2].any()
     pa, pb = (got["crc"] == 0) & found, (crc == 0) & found
     both = pa & pb
     clash = int((both & (got["l2"] != l2).any(axis=1)).sum())
@@ -47,6 +60,12 @@ def test_bench_nt3_100k_decoder_choice(gpu_api, orc, pkg):
     with orc.conv_mode(1):
         o_fr = orc.tch3_decode(ds["ebits"], 0)
         o_fa = orc.facch3_decode(df["ebits"].reshape(-1, 4, 104))
+    with gpu_api.conv_decoder(gpu_api.CONV_ACC):
+        a_fr = gpu_api.tch3_decode_batch(ds["ebits"], 0)
+        a_fa = gpu_api.facch3_decode_batch(df["ebits"].reshape(-1, 4, 104))
+    for k in (0, 1):
+        assert np.array_equal(a_fr[k], o_fr[k]), "TCH3 frames under the accelerated decoder differ from the oracle's D1b"
+    assert np.array_equal(a_fa[0], o_fa[0]) and np.array_equal(a_fa[2], o_fa[2])
     # speech: no CRC -- class-1 bits (6 bytes per frame) against what was sent, under each decoder
     one_sided = differ = recovered = 0
     for k in (0, 1):

@@ -119,8 +119,8 @@ static int build_code(const struct code_def *d, struct osmo_conv_code *c)
 	c->K = d->K;
 	c->len = d->len;
 	c->term = d->term;
-	c->next_output = g_next_output;
-	c->next_state = g_next_state;
+	c->next_output = (const uint8_t (*)[2])g_next_output;
+	c->next_state = (const uint8_t (*)[2])g_next_state;
 	c->puncture = n_punct ? g_punct : NULL;
 	return n_punct;
 }
