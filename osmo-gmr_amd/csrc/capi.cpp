@@ -228,7 +228,7 @@ static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
 		const char *e = getenv("GMR1_HIP_RX_GEN");
 		gen_off = (e && atoi(e) == 0) ? 1 : 0;
 	}
-	if (!gen_off && n > 4096 && sps == 4 && a.dbg_stop == 0 && ht.n_sync == 1 && ht.nbits == 2 && ht.n_chunks[0] >= 1 &&
+	if (!gen_off && n > 4096 && sps == 4 && ht.n_sync == 1 && ht.nbits == 2 && ht.n_chunks[0] >= 1 &&
 	    ht.n_chunks[0] <= 3 && ht.sync_tl[0] <= 18 && ht.len <= 256 && in_len <= 1024 && w <= 128 && ht.ebits <= 432) {
 		bool fits = true;
 		int stage = 0;

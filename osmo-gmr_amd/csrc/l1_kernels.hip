@@ -66,7 +66,7 @@ __constant__ Syn92 c_syn92 = make_syn92();
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t v)
 {
-	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);   // every lane has a source: nothing to preset
 }
 template <int X>
 __device__ __forceinline__ uint32_t row_xor(uint32_t v)
@@ -371,6 +371,57 @@ static constexpr T3Map make_t3map()
 }
 __constant__ T3Map c_t3map = make_t3map();
 
+// The same per TRELLIS STEP s (coded bits 2s, always sent, and 2s+1, punctured when s is odd; the sent bits are
+// c[idx - (idx >> 2)], punct.c:48-133 with P(1;2)):  bits 0-7 index of the first soft bit in the burst's 212 e-bits,
+// bit 8 the scrambler flips it, bits 16-23 / 24 the same for the second one -- a punctured second bit points at byte 212
+// of the LDS copy, which is kept zero (an erasure costs nothing).
+struct T3Steps { uint32_t w[2][2][kT3Steps]; };  // [m][fr][s]
+static constexpr T3Steps make_t3steps()
+{
+	const T3Map mp = make_t3map();
+	T3Steps t{};
+	for (int m = 0; m < 2; m++)
+		for (int fr = 0; fr < 2; fr++)
+			for (int s = 0; s < kT3Steps; s++) {
+				const int i0 = 2 * s, i1 = 2 * s + 1;
+				const uint32_t m0 = mp.q[m][fr][i0 - (i0 >> 2)];
+				const uint32_t q0 = m0 & 0xffu;
+				uint32_t w = (q0 < 52 ? q0 : q0 + 4) | (m0 & 0x100u);
+				if (s & 1) {
+					w |= 212u << 16;
+				} else {
+					const uint32_t m1 = mp.q[m][fr][i1 - (i1 >> 2)];
+					const uint32_t q1 = m1 & 0xffu;
+					w |= ((q1 < 52 ? q1 : q1 + 4) | (m1 & 0x100u)) << 16;
+				}
+				t.w[m][fr][s] = w;
+			}
+	return t;
+}
+__constant__ T3Steps c_t3steps = make_t3steps();
+
+// What a soft bit contributes to a step's table: index = the soft bit as uint8, + 256 when scrambler / cipher flip it
+// ((int8)(-v): -128 stays -128 as in gmr1_scramble_sbit); entry = (cost as a 1 - cost as a 0) in the low half, their sum
+// in the high half.  [0]: the generic decoder's ((in -+ 127)^2 >> 9, erasure 0), [1]: the accelerated one's (|in| for the
+// contradicted value).
+struct T3Cost { uint32_t w[2][512]; };
+static constexpr T3Cost make_t3cost()
+{
+	T3Cost t{};
+	for (int idx = 0; idx < 512; idx++) {
+		int v = (int)(int8_t)(uint8_t)(idx & 255);
+		if (idx & 256)
+			v = (int)(int8_t)(uint8_t)(-v);
+		const int e0 = v - 127, e1 = v + 127;
+		const int c0 = v ? ((e0 * e0) >> 9) : 0, c1 = v ? ((e1 * e1) >> 9) : 0;
+		t.w[0][idx] = ((uint32_t)(c1 - c0) & 0xffffu) | ((uint32_t)(c0 + c1) << 16);
+		const int a0 = v < 0 ? -v : 0, a1 = v > 0 ? v : 0;
+		t.w[1][idx] = ((uint32_t)(a1 - a0) & 0xffffu) | ((uint32_t)(a0 + a1) << 16);
+	}
+	return t;
+}
+__constant__ T3Cost c_t3cost = make_t3cost();
+
 // soft bit c[kc] of frame `fr`: the descrambled / deciphered value
 __device__ __forceinline__ int tch3_c(const int8_t *__restrict__ e, const uint8_t *__restrict__ ciph,
                                       int fr, int m, int kc)
@@ -569,6 +620,8 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 		uint32_t *dst = reinterpret_cast<uint32_t *>(s_e);
 		if (lane < 53)
 			dst[lane] = src[lane];
+		if (lane == 53)
+			dst[53] = 0;                             // byte 212: what a punctured position reads
 	}
 	WSYNC();
 
@@ -576,38 +629,56 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	if (a.bits_s && lane < 4)
 		a.bits_s[(size_t)g * 4 + lane] = s_e[52 + lane] < 0;
 
-	// ---- branch metrics: step s has coded bits 2s (always sent) and 2s+1 (punctured when
-	// 2s+1 = 3 mod 4, i.e. s odd); the sent bits are c[idx - (idx>>2)]   (punct.c:48-133, P(1;2)).
-	// 2 x 48 steps: frame 0 on lanes 0-47, then frame 1; sum of K per frame
-	int ksum = 0;
+	// ---- branch metrics.  Lane s < 48 owns trellis step s of both frames: one descriptor (c_t3steps) says where its two
+	// soft bits sit, one table word per soft bit (c_t3cost) gives the cost difference d = cost as a 1 - cost as a 0 and the
+	// cost sum; the four code words o = (g0 bit << 1) | g1 bit then cost (+-da +-db) (+ a constant that cancels).
+	// Word table for the recording pass, and behind it the packed form of the warm-up pass: high half the lane's r = 1
+	// state, whose code word is the own one xor the phase's constant -- i.e. da / db with their signs turned.
+	uint32_t ksp = 0;                                                // sum of K: frame 0 in the low half, frame 1 in the high half
+	if (lane < kT3Steps) {
+		const int s = lane;
+		constexpr uint32_t kPairMasks = k7_pair_mask(0) | (k7_pair_mask(1) << 2) | (k7_pair_mask(2) << 4) |
+		                                (k7_pair_mask(3) << 6) | (k7_pair_mask(4) << 8) | (k7_pair_mask(5) << 10);
+		const uint32_t ph = (uint32_t)s - 6u * (((uint32_t)s * 43u) >> 8);      // s % 6
+		const uint32_t mk = (kPairMasks >> (2u * ph)) & 3u;
+		const int sga = 1 - (int)(mk & 2u), sgb = 1 - 2 * (int)(mk & 1u);
+		const uint32_t *ct = c_t3cost.w[ACC ? 1 : 0];
+		const uint8_t *se = reinterpret_cast<const uint8_t *>(s_e);
 #pragma unroll
-	for (int f = 0; f < 2; f++) {
-		int ks = 0;
-		if (lane < kT3Steps) {
-			const int s = lane;
-			const int i0 = 2 * s, i1 = 2 * s + 1;
-			const int v0 = tch3_c(s_e, ciph, f, m, i0 - (i0 >> 2));
-			const int v1 = (s & 1) ? 0 : tch3_c(s_e, ciph, f, m, i1 - (i1 >> 2));
-			const int a0 = sbit_cost<ACC>(v0, 0), a1 = sbit_cost<ACC>(v0, 1);
-			const int b0 = sbit_cost<ACC>(v1, 0), b1c = sbit_cost<ACC>(v1, 1);
-			const int da = a1 - a0, db = b1c - b0;
-			ks = a0 + a1 + b0 + b1c;
-			// code word o = (g0 bit << 1) | g1 bit
-			const uint32_t t[4] = {(uint32_t)(-da - db) << 16, (uint32_t)(-da + db) << 16, (uint32_t)(da - db) << 16,
-			                       (uint32_t)(da + db) << 16};
-			*reinterpret_cast<uint4 *>(&s_tab[f][4 * s]) = make_uint4(t[0], t[1], t[2], t[3]);
-			// packed form: high half the lane's r = 1 state, whose code word is the own one xor the phase's constant
-			const uint32_t mk = (s % 6 == 0) ? k7_pair_mask(0) : (s % 6 == 1) ? k7_pair_mask(1) : (s % 6 == 2) ? k7_pair_mask(2)
-			                  : (s % 6 == 3) ? k7_pair_mask(3) : (s % 6 == 4) ? k7_pair_mask(4) : k7_pair_mask(5);
+		for (int f = 0; f < 2; f++) {
+			const uint32_t st = c_t3steps.w[m][f][s];
+			uint32_t ia = (uint32_t)se[st & 0xffu] | (st & 0x100u);
+			uint32_t ib = (uint32_t)se[(st >> 16) & 0xffu] | ((st >> 16) & 0x100u);
+			if (ciph) {
+				const uint32_t e0 = st & 0xffu, e1 = (st >> 16) & 0xffu;
+				ia ^= ciph[e0 < 52 ? e0 : e0 - 4] ? 0x100u : 0u;
+				if (!(s & 1))
+					ib ^= ciph[e1 < 52 ? e1 : e1 - 4] ? 0x100u : 0u;
+			}
+			const uint32_t A = ct[ia], B = ct[ib];
+			const int da = (int)(int16_t)A, db = (int)(int16_t)B;
+			ksp += ((A >> 16) + (B >> 16)) << (16 * f);
+			const int sum = da + db, dif = da - db;
+			*reinterpret_cast<uint4 *>(&s_tab[f][4 * s]) =
+			    make_uint4((uint32_t)(-sum) << 16, (uint32_t)(-dif) << 16, (uint32_t)dif << 16, (uint32_t)sum << 16);
+			const int dap = da * sga, dbp = db * sgb;
+			const int sump = dap + dbp, difp = dap - dbp;
+			// (high << 16) | (low & 0xffff)
 			*reinterpret_cast<uint4 *>(&s_tab_all[2 + f][4 * s]) =
-			    make_uint4(t[0 ^ mk] | (t[0] >> 16), t[1 ^ mk] | (t[1] >> 16), t[2 ^ mk] | (t[2] >> 16), t[3 ^ mk] | (t[3] >> 16));
+			    make_uint4(__builtin_amdgcn_perm((uint32_t)(-sump), (uint32_t)(-sum), 0x05040100u),
+			               __builtin_amdgcn_perm((uint32_t)(-difp), (uint32_t)(-dif), 0x05040100u),
+			               __builtin_amdgcn_perm((uint32_t)difp, (uint32_t)dif, 0x05040100u),
+			               __builtin_amdgcn_perm((uint32_t)sump, (uint32_t)sum, 0x05040100u));
 		}
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1)
-			ks += __shfl_xor(ks, o);
-		if (fr == f)
-			ksum = ks;
 	}
+	// both sums over the wave at once: rows by DPP, the four row totals through the scalar unit
+	ksp += dpp<0xB1>(ksp);
+	ksp += dpp<0x4E>(ksp);
+	ksp += dpp<0x141>(ksp);
+	ksp += dpp<0x140>(ksp);
+	const uint32_t ks_all = (uint32_t)__builtin_amdgcn_readlane((int)ksp, 0) + (uint32_t)__builtin_amdgcn_readlane((int)ksp, 16) +
+	                        (uint32_t)__builtin_amdgcn_readlane((int)ksp, 32) + (uint32_t)__builtin_amdgcn_readlane((int)ksp, 48);
+	const int ksum = (int)(fr ? ks_all >> 16 : ks_all & 0xffffu);
 	WSYNC();
 
 	// ---- per-lane constants
@@ -670,21 +741,16 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 	// best end state of each frame: smallest metric, lowest state on ties (48 = 8 * 6 steps: every state is
 	// back in its phase-0 position)
 	// (ACC: best sum, the first in conv_acc.c's own state numbering -- newest bit on top, i.e. bit-reversed -- on ties)
-	unsigned long long key;
+	uint32_t key;
 	{
 		const uint32_t s0 = c_k7.st[0][p], s1 = c_k7.st[1][p];
-		const unsigned long long k0 = ((unsigned long long)(w[0] >> 16) << 32) | (ACC ? __brev(s0) >> 26 : s0);
-		const unsigned long long k1 = ((unsigned long long)(w[1] >> 16) << 32) | (ACC ? __brev(s1) >> 26 : s1);
-		key = k1 < k0 ? k1 : k0;
+		const uint32_t k0 = (w[0] & 0xffff0000u) | (ACC ? __brev(s0) >> 26 : s0);
+		const uint32_t k1 = (w[1] & 0xffff0000u) | (ACC ? __brev(s1) >> 26 : s1);
+		key = half_min(k1 < k0 ? k1 : k0);
 	}
-#pragma unroll
-	for (int o = 16; o > 0; o >>= 1) {
-		const unsigned long long ok = __shfl_xor(key, o);
-		key = ok < key ? ok : key;
-	}
-	const uint32_t end_state = ACC ? __brev((uint32_t)key & 63u) >> 26 : (uint32_t)key & 63u;
+	const uint32_t end_state = ACC ? __brev(key & 63u) >> 26 : key & 63u;
 	// words hold 2 * ae - sum K (+ bias); osmo_conv_decode_acc returns 0
-	const int32_t min_ae = ACC ? 0 : ((int)(uint32_t)(key >> 32) - (int)kBias + ksum) >> 1;
+	const int32_t min_ae = ACC ? 0 : ((int)(key >> 16) - (int)kBias + ksum) >> 1;
 
 	// ---- survivor chain (uniform across the half-wave): four dependent 16-bit reads.
 	// u[42..47] are the end state's bits (bit j = u[47 - j]); window m gives u[12m-6 .. 12m+5] LSB first

@@ -1581,7 +1581,10 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
 		off[3] = 0;
 		const size_t p1 = stage_bytes + corr_bytes + 18 * 8;
 		const size_t p2 = 4 * 432 + kSbLutBytes;      // pass 2: soft-bit rows, then the soft-bit table
-		return align16(p1 > p2 ? p1 : p2);
+		// the small formats' pass 1 (one burst per row): 4 x 64 staged samples, 4 x <= 128 correlation values, 4 x 16 coefficients
+		const size_t p3 = 4 * 64 * 8 + 4 * 128 * 4 + 4 * 16 * 8;
+		const size_t m = p1 > p2 ? p1 : p2;
+		return align16(m > p3 ? m : p3);
 	}
 	size_t total = stage_bytes + corr_bytes + 18 * 8;
 	if (total < dec_bytes + 4 * 432)
@@ -1665,6 +1668,123 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
 
 	// =========================== pass 1: correlation magnitudes ===========================
+	if constexpr (SMALL) {
+		// The short formats (<= 512 samples, one sync chunk of <= 16 symbols, <= 64 lags) take pass 1 with ONE BURST PER ROW
+		// as well: lane `col` of a row reads samples col, col + 16, ... of the row's burst (16 lanes x 8 B = one 128-byte
+		// line per row and load), so window sums, the division, the rotated reference, the staged sync window and the
+		// correlation are formed once per wave for its four bursts instead of once per burst with the other rows' lanes
+		// idle or duplicating.
+		const DevBurst &bt = c_types[a.fixed_type];
+		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[0]);
+		const int w = in_len - bt.len * sps + 1;
+		const int tl = bt.sync_tl[0];
+		const int len0 = bt.sync[0][0].len;
+		const int wl = len0 * sps + w - 1;                 // samples under the sync chunk for every lag (<= 64)
+		const int gq = row_live ? g_row : g0;              // a dead row shadows the wave's first burst
+		const float2 *__restrict__ in = a.iq + io.offset[gq];
+		const float fsh = io.freq_shift ? io.freq_shift[gq] : 0.0f;
+		const float fs = (fsh - bt.rotation) / (float)sps;
+		float2 *xs = reinterpret_cast<float2 *>(lds_raw) + row * 64;
+		L.corr = reinterpret_cast<float *>(lds_raw + 2048);
+		float2 *coef = reinterpret_cast<float2 *>(lds_raw + 4096) + row * 16;
+		// what needs memory is asked for first: the samples under the sync chunk ...
+		float2 sv[4];
+		{
+			const float2 *__restrict__ src = in + bt.sync[0][0].pos * sps;
+#pragma unroll
+			for (int h = 0; h < 4; h++) {
+				const int sidx = col + 16 * h;
+				sv[h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
+			}
+		}
+		// ... and the whole window, ONE sweep: sum x and sum |x|^2 (a second sweep for the variance about the mean would
+		// be a third trip through the memory system for a kernel whose two -- this one and pass 2's -- already load it
+		// fully; sigma only sets a scale nothing downstream depends on)
+		const int nit = in_len >> 4, rem = in_len & 15;
+		const bool want_en = io.energy != nullptr;
+		v2f s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll 8
+		for (int t = 0; t < nit; t++) {
+			const float2 x = in[col + 16 * t];
+			s2 += (v2f){x.x, x.y};
+			q2 = __builtin_elementwise_fma((v2f){x.x, x.y}, (v2f){x.x, x.y}, q2);
+		}
+		if (col < rem) {
+			const float2 x = in[col + 16 * nit];
+			s2 += (v2f){x.x, x.y};
+			q2 = __builtin_elementwise_fma((v2f){x.x, x.y}, (v2f){x.x, x.y}, q2);
+		}
+		float en = 0.f;
+		if (want_en) {
+			// burst_energy() (gmr1_rx.c:172-182): the inner 30 / 32 of the raw window, served by the caches
+			const int bd = in_len >> 5;
+			for (int idx = col; idx < in_len; idx += 16)
+				if (idx >= bd && idx < in_len - bd) {
+					const float2 x = in[idx];
+					en = fmaf(x.x, x.x, fmaf(x.y, x.y, en));
+				}
+		}
+		// rotated reference of the training sequence(s), one value per lane of the row, while the samples travel
+		if constexpr (FAC) {
+			if (col < 2 * tl)
+				coef[col] = sync_coef_seq1(bt, col >= tl ? 1 : 0, col >= tl ? col - tl : col, sps, fs);
+		} else {
+			float2 cfl = make_float2(0.f, 0.f);
+			if (io.freq_shift == nullptr)
+				cfl = g_coef0[sps][a.fixed_type][col];
+			else if (col < tl)
+				cfl = sync_coef0(bt, col, sps, fs);
+			coef[col] = cfl;
+		}
+		const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
+		const float avr = row_sum(s2.x) / (float)in_len, avi = row_sum(s2.y) / (float)in_len;     // true division, see load_normalise
+		const v2f av = {avr, avi};
+		// sum |x - m|^2 = sum |x|^2 - n |m|^2 (never below zero)
+		const float var = fmaxf(fmaf(-(float)in_len, fmaf(avr, avr, avi * avi), row_sum(q2.x + q2.y)), 0.0f) * inv_n;
+		float stddev = __builtin_amdgcn_sqrtf(var);
+		if (stddev == 0.0f)
+			stddev = 1.0f;
+		const float inv = __builtin_amdgcn_rcpf(stddev);
+		avr_r = avr;
+		avi_r = avi;
+		if (want_en) {
+			const float e = row_sum(en) / (float)in_len;
+			if (col == 0 && row_live)
+				io.energy[g_row] = e;
+		}
+#pragma unroll
+		for (int h = 0; h < 4; h++) {
+			const int sidx = col + 16 * h;
+			if (sidx < wl) {
+				const v2f nv = ((v2f){sv[h].x, sv[h].y} - av) * (v2f){inv, inv};
+				xs[sidx] = make_float2(nv.x, nv.y);
+			}
+		}
+		WSYNC();
+		float *corr = L.corr + row * cw;
+		for (int j = col; j < w; j += 16) {
+			const float2 *xp = xs + j;
+			v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+			for (int n = 0; n < len0; n++) {
+				const float2 x = xp[n * sps];
+				const float2 c0 = coef[n];
+				acc0 = __builtin_elementwise_fma((v2f){-c0.y, c0.y}, (v2f){x.y, x.x}, acc0);
+				acc0 = __builtin_elementwise_fma((v2f){c0.x, c0.x}, (v2f){x.x, x.y}, acc0);
+				if constexpr (FAC) {
+					const float2 c1 = coef[tl + n];
+					acc1 = __builtin_elementwise_fma((v2f){-c1.y, c1.y}, (v2f){x.y, x.x}, acc1);
+					acc1 = __builtin_elementwise_fma((v2f){c1.x, c1.x}, (v2f){x.x, x.y}, acc1);
+				}
+			}
+			float cj = 0.f;
+			cj += sqrtf(fmaf(acc0.x, acc0.x, acc0.y * acc0.y));
+			corr[j] = cj;                                   // FAC: sequence 0
+			if constexpr (FAC) {
+				cj += sqrtf(fmaf(acc1.x, acc1.x, acc1.y * acc1.y));
+				corr[cwh + j] = cj;                         // what sequence 1 is ranked and timed on
+			}
+		}
+	} else {
 	float2 wv[NPL];
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
@@ -1804,6 +1924,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 			corr[j] = cj;
 		}
+	}
 	}
 	WSYNC();
 	if (a.dbg_stop == 2) return;
