@@ -333,6 +333,44 @@ def run_rx_workload(args):
         out["cpu_baseline"] = {"value": ns / tc / 1e6, "unit": "Msamp/s", "cores": 1, "kind": "port",
                                "sample": f"carrier 0 ({args.seconds:g} s), gcc -O2 oracle, 1 thread, {tc * 1e3:.0f} ms"}
         out["checks"] = {"frames_identical_to_oracle": bool(key(mine) == key(orec)), "oracle_frames": int(len(orec))}
+        # the same port on every host core: the A carriers dealt out to one thread per core (the reference would run one
+        # gmr1_rx process per carrier file)
+        from concurrent.futures import ThreadPoolExecutor
+        cores = os.cpu_count() or 1
+
+        def work(t):
+            for a_ in range(t, A, cores):
+                oracle_lib.rx_run(host[a_ % distinct], sps=sps, arfcn=a_)
+        ta = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(work, range(cores)))
+        ta = time.perf_counter() - ta
+        out["cpu_baseline_all_cores"] = {"value": A * ns / ta / 1e6, "unit": "Msamp/s", "cores": cores, "kind": "port",
+                                         "sample": f"all {A} carriers, one oracle loop per carrier, {cores} threads, {ta * 1e3:.0f} ms"}
+        out["gpu_vs_all_cores"] = out["value"] / out["cpu_baseline_all_cores"]["value"]
+    # What 8 GPUs would do with THIS capture (strong scaling): every rank gets A / 8 carriers.  The loop is a chain of
+    # dependent rounds per carrier (rx_bcch feeds align and a FLOAT freq_err back, gmr1_rx.c:782-789), so fewer carriers per
+    # GPU shorten nothing but the acquisition: measured here by running A / 8 carriers on this one GPU; the scatter of the
+    # other ranks' samples from rank 0 is priced at the per-link xGMI rate (7 peers at once, one link each).
+    if A >= 8 and A % 8 == 0:
+        A8 = A // 8
+        res8 = [None]
+
+        def step8():
+            res8[0] = api.rx_run_dev(stream.cuda_stream, iq.data_ptr(), offset[:A8], length[:A8], sps=sps, out=rec_buf)
+        for _ in range(3):
+            step8()
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        for _ in range(args.steps):
+            step8()
+        torch.cuda.synchronize()
+        t8 = (time.perf_counter() - t8) / args.steps
+        scatter_s = A8 * ns * 8 / 153e9
+        out["projected_n8"] = {"carriers_per_gpu": A8, "rx_ms_per_gpu_measured_here": t8 * 1e3, "scatter_ms_at_153_GB_per_s_per_link": scatter_s * 1e3,
+                               "total_ms": (t8 + scatter_s) * 1e3, "speedup_over_one_gpu": step_s / (t8 + scatter_s),
+                               "speedup_without_scatter": step_s / t8,
+                               "note": "latency chain: the rounds of a carrier cannot be shortened by adding GPUs; 8 GPUs carry 8x the carriers in the same time (weak scaling), they do not finish these sooner"}
     emit(out)
 
 
@@ -736,27 +774,82 @@ def sharded_rx_extra(args, pkg, dev, backend, rank, world, partial):
         t1 = time.perf_counter()
         rec, key = sh.rx_run_on_slices(api, mine, ns, sps=sps, device=dev, with_key=True,
                                            max_records=max(len(mine), 1) * 4096)
+        t1b = time.perf_counter()
         dist.barrier()
         t2 = time.perf_counter()
         out = sh.gather_records(rec, dst=0, device=cdev, order_key=key)
         dist.barrier()
         t3 = time.perf_counter()
-        t = {"scatter_ms": (t1 - t0) * 1e3, "rx_loop_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3}
-    tt = torch.tensor([t["scatter_ms"], t["rx_loop_ms"], t["gather_ms"]], dtype=torch.float64,
-                      device=dev if backend == "nccl" else "cpu")
+        t = {"scatter_ms": (t1 - t0) * 1e3, "rx_loop_ms": (t2 - t1) * 1e3, "gather_ms": (t3 - t2) * 1e3,
+             "rx_only_ms": (t1b - t1) * 1e3}
+    tdev = dev if backend == "nccl" else "cpu"
+    tt = torch.tensor([t["scatter_ms"], t["rx_loop_ms"], t["gather_ms"]], dtype=torch.float64, device=tdev)
+    # the receive loop alone, per rank, without the barrier behind it: its spread over the ranks
+    lo = torch.tensor([t["rx_only_ms"]], dtype=torch.float64, device=tdev)
+    hi = lo.clone()
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+
+    # ---- the other way to feed the ranks: every rank already holds the carriers it owns (a recorder hands each GPU its
+    # carriers; here every rank synthesises its own).  No scatter; same loop, same gather.
+    own_ids = sh.my_arfcns(A, world, rank)
+    need = sorted({a % distinct for a in own_ids})
+    gen = {d: torch.from_numpy(workloads.bcch_carrier(pkg, 700 + d, seconds=seconds, sps=sps, stn=(5 * d) % 24, delay=d % 8,
+                                                      cfo_hz=40.0 * (d - 3), esn0_db=10.0 + d)[0]) for d in need}
+    if cdev is not None:
+        gen = {d: g.to(cdev) for d, g in gen.items()}
+    resident = {a: gen[a % distinct] for a in own_ids}
+    tr = {}
+    out_res = None
+    for it in range(2):
+        dist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rec, key = sh.rx_run_on_slices(api, resident, ns, sps=sps, device=dev, with_key=True, max_records=max(len(resident), 1) * 4096)
+        t1 = time.perf_counter()
+        dist.barrier()
+        t2 = time.perf_counter()
+        out_res = sh.gather_records(rec, dst=0, device=cdev, order_key=key)
+        dist.barrier()
+        t3 = time.perf_counter()
+        tr = {"rx_loop_ms": (t2 - t0) * 1e3, "gather_ms": (t3 - t2) * 1e3, "rx_only_ms": (t1 - t0) * 1e3}
+    tr_t = torch.tensor([tr["rx_loop_ms"], tr["gather_ms"]], dtype=torch.float64, device=tdev)
+    rlo = torch.tensor([tr["rx_only_ms"]], dtype=torch.float64, device=tdev)
+    rhi = rlo.clone()
+    dist.all_reduce(tr_t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(rlo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(rhi, op=dist.ReduceOp.MAX)
+
     res = None
     if rank == 0:
         res = _sharded_summary(args, dist, host, out, tt, A, ns, seconds, distinct, world, sps)
+        res["rx_loop_ms_per_rank_min_max"] = [float(lo[0]), float(hi[0])]
+        key = lambda r: [(int(x["arfcn"]), int(x["chain"]), int(x["type"]), int(x["fn"]), int(x["tn"]), bytes(x["l2"])) for x in r]
+        res["resident"] = {"what": "every rank holds the carriers it owns already (no scatter): receive loop + record gather",
+                           "rx_loop_ms": float(tr_t[0]), "gather_ms": float(tr_t[1]),
+                           "rx_loop_ms_per_rank_min_max": [float(rlo[0]), float(rhi[0])],
+                           "records_identical_to_scattered_run": bool(key(out_res) == key(out))}
+        # and the whole exchange against ONE gmr1_hip_rx_run over all carriers on this GPU: every record of every carrier
+        if dev.type == "cuda":
+            iq_all = torch.cat([torch.view_as_real(b.to(dev)).reshape(-1) for b in base]).contiguous()
+            off1 = (np.arange(A, dtype=np.uint64) % np.uint64(distinct)) * np.uint64(ns)
+            one, _, _, _ = api.rx_run_dev(torch.cuda.current_stream(dev).cuda_stream, iq_all.data_ptr(), off1, np.full(A, ns, np.uint64),
+                                          sps=sps, arfcn=np.arange(A, dtype=np.uint16), max_records=A * 4096)
+            res["records_identical_to_single_gpu_run"] = bool(key(one) == key(out))
+            res["single_gpu_run_frames"] = int(len(one))
+            del iq_all
         partial["sharded_rx"] = res                  # what the watchdog prints if the native leg below never returns
     if backend == "nccl":
-        nat = _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base if rank == 0 else None, out)
+        nat = _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base if rank == 0 else None, out,
+                              resident=(resident, own_ids))
         if rank == 0:
             res["native"] = nat
     return res
 
 
-def _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base, torch_records):
+def _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base, torch_records, resident=None):
     """The same exchange through the library's own C entry point (gmr1_hip_rx_run_sharded, include/gmr1_hip_shard.h):
     ncclSend / ncclRecv posted from C++, no Python between scatter, receive loop and gather."""
     import torch
@@ -775,13 +868,34 @@ def _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base, tor
             rec, status, chains, tim = sh.rx_run(st, iq_all.data_ptr() if rank == 0 else 0, offset, length, sps=sps,
                                                  arfcn=np.arange(A, dtype=np.uint16), max_records=A * 4096)
         tt = torch.tensor(tim.astype(np.float64), device=dev)
+        lo, hi = tt[1:2].clone(), tt[1:2].clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        # every rank's carriers already in its own memory (gmr1_hip_rx_run_sharded_resident): no scatter
+        rec2 = tim2 = None
+        if resident is not None:
+            mine, own_ids = resident
+            pos = {a: k for k, a in enumerate(own_ids)}
+            mem = (torch.cat([torch.view_as_real(mine[a].to(dev)).reshape(-1) for a in own_ids]).contiguous()
+                   if own_ids else torch.zeros(2, device=dev))
+            off2 = np.array([pos.get(a, 0) * ns for a in range(A)], np.uint64)
+            for _ in range(2):
+                dist.barrier()
+                rec2, _, _, tim2 = sh.rx_run(st, mem.data_ptr(), off2, length, sps=sps, arfcn=np.arange(A, dtype=np.uint16),
+                                             max_records=A * 4096, resident=True)
+            t2 = torch.tensor(tim2.astype(np.float64), device=dev)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
         if rank != 0:
             return None
         key = lambda r: [(int(x["arfcn"]), int(x["chain"]), int(x["type"]), int(x["fn"]), int(x["tn"]), bytes(x["l2"])) for x in r]
-        return {"entry_point": "gmr1_hip_rx_run_sharded (RCCL from C++)", "scatter_ms": float(tt[0]), "rx_loop_ms": float(tt[1]),
-                "gather_ms": float(tt[2]), "frames": int(rec.size),
-                "records_identical_to_torch_distributed_path": bool(key(rec) == key(torch_records))}
+        res = {"entry_point": "gmr1_hip_rx_run_sharded (RCCL from C++)", "scatter_ms": float(tt[0]), "rx_loop_ms": float(tt[1]),
+               "gather_ms": float(tt[2]), "rx_loop_ms_per_rank_min_max": [float(lo[0]), float(hi[0])], "frames": int(rec.size),
+               "records_identical_to_torch_distributed_path": bool(key(rec) == key(torch_records))}
+        if rec2 is not None:
+            res["resident"] = {"entry_point": "gmr1_hip_rx_run_sharded_resident", "rx_loop_ms": float(t2[1]), "gather_ms": float(t2[2]),
+                               "records_identical_to_scattered_run": bool(key(rec2) == key(rec))}
+        return res
     finally:
         sh.close()
 
@@ -943,7 +1057,9 @@ def main():
                 part["error"] = f"not finished after {args.shard_timeout:g} s"
                 line["sharded_rx"] = part
                 emit(line, flush=True)
-            os._exit(0 if line or rank != 0 else 1)
+            # the headline part of the line is valid and printed, but an exchange that hung is a failed run: every rank
+            # says so with its exit code (spawn_ranks and a launcher then report it), not only with the "error" key
+            os._exit(3)
         dog = threading.Timer(args.shard_timeout, give_up)
         dog.daemon = True
     else:

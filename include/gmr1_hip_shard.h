@@ -54,6 +54,20 @@ int gmr1_hip_rx_run_sharded(struct gmr1_hip_shard *sh, void *stream, int root, i
                             struct gmr1_hip_rx_record *out, int max_records, int *n_records,
                             int32_t *status, int32_t *n_chains, float *timing_ms);
 
+/* The same with the samples already where they are processed: every rank passes ITS OWN device memory as `iq`, holding
+ * the carriers it owns (a % world == rank) at offset[a] .. offset[a] + length[a]; nothing is scattered (a recorder hands
+ * every GPU its carriers directly: the scatter of a minute of 8 carriers costs about as much as the loop that follows).
+ * offset[] / length[] / arfcn[] still have n_arfcn entries on every rank; a rank reads its own carriers' offsets only. */
+int gmr1_hip_rx_run_sharded_resident(struct gmr1_hip_shard *sh, void *stream, int root, int n_arfcn, int sps, const float *iq,
+                                     const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                                     struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                                     int32_t *status, int32_t *n_chains, float *timing_ms);
+
+/* Failure behaviour of both (world > 1): a rank that fails locally -- bad pointer, allocation, its receive loop -- does
+ * not leave the others inside a collective: the failure travels in a status word at three agreement points (before the
+ * scatter, with the counts, before the records) and EVERY rank returns an error from the same point; an RCCL group that
+ * was opened is always closed. */
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_puncturer_generate",
     "gmr1_hip_ddc_plan", "gmr1_hip_ddc_dev", "gmr1_hip_ddc",
     "gmr1_hip_shard_unique_id", "gmr1_hip_shard_create", "gmr1_hip_shard_adopt", "gmr1_hip_shard_destroy",
-    "gmr1_hip_rx_run_sharded",
+    "gmr1_hip_rx_run_sharded", "gmr1_hip_rx_run_sharded_resident",
     "gmr1_codec_alloc", "gmr1_codec_release", "gmr1_codec_decode_frame", "gmr1_codec_decode_dtx",
     "gmr1_hip_codec_state_bytes", "gmr1_hip_codec_init_dev", "gmr1_hip_codec_decode_batch_dev",
     "gmr1_hip_codec_decode_batch", "gmr1_hip_codec_host_tables", "gmr1_hip_codec_libm_check",
@@ -111,7 +111,8 @@ _lib = None
 
 
 def lib_path() -> str:
-    return _build.LIB
+    # tools/ (never the tests, never bench.py's default run) may point at the profiling build: build.py --profile
+    return os.environ.get("GMR1_HIP_LIBRARY") or _build.LIB
 
 
 def load(build_if_missing: bool = False):
@@ -1357,9 +1358,10 @@ class Shard:
         _check(load().gmr1_hip_shard_unique_id(buf), "gmr1_hip_shard_unique_id")
         return bytes(buf)
 
-    def rx_run(self, stream, iq_ptr, offset, length, sps=4, arfcn=None, root=0, max_records=1 << 17):
-        """gmr1_hip_rx_run_sharded.  Returns (records, status, n_chains, timing_ms) on root, (None, None, None, timing_ms)
-        elsewhere."""
+    def rx_run(self, stream, iq_ptr, offset, length, sps=4, arfcn=None, root=0, max_records=1 << 17, resident=False):
+        """gmr1_hip_rx_run_sharded (resident: gmr1_hip_rx_run_sharded_resident -- iq_ptr is this rank's own memory holding
+        the carriers it owns, nothing is scattered).  Returns (records, status, n_chains, timing_ms) on root,
+        (None, None, None, timing_ms) elsewhere."""
         offset, p_off = _np(offset, np.uint64)
         length, p_len = _np(length, np.uint64)
         n = len(offset)
@@ -1372,13 +1374,13 @@ class Shard:
         status = np.zeros(max(n, 1), np.int32)
         chains = np.zeros(max(n, 1), np.int32)
         timing = np.zeros(3, np.float32)
-        f = load().gmr1_hip_rx_run_sharded
+        f = load().gmr1_hip_rx_run_sharded_resident if resident else load().gmr1_hip_rx_run_sharded
         f.restype = C.c_int
         rc = f(self._h, C.c_void_p(stream) if stream else None, C.c_int(root), C.c_int(n), C.c_int(sps),
                C.c_void_p(iq_ptr) if iq_ptr else None, p_off, p_len, p_arfcn,
                out.ctypes.data_as(C.c_void_p) if is_root else None, C.c_int(max_records), C.byref(n_rec),
                status.ctypes.data_as(C.c_void_p), chains.ctypes.data_as(C.c_void_p), timing.ctypes.data_as(C.c_void_p))
-        _check(rc, "gmr1_hip_rx_run_sharded")
+        _check(rc, "gmr1_hip_rx_run_sharded_resident" if resident else "gmr1_hip_rx_run_sharded")
         if not is_root:
             return None, None, None, timing
         return out[:min(n_rec.value, max_records)].copy(), status[:n], chains[:n], timing

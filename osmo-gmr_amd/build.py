@@ -50,19 +50,40 @@ def needs_build() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+PROFILE_LIB = os.path.join(HERE, "libgmr1_hip_prof.so")
+
+
+def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
+    """profile=True: the same sources with -DGMR1_HIP_PROFILE into libgmr1_hip_prof.so -- the only build in which the
+    GMR1_HIP_DBG_STOP / _AMBE_DBG / _RX_IMPL / ... switches exist (tools/ load it through GMR1_HIP_LIBRARY)."""
+    if profile:
+        return _build(PROFILE_LIB, ["-DGMR1_HIP_PROFILE"], ".prof.o", verbose)
     if not force and not needs_build():
         return LIB
-    objs = []
-    for src in sources():
-        obj = os.path.splitext(src)[0] + ".o"
-        cmd = [hipcc()] + COMMON + ["--offload-arch=" + ARCH, "-c", src, "-o", obj]
+    return _build(LIB, [], ".o", verbose)
+
+
+def _build(lib: str, extra, suffix: str, verbose: bool) -> str:
+    LIB = lib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_one(src):
+        obj = os.path.splitext(src)[0] + suffix
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in [src] + headers):
+            return obj
+        cmd = [hipcc()] + COMMON + extra + ["--offload-arch=" + ARCH, "-c", src, "-o", obj]
         if src.endswith(".hip"):
             cmd.insert(1, "-xhip")
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-        objs.append(obj)
+        return obj
+
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    for d, _, files in os.walk(os.path.join(ROOT, "include")):
+        headers += [os.path.join(d, f) for f in files]
+    with ThreadPoolExecutor(max(1, min(6, os.cpu_count() or 1))) as ex:
+        objs = list(ex.map(compile_one, sources()))
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
@@ -72,4 +93,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ambe_dev.h"
+#include "profile_env.h"
 
 namespace gmr1 {
 
@@ -803,7 +804,7 @@ hipError_t launch_ambe(const AmbeArgs &a, hipStream_t stream)
 		return hipSuccess;
 	static int dbg = -1;
 	if (dbg < 0) {
-		const char *e = getenv("GMR1_HIP_AMBE_DBG");
+		const char *e = profile_env("GMR1_HIP_AMBE_DBG");
 		dbg = e ? atoi(e) : 0;
 	}
 	AmbeArgs b = a;

@@ -188,7 +188,7 @@ static int dbg_stop_env()
 {
 	static int v = -1;
 	if (v < 0) {
-		const char *e = getenv("GMR1_HIP_DBG_STOP");
+		const char *e = profile_env("GMR1_HIP_DBG_STOP");
 		v = e ? atoi(e) : 0;
 	}
 	return v;
@@ -225,7 +225,7 @@ static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
 	// serial phases of four bursts share their instructions (k_rx4g); everything else, and small batches, one burst per wave.
 	static int gen_off = -1;                    // profiling only: GMR1_HIP_RX_GEN=0 keeps every batch on k_rx
 	if (gen_off < 0) {
-		const char *e = getenv("GMR1_HIP_RX_GEN");
+		const char *e = profile_env("GMR1_HIP_RX_GEN");
 		gen_off = (e && atoi(e) == 0) ? 1 : 0;
 	}
 	if (!gen_off && n > 4096 && sps == 4 && ht.n_sync == 1 && ht.nbits == 2 && ht.n_chunks[0] >= 1 &&
@@ -675,7 +675,7 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 	{
 		static int impl = -1;
 		if (impl < 0) {
-			const char *e = getenv("GMR1_HIP_RX_IMPL");
+			const char *e = profile_env("GMR1_HIP_RX_IMPL");
 			impl = e ? atoi(e) : 0;
 		}
 		a.impl = impl;

@@ -194,12 +194,24 @@ struct RxRun {
 // grow-only device scratch of the acquisition (its sweeps use the library's shared workspace themselves)
 static int acq_scratch(size_t bytes, unsigned char **out)
 {
-	struct Buf { void *p = nullptr; size_t n = 0; };
+	// (per thread AND per device: a thread that moves on to another GPU must not hand that GPU's kernels this one's memory)
+	struct Buf { void *p = nullptr; size_t n = 0; int dev = -1; };
 	static thread_local Buf b;
-	if (b.n < bytes) {
-		if (b.p) (void)hipFree(b.p);
+	int dev = 0;
+	HIP_TRY(hipGetDevice(&dev));
+	if (b.n < bytes || b.dev != dev) {
+		if (b.p) {
+			int back = dev;
+			if (b.dev >= 0 && b.dev != dev && hipSetDevice(b.dev) == hipSuccess) {
+				(void)hipFree(b.p);
+				(void)hipSetDevice(back);
+			} else {
+				(void)hipFree(b.p);
+			}
+		}
 		b.p = nullptr;
 		b.n = 0;
+		b.dev = dev;
 		HIP_TRY(hipMalloc(&b.p, bytes + bytes / 4));
 		b.n = bytes + bytes / 4;
 	}
@@ -995,7 +1007,7 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	run.align.assign(n_arfcn, kStartDiscard); run.base_align.assign(n_arfcn, 0);
 	run.ferr.assign(n_arfcn, 0.0f);
 	// GMR1_HIP_RX_TIMING=1: wall time of the phases on stderr (profiling only)
-	static const bool timing = getenv("GMR1_HIP_RX_TIMING") != nullptr;
+	static const bool timing = profile_env("GMR1_HIP_RX_TIMING") != nullptr;
 	auto now = [] { return std::chrono::steady_clock::now(); };
 	const auto t0 = now();
 	if ((r = run.acquire())) return r;

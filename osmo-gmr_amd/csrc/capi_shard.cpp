@@ -73,6 +73,7 @@ struct gmr1_hip_shard {
 	void *d_iq = nullptr;   size_t iq_bytes = 0;
 	void *d_rec = nullptr;  size_t rec_bytes = 0;
 	void *d_meta = nullptr; size_t meta_bytes = 0;
+	void *d_flag = nullptr;                       // 1 + world status words: "can every rank go on?" (allocated with the shard)
 };
 
 namespace {
@@ -94,6 +95,10 @@ int make(struct gmr1_hip_shard **out, ncclComm_t comm, bool own, int rank, int w
 {
 	gmr1_hip_shard *sh = new gmr1_hip_shard;
 	sh->comm = comm; sh->own = own; sh->rank = rank; sh->world = world;
+	if (hipMalloc(&sh->d_flag, (size_t)(world + 1) * 4) != hipSuccess) {
+		delete sh;
+		return fail(-ENOMEM, "shard: no device memory for the status block");
+	}
 	*out = sh;
 	return 0;
 }
@@ -150,94 +155,182 @@ void gmr1_hip_shard_destroy(struct gmr1_hip_shard *sh)
 	if (sh->d_iq) (void)hipFree(sh->d_iq);
 	if (sh->d_rec) (void)hipFree(sh->d_rec);
 	if (sh->d_meta) (void)hipFree(sh->d_meta);
+	if (sh->d_flag) (void)hipFree(sh->d_flag);
 	if (sh->own && sh->comm && rccl().ok)
 		(void)rccl().CommDestroy(sh->comm);
 	delete sh;
 }
 
-int gmr1_hip_rx_run_sharded(struct gmr1_hip_shard *sh, void *stream, int root, int n_arfcn, int sps, const float *iq,
-                            const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
-                            struct gmr1_hip_rx_record *out, int max_records, int *n_records,
-                            int32_t *status, int32_t *n_chains, float *timing_ms)
+}  // extern "C"
+
+namespace {
+
+// A group of point-to-point calls must be closed whatever happens inside it: the first failure is kept, the rest of
+// the group is still posted (a peer is waiting for every one of them), and ncclGroupEnd always runs.
+struct Group {
+	const Rccl &R;
+	ncclResult_t first = ncclSuccess;
+	const char *what = "";
+	bool open = false;
+	explicit Group(const Rccl &r) : R(r)
+	{
+		note(R.GroupStart(), "ncclGroupStart");
+		open = first == ncclSuccess;
+	}
+	void note(ncclResult_t r, const char *w)
+	{
+		if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; }
+	}
+	int end()
+	{
+		if (open) {
+			note(R.GroupEnd(), "ncclGroupEnd");
+			open = false;
+		}
+		return first == ncclSuccess ? 0 : fail(-EIO, "%s: %s", what, R.GetErrorString(first));
+	}
+	~Group() { if (open) (void)R.GroupEnd(); }
+};
+
+// Collective "is everybody fine?": every rank contributes its status word; returns the first non-zero one in rank
+// order (so every rank returns the same value), 0 when all are fine.  Uses the shard's small device block.
+int agree(gmr1_hip_shard *sh, hipStream_t st, int32_t mine, int32_t *first_bad_rank)
 {
+	const Rccl &R = rccl();
+	const int world = sh->world;
+	*first_bad_rank = mine ? sh->rank : -1;
+	if (world == 1)
+		return mine;
+	int32_t *d = static_cast<int32_t *>(sh->d_flag);
+	std::vector<int32_t> all((size_t)world, 0);
+	hipError_t e = hipMemcpyAsync(d, &mine, 4, hipMemcpyHostToDevice, st);
+	ncclResult_t r = ncclSuccess;
+	if (e == hipSuccess)
+		r = R.AllGather(d, d + 1, 1, ncclInt32, sh->comm, st);
+	if (e == hipSuccess && r == ncclSuccess)
+		e = hipMemcpyAsync(all.data(), d + 1, (size_t)world * 4, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess && r == ncclSuccess)
+		e = hipStreamSynchronize(st);
+	if (e != hipSuccess || r != ncclSuccess)
+		return fail(-EIO, "rx_run_sharded: status exchange failed (%s)", e != hipSuccess ? hipGetErrorString(e) : R.GetErrorString(r));
+	for (int k = 0; k < world; k++)
+		if (all[k]) { *first_bad_rank = k; return all[k]; }
+	return 0;
+}
+
+int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool scatter, int n_arfcn, int sps, const float *iq,
+                        const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                        struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                        int32_t *status, int32_t *n_chains, float *timing_ms)
+{
+	// ---- arguments every rank can check alike (same values everywhere by contract): a plain return is safe here ------
 	if (!sh || n_arfcn < 0 || !offset || !length || root < 0 || root >= sh->world)
 		return fail(-EINVAL, "rx_run_sharded: bad argument");
+	if (sps < 1 || sps > 16)
+		return fail(-EINVAL, "rx_run_sharded: sps=%d out of range (1..16)", sps);
 	const int rank = sh->rank, world = sh->world;
 	const bool is_root = rank == root;
-	if (is_root && (!iq || !out || !n_records || max_records < 0))
-		return fail(-EINVAL, "rx_run_sharded: root needs iq, out and n_records");
+	const int per = (n_arfcn + world - 1) / world;          // carriers a rank owns at most: a = rank, rank + world, ...
+	if (per > 65535)
+		return fail(-EINVAL, "rx_run_sharded: %d carriers per rank (records label their carrier with 16 bits)", per);
 	hipStream_t st = (hipStream_t)stream;
 	const Rccl &R = rccl();
-	const int per = (n_arfcn + world - 1) / world;          // carriers a rank owns at most: a = rank, rank + world, ...
 	auto t0 = std::chrono::steady_clock::now();
+	int32_t bad_rank = -1;
 
-	// ---- scatter: carrier a -> rank a mod world, all transfers in one group --------------------------------------
+	// ---- what only this rank can know: its own arguments and allocations.  From here on a local failure is CARRIED
+	// to the next agreement point -- no rank leaves while the others are inside a collective ---------------------------
+	int err = 0;
+	if (is_root && (!out || !n_records || max_records < 0))
+		err = fail(-EINVAL, "rx_run_sharded: root needs out and n_records");
 	std::vector<int> mine;
 	for (int a = rank; a < n_arfcn; a += world)
 		mine.push_back(a);
 	const int nm = (int)mine.size();
+	if (!err && !iq && (scatter ? is_root : nm > 0))
+		err = fail(-EINVAL, "rx_run_sharded: iq is NULL on a rank that holds samples");
 	std::vector<uint64_t> loff((size_t)nm), llen((size_t)nm);
 	std::vector<uint16_t> lname((size_t)nm);
 	const float *liq = iq;
-	if (is_root) {
-		for (int k = 0; k < nm; k++) { loff[k] = offset[mine[k]]; llen[k] = length[mine[k]]; }   // root's own stay where they are
+	if (!scatter || is_root) {
+		for (int k = 0; k < nm; k++) { loff[k] = offset[mine[k]]; llen[k] = length[mine[k]]; }   // already where they are used
 	} else {
 		uint64_t tot = 0;
 		for (int k = 0; k < nm; k++) { loff[k] = tot; llen[k] = length[mine[k]]; tot += llen[k]; }
-		int r = grow(&sh->d_iq, &sh->iq_bytes, (size_t)(tot ? tot : 1) * 8);
-		if (r) return r;
+		if (!err)
+			err = grow(&sh->d_iq, &sh->iq_bytes, (size_t)(tot ? tot : 1) * 8);
 		liq = static_cast<const float *>(sh->d_iq);
 	}
 	for (int k = 0; k < nm; k++)
 		lname[k] = arfcn ? arfcn[mine[k]] : (uint16_t)mine[k];
-	if (world > 1) {
-		RCCL_TRY(R.GroupStart());
+	if (!err && world > 1 && !sh->d_flag)
+		err = fail(-EIO, "rx_run_sharded: the shard has no status block");
+	{
+		const int rc = agree(sh, st, err, &bad_rank);
+		if (rc)
+			return err ? err : fail(rc, "rx_run_sharded: rank %d cannot take part (%d)", bad_rank, rc);
+	}
+
+	// ---- scatter: carrier a -> rank a mod world, all transfers in one group --------------------------------------
+	if (scatter && world > 1) {
+		Group g(R);
 		if (is_root) {
 			for (int a = 0; a < n_arfcn; a++)
 				if (a % world != root && length[a])
-					RCCL_TRY(R.Send(iq + 2 * offset[a], (size_t)length[a] * 2, ncclFloat, a % world, sh->comm, st));
+					g.note(R.Send(iq + 2 * offset[a], (size_t)length[a] * 2, ncclFloat, a % world, sh->comm, st), "ncclSend (scatter)");
 		} else {
 			for (int k = 0; k < nm; k++)
 				if (llen[k])
-					RCCL_TRY(R.Recv(static_cast<float *>(sh->d_iq) + 2 * loff[k], (size_t)llen[k] * 2, ncclFloat, root,
-					                sh->comm, st));
+					g.note(R.Recv(static_cast<float *>(sh->d_iq) + 2 * loff[k], (size_t)llen[k] * 2, ncclFloat, root, sh->comm, st),
+					       "ncclRecv (scatter)");
 		}
-		RCCL_TRY(R.GroupEnd());
+		err = g.end();
 	}
 	if (timing_ms) {
-		HIP_TRY(hipStreamSynchronize(st));
+		if (!err && hipStreamSynchronize(st) != hipSuccess)
+			err = fail(-EIO, "rx_run_sharded: stream synchronise after the scatter failed");
 		timing_ms[0] = (float)ms_since(t0);
 		t0 = std::chrono::steady_clock::now();
 	}
 
 	// ---- the receive loop on this rank's carriers ----------------------------------------------------------------
-	// a carrier yields at most ~22 frames per second of capture; the buffer is sized from the longest one
+	// A carrier yields about one record per TDMA frame and chain; FCCH acquisition keeps up to 16 chains (beams) per
+	// carrier.  Start with room for two chains per carrier and run again with the real count if that was too little
+	// (gmr1_hip_rx_run_dev reports the full count even when it could not store it).
 	uint64_t longest = 1;
 	for (int k = 0; k < nm; k++)
 		if (llen[k] > longest) longest = llen[k];
-	const int cap_per = (int)(longest / ((uint64_t)sps * 39 * 24) + 64);      // one record per TDMA frame at the very most
-	const int cap = nm > 0 ? nm * cap_per : 1;
-	std::vector<gmr1_hip_rx_record> rec((size_t)cap);
-	std::vector<int32_t> lstat((size_t)per, 0), lnch((size_t)per, 0);
+	const size_t cap_per = (size_t)(longest / ((uint64_t)sps * 39 * 24) + 64);
+	std::vector<gmr1_hip_rx_record> rec;
+	std::vector<int32_t> lstat((size_t)per + 1, 0), lnch((size_t)per + 1, 0);
 	int nrec = 0;
-	if (nm > 0) {
+	if (!err && nm > 0) {
 		std::vector<uint16_t> lidx((size_t)nm);
 		for (int k = 0; k < nm; k++)
 			lidx[k] = (uint16_t)k;
-		int r = gmr1_hip_rx_run_dev(stream, nm, sps, liq, loff.data(), llen.data(), lidx.data(), rec.data(), cap, &nrec,
-		                            lstat.data(), lnch.data());
-		if (r) return r;
-		if (nrec > cap)
-			return fail(-EIO, "rx_run_sharded: %d records from %d carriers do not fit %d", nrec, nm, cap);
+		size_t cap = (size_t)nm * cap_per * 2;
+		for (int attempt = 0; attempt < 2 && !err; attempt++) {
+			if (cap > (size_t)INT32_MAX) cap = INT32_MAX;
+			rec.assign(cap, gmr1_hip_rx_record{});
+			err = gmr1_hip_rx_run_dev(stream, nm, sps, liq, loff.data(), llen.data(), lidx.data(), rec.data(), (int)cap, &nrec,
+			                          lstat.data(), lnch.data());
+			if (err || (size_t)nrec <= cap)
+				break;
+			cap = (size_t)nrec;
+			if (attempt == 1)
+				err = fail(-EIO, "rx_run_sharded: the record count changed between two runs over the same samples");
+		}
 	}
+	if (err)
+		nrec = 0;
 	if (timing_ms) {
 		timing_ms[1] = (float)ms_since(t0);
 		t0 = std::chrono::steady_clock::now();
 	}
 
 	// ---- gather ---------------------------------------------------------------------------------------------------
-	// per rank: [records of local carrier 0..per-1 | status | chains | total], all gathered everywhere (3 per + 1 words)
-	const int mw = 3 * per + 1;
+	// per rank: [records of local carrier 0..per-1 | status | chains | total | this rank's error], gathered everywhere
+	const int mw = 3 * per + 2;
 	std::vector<int32_t> meta((size_t)mw, 0), all((size_t)mw * world, 0);
 	// (the loop labelled its records with the local carrier index: counted per carrier here, then given the caller's labels)
 	for (int i = 0; i < nrec; i++) {
@@ -248,15 +341,32 @@ int gmr1_hip_rx_run_sharded(struct gmr1_hip_shard *sh, void *stream, int root, i
 	for (int k = 0; k < nm; k++) { meta[per + k] = lstat[k]; meta[2 * per + k] = lnch[k]; }
 	meta[3 * per] = nrec;
 	if (world > 1) {
-		int r = grow(&sh->d_meta, &sh->meta_bytes, (size_t)mw * 4 * (world + 1));
-		if (r) return r;
+		// (an allocation failure here is carried in the status word like any other: the block below is then skipped by
+		// this rank only if it cannot even hold the counts, which the d_flag agreement makes known to everybody first)
+		int aerr = grow(&sh->d_meta, &sh->meta_bytes, (size_t)mw * 4 * (world + 1));
+		if (!err) err = aerr;
+		const int rc = agree(sh, st, aerr, &bad_rank);
+		if (rc)
+			return err ? err : fail(rc, "rx_run_sharded: rank %d could not stage its counts (%d)", bad_rank, rc);
+		meta[3 * per + 1] = err;
 		int32_t *d_me = static_cast<int32_t *>(sh->d_meta), *d_all = d_me + mw;
-		HIP_TRY(hipMemcpyAsync(d_me, meta.data(), (size_t)mw * 4, hipMemcpyHostToDevice, st));
-		RCCL_TRY(R.AllGather(d_me, d_all, (size_t)mw, ncclInt32, sh->comm, st));
-		HIP_TRY(hipMemcpyAsync(all.data(), d_all, (size_t)mw * 4 * world, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
+		hipError_t e = hipMemcpyAsync(d_me, meta.data(), (size_t)mw * 4, hipMemcpyHostToDevice, st);
+		ncclResult_t r = R.AllGather(d_me, d_all, (size_t)mw, ncclInt32, sh->comm, st);    // posted whatever happened before
+		if (e == hipSuccess && r == ncclSuccess)
+			e = hipMemcpyAsync(all.data(), d_all, (size_t)mw * 4 * world, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess && r == ncclSuccess)
+			e = hipStreamSynchronize(st);
+		if (e != hipSuccess || r != ncclSuccess)
+			return fail(-EIO, "rx_run_sharded: count exchange failed (%s)", e != hipSuccess ? hipGetErrorString(e) : R.GetErrorString(r));
 	} else {
+		meta[3 * per + 1] = err;
 		all = meta;
+	}
+	// a rank whose receive loop failed has told everybody: all ranks stop here, with that rank's error
+	for (int r2 = 0; r2 < world; r2++) {
+		const int32_t e2 = all[(size_t)r2 * mw + 3 * per + 1];
+		if (e2)
+			return err ? err : fail(e2, "rx_run_sharded: the receive loop failed on rank %d (%d)", r2, e2);
 	}
 	// records: every rank's block to root
 	std::vector<size_t> base((size_t)world + 1, 0);
@@ -266,34 +376,44 @@ int gmr1_hip_rx_run_sharded(struct gmr1_hip_shard *sh, void *stream, int root, i
 	std::vector<gmr1_hip_rx_record> gathered;
 	if (world > 1) {
 		const size_t need = (is_root ? total : (size_t)nrec) * sizeof(gmr1_hip_rx_record);
-		int r = grow(&sh->d_rec, &sh->rec_bytes, need ? need : 1);
-		if (r) return r;
-		unsigned char *d = static_cast<unsigned char *>(sh->d_rec);
-		if (!is_root && nrec)
-			HIP_TRY(hipMemcpyAsync(d, rec.data(), (size_t)nrec * sizeof(gmr1_hip_rx_record), hipMemcpyHostToDevice, st));
-		RCCL_TRY(R.GroupStart());
-		if (is_root) {
-			for (int r2 = 0; r2 < world; r2++) {
-				const size_t n = base[r2 + 1] - base[r2];
-				if (r2 != root && n)
-					RCCL_TRY(R.Recv(d + base[r2] * sizeof(gmr1_hip_rx_record), n * sizeof(gmr1_hip_rx_record), ncclUint8, r2,
-					                sh->comm, st));
-			}
-		} else if (nrec) {
-			RCCL_TRY(R.Send(d, (size_t)nrec * sizeof(gmr1_hip_rx_record), ncclUint8, root, sh->comm, st));
+		int aerr = grow(&sh->d_rec, &sh->rec_bytes, need ? need : 1);
+		{
+			const int rc = agree(sh, st, aerr, &bad_rank);
+			if (rc)
+				return aerr ? aerr : fail(rc, "rx_run_sharded: rank %d could not stage its records (%d)", bad_rank, rc);
 		}
-		RCCL_TRY(R.GroupEnd());
-		if (is_root) {
+		unsigned char *d = static_cast<unsigned char *>(sh->d_rec);
+		hipError_t e = hipSuccess;
+		if (!is_root && nrec)
+			e = hipMemcpyAsync(d, rec.data(), (size_t)nrec * sizeof(gmr1_hip_rx_record), hipMemcpyHostToDevice, st);
+		{
+			Group g(R);
+			if (is_root) {
+				for (int r2 = 0; r2 < world; r2++) {
+					const size_t n = base[r2 + 1] - base[r2];
+					if (r2 != root && n)
+						g.note(R.Recv(d + base[r2] * sizeof(gmr1_hip_rx_record), n * sizeof(gmr1_hip_rx_record), ncclUint8, r2,
+						              sh->comm, st), "ncclRecv (records)");
+				}
+			} else if (nrec) {
+				g.note(R.Send(d, (size_t)nrec * sizeof(gmr1_hip_rx_record), ncclUint8, root, sh->comm, st), "ncclSend (records)");
+			}
+			err = g.end();
+		}
+		if (!err && e != hipSuccess)
+			err = fail(-EIO, "rx_run_sharded: staging the records failed (%s)", hipGetErrorString(e));
+		if (is_root && !err) {
 			gathered.resize(total ? total : 1);
-			if (total)
-				HIP_TRY(hipMemcpyAsync(gathered.data(), d, total * sizeof(gmr1_hip_rx_record), hipMemcpyDeviceToHost, st));
-			HIP_TRY(hipStreamSynchronize(st));
-			// root's own block did not travel
+			if (total && hipMemcpyAsync(gathered.data(), d, total * sizeof(gmr1_hip_rx_record), hipMemcpyDeviceToHost, st) != hipSuccess)
+				err = fail(-EIO, "rx_run_sharded: reading the gathered records failed");
+		}
+		if (hipStreamSynchronize(st) != hipSuccess && !err)
+			err = fail(-EIO, "rx_run_sharded: stream synchronise after the gather failed");
+		if (err)
+			return err;
+		if (is_root)                                  // root's own block did not travel
 			for (int i = 0; i < nrec; i++)
 				gathered[base[root] + i] = rec[i];
-		} else {
-			HIP_TRY(hipStreamSynchronize(st));
-		}
 	} else {
 		gathered.assign(rec.begin(), rec.begin() + nrec);
 	}
@@ -316,6 +436,28 @@ int gmr1_hip_rx_run_sharded(struct gmr1_hip_shard *sh, void *stream, int root, i
 	if (timing_ms)
 		timing_ms[2] = (float)ms_since(t0);
 	return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmr1_hip_rx_run_sharded(struct gmr1_hip_shard *sh, void *stream, int root, int n_arfcn, int sps, const float *iq,
+                            const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                            struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                            int32_t *status, int32_t *n_chains, float *timing_ms)
+{
+	return rx_run_sharded_impl(sh, stream, root, true, n_arfcn, sps, iq, offset, length, arfcn, out, max_records, n_records,
+	                           status, n_chains, timing_ms);
+}
+
+int gmr1_hip_rx_run_sharded_resident(struct gmr1_hip_shard *sh, void *stream, int root, int n_arfcn, int sps, const float *iq,
+                                     const uint64_t *offset, const uint64_t *length, const uint16_t *arfcn,
+                                     struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                                     int32_t *status, int32_t *n_chains, float *timing_ms)
+{
+	return rx_run_sharded_impl(sh, stream, root, false, n_arfcn, sps, iq, offset, length, arfcn, out, max_records, n_records,
+	                           status, n_chains, timing_ms);
 }
 
 }  // extern "C"

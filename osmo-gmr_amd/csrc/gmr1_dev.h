@@ -7,6 +7,8 @@
 #include "gmr1_hip.h"
 #include "rx_loop.h"
 
+#include "profile_env.h"
+
 namespace gmr1 {
 
 constexpr int kMaxSync = GMR1_HIP_MAX_SYNC;

@@ -2800,13 +2800,13 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 			const size_t lds4 = lds4_layout(a.stage_samples, cw, off4);
 			static size_t pad = (size_t)-1;     // profiling only: extra LDS per wave to cap the occupancy
 			if (pad == (size_t)-1) {
-				const char *e = getenv("GMR1_HIP_LDS_PAD");
+				const char *e = profile_env("GMR1_HIP_LDS_PAD");
 				pad = e ? (size_t)atoi(e) : 0;
 			}
 			// small batches (the receive loop's rounds): one burst per wave, four times the waves
 			static int bpw_force = -1;          // profiling only: GMR1_HIP_RX_BPW = 1 | 4
 			if (bpw_force < 0) {
-				const char *e = getenv("GMR1_HIP_RX_BPW");
+				const char *e = profile_env("GMR1_HIP_RX_BPW");
 				bpw_force = e ? atoi(e) : 0;
 			}
 			const int bpw = bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4);

@@ -94,3 +94,9 @@ def test_bench_gpus2_over_gloo_on_one_gpu():
     assert sh["frames_identical_to_oracle"] and sh["tiles_of_carrier0_identical_across_ranks"]
     for k in ("scatter_ms", "rx_loop_ms", "gather_ms"):
         assert sh[k] > 0
+    # every record of every carrier: the sharded exchange returns what ONE gmr1_hip_rx_run over all carriers returns
+    assert sh["records_identical_to_single_gpu_run"] and sh["single_gpu_run_frames"] == sh["frames"]
+    # and the other way to feed the ranks (each holds its own carriers, no scatter) returns the same records
+    assert sh["resident"]["records_identical_to_scattered_run"] and sh["resident"]["rx_loop_ms"] > 0
+    lo, hi = sh["rx_loop_ms_per_rank_min_max"]
+    assert 0 < lo <= hi

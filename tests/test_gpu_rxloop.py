@@ -174,6 +174,15 @@ def test_native_sharded_entry_world_of_one(gpu_api, orc, pkg):
             assert _key(rec) == _key(one) and len(rec) > 0
             assert np.array_equal(status, st1) and np.array_equal(chains, ch1)
             assert (timing >= 0).all() and timing[1] > 0
+            # the samples already where they are processed (gmr1_hip_rx_run_sharded_resident): the same records
+            rec2, st2, ch2, _ = sh.rx_run(st, iq.data_ptr(), offset, length, sps=SPS, arfcn=labels, resident=True)
+            assert _key(rec2) == _key(one) and np.array_equal(st2, st1) and np.array_equal(ch2, ch1)
+        # arguments every rank can check are refused before anything collective starts
+        for bad in (0, 17):
+            with pytest.raises(gpu_api.Gmr1HipError, match="-22"):
+                sh.rx_run(st, iq.data_ptr(), offset, length, sps=bad)
+        with pytest.raises(gpu_api.Gmr1HipError, match="-22"):
+            sh.rx_run(st, 0, offset, length, sps=SPS)                      # root without samples
     finally:
         sh.close()
     ref = np.concatenate([orc.rx_run(xs[a], sps=SPS, arfcn=[9, 9, 11][a])[1] for a in range(3)])

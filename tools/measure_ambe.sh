@@ -1,5 +1,8 @@
 # AMBE decoder measurement set (GPU box, repo root): bash tools/measure_ambe.sh <tag>  -> gpurun_out/<tag>/
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# the switches below exist only in the profiling build (python osmo-gmr_amd/build.py --profile)
+export GMR1_HIP_LIBRARY=$GRAFT_REPO_ROOT/osmo-gmr_amd/libgmr1_hip_prof.so
+[ -f $GMR1_HIP_LIBRARY ] || python3 osmo-gmr_amd/build.py --profile > /dev/null
 t=$1
 o=gpurun_out/$t
 mkdir -p $o

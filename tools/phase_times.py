@@ -6,7 +6,9 @@ what the second read costs).  Run on the GPU box from the repo root."""
 import json, os, subprocess, sys
 prev = 0.0
 for st in (2, 3, 5, 6, 7, 0, 100):
-    env = dict(os.environ, GMR1_HIP_DBG_STOP=str(st))
+    # the cut-offs exist only in the profiling build: python osmo-gmr_amd/build.py --profile
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "osmo-gmr_amd", "libgmr1_hip_prof.so")
+    env = dict(os.environ, GMR1_HIP_DBG_STOP=str(st), GMR1_HIP_LIBRARY=os.environ.get("GMR1_HIP_LIBRARY", prof))
     r = subprocess.run([sys.executable, "bench.py", "--no-cpu", "--steps", "60", "--warmup", "5"] + sys.argv[1:],
                        capture_output=True, text=True, env=env)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,6 +1,9 @@
 # VALU / SALU / LDS instructions and wave cycles of the headline kernel cut off after each phase (GPU box, repo root):
 #   bash tools/phases.sh <tag>      -> gpurun_out/phases_<tag>.txt
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# the switches below exist only in the profiling build (python osmo-gmr_amd/build.py --profile)
+export GMR1_HIP_LIBRARY=$GRAFT_REPO_ROOT/osmo-gmr_amd/libgmr1_hip_prof.so
+[ -f $GMR1_HIP_LIBRARY ] || python3 osmo-gmr_amd/build.py --profile > /dev/null
 tag=$1
 out=gpurun_out/phases_$tag.txt
 : > $out

@@ -1,5 +1,8 @@
 # VALU / SALU / LDS instructions of k_ambe with phases cut off (GPU box, repo root): bash tools/phases_ambe.sh <tag>
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# the switches below exist only in the profiling build (python osmo-gmr_amd/build.py --profile)
+export GMR1_HIP_LIBRARY=$GRAFT_REPO_ROOT/osmo-gmr_amd/libgmr1_hip_prof.so
+[ -f $GMR1_HIP_LIBRARY ] || python3 osmo-gmr_amd/build.py --profile > /dev/null
 tag=$1
 out=gpurun_out/phases_ambe_$tag.txt
 : > $out

@@ -10,7 +10,9 @@ import time
 
 if len(sys.argv) < 2:
     for st in (1, 2, 3, 4, 5, 0):
-        env = dict(os.environ, GMR1_HIP_DBG_STOP=str(st))
+        # the cut-offs exist only in the profiling build: python osmo-gmr_amd/build.py --profile
+        prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "osmo-gmr_amd", "libgmr1_hip_prof.so")
+        env = dict(os.environ, GMR1_HIP_DBG_STOP=str(st), GMR1_HIP_LIBRARY=os.environ.get("GMR1_HIP_LIBRARY", prof))
         subprocess.run([sys.executable, os.path.abspath(__file__), str(st)], env=env, check=False)
     sys.exit(0)
 

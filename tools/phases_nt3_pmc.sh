@@ -1,6 +1,9 @@
 # VALU / SALU / LDS instructions per wave of the NT3 speech demodulator (k_rx4g<8,4>) cut off after each phase
 # (GPU box, repo root; needs a library built with -DGMR1_HIP_PROFILE):  bash tools/phases_nt3_pmc.sh <tag>
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+# the switches below exist only in the profiling build (python osmo-gmr_amd/build.py --profile)
+export GMR1_HIP_LIBRARY=$GRAFT_REPO_ROOT/osmo-gmr_amd/libgmr1_hip_prof.so
+[ -f $GMR1_HIP_LIBRARY ] || python3 osmo-gmr_amd/build.py --profile > /dev/null
 tag=$1
 out=gpurun_out/phases_nt3_$tag.txt
 : > $out
