@@ -110,7 +110,8 @@ int gmr1_hip_demod_batch(int burst_id, int n, int sps, int in_len,
                          float *toa, float *freq_err, float *ssyms, int32_t *rv);
 
 /* ---- burst type detection / modulation order -------------------------------
- * burst_ids: 1..4 candidate types (same length / modulation family); e_toa optional. */
+ * burst_ids: any number of candidate types (same length / modulation family; more than four run as several launches
+ * that hand the best so far on); e_toa optional. */
 int gmr1_hip_detect_batch_dev(void *stream, int n_types, const int *burst_ids, int n, int sps, int in_len,
                               const float *iq, const uint64_t *offset, const float *freq_shift,
                               const float *e_toa, int32_t *bt_id, int32_t *sync_id, float *toa, int32_t *rv);

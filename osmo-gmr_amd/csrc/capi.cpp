@@ -618,10 +618,11 @@ int gmr1_ccch_decode(uint8_t *l2, const sbit_t *bits_e, int *conv_rv) { return d
 namespace gmr1 {
 namespace {
 // what every burst of the fused BCCH / CCCH path shares
-int rx_base_args(int sps, const float *iq, RxArgs *out)
+int rx_base_args(int sps, const float *iq, RxArgs *out, int min_sps = 4)
 {
-	if (sps < 4 || sps > 8)
-		return fail(-EINVAL, "rx_bcch_ccch: sps=%d unsupported (4..8)", sps);
+	// (more than 8 samples per symbol: the BCCH window of 254 symbols passes the 2048 samples a burst window may have)
+	if (sps < min_sps || sps > 8)
+		return fail(-EINVAL, "rx_bcch_ccch: sps=%d unsupported (%d..8)", sps, min_sps);
 	RxArgs a;
 	std::memset(&a, 0, sizeof(a));
 	a.sps = sps;
@@ -668,7 +669,7 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 	int r = dev_state(&s);
 	if (r) return r;
 	RxArgs a;
-	r = rx_base_args(sps, iq, &a);
+	r = rx_base_args(sps, iq, &a, 1);
 	if (r) return r;
 	a.n = n;
 	a.dbg_stop = dbg_stop_env();
@@ -679,6 +680,10 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 			impl = e ? atoi(e) : 0;
 		}
 		a.impl = impl;
+		// below four samples per symbol the reference delays the burst by a fraction of a sample with a 21-tap sinc
+		// (pi4cxpsk.c:298-343) instead of picking samples: the one-burst-at-a-time body has that branch, the row-batched one not
+		if (sps < 4)
+			a.impl = 1;
 	}
 	a.offset = offset; a.kind = kind; a.freq_shift = freq_shift;
 	a.l2 = l2; a.crc = crc; a.conv = conv; a.toa = toa; a.freq_err = freq_err;

@@ -158,9 +158,10 @@ struct DdcPlan {
 	double resamp = 1.0;
 	std::vector<float> taps1, taps2;         // host copies (stage 1 taps are turned per carrier at call time)
 	int tpf = 0, j0 = 0;
+	int bank_tpf = 30;                       // row length of the bank on the device: the kernel instantiation's 30 or 96 taps
 	long long num = 0, den = 1;
 	float2 *d_taps2 = nullptr;               // real taps as (t, 0)
-	float2 *d_bank = nullptr;                // resampler bank, rows padded to the kernel's 30 taps
+	float2 *d_bank = nullptr;                // resampler bank, rows padded to bank_tpf taps
 };
 std::deque<DdcPlan> g_ddc_plans;
 
@@ -229,10 +230,13 @@ int get_ddc_plan(double samp_rate, int sps, const DdcPlan **out)
 		return fail(-EINVAL, "ddc: filters of %zu / %zu taps (at most %d)", p.taps1.size(), p.taps2.size(), kDdcMaxTaps);
 	const int nt = (int)rrc.size();
 	p.tpf = (nt + kNfilt - 1) / kNfilt;
-	constexpr int kBankTaps = 30;            // what k_resamp keeps in registers per phase
+	// what k_resamp keeps in registers per phase: 30 taps, or 96 in its long instantiation (plans that resample down:
+	// 1.0 Msps -> rate 0.468, 95 taps per phase)
+	const int kBankTaps = p.tpf <= 30 ? 30 : 96;
 	if (p.tpf > kBankTaps)
 		return fail(-EINVAL, "ddc: the resampler of this plan (rate %.4f, %d taps per phase) is longer than the %d the kernel "
 		                     "holds", resamp, p.tpf, kBankTaps);
+	p.bank_tpf = kBankTaps;
 	p.j0 = (nt / 2) % kNfilt;
 	// phase step nfilt / rate = nfilt * samp_rate / (d1 d2 out_rate), as a reduced fraction
 	long long num = (long long)kNfilt * (long long)std::llround(samp_rate), den = (long long)p.d1 * p.d2 * (long long)out_rate;
@@ -356,7 +360,7 @@ int gmr1_hip_ddc_dev(void *stream, double samp_rate, int sps, const float *wide,
 	}
 	ResampArgs ra;
 	std::memset(&ra, 0, sizeof(ra));
-	ra.n_slots = n_sel; ra.nfilt = kNfilt; ra.tpf = 30; ra.j0 = p->j0; ra.num = p->num; ra.den = p->den;
+	ra.n_slots = n_sel; ra.nfilt = kNfilt; ra.tpf = p->bank_tpf; ra.j0 = p->j0; ra.num = p->num; ra.den = p->den;
 	ra.T = n2; ra.n_out = (long long)n_out; ra.out_stride = (long long)out_stride;
 	ra.y = d_y2; ra.bank = p->d_bank; ra.out = reinterpret_cast<float2 *>(out);
 	HIP_TRY(launch_resamp(ra, st));

@@ -276,13 +276,17 @@ hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream)
 // which the wave stages with coalesced loads one period ahead.  Single-wavefront work-groups, no
 // s_barrier; outputs of a wave are 64 consecutive samples = one 512-byte store.
 // ---------------------------------------------------------------------------
-static constexpr int kRsTaps = 30;           // taps per filter of the 941-tap / 32-phase bank
+// taps per filter: 30 for the 941-tap / 32-phase bank of every plan that raises the rate; the direct mode at 1.0 Msps
+// resamples DOWN (rate 0.468) and its root-raised cosine is 95 taps per phase long -- a second instantiation
+static constexpr int kRsTapsShort = 30, kRsTapsLong = 96;
 static constexpr int kRsPeriods = 32;        // periods one wave walks
-static constexpr int kRsWin = 256;           // LDS window (samples) per wave, >= span
+static constexpr int kRsWinShort = 256, kRsWinLong = 512;     // LDS window (samples) per wave, >= span
 
+template <int kRsTaps, int kRsWin>
 __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long long Q, int span)
 {
 	__shared__ float2 xs[kRsWin];
+	constexpr int NH = kRsWin / 64;
 	const int lane = threadIdx.x;
 	const int sl = blockIdx.y;
 	const long long p0 = (long long)blockIdx.x * 64;
@@ -308,10 +312,10 @@ __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long l
 	const long long m0 = (long long)blockIdx.z * kRsPeriods;
 
 	// window of period m: inputs i_first + m Q + [0, span)
-	float2 nx[4];
+	float2 nx[NH];
 	auto fetch = [&](long long m) {
 #pragma unroll
-		for (int h = 0; h < 4; h++) {
+		for (int h = 0; h < NH; h++) {
 			const int w = lane + 64 * h;
 			const long long s = i_first + m * Q + w;
 			nx[h] = (w < span && s >= 0 && s < a.T) ? y[s] : make_float2(0.f, 0.f);
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long l
 			break;
 		WSYNC();
 #pragma unroll
-		for (int h = 0; h < 4; h++)
+		for (int h = 0; h < NH; h++)
 			if (lane + 64 * h < span)
 				xs[lane + 64 * h] = nx[h];
 		WSYNC();
@@ -413,18 +417,23 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 {
 	if (a.n_out <= 0 || a.n_slots <= 0)
 		return hipSuccess;
-	if (a.tpf != kRsTaps)
+	const bool lng = a.tpf == kRsTapsLong;
+	if (a.tpf != kRsTapsShort && !lng)
 		return hipErrorInvalidValue;
+	const int taps = lng ? kRsTapsLong : kRsTapsShort, win = lng ? kRsWinLong : kRsWinShort;
 	long long g = a.num, b = a.den * a.nfilt;
 	while (b) { const long long t = g % b; g = b; b = t; }
 	const long long P = a.den * a.nfilt / g, Q = a.num / g;
 	// inputs the 64 phases of a wave can touch
-	const int span = (int)((63 * a.num) / (a.den * a.nfilt)) + kRsTaps + 2;
-	if (span > kRsWin)
+	const int span = (int)((63 * a.num) / (a.den * a.nfilt)) + taps + 2;
+	if (span > win)
 		return hipErrorInvalidValue;
 	const long long periods = (a.n_out + P - 1) / P;
 	const unsigned gx = (unsigned)((P + 63) / 64), gz = (unsigned)((periods + kRsPeriods - 1) / kRsPeriods);
-	hipLaunchKernelGGL(k_resamp, dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
+	if (lng)
+		hipLaunchKernelGGL((k_resamp<kRsTapsLong, kRsWinLong>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
+	else
+		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinShort>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	return hipGetLastError();
 }
 

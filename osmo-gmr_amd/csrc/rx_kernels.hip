@@ -2574,11 +2574,16 @@ __global__ __launch_bounds__(64) void k_detect(DetectArgs a, int max_in_len)
 	const int sps = SPS ? SPS : a.sps;
 	load_normalise<NPL>(a.iq + a.offset[g], a.in_len, L, lane);
 	const float fsh = a.freq_shift ? a.freq_shift[g] : 0.0f;
-	const float fs = (fsh - c_types[a.types[0]].rotation) / (float)sps;
+	const float fs = (fsh - a.rot0) / (float)sps;
 	const float e_toa = a.e_toa ? a.e_toa[g] : -1.0f;
 	int p_id = -1, p_sid = -1, rv = 0;
 	float p_toa = 0.f, p_pwr = 0.f;
-	for (int id = 0; id < a.n_types; id++) {
+	if (a.carry) {
+		// a list of more than four candidates runs as several launches: pick up where the last one stopped
+		rv = a.rv[g];
+		p_id = a.bt_id[g]; p_sid = a.sync_id[g]; p_toa = a.toa[g]; p_pwr = a.best_pwr[g];
+	}
+	for (int id = 0; id < a.n_types && rv == 0; id++) {
 		float toa, pwr;
 		const int sid = sync_search<SPS>(a.types[id], a.in_len, a.sps, fs, L, lane, 0, toa, pwr);
 		if (sid < 0) {
@@ -2588,7 +2593,7 @@ __global__ __launch_bounds__(64) void k_detect(DetectArgs a, int max_in_len)
 		if (e_toa >= 0.0f)
 			pwr = (float)((double)pwr / fabs((double)(e_toa - toa)));
 		if (pwr > p_pwr) {
-			p_id = id; p_sid = sid; p_pwr = pwr; p_toa = toa;
+			p_id = a.first + id; p_sid = sid; p_pwr = pwr; p_toa = toa;
 		}
 	}
 	if (lane == 0) {
@@ -2596,6 +2601,7 @@ __global__ __launch_bounds__(64) void k_detect(DetectArgs a, int max_in_len)
 		if (a.bt_id) a.bt_id[g] = rv ? -1 : p_id;
 		if (a.sync_id) a.sync_id[g] = rv ? -1 : p_sid;
 		if (a.toa) a.toa[g] = rv ? 0.f : p_toa;
+		if (a.best_pwr) a.best_pwr[g] = p_pwr;
 	}
 }
 

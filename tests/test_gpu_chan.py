@@ -154,10 +154,11 @@ def test_wideband_sharded_single_rank(gpu_api, pkg):
 
 
 # ---- direct mode (gmr1_rx_sdr.py:605-807): gmr1_hip_ddc* -----------------------------------------------------------
-@pytest.mark.parametrize("fs", [2.0e6, 1.25e6, 2.5e6, 4.0e6])
+@pytest.mark.parametrize("fs", [2.0e6, 1.25e6, 2.5e6, 4.0e6, 1.0e6])
 def test_direct_mode_matches_oracle(gpu_api, fs):
     """Frequency-translating FIR, second FIR, arbitrary resampler against the numpy restatement, at the decimation
-    splits the script picks for these rates (7 x 6, 5 x 5, 7 x 7, 12 x 7), carriers on and off the 31.25 kHz raster."""
+    splits the script picks for these rates (7 x 6, 5 x 5, 7 x 7, 12 x 7; 1.0 Msps: 5 x 1 and a resampler that goes DOWN,
+    rate 0.468, 95 taps per phase -- the kernel's long instantiation), carriers on and off the 31.25 kHz raster."""
     import orc_chan
     pl = orc_chan.DirectPlan(fs)
     d1, d2, rs, n_out = gpu_api.ddc_plan(fs, 4, 200000)
@@ -183,8 +184,10 @@ def test_direct_mode_matches_oracle(gpu_api, fs):
 def test_direct_mode_refusals(gpu_api):
     with pytest.raises(gpu_api.Gmr1HipError, match="-22"):
         gpu_api.ddc_plan(93600.0 * 20, 4, 1000)           # the reference's own exact case cannot run
-    with pytest.raises(gpu_api.Gmr1HipError, match="-22"):
-        gpu_api.ddc_plan(1.0e6, 4, 1000)                  # rate 0.468: 95 taps per resampler phase
+    # (no plan's resampler is refused for its length any more: the longest, rate 0.468 at 0.8 / 1.0 Msps, has 95 taps per
+    # phase and the kernel's long instantiation holds 96)
+    d1, d2, rs, _ = gpu_api.ddc_plan(1.5e6, 4, 100000)
+    assert (d1, d2) == (8, 1) and abs(rs - 0.4992) < 1e-9
 
 
 def test_direct_mode_decodes_end_to_end(gpu_api, pkg):

@@ -245,6 +245,22 @@ def test_detect_and_mod_order(gpu_api, orc, pkg):
         odd.burst.sync[0][0].syms[k] ^= 2            # every other training symbol turned by 180 degrees
     assert gpu_api.pi4cxpsk_detect([odd, c_sp], 3.0, iq[i_sp], sps)["bt_id"] == 1
     assert gpu_api.pi4cxpsk_detect([c_sp, odd], 3.0, iq[i_sp], sps)["bt_id"] == 0
+    # lists longer than four (the reference takes any NULL-terminated list): batch form with built-in ids, the
+    # reference's call with built-in and caller-defined descriptions mixed; against the oracle on the same list, and the
+    # winner's position is the one in the caller's list
+    long_list = ["nt3_facch", "nt3_speech", "nt3_facch", "nt3_speech", "nt3_speech", "nt3_facch", "nt3_speech"]
+    got = gpu_api.detect_batch(long_list, iq, offset, in_len, sps=sps, e_toa=3.0)
+    for i in range(n):
+        o = orc.detect(long_list, 3.0, iq[i], sps)
+        assert (got["rv"][i], got["bt_id"][i], got["sync_id"][i]) == (0, o["bt_id"], o["sync_id"]), i
+        assert got["bt_id"][i] in (0, 1)                 # a later copy never beats the first (strict >)
+    odd_first = [odd, odd, odd, odd, odd, c_sp, "nt3_facch"]
+    assert gpu_api.pi4cxpsk_detect(odd_first, 3.0, iq[i_sp], sps)["bt_id"] == 5
+    mixed = [c_fa, odd, "nt3_facch", odd, c_sp, "nt3_speech"]
+    for i in range(0, n, 9):
+        o = orc.detect(["nt3_facch", "nt3_speech"], 3.0, iq[i], sps)
+        d = gpu_api.pi4cxpsk_detect(mixed, 3.0, iq[i], sps)
+        assert d["rv"] == 0 and d["bt_id"] == (0 if o["bt_id"] == 0 else 4) and d["sync_id"] == o["sync_id"], (i, d, o)
     order = gpu_api.mod_order_batch(iq, offset, in_len, sps=sps)
     for i in range(n):
         assert order[i] == orc.mod_order(iq[i], sps), i
@@ -308,7 +324,7 @@ def test_demod_low_oversampling(gpu_api, orc, pkg):
         assert (hard != ebits).mean() < 0.03, (sps, name)
 
 
-@pytest.mark.parametrize("sps", [5, 8])
+@pytest.mark.parametrize("sps", [2, 3, 5, 8])
 def test_fused_rx_other_oversampling(gpu_api, orc, pkg, sps, decoder):
     """The fused path at sps != 4 (generic k_rx4 instantiation; windows of 234 sps + 20 sps / 10 sps samples)."""
     wl = workloads.bcch_ccch_mix(pkg, n=403, seed=7, sps=sps, toa_jitter=2 * sps)
