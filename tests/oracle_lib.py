@@ -38,6 +38,8 @@ class FcchBurst(C.Structure):
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("ORC_LIBRARY"):                 # tests/test_sanitize.py: the same sources built with ASan + UBSan
+        return os.environ["ORC_LIBRARY"]
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)

@@ -7,6 +7,10 @@ import workloads
 pytestmark = pytest.mark.gpu
 
 
+def sps_of_label(label):
+    return int(label[3:]) if label.startswith("sps") else 4
+
+
 def _compare_fused(got, ref, wl, *, label):
     n = wl["kind"].size
     assert np.array_equal(got["rv"], ref["rv"]), f"{label}: rv differs"
@@ -50,7 +54,9 @@ def _compare_fused(got, ref, wl, *, label):
     # number of ~30 turns on both sides, i.e. quantised to ~1e-3 of a soft-bit step, and the two sides round it in
     # different places, so about 4e-4 of the soft bits sit on a step's edge and come out 1 LSB apart)
     eq = same & np.all(got["ebits"] == ref["ebits"], axis=1)
-    assert eq.mean() > 0.75
+    # documented: 85 % at sps 4; the bound is that minus three standard deviations of the sample
+    want = 0.85 if sps_of_label(label) == 4 else 0.80
+    assert eq.mean() > want - 3.0 * np.sqrt(want * (1 - want) / n), f"{label}: only {eq.mean():.3f} of the bursts have all soft bits identical"
     assert np.array_equal(got["l2"][eq], ref["l2"][eq]), f"{label}: L2 differs on identical soft bits"
     assert np.array_equal(got["crc"][eq], ref["crc"][eq])
     assert np.array_equal(got["conv"][eq], ref["conv"][eq])
@@ -61,7 +67,7 @@ def _compare_fused(got, ref, wl, *, label):
     good = got["crc"] == 0
     assert np.array_equal(got["l2"][good], wl["l2"][good]), f"{label}: payload is not what was sent"
     return dict(flips=int(flip.sum()), dss=float(dss.max()), eb_diff=float((deb != 0).mean()),
-                crc_fail=int((got["crc"] != 0).sum()))
+                crc_fail=int((got["crc"] != 0).sum()), all_soft_bits_identical=float(eq.mean()))
 
 
 def test_l1_bcch_ccch_bit_exact(gpu_api, orc, pkg, decoder):
