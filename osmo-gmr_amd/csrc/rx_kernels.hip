@@ -1615,7 +1615,23 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 // k_rx4 is the batch kernel around it, k_rx_loop (below) the receive loop that calls it round after round.
 // per-burst arrays of a launch: the batch kernel takes them from its arguments, the receive loop points them
 // at the current round's log blocks (by value: they stay in scalar registers)
+#ifdef GMR1_HIP_PROFILE
+// cycle stamps of ONE burst of the receive loop (chain 0, the BCCH burst of round kStampRound): tools/loop_stamps.py
+__device__ unsigned long long g_stamp[16];
+constexpr int kStampRound = 40;
+#define GMR1_STAMP(k)                                                        \
+	do {                                                                    \
+		if (LAT && io.stamp && lane == 0)                                   \
+			io.stamp[k] = __builtin_readcyclecounter();                     \
+	} while (0)
+#else
+#define GMR1_STAMP(k) do { } while (0)
+#endif
+
 struct RxIo {
+#ifdef GMR1_HIP_PROFILE
+	unsigned long long *stamp;
+#endif
 	const uint64_t *offset;
 	const uint8_t *kind;
 	const float *freq_shift;
@@ -1624,6 +1640,20 @@ struct RxIo {
 	float *toa, *freq_err, *energy;
 	int8_t *ebits;
 	float *ssyms;
+};
+
+// What a wave of the receive loop carries from one round into the next (LAT): the window -- and, again, the samples under
+// the sync chunks -- of the burst it will most likely be given next, eight frames on, asked for as soon as the current
+// burst's copies are dead.  They travel during the rest of the burst, the barrier and the chain's book-keeping; a round
+// whose burst turns out to sit elsewhere (the BCCH feedback moved the chain) simply loads as before.
+template <int NPL, int SPS>
+struct LatPre {
+	static constexpr int SIT = SPS == 4 ? 2 : 4;
+	float2 wv[NPL];
+	float2 sv[3][SIT];
+	uint64_t off = ~0ull;      // first sample of the window held (~0: none)
+	uint64_t lim = 0;          // end of the chain's capture: nothing is asked for beyond it
+	int kind = -1;
 };
 
 // LAT: the caller cares about the latency of ONE burst (the receive loop), not about throughput
@@ -1635,7 +1665,7 @@ struct RxIo {
 // sequence; `cw` holds both correlation arrays of a burst (first cw / 2 lags: sequence 0, then the sum).
 template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
-                                         unsigned char *__restrict__ lds_raw, int lane)
+                                         unsigned char *__restrict__ lds_raw, int lane, LatPre<NPL, SPS> *pre = nullptr)
 {
 	const int row = lane >> 4, col = lane & 15;
 	const int sps = SPS ? SPS : a.sps;
@@ -1667,6 +1697,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
 
+	GMR1_STAMP(0);
 	// =========================== pass 1: correlation magnitudes ===========================
 	if constexpr (SMALL) {
 		// The short formats (<= 512 samples, one sync chunk of <= 16 symbols, <= 64 lags) take pass 1 with ONE BURST PER ROW
@@ -1785,7 +1816,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 	} else {
-	float2 wv[NPL];
+	float2 wv_own[NPL];
+	float2 (&wv)[NPL] = *(LAT ? &pre->wv : &wv_own);
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
 		if (g >= n_end)
@@ -1806,18 +1838,38 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		// the ~300 samples under the sync chunks (they go to LDS; the second request hits the lines the
 		// first one is fetching) -- and what needs no data (the rotated reference) is computed while it
 		// travels
-		if (q == 0 || !PREFETCH_NEXT)
-			window_fetch<NPL, NFULL>(in, in_len, lane, wv);
 		constexpr int SIT = SMALL ? 1 : (SPS == 4 ? 2 : 4);   // 64-sample pieces per chunk window
-		float2 sv[NCHK][SIT];
+		float2 sv_own[NCHK][SIT];
+		float2 (&sv)[NCHK][SIT] = *(LAT ? reinterpret_cast<float2 (*)[NCHK][SIT]>(&pre->sv) : &sv_own);
+		auto fetch_window = [&](const float2 *__restrict__ from) {
+			window_fetch<NPL, NFULL>(from, in_len, lane, wv);
 #pragma unroll
-		for (int c = 0; c < NCHK; c++) {
-			const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
-			const float2 *__restrict__ src = in + (c < nch ? bt.sync[0][c].pos * sps : 0);
+			for (int c = 0; c < NCHK; c++) {
+				const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
+				const float2 *__restrict__ src = from + (c < nch ? bt.sync[0][c].pos * sps : 0);
 #pragma unroll
-			for (int h = 0; h < SIT; h++) {
-				const int sidx = lane + 64 * h;
-				sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
+				for (int h = 0; h < SIT; h++) {
+					const int sidx = lane + 64 * h;
+					sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
+				}
+			}
+		};
+		if constexpr (LAT) {
+			// the window asked for a round ago, if the burst sits where it was expected
+			if (!(pre->off == io.offset[g] && pre->kind == kind))
+				fetch_window(in);
+		} else {
+			if (q == 0 || !PREFETCH_NEXT)
+				window_fetch<NPL, NFULL>(in, in_len, lane, wv);
+#pragma unroll
+			for (int c = 0; c < NCHK; c++) {
+				const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
+				const float2 *__restrict__ src = in + (c < nch ? bt.sync[0][c].pos * sps : 0);
+#pragma unroll
+				for (int h = 0; h < SIT; h++) {
+					const int sidx = lane + 64 * h;
+					sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
+				}
 			}
 		}
 		// rotated reference of the (single) sync sequence: without a caller-supplied frequency shift it only depends on
@@ -1838,6 +1890,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			L.coef[lane] = cfl;
 		float avr, avi, inv;
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
+		GMR1_STAMP(1);
 		if (row == q) { avr_r = avr; avi_r = avi; }
 		if (LAT && io.energy) {
 			// burst_energy() while the window is still in registers
@@ -1871,6 +1924,20 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 					}
 				}
 				wb += wl;
+			}
+		}
+		if constexpr (LAT) {
+			// this burst's copies are dead: ask for the window the chain's schedule puts eight frames on (the same slot of
+			// the next round) -- it has the rest of this burst and the round's turn-around to arrive.  (Asked for later --
+			// just before the Viterbi decoder -- the requests' own issue time lands on the round's critical path: measured,
+			// 4.07 ms against 3.92 ms for 64 carriers x 60 s.)
+			const uint64_t nxt = io.offset[g] + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
+			if (nxt + (uint64_t)in_len <= pre->lim) {
+				fetch_window(a.iq + nxt);
+				pre->off = nxt;
+				pre->kind = kind;
+			} else {
+				pre->off = ~0ull;
 			}
 		}
 		WSYNC();
@@ -1927,6 +1994,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 	}
 	WSYNC();
+	GMR1_STAMP(2);
 	if (a.dbg_stop == 2) return;
 
 	// per-row (lane-resident) burst parameters: looked up here, not before pass 1, which has no register to spare for them
@@ -2080,6 +2148,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 	}
 	const bool found_r = sid_r >= 0;
+	GMR1_STAMP(3);
 	if (a.dbg_stop == 3) return;
 	const int d_r = (int)roundf(toa_r);
 
@@ -2208,6 +2277,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 		psi_r = atan2_fast(row_sum(ti), row_sum(tr));
 	}
+	GMR1_STAMP(4);
 	if (a.dbg_stop == 5) return;
 
 	// per-burst results
@@ -2318,15 +2388,18 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 	if (GEN || (a.dbg_stop && a.dbg_stop < 7))
 		return;
+	GMR1_STAMP(5);
 
 	// =========================== rows: layer 1 ===========================
 	WSYNC();     // the window is dead: bm / surv / ubits overlay it
 	branch_metrics4_k5_12<ACC>(L.eb, 432, row_ok, row_chain, L.bm, lane);
 	WSYNC();
+	GMR1_STAMP(6);
 	if (a.dbg_stop == 7)
 		return;
 	uint32_t syn, fae;
 	decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae);
+	GMR1_STAMP(7);
 	if (col == 0 && row_live) {
 		if ((row_ok >> row) & 1) {
 			store_l2(io.l2 + (size_t)g_row * 24, L.ubits + row * 8);
@@ -2357,7 +2430,11 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
 	// which shortens the critical path of a wave to a quarter
 	const int g0 = blockIdx.x * bpw;
-	const RxIo io = {a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
+	const RxIo io = {
+#ifdef GMR1_HIP_PROFILE
+	                 nullptr,
+#endif
+	                 a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
 	rx4_body<NPL, SPS, false, false, false, ACC>(a, io, stage_samples, cw, g0, min(a.n, g0 + bpw), lds_raw, (int)threadIdx.x);
 }
@@ -2368,7 +2445,11 @@ __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int g0 = blockIdx.x * 4;
-	const RxIo io = {a.offset, nullptr, a.freq_shift, nullptr, nullptr, nullptr, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
+	const RxIo io = {
+#ifdef GMR1_HIP_PROFILE
+	                 nullptr,
+#endif
+	                 a.offset, nullptr, a.freq_shift, nullptr, nullptr, nullptr, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
 	rx4_body<NPL, SPS, false, true, FAC>(a, io, stage_samples, cw, g0, min(a.n, g0 + 4), lds_raw, (int)threadIdx.x);
 }
@@ -2471,6 +2552,8 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 			rx_loop_advance(st, sps);
 		}
 	};
+	LatPre<NPL, SPS> pre;
+	pre.lim = lim;
 	int round = 0;
 	for (; round < la.max_rounds; round++) {
 		const int cb = round & 1, pb = cb ^ 1;
@@ -2528,19 +2611,16 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 		if (n == 0)
 			break;
 		if (wave < n) {
-			// the windows of the next round lie eight frames further on (give or take the feedback): touch their
-			// lines now, so that HBM and page-walk latency overlap this round's arithmetic instead of heading it
-			float sink = 0.f;
-			{
-				const uint64_t nxt = s_off[wave] + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
-				if (nxt >= 64 && nxt + 1100 < lim)
-					sink = reinterpret_cast<const float *>(a.iq + nxt - 64)[lane * 32];
-			}
-			const RxIo io = {s_off, s_kind, s_fs, &s_l2[cb][0][0], s_crc[cb], s_conv[cb], s_rv[cb], nullptr,
+			// (the window of the next round's burst in this slot -- eight frames on, give or take the feedback -- is asked
+			// for inside the body as soon as this burst's is dead: LatPre)
+			const RxIo io = {
+#ifdef GMR1_HIP_PROFILE
+			                 (chain == 0 && round == kStampRound && wave == n - 1) ? g_stamp : nullptr,
+#endif
+			                 s_off, s_kind, s_fs, &s_l2[cb][0][0], s_crc[cb], s_conv[cb], s_rv[cb], nullptr,
 			                 s_toa[cb], s_fe[cb], s_en[cb], nullptr, nullptr};
-			rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane);
-			if (sink == 1.2345678e-30f)
-				s_fs[wave] = 0.f;                  // keeps the touch alive
+			rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane,
+			                                            &pre);
 		}
 		__syncthreads();
 	}
@@ -2862,6 +2942,13 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 		return launch_rx_t<32, 4>(a, decode, max_in_len, max_len, stream);
 	return launch_rx_t<32, 0>(a, decode, max_in_len, max_len, stream);
 }
+
+#ifdef GMR1_HIP_PROFILE
+extern "C" int gmr1_hip_prof_stamps(unsigned long long *out16)
+{
+	return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) == hipSuccess ? 0 : -5;
+}
+#endif
 
 hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream)
 {
