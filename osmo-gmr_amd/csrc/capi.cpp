@@ -3,6 +3,7 @@
 // step is a HIP kernel (rx_kernels.hip).  There is no CPU fallback: without a
 // HIP device every call returns -ENODEV.
 #include <cerrno>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -639,11 +640,20 @@ int rx_base_args(int sps, const float *iq, RxArgs *out, int min_sps = 4)
 	const int ty[2] = {GMR1_HIP_BCCH, GMR1_HIP_DC6};
 	a.stage_samples = 0;
 	// the fused kernels unroll the sync correlation for these two formats (corr_fixed, rx_kernels.hip)
+	// ... and carry both formats' geometry and training symbols as constants (Fmt<false>, rx_kernels.hip; nb.c:36-62, 94-120)
 	static const int kTaps[2][3] = {{11, 3, 3}, {7, 3, 3}};
+	static const int kPos[3] = {28, 119, 197};
+	static const uint8_t kSyms[2][17] = {{0, 2, 2, 0, 0, 0, 2, 0, 2, 2, 2, 2, 2, 0, 2, 2, 0}, {0, 0, 0, 2, 2, 0, 2, 0, 3, 0, 3, 1, 1}};
 	for (int k = 0; k < 2; k++) {
 		const DevBurst &bt = g_host_types[ty[k]];
-		if (bt.n_sync != 1 || bt.n_chunks[0] != 3 || bt.sync[0][0].len != kTaps[k][0] ||
-		    bt.sync[0][1].len != kTaps[k][1] || bt.sync[0][2].len != kTaps[k][2])
+		bool ok = bt.n_sync == 1 && bt.n_chunks[0] == 3 && bt.len == 234 && bt.nbits == 2 && bt.rotation == (float)M_PI / 4.0f &&
+		          bt.sync_tl[0] == kTaps[k][0] + 6;
+		for (int c = 0, n = 0; ok && c < 3; c++) {
+			ok = bt.sync[0][c].len == kTaps[k][c] && bt.sync[0][c].pos == kPos[c];
+			for (int j = 0; ok && j < kTaps[k][c]; j++, n++)
+				ok = bt.sync[0][c].syms[j] == kSyms[k][n];
+		}
+		if (!ok)
 			return fail(-EINVAL, "rx_bcch_ccch: burst table %d does not have the training layout the kernel is built for", ty[k]);
 		const int w = a.in_len[k] - bt.len * sps + 1;
 		int tot = 0;

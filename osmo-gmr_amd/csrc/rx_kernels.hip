@@ -1642,6 +1642,36 @@ struct RxIo {
 	float *ssyms;
 };
 
+// Burst-format parameters as the body reads them.  GEN (any one format per launch): the descriptor table.  The fused BCCH /
+// DC6 path: the two formats' numbers themselves (nb.c:36-62, 94-120) -- one sync chunk of 11 / 7 symbols at 28, two of 3
+// at 119 and 197, 234 pi/4-CQPSK symbols --, so that no phase waits for a table entry (a per-row descriptor lookup is a
+// vector load from constant memory: three dependent ones sat in front of the sync-symbol terms); the host refuses to start
+// the fused kernels unless the tables say exactly this (fused_formats_match, capi.cpp).
+constexpr unsigned long long kFusedSymsBcch =      // [0 2 2 0 0 0 2 0 2 2 2 | 2 2 0 | 2 2 0], two bits each, first symbol lowest
+	0ull | 2ull << 2 | 2ull << 4 | 0ull << 6 | 0ull << 8 | 0ull << 10 | 2ull << 12 | 0ull << 14 | 2ull << 16 | 2ull << 18 | 2ull << 20 |
+	2ull << 22 | 2ull << 24 | 0ull << 26 | 2ull << 28 | 2ull << 30 | 0ull << 32;
+constexpr unsigned long long kFusedSymsDc6 =       // [0 0 0 2 2 0 2 | 0 3 0 | 3 1 1]
+	0ull | 0ull << 2 | 0ull << 4 | 2ull << 6 | 2ull << 8 | 0ull << 10 | 2ull << 12 |
+	0ull << 14 | 3ull << 16 | 0ull << 18 | 3ull << 20 | 1ull << 22 | 1ull << 24;
+template <bool GEN>
+struct Fmt {
+	static __device__ __forceinline__ int len(const DevBurst &b) { return GEN ? b.len : 234; }
+	static __device__ __forceinline__ int nbits(const DevBurst &b) { return GEN ? b.nbits : 2; }
+	static __device__ __forceinline__ float rotation(const DevBurst &b) { return GEN ? b.rotation : kPif / 4.0f; }
+	static __device__ __forceinline__ int tl(const DevBurst &b, int kind) { return GEN ? b.sync_tl[0] : (kind ? 13 : 17); }
+	static __device__ __forceinline__ int nch(const DevBurst &b) { return GEN ? b.n_chunks[0] : 3; }
+	static __device__ __forceinline__ int clen(const DevBurst &b, int kind, int c) { return GEN ? b.sync[0][c].len : (c == 0 ? (kind ? 7 : 11) : 3); }
+	static __device__ __forceinline__ int cpos(const DevBurst &b, int c) { return GEN ? b.sync[0][c].pos : (c == 0 ? 28 : (c == 1 ? 119 : 197)); }
+	// training symbol n (counted through the chunks) of the first sequence; GEN: symbol nn of chunk ch of sequence sq
+	static __device__ __forceinline__ int sym(const DevBurst &b, int kind, int sq, int ch, int nn, int n)
+	{
+		if constexpr (GEN)
+			return b.sync[sq][ch].syms[nn];
+		else
+			return (int)(((kind ? kFusedSymsDc6 : kFusedSymsBcch) >> (2 * n)) & 3ull);
+	}
+};
+
 // What a wave of the receive loop carries from one round into the next (LAT): the window -- and, again, the samples under
 // the sync chunks -- of the burst it will most likely be given next, eight frames on, asked for as soon as the current
 // burst's copies are dead.  They travel during the rest of the burst, the barrier and the chain's book-keeping; a round
@@ -1826,13 +1856,14 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int type = GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
 		const DevBurst &bt = c_types[type];
-		const int w = in_len - bt.len * sps + 1;
+		typedef Fmt<GEN> F;
+		const int w = in_len - F::len(bt) * sps + 1;
 		const float fsh = io.freq_shift ? io.freq_shift[g] : 0.0f;
-		const float fs = (fsh - bt.rotation) / (float)sps;
+		const float fs = (fsh - F::rotation(bt)) / (float)sps;
 
 		const float2 *__restrict__ in = a.iq + io.offset[g];
-		const int tl = bt.sync_tl[0];
-		const int nch = bt.n_chunks[0];
+		const int tl = F::tl(bt, kind);
+		const int nch = F::nch(bt);
 		constexpr int NFULL = (!GEN && SPS == 4 && NPL == 16) ? 15 : -1;
 		// everything that needs memory is asked for first -- the whole window (statistics) and, again,
 		// the ~300 samples under the sync chunks (they go to LDS; the second request hits the lines the
@@ -1845,8 +1876,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			window_fetch<NPL, NFULL>(from, in_len, lane, wv);
 #pragma unroll
 			for (int c = 0; c < NCHK; c++) {
-				const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
-				const float2 *__restrict__ src = from + (c < nch ? bt.sync[0][c].pos * sps : 0);
+				const int wl = c < nch ? F::clen(bt, kind, c) * sps + w - 1 : 0;
+				const float2 *__restrict__ src = from + (c < nch ? F::cpos(bt, c) * sps : 0);
 #pragma unroll
 				for (int h = 0; h < SIT; h++) {
 					const int sidx = lane + 64 * h;
@@ -1863,8 +1894,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				window_fetch<NPL, NFULL>(in, in_len, lane, wv);
 #pragma unroll
 			for (int c = 0; c < NCHK; c++) {
-				const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
-				const float2 *__restrict__ src = in + (c < nch ? bt.sync[0][c].pos * sps : 0);
+				const int wl = c < nch ? F::clen(bt, kind, c) * sps + w - 1 : 0;
+				const float2 *__restrict__ src = in + (c < nch ? F::cpos(bt, c) * sps : 0);
 #pragma unroll
 				for (int h = 0; h < SIT; h++) {
 					const int sidx = lane + 64 * h;
@@ -1914,7 +1945,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			int wb = 0;
 #pragma unroll
 			for (int c = 0; c < NCHK; c++) {
-				const int wl = c < nch ? bt.sync[0][c].len * sps + w - 1 : 0;
+				const int wl = c < nch ? F::clen(bt, kind, c) * sps + w - 1 : 0;
 #pragma unroll
 				for (int h = 0; h < SIT; h++) {
 					const int sidx = lane + 64 * h;
@@ -1972,7 +2003,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			float cj = 0.f;
 			int base = 0, wb = 0;
 			for (int ch = 0; ch < nch; ch++) {
-				const int len = bt.sync[0][ch].len;
+				const int len = F::clen(bt, kind, ch);
 				const float2 *xp = L.x + wb + j;          // staged window of this chunk
 				const float2 *cp = L.coef + base;
 				// (ar, ai) += c x as two packed FMAs: (-c.im x.im, c.im x.re) first, then c.re (x.re, x.im) -- the order the
@@ -2000,11 +2031,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// per-row (lane-resident) burst parameters: looked up here, not before pass 1, which has no register to spare for them
 	const int kind_r = (!GEN && row_live) ? (io.kind[g_row] ? 1 : 0) : 0;
 	const int type_r = GEN ? a.fixed_type : (kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
-	const int in_len_r = a.in_len[kind_r];
+	typedef Fmt<GEN> F;
+	const int in_len_r = kind_r ? a.in_len[1] : a.in_len[0];
 	const float fsh_r = (row_live && io.freq_shift) ? io.freq_shift[g_row] : 0.0f;
 	const DevBurst &bt_r = c_types[type_r];
-	const float fs_r = (fsh_r - bt_r.rotation) / (float)sps;     // pi4cxpsk.c:539
-	const int w_r = in_len_r - bt_r.len * sps + 1;
+	const float fs_r = (fsh_r - F::rotation(bt_r)) / (float)sps;     // pi4cxpsk.c:539
+	const int w_r = in_len_r - F::len(bt_r) * sps + 1;
 	const float2 *__restrict__ in_r = a.iq + (row_live ? io.offset[g_row] : 0);
 
 	// =========================== rows: peak + early/late timing ===========================
@@ -2012,7 +2044,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// LAT: the one burst is row 0's; the other rows work on ITS correlation (speculative bisection below)
 	const float *cr = L.corr + (LAT ? 0 : row) * cw;          // FAC: moved to the second array for the second sequence
 	const int w_p = LAT ? __builtin_amdgcn_readlane(w_r, 0) : w_r;
-	const int tl_p = LAT ? c_types[__builtin_amdgcn_readlane(type_r, 0)].sync_tl[0] : bt_r.sync_tl[0];
+	const int tl_p = LAT ? F::tl(c_types[__builtin_amdgcn_readlane(type_r, 0)], __builtin_amdgcn_readlane(kind_r, 0)) : F::tl(bt_r, kind_r);
 	const int win = w_p < 3 ? w_p : 3;
 	float toa_r = 0.f, p_pwr = 0.f;                    // pi4cxpsk.c:227-237: the best sequence so far
 	int sid_r = -1;
@@ -2168,7 +2200,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int in_len = __builtin_amdgcn_readlane(in_len_r, src);
 		const int d = __builtin_amdgcn_readlane(d_r, src);
 		const float2 *__restrict__ in = a.iq + io.offset[g];
-		const int blen = bt.len;
+		const int blen = F::len(bt);
 #pragma unroll
 		for (int r = 0; r < NSYM; r++) {
 			const int i = lane + 64 * r;
@@ -2185,9 +2217,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	Sym4 first, second;
 
 	// =========================== rows: sync symbols, frequency, phase ===========================
-	const int nbits_r = bt_r.nbits;
-	const int nch_r = bt_r.n_chunks[0];
-	const int tl_r = bt_r.sync_tl[0];
+	const int nbits_r = F::nbits(bt_r);
+	const int nch_r = F::nch(bt_r);
+	const int tl_r = F::tl(bt_r, kind_r);
 	float ffe_r = 0.f, psi_r = 0.f;
 	{
 		// lane col holds sync symbols n = col and n = col + 16 (< tl <= 32); their samples are asked for first (loads
@@ -2203,11 +2235,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (n < tl_r && row_live) {
 				int ch = 0, base = 0, cum = 0, wb = 0;
 				for (int c = 0; c < nch_r - 1; c++) {
-					cum += bt_r.sync[0][c].len;
-					if (n >= cum) { base = cum; ch = c + 1; wb += bt_r.sync[0][c].len * sps + w_r - 1; }
+					cum += F::clen(bt_r, kind_r, c);
+					if (n >= cum) { base = cum; ch = c + 1; wb += F::clen(bt_r, kind_r, c) * sps + w_r - 1; }
 				}
 				const int nn = n - base;
-				const int sp = bt_r.sync[0][ch].pos + nn;
+				const int sp = F::cpos(bt_r, ch) + nn;
 				const int idx = sp * sps + d_r;
 				if (idx >= 0 && idx < in_len_r) {
 					// LAT, the wave's one burst: its sync-chunk windows are still staged (normalised, which no angle
@@ -2234,7 +2266,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				float s, c;
 				sincos_fast(fs_r * (float)idx, s, c);
 				x = cmul(x, make_float2(c, s));
-				t0[h] = conj_ref_mul(nbits_r, bt_r.sync[FAC ? (sid_r > 0 ? 1 : 0) : 0][ch].syms[nn], x);
+				t0[h] = conj_ref_mul(nbits_r, F::sym(bt_r, kind_r, FAC ? (sid_r > 0 ? 1 : 0) : 0, ch, nn, col + 16 * h), x);
 				chn[h] = ch;
 				spos[h] = sp;
 			}
@@ -2253,8 +2285,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 #pragma unroll
 			for (int i = 1; i < 4; i++) {
 				if (i < nch_r) {
-					const float ppos = (float)bt_r.sync[0][i - 1].pos + (float)bt_r.sync[0][i - 1].len / 2.0f;
-					const float cpos = (float)bt_r.sync[0][i].pos + (float)bt_r.sync[0][i].len / 2.0f;
+					const float ppos = (float)F::cpos(bt_r, i - 1) + (float)F::clen(bt_r, kind_r, i - 1) / 2.0f;
+					const float cpos = (float)F::cpos(bt_r, i) + (float)F::clen(bt_r, kind_r, i) / 2.0f;
 					const float re = sumr[i] * sumr[i - 1] - sumi[i] * (-sumi[i - 1]);
 					const float im = sumr[i] * (-sumi[i - 1]) + sumi[i] * sumr[i - 1];
 					f += atan2_fast(im, re) / (cpos - ppos);
@@ -2320,7 +2352,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const float rps = -lane_val(ffe_r, src);
 		const float psi = lane_val(psi_r, src);
 		const float avr = lane_val(avr_r, src), avi = lane_val(avi_r, src);
-		const int blen = bt.len, nbits = bt.nbits;
+		const int blen = F::len(bt), nbits = F::nbits(bt);
 		float *gss = io.ssyms ? io.ssyms + (size_t)g * a.ssyms_stride : nullptr;
 		int8_t *eb = L.eb + q * 432;
 		row_chain |= kind << q;
