@@ -1175,8 +1175,9 @@ __constant__ DecTable c_dec = make_dec();
 	             : [rn] "+v"(R[J]), [qn] "+v"(Q[J])                                                  \
 	             : [ao] "v"(ao[PH]), [ap] "v"(ap[PH]), [off] "i"(4 * (K)))
 
+struct DecPre;
 __device__ __forceinline__ void k5_12_survivors_crc(uint64_t *__restrict__ surv, uint32_t *__restrict__ ubits, int lane,
-                                                    uint32_t &syn_o);
+                                                    uint32_t &syn_o, const DecPre *dp = nullptr);
 
 // bm: 4 rows x 212 words; surv: 13 x 64 halfwords of window decisions; ubits: 4 rows x 8 words
 // (decoded bits, LSB first)
@@ -1185,15 +1186,18 @@ __device__ __forceinline__ void k5_12_survivors_crc(uint64_t *__restrict__ surv,
 // c_cost_acc): every start state is allowed, state 0 leading by 127 * N * K; the four flush steps are ordinary
 // butterflies (the survivor walk still starts in state 0); no path metric is returned.  Ties between the two paths into
 // a state fall to the same (lower) predecessor in both decoders.
+struct DecPre { uint32_t dc; uint4 sy0, sy1; };     // the decoder's per-lane constants, when the caller keeps them (receive loop)
+
 template <bool ACC = false>
 __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restrict__ surv,
-                              uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae)
+                              uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae,
+                              const DecPre *dp = nullptr)
 {
 	typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
 	const int row = lane >> 4;
 	const uint32_t loc = (uint32_t)lane & 15u;
 	// per-location constants (c_dec): cost byte of the own / partner transition per phase, tb pattern
-	const uint32_t dc = c_dec.v[loc];
+	const uint32_t dc = dp ? dp->dc : c_dec.v[loc];
 	const uint32_t row_base = (uint32_t)(uintptr_t)(lds_cbyte *)(bm + row * kSteps12);
 	uint32_t ao[4], ap[4];      // LDS byte address of this lane's own / partner cost in step 0 of the phase
 	bool hi[4];
@@ -1262,18 +1266,18 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 	dump[12 * 64] = (uint16_t)w;
 	// state 0 ends in location 0 of the row; osmo_conv_decode_acc returns 0, not a metric
 	final_ae = ACC ? 0u : w >> 16;
-	k5_12_survivors_crc(surv, ubits, lane, syn_o);
+	k5_12_survivors_crc(surv, ubits, lane, syn_o, dp);
 }
 
 // second half of the decoder: survivor chain and CRC16 of the four rows (shared with the 16-bit-lane forward pass below)
 __device__ __forceinline__ void k5_12_survivors_crc(uint64_t *__restrict__ surv, uint32_t *__restrict__ ubits, int lane,
-                                                    uint32_t &syn_o)
+                                                    uint32_t &syn_o, const DecPre *dp)
 {
 	const int row = lane >> 4;
 	const uint32_t loc = (uint32_t)lane & 15u;
 	// this lane's CRC syndrome words travel while the survivor chain is walked
-	const uint4 sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][0]);
-	const uint4 sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][4]);
+	const uint4 sy0 = dp ? dp->sy0 : *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][0]);
+	const uint4 sy1 = dp ? dp->sy1 : *reinterpret_cast<const uint4 *>(&c_syn_rows.w[loc][4]);
 	WSYNC();
 
 	// survivor chain, one lane per row: window m's decisions at the survivor's location are the
@@ -1684,6 +1688,15 @@ struct LatPre {
 	uint64_t off = ~0ull;      // first sample of the window held (~0: none)
 	uint64_t lim = 0;          // end of the chain's capture: nothing is asked for beyond it
 	int kind = -1;
+	// What every burst reads from constant tables, kept where a wave of the loop gets at it in an LDS access instead of a
+	// trip to the L2 (each of these sat at the head of a phase of every burst of every round): the soft-bit table, the
+	// trellis-step descriptors and the cost words of the branch metrics (work-group copies), the decoder's per-lane
+	// constants and CRC syndrome words (registers).
+	const unsigned char *lut = nullptr;
+	const uint32_t *steps = nullptr;       // [2][kSteps12]
+	const uint32_t *cost_a = nullptr, *cost_b = nullptr;   // [512] each
+	uint32_t dc = 0;
+	uint4 sy0, sy1;
 };
 
 // LAT: the caller cares about the latency of ONE burst (the receive loop), not about throughput
@@ -1911,7 +1924,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (lane < 32)
 				cfl = g_coef0[sps][type][lane];
 		} else if (lane < tl) {
-			cfl = sync_coef0(bt, lane, sps, fs);
+			if constexpr (GEN) {
+				cfl = sync_coef0(bt, lane, sps, fs);
+			} else {
+				// the same with the fused formats' numbers (Fmt<false>): no table walk
+				const int l0 = kind ? 7 : 11;
+				const int nn = lane < l0 ? lane : (lane < l0 + 3 ? lane - l0 : lane - l0 - 3);
+				float sn, cs;
+				sincos_fast(fs * (float)(nn * sps), sn, cs);
+				cfl = conj_ref_mul(2, F::sym(bt, kind, 0, 0, 0, lane), make_float2(cs, sn));
+			}
 		}
 		WSYNC();
 		if constexpr (FAC) {
@@ -2083,6 +2105,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				if (e > pe) { pe = e; p = mi + k; }
 			}
 		}
+		GMR1_STAMP(8);
 		// interpolated correlation at `pos` (lanes 0-7 of the row) and at `pos + 2` (lanes 8-15): same
 		// fractional part, so the same 21 weights; lane sub = col & 7 holds taps k = 3 sub - 10 + {0,1,2}
 		const int ipt = col >> 3, isub = col & 7;
@@ -2117,44 +2140,78 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		bool active = true;
 		float toa_s, pk_s;
 		if constexpr (LAT) {
-			// Two levels of the bisection per evaluation: row 0 evaluates the current point, rows 1 / 2 the points
-			// the search moves to if the early / the late side wins -- the same instructions on the same
-			// operands as the level-by-level walk, so the same decisions.
-			auto decide = [](float se, float sl) { const float ee = se * se, le = sl * sl; return ee > le ? -1 : (ee < le ? 1 : 0); };
-	#pragma unroll 1
-			for (int it = 0; it < 8; it += 2) {       // levels it, it + 1
-				const float pos = row == 1 ? early - incr : (row == 2 ? early + incr : early);
-				float se, sl;
-				interp2(pos, se, sl);
-				const int dec = decide(se, sl);
-				const int d0 = __builtin_amdgcn_readlane(dec, 0), d1 = __builtin_amdgcn_readlane(dec, 16),
-				          d2 = __builtin_amdgcn_readlane(dec, 32);
-				if (active) {
-					if (d0 == 0) {
-						active = false;
-					} else {
-						early = d0 < 0 ? early - incr : early + incr;
-						const int dn = d0 < 0 ? d1 : d2;
-						const float half = incr * 0.5f;
-						if (dn == 0)
-							active = false;
-						else
-							early = dn < 0 ? early - half : early + half;
-					}
+			// THREE levels of the bisection per evaluation (the eight groups of 8 lanes each interpolate the correlation at one
+			// candidate position and two samples later -- same fractional part, same 21 weights, lane sub holding taps
+			// k = 3 sub - 10 + {0,1,2}): group 0 at the current point, groups 1 / 2 where the search goes if the early / the
+			// late side wins, groups 3..6 one level further down.  The candidates are formed by the float operations the
+			// level-by-level walk performs and summed in its order, so the decisions are its decisions; the walk itself is
+			// scalar work on two ballots.  Nine levels = three evaluations, then the peak value at the point reached.
+			const int grp = lane >> 3, isub8 = lane & 7;
+			auto interp_pair = [&](float pos, float &se, float &sl) {
+				const float fl = floorf(pos);
+				const int ib = (int)fl;
+				const float f = pos - fl;
+				const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
+				int be = ib - 10, ee = ib + 11, bl = ib - 8, el = ib + 13;
+				if (be < 0) be = 0;
+				if (bl < 0) bl = 0;
+				if (ee >= w_p) ee = w_p - 1;
+				if (el >= w_p) el = w_p - 1;
+				float ae = 0.f, al = 0.f;
+	#pragma unroll
+				for (int tt = 0; tt < 3; tt++) {
+					const int k = 3 * isub8 - 10 + tt;
+					const float sg = ((isub8 + tt) & 1) ? S : -S;
+					const float xx = kPif * ((float)k - f);
+					const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
+					const int ie = ib + k, il = ib + 2 + k;
+					const bool ve = k <= 10 && ie >= be && ie < ee;
+					const bool vl = k <= 10 && il >= bl && il < el;
+					const float ce = cr[ve ? ie : 0], cl = cr[vl ? il : 0];
+					ae += ve ? ce * wgt : 0.0f;
+					al += vl ? cl * wgt : 0.0f;
 				}
-				incr *= 0.25f;
-			}
-			// level 8 on row 0; rows 1 / 2 / 3 already evaluate the peak at the three places it can end
-			{
-				const float pos = row == 0 ? early : (row == 1 ? early - incr : (row == 2 ? early + incr : early)) + 1.0f;
+				ae += row_xorf<1>(ae);
+				ae += row_xorf<2>(ae);
+				ae += row_xorf<4>(ae);
+				al += row_xorf<1>(al);
+				al += row_xorf<2>(al);
+				al += row_xorf<4>(al);
+				se = ae;
+				sl = al;
+			};
+	#pragma unroll 1
+			for (int it = 0; it < 3; it++) {
+				const float half = incr * 0.5f, quarter = incr * 0.25f;
+				float pos = early;
+				if (grp == 1) {
+					pos = early - incr;
+				} else if (grp == 2) {
+					pos = early + incr;
+				} else if (grp >= 3 && grp <= 6) {
+					const float a1 = grp < 5 ? early - incr : early + incr;
+					pos = (grp & 1) ? a1 - half : a1 + half;           // 3: - -, 4: - +, 5: + -, 6: + +
+				}
 				float se, sl;
-				interp2(pos, se, sl);
-				const int d0 = active ? __builtin_amdgcn_readlane(decide(se, sl), 0) : 0;
-				const float p1 = lane_val(se, 16), p2 = lane_val(se, 32), p3 = lane_val(se, 48);
-				early = d0 < 0 ? early - incr : (d0 > 0 ? early + incr : early);
-				pk_s = d0 < 0 ? p1 : (d0 > 0 ? p2 : p3);
-				toa_s = early + 1.0f;
+				interp_pair(pos, se, sl);
+				const float ee = se * se, le = sl * sl;
+				const unsigned long long m_neg = __ballot(ee > le), m_pos = __ballot(ee < le);
+				auto dec = [&](int gq) -> int { return ((m_neg >> (8 * gq)) & 1ull) ? -1 : (((m_pos >> (8 * gq)) & 1ull) ? 1 : 0); };
+				const int d0 = dec(0);
+				if (d0 == 0) break;
+				early = d0 < 0 ? early - incr : early + incr;
+				const int d1 = dec(d0 < 0 ? 1 : 2);
+				if (d1 == 0) break;
+				early = d1 < 0 ? early - half : early + half;
+				const int d2 = dec(3 + (d0 > 0 ? 2 : 0) + (d1 > 0 ? 1 : 0));
+				if (d2 == 0) break;
+				early = d2 < 0 ? early - quarter : early + quarter;
+				incr *= 0.125f;
 			}
+			toa_s = early + 1.0f;
+			GMR1_STAMP(9);
+			float dummy;
+			interp2(toa_s, pk_s, dummy);
 		} else {
 	#pragma unroll 1
 			for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
@@ -2324,14 +2381,20 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// =========================== pass 2: soft symbols / soft bits ===========================
 	// the soft-bit table overlays the pass-1 data (fused: where the branch metrics go after pass 2; demodulation
 	// only: behind the soft-bit rows, which themselves overlay the correlation the rows above were reading)
-	unsigned char *const lut = lds_raw + (GEN ? 4 * 432 : 0);
-	// the soft-bit table (2 KB, L2-resident) goes to LDS now that the rows are done with the pass-1 data it overlays
-	const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(FAC ? g_sb_lut1.v : g_sb_lut.v);
-	const uint4 lut_a = lut_src[lane], lut_b = lut_src[lane + 64];
-	WSYNC();
-	reinterpret_cast<uint4 *>(lut)[lane] = lut_a;
-	reinterpret_cast<uint4 *>(lut)[lane + 64] = lut_b;
-	WSYNC();
+	const unsigned char *lut = lds_raw + (GEN ? 4 * 432 : 0);
+	if constexpr (LAT) {
+		lut = pre->lut;                             // the work-group's resident copy
+		WSYNC();
+	} else {
+		// the soft-bit table (2 KB, L2-resident) goes to LDS now that the rows are done with the pass-1 data it overlays
+		unsigned char *const lutw = lds_raw + (GEN ? 4 * 432 : 0);
+		const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(FAC ? g_sb_lut1.v : g_sb_lut.v);
+		const uint4 lut_a = lut_src[lane], lut_b = lut_src[lane + 64];
+		WSYNC();
+		reinterpret_cast<uint4 *>(lutw)[lane] = lut_a;
+		reinterpret_cast<uint4 *>(lutw)[lane + 64] = lut_b;
+		WSYNC();
+	}
 	int row_ok = 0, row_chain = 0;
 	Sym4 nxt1 = first, nxt2 = second;
 #pragma unroll
@@ -2424,13 +2487,31 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 
 	// =========================== rows: layer 1 ===========================
 	WSYNC();     // the window is dead: bm / surv / ubits overlay it
-	branch_metrics4_k5_12<ACC>(L.eb, 432, row_ok, row_chain, L.bm, lane);
+	DecPre dpre;
+	if constexpr (LAT) {
+		// one burst (row 0; what the other rows decode is never looked at), tables from the work-group's LDS copies
+		const int chain = row_chain & 1;
+		const bool ok = (row_ok & 1) != 0;
+#pragma unroll
+		for (int it = 0; it < 4; it++) {
+			const int k = lane + 64 * it;
+			if (k < kSteps12) {
+				const uint32_t stw = pre->steps[chain * kSteps12 + k];
+				const uint32_t ia = (uint32_t)(uint8_t)L.eb[stw & 0x3ffu] | ((stw >> 2) & 0x100u);
+				const uint32_t ib = (uint32_t)(uint8_t)L.eb[(stw >> 16) & 0x3ffu] | ((stw >> 18) & 0x100u);
+				L.bm[k] = ok ? pre->cost_a[ia] + pre->cost_b[ib] : 0u;
+			}
+		}
+		dpre.dc = pre->dc; dpre.sy0 = pre->sy0; dpre.sy1 = pre->sy1;
+	} else {
+		branch_metrics4_k5_12<ACC>(L.eb, 432, row_ok, row_chain, L.bm, lane);
+	}
 	WSYNC();
 	GMR1_STAMP(6);
 	if (a.dbg_stop == 7)
 		return;
 	uint32_t syn, fae;
-	decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae);
+	decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae, LAT ? &dpre : nullptr);
 	GMR1_STAMP(7);
 	if (col == 0 && row_live) {
 		if ((row_ok >> row) & 1) {
@@ -2584,8 +2665,30 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 			rx_loop_advance(st, sps);
 		}
 	};
+	// work-group copies of the constant tables every burst reads (see LatPre)
+	__shared__ __align__(16) uint16_t s_lut[1024];
+	__shared__ uint32_t s_steps[2 * kSteps12];
+	__shared__ uint32_t s_cost_a[512], s_cost_b[512];
+	{
+		const CostTable &ctab = ACC ? c_cost_acc : c_cost;
+		for (int i = (int)threadIdx.x; i < 1024; i += 64 * kLoopPerRound)
+			s_lut[i] = g_sb_lut.v[i];
+		for (int i = (int)threadIdx.x; i < 2 * kSteps12; i += 64 * kLoopPerRound)
+			s_steps[i] = c_steps.w[i / kSteps12][i % kSteps12];
+		for (int i = (int)threadIdx.x; i < 512; i += 64 * kLoopPerRound) {
+			s_cost_a[i] = ctab.a[i];
+			s_cost_b[i] = ctab.b[i];
+		}
+	}
 	LatPre<NPL, SPS> pre;
 	pre.lim = lim;
+	pre.lut = reinterpret_cast<const unsigned char *>(s_lut);
+	pre.steps = s_steps;
+	pre.cost_a = s_cost_a;
+	pre.cost_b = s_cost_b;
+	pre.dc = c_dec.v[lane & 15];
+	pre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
+	pre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
 	int round = 0;
 	for (; round < la.max_rounds; round++) {
 		const int cb = round & 1, pb = cb ^ 1;

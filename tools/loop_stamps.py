@@ -39,3 +39,5 @@ names = ["start", "window loaded + statistics", "staging + correlation", "peak +
 print("cycles since the burst started (shader clock), and per phase:")
 for k in range(1, 8):
     print(f"  {names[k]:34s} {t[k] - t[0]:8d}  (+{t[k] - t[k - 1]})")
+print(f"  inside the timing phase: coarse peak found at {t[8] - t[0]} (+{t[8] - t[2]}), nine halvings done at {t[9] - t[0]} (+{t[9] - t[8]}), "
+      f"peak value + bookkeeping +{t[3] - t[9]}")
