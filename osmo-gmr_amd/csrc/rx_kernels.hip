@@ -1178,6 +1178,8 @@ __constant__ DecTable c_dec = make_dec();
 struct DecPre;
 __device__ __forceinline__ void k5_12_survivors_crc(uint64_t *__restrict__ surv, uint32_t *__restrict__ ubits, int lane,
                                                     uint32_t &syn_o, const DecPre *dp = nullptr);
+__device__ __forceinline__ void k5_12_survivors_crc_lat(uint64_t *__restrict__ surv, uint32_t *__restrict__ ubits, int lane,
+                                                        uint32_t &syn_o, const DecPre *dp);
 
 // bm: 4 rows x 212 words; surv: 13 x 64 halfwords of window decisions; ubits: 4 rows x 8 words
 // (decoded bits, LSB first)
@@ -1188,7 +1190,7 @@ __device__ __forceinline__ void k5_12_survivors_crc(uint64_t *__restrict__ surv,
 // a state fall to the same (lower) predecessor in both decoders.
 struct DecPre { uint32_t dc; uint4 sy0, sy1; };     // the decoder's per-lane constants, when the caller keeps them (receive loop)
 
-template <bool ACC = false>
+template <bool ACC = false, bool LATW = false>
 __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restrict__ surv,
                               uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae,
                               const DecPre *dp = nullptr)
@@ -1266,7 +1268,67 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 	dump[12 * 64] = (uint16_t)w;
 	// state 0 ends in location 0 of the row; osmo_conv_decode_acc returns 0, not a metric
 	final_ae = ACC ? 0u : w >> 16;
-	k5_12_survivors_crc(surv, ubits, lane, syn_o, dp);
+	if constexpr (LATW)
+		k5_12_survivors_crc_lat(surv, ubits, lane, syn_o, dp);
+	else
+		k5_12_survivors_crc(surv, ubits, lane, syn_o, dp);
+}
+
+// Tail of the decoder shaped for the LATENCY of one burst (the receive loop: one burst per wave, nothing to overlap with):
+// the 13 window words of every location are read at once and the survivor chain is walked with v_readlane on scalars --
+// 13 dependent LDS round trips become one.  Row 0 only; the CRC as in k5_12_survivors_crc.
+__device__ __forceinline__ void k5_12_survivors_crc_lat(uint64_t *__restrict__ surv, uint32_t *__restrict__ ubits, int lane,
+                                                        uint32_t &syn_o, const DecPre *dp)
+{
+	const int row = lane >> 4;
+	const uint32_t loc = (uint32_t)lane & 15u;
+	WSYNC();
+	// survivor chain of row 0: every location's 13 window words at once, then the walk on scalars
+	{
+		constexpr unsigned long long kLocOf =
+			0x0ull | (0x8ull << 4) | (0x7ull << 8) | (0xFull << 12) | (0x2ull << 16) | (0xAull << 20) |
+			(0x5ull << 24) | (0xDull << 28) | (0x1ull << 32) | (0x9ull << 36) | (0x6ull << 40) |
+			(0xEull << 44) | (0x3ull << 48) | (0xBull << 52) | (0x4ull << 56) | (0xCull << 60);
+		const uint16_t *d16 = reinterpret_cast<const uint16_t *>(surv) + loc;      // (rows 1-3 read row 0's words too)
+		uint32_t H[13];
+#pragma unroll
+		for (int m = 0; m < 13; m++)
+			H[m] = d16[m * 64];
+		uint32_t L = 0, hv[13];
+#pragma unroll
+		for (int m = 12; m >= 0; m--) {
+			hv[m] = (uint32_t)__builtin_amdgcn_readlane((int)H[m], (int)L);
+			L = (uint32_t)(kLocOf >> (4 * (hv[m] & 15u))) & 15u;
+		}
+		if (lane == 0) {
+#pragma unroll
+			for (int m = 0; m < 13; m += 2)
+				ubits[m >> 1] = hv[m] | (m == 12 ? 0u : (hv[m + 1] << 16));
+		}
+	}
+	WSYNC();
+	// CRC16 over the 208 decoded bits, 13 bits per lane of the row, XOR-reduced with DPP (as in k5_12_survivors_crc)
+	uint32_t syn = 0;
+	{
+		const uint32_t *ub = ubits + row * 8;
+		const uint32_t k0 = loc * 13u;
+		const uint32_t lo = ub[k0 >> 5], hi2 = ub[(k0 >> 5) + 1];
+		const uint32_t cbits = __builtin_amdgcn_alignbit(hi2, lo, k0 & 31u);
+		const uint32_t sy[7] = {dp->sy0.x, dp->sy0.y, dp->sy0.z, dp->sy0.w, dp->sy1.x, dp->sy1.y, dp->sy1.z};
+		uint32_t acc = 0;
+#pragma unroll
+		for (int pq = 0; pq < 7; pq++) {
+			const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)cbits, 2 * pq, 1);
+			const uint32_t m1 = pq < 6 ? (uint32_t)__builtin_amdgcn_sbfe((int)cbits, 2 * pq + 1, 1) : 0u;
+			acc ^= sy[pq] & ((m0 & 0xffffu) | (m1 & 0xffff0000u));
+		}
+		syn = (acc ^ (acc >> 16)) & 0xffffu;
+		syn ^= row_xor<1>(syn);
+		syn ^= row_xor<2>(syn);
+		syn ^= row_xor<4>(syn);
+		syn ^= row_xor<8>(syn);
+	}
+	syn_o = syn;
 }
 
 // second half of the decoder: survivor chain and CRC16 of the four rows (shared with the 16-bit-lane forward pass below)
@@ -2511,7 +2573,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	if (a.dbg_stop == 7)
 		return;
 	uint32_t syn, fae;
-	decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae, LAT ? &dpre : nullptr);
+	if constexpr (LAT)
+		decode4_k5_12<ACC, true>(L.bm, L.surv, L.ubits, lane, syn, fae, &dpre);
+	else
+		decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae, nullptr);
 	GMR1_STAMP(7);
 	if (col == 0 && row_live) {
 		if ((row_ok >> row) & 1) {
