@@ -417,11 +417,18 @@ int RxRun::frame_loop()
 	const size_t rf_bytes = want_ctx ? up128((size_t)nc * rec_stride * 4) : 0;
 	const size_t fl_bytes = want_ctx ? up128((size_t)nc * max_frames * sizeof(RxLoopFrame)) : 0;
 	const size_t total = rec_bytes + cnt_bytes + st_bytes + 2 * rf_bytes + fl_bytes;
+	// ... and, device only, what passes between the loop's three launches (RxLoopArgs): the round logs, the CCCH lists
+	const int c_stride = (max_frames + 3) & ~3;                // a frame holds at most one burst of the list
+	const size_t nslot = (size_t)nc * c_stride;
+	const size_t rl_bytes = up128((size_t)nc * max_rounds * sizeof(RxLoopRound));
+	const size_t s8 = up128(nslot * 8), s4 = up128(nslot * 4), s1 = up128(nslot), s12 = up128(nslot * sizeof(RxLoopCcch)),
+	             s24 = up128(nslot * 24);
+	const size_t scratch = rl_bytes + up128((size_t)nc * 4) + s8 + s4 + s1 + s12 + s24 + 4 * s4;
 	DevState *ds;
 	r = dev_state(&ds);
 	if (r) return r;
 	void *ws;
-	r = dev_workspace(ds, total + 128, &ws);
+	r = dev_workspace(ds, total + scratch + 128, &ws);
 	if (r) return r;
 	unsigned char *d = reinterpret_cast<unsigned char *>(((uintptr_t)ws + 127) & ~(uintptr_t)127);
 	unsigned char *h;
@@ -443,6 +450,22 @@ int RxRun::frame_loop()
 		la.rec_minen = reinterpret_cast<float *>(d + o_me);
 		la.flog = reinterpret_cast<RxLoopFrame *>(d + o_fl);
 		la.flog_stride = max_frames;
+	}
+	{
+		unsigned char *q = d + total;
+		auto take = [&](size_t bytes) { unsigned char *p = q; q += bytes; return p; };
+		la.rounds = reinterpret_cast<RxLoopRound *>(take(rl_bytes));
+		la.n_ccch = reinterpret_cast<int32_t *>(take(up128((size_t)nc * 4)));
+		la.c_stride = c_stride;
+		la.c_off = reinterpret_cast<uint64_t *>(take(s8));
+		la.c_fs = reinterpret_cast<float *>(take(s4));
+		la.c_kind = reinterpret_cast<uint8_t *>(take(s1));
+		la.c_meta = reinterpret_cast<RxLoopCcch *>(take(s12));
+		la.c_l2 = reinterpret_cast<uint8_t *>(take(s24));
+		la.c_crc = reinterpret_cast<int32_t *>(take(s4));
+		la.c_conv = reinterpret_cast<int32_t *>(take(s4));
+		la.c_rv = reinterpret_cast<int32_t *>(take(s4));
+		la.c_en = reinterpret_cast<float *>(take(s4));
 	}
 	HIP_TRY(hipMemcpyAsync(la.state, st0.data(), (size_t)nc * sizeof(RxLoopState), hipMemcpyHostToDevice, st));
 	r = rx_loop_dev_impl(st, nc, sps, iq, la);

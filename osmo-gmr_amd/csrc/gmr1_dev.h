@@ -54,6 +54,8 @@ struct RxArgs {
 	int impl;              // fused path: 0 = k_rx4 (row-batched serial phases), 1 = k_rx (one burst at a time);
 	                       // demod only: 2 / 3 = k_rx4g (four bursts per wave; 3: its small-format variant), else k_rx
 	int conv_acc;          // fused path: 1 = libosmocore's accelerated Viterbi decoder (GMR1_HIP_CONV_ACC), 0 = its generic one
+	int seg_stride;        // fused path, with seg_count: the bursts are listed in segments of seg_stride slots (a multiple of 4) ...
+	const int32_t *seg_count;   // ... of which the first seg_count[s] are in use (the receive loop's CCCH lists); NULL: all n
 	const float2 *iq;
 	const uint64_t *offset;
 	const uint8_t *kind;
@@ -69,8 +71,22 @@ struct RxArgs {
 	int32_t *sync_id;
 };
 
-// the receive loop of all chains in one launch (k_rx_loop, rx_kernels.hip); `a` carries what every burst
-// shares (iq, sps, window lengths, staging size), the per-burst arrays are the loop's own (LDS)
+// The receive loop of all chains (rx_kernels.hip), three launches:
+//   k_rx_chain  one wavefront per chain walks the feedback chain -- list a round, demodulate and decode its BCCH burst,
+//               apply the result -- and only LISTS the round's CCCH bursts (nothing feeds back from them);
+//   k_rx4       the listed CCCH bursts of all chains, four per wavefront (the burst kernel at its throughput shape);
+//   k_rx_merge  one wavefront per chain writes the records in frame order, exactly as rx_bcch / rx_ccch emit them.
+// `a` carries what every burst shares (iq, sps, window lengths, staging size).
+struct RxLoopRound {               // what a round leaves for k_rx_merge
+	int32_t c_first, c_n;          // its CCCH bursts in the chain's list
+	float minen;                   // the CCCH energy gate level the round started with (gmr1_rx.c:813)
+	int32_t b_emit;                // 1: its BCCH burst was found and passed the CRC (a record)
+	int32_t b_fn, b_tn;            // ... after the SI1 alignment
+	int32_t b_conv, b_frame;
+	uint8_t b_l2[24];
+};
+struct RxLoopCcch { int32_t fn, tn, frame; };    // what a CCCH record needs besides the burst kernel's outputs
+
 struct RxLoopArgs {
 	RxLoopState *state;            // n_chains: starting states in, final states out
 	gmr1_hip_rx_record *rec;       // n_chains x rec_stride records, frame order per chain
@@ -80,6 +96,17 @@ struct RxLoopArgs {
 	int rec_stride, flog_stride;
 	int max_rounds;
 	int32_t *n_rounds, *n_rec, *n_frames;   // n_chains each
+	// between the three launches (device scratch)
+	RxLoopRound *rounds;           // n_chains x max_rounds
+	int c_stride;                  // CCCH list slots per chain (a multiple of 4, >= the frames of the longest chain)
+	int32_t *n_ccch;               // n_chains: bursts listed
+	uint64_t *c_off;               // n_chains x c_stride each: the burst kernel's operands ...
+	float *c_fs;
+	uint8_t *c_kind;
+	RxLoopCcch *c_meta;
+	uint8_t *c_l2;                 // ... and results (x 24)
+	int32_t *c_crc, *c_conv, *c_rv;
+	float *c_en;
 };
 
 struct DetectArgs {

@@ -1684,6 +1684,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 #ifdef GMR1_HIP_PROFILE
 // cycle stamps of ONE burst of the receive loop (chain 0, the BCCH burst of round kStampRound): tools/loop_stamps.py
 __device__ unsigned long long g_stamp[16];
+__device__ int g_prof_flag;              // experiments of the profiling build (gmr1_hip_prof_flag)
 constexpr int kStampRound = 40;
 #define GMR1_STAMP(k)                                                        \
 	do {                                                                    \
@@ -2608,13 +2609,21 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
 	// which shortens the critical path of a wave to a quarter
 	const int g0 = blockIdx.x * bpw;
+	int n_end = min(a.n, g0 + bpw);
+	if (a.seg_count) {
+		// bursts listed in segments with unused slots at each segment's end (the receive loop's CCCH lists)
+		const int sg = g0 / a.seg_stride;
+		n_end = min(n_end, sg * a.seg_stride + a.seg_count[sg]);
+		if (g0 >= n_end)
+			return;
+	}
 	const RxIo io = {
 #ifdef GMR1_HIP_PROFILE
 	                 nullptr,
 #endif
 	                 a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
-	rx4_body<NPL, SPS, false, false, false, ACC>(a, io, stage_samples, cw, g0, min(a.n, g0 + bpw), lds_raw, (int)threadIdx.x);
+	rx4_body<NPL, SPS, false, false, false, ACC>(a, io, stage_samples, cw, g0, n_end, lds_raw, (int)threadIdx.x);
 }
 
 // demodulation only, one burst format per launch, four bursts per wavefront (rx4_body<..., GEN>)
@@ -2633,114 +2642,59 @@ __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw
 }
 
 // ---------------------------------------------------------------------------
-// k_rx_loop -- process_bcch (reference src/gmr1_rx.c:852-895) for one chain per work-group, from its first
-// frame to the end of the capture, without leaving the GPU.  The feedback of the loop only crosses a BCCH
-// frame, so it runs in rounds: wave 0 lists the chain's CCCH bursts up to and including its next BCCH burst
-// (rx_loop_build_round, rx_loop.h), up to eight wavefronts demodulate and decode one burst each (rx4_body,
-// the burst kernel itself), wave 0 applies the BCCH feedback (time, frequency, SI1 TDMA position), lists the next
-// round and, while that one is already running, turns the finished round's results into records exactly as
-// rx_bcch / rx_ccch do (energy gate, CRC).  A round's operands
-// and results never leave LDS; what goes to HBM is what the reference hands to GSMTAP: the 40-byte records, in
-// frame order, plus -- when a traffic pass follows -- the per-frame context rx_tch3 sees.  A round is about
-// one wave's latency instead of launch + kernel + synchronise + host (~59 us).
+// The receive loop -- process_bcch (reference src/gmr1_rx.c:852-895) of every chain, from its first frame to the end of the
+// capture, without leaving the GPU.  The feedback of the loop only crosses a BCCH burst (time, frequency, SI1 TDMA
+// position, gmr1_rx.c:782-791); nothing a CCCH burst yields is read by a later burst.  So the loop runs as
+//
+//   k_rx_chain   one wavefront per chain, ALONE on its SIMD: list the frames up to and including the next BCCH burst
+//                (rx_loop_build_round, rx_loop.h), demodulate and decode that burst (rx4_body, the burst kernel itself, at
+//                its latency shape), apply its result, log the round; the round's CCCH bursts are only listed -- where they
+//                sit, the frequency shift and the energy gate level of the moment.  A round is one burst's latency; with
+//                the CCCH bursts on the same work-group's other waves (the previous form) it was 1.2 x that, the BCCH wave
+//                sharing its SIMD's issue slots with a CCCH wave, and the round waited for the slowest of seven;
+//   k_rx4        the listed CCCH bursts of all chains as one batch, four per wavefront (the throughput shape);
+//   k_rx_merge   one wavefront per chain: the records, in frame order, exactly as rx_bcch / rx_ccch emit them (energy gate
+//                first, then found, then CRC; gmr1_rx.c:746-850).
+//
+// What goes to HBM in between is a few dozen bytes per burst (RxLoopRound, RxLoopCcch, the burst kernel's own outputs).
 // ---------------------------------------------------------------------------
 template <int NPL, int SPS, bool ACC = false>
-__global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoopArgs la, int stage_samples, int cw,
-                                                                int lds_per_wave)
+__global__ __launch_bounds__(64) void k_rx_chain(RxArgs a, RxLoopArgs la, int stage_samples, int cw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
-	// operands of the round's bursts; items and results double-buffered by round parity, so that the records of
-	// round r - 1 can be written while round r is already running
-	__shared__ uint64_t s_off[kLoopPerRound];
-	__shared__ float s_fs[kLoopPerRound];
-	__shared__ uint8_t s_kind[kLoopPerRound];
-	__shared__ RxLoopItem s_items[2][kLoopPerRound];
-	__shared__ __align__(8) uint8_t s_l2[2][kLoopPerRound][24];
-	__shared__ int32_t s_crc[2][kLoopPerRound], s_conv[2][kLoopPerRound], s_rv[2][kLoopPerRound];
-	__shared__ float s_toa[2][kLoopPerRound], s_fe[2][kLoopPerRound], s_en[2][kLoopPerRound];
-	__shared__ int s_n;
+	// operands and results of the round's BCCH burst
+	__shared__ uint64_t s_off[1];
+	__shared__ float s_fs[1];
+	__shared__ uint8_t s_kind[1];
+	__shared__ RxLoopItem s_items[kLoopPerRound];
+	__shared__ __align__(8) uint8_t s_l2[24];
+	__shared__ int32_t s_crc[1], s_conv[1], s_rv[1];
+	__shared__ float s_toa[1], s_fe[1], s_en[1];
 	const int chain = blockIdx.x;
-	const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+	const int lane = (int)threadIdx.x;
 	const int sps = a.sps;
-	RxLoopState st = la.state[chain];          // wave 0 keeps the live copy (all its lanes compute the same)
+	RxLoopState st = la.state[chain];          // every lane computes the same
 	const uint64_t lim = st.base + (uint64_t)st.len;
-	gmr1_hip_rx_record *rec = la.rec + (size_t)chain * la.rec_stride;
-	int32_t *rec_frame = la.rec_frame ? la.rec_frame + (size_t)chain * la.rec_stride : nullptr;
-	float *rec_minen = la.rec_minen ? la.rec_minen + (size_t)chain * la.rec_stride : nullptr;
 	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
-	int n_rec = 0, n_frames = 0;               // records emitted / frames completed so far
-	int prev_n = 0, frames_at_round = 0;
-	// what the deferred record writer of the previous round needs (wave 0)
-	int e_n = 0, e_frames = 0, e_fn = 0, e_tn = 0;
-	bool e_moved = false;
-	float e_minen = 0.f;
+	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
+	const size_t c_base = (size_t)chain * la.c_stride;
+	int n_frames = 0, n_ccch = 0;
 	auto on_frame = [&](const RxLoopState &x) {
 		if (flog && lane == 0 && n_frames < la.flog_stride)
 			flog[n_frames] = {x.align, x.freq_err, x.fn};
 		n_frames++;
 	};
-	// records of a finished round (rx_ccch gmr1_rx.c:800-850, rx_bcch :746-798), compacted in burst order
-	auto write_records = [&](int pb) {
-		const int k = lane < e_n ? lane : 0;
-		const RxLoopItem it = s_items[pb][k];
-		const bool is_b = it.is_bcch != 0;
-		bool emit = false;
-		if (lane < e_n)
-			emit = is_b ? e_moved                                          // found, CRC passed (:782-795)
-			            : (!(s_en[pb][k] < e_minen) && !s_rv[pb][k] && !s_crc[pb][k]);   // energy gate first (:813-816)
-		const unsigned long long mask = __ballot(emit);
-		if (emit) {
-			const int slot = n_rec + __popcll(mask & ((1ull << lane) - 1ull));
-			if (slot < la.rec_stride) {
-				uint32_t *d = reinterpret_cast<uint32_t *>(rec + slot);
-				const uint32_t *l2w = reinterpret_cast<const uint32_t *>(s_l2[pb][k]);
-				d[0] = (uint32_t)st.arfcn | ((uint32_t)st.chain << 16) | ((is_b ? 1u : 2u) << 24);
-				d[1] = (uint32_t)(is_b ? e_fn : it.fn);                    // BCCH: after the SI1 alignment
-				d[2] = ((uint32_t)(is_b ? e_tn : it.tn) & 0xffu) | (24u << 16);     // crc = 0, len = 24
-				d[3] = (uint32_t)s_conv[pb][k];
-#pragma unroll
-				for (int i = 0; i < 6; i++)
-					d[4 + i] = l2w[i];
-				if (rec_frame) {
-					rec_frame[slot] = e_frames + it.frames_before;
-					rec_minen[slot] = e_minen;
-				}
-			}
-		}
-		n_rec += __popcll(mask);
-	};
-	// the finished round's BCCH burst (always its last) feeds back before the next round is listed (wave 0)
-	auto feedback = [&](int pb) {
-		e_n = prev_n;
-		if (!prev_n)
-			return;
-		e_minen = st.bcch_energy / 2.0f;                        // the gate level the round started with
-		e_frames = frames_at_round;
-		e_moved = false;
-		const int kb = prev_n - 1;
-		if (s_items[pb][kb].is_bcch) {
-			if (!s_rv[pb][kb]) {
-				st.bcch_energy = s_en[pb][kb];
-				e_moved = rx_loop_bcch_result(st, sps, s_rv[pb][kb], s_crc[pb][kb], s_toa[pb][kb], s_fe[pb][kb],
-				                              s_l2[pb][kb], s_items[pb][kb].e_toa) != 0;
-			}
-			e_fn = st.fn;
-			e_tn = st.stn;
-			on_frame(st);                                        // rx_tch3 of this frame sees the updated state
-			rx_loop_advance(st, sps);
-		}
-	};
-	// work-group copies of the constant tables every burst reads (see LatPre)
+	// LDS copies of the constant tables every burst reads (see LatPre)
 	__shared__ __align__(16) uint16_t s_lut[1024];
 	__shared__ uint32_t s_steps[2 * kSteps12];
 	__shared__ uint32_t s_cost_a[512], s_cost_b[512];
 	{
 		const CostTable &ctab = ACC ? c_cost_acc : c_cost;
-		for (int i = (int)threadIdx.x; i < 1024; i += 64 * kLoopPerRound)
+		for (int i = lane; i < 1024; i += 64)
 			s_lut[i] = g_sb_lut.v[i];
-		for (int i = (int)threadIdx.x; i < 2 * kSteps12; i += 64 * kLoopPerRound)
+		for (int i = lane; i < 2 * kSteps12; i += 64)
 			s_steps[i] = c_steps.w[i / kSteps12][i % kSteps12];
-		for (int i = (int)threadIdx.x; i < 512; i += 64 * kLoopPerRound) {
+		for (int i = lane; i < 512; i += 64) {
 			s_cost_a[i] = ctab.a[i];
 			s_cost_b[i] = ctab.b[i];
 		}
@@ -2754,89 +2708,187 @@ __global__ __launch_bounds__(64 * kLoopPerRound) void k_rx_loop(RxArgs a, RxLoop
 	pre.dc = c_dec.v[lane & 15];
 	pre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
 	pre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
+	WSYNC();
 	int round = 0;
 	for (; round < la.max_rounds; round++) {
-		const int cb = round & 1, pb = cb ^ 1;
-		if (wave == 0) {
-			feedback(pb);
-			frames_at_round = n_frames;
-			// ---- the next round: what rx_loop_build_round does frame after frame, for the usual case (the next
-			// sixteen frames all lie inside the capture) with one frame per lane
-			int n;
-			{
-				const int frame_len = sps * 24 * 39;
-				const int j = lane & 15;
-				const int fn_j = st.fn + j, align_j = st.align + j * frame_len;
-				const bool inside = !st.done && st.align + 17 * frame_len <= st.len;   // frames 0..15 are all reached
-				const int m = (fn_j - st.delay) & 7;
-				const int tn_off = sps * st.stn * 39;
-				const int b_b = align_j + tn_off - 10 * sps, b_c = align_j + tn_off - 5 * sps;   // burst_map, e_toa = win / 2
-				const bool ok_b = b_b >= 0 && b_b + 234 * sps + 20 * sps <= st.len;
-				const bool ok_c = b_c >= 0 && b_c + 234 * sps + 10 * sps <= st.len;
-				const uint32_t mb = (uint32_t)__ballot(lane < 16 && m == 2 && ok_b) & 0xffffu;
-				const uint32_t mc = (uint32_t)__ballot(lane < 16 && m != 0 && m != 2 && ok_c) & 0xffffu;
-				const int jb = mb ? __builtin_ctz(mb) : 16;             // the first BCCH burst
-				const uint32_t before = mc & ((1u << jb) - 1u);
-				if (inside && mb && __popc(before) < kLoopPerRound - 1) {
-					// CCCH bursts of frames 0 .. jb-1, then the BCCH burst of frame jb (which stays the current frame)
-					const uint32_t items = before | (1u << jb);
-					if (lane < 16 && ((items >> j) & 1u)) {
-						const int idx = __popc(items & ((1u << j) - 1u));
-						const bool is_b = j == jb;
-						s_items[cb][idx] = {is_b ? b_b : b_c, is_b ? 1 : 0, fn_j, st.stn, is_b ? 10 * sps : 5 * sps, j};
-					}
-					if (flog && lane < jb && n_frames + lane < la.flog_stride)
-						flog[n_frames + lane] = {align_j, st.freq_err, fn_j};
-					n_frames += jb;
-					st.fn += jb;
-					st.align += jb * frame_len;
-					n = __popc(items);
-				} else {
-					n = rx_loop_build_round(st, sps, s_items[cb], on_frame);
+		const int frames_at_round = n_frames;
+		const float minen = st.bcch_energy / 2.0f;              // the gate level the round starts with
+		// ---- the round: what rx_loop_build_round does frame after frame, for the usual case (the next sixteen frames all
+		// lie inside the capture) with one frame per lane
+		int n;
+		{
+			const int frame_len = sps * 24 * 39;
+			const int j = lane & 15;
+			const int fn_j = st.fn + j, align_j = st.align + j * frame_len;
+			const bool inside = !st.done && st.align + 17 * frame_len <= st.len;   // frames 0..15 are all reached
+			const int m = (fn_j - st.delay) & 7;
+			const int tn_off = sps * st.stn * 39;
+			const int b_b = align_j + tn_off - 10 * sps, b_c = align_j + tn_off - 5 * sps;   // burst_map, e_toa = win / 2
+			const bool ok_b = b_b >= 0 && b_b + 234 * sps + 20 * sps <= st.len;
+			const bool ok_c = b_c >= 0 && b_c + 234 * sps + 10 * sps <= st.len;
+			const uint32_t mb = (uint32_t)__ballot(lane < 16 && m == 2 && ok_b) & 0xffffu;
+			const uint32_t mc = (uint32_t)__ballot(lane < 16 && m != 0 && m != 2 && ok_c) & 0xffffu;
+			const int jb = mb ? __builtin_ctz(mb) : 16;             // the first BCCH burst
+			const uint32_t before = mc & ((1u << jb) - 1u);
+			if (inside && mb && __popc(before) < kLoopPerRound - 1) {
+				// CCCH bursts of frames 0 .. jb-1, then the BCCH burst of frame jb (which stays the current frame)
+				const uint32_t items = before | (1u << jb);
+				if (lane < 16 && ((items >> j) & 1u)) {
+					const int idx = __popc(items & ((1u << j) - 1u));
+					const bool is_b = j == jb;
+					s_items[idx] = {is_b ? b_b : b_c, is_b ? 1 : 0, fn_j, st.stn, is_b ? 10 * sps : 5 * sps, j};
 				}
+				if (flog && lane < jb && n_frames + lane < la.flog_stride)
+					flog[n_frames + lane] = {align_j, st.freq_err, fn_j};
+				n_frames += jb;
+				st.fn += jb;
+				st.align += jb * frame_len;
+				n = __popc(items);
+			} else {
+				n = rx_loop_build_round(st, sps, s_items, on_frame);
 			}
-			if (lane < n) {
-				s_off[lane] = st.base + (uint64_t)s_items[cb][lane].begin;
-				s_fs[lane] = -st.freq_err;
-				s_kind[lane] = s_items[cb][lane].is_bcch ? 0 : 1;
-			}
-			if (lane == 0)
-				s_n = n;
-			prev_n = n;
 		}
-		__syncthreads();
-		const int n = s_n;
-		if (wave == 0 && e_n)
-			write_records(pb);                     // off the critical path: the round's BCCH burst runs on the last wave
+		WSYNC();
 		if (n == 0)
 			break;
-		if (wave < n) {
-			// (the window of the next round's burst in this slot -- eight frames on, give or take the feedback -- is asked
-			// for inside the body as soon as this burst's is dead: LatPre)
+		const bool has_b = s_items[n - 1].is_bcch != 0;           // always the round's last item
+		const int n_c = has_b ? n - 1 : n;
+		// the CCCH bursts: listed for the batch that follows
+		if (lane < n_c && n_ccch + lane < la.c_stride) {
+			const RxLoopItem it = s_items[lane];
+			const size_t k = c_base + (size_t)(n_ccch + lane);
+			la.c_off[k] = st.base + (uint64_t)it.begin;
+			la.c_fs[k] = -st.freq_err;
+			la.c_kind[k] = 1;
+			la.c_meta[k] = {it.fn, it.tn, frames_at_round + it.frames_before};
+		}
+		int b_emit = 0, b_fn = 0, b_tn = 0, b_frame = 0;
+		if (has_b) {
+			const RxLoopItem it = s_items[n - 1];
+			if (lane == 0) {
+				s_off[0] = st.base + (uint64_t)it.begin;
+				s_fs[0] = -st.freq_err;
+				s_kind[0] = 0;
+			}
+			WSYNC();
+			// (the window of the next round's BCCH burst -- eight frames on, give or take the feedback -- is asked for inside
+			// the body as soon as this burst's is dead: LatPre)
 			const RxIo io = {
 #ifdef GMR1_HIP_PROFILE
-			                 (chain == 0 && round == kStampRound && wave == n - 1) ? g_stamp : nullptr,
+			                 (chain == 0 && round == kStampRound) ? g_stamp : nullptr,
 #endif
-			                 s_off, s_kind, s_fs, &s_l2[cb][0][0], s_crc[cb], s_conv[cb], s_rv[cb], nullptr,
-			                 s_toa[cb], s_fe[cb], s_en[cb], nullptr, nullptr};
-			rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, wave, wave + 1, lds_raw + (size_t)wave * lds_per_wave, lane,
-			                                            &pre);
+			                 s_off, s_kind, s_fs, s_l2, s_crc, s_conv, s_rv, nullptr, s_toa, s_fe, s_en, nullptr, nullptr};
+			rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, 0, 1, lds_raw, lane, &pre);
+			WSYNC();
+			// the BCCH burst feeds back before the next round is listed (rx_bcch, gmr1_rx.c:782-795)
+			b_frame = frames_at_round + it.frames_before;
+			if (!s_rv[0]) {
+				st.bcch_energy = s_en[0];
+				b_emit = rx_loop_bcch_result(st, sps, s_rv[0], s_crc[0], s_toa[0], s_fe[0], s_l2, it.e_toa);
+			}
+			b_fn = st.fn;
+			b_tn = st.stn;
+			on_frame(st);                                        // rx_tch3 of this frame sees the updated state
+			rx_loop_advance(st, sps);
 		}
-		__syncthreads();
+		{
+			// the round's log entry: 14 words
+			uint32_t *d = reinterpret_cast<uint32_t *>(rlog + round);
+			const uint32_t *l2w = reinterpret_cast<const uint32_t *>(s_l2);
+			uint32_t v = 0;
+			switch (lane) {
+			case 0: v = (uint32_t)n_ccch; break;
+			case 1: v = (uint32_t)n_c; break;
+			case 2: v = __float_as_uint(minen); break;
+			case 3: v = (uint32_t)b_emit; break;
+			case 4: v = (uint32_t)b_fn; break;
+			case 5: v = (uint32_t)b_tn; break;
+			case 6: v = has_b ? (uint32_t)s_conv[0] : 0u; break;
+			case 7: v = (uint32_t)b_frame; break;
+			default: v = (has_b && lane < 14) ? l2w[lane - 8] : 0u; break;
+			}
+			if (lane < 14)
+				d[lane] = v;
+		}
+		n_ccch += n_c;
+		WSYNC();
 	}
-	if (round == la.max_rounds && wave == 0 && prev_n) {
-		// the bound on the rounds was reached with a round still pending (never with the host's sizing; the host
-		// reports it as this chain's failure): its feedback and records are not lost
-		const int pb = (round & 1) ^ 1;
-		feedback(pb);
-		write_records(pb);
-	}
-	if (threadIdx.x == 0) {
+	if (lane == 0) {
 		la.n_rounds[chain] = round;
-		la.n_rec[chain] = n_rec;
+		la.n_ccch[chain] = n_ccch;
 		la.n_frames[chain] = n_frames;
 		la.state[chain] = st;
 	}
+}
+
+// records of a chain from its rounds' logs and the CCCH batch's results (rx_ccch gmr1_rx.c:800-850, rx_bcch :746-798),
+// compacted in burst order: 128 rounds per step of the work-group, thread = round x 8 + burst (a round's BCCH burst is its
+// last); the slots come from a ballot per wave and the waves' counts summed through LDS
+constexpr int kMergeWaves = 16;
+__global__ __launch_bounds__(64 * kMergeWaves) void k_rx_merge(RxLoopArgs la)
+{
+	__shared__ int s_cnt[2][kMergeWaves];
+	const int chain = blockIdx.x;
+	const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+	const RxLoopState st = la.state[chain];
+	const int nr = min(la.n_rounds[chain], la.max_rounds);
+	const int n_c = min(la.n_ccch[chain], la.c_stride);
+	const RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
+	const size_t c_base = (size_t)chain * la.c_stride;
+	gmr1_hip_rx_record *rec = la.rec + (size_t)chain * la.rec_stride;
+	int32_t *rec_frame = la.rec_frame ? la.rec_frame + (size_t)chain * la.rec_stride : nullptr;
+	float *rec_minen = la.rec_minen ? la.rec_minen + (size_t)chain * la.rec_stride : nullptr;
+	int n_rec = 0;
+	for (int r0 = 0, step = 0; r0 < nr; r0 += 8 * kMergeWaves, step++) {
+		const int r = r0 + (tid >> 3), it = tid & 7;
+		bool emit = false;
+		RxLoopRound rl = {};
+		size_t k = 0;
+		if (r < nr) {
+			rl = rlog[r];
+			if (it == 7) {
+				emit = rl.b_emit != 0;
+			} else if (it < rl.c_n && rl.c_first + it < n_c) {
+				k = c_base + (size_t)(rl.c_first + it);
+				emit = !(la.c_en[k] < rl.minen) && !la.c_rv[k] && !la.c_crc[k];     // energy gate first (:813-816)
+			}
+		}
+		const unsigned long long mask = __ballot(emit);
+		if (lane == 0)
+			s_cnt[step & 1][wave] = __popcll(mask);
+		__syncthreads();
+		int before = 0, total = 0;
+#pragma unroll
+		for (int v = 0; v < kMergeWaves; v++) {
+			const int c = s_cnt[step & 1][v];
+			before += v < wave ? c : 0;
+			total += c;
+		}
+		if (emit) {
+			const int slot = n_rec + before + __popcll(mask & ((1ull << lane) - 1ull));
+			if (slot < la.rec_stride) {
+				const bool is_b = it == 7;
+				uint32_t *d = reinterpret_cast<uint32_t *>(rec + slot);
+				const uint32_t *l2w = is_b ? reinterpret_cast<const uint32_t *>(rlog[r].b_l2)
+				                           : reinterpret_cast<const uint32_t *>(la.c_l2 + k * 24);
+				const RxLoopCcch cm = is_b ? RxLoopCcch{rl.b_fn, rl.b_tn, rl.b_frame} : la.c_meta[k];
+				d[0] = (uint32_t)st.arfcn | ((uint32_t)st.chain << 16) | ((is_b ? 1u : 2u) << 24);
+				d[1] = (uint32_t)cm.fn;
+				d[2] = ((uint32_t)cm.tn & 0xffu) | (24u << 16);                // crc = 0, len = 24
+				d[3] = (uint32_t)(is_b ? rl.b_conv : la.c_conv[k]);
+#pragma unroll
+				for (int i = 0; i < 6; i++)
+					d[4 + i] = l2w[i];
+				if (rec_frame) {
+					rec_frame[slot] = cm.frame;
+					rec_minen[slot] = rl.minen;
+				}
+			}
+		}
+		n_rec += total;
+	}
+	if (tid == 0)
+		la.n_rec[chain] = n_rec;
 }
 
 // ---------------------------------------------------------------------------
@@ -3148,26 +3200,30 @@ extern "C" int gmr1_hip_prof_stamps(unsigned long long *out16)
 {
 	return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) == hipSuccess ? 0 : -5;
 }
+extern "C" int gmr1_hip_prof_flag(int v)
+{
+	return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_flag), &v, sizeof(v)) == hipSuccess ? 0 : -5;
+}
 #endif
 
 hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream)
 {
 	if (n_chains <= 0)
 		return hipSuccess;
-	if (a.in_len[0] > kMaxInLen || a.dbg_stop)
+	if (a.in_len[0] > kMaxInLen || a.dbg_stop || la.c_stride < 4 || (la.c_stride & 3))
 		return hipErrorInvalidValue;
 	const int max_len = 20 * a.sps + 1;
 	const int cw = (max_len + 15) & ~15;
 	size_t off4[4];
-	const size_t lds4 = (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
-	const size_t lds = lds4 * kLoopPerRound;
-	const dim3 grid((unsigned)n_chains), block(64 * kLoopPerRound);
-#define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                      \
-	do {                                                                                                               \
-		if (a.conv_acc)                                                                                                \
-			hipLaunchKernelGGL((k_rx_loop<NPL, SPS, true>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4); \
-		else                                                                                                           \
-			hipLaunchKernelGGL((k_rx_loop<NPL, SPS>), grid, block, lds, stream, a, la, a.stage_samples, cw, (int)lds4);  \
+	const size_t lds = (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
+	const dim3 grid((unsigned)n_chains), block(64);
+	// 1. the feedback chains
+#define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                \
+	do {                                                                                                         \
+		if (a.conv_acc)                                                                                          \
+			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds, stream, a, la, a.stage_samples, cw);  \
+		else                                                                                                     \
+			hipLaunchKernelGGL((k_rx_chain<NPL, SPS>), grid, block, lds, stream, a, la, a.stage_samples, cw);        \
 	} while (0)
 	if (a.in_len[0] <= 1024) {
 		if (a.sps == 4)
@@ -3181,6 +3237,28 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 			GMR1_LOOP_LAUNCH(32, 0);
 	}
 #undef GMR1_LOOP_LAUNCH
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		return e;
+	// 2. the CCCH bursts they listed
+	RxArgs b = a;
+	b.n = n_chains * la.c_stride;
+	b.impl = 0;
+	b.seg_stride = la.c_stride;
+	b.seg_count = la.n_ccch;
+	b.offset = la.c_off;
+	b.kind = la.c_kind;
+	b.freq_shift = la.c_fs;
+	b.l2 = la.c_l2;
+	b.crc = la.c_crc;
+	b.conv = la.c_conv;
+	b.rv = la.c_rv;
+	b.energy = la.c_en;
+	e = launch_rx(b, true, b.in_len[0], stream);
+	if (e != hipSuccess)
+		return e;
+	// 3. the records
+	hipLaunchKernelGGL(k_rx_merge, grid, dim3(64 * kMergeWaves), 0, stream, la);
 	return hipGetLastError();
 }
 

@@ -28,9 +28,18 @@ iq = torch.cat([base] * 8)[:A * ns * 2].contiguous()
 offset = np.arange(A, dtype=np.uint64) * np.uint64(ns)
 length = np.full(A, ns, np.uint64)
 st = torch.cuda.current_stream().cuda_stream
+if os.environ.get("LOOP_FLAG"):
+    assert L.gmr1_hip_prof_flag(int(os.environ["LOOP_FLAG"])) == 0
 for _ in range(3):
     api.rx_run_dev(st, iq.data_ptr(), offset, length, sps=sps)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    api.rx_run_dev(st, iq.data_ptr(), offset, length, sps=sps)
+e1.record()
+torch.cuda.synchronize()
+print(f"{A} carriers x {seconds} s: {e0.elapsed_time(e1) / 5:.3f} ms per run (acquisition + loop)")
 out = (C.c_ulonglong * 16)()
 assert L.gmr1_hip_prof_stamps(out) == 0
 t = np.array(list(out), np.int64)
