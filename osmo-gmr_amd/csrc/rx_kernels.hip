@@ -2008,7 +2008,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
 		GMR1_STAMP(1);
 		if (row == q) { avr_r = avr; avi_r = avi; }
-		if (LAT && io.energy) {
+		if ((LAT || !PREFETCH_NEXT) && io.energy) {
 			// burst_energy() while the window is still in registers
 			const float e = window_energy_regs<NPL>(wv, in_len, lane);
 			if (lane == 0)
@@ -2019,7 +2019,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			const int kind1 = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
 			window_fetch<NPL, NFULL>(a.iq + io.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
 		}
-		if (!LAT && io.energy) {
+		if (!LAT && PREFETCH_NEXT && io.energy) {
 			// second read (L2): the registers already hold the next burst's window
 			const float e = window_energy<NPL>(in, in_len, lane);
 			if (lane == 0)
