@@ -1739,28 +1739,79 @@ struct Fmt {
 	}
 };
 
-// What a wave of the receive loop carries from one round into the next (LAT): the window -- and, again, the samples under
-// the sync chunks -- of the burst it will most likely be given next, eight frames on, asked for as soon as the current
-// burst's copies are dead.  They travel during the rest of the burst, the barrier and the chain's book-keeping; a round
-// whose burst turns out to sit elsewhere (the BCCH feedback moved the chain) simply loads as before.
+// What the receive loop hands its burst body (LAT).
+// (1) What depends only on WHERE the burst sits -- the window's mean and deviation, its energy, the normalised samples under
+// the sync chunks -- prepared a round ahead by the chain's second wave (lat_prepare, on another SIMD) for the place the
+// chain's schedule puts the next BCCH burst, eight frames on; a burst that turns out to sit elsewhere (the feedback moved
+// the chain) is prepared by the body itself, as every burst of the batch kernels is.
+// (2) What every burst reads from constant tables, kept where a wave of the loop gets at it in an LDS access instead of a
+// trip to the L2 (each of these sat at the head of a phase of every burst of every round): the soft-bit table, the
+// trellis-step descriptors and the cost words of the branch metrics (work-group copies), the decoder's per-lane
+// constants and CRC syndrome words (registers).
 template <int NPL, int SPS>
 struct LatPre {
-	static constexpr int SIT = SPS == 4 ? 2 : 4;
-	float2 wv[NPL];
-	float2 sv[3][SIT];
-	uint64_t off = ~0ull;      // first sample of the window held (~0: none)
-	uint64_t lim = 0;          // end of the chain's capture: nothing is asked for beyond it
-	int kind = -1;
-	// What every burst reads from constant tables, kept where a wave of the loop gets at it in an LDS access instead of a
-	// trip to the L2 (each of these sat at the head of a phase of every burst of every round): the soft-bit table, the
-	// trellis-step descriptors and the cost words of the branch metrics (work-group copies), the decoder's per-lane
-	// constants and CRC syndrome words (registers).
+	const uint64_t *h_off = nullptr;       // LDS: first sample of the window prepared (~0: none)
+	const int *h_kind = nullptr;
+	const float *h_stat = nullptr;         // LDS: mean re, mean im, 1 / deviation, burst energy
+	const float2 *h_x = nullptr;           // LDS: the staged sync-chunk windows
 	const unsigned char *lut = nullptr;
 	const uint32_t *steps = nullptr;       // [2][kSteps12]
 	const uint32_t *cost_a = nullptr, *cost_b = nullptr;   // [512] each
 	uint32_t dc = 0;
 	uint4 sy0, sy1;
 };
+
+// The position-only part of a fused-format burst's pass 1 (rx4_body does the same, operation for operation): window,
+// statistics, burst energy, normalised sync-chunk windows.
+template <int NPL, int SPS>
+__device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int kind, int lane, float2 *__restrict__ hx,
+                                            float *__restrict__ hs)
+{
+	const int sps = SPS ? SPS : a.sps;
+	const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
+	typedef Fmt<false> F;
+	const DevBurst &bt = c_types[kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH];
+	const int w = in_len - 234 * sps + 1;
+	const float2 *__restrict__ in = a.iq + off;
+	constexpr int NFULL = (SPS == 4 && NPL == 16) ? 15 : -1;
+	constexpr int SIT = SPS == 4 ? 2 : 4;
+	float2 wv[NPL];
+	float2 sv[3][SIT];
+	window_fetch<NPL, NFULL>(in, in_len, lane, wv);
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		const int wl = F::clen(bt, kind, c) * sps + w - 1;
+		const float2 *__restrict__ src = in + F::cpos(bt, c) * sps;
+#pragma unroll
+		for (int h = 0; h < SIT; h++) {
+			const int sidx = lane + 64 * h;
+			sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
+		}
+	}
+	float avr, avi, inv;
+	window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
+	const float e = window_energy_regs<NPL>(wv, in_len, lane);
+	int wb = 0;
+#pragma unroll
+	for (int c = 0; c < 3; c++) {
+		const int wl = F::clen(bt, kind, c) * sps + w - 1;
+#pragma unroll
+		for (int h = 0; h < SIT; h++) {
+			const int sidx = lane + 64 * h;
+			if (sidx < wl) {
+				const v2f nv = ((v2f){sv[c][h].x, sv[c][h].y} - (v2f){avr, avi}) * (v2f){inv, inv};
+				hx[wb + sidx] = make_float2(nv.x, nv.y);
+			}
+		}
+		wb += wl;
+	}
+	if (lane == 0) {
+		hs[0] = avr;
+		hs[1] = avi;
+		hs[2] = inv;
+		hs[3] = e;
+	}
+}
 
 // LAT: the caller cares about the latency of ONE burst (the receive loop), not about throughput
 // GEN: demodulation only, every burst of the one format a.fixed_type (one training sequence, QPSK, <= 3 sync chunks,
@@ -1802,6 +1853,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const bool row_live = g_row < n_end;
 
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
+	const float2 *xst_lat = L.x;                       // LAT: where the one burst's sync-chunk windows are staged
 
 	GMR1_STAMP(0);
 	// =========================== pass 1: correlation magnitudes ===========================
@@ -1923,7 +1975,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 	} else {
 	float2 wv_own[NPL];
-	float2 (&wv)[NPL] = *(LAT ? &pre->wv : &wv_own);
+	float2 (&wv)[NPL] = wv_own;
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
 		if (g >= n_end)
@@ -1947,7 +1999,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		// travels
 		constexpr int SIT = SMALL ? 1 : (SPS == 4 ? 2 : 4);   // 64-sample pieces per chunk window
 		float2 sv_own[NCHK][SIT];
-		float2 (&sv)[NCHK][SIT] = *(LAT ? reinterpret_cast<float2 (*)[NCHK][SIT]>(&pre->sv) : &sv_own);
+		float2 (&sv)[NCHK][SIT] = sv_own;
 		auto fetch_window = [&](const float2 *__restrict__ from) {
 			window_fetch<NPL, NFULL>(from, in_len, lane, wv);
 #pragma unroll
@@ -1961,9 +2013,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				}
 			}
 		};
+		// LAT: prepared a round ago by the chain's helper wave, if the burst sits where it was expected (LatPre)
+		bool prepared = false;
+		const float2 *__restrict__ xst = L.x;
 		if constexpr (LAT) {
-			// the window asked for a round ago, if the burst sits where it was expected
-			if (!(pre->off == io.offset[g] && pre->kind == kind))
+			prepared = *pre->h_off == io.offset[g] && *pre->h_kind == kind;
+			if (prepared)
+				xst = xst_lat = pre->h_x;
+		}
+		if (LAT) {
+			if (!prepared)
 				fetch_window(in);
 		} else {
 			if (q == 0 || !PREFETCH_NEXT)
@@ -2005,16 +2064,24 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		} else if (GEN && lane < tl)
 			L.coef[lane] = cfl;
 		float avr, avi, inv;
+		if (prepared) {
+			avr = pre->h_stat[0];
+			avi = pre->h_stat[1];
+			inv = pre->h_stat[2];
+			if (io.energy && lane == 0)
+				io.energy[g] = pre->h_stat[3];
+		} else {
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
-		GMR1_STAMP(1);
-		if (row == q) { avr_r = avr; avi_r = avi; }
 		if ((LAT || !PREFETCH_NEXT) && io.energy) {
 			// burst_energy() while the window is still in registers
 			const float e = window_energy_regs<NPL>(wv, in_len, lane);
 			if (lane == 0)
 				io.energy[g] = e;
 		}
-		if (PREFETCH_NEXT && q + 1 < 4 && g + 1 < n_end) {
+		}
+		GMR1_STAMP(1);
+		if (row == q) { avr_r = avr; avi_r = avi; }
+		if (PREFETCH_NEXT && !LAT && q + 1 < 4 && g + 1 < n_end) {
 			// the next burst's window travels during this burst's correlation
 			const int kind1 = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
 			window_fetch<NPL, NFULL>(a.iq + io.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
@@ -2026,7 +2093,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				io.energy[g] = e;
 		}
 		// stage the sync-chunk windows, normalised: window c = samples [pos_c sps, pos_c sps + len_c sps + w - 1)
-		{
+		if (!prepared) {
 			int wb = 0;
 #pragma unroll
 			for (int c = 0; c < NCHK; c++) {
@@ -2042,28 +2109,14 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				wb += wl;
 			}
 		}
-		if constexpr (LAT) {
-			// this burst's copies are dead: ask for the window the chain's schedule puts eight frames on (the same slot of
-			// the next round) -- it has the rest of this burst and the round's turn-around to arrive.  (Asked for later --
-			// just before the Viterbi decoder -- the requests' own issue time lands on the round's critical path: measured,
-			// 4.07 ms against 3.92 ms for 64 carriers x 60 s.)
-			const uint64_t nxt = io.offset[g] + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
-			if (nxt + (uint64_t)in_len <= pre->lim) {
-				fetch_window(a.iq + nxt);
-				pre->off = nxt;
-				pre->kind = kind;
-			} else {
-				pre->off = ~0ull;
-			}
-		}
 		WSYNC();
 		float *corr = L.corr + q * cw;
 		if constexpr (!GEN) {
 			// BCCH / DC6: static tap structure (the host refuses to start this kernel if the tables say otherwise)
 			if (kind == 0)
-				corr_fixed<SPS, 11, 3, 3>(L.x, sps, w, lane, cfl, corr);
+				corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, cfl, corr);
 			else
-				corr_fixed<SPS, 7, 3, 3>(L.x, sps, w, lane, cfl, corr);
+				corr_fixed<SPS, 7, 3, 3>(xst, sps, w, lane, cfl, corr);
 		} else if constexpr (FAC) {
 			const int len = bt.sync[0][0].len;
 			for (int j = lane; j < w; j += 64) {
@@ -2364,7 +2417,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				if (idx >= 0 && idx < in_len_r) {
 					// LAT, the wave's one burst: its sync-chunk windows are still staged (normalised, which no angle
 					// below notices) -- no second trip to L2
-					xr[h] = LAT ? L.x[wb + nn * sps + d_r] : in_r[idx];
+					xr[h] = LAT ? xst_lat[wb + nn * sps + d_r] : in_r[idx];
 				}
 				chn[h] = ch;
 				spos[h] = sp;
@@ -2659,9 +2712,17 @@ __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw
 // What goes to HBM in between is a few dozen bytes per burst (RxLoopRound, RxLoopCcch, the burst kernel's own outputs).
 // ---------------------------------------------------------------------------
 template <int NPL, int SPS, bool ACC = false>
-__global__ __launch_bounds__(64) void k_rx_chain(RxArgs a, RxLoopArgs la, int stage_samples, int cw)
+__global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
+	// wave 0 walks the chain; wave 1 (another SIMD) prepares, a round ahead, what depends only on where the next BCCH
+	// burst sits (LatPre, lat_prepare): the two meet at one barrier per round
+	__shared__ uint64_t h_off[2], s_pred;
+	__shared__ int h_kind[2], s_go;
+	__shared__ float h_stat[2][4];
+	float2 *h_x[2] = {reinterpret_cast<float2 *>(lds_raw + lds_body),
+	                  reinterpret_cast<float2 *>(lds_raw + lds_body) + ((stage_samples + 15) & ~15)};
+	const int wave = (int)threadIdx.x >> 6;
 	// operands and results of the round's BCCH burst
 	__shared__ uint64_t s_off[1];
 	__shared__ float s_fs[1];
@@ -2671,8 +2732,26 @@ __global__ __launch_bounds__(64) void k_rx_chain(RxArgs a, RxLoopArgs la, int st
 	__shared__ int32_t s_crc[1], s_conv[1], s_rv[1];
 	__shared__ float s_toa[1], s_fe[1], s_en[1];
 	const int chain = blockIdx.x;
-	const int lane = (int)threadIdx.x;
+	const int lane = (int)threadIdx.x & 63;
 	const int sps = a.sps;
+	if (threadIdx.x < 2)
+		h_off[threadIdx.x] = ~0ull;
+	if (wave == 1) {
+		for (int round = 0; round < la.max_rounds; round++) {
+			__syncthreads();
+			if (!s_go)
+				break;
+			const uint64_t pred = s_pred;
+			const int nb = (round + 1) & 1;
+			if (pred != ~0ull)
+				lat_prepare<NPL, SPS>(a, pred, 0, lane, h_x[nb], h_stat[nb]);
+			if (lane == 0) {
+				h_off[nb] = pred;
+				h_kind[nb] = 0;
+			}
+		}
+		return;
+	}
 	RxLoopState st = la.state[chain];          // every lane computes the same
 	const uint64_t lim = st.base + (uint64_t)st.len;
 	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
@@ -2700,7 +2779,6 @@ __global__ __launch_bounds__(64) void k_rx_chain(RxArgs a, RxLoopArgs la, int st
 		}
 	}
 	LatPre<NPL, SPS> pre;
-	pre.lim = lim;
 	pre.lut = reinterpret_cast<const unsigned char *>(s_lut);
 	pre.steps = s_steps;
 	pre.cost_a = s_cost_a;
@@ -2749,9 +2827,21 @@ __global__ __launch_bounds__(64) void k_rx_chain(RxArgs a, RxLoopArgs la, int st
 			}
 		}
 		WSYNC();
+		const bool has_b = n > 0 && s_items[n - 1].is_bcch != 0;  // always the round's last item
+		if (lane == 0) {
+			// where the next round's BCCH burst will most likely sit: eight frames on
+			uint64_t pred = ~0ull;
+			if (has_b) {
+				pred = st.base + (uint64_t)s_items[n - 1].begin + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
+				if (pred + (uint64_t)a.in_len[0] > lim)
+					pred = ~0ull;
+			}
+			s_pred = pred;
+			s_go = n > 0;
+		}
+		__syncthreads();
 		if (n == 0)
 			break;
-		const bool has_b = s_items[n - 1].is_bcch != 0;           // always the round's last item
 		const int n_c = has_b ? n - 1 : n;
 		// the CCCH bursts: listed for the batch that follows
 		if (lane < n_c && n_ccch + lane < la.c_stride) {
@@ -2771,8 +2861,10 @@ __global__ __launch_bounds__(64) void k_rx_chain(RxArgs a, RxLoopArgs la, int st
 				s_kind[0] = 0;
 			}
 			WSYNC();
-			// (the window of the next round's BCCH burst -- eight frames on, give or take the feedback -- is asked for inside
-			// the body as soon as this burst's is dead: LatPre)
+			pre.h_off = &h_off[round & 1];
+			pre.h_kind = &h_kind[round & 1];
+			pre.h_stat = h_stat[round & 1];
+			pre.h_x = h_x[round & 1];
 			const RxIo io = {
 #ifdef GMR1_HIP_PROFILE
 			                 (chain == 0 && round == kStampRound) ? g_stamp : nullptr,
@@ -3216,14 +3308,15 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	const int cw = (max_len + 15) & ~15;
 	size_t off4[4];
 	const size_t lds = (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
-	const dim3 grid((unsigned)n_chains), block(64);
+	const dim3 grid((unsigned)n_chains), block(128);
+	const size_t lds_h = 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2);      // the helper wave's two staged windows
 	// 1. the feedback chains
 #define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                \
 	do {                                                                                                         \
 		if (a.conv_acc)                                                                                          \
-			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds, stream, a, la, a.stage_samples, cw);  \
+			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds); \
 		else                                                                                                     \
-			hipLaunchKernelGGL((k_rx_chain<NPL, SPS>), grid, block, lds, stream, a, la, a.stage_samples, cw);        \
+			hipLaunchKernelGGL((k_rx_chain<NPL, SPS>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds); \
 	} while (0)
 	if (a.in_len[0] <= 1024) {
 		if (a.sps == 4)
