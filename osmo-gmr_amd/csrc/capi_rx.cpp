@@ -53,6 +53,8 @@ struct RxChain {
 	float bcch_energy;
 	bool done;
 	std::vector<gmr1_hip_rx_record> rec;
+	const gmr1_hip_rx_record *rec_view = nullptr;   // without a traffic pass the loop's records stay where the copy from the
+	int rec_view_n = 0;                             // device put them (pinned host log) until they are handed back
 	std::vector<int> rec_frame;          // frame (index into log) each record belongs to
 	std::vector<FrameCtx> log;           // one entry per loop iteration of process_bcch (only with a traffic carrier)
 	std::vector<AssEvt> events;
@@ -487,7 +489,12 @@ int RxRun::frame_loop()
 			continue;
 		}
 		const gmr1_hip_rx_record *rp = reinterpret_cast<const gmr1_hip_rx_record *>(h) + (size_t)ci * rec_stride;
-		c.rec.assign(rp, rp + h_nrec[ci]);
+		if (!tch && !csd) {
+			c.rec_view = rp;
+			c.rec_view_n = h_nrec[ci];
+		} else {
+			c.rec.assign(rp, rp + h_nrec[ci]);
+		}
 		if (want_ctx) {
 			const int32_t *fp = reinterpret_cast<const int32_t *>(h + o_rf) + (size_t)ci * rec_stride;
 			const float *mp = reinterpret_cast<const float *>(h + o_me) + (size_t)ci * rec_stride;
@@ -502,7 +509,7 @@ int RxRun::frame_loop()
 				if (rp[k].type == 2 && l2[1] == 0x06 && l2[2] == 0x3f)
 					c.events.push_back({fp[k], ((l2[8] & 0x03) << 3) | (l2[9] >> 5), (l2[8] & 0xfc) >> 2, mp[k]});
 			}
-		} else {
+		} else if (!c.rec_view) {
 			c.rec_frame.assign((size_t)h_nrec[ci], 0);
 		}
 		const RxLoopState &s = h_st[ci];
@@ -1051,11 +1058,12 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	// ---- hand back: carriers in order, chains in order, frames in order -------------------------
 	int total = 0;
 	for (const RxChain &c : chains) {       // chains were created carrier by carrier, chain by chain
-		for (const gmr1_hip_rx_record &rec : c.rec) {
-			if (total < max_records)
-				out[total] = rec;
-			total++;
-		}
+		const gmr1_hip_rx_record *src = c.rec_view ? c.rec_view : c.rec.data();
+		const int cnt = c.rec_view ? c.rec_view_n : (int)c.rec.size();
+		const int fit = std::max(0, std::min(cnt, max_records - total));
+		if (fit)
+			std::memcpy(out + total, src, (size_t)fit * sizeof(gmr1_hip_rx_record));
+		total += cnt;
 	}
 	*n_records = total;
 	if (n_big) {
