@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--cpu-passes", type=int, default=3,
                     help="bursts workload: passes of the CPU oracle over its sample (3 x 100k bursts = about 11 s of CPU work)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--nt3-two-launches", action="store_true",
+                    help="nt3 workload: demodulate and decode the speech bursts with the two separate calls")
     ap.add_argument("--workload", default="bursts", choices=["bursts", "fcch", "tch3", "nt3", "rx", "chan", "ambe"],
                     help="bursts = configs[2] (default, the headline metric); fcch = configs[1] rough sweep "
                          "over 1-s streams; tch3 = configs[4] l1-only TCH3 decode; nt3 = configs[4] from samples (90 %% speech + 10 %% FACCH3: demod + "
@@ -540,10 +542,19 @@ def run_nt3_workload(args):
     sp = C.c_void_p(stream.cuda_stream)
     id_s, id_f = api.BURST_IDS.index("nt3_speech"), api.BURST_IDS.index("nt3_facch")
 
+    want_eb = [False]
+
     def step():
-        rc = L.gmr1_hip_demod_batch_dev(sp, C.c_int(id_s), C.c_int(n_s), C.c_int(4), C.c_int(474), P(iq), P(off_s), P(fs_s),
-                                        P(eb_s), C.c_int(212), P(sid_s), P(toa_s), None, None, P(rv_s))
-        rc |= L.gmr1_hip_tch3_decode_batch_dev(sp, C.c_int(n_s), C.c_int(0), P(eb_s), None, P(frames), P(st), P(conv_s))
+        if args.nt3_two_launches:
+            rc = L.gmr1_hip_demod_batch_dev(sp, C.c_int(id_s), C.c_int(n_s), C.c_int(4), C.c_int(474), P(iq), P(off_s), P(fs_s),
+                                            P(eb_s), C.c_int(212), P(sid_s), P(toa_s), None, None, P(rv_s))
+            rc |= L.gmr1_hip_tch3_decode_batch_dev(sp, C.c_int(n_s), C.c_int(0), P(eb_s), None, P(frames), P(st), P(conv_s))
+        else:
+            # rx_tch3's burst step as one call (one launch: the soft bits stay in LDS and, in the timed steps, are not
+            # written out -- rx_tch3 has no use for them either; the one step after the timed ones asks for them, for the checks)
+            rc = L.gmr1_hip_tch3_rx_batch_dev(sp, C.c_int(n_s), C.c_int(4), C.c_int(474), P(iq), P(off_s), P(fs_s), C.c_int(0),
+                                              None, P(eb_s) if want_eb[0] else None, P(sid_s), P(toa_s), P(rv_s), P(frames), P(st),
+                                              P(conv_s))
         rc |= L.gmr1_hip_demod_batch_dev(sp, C.c_int(id_f), C.c_int(n_f), C.c_int(4), C.c_int(474), P(iq), P(off_f), P(fs_f),
                                          P(eb_f), C.c_int(104), P(sid_f), P(toa_f), None, None, P(rv_f))
         rc |= L.gmr1_hip_facch3_decode_batch_dev(sp, C.c_int(n_f // 4), P(eb_f), None, P(l2f), P(bs_f), P(crc_f), P(conv_f))
@@ -563,6 +574,9 @@ def run_nt3_workload(args):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     step_ms = ev0.elapsed_time(ev1) / args.steps
+    want_eb[0] = True
+    step()
+    torch.cuda.synchronize()
     # speech 474 x 8 + 20 + 4 + 12 = 3 828 B, FACCH3 474 x 8 per burst + (10 + 32 + 8) per group
     bytes_per_step = n_s * 3828 + n_f * 3792 + (n_f // 4) * 50
     achieved = bytes_per_step / (step_ms * 1e-3) / 1e9

@@ -162,6 +162,22 @@ int gmr1_hip_tch3_decode_batch_dev(void *stream, int n, int m, const int8_t *ebi
                                    uint8_t *frames, uint8_t *bits_s, int32_t *conv);
 int gmr1_hip_tch3_decode_batch(int n, int m, const int8_t *ebits, const uint8_t *ciph,
                                uint8_t *frames, uint8_t *bits_s, int32_t *conv);
+/* What rx_tch3 does with a speech burst (src/gmr1_rx.c:551-587): gmr1_pi4cxpsk_demod of the NT3 speech format
+ * (include/osmocom/gmr1/sdr/pi4cxpsk.h:101-105, src/sdr/nb.c gmr1_nt3_speech_burst), then gmr1_tch3_decode
+ * (include/osmocom/gmr1/l1/tch3.h:35-37) of its 212 soft bits -- n bursts from samples to 2 x 10-byte speech frames.  The
+ * outputs are those of gmr1_hip_demod_batch* (ebits n x 212, sync_id, toa, rv: optional except rv) followed by those of
+ * gmr1_hip_tch3_decode_batch* (frames n x 20, bits_s n x 4, conv n x 2) and identical to calling the two in sequence; large
+ * batches at 4 samples per symbol run as ONE launch with the soft bits kept on chip. */
+int gmr1_hip_tch3_rx_batch_dev(void *stream, int n, int sps, int in_len,
+                               const float *iq, const uint64_t *offset, const float *freq_shift,
+                               int m, const uint8_t *ciph,
+                               int8_t *ebits, int32_t *sync_id, float *toa, int32_t *rv,
+                               uint8_t *frames, uint8_t *bits_s, int32_t *conv);
+int gmr1_hip_tch3_rx_batch(int n, int sps, int in_len,
+                           const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
+                           int m, const uint8_t *ciph,
+                           int8_t *ebits, int32_t *sync_id, float *toa, int32_t *rv,
+                           uint8_t *frames, uint8_t *bits_s, int32_t *conv);
 
 /* ---- TCH3 follow-up pieces --------------------------------------------------
  * DKAB demodulation (gmr1_dkab_demod, include/osmocom/gmr1/sdr/dkab.h:39-41): n windows of in_len

@@ -31,7 +31,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_fcch_rough", "gmr1_fcch_fine", "gmr1_fcch_snr", "gmr1_fcch_rough_multi",
     "gmr1_hip_fcch_rough_multi_batch_dev", "gmr1_hip_fcch_rough_multi_batch",
     "gmr1_hip_facch3_decode_batch_dev", "gmr1_hip_facch3_decode_batch",
-    "gmr1_hip_tch3_decode_batch_dev", "gmr1_hip_tch3_decode_batch",
+    "gmr1_hip_tch3_decode_batch_dev", "gmr1_hip_tch3_decode_batch", "gmr1_hip_tch3_rx_batch_dev", "gmr1_hip_tch3_rx_batch",
     "gmr1_facch3_decode", "gmr1_tch3_decode",
     "gmr1_hip_detect_batch_dev", "gmr1_hip_detect_batch",
     "gmr1_hip_mod_order_batch_dev", "gmr1_hip_mod_order_batch",
@@ -467,6 +467,32 @@ def tch3_decode_batch(ebits, m=0, ciph=None):
                                            s.ctypes.data_as(C.c_void_p), conv.ctypes.data_as(C.c_void_p))
     _check(rc, "gmr1_hip_tch3_decode_batch")
     return fr[:, 0], fr[:, 1], s, conv[:, 0], conv[:, 1]
+
+
+def tch3_rx_batch(iq, offset, in_len, sps=4, freq_shift=None, m=0, ciph=None, want_ebits=True):
+    """NT3 speech bursts from samples to speech frames (rx_tch3's demodulate-then-decode, one call):
+    dict(rv, sync_id, toa, ebits (n, 212), frame0, frame1, bits_s, conv0, conv1)."""
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    offset, p_off = _np(offset, np.uint64)
+    n = offset.size
+    fs_p = cp = None
+    if freq_shift is not None:
+        fs, fs_p = _np(freq_shift, np.float32)
+    if ciph is not None:
+        ciph, cp = _np(ciph, np.uint8)
+    eb = np.zeros((n, 212), np.int8) if want_ebits else None
+    sid = np.zeros(n, np.int32)
+    toa = np.zeros(n, np.float32)
+    rv = np.zeros(n, np.int32)
+    fr = np.zeros((n, 2, 10), np.uint8)
+    st = np.zeros((n, 4), np.uint8)
+    conv = np.zeros((n, 2), np.int32)
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    rc = load().gmr1_hip_tch3_rx_batch(C.c_int(n), C.c_int(sps), C.c_int(in_len), p_iq, C.c_uint64(iq.size), p_off, fs_p,
+                                       C.c_int(m), cp, vp(eb), vp(sid), vp(toa), vp(rv), vp(fr), vp(st), vp(conv))
+    _check(rc, "gmr1_hip_tch3_rx_batch")
+    return dict(rv=rv, sync_id=sid, toa=toa, ebits=eb, frame0=fr[:, 0], frame1=fr[:, 1], bits_s=st, conv0=conv[:, 0],
+                conv1=conv[:, 1])
 
 
 def facch3_decode(ebits):

@@ -195,10 +195,11 @@ static int dbg_stop_env()
 	return v;
 }
 
-static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
-                          int n, int sps, int in_len, const float *iq, const uint64_t *offset,
-                          const float *freq_shift, int8_t *ebits, int ebits_stride, int32_t *sync_id,
-                          float *toa, float *freq_err, float *ssyms, int32_t *rv, float *energy = nullptr)
+// the launch arguments of a demodulation batch, with the kernel chosen for it (RxArgs::impl)
+static int demod_args(int type, const DevBurst &ht,
+                      int n, int sps, int in_len, const float *iq, const uint64_t *offset,
+                      const float *freq_shift, int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                      float *toa, float *freq_err, float *ssyms, int32_t *rv, float *energy, RxArgs *out)
 {
 	if (n < 0 || !iq || !offset || !rv)
 		return fail(-EINVAL, "demod: n/iq/offset/rv are required");
@@ -256,6 +257,19 @@ static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
 			a.stage_samples = stage;
 		}
 	}
+	*out = a;
+	return 0;
+}
+
+static int demod_dev_impl(hipStream_t st, int type, const DevBurst &ht,
+                          int n, int sps, int in_len, const float *iq, const uint64_t *offset,
+                          const float *freq_shift, int8_t *ebits, int ebits_stride, int32_t *sync_id,
+                          float *toa, float *freq_err, float *ssyms, int32_t *rv, float *energy = nullptr)
+{
+	RxArgs a;
+	int r = demod_args(type, ht, n, sps, in_len, iq, offset, freq_shift, ebits, ebits_stride, sync_id, toa, freq_err, ssyms, rv,
+	                   energy, &a);
+	if (r) return r;
 	HIP_TRY(launch_rx(a, false, in_len, st));
 	return 0;
 }
@@ -279,6 +293,46 @@ int demod_dev_energy(hipStream_t st, int burst_id, int n, int sps, int in_len, c
 }  // namespace gmr1
 
 extern "C" {
+
+// What rx_tch3 does with a speech burst (gmr1_rx.c:551-587): gmr1_pi4cxpsk_demod of the NT3 speech format, then
+// gmr1_tch3_decode of its 212 soft bits -- for a batch, in ONE launch where the four-bursts-per-wave demodulator applies
+// (k_rx4g_tch3: the soft bits never leave LDS), otherwise as the two launches the separate entry points make.
+int gmr1_hip_tch3_rx_batch_dev(void *stream, int n, int sps, int in_len,
+                               const float *iq, const uint64_t *offset, const float *freq_shift,
+                               int m, const uint8_t *ciph,
+                               int8_t *ebits, int32_t *sync_id, float *toa, int32_t *rv,
+                               uint8_t *frames, uint8_t *bits_s, int32_t *conv)
+{
+	if (n < 0 || !iq || !offset || !rv || !frames)
+		return fail(-EINVAL, "tch3 rx: n/iq/offset/rv/frames are required");
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n == 0) return 0;
+	const int type = GMR1_HIP_NT3_SPEECH;
+	const DevBurst &ht = g_host_types[type];
+	RxArgs a;
+	r = demod_args(type, ht, n, sps, in_len, iq, offset, freq_shift, ebits, 212, sync_id, toa, nullptr, nullptr, rv, nullptr, &a);
+	if (r) return r;
+	Tch3Args t;
+	t.n = n; t.m = m ? 1 : 0; t.conv_acc = conv_acc(); t.ebits = ebits; t.ciph = ciph; t.frames = frames; t.bits_s = bits_s;
+	t.conv = conv;
+	if (a.impl == 3 && ht.ebits == 212 && a.dbg_stop == 0) {
+		HIP_TRY(launch_rx_tch3(a, t, (hipStream_t)stream));
+		return 0;
+	}
+	// two launches; the soft bits pass through the caller's buffer or the library's workspace
+	if (!ebits) {
+		void *ws;
+		r = dev_workspace(s, (size_t)n * 212, &ws);
+		if (r) return r;
+		a.ebits = reinterpret_cast<int8_t *>(ws);
+		t.ebits = a.ebits;
+	}
+	HIP_TRY(launch_rx(a, false, in_len, (hipStream_t)stream));
+	HIP_TRY(launch_tch3(t, (hipStream_t)stream));
+	return 0;
+}
 
 int gmr1_hip_demod_batch_dev(void *stream, int burst_id, int n, int sps, int in_len,
                              const float *iq, const uint64_t *offset, const float *freq_shift,
@@ -345,6 +399,60 @@ static int demod_host_impl(int type, const DevBurst &ht, const DevBurst *custom,
 	if (toa) HIP_TRY(hipMemcpy(toa, d_toa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	if (freq_err) HIP_TRY(hipMemcpy(freq_err, d_fe.p, (size_t)n * 4, hipMemcpyDeviceToHost));
 	if (ssyms) HIP_TRY(hipMemcpy(ssyms, d_ss.p, (size_t)n * ht.len * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// host pointers: staged through HBM
+int gmr1_hip_tch3_rx_batch(int n, int sps, int in_len,
+                           const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
+                           int m, const uint8_t *ciph,
+                           int8_t *ebits, int32_t *sync_id, float *toa, int32_t *rv,
+                           uint8_t *frames, uint8_t *bits_s, int32_t *conv)
+{
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	if (n <= 0)
+		return 0;
+	if (!iq || !offset || !rv || !frames)
+		return fail(-EINVAL, "tch3 rx: n/iq/offset/rv/frames are required");
+	for (int i = 0; i < n; i++)
+		if (offset[i] + (uint64_t)in_len > iq_len)
+			return fail(-EINVAL, "burst %d runs past the end of iq", i);
+	DBuf d_iq, d_off, d_fs, d_ci, d_eb, d_sid, d_toa, d_rv, d_fr, d_s, d_conv;
+	HIP_TRY(d_iq.alloc(iq_len * 8));
+	HIP_TRY(d_off.alloc((size_t)n * 8));
+	HIP_TRY(d_rv.alloc((size_t)n * 4));
+	HIP_TRY(d_fr.alloc((size_t)n * 20));
+	HIP_TRY(hipMemcpy(d_iq.p, iq, iq_len * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_off.p, offset, (size_t)n * 8, hipMemcpyHostToDevice));
+	if (freq_shift) {
+		HIP_TRY(d_fs.alloc((size_t)n * 4));
+		HIP_TRY(hipMemcpy(d_fs.p, freq_shift, (size_t)n * 4, hipMemcpyHostToDevice));
+	}
+	if (ciph) {
+		HIP_TRY(d_ci.alloc((size_t)n * 208));
+		HIP_TRY(hipMemcpy(d_ci.p, ciph, (size_t)n * 208, hipMemcpyHostToDevice));
+	}
+	if (ebits) HIP_TRY(d_eb.alloc((size_t)n * 212));
+	if (sync_id) HIP_TRY(d_sid.alloc((size_t)n * 4));
+	if (toa) HIP_TRY(d_toa.alloc((size_t)n * 4));
+	if (bits_s) HIP_TRY(d_s.alloc((size_t)n * 4));
+	if (conv) HIP_TRY(d_conv.alloc((size_t)n * 8));
+	r = gmr1_hip_tch3_rx_batch_dev(nullptr, n, sps, in_len, d_iq.as<float>(), d_off.as<uint64_t>(),
+	                               freq_shift ? d_fs.as<float>() : nullptr, m, ciph ? d_ci.as<uint8_t>() : nullptr,
+	                               ebits ? d_eb.as<int8_t>() : nullptr, sync_id ? d_sid.as<int32_t>() : nullptr,
+	                               toa ? d_toa.as<float>() : nullptr, d_rv.as<int32_t>(), d_fr.as<uint8_t>(),
+	                               bits_s ? d_s.as<uint8_t>() : nullptr, conv ? d_conv.as<int32_t>() : nullptr);
+	if (r) return r;
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(rv, d_rv.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(hipMemcpy(frames, d_fr.p, (size_t)n * 20, hipMemcpyDeviceToHost));
+	if (ebits) HIP_TRY(hipMemcpy(ebits, d_eb.p, (size_t)n * 212, hipMemcpyDeviceToHost));
+	if (sync_id) HIP_TRY(hipMemcpy(sync_id, d_sid.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (toa) HIP_TRY(hipMemcpy(toa, d_toa.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (bits_s) HIP_TRY(hipMemcpy(bits_s, d_s.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+	if (conv) HIP_TRY(hipMemcpy(conv, d_conv.p, (size_t)n * 8, hipMemcpyDeviceToHost));
 	return 0;
 }
 

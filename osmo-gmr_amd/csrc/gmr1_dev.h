@@ -407,6 +407,7 @@ hipError_t launch_bitmap(const BitMapArgs &a, hipStream_t stream);
 hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream);
 hipError_t launch_facch3(const Facch3Args &a, hipStream_t stream);
 hipError_t launch_tch3(const Tch3Args &a, hipStream_t stream);
+hipError_t launch_rx_tch3(const RxArgs &a, const Tch3Args &t, hipStream_t stream);   // a.impl == 3, NT3 speech
 
 // launchers (rx_kernels.hip)
 // descriptors live in __constant__ memory of the current device

@@ -35,6 +35,7 @@
 //     state's 32-bit word is [metric:16 | decisions of the current 16-step window:16]; v_min_u32
 //     does compare, select, tie-break and decision recording at once (see decode4_k5_12).
 #include "gmr1_dev.h"
+#include "tch3_body.h"
 
 namespace gmr1 {
 
@@ -2539,6 +2540,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (io.ebits)
 				for (int i = lane; i < a.ebits_stride; i += 64)
 					io.ebits[(size_t)g * a.ebits_stride + i] = 0;
+			if constexpr (GEN)                                  // (a fused decoder reads the LDS row)
+				for (int i = lane; i < 108; i += 64)
+					reinterpret_cast<uint32_t *>(eb)[i] = 0;
 			if (gss)
 				for (int i = lane; i < blen; i += 64)
 					gss[i] = 0.f;
@@ -2692,6 +2696,38 @@ __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw
 	                 a.offset, nullptr, a.freq_shift, nullptr, nullptr, nullptr, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
 	rx4_body<NPL, SPS, false, true, FAC>(a, io, stage_samples, cw, g0, min(a.n, g0 + 4), lds_raw, (int)threadIdx.x);
+}
+
+// NT3 speech bursts from samples to speech frames in one launch (what rx_tch3 does with a burst, gmr1_rx.c:551-587:
+// gmr1_pi4cxpsk_demod, then gmr1_tch3_decode): the small-format demodulator of four bursts per wavefront, then the TCH3
+// decoder (tch3_body.h) on each of the four while their soft bits are still in the wave's LDS rows -- no 212-byte trip to
+// HBM and back per burst, one launch, and a compute unit always holds wavefronts in the traffic-bound half next to
+// wavefronts in the issue-bound half.
+template <bool ACC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx4g_tch3(RxArgs a, Tch3Args t, int stage_samples, int cw)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const int g0 = blockIdx.x * 4;
+	const int lane = (int)threadIdx.x;
+	const int n_end = min(a.n, g0 + 4);
+	const RxIo io = {
+#ifdef GMR1_HIP_PROFILE
+	                 nullptr,
+#endif
+	                 a.offset, nullptr, a.freq_shift, nullptr, nullptr, nullptr, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
+	                 a.ebits, a.ssyms};
+	rx4_body<8, 4, false, true, false>(a, io, stage_samples, cw, g0, n_end, lds_raw, lane);
+	// soft-bit rows of the four bursts at the front of the wave's LDS (432 bytes apart, lds4_layout), the decoder's behind them
+	t3::Tch3Lds *S = reinterpret_cast<t3::Tch3Lds *>(lds_raw + 4 * 432);
+	WSYNC();
+	t3::tch3_fill_locof(S, lane);
+	if (lane < 4)
+		*reinterpret_cast<uint32_t *>(lds_raw + lane * 432 + 212) = 0;      // byte 212: what a punctured position reads
+	WSYNC();
+	for (int q = 0; q < 4 && g0 + q < n_end; q++) {
+		t3::tch3_burst<ACC>(t, g0 + q, lane, reinterpret_cast<const int8_t *>(lds_raw + q * 432), S);
+		WSYNC();
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -3297,6 +3333,26 @@ extern "C" int gmr1_hip_prof_flag(int v)
 	return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_flag), &v, sizeof(v)) == hipSuccess ? 0 : -5;
 }
 #endif
+
+hipError_t launch_rx_tch3(const RxArgs &a, const Tch3Args &t, hipStream_t stream)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	if (a.impl != 3 || a.sps != 4 || a.in_len[0] > 512 || a.ebits_stride != 212 || a.n != t.n)
+		return hipErrorInvalidValue;
+	const int cw = (a.in_len[0] - a.ssyms_stride * 4 + 1 + 15) & ~15;          // lags (ssyms_stride = symbols per burst)
+	size_t off4[4];
+	size_t lds = lds4_layout(a.stage_samples, cw, off4, true);
+	const size_t need = 4 * 432 + sizeof(t3::Tch3Lds);
+	if (lds < need)
+		lds = need;
+	const int grid4 = (a.n + 3) / 4;
+	if (t.conv_acc)
+		hipLaunchKernelGGL(k_rx4g_tch3<true>, dim3(grid4), dim3(64), lds, stream, a, t, a.stage_samples, cw);
+	else
+		hipLaunchKernelGGL(k_rx4g_tch3<false>, dim3(grid4), dim3(64), lds, stream, a, t, a.stage_samples, cw);
+	return hipGetLastError();
+}
 
 hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream)
 {

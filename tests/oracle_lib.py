@@ -195,9 +195,11 @@ def tch3_encode(f0, f1, bits_s, m=0, ciph=None):
     return out
 
 
-def tch3_decode(ebits, m=0):
+def tch3_decode(ebits, m=0, ciph=None):
     ebits = np.ascontiguousarray(ebits, np.int8)
     n = ebits.shape[0]
+    if ciph is not None:
+        ciph = np.ascontiguousarray(ciph, np.uint8).reshape(n, 208)
     f0 = np.zeros((n, 10), np.uint8)
     f1 = np.zeros((n, 10), np.uint8)
     s = np.zeros((n, 4), np.uint8)
@@ -206,7 +208,8 @@ def tch3_decode(ebits, m=0):
     a, b = C.c_int(), C.c_int()
     for i in range(n):
         lib().orc_tch3_decode(_p(f0[i], C.c_uint8), _p(f1[i], C.c_uint8), _p(s[i], C.c_uint8),
-                              _p(ebits[i], C.c_int8), None, C.c_int(m), C.byref(a), C.byref(b))
+                              _p(ebits[i], C.c_int8), None if ciph is None else _p(ciph[i], C.c_uint8), C.c_int(m),
+                              C.byref(a), C.byref(b))
         c0[i], c1[i] = a.value, b.value
     return f0, f1, s, c0, c1
 

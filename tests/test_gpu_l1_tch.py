@@ -184,3 +184,39 @@ def test_demod_four_per_wave_equals_one_per_wave(gpu_api, orc, pkg, name, win):
         assert r["rv"] == 0 and abs(r["toa"] - big["toa"][k]) <= 16 / 1024 + 1e-6
         if np.rint(r["toa"]) == np.rint(big["toa"][k]):
             assert np.max(np.abs(r["ebits"].astype(int) - big["ebits"][k].astype(int))) <= 1
+
+
+@pytest.mark.gpu
+def test_tch3_rx_one_launch_equals_demod_then_decode(gpu_api, orc, pkg, decoder):
+    """gmr1_hip_tch3_rx_batch (rx_tch3's burst step: demodulate, then decode) against the two separate calls: identical
+    outputs for a batch large enough for the one-launch kernel (soft bits never leave LDS; not a multiple of four; one
+    window of silence: rv = -1, zero soft bits, decoded all the same), for a small batch (two launches), with a cipher
+    stream and in both multiplexing modes; and the frames against the oracle's decoder on the GPU's soft bits."""
+    import workloads
+    wl = workloads.nt3_mix(pkg, 8000, seed=61)
+    sp = wl["speech"]
+    iq = wl["iq"].copy().reshape(-1, wl["stride"])
+    n = 4099
+    assert sp.size >= n
+    iq[sp[4098]] = 0
+    off, fs = wl["offset"][sp[:n]], wl["freq_shift"][sp[:n]]
+    rng = np.random.default_rng(7)
+    ciph = rng.integers(0, 2, (n, 208), dtype=np.uint8)
+    for m, cp, cnt in ((0, None, n), (1, ciph, n), (0, ciph, 1500), (1, None, 1500)):
+        one = gpu_api.tch3_rx_batch(iq, off[:cnt], 474, sps=4, freq_shift=fs[:cnt], m=m, ciph=None if cp is None else cp[:cnt])
+        d = gpu_api.demod_batch("nt3_speech", iq, off[:cnt], 474, sps=4, freq_shift=fs[:cnt], want_ssyms=False)
+        f0, f1, st, c0, c1 = gpu_api.tch3_decode_batch(d["ebits"], m=m, ciph=None if cp is None else cp[:cnt])
+        assert np.array_equal(one["rv"], d["rv"]) and np.array_equal(one["sync_id"], d["sync_id"])
+        assert np.array_equal(one["toa"], d["toa"]) and np.array_equal(one["ebits"], d["ebits"])
+        assert np.array_equal(one["frame0"], f0) and np.array_equal(one["frame1"], f1) and np.array_equal(one["bits_s"], st)
+        assert np.array_equal(one["conv0"], c0) and np.array_equal(one["conv1"], c1)
+        if cnt == n:
+            assert one["rv"][4098] == -1 and not one["ebits"][4098].any() and not one["rv"][:4098].any()
+        k = np.arange(0, cnt, 37)
+        r0, r1, rs, rc0, rc1 = orc.tch3_decode(one["ebits"][k], m=m, ciph=None if cp is None else cp[k])
+        assert np.array_equal(one["frame0"][k], r0) and np.array_equal(one["frame1"][k], r1) and np.array_equal(one["bits_s"][k], rs)
+        assert np.array_equal(one["conv0"][k], rc0) and np.array_equal(one["conv1"][k], rc1)
+    # without the soft-bit output
+    lean = gpu_api.tch3_rx_batch(iq, off, 474, sps=4, freq_shift=fs, m=0, want_ebits=False)
+    full = gpu_api.tch3_rx_batch(iq, off, 474, sps=4, freq_shift=fs, m=0)
+    assert np.array_equal(lean["frame0"], full["frame0"]) and np.array_equal(lean["frame1"], full["frame1"])
