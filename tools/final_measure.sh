@@ -14,8 +14,11 @@ for w in nt3 tch3 fcch rx chan ambe; do python3 bench.py --workload $w > $o/benc
 python3 bench.py --workload rx --arfcns 512 --seconds 20 --no-cpu > $o/bench_rx_512x20s.json 2> $o/bench_rx_512.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_nt3 -- python3 bench.py --workload nt3 --no-cpu --steps 20 > /dev/null 2> $o/stats_nt3.err
 cp $(ls $o/stats_nt3/*/*kernel_stats.csv | head -1) $o/kernel_stats_nt3_1M.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_rx -- python3 bench.py --workload rx --no-cpu --steps 10 > /dev/null 2> $o/stats_rx.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_rx -- python3 bench.py --workload rx --no-cpu --no-shard --steps 10 > /dev/null 2> $o/stats_rx.err
 cp $(ls $o/stats_rx/*/*kernel_stats.csv | head -1) $o/kernel_stats_rx_64x60s.csv
+python3 bench.py --workload nt3 --no-cpu --nt3-two-launches > $o/bench_nt3_two_launches.json 2> $o/bench_nt3_two.err
+bash tools/pmc_nt3.sh ${t}_pmc_nt3 > /dev/null 2>&1; cp gpurun_out/${t}_pmc_nt3_kernels.txt $o/pmc_nt3_kernels.txt
+python3 tools/loop_stamps.py > $o/loop_stamps.txt 2>&1
 python3 tools/time_legacy.py > $o/legacy_one_burst_calls.json 2> $o/legacy.err
 GMR1_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 --shard-arfcns 16 --shard-seconds 20 > $o/bench_gloo2_one_gpu.json 2> $o/bench_gloo2.err
 rm -rf $o/stats_bench $o/stats_nt3 $o/stats_rx
