@@ -1821,7 +1821,11 @@ __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int k
 // Both sequences are correlated over the one staged window; the second is ranked and timed on the SUM of both
 // correlations, as the reference's uncleared accumulator has it (pi4cxpsk.c:207-237); the timing rows run once per
 // sequence; `cw` holds both correlation arrays of a burst (first cw / 2 lags: sequence 0, then the sum).
-template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false>
+// EN (fused batch kernel only): the caller wants burst_energy() of every window (RxArgs::energy; the receive loop's CCCH batch).
+// A template parameter because keeping the window registers alive for it costs the headline instantiation its sixth wave
+// (80 VGPRs with 2 spilled against 78 with none: 0.257 -> 0.265 ms per 100 k bursts, and the spill stores tripled the kernel's
+// write traffic -- which is how it was found).
+template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false, bool EN = true>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
                                          unsigned char *__restrict__ lds_raw, int lane, LatPre<NPL, SPS> *pre = nullptr)
 {
@@ -2073,7 +2077,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				io.energy[g] = pre->h_stat[3];
 		} else {
 		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
-		if ((LAT || !PREFETCH_NEXT) && io.energy) {
+		if ((LAT || !PREFETCH_NEXT) && EN && io.energy) {
 			// burst_energy() while the window is still in registers
 			const float e = window_energy_regs<NPL>(wv, in_len, lane);
 			if (lane == 0)
@@ -2087,7 +2091,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			const int kind1 = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
 			window_fetch<NPL, NFULL>(a.iq + io.offset[g + 1], __builtin_amdgcn_readfirstlane(a.in_len[kind1]), lane, wv);
 		}
-		if (!LAT && PREFETCH_NEXT && io.energy) {
+		if (!LAT && PREFETCH_NEXT && EN && io.energy) {
 			// second read (L2): the registers already hold the next burst's window
 			const float e = window_energy<NPL>(in, in_len, lane);
 			if (lane == 0)
@@ -2658,7 +2662,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 template <int NPL, int SPS>
 constexpr int kRx4Waves = NPL > 16 ? 3 : (SPS == 4 ? 6 : 5);
 
-template <int NPL, int SPS, bool ACC = false>
+template <int NPL, int SPS, bool ACC = false, bool EN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS>, kRx4Waves<NPL, SPS>)))
 void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
@@ -2667,7 +2671,7 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 	// which shortens the critical path of a wave to a quarter
 	const int g0 = blockIdx.x * bpw;
 	int n_end = min(a.n, g0 + bpw);
-	if (a.seg_count) {
+	if (EN && a.seg_count) {
 		// bursts listed in segments with unused slots at each segment's end (the receive loop's CCCH lists)
 		const int sg = g0 / a.seg_stride;
 		n_end = min(n_end, sg * a.seg_stride + a.seg_count[sg]);
@@ -2680,7 +2684,7 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 #endif
 	                 a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
-	rx4_body<NPL, SPS, false, false, false, ACC>(a, io, stage_samples, cw, g0, n_end, lds_raw, (int)threadIdx.x);
+	rx4_body<NPL, SPS, false, false, false, ACC, EN>(a, io, stage_samples, cw, g0, n_end, lds_raw, (int)threadIdx.x);
 }
 
 // demodulation only, one burst format per launch, four bursts per wavefront (rx4_body<..., GEN>)
@@ -3277,10 +3281,19 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 			}
 			const int bpw = bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4);
 			const int grid4 = (a.n + bpw - 1) / bpw;
-			if (a.conv_acc)
-				hipLaunchKernelGGL((k_rx4<NPL, SPS, true>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
-			else
-				hipLaunchKernelGGL((k_rx4<NPL, SPS>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+			// (the instantiation with the burst energy and the segment bound is the receive loop's: see rx4_body's EN)
+			const bool en = a.energy != nullptr || a.seg_count != nullptr;
+			if (a.conv_acc) {
+				if (en)
+					hipLaunchKernelGGL((k_rx4<NPL, SPS, true, true>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+				else
+					hipLaunchKernelGGL((k_rx4<NPL, SPS, true, false>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+			} else {
+				if (en)
+					hipLaunchKernelGGL((k_rx4<NPL, SPS, false, true>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+				else
+					hipLaunchKernelGGL((k_rx4<NPL, SPS, false, false>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+			}
 		}
 	} else {
 		hipLaunchKernelGGL((k_rx<NPL, SPS, false>), dim3(a.n), dim3(64), lds, stream, a, max_in_len, max_len);
