@@ -140,6 +140,8 @@ def test_no_cpu_fallback(pkg):
     with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
         pkg.api.xch_dc12_decode_batch(np.zeros((2, 432), np.int8))
     with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
+        pkg.api.tch3_rx_batch(np.zeros(1024, np.complex64), [0, 480], 474)
+    with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
         pkg.api.rach_decode_batch(np.zeros((2, 494), np.int8), 0)
     with pytest.raises(pkg.api.Gmr1HipError, match="-19"):
         pkg.api.xch_dc12_decode(np.zeros(432, np.int8))
