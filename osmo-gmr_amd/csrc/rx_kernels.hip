@@ -1275,6 +1275,127 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 		k5_12_survivors_crc(surv, ubits, lane, syn_o, dp);
 }
 
+// The K=5 rate-1/2 decoder shaped for the LATENCY of one burst (the receive loop: a wave alone on its SIMD issues one
+// instruction every four to five cycles whatever the dependences, so a round costs what its instruction count says).
+// The batch decoder above spends 7 instructions per trellis step (wait, add, add-dpp, min, add of the next tie-break bit, two
+// cost-byte reads).  Here a step's operands come ready-made from a table the branch-metric phase expands once per burst:
+// per step and code word two 8-byte entries (this lane the HIGH predecessor or not) -- both generators have the D^0 and D^4
+// taps, so the partner's code word is the own one's complement -- holding  own cost << 16 | tie-break bit if this lane is the
+// HIGH predecessor,  partner's cost << 16 | tie-break bit if the partner is.  One ds_read_b64 and three VALU per step: 5
+// instructions.  212 x 64 B of LDS, which only the loop (one burst per work-group) can afford.  Arithmetic, ties and
+// decisions are the batch decoder's.
+static constexpr bool dec_partner_is_complement()
+{
+	const DecTable t = make_dec();
+	for (int loc = 0; loc < 16; loc++)
+		for (int ph = 0; ph < 4; ph++)
+			if (((t.v[loc] >> (8 + 2 * ph)) & 3u) != (((t.v[loc] >> (2 * ph)) & 3u) ^ 3u))
+				return false;
+	return true;
+}
+static_assert(dec_partner_is_complement(), "the partner transition's code word must be the own one's complement");
+typedef uint32_t lat_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kLatTabBytes = kSteps12 * 64;
+#define ACSL_CORE(PH)                                                                              \
+	"s_waitcnt lgkmcnt(%[wt])\n\t"                                                                  \
+	"v_add_u32 %[t1], %[w], %[r]\n\t"                                                               \
+	"v_add_u32_dpp %[t2], %[w], %[q] " GMR1_DPP_PH##PH " row_mask:0xf bank_mask:0xf\n\t"            \
+	"v_min_u32 %[w], %[t1], %[t2]\n\t"
+#define ACSL_PF(J, PH, WAIT)                                                                       \
+	asm volatile(ACSL_CORE(PH)                                                                     \
+	             "ds_read_b64 %[rqn], %[a] offset:%[off]\n\t"                                       \
+	             : [w] "+v"(w), [rqn] "=v"(RQ[((J) + 8) & 15]), [t1] "=&v"(t1), [t2] "=&v"(t2)        \
+	             : [r] "v"(RQ[J].x), [q] "v"(RQ[J].y), [a] "v"(A[PH]), [off] "i"(16 * ((J) + 8)), [wt] "i"(WAIT))
+#define ACSL_NP(J, PH, WAIT)                                                                       \
+	asm volatile(ACSL_CORE(PH)                                                                     \
+	             : [w] "+v"(w), [t1] "=&v"(t1), [t2] "=&v"(t2)                                       \
+	             : [r] "v"(RQ[J].x), [q] "v"(RQ[J].y), [wt] "i"(WAIT))
+#define ACSL_LOAD(J, PH, K)                                                                        \
+	asm volatile("ds_read_b64 %[rqn], %[a] offset:%[off]\n\t" : [rqn] "=v"(RQ[J]) : [a] "v"(A[PH]), [off] "i"(16 * (K)))
+
+// one step's eight entries from its cost word (byte j = cost of code word j): cls = 2 * code word + HIGH
+__device__ __forceinline__ void lat_expand_step(uint32_t *__restrict__ tab, int k, uint32_t word)
+{
+	const uint32_t bit = 1u << (k < 4 ? k : ((k - 4) & 15));
+	const uint32_t c0 = (word << 16) & 0x00ff0000u, c1 = (word << 8) & 0x00ff0000u, c2 = word & 0x00ff0000u,
+	               c3 = (word >> 8) & 0x00ff0000u;
+	// code-word-major ([j][step], 16 bytes each: not HIGH {c_j, c_(3-j) | bit}, HIGH {c_j | bit, c_(3-j)}): lanes own
+	// consecutive steps, so a wave's 16-byte writes are consecutive in LDS (step-major they were 64 bytes apart: eight-way
+	// bank conflicts, 1 400 cycles)
+	uint4 *d = reinterpret_cast<uint4 *>(tab) + k;
+	d[0 * kSteps12] = make_uint4(c0, c3 | bit, c0 | bit, c3);
+	d[1 * kSteps12] = make_uint4(c1, c2 | bit, c1 | bit, c2);
+	d[2 * kSteps12] = make_uint4(c2, c1 | bit, c2 | bit, c1);
+	d[3 * kSteps12] = make_uint4(c3, c0 | bit, c3 | bit, c0);
+}
+
+template <bool ACC = false>
+__device__ void decode1_k5_12_lat(const uint32_t *__restrict__ tab, uint64_t *__restrict__ surv,
+                                  uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae,
+                                  const DecPre *dp)
+{
+	typedef __attribute__((address_space(3))) const unsigned char lds_cbyte;
+	const uint32_t loc = (uint32_t)lane & 15u;
+	const uint32_t dc = dp->dc;
+	const uint32_t base = (uint32_t)(uintptr_t)(lds_cbyte *)tab;
+	uint32_t A[4];              // LDS byte address of this lane's entry in step 0 of the phase
+	bool hi[4];
+#pragma unroll
+	for (int ph = 0; ph < 4; ph++) {
+		hi[ph] = ((dc >> (16 + ph)) & 1u) != 0;
+		A[ph] = base + (uint32_t)(kSteps12 * 16) * ((dc >> (2 * ph)) & 3u) + (hi[ph] ? 8u : 0u);
+	}
+	lat_u32x2 RQ[16];
+	uint32_t w = loc ? (ACC ? kAccLeadK5r2 << 16 : kSentinel) : 0u;
+	uint32_t t1, t2;
+	uint16_t *dump = reinterpret_cast<uint16_t *>(surv) + lane;
+
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	// steps 0..3: the decisions are u[-4..-1], dropped
+	ACSL_LOAD(0, 0, 0); ACSL_LOAD(1, 1, 1); ACSL_LOAD(2, 2, 2); ACSL_LOAD(3, 3, 3);
+	ACSL_NP(0, 0, 3); ACSL_NP(1, 1, 2); ACSL_NP(2, 2, 1); ACSL_NP(3, 3, 0);
+	w &= 0xffff0000u;
+#pragma unroll
+	for (int ph = 0; ph < 4; ph++)
+		A[ph] += 4 * 16;
+	// window pipeline: the operands of 8 steps are always in flight
+	ACSL_LOAD(0, 0, 0); ACSL_LOAD(1, 1, 1); ACSL_LOAD(2, 2, 2); ACSL_LOAD(3, 3, 3);
+	ACSL_LOAD(4, 0, 4); ACSL_LOAD(5, 1, 5); ACSL_LOAD(6, 2, 6); ACSL_LOAD(7, 3, 7);
+#pragma unroll 1
+	for (int m = 0; m < 12; m++) {
+		ACSL_PF(0, 0, 7); ACSL_PF(1, 1, 7); ACSL_PF(2, 2, 7); ACSL_PF(3, 3, 7);
+		ACSL_PF(4, 0, 7); ACSL_PF(5, 1, 7); ACSL_PF(6, 2, 7); ACSL_PF(7, 3, 7);
+		ACSL_PF(8, 0, 7); ACSL_PF(9, 1, 7); ACSL_PF(10, 2, 7); ACSL_PF(11, 3, 7);
+		ACSL_PF(12, 0, 7); ACSL_PF(13, 1, 7); ACSL_PF(14, 2, 7); ACSL_PF(15, 3, 7);
+		dump[m * 64] = (uint16_t)w;
+		w &= 0xffff0000u;
+#pragma unroll
+		for (int ph = 0; ph < 4; ph++)
+			A[ph] += 16 * 16;
+	}
+	// window 12: steps 196..211, the last four are the flush (generic decoder: b = 0 transitions only -- the lanes whose new
+	// state ends in 1 become unreachable)
+	ACSL_PF(0, 0, 7); ACSL_PF(1, 1, 7); ACSL_PF(2, 2, 7); ACSL_PF(3, 3, 7);
+	ACSL_PF(4, 0, 7); ACSL_PF(5, 1, 7); ACSL_PF(6, 2, 7); ACSL_PF(7, 3, 7);
+	ACSL_NP(8, 0, 7); ACSL_NP(9, 1, 6); ACSL_NP(10, 2, 5); ACSL_NP(11, 3, 4);
+	if constexpr (ACC) {
+		ACSL_NP(12, 0, 3); ACSL_NP(13, 1, 2); ACSL_NP(14, 2, 1); ACSL_NP(15, 3, 0);
+		(void)hi;
+	} else {
+		ACSL_NP(12, 0, 3);
+		w = hi[0] ? kSentinel : w;
+		ACSL_NP(13, 1, 2);
+		w = hi[1] ? kSentinel : w;
+		ACSL_NP(14, 2, 1);
+		w = hi[2] ? kSentinel : w;
+		ACSL_NP(15, 3, 0);
+		w = hi[3] ? kSentinel : w;
+	}
+	dump[12 * 64] = (uint16_t)w;
+	final_ae = ACC ? 0u : w >> 16;
+	k5_12_survivors_crc_lat(surv, ubits, lane, syn_o, dp);
+}
+
 // Tail of the decoder shaped for the LATENCY of one burst (the receive loop: one burst per wave, nothing to overlap with):
 // the 13 window words of every location are read at once and the survivor chain is walked with v_readlane on scalars --
 // 13 dependent LDS round trips become one.  Row 0 only; the CRC as in k5_12_survivors_crc.
@@ -1758,6 +1879,7 @@ struct LatPre {
 	const unsigned char *lut = nullptr;
 	const uint32_t *steps = nullptr;       // [2][kSteps12]
 	const uint32_t *cost_a = nullptr, *cost_b = nullptr;   // [512] each
+	uint32_t *vtab = nullptr;              // LDS: the decoder's per-step operand table (decode1_k5_12_lat), kLatTabBytes
 	uint32_t dc = 0;
 	uint4 sy0, sy1;
 };
@@ -2623,7 +2745,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const uint32_t stw = pre->steps[chain * kSteps12 + k];
 				const uint32_t ia = (uint32_t)(uint8_t)L.eb[stw & 0x3ffu] | ((stw >> 2) & 0x100u);
 				const uint32_t ib = (uint32_t)(uint8_t)L.eb[(stw >> 16) & 0x3ffu] | ((stw >> 18) & 0x100u);
-				L.bm[k] = ok ? pre->cost_a[ia] + pre->cost_b[ib] : 0u;
+				lat_expand_step(pre->vtab, k, ok ? pre->cost_a[ia] + pre->cost_b[ib] : 0u);
 			}
 		}
 		dpre.dc = pre->dc; dpre.sy0 = pre->sy0; dpre.sy1 = pre->sy1;
@@ -2636,7 +2758,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		return;
 	uint32_t syn, fae;
 	if constexpr (LAT)
-		decode4_k5_12<ACC, true>(L.bm, L.surv, L.ubits, lane, syn, fae, &dpre);
+		decode1_k5_12_lat<ACC>(pre->vtab, L.surv, L.ubits, lane, syn, fae, &dpre);
 	else
 		decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae, nullptr);
 	GMR1_STAMP(7);
@@ -2659,11 +2781,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 
 // resident waves per SIMD each instantiation is compiled for: the headline one (windows <= 1024 samples at sps 4) fits six
 // without spilling, the run-time-sps one five; the long windows (sps 8: 32 samples per lane) need the registers of three
-template <int NPL, int SPS>
-constexpr int kRx4Waves = NPL > 16 ? 3 : (SPS == 4 ? 6 : 5);
+// (the receive loop's instantiation, EN, keeps the window registers for the burst energy: five)
+template <int NPL, int SPS, bool EN = false>
+constexpr int kRx4Waves = NPL > 16 ? 3 : ((SPS == 4 && !EN) ? 6 : 5);
 
 template <int NPL, int SPS, bool ACC = false, bool EN = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS>, kRx4Waves<NPL, SPS>)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS, EN>, kRx4Waves<NPL, SPS, EN>)))
 void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -2762,6 +2885,7 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	__shared__ float h_stat[2][4];
 	float2 *h_x[2] = {reinterpret_cast<float2 *>(lds_raw + lds_body),
 	                  reinterpret_cast<float2 *>(lds_raw + lds_body) + ((stage_samples + 15) & ~15)};
+	uint32_t *vtab = reinterpret_cast<uint32_t *>(h_x[1] + ((stage_samples + 15) & ~15));      // the decoder's operand table
 	const int wave = (int)threadIdx.x >> 6;
 	// operands and results of the round's BCCH burst
 	__shared__ uint64_t s_off[1];
@@ -2823,6 +2947,7 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	pre.steps = s_steps;
 	pre.cost_a = s_cost_a;
 	pre.cost_b = s_cost_b;
+	pre.vtab = vtab;
 	pre.dc = c_dec.v[lane & 15];
 	pre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
 	pre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
@@ -3378,7 +3503,8 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	size_t off4[4];
 	const size_t lds = (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
 	const dim3 grid((unsigned)n_chains), block(128);
-	const size_t lds_h = 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2);      // the helper wave's two staged windows
+	// the helper wave's two staged windows, then the latency decoder's operand table
+	const size_t lds_h = 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
 	// 1. the feedback chains
 #define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                \
 	do {                                                                                                         \
