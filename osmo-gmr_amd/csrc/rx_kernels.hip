@@ -1189,7 +1189,22 @@ __device__ __forceinline__ void k5_12_survivors_crc_lat(uint64_t *__restrict__ s
 // c_cost_acc): every start state is allowed, state 0 leading by 127 * N * K; the four flush steps are ordinary
 // butterflies (the survivor walk still starts in state 0); no path metric is returned.  Ties between the two paths into
 // a state fall to the same (lower) predecessor in both decoders.
-struct DecPre { uint32_t dc; uint4 sy0, sy1; };     // the decoder's per-lane constants, when the caller keeps them (receive loop)
+struct DecPre {                                    // the decoder's per-lane constants, when the caller keeps them (receive loop)
+	uint32_t dc;
+	uint4 sy0, sy1;
+#ifdef GMR1_HIP_PROFILE
+	unsigned long long *stamp = nullptr;
+#endif
+};
+#ifdef GMR1_HIP_PROFILE
+#define GMR1_DSTAMP(dp, k, lane)                                             \
+	do {                                                                    \
+		if ((dp)->stamp && (lane) == 0)                                     \
+			(dp)->stamp[k] = __builtin_readcyclecounter();                  \
+	} while (0)
+#else
+#define GMR1_DSTAMP(dp, k, lane) do { } while (0)
+#endif
 
 template <bool ACC = false, bool LATW = false>
 __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restrict__ surv,
@@ -1393,6 +1408,7 @@ __device__ void decode1_k5_12_lat(const uint32_t *__restrict__ tab, uint64_t *__
 	}
 	dump[12 * 64] = (uint16_t)w;
 	final_ae = ACC ? 0u : w >> 16;
+	GMR1_DSTAMP(dp, 12, lane);
 	k5_12_survivors_crc_lat(surv, ubits, lane, syn_o, dp);
 }
 
@@ -1429,6 +1445,7 @@ __device__ __forceinline__ void k5_12_survivors_crc_lat(uint64_t *__restrict__ s
 		}
 	}
 	WSYNC();
+	GMR1_DSTAMP(dp, 13, lane);
 	// CRC16 over the 208 decoded bits, 13 bits per lane of the row, XOR-reduced with DPP (as in k5_12_survivors_crc)
 	uint32_t syn = 0;
 	{
@@ -2310,14 +2327,53 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const float *cr = L.corr + (LAT ? 0 : row) * cw;          // FAC: moved to the second array for the second sequence
 	const int w_p = LAT ? __builtin_amdgcn_readlane(w_r, 0) : w_r;
 	const int tl_p = LAT ? F::tl(c_types[__builtin_amdgcn_readlane(type_r, 0)], __builtin_amdgcn_readlane(kind_r, 0)) : F::tl(bt_r, kind_r);
-	const int win = w_p < 3 ? w_p : 3;
+	// (LAT: the loop's windows have 10 * sps + 1 or 20 * sps + 1 lags -- a constant lets the two little loops below unroll)
+	const int win = LAT ? 3 : (w_p < 3 ? w_p : 3);
 	float toa_r = 0.f, p_pwr = 0.f;                    // pi4cxpsk.c:227-237: the best sequence so far
 	int sid_r = -1;
 	for (int sq = 0; sq < (FAC ? 2 : 1); sq++) {
 		if (FAC)
 			cr = L.corr + row * cw + sq * cwh;
+		GMR1_STAMP(10);
+		int mi;
+		if constexpr (LAT) {
+			// the one burst's <= 128 lags, two per lane: the largest window energy as a 32-bit maximum (a non-negative float's
+			// bits order like its value) by four DPP steps and four v_readlane, then the LOWEST lag that has it from two ballots
+			// -- what the 64-bit (energy, ~index) keys of the batch form decide, in a quarter of the instructions
+			constexpr int NH = SPS == 4 ? 2 : 3;              // 81 lags at sps 4, <= 161 at sps 8
+			uint32_t eb2[NH];
+			bool ok2[NH];
+			uint32_t mx = 0;
+#pragma unroll
+			for (int h = 0; h < NH; h++) {
+				const int m = lane + 64 * h;
+				ok2[h] = m + win <= w_p;
+				float e = 0.f;
+				for (int k = 0; k < win; k++) {
+					const float c = cr[ok2[h] ? m + k : 0];
+					e += c * c;
+				}
+				eb2[h] = ok2[h] ? __builtin_bit_cast(uint32_t, e) : 0u;
+				mx = eb2[h] > mx ? eb2[h] : mx;
+			}
+			uint32_t o;
+			o = dpp<0xB1>(mx); mx = o > mx ? o : mx;
+			o = dpp<0x4E>(mx); mx = o > mx ? o : mx;
+			o = dpp<0x141>(mx); mx = o > mx ? o : mx;
+			o = dpp<0x140>(mx); mx = o > mx ? o : mx;
+			const uint32_t m01 = max((uint32_t)__builtin_amdgcn_readlane((int)mx, 0), (uint32_t)__builtin_amdgcn_readlane((int)mx, 16));
+			const uint32_t m23 = max((uint32_t)__builtin_amdgcn_readlane((int)mx, 32), (uint32_t)__builtin_amdgcn_readlane((int)mx, 48));
+			const uint32_t M = max(m01, m23);
+			mi = 0;
+#pragma unroll
+			for (int h = NH - 1; h >= 0; h--) {
+				const unsigned long long bh = __ballot(ok2[h] && eb2[h] == M);
+				if (bh)
+					mi = 64 * h + __builtin_ctzll(bh);
+			}
+		} else {
 		unsigned long long key = 0;
-		for (int m = LAT ? lane : col; m + win <= w_p; m += LAT ? 64 : 16) {
+		for (int m = col; m + win <= w_p; m += 16) {
 			float e = 0.f;
 			for (int k = 0; k < win; k++) {
 				const float c = cr[m + k];
@@ -2330,15 +2386,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		key = row_max_u64<2>(key);
 		key = row_max_u64<4>(key);
 		key = row_max_u64<8>(key);
-		if (LAT) {                                        // the four rows searched the one burst's lags together
-			unsigned long long o = __shfl_xor(key, 16);
-			key = o > key ? o : key;
-			o = __shfl_xor(key, 32);
-			key = o > key ? o : key;
+		mi = (int)(~(uint32_t)key);
 		}
-		int mi = (int)(~(uint32_t)key);
 		if (mi < 0 || mi + win > w_p)
 			mi = 0;
+		GMR1_STAMP(11);
 		int p = mi;
 		{
 			float pe = -1.f;
@@ -2749,6 +2801,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 		dpre.dc = pre->dc; dpre.sy0 = pre->sy0; dpre.sy1 = pre->sy1;
+#ifdef GMR1_HIP_PROFILE
+		dpre.stamp = io.stamp;
+#endif
 	} else {
 		branch_metrics4_k5_12<ACC>(L.eb, 432, row_ok, row_chain, L.bm, lane);
 	}

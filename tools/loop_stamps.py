@@ -50,3 +50,5 @@ for k in range(1, 8):
     print(f"  {names[k]:34s} {t[k] - t[0]:8d}  (+{t[k] - t[k - 1]})")
 print(f"  inside the timing phase: coarse peak found at {t[8] - t[0]} (+{t[8] - t[2]}), nine halvings done at {t[9] - t[0]} (+{t[9] - t[8]}), "
       f"peak value + bookkeeping +{t[3] - t[9]}")
+print(f"  finer: parameters looked up at +{t[10] - t[2]} of the timing phase, window argmax reduced at +{t[11] - t[2]}, coarse peak at +{t[8] - t[2]}; "
+      f"decoder: forward pass {t[12] - t[6]}, survivor walk {t[13] - t[12]}, CRC + results {t[7] - t[13]}")
