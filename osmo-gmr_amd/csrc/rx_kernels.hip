@@ -1312,7 +1312,9 @@ static_assert(dec_partner_is_complement(), "the partner transition's code word m
 typedef uint32_t lat_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kLatTabBytes = kSteps12 * 64;
 #define ACSL_CORE(PH)                                                                              \
+	".if %[wt] >= 0\n\t"                                                                            \
 	"s_waitcnt lgkmcnt(%[wt])\n\t"                                                                  \
+	".endif\n\t"                                                                                    \
 	"v_add_u32 %[t1], %[w], %[r]\n\t"                                                               \
 	"v_add_u32_dpp %[t2], %[w], %[q] " GMR1_DPP_PH##PH " row_mask:0xf bank_mask:0xf\n\t"            \
 	"v_min_u32 %[w], %[t1], %[t2]\n\t"
@@ -1378,10 +1380,11 @@ __device__ void decode1_k5_12_lat(const uint32_t *__restrict__ tab, uint64_t *__
 	ACSL_LOAD(4, 0, 4); ACSL_LOAD(5, 1, 5); ACSL_LOAD(6, 2, 6); ACSL_LOAD(7, 3, 7);
 #pragma unroll 1
 	for (int m = 0; m < 12; m++) {
-		ACSL_PF(0, 0, 7); ACSL_PF(1, 1, 7); ACSL_PF(2, 2, 7); ACSL_PF(3, 3, 7);
-		ACSL_PF(4, 0, 7); ACSL_PF(5, 1, 7); ACSL_PF(6, 2, 7); ACSL_PF(7, 3, 7);
-		ACSL_PF(8, 0, 7); ACSL_PF(9, 1, 7); ACSL_PF(10, 2, 7); ACSL_PF(11, 3, 7);
-		ACSL_PF(12, 0, 7); ACSL_PF(13, 1, 7); ACSL_PF(14, 2, 7); ACSL_PF(15, 3, 7);
+		// (one wait per four steps: eight loads are in flight, the four oldest must have landed)
+		ACSL_PF(0, 0, 4); ACSL_PF(1, 1, -1); ACSL_PF(2, 2, -1); ACSL_PF(3, 3, -1);
+		ACSL_PF(4, 0, 4); ACSL_PF(5, 1, -1); ACSL_PF(6, 2, -1); ACSL_PF(7, 3, -1);
+		ACSL_PF(8, 0, 4); ACSL_PF(9, 1, -1); ACSL_PF(10, 2, -1); ACSL_PF(11, 3, -1);
+		ACSL_PF(12, 0, 4); ACSL_PF(13, 1, -1); ACSL_PF(14, 2, -1); ACSL_PF(15, 3, -1);
 		dump[m * 64] = (uint16_t)w;
 		w &= 0xffff0000u;
 #pragma unroll
@@ -1390,20 +1393,20 @@ __device__ void decode1_k5_12_lat(const uint32_t *__restrict__ tab, uint64_t *__
 	}
 	// window 12: steps 196..211, the last four are the flush (generic decoder: b = 0 transitions only -- the lanes whose new
 	// state ends in 1 become unreachable)
-	ACSL_PF(0, 0, 7); ACSL_PF(1, 1, 7); ACSL_PF(2, 2, 7); ACSL_PF(3, 3, 7);
-	ACSL_PF(4, 0, 7); ACSL_PF(5, 1, 7); ACSL_PF(6, 2, 7); ACSL_PF(7, 3, 7);
-	ACSL_NP(8, 0, 7); ACSL_NP(9, 1, 6); ACSL_NP(10, 2, 5); ACSL_NP(11, 3, 4);
+	ACSL_PF(0, 0, 4); ACSL_PF(1, 1, -1); ACSL_PF(2, 2, -1); ACSL_PF(3, 3, -1);
+	ACSL_PF(4, 0, 4); ACSL_PF(5, 1, -1); ACSL_PF(6, 2, -1); ACSL_PF(7, 3, -1);
+	ACSL_NP(8, 0, 4); ACSL_NP(9, 1, -1); ACSL_NP(10, 2, -1); ACSL_NP(11, 3, -1);
 	if constexpr (ACC) {
-		ACSL_NP(12, 0, 3); ACSL_NP(13, 1, 2); ACSL_NP(14, 2, 1); ACSL_NP(15, 3, 0);
+		ACSL_NP(12, 0, 0); ACSL_NP(13, 1, -1); ACSL_NP(14, 2, -1); ACSL_NP(15, 3, -1);
 		(void)hi;
 	} else {
-		ACSL_NP(12, 0, 3);
+		ACSL_NP(12, 0, 0);
 		w = hi[0] ? kSentinel : w;
-		ACSL_NP(13, 1, 2);
+		ACSL_NP(13, 1, -1);
 		w = hi[1] ? kSentinel : w;
-		ACSL_NP(14, 2, 1);
+		ACSL_NP(14, 2, -1);
 		w = hi[2] ? kSentinel : w;
-		ACSL_NP(15, 3, 0);
+		ACSL_NP(15, 3, -1);
 		w = hi[3] ? kSentinel : w;
 	}
 	dump[12 * 64] = (uint16_t)w;
