@@ -2607,8 +2607,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				nnv[h] = nn;
 			}
 		}
-		fetch(3, first);
-		fetch(2, second);
+		if constexpr (LAT) {
+			fetch(0, first);            // the one burst's kept samples travel during the whole sync-term phase
+		} else {
+			fetch(3, first);
+			fetch(2, second);
+		}
 #pragma unroll
 		for (int h = 0; h < NSH; h++) {
 			if (chn[h] >= 0) {
@@ -2698,9 +2702,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 #pragma unroll
 	for (int q = 3; q >= 0; q--) {
 		const int g = g0 + q;
-		const Sym4 cur = nxt1;
-		nxt1 = nxt2;
-		fetch(q - 2, nxt2);             // the samples of burst q - 2 travel while q and q - 1 are worked on
+		Sym4 cur;
+		if constexpr (LAT) {
+			if (q != 0)
+				continue;
+			cur = first;
+		} else {
+			cur = nxt1;
+			nxt1 = nxt2;
+			fetch(q - 2, nxt2);         // the samples of burst q - 2 travel while q and q - 1 are worked on
+		}
 		if (g >= n_end)
 			continue;
 		const int src = 16 * q;
