@@ -317,11 +317,11 @@ def run_rx_workload(args):
            "roofline": None}
     # The loop is a chain of dependent bursts per carrier (the next BCCH window is placed by the previous one's timing
     # and frequency): latency-bound by construction.  The figure below prices only what it has to read -- the windows of
-    # the frames it decoded -- over the whole step (acquisition + k_rx_loop + record collection), to show how far from
+    # the frames it decoded -- over the whole step (acquisition + k_rx_chain / k_rx4 / k_rx_merge + record collection), to show how far from
     # the HBM roofline a feedback loop sits; it is not a kernel-quality number.
     alg = float(found) * 7893.7
     step_s = wall / args.steps
-    out["roofline"] = {"bound": "hbm", "kernel": "k_rx_loop (+ FCCH acquisition), whole step", "achieved": alg / step_s / 1e9,
+    out["roofline"] = {"bound": "hbm", "kernel": "k_rx_chain + k_rx4 + k_rx_merge (+ FCCH acquisition), whole step", "achieved": alg / step_s / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                        "kernel_ms": step_s * 1e3, "algorithmic_bytes_per_launch": alg,
                        "note": "latency-bound feedback chain: 188 dependent BCCH bursts per carrier-minute"}

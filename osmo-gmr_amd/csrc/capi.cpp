@@ -811,7 +811,7 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 	return 0;
 }
 
-// process_bcch of n_chains chains in one launch (k_rx_loop); every pointer in `la` is device memory
+// process_bcch of n_chains chains (launch_rx_loop: k_rx_chain, k_rx4, k_rx_merge); every pointer in `la` is device memory
 int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la)
 {
 	if (n_chains < 0 || !iq || !la.state || !la.rec || !la.n_rounds || !la.n_rec || !la.n_frames || la.max_rounds < 1 ||

@@ -52,7 +52,7 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           float *toa, float *freq_err, float *energy,
                           int8_t *ebits, float *ssyms, int32_t *rv);
 
-// process_bcch of n_chains chains in one launch (capi.cpp / k_rx_loop); every pointer in `la` is device memory
+// process_bcch of n_chains chains in one launch (capi.cpp / launch_rx_loop); every pointer in `la` is device memory
 int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la);
 
 // TCH9 bursts of several interleaver runs of unequal length in one launch (capi_nt9.cpp)

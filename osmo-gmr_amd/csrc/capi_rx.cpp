@@ -7,10 +7,10 @@
 // only writer of align / freq_err / fn / sa_*), so between two BCCH frames of one chain every
 // burst is independent, and different chains / carriers are independent throughout.  The frame
 // loop therefore runs in ROUNDS -- a chain's CCCH bursts up to and including its next BCCH burst,
-// one wavefront each, then the BCCH feedback -- and it runs them ON THE GPU: one launch of
-// k_rx_loop (rx_kernels.hip), one work-group per chain, from the first frame to the end of the
-// capture; it writes the records itself (the integer control logic is in rx_loop.h) and the host
-// only collects them.  FCCH acquisition is three batched sweeps
+// then the BCCH feedback -- and it runs them ON THE GPU: k_rx_chain (rx_kernels.hip) walks every
+// chain's feedback path from the first frame to the end of the capture and lists its CCCH bursts, one
+// k_rx4 batch takes those, k_rx_merge writes the records (the integer control logic is in rx_loop.h);
+// the host only collects them.  FCCH acquisition is three batched sweeps
 // (rough / rough_multi / fine + snr) over all carriers.  The arithmetic of every step runs on the
 // GPU; the host keeps only the per-chain integers the reference keeps in struct chan_desc.
 // There is no CPU fallback.
@@ -388,10 +388,10 @@ int RxRun::acquire()
 int RxRun::frame_loop()
 {
 	// ---- process_bcch (gmr1_rx.c:852-895) for every chain ------------------------------------------
-	// One launch: k_rx_loop walks each chain through all of its frames on the GPU (rounds of CCCH bursts
-	// up to the next BCCH burst, whose result feeds back before the next round; rx_loop.h) and writes what
-	// the reference hands to GSMTAP -- the records, in frame order -- plus, when a traffic pass follows, the
-	// per-frame context rx_tch3 sees.  The host only collects them.
+	// Three launches (launch_rx_loop): k_rx_chain walks each chain through all of its frames on the GPU (rounds of
+	// CCCH bursts up to the next BCCH burst, whose result feeds back before the next round; rx_loop.h), k_rx4 takes the
+	// CCCH bursts it listed, k_rx_merge writes what the reference hands to GSMTAP -- the records, in frame order -- plus,
+	// when a traffic pass follows, the per-frame context rx_tch3 sees.  The host only collects them.
 	const int nc = (int)chains.size();
 	if (!nc)
 		return 0;

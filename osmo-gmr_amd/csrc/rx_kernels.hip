@@ -12,15 +12,16 @@
 //   k_rx4                  : the default fused BCCH / CCCH kernel: the same arithmetic with the
 //                            serial phases (timing bisection, sync-symbol terms) done once for
 //                            the four bursts of a wave, one burst per 16-lane row.
-//   k_rx_loop              : the frame loop of gmr1_rx (process_bcch, src/gmr1_rx.c:852-895) for one chain
-//                            per work-group of eight waves, all frames of the capture in one launch: the
-//                            body of k_rx4 (rx4_body) per burst, BCCH feedback, records written in place.
+//   k_rx_chain, k_rx_merge : the frame loop of gmr1_rx (process_bcch, src/gmr1_rx.c:852-895): k_rx_chain walks the
+//                            BCCH feedback chain of one chain per work-group (rx4_body in its latency shape) and
+//                            lists the CCCH bursts, k_rx4 takes those as one batch, k_rx_merge writes the records.
+//   k_rx4g, k_rx4g_tch3    : demodulation only, four bursts per wave; with the TCH3 decoder behind it (tch3_body.h).
 //   k_detect, k_mod_order  : gmr1_pi4cxpsk_detect / _mod_order (pi4cxpsk.c:617-729).
 //   k_l1                   : the layer-1 chain alone on soft bits read from HBM.
 //
 // Design notes (DESIGN.md has the long form):
 //   * Work-groups are single 64-lane wavefronts: every hand-off goes through the
-//     wave's own LDS slice and needs no s_barrier (k_rx_loop: eight of them, two barriers per round).
+//     wave's own LDS slice and needs no s_barrier (k_rx_chain: two waves, one barrier per round).
 //   * Samples are loaded once from HBM with coalesced 8-byte-per-lane loads, DC /
 //     power normalised in registers and parked in LDS; everything else reads LDS.
 //   * Burst formats live in __constant__ memory and are read with scalar loads.
@@ -1820,7 +1821,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 }
 
 // The body works on bursts g0 .. n_end-1 (at most four) of `a` with one wavefront and its own LDS slice;
-// k_rx4 is the batch kernel around it, k_rx_loop (below) the receive loop that calls it round after round.
+// k_rx4 is the batch kernel around it, k_rx_chain (below) the receive loop's feedback chain that calls it round after round.
 // per-burst arrays of a launch: the batch kernel takes them from its arguments, the receive loop points them
 // at the current round's log blocks (by value: they stay in scalar registers)
 #ifdef GMR1_HIP_PROFILE

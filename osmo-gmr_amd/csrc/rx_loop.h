@@ -1,5 +1,5 @@
 // rx_loop.h -- the integer control logic of process_bcch (reference src/gmr1_rx.c:852-895) with its helpers
-// burst_map (:149-170) and bcch_tdma_align (:194-233).  The device runs it inside k_rx_loop (one work-group
+// burst_map (:149-170) and bcch_tdma_align (:194-233).  The device runs it inside k_rx_chain (one work-group
 // walks one chain through ALL of its frames, no host round trip between them); it is host-callable too
 // (tests, sizing).  No signal arithmetic here.
 #pragma once

@@ -1,5 +1,5 @@
 // Host-side exercise of osmo-gmr_amd/csrc/rx_loop.h (the receive loop's integer control logic, which the
-// device runs inside k_rx_loop): walks a chain through a capture and prints every round's bursts, applying a
+// device runs inside k_rx_chain): walks a chain through a capture and prints every round's bursts, applying a
 // scripted BCCH feedback.  tests/test_rx_loop_host.py compares the output with a Python model of
 // process_bcch (reference src/gmr1_rx.c:852-895).
 //   usage: rx_loop_host sps len align fn delay stn toa_step

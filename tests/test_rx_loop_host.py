@@ -1,4 +1,4 @@
-"""CPU test of the receive loop's control logic (osmo-gmr_amd/csrc/rx_loop.h, the code k_rx_loop runs on the
+"""CPU test of the receive loop's control logic (osmo-gmr_amd/csrc/rx_loop.h, the code k_rx_chain runs on the
 GPU): compiled for the host and walked through whole captures, against a Python model written from the
 reference's process_bcch / burst_map / bcch_tdma_align (src/gmr1_rx.c:149-170, 194-233, 852-895)."""
 import os
