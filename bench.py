@@ -324,7 +324,7 @@ def run_rx_workload(args):
     out["roofline"] = {"bound": "hbm", "kernel": "k_rx_chain + k_rx4 + k_rx_merge (+ FCCH acquisition), whole step", "achieved": alg / step_s / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                        "kernel_ms": step_s * 1e3, "algorithmic_bytes_per_launch": alg,
-                       "note": "latency-bound feedback chain: 188 dependent BCCH bursts per carrier-minute"}
+                       "note": "latency-bound feedback chain: 187 dependent BCCH bursts per carrier-minute"}
     if not args.no_cpu:
         oracle_lib.lib()
         tc = time.perf_counter()
@@ -587,7 +587,7 @@ def run_nt3_workload(args):
            "config": {"workload": f"configs[4] from samples: {n} NT3 bursts ({n_s} speech + {n_f} FACCH3 in groups of 4, "
                                   f"{base} distinct, tiled x{reps}), window 474 @ sps 4: pi4cxpsk demod + TCH3 / FACCH3 layer 1"},
            "iq_msamp_per_s": n * 474 * args.steps / wall / 1e6,
-           "roofline": {"bound": "hbm", "kernel": "k_rx<16,4,false> x2 + k_tch3 + k_facch3 (whole step)", "achieved": achieved,
+           "roofline": {"bound": "hbm", "kernel": ("k_rx4g<8,4> + k_tch3" if args.nt3_two_launches else "k_rx4g_tch3") + " + k_rx4g<8,4,FAC> + k_facch3 (whole step)", "achieved": achieved,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "kernel_ms": step_ms, "algorithmic_bytes_per_launch": bytes_per_step},
            "checks": {"workload_gen_s": round(t_gen, 1)}}
