@@ -815,7 +815,7 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la)
 {
 	if (n_chains < 0 || !iq || !la.state || !la.rec || !la.n_rounds || !la.n_rec || !la.n_frames || la.max_rounds < 1 ||
-	    la.rec_stride < 1 || (la.rec_frame && !la.rec_minen) || (la.flog && la.flog_stride < 1) || !la.rounds || !la.n_ccch ||
+	    la.rec_stride < 1 || (la.rec_frame && !la.rec_minen) || (la.flog && la.flog_stride < 1) || !la.rounds || !la.n_ccch || !la.fin || !la.slice_end ||
 	    la.c_stride < 4 || (la.c_stride & 3) || !la.c_off || !la.c_fs || !la.c_kind || !la.c_meta || !la.c_l2 || !la.c_crc ||
 	    !la.c_conv || !la.c_rv || !la.c_en)
 		return fail(-EINVAL, "rx_loop: bad arguments");

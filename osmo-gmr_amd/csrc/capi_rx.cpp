@@ -420,12 +420,13 @@ int RxRun::frame_loop()
 	const size_t fl_bytes = want_ctx ? up128((size_t)nc * max_frames * sizeof(RxLoopFrame)) : 0;
 	const size_t total = rec_bytes + cnt_bytes + st_bytes + 2 * rf_bytes + fl_bytes;
 	// ... and, device only, what passes between the loop's three launches (RxLoopArgs): the round logs, the CCCH lists
-	const int c_stride = (max_frames + 3) & ~3;                // a frame holds at most one burst of the list
+	// (a frame holds at most one burst of the list; each time slice of the walk starts its part at a multiple of four)
+	const int c_stride = ((max_frames + 3) & ~3) + 4 * kLoopSlices;
 	const size_t nslot = (size_t)nc * c_stride;
 	const size_t rl_bytes = up128((size_t)nc * max_rounds * sizeof(RxLoopRound));
 	const size_t s8 = up128(nslot * 8), s4 = up128(nslot * 4), s1 = up128(nslot), s12 = up128(nslot * sizeof(RxLoopCcch)),
 	             s24 = up128(nslot * 24);
-	const size_t scratch = rl_bytes + up128((size_t)nc * 4) + s8 + s4 + s1 + s12 + s24 + 4 * s4;
+	const size_t scratch = rl_bytes + up128((size_t)nc * 4) * (2 + kLoopSlices + 1) + s8 + s4 + s1 + s12 + s24 + 4 * s4;
 	DevState *ds;
 	r = dev_state(&ds);
 	if (r) return r;
@@ -458,6 +459,8 @@ int RxRun::frame_loop()
 		auto take = [&](size_t bytes) { unsigned char *p = q; q += bytes; return p; };
 		la.rounds = reinterpret_cast<RxLoopRound *>(take(rl_bytes));
 		la.n_ccch = reinterpret_cast<int32_t *>(take(up128((size_t)nc * 4)));
+		la.fin = reinterpret_cast<int32_t *>(take(up128((size_t)nc * 4)));
+		la.slice_end = reinterpret_cast<int32_t *>(take(up128((size_t)nc * 4) * (kLoopSlices + 1)));
 		la.c_stride = c_stride;
 		la.c_off = reinterpret_cast<uint64_t *>(take(s8));
 		la.c_fs = reinterpret_cast<float *>(take(s4));

@@ -56,6 +56,8 @@ struct RxArgs {
 	int conv_acc;          // fused path: 1 = libosmocore's accelerated Viterbi decoder (GMR1_HIP_CONV_ACC), 0 = its generic one
 	int seg_stride;        // fused path, with seg_count: the bursts are listed in segments of seg_stride slots (a multiple of 4) ...
 	const int32_t *seg_count;   // ... of which the first seg_count[s] are in use (the receive loop's CCCH lists); NULL: all n
+	const int32_t *seg_first;   // optional, with seg_count: only the slots from seg_first[s] (rounded up to a multiple of 4) on are this launch's
+	int seg_groups;             // with seg_first: groups of four slots the launch covers per segment (its grid is n_segments x seg_groups)
 	const float2 *iq;
 	const uint64_t *offset;
 	const uint8_t *kind;
@@ -87,6 +89,7 @@ struct RxLoopRound {               // what a round leaves for k_rx_merge
 };
 struct RxLoopCcch { int32_t fn, tn, frame; };    // what a CCCH record needs besides the burst kernel's outputs
 
+constexpr int kLoopSlices = 4;     // time slices the chains are walked in (see launch_rx_loop)
 struct RxLoopArgs {
 	RxLoopState *state;            // n_chains: starting states in, final states out
 	gmr1_hip_rx_record *rec;       // n_chains x rec_stride records, frame order per chain
@@ -98,8 +101,10 @@ struct RxLoopArgs {
 	int32_t *n_rounds, *n_rec, *n_frames;   // n_chains each
 	// between the three launches (device scratch)
 	RxLoopRound *rounds;           // n_chains x max_rounds
-	int c_stride;                  // CCCH list slots per chain (a multiple of 4, >= the frames of the longest chain)
+	int c_stride;                  // CCCH list slots per chain (a multiple of 4, >= the frames of the longest chain + 4 per time slice)
 	int32_t *n_ccch;               // n_chains: bursts listed
+	int32_t *fin;                  // n_chains: 1 once the chain has reached the end of its capture
+	int32_t *slice_end;            // (kLoopSlices + 1) x n_chains: list length at the end of each time slice ([0] = zeros)
 	uint64_t *c_off;               // n_chains x c_stride each: the burst kernel's operands ...
 	float *c_fs;
 	uint8_t *c_kind;

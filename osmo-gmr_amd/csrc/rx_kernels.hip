@@ -2862,13 +2862,25 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	// bpw bursts per wavefront: 4 for throughput; 1 when the batch is too small to fill the machine anyway,
 	// which shortens the critical path of a wave to a quarter
-	const int g0 = blockIdx.x * bpw;
+	int g0 = blockIdx.x * bpw;
 	int n_end = min(a.n, g0 + bpw);
 	if (EN && a.seg_count) {
-		// bursts listed in segments with unused slots at each segment's end (the receive loop's CCCH lists)
-		const int sg = g0 / a.seg_stride;
-		n_end = min(n_end, sg * a.seg_stride + a.seg_count[sg]);
-		if (g0 >= n_end)
+		// bursts listed in segments with unused slots at each segment's end (the receive loop's CCCH lists); with seg_first a
+		// launch takes one time slice of every list: block -> (segment, group of four behind the slice's first slot)
+		int sg = g0 / a.seg_stride;
+		int lo = 0;
+		if (a.seg_first) {
+			if (a.seg_groups > 0) {
+				sg = (int)blockIdx.x / a.seg_groups;
+				lo = (a.seg_first[sg] + 3) & ~3;
+				g0 = sg * a.seg_stride + lo + ((int)blockIdx.x % a.seg_groups) * bpw;
+			} else {
+				lo = (a.seg_first[sg] + 3) & ~3;
+			}
+		}
+		const int base = sg * a.seg_stride;
+		n_end = min(min(a.n, g0 + bpw), base + min(a.seg_count[sg], a.seg_stride));
+		if (g0 >= n_end || g0 < base + lo)
 			return;
 	}
 	const RxIo io = {
@@ -2945,7 +2957,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 // What goes to HBM in between is a few dozen bytes per burst (RxLoopRound, RxLoopCcch, the burst kernel's own outputs).
 // ---------------------------------------------------------------------------
 template <int NPL, int SPS, bool ACC = false>
-__global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body)
+__global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body, int slice,
+                                                   int slice_rounds)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	// wave 0 walks the chain; wave 1 (another SIMD) prepares, a round ahead, what depends only on where the next BCCH
@@ -2970,8 +2983,20 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	const int sps = a.sps;
 	if (threadIdx.x < 2)
 		h_off[threadIdx.x] = ~0ull;
+	// this launch walks the chain through one time slice: rounds [round0, round_end) -- it picks up where the previous
+	// slice left the chain (state, counters) and, at its end, notes how long the CCCH list has become (slice_end); the next
+	// slice's entries start at the next multiple of four, so that the batch kernel's groups of four never straddle two slices
+	const int round0 = la.n_rounds[chain];
+	const int round_end = min(round0 + slice_rounds, la.max_rounds);
+	if (la.fin[chain]) {
+		if (threadIdx.x == 0)
+			la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = la.slice_end[(size_t)slice * gridDim.x + chain];
+		return;
+	}
+	// (alone on its SIMD only until the previous slice's CCCH batch arrives on the same CU: the chain goes first)
+	__builtin_amdgcn_s_setprio(3);
 	if (wave == 1) {
-		for (int round = 0; round < la.max_rounds; round++) {
+		for (int round = round0; round < round_end; round++) {
 			__syncthreads();
 			if (!s_go)
 				break;
@@ -2991,7 +3016,7 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
 	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
 	const size_t c_base = (size_t)chain * la.c_stride;
-	int n_frames = 0, n_ccch = 0;
+	int n_frames = la.n_frames[chain], n_ccch = (la.slice_end[(size_t)slice * gridDim.x + chain] + 3) & ~3;
 	auto on_frame = [&](const RxLoopState &x) {
 		if (flog && lane == 0 && n_frames < la.flog_stride)
 			flog[n_frames] = {x.align, x.freq_err, x.fn};
@@ -3022,8 +3047,9 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	pre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
 	pre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
 	WSYNC();
-	int round = 0;
-	for (; round < la.max_rounds; round++) {
+	int round = round0;
+	bool finished = false;
+	for (; round < round_end; round++) {
 		const int frames_at_round = n_frames;
 		const float minen = st.bcch_energy / 2.0f;              // the gate level the round starts with
 		// ---- the round: what rx_loop_build_round does frame after frame, for the usual case (the next sixteen frames all
@@ -3075,8 +3101,10 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 			s_go = n > 0;
 		}
 		__syncthreads();
-		if (n == 0)
+		if (n == 0) {
+			finished = true;
 			break;
+		}
 		const int n_c = has_b ? n - 1 : n;
 		// the CCCH bursts: listed for the batch that follows
 		if (lane < n_c && n_ccch + lane < la.c_stride) {
@@ -3145,6 +3173,8 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 		la.n_ccch[chain] = n_ccch;
 		la.n_frames[chain] = n_frames;
 		la.state[chain] = st;
+		la.fin[chain] = finished ? 1 : 0;
+		la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = min(n_ccch, la.c_stride);
 	}
 }
 
@@ -3474,8 +3504,9 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 				const char *e = profile_env("GMR1_HIP_RX_BPW");
 				bpw_force = e ? atoi(e) : 0;
 			}
-			const int bpw = bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4);
-			const int grid4 = (a.n + bpw - 1) / bpw;
+			const bool sliced = a.seg_first && a.seg_groups > 0 && a.seg_stride > 0;
+			const int bpw = sliced ? 4 : (bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4));
+			const int grid4 = sliced ? (a.n / a.seg_stride) * a.seg_groups : (a.n + bpw - 1) / bpw;
 			// (the instantiation with the burst energy and the segment bound is the receive loop's: see rx4_body's EN)
 			const bool en = a.energy != nullptr || a.seg_count != nullptr;
 			if (a.conv_acc) {
@@ -3562,11 +3593,45 @@ hipError_t launch_rx_tch3(const RxArgs &a, const Tch3Args &t, hipStream_t stream
 	return hipGetLastError();
 }
 
+// the side stream and the events the loop's time slices are chained with, per device (created on first use, kept)
+struct LoopStreams {
+	hipStream_t side = nullptr;
+	hipEvent_t chain_done[kLoopSlices] = {}, side_done = nullptr;
+	bool ok = false;
+};
+static LoopStreams *loop_streams()
+{
+	static LoopStreams per_dev[64];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+		return nullptr;
+	LoopStreams &s = per_dev[dev];
+	if (!s.ok) {
+		if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess)
+			return nullptr;
+		for (int i = 0; i < kLoopSlices; i++)
+			if (hipEventCreateWithFlags(&s.chain_done[i], hipEventDisableTiming) != hipSuccess)
+				return nullptr;
+		if (hipEventCreateWithFlags(&s.side_done, hipEventDisableTiming) != hipSuccess)
+			return nullptr;
+		s.ok = true;
+	}
+	return &s;
+}
+
+// The chains are walked in kLoopSlices time slices (launches of k_rx_chain on the caller's stream, each picking up where the
+// previous one left its chains); the CCCH bursts a slice listed run as a k_rx4 batch on a side stream WHILE the next slice
+// walks on -- the chain kernel keeps one wave per chain busy, the rest of the machine is free --, and the record writer waits
+// for both.  Only the last slice's batch (the shortest: the slices are cut by rounds, and the last one holds what is left)
+// is not hidden.  One call at a time per device (the side stream and its events are the device's).
 hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream)
 {
 	if (n_chains <= 0)
 		return hipSuccess;
-	if (a.in_len[0] > kMaxInLen || a.dbg_stop || la.c_stride < 4 || (la.c_stride & 3))
+	if (a.in_len[0] > kMaxInLen || a.dbg_stop || la.c_stride < 4 || (la.c_stride & 3) || !la.fin || !la.slice_end)
+		return hipErrorInvalidValue;
+	LoopStreams *ls = loop_streams();
+	if (!ls)
 		return hipErrorInvalidValue;
 	const int max_len = 20 * a.sps + 1;
 	const int cw = (max_len + 15) & ~15;
@@ -3575,47 +3640,61 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	const dim3 grid((unsigned)n_chains), block(128);
 	// the helper wave's two staged windows, then the latency decoder's operand table
 	const size_t lds_h = 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
-	// 1. the feedback chains
+	hipError_t e;
+	// counters of the walk: rounds, CCCH list lengths, frames, finished flags, slice ends
+	if ((e = hipMemsetAsync(la.n_rounds, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(la.n_ccch, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(la.n_frames, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(la.fin, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
+	if ((e = hipMemsetAsync(la.slice_end, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
+	const int slice_rounds = (la.max_rounds + kLoopSlices - 1) / kLoopSlices;
 #define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                \
 	do {                                                                                                         \
 		if (a.conv_acc)                                                                                          \
-			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds); \
+			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds, \
+			                   sl, slice_rounds);                                                                \
 		else                                                                                                     \
-			hipLaunchKernelGGL((k_rx_chain<NPL, SPS>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds); \
+			hipLaunchKernelGGL((k_rx_chain<NPL, SPS>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds, \
+			                   sl, slice_rounds);                                                                \
 	} while (0)
-	if (a.in_len[0] <= 1024) {
-		if (a.sps == 4)
-			GMR1_LOOP_LAUNCH(16, 4);
-		else
-			GMR1_LOOP_LAUNCH(16, 0);
-	} else {
-		if (a.sps == 4)
-			GMR1_LOOP_LAUNCH(32, 4);
-		else
-			GMR1_LOOP_LAUNCH(32, 0);
+	for (int sl = 0; sl < kLoopSlices; sl++) {
+		// 1. the feedback chains, one time slice
+		if (a.in_len[0] <= 1024) {
+			if (a.sps == 4)
+				GMR1_LOOP_LAUNCH(16, 4);
+			else
+				GMR1_LOOP_LAUNCH(16, 0);
+		} else {
+			if (a.sps == 4)
+				GMR1_LOOP_LAUNCH(32, 4);
+			else
+				GMR1_LOOP_LAUNCH(32, 0);
+		}
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		// 2. the CCCH bursts it listed, on the side stream
+		if ((e = hipEventRecord(ls->chain_done[sl], stream)) != hipSuccess) return e;
+		if ((e = hipStreamWaitEvent(ls->side, ls->chain_done[sl], 0)) != hipSuccess) return e;
+		RxArgs b = a;
+		b.n = n_chains * la.c_stride;
+		b.impl = 0;
+		b.seg_stride = la.c_stride;
+		b.seg_first = la.slice_end + (size_t)sl * n_chains;
+		b.seg_groups = (slice_rounds * (kLoopPerRound - 1) + 3) / 4 + 1;       // <= 7 CCCH bursts per round
+		b.seg_count = la.slice_end + (size_t)(sl + 1) * n_chains;
+		b.offset = la.c_off;
+		b.kind = la.c_kind;
+		b.freq_shift = la.c_fs;
+		b.l2 = la.c_l2;
+		b.crc = la.c_crc;
+		b.conv = la.c_conv;
+		b.rv = la.c_rv;
+		b.energy = la.c_en;
+		if ((e = launch_rx(b, true, b.in_len[0], ls->side)) != hipSuccess) return e;
 	}
 #undef GMR1_LOOP_LAUNCH
-	hipError_t e = hipGetLastError();
-	if (e != hipSuccess)
-		return e;
-	// 2. the CCCH bursts they listed
-	RxArgs b = a;
-	b.n = n_chains * la.c_stride;
-	b.impl = 0;
-	b.seg_stride = la.c_stride;
-	b.seg_count = la.n_ccch;
-	b.offset = la.c_off;
-	b.kind = la.c_kind;
-	b.freq_shift = la.c_fs;
-	b.l2 = la.c_l2;
-	b.crc = la.c_crc;
-	b.conv = la.c_conv;
-	b.rv = la.c_rv;
-	b.energy = la.c_en;
-	e = launch_rx(b, true, b.in_len[0], stream);
-	if (e != hipSuccess)
-		return e;
-	// 3. the records
+	// 3. the records, once both streams are through
+	if ((e = hipEventRecord(ls->side_done, ls->side)) != hipSuccess) return e;
+	if ((e = hipStreamWaitEvent(stream, ls->side_done, 0)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_rx_merge, grid, dim3(64 * kMergeWaves), 0, stream, la);
 	return hipGetLastError();
 }
