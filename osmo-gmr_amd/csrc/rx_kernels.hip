@@ -1828,7 +1828,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 // cycle stamps of ONE burst of the receive loop (chain 0, the BCCH burst of round kStampRound): tools/loop_stamps.py
 __device__ unsigned long long g_stamp[16];
 __device__ int g_prof_flag;              // experiments of the profiling build (gmr1_hip_prof_flag)
-constexpr int kStampRound = 40;
+constexpr int kStampRound = 55;    // (late in a time slice: its first rounds share the CU with the previous slice's CCCH batch)
 #define GMR1_STAMP(k)                                                        \
 	do {                                                                    \
 		if (LAT && io.stamp && lane == 0)                                   \

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Cycle stamps of one BCCH burst inside the receive loop (chain 0, round 40): where a round's 19 microseconds go.
+"""Cycle stamps of one BCCH burst inside the receive loop (chain 0, round 55): where a round's 19 microseconds go.
 Needs the profiling build (python osmo-gmr_amd/build.py --profile).  Run on the GPU box from the repo root."""
 import ctypes as C
 import os
