@@ -35,6 +35,8 @@
 //     each), so the partner metric arrives folded into the add and no metric ever moves.  A
 //     state's 32-bit word is [metric:16 | decisions of the current 16-step window:16]; v_min_u32
 //     does compare, select, tie-break and decision recording at once (see decode4_k5_12).
+#include <mutex>
+
 #include "gmr1_dev.h"
 #include "tch3_body.h"
 
@@ -1207,7 +1209,7 @@ struct DecPre {                                    // the decoder's per-lane con
 #define GMR1_DSTAMP(dp, k, lane) do { } while (0)
 #endif
 
-template <bool ACC = false, bool LATW = false>
+template <bool ACC = false>
 __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restrict__ surv,
                               uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae,
                               const DecPre *dp = nullptr)
@@ -1285,10 +1287,7 @@ __device__ void decode4_k5_12(const uint32_t *__restrict__ bm, uint64_t *__restr
 	dump[12 * 64] = (uint16_t)w;
 	// state 0 ends in location 0 of the row; osmo_conv_decode_acc returns 0, not a metric
 	final_ae = ACC ? 0u : w >> 16;
-	if constexpr (LATW)
-		k5_12_survivors_crc_lat(surv, ubits, lane, syn_o, dp);
-	else
-		k5_12_survivors_crc(surv, ubits, lane, syn_o, dp);
+	k5_12_survivors_crc(surv, ubits, lane, syn_o, dp);
 }
 
 // The K=5 rate-1/2 decoder shaped for the LATENCY of one burst (the receive loop: a wave alone on its SIMD issues one
@@ -3602,9 +3601,11 @@ struct LoopStreams {
 static LoopStreams *loop_streams()
 {
 	static LoopStreams per_dev[64];
+	static std::mutex mu;
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
 		return nullptr;
+	std::lock_guard<std::mutex> lk(mu);
 	LoopStreams &s = per_dev[dev];
 	if (!s.ok) {
 		if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess)
