@@ -729,9 +729,8 @@ namespace {
 // what every burst of the fused BCCH / CCCH path shares
 int rx_base_args(int sps, const float *iq, RxArgs *out, int min_sps = 4)
 {
-	// (more than 8 samples per symbol: the BCCH window of 254 symbols passes the 2048 samples a burst window may have)
-	if (sps < min_sps || sps > 8)
-		return fail(-EINVAL, "rx_bcch_ccch: sps=%d unsupported (%d..8)", sps, min_sps);
+	if (sps < min_sps || sps > 16)
+		return fail(-EINVAL, "rx_bcch_ccch: sps=%d unsupported (%d..16)", sps, min_sps);
 	RxArgs a;
 	std::memset(&a, 0, sizeof(a));
 	a.sps = sps;

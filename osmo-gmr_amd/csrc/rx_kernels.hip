@@ -3483,12 +3483,13 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 	const size_t lds = lds_layout(max_in_len, max_len, decode, off);
 	if (decode) {
 		const int grid = (a.n + 3) / 4;
-		if (a.impl == 1) {
+		// (windows beyond 2048 samples -- more than 8 samples per symbol -- exist only in the one-burst-at-a-time body)
+		if (a.impl == 1 || NPL > 32) {
 			if (a.conv_acc)
 				hipLaunchKernelGGL((k_rx<NPL, SPS, true, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
 			else
 				hipLaunchKernelGGL((k_rx<NPL, SPS, true>), dim3(grid), dim3(64), lds, stream, a, max_in_len, max_len);
-		} else {
+		} else if constexpr (NPL <= 32) {
 			const int cw = (max_len + 15) & ~15;
 			size_t off4[4];
 			const size_t lds4 = lds4_layout(a.stage_samples, cw, off4);
@@ -3556,9 +3557,12 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 			return launch_rx_t<16, 4>(a, decode, max_in_len, max_len, stream);
 		return launch_rx_t<16, 0>(a, decode, max_in_len, max_len, stream);
 	}
-	if (a.sps == 4)
-		return launch_rx_t<32, 4>(a, decode, max_in_len, max_len, stream);
-	return launch_rx_t<32, 0>(a, decode, max_in_len, max_len, stream);
+	if (max_in_len <= 2048) {
+		if (a.sps == 4)
+			return launch_rx_t<32, 4>(a, decode, max_in_len, max_len, stream);
+		return launch_rx_t<32, 0>(a, decode, max_in_len, max_len, stream);
+	}
+	return launch_rx_t<64, 0>(a, decode, max_in_len, max_len, stream);
 }
 
 #ifdef GMR1_HIP_PROFILE
@@ -3713,11 +3717,13 @@ hipError_t launch_detect(const DetectArgs &a, hipStream_t stream)
 			hipLaunchKernelGGL((k_detect<16, 4>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
 		else
 			hipLaunchKernelGGL((k_detect<16, 0>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
-	} else {
+	} else if (a.in_len <= 2048) {
 		if (a.sps == 4)
 			hipLaunchKernelGGL((k_detect<32, 4>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
 		else
 			hipLaunchKernelGGL((k_detect<32, 0>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+	} else {
+		hipLaunchKernelGGL((k_detect<64, 0>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
 	}
 	return hipGetLastError();
 }
@@ -3732,8 +3738,10 @@ hipError_t launch_mod_order(const ModOrderArgs &a, hipStream_t stream)
 	const size_t lds = lds_layout(a.in_len, 0, false, off);
 	if (a.in_len <= 1024)
 		hipLaunchKernelGGL((k_mod_order<16>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
-	else
+	else if (a.in_len <= 2048)
 		hipLaunchKernelGGL((k_mod_order<32>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
+	else
+		hipLaunchKernelGGL((k_mod_order<64>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);
 	return hipGetLastError();
 }
 

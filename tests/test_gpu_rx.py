@@ -303,7 +303,8 @@ def test_fused_rx_full_size_properties(gpu_api, orc, pkg):
 def test_demod_low_oversampling(gpu_api, orc, pkg):
     """sps < 4: the reference's sinc fractional-delay branch (pi4cxpsk.c:298-343), and sps 1."""
     rng = np.random.default_rng(51)
-    for sps, name, win in ((2, "bcch", 20), (2, "nt3_speech", 4), (3, "dc6", 12), (1, "bcch", 6), (8, "dc2", 32)):
+    for sps, name, win in ((2, "bcch", 20), (2, "nt3_speech", 4), (3, "dc6", 12), (1, "bcch", 6), (8, "dc2", 32),
+                           (12, "bcch", 48), (16, "dc6", 64)):          # windows beyond 2048 samples: the 64-samples-per-lane body
         fmt = pkg.api.burst_format(name)
         n = 16
         ebits = rng.integers(0, 2, size=(n, fmt.ebits), dtype=np.uint8)
@@ -330,9 +331,10 @@ def test_demod_low_oversampling(gpu_api, orc, pkg):
         assert (hard != ebits).mean() < 0.03, (sps, name)
 
 
-@pytest.mark.parametrize("sps", [2, 3, 5, 8])
+@pytest.mark.parametrize("sps", [2, 3, 5, 8, 10, 16])
 def test_fused_rx_other_oversampling(gpu_api, orc, pkg, sps, decoder):
-    """The fused path at sps != 4 (generic k_rx4 instantiation; windows of 234 sps + 20 sps / 10 sps samples)."""
+    """The fused path at sps != 4 (generic k_rx4 instantiation; windows of 234 sps + 20 sps / 10 sps samples; below 4 and
+    above 8 samples per symbol the one-burst-at-a-time body, whose windows go up to 4 096 samples)."""
     wl = workloads.bcch_ccch_mix(pkg, n=403, seed=7, sps=sps, toa_jitter=2 * sps)
     got = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=sps)
     ref = orc.demod_decode_batch(wl["iq"], wl["offset"], wl["kind"], sps=sps)
