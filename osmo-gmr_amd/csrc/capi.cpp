@@ -822,7 +822,7 @@ int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq,
 	int r = dev_state(&s);
 	if (r) return r;
 	RxArgs a;
-	r = rx_base_args(sps, iq, &a);
+	r = rx_base_args(sps, iq, &a, 1);
 	if (r) return r;
 	HIP_TRY(launch_rx_loop(a, la, n_chains, stream));
 	return 0;

@@ -1021,8 +1021,8 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 		return fail(-EINVAL, "rx_run: the CSD carrier needs the traffic carrier and the big-record outputs");
 	if (n_arfcn < 0 || !iq || !offset || !length || !n_records || (max_records > 0 && !out) || max_records < 0)
 		return fail(-EINVAL, "rx_run: iq/offset/length/n_records (and out when max_records > 0) are required");
-	if (sps < 4 || sps > 8)
-		return fail(-EINVAL, "rx_run: sps=%d unsupported (4..8)", sps);
+	if (sps < 1 || sps > 16)                  // gmr1_rx.c:919-922
+		return fail(-EINVAL, "rx_run: sps=%d unsupported (1..16)", sps);
 	DevState *ds;
 	int r = dev_state(&ds);
 	if (r) return r;

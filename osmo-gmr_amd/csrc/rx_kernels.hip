@@ -1552,13 +1552,32 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 	const Lds L = lds_carve(lds_raw, max_in_len, max_len, DECODE);
 
 	constexpr int PER = DECODE ? 4 : 1;
-	const int g0 = blockIdx.x * PER;
+	int g0 = blockIdx.x * PER;
+	int n_end = a.n;
+	if (DECODE && a.seg_count) {
+		// the receive loop's CCCH lists (see k_rx4): segments with unused slots, one time slice of each per launch
+		int sg = g0 / a.seg_stride;
+		int lo = 0;
+		if (a.seg_first) {
+			if (a.seg_groups > 0) {
+				sg = (int)blockIdx.x / a.seg_groups;
+				lo = (a.seg_first[sg] + 3) & ~3;
+				g0 = sg * a.seg_stride + lo + ((int)blockIdx.x % a.seg_groups) * PER;
+			} else {
+				lo = (a.seg_first[sg] + 3) & ~3;
+			}
+		}
+		const int base = sg * a.seg_stride;
+		n_end = min(min(a.n, g0 + PER), base + min(a.seg_count[sg], a.seg_stride));
+		if (g0 >= n_end || g0 < base + lo)
+			return;
+	}
 	int row_ok = 0;       // bit q: burst q of this wave demodulated fine
 	int row_chain = 0;    // bit q: burst q is CCCH
 
 	for (int q = 0; q < PER; q++) {
 		const int g = g0 + q;
-		if (g >= a.n)
+		if (g >= n_end)
 			break;
 		int type, in_len;
 		if (DECODE) {
@@ -1627,7 +1646,7 @@ __global__ __launch_bounds__(64) void k_rx(RxArgs a, int max_in_len, int max_len
 		decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae);
 		const int row = lane >> 4;
 		const int g = g0 + row;
-		if ((lane & 15) == 0 && g < a.n) {
+		if ((lane & 15) == 0 && g < n_end) {
 			if ((row_ok >> row) & 1) {
 				store_l2(a.l2 + (size_t)g * 24, L.ubits + row * 8);
 				a.crc[g] = syn ? 1 : 0;
@@ -2938,6 +2957,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 	}
 }
 
+// The receive loop's BCCH burst where rx4_body has no instantiation -- below 4 samples per symbol (the sinc fractional
+// delay of pi4cxpsk.c:298-343) and above 8 (windows beyond 2048 samples): the one-burst-at-a-time body of k_rx on the one
+// burst, operands and results in the chain's LDS slots (io).  Not shaped for latency; the reference's program accepts
+// 1..16 samples per symbol (gmr1_rx.c:919-922) and so does the loop.
+template <int NPL, int SPS, bool ACC>
+__device__ void rx1_lat_body(const RxArgs &a, const RxIo io, int max_in_len, int max_len, unsigned char *lds_raw, int lane)
+{
+	const Lds L = lds_carve(lds_raw, max_in_len, max_len, true);
+	const int kind = __builtin_amdgcn_readfirstlane(io.kind[0] ? 1 : 0);
+	const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
+	const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
+	const float fsh = io.freq_shift ? io.freq_shift[0] : 0.0f;
+	const float2 *__restrict__ in = a.iq + io.offset[0];
+	int sid = -1;
+	float toa = 0.f, fe = 0.f;
+	WSYNC();
+	const int rv = demod_one<NPL, SPS>(type, in, in_len, a.sps, fsh, L, L.eb, lane, 0, sid, toa, fe, nullptr);
+	const float e = window_energy<NPL>(in, in_len, lane);
+	if (lane == 0) {
+		io.rv[0] = rv;
+		io.toa[0] = rv ? 0.f : toa;
+		io.freq_err[0] = rv ? 0.f : fe;
+		if (io.energy)
+			io.energy[0] = e;
+	}
+	WSYNC();     // x is dead from here on: bm / surv / ubits overlay it
+	if (rv == 0)
+		branch_metrics_k5_12<ACC>(L.eb, kind, L.bm, lane);
+	for (int k = lane + (rv == 0 ? kSteps12 : 0); k < 4 * kSteps12; k += 64)
+		L.bm[k] = 0;
+	WSYNC();
+	uint32_t syn, fae;
+	decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae);
+	if (lane == 0) {
+		uint32_t *l2w = reinterpret_cast<uint32_t *>(io.l2);
+#pragma unroll
+		for (int i = 0; i < 6; i++)
+			l2w[i] = rv == 0 ? L.ubits[i] : 0u;
+		io.crc[0] = rv == 0 ? (syn ? 1 : 0) : -1;
+		io.conv[0] = rv == 0 ? (int32_t)fae : 0;
+	}
+	WSYNC();
+}
+
 // ---------------------------------------------------------------------------
 // The receive loop -- process_bcch (reference src/gmr1_rx.c:852-895) of every chain, from its first frame to the end of the
 // capture, without leaving the GPU.  The feedback of the loop only crosses a BCCH burst (time, frequency, SI1 TDMA
@@ -2955,7 +3018,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 //
 // What goes to HBM in between is a few dozen bytes per burst (RxLoopRound, RxLoopCcch, the burst kernel's own outputs).
 // ---------------------------------------------------------------------------
-template <int NPL, int SPS, bool ACC = false>
+// ONE: the one-burst generic body (rx1_lat_body) instead of rx4_body's latency shape; stage_samples / cw then carry the
+// window length and the lag count its LDS layout is sized by, and nothing is prepared ahead
+template <int NPL, int SPS, bool ACC = false, bool ONE = false>
 __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body, int slice,
                                                    int slice_rounds)
 {
@@ -3001,8 +3066,9 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 				break;
 			const uint64_t pred = s_pred;
 			const int nb = (round + 1) & 1;
-			if (pred != ~0ull)
-				lat_prepare<NPL, SPS>(a, pred, 0, lane, h_x[nb], h_stat[nb]);
+			if constexpr (!ONE)
+				if (pred != ~0ull)
+					lat_prepare<NPL, SPS>(a, pred, 0, lane, h_x[nb], h_stat[nb]);
 			if (lane == 0) {
 				h_off[nb] = pred;
 				h_kind[nb] = 0;
@@ -3025,7 +3091,7 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	__shared__ __align__(16) uint16_t s_lut[1024];
 	__shared__ uint32_t s_steps[2 * kSteps12];
 	__shared__ uint32_t s_cost_a[512], s_cost_b[512];
-	{
+	if constexpr (!ONE) {
 		const CostTable &ctab = ACC ? c_cost_acc : c_cost;
 		for (int i = lane; i < 1024; i += 64)
 			s_lut[i] = g_sb_lut.v[i];
@@ -3091,7 +3157,7 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 		if (lane == 0) {
 			// where the next round's BCCH burst will most likely sit: eight frames on
 			uint64_t pred = ~0ull;
-			if (has_b) {
+			if (has_b && !ONE) {
 				pred = st.base + (uint64_t)s_items[n - 1].begin + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
 				if (pred + (uint64_t)a.in_len[0] > lim)
 					pred = ~0ull;
@@ -3132,7 +3198,10 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 			                 (chain == 0 && round == kStampRound) ? g_stamp : nullptr,
 #endif
 			                 s_off, s_kind, s_fs, s_l2, s_crc, s_conv, s_rv, nullptr, s_toa, s_fe, s_en, nullptr, nullptr};
-			rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, 0, 1, lds_raw, lane, &pre);
+			if constexpr (ONE)
+				rx1_lat_body<NPL, SPS, ACC>(a, io, stage_samples, cw, lds_raw, lane);
+			else
+				rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, 0, 1, lds_raw, lane, &pre);
 			WSYNC();
 			// the BCCH burst feeds back before the next round is listed (rx_bcch, gmr1_rx.c:782-795)
 			b_frame = frames_at_round + it.frames_before;
@@ -3482,7 +3551,8 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 	size_t off[3];
 	const size_t lds = lds_layout(max_in_len, max_len, decode, off);
 	if (decode) {
-		const int grid = (a.n + 3) / 4;
+		const bool sliced = a.seg_first && a.seg_groups > 0 && a.seg_stride > 0;       // the receive loop's lists, one time slice
+		const int grid = sliced ? (a.n / a.seg_stride) * a.seg_groups : (a.n + 3) / 4;
 		// (windows beyond 2048 samples -- more than 8 samples per symbol -- exist only in the one-burst-at-a-time body)
 		if (a.impl == 1 || NPL > 32) {
 			if (a.conv_acc)
@@ -3504,7 +3574,6 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 				const char *e = profile_env("GMR1_HIP_RX_BPW");
 				bpw_force = e ? atoi(e) : 0;
 			}
-			const bool sliced = a.seg_first && a.seg_groups > 0 && a.seg_stride > 0;
 			const int bpw = sliced ? 4 : (bpw_force == 1 || bpw_force == 4 ? bpw_force : (a.n <= 4096 ? 1 : 4));
 			const int grid4 = sliced ? (a.n / a.seg_stride) * a.seg_groups : (a.n + bpw - 1) / bpw;
 			// (the instantiation with the burst energy and the segment bound is the receive loop's: see rx4_body's EN)
@@ -3640,11 +3709,14 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 		return hipErrorInvalidValue;
 	const int max_len = 20 * a.sps + 1;
 	const int cw = (max_len + 15) & ~15;
-	size_t off4[4];
-	const size_t lds = (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
+	// below 4 and above 8 samples per symbol: the one-burst generic body (k_rx_chain<..., ONE>, rx1_lat_body)
+	const bool one = a.sps < 4 || a.sps > 8 || a.in_len[0] > 2048;
+	size_t off4[4], off3[3];
+	const size_t lds = one ? (lds_layout(a.in_len[0], max_len, true, off3) + 127) & ~(size_t)127
+	                       : (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
 	const dim3 grid((unsigned)n_chains), block(128);
 	// the helper wave's two staged windows, then the latency decoder's operand table
-	const size_t lds_h = 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
+	const size_t lds_h = one ? 0 : 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
 	hipError_t e;
 	// counters of the walk: rounds, CCCH list lengths, frames, finished flags, slice ends
 	if ((e = hipMemsetAsync(la.n_rounds, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
@@ -3662,9 +3734,25 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 			hipLaunchKernelGGL((k_rx_chain<NPL, SPS>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds, \
 			                   sl, slice_rounds);                                                                \
 	} while (0)
+#define GMR1_LOOP_LAUNCH_ONE(NPL)                                                                                 \
+	do {                                                                                                         \
+		if (a.conv_acc)                                                                                          \
+			hipLaunchKernelGGL((k_rx_chain<NPL, 0, true, true>), grid, block, lds, stream, a, la, a.in_len[0], max_len, (int)lds, \
+			                   sl, slice_rounds);                                                                \
+		else                                                                                                     \
+			hipLaunchKernelGGL((k_rx_chain<NPL, 0, false, true>), grid, block, lds, stream, a, la, a.in_len[0], max_len, (int)lds, \
+			                   sl, slice_rounds);                                                                \
+	} while (0)
 	for (int sl = 0; sl < kLoopSlices; sl++) {
 		// 1. the feedback chains, one time slice
-		if (a.in_len[0] <= 1024) {
+		if (one) {
+			if (a.in_len[0] <= 1024)
+				GMR1_LOOP_LAUNCH_ONE(16);
+			else if (a.in_len[0] <= 2048)
+				GMR1_LOOP_LAUNCH_ONE(32);
+			else
+				GMR1_LOOP_LAUNCH_ONE(64);
+		} else if (a.in_len[0] <= 1024) {
 			if (a.sps == 4)
 				GMR1_LOOP_LAUNCH(16, 4);
 			else
@@ -3681,7 +3769,7 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 		if ((e = hipStreamWaitEvent(ls->side, ls->chain_done[sl], 0)) != hipSuccess) return e;
 		RxArgs b = a;
 		b.n = n_chains * la.c_stride;
-		b.impl = 0;
+		b.impl = one ? 1 : 0;
 		b.seg_stride = la.c_stride;
 		b.seg_first = la.slice_end + (size_t)sl * n_chains;
 		b.seg_groups = (slice_rounds * (kLoopPerRound - 1) + 3) / 4 + 1;       // <= 7 CCCH bursts per round
@@ -3697,6 +3785,7 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 		if ((e = launch_rx(b, true, b.in_len[0], ls->side)) != hipSuccess) return e;
 	}
 #undef GMR1_LOOP_LAUNCH
+#undef GMR1_LOOP_LAUNCH_ONE
 	// 3. the records, once both streams are through
 	if ((e = hipEventRecord(ls->side_done, ls->side)) != hipSuccess) return e;
 	if ((e = hipStreamWaitEvent(stream, ls->side_done, 0)) != hipSuccess) return e;

@@ -128,8 +128,9 @@ def test_rx_loop_rejects_bad_arguments(gpu_api):
     x = np.zeros(1000, np.complex64)
     with pytest.raises(Exception):
         gpu_api.rx_run(x, [0], [2000], sps=SPS)            # carrier runs past the buffer
-    with pytest.raises(Exception):
-        gpu_api.rx_run(x, [0], [1000], sps=2)              # sps outside the fused path's range
+    for bad in (0, 17):
+        with pytest.raises(Exception):
+            gpu_api.rx_run(x, [0], [1000], sps=bad)        # sps outside the reference's 1..16 (gmr1_rx.c:919-922)
     rec, status, chains, found = gpu_api.rx_run(x, [0], [1000], sps=SPS)
     assert found == 0 and status[0] < 0
 
@@ -246,6 +247,32 @@ def test_rx_loop_at_sps_8(gpu_api, orc, pkg):
     assert _key(rec) == _key(orec)
     mb, nb, mc, nc, mp = workloads.match_records(rec, sent)
     assert nb >= 5 and mp == nb and mc >= nc - 1
+
+
+@pytest.mark.parametrize("sps", [2, 3, 10, 16])
+def test_rx_loop_outside_4_to_8_samples_per_symbol(gpu_api, orc, pkg, sps, decoder):
+    """gmr1_rx accepts 1..16 samples per symbol (gmr1_rx.c:919-922).  Below 4 the demodulator delays the burst by a
+    fraction of a sample (pi4cxpsk.c:298-343), above 8 a BCCH window passes 2048 samples: the loop then runs the one-burst
+    generic body (k_rx_chain<..., ONE>, k_rx for the CCCH lists).  Records identical to the oracle's loop."""
+    x, sent = workloads.bcch_carrier(pkg, 80 + sps, seconds=2.5, sps=sps, stn=4, delay=2, cfo_hz=70.0)
+    rec, status, chains, found = gpu_api.rx_run(x, [0], [x.size], sps=sps)
+    orv, orec, och = orc.rx_run(x, sps=sps, arfcn=0)
+    assert status[0] == orv == 0 and chains[0] == och
+    assert _key(rec) == _key(orec)
+    mb, nb, mc, nc, mp = workloads.match_records(rec, sent)
+    assert nb >= 5 and mp == nb and mc >= nc - 1
+
+
+@pytest.mark.parametrize("sps", [2, 10])
+def test_rx_loop_tch3_follow_up_outside_4_to_8(gpu_api, orc, pkg, sps):
+    """The TCH3 follow-up (IMM.ASS -> DKAB / speech / FACCH3, ciphered) at 2 and 10 samples per symbol: records are the oracle's."""
+    kc = np.array([9, 8, 7, 6, 5, 4, 3, 2], np.uint8)
+    b, t, s_b, s_t = workloads.bcch_tch_pair(pkg, 15 + sps, seconds=4.0, sps=sps, kc=kc, cipher_after=25)
+    rec, status, chains, found = gpu_api.rx_run_tch(b, t, [0], [b.size], sps=sps, kc=kc[None, :])
+    orv, orec, och = orc.rx_run_tch(b, t, sps=sps, arfcn=0, kc=kc)
+    assert status[0] == orv == 0 and chains[0] == och
+    assert _key_n(rec) == _key_n(orec)
+    assert int(np.sum(orec["type"] >= 0x10)) > 20
 
 
 def _key_big(rec):
