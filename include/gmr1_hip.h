@@ -44,7 +44,7 @@ extern "C" {
 #define GMR1_HIP_MAX_SYNC       4
 #define GMR1_HIP_MAX_CHUNKS     8
 #define GMR1_HIP_MAX_SYNC_SYMS  32
-#define GMR1_HIP_MAX_WINDOW     256   /* max search window (lags) the demod kernel handles */
+#define GMR1_HIP_MAX_WINDOW     256   /* lags the demod kernels keep room for by default; wider search windows size their own */
 #define GMR1_HIP_MAX_IN_LEN     4096  /* max samples per burst window (BCCH at 16 samples per symbol: 4 064) */
 
 /* burst type ids (order of include/osmocom/gmr1/sdr/nb.h:37-46) */

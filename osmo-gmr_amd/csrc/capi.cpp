@@ -206,9 +206,8 @@ static int demod_args(int type, const DevBurst &ht,
 	if (sps < 1 || sps > 16)
 		return fail(-EINVAL, "demod: sps=%d out of range (1..16)", sps);
 	const int w = in_len - ht.len * sps + 1;
-	if (w < 1 || w > kMaxWindow || in_len > kMaxInLen)
-		return fail(-EINVAL, "demod: window of %d samples gives %d lags (1..%d supported, <= %d samples)",
-		            in_len, w, kMaxWindow, kMaxInLen);
+	if (w < 1 || in_len > kMaxInLen)
+		return fail(-EINVAL, "demod: window of %d samples gives %d lags (>= 1, <= %d samples supported)", in_len, w, kMaxInLen);
 	if (ebits && ebits_stride < ht.ebits)
 		return fail(-EINVAL, "demod: ebits_stride %d < %d", ebits_stride, ht.ebits);
 	RxArgs a;

@@ -31,15 +31,18 @@ static int detect_dev_impl(hipStream_t stream, int n_types, const int *slots, co
 	DevState *s;
 	int r = dev_state(&s);
 	if (r) return r;
+	int max_lags = 0;
 	for (int i = 0; i < n_types; i++) {
 		const DevBurst &ht = *hts[i];
 		const int w = in_len - ht.len * sps + 1;
-		if (w < 1 || w > kMaxWindow || in_len > kMaxInLen)
-			return fail(-EINVAL, "detect: window of %d samples gives %d lags (1..%d supported)", in_len, w, kMaxWindow);
+		if (w < 1 || in_len > kMaxInLen)
+			return fail(-EINVAL, "detect: window of %d samples (<= %d supported) gives %d lags", in_len, kMaxInLen, w);
+		if (w > max_lags) max_lags = w;
 	}
 	DetectArgs a;
 	std::memset(&a, 0, sizeof(a));
 	a.n = n; a.sps = sps; a.in_len = in_len;
+	a.max_lags = max_lags;
 	a.rot0 = hts[0]->rotation;
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.freq_shift = freq_shift; a.e_toa = e_toa;

@@ -118,6 +118,7 @@ struct DetectArgs {
 	int n, sps, in_len;
 	int n_types;
 	int types[4];          // candidate burst types of THIS launch (same length / modulation family): table slots
+	int max_lags;          // most lags any candidate of this launch searches (sizes the correlation accumulator when > 256)
 	int first;             // position of types[0] in the caller's list (longer lists run as several launches)
 	int carry;             // 1: rv / bt_id / sync_id / toa / best_pwr hold the outcome of the earlier candidates
 	float rot0;            // rotation of the caller's FIRST candidate: the window is normalised with it once (pi4cxpsk.c:629)

@@ -394,6 +394,13 @@ struct Lds {
 
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+__host__ __device__ inline size_t lds_corr_bytes(int max_len, bool decode)
+{
+	if (decode)
+		return align16((size_t)max_len * 4);
+	return align16((size_t)(max_len > kMaxWindow ? max_len : kMaxWindow) * 4);
+}
+
 __host__ __device__ inline size_t lds_layout(int max_in_len, int max_len, bool decode, size_t *off)
 {
 	size_t o = 0;
@@ -404,7 +411,8 @@ __host__ __device__ inline size_t lds_layout(int max_in_len, int max_len, bool d
 	off[0] = o; o += xbytes;
 	// aux = correlation accumulator + rotated sync reference.  The fused BCCH / CCCH path knows
 	// its formats (<= max_len lags, 17 sync symbols), which keeps 15 wavefronts per CU resident
-	const size_t corr_bytes = decode ? align16((size_t)max_len * 4) : (size_t)kMaxWindow * 4;
+	// (demodulation only: the caller's lag count when it passes the 256 the layout has always had room for)
+	const size_t corr_bytes = lds_corr_bytes(max_len, decode);
 	const size_t coef_bytes = decode ? 32 * 8 : (size_t)kMaxCoef * 8;
 	off[1] = o; o += corr_bytes + coef_bytes;
 	off[2] = o; o += decode ? 4 * kEbRow : kEbitsLds;
@@ -418,7 +426,7 @@ __device__ __forceinline__ Lds lds_carve(unsigned char *raw, int max_in_len, int
 	Lds L;
 	L.x = reinterpret_cast<float2 *>(raw + off[0]);
 	L.corr = reinterpret_cast<float *>(raw + off[1]);
-	L.coef = reinterpret_cast<float2 *>(raw + off[1] + (decode ? align16((size_t)max_len * 4) : (size_t)kMaxWindow * 4));
+	L.coef = reinterpret_cast<float2 *>(raw + off[1] + lds_corr_bytes(max_len, decode));
 	L.y = reinterpret_cast<float2 *>(raw + off[1]);
 	L.eb = reinterpret_cast<int8_t *>(raw + off[2]);
 	L.bm = reinterpret_cast<uint32_t *>(raw + off[0]);
@@ -3326,7 +3334,7 @@ __global__ __launch_bounds__(64) void k_detect(DetectArgs a, int max_in_len)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int lane = threadIdx.x;
-	const Lds L = lds_carve(lds_raw, max_in_len, 0, false);
+	const Lds L = lds_carve(lds_raw, max_in_len, a.max_lags, false);
 	const int g = blockIdx.x;
 	const int sps = SPS ? SPS : a.sps;
 	load_normalise<NPL>(a.iq + a.offset[g], a.in_len, L, lane);
@@ -3604,7 +3612,9 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 		return hipErrorInvalidValue;
 	// symbols per burst: fused path is BCCH/DC6 (234); generic path sizes for the longest format
 	// third kernel argument: lags the correlation accumulator must hold (fused path: 20*sps + 1)
-	const int max_len = decode ? (20 * a.sps + 1) : kMaxWindow;
+	// (demodulation only: the lags of this launch's one format, in_len - symbols * sps + 1; ssyms_stride = symbols per burst)
+	const int w_demod = a.in_len[0] - a.ssyms_stride * a.sps + 1;
+	const int max_len = decode ? (20 * a.sps + 1) : (w_demod > kMaxWindow ? w_demod : kMaxWindow);
 	if (!decode && (a.impl == 2 || a.impl == 3 || a.impl == 4) && a.sps == 4 && max_in_len <= 1024) {
 		// large batch of one simple burst format (the host checked what rx4_body<GEN> assumes; impl 3: also what its
 		// small variant assumes; impl 4: the small variant for two training sequences and BPSK): four bursts per wave
@@ -3800,7 +3810,7 @@ hipError_t launch_detect(const DetectArgs &a, hipStream_t stream)
 	if (a.in_len > kMaxInLen)
 		return hipErrorInvalidValue;
 	size_t off[3];
-	const size_t lds = lds_layout(a.in_len, 0, false, off);
+	const size_t lds = lds_layout(a.in_len, a.max_lags, false, off);
 	if (a.in_len <= 1024) {
 		if (a.sps == 4)
 			hipLaunchKernelGGL((k_detect<16, 4>), dim3(a.n), dim3(64), lds, stream, a, a.in_len);

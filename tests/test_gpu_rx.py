@@ -331,6 +331,33 @@ def test_demod_low_oversampling(gpu_api, orc, pkg):
         assert (hard != ebits).mean() < 0.03, (sps, name)
 
 
+def test_demod_and_detect_wide_search_windows(gpu_api, orc, pkg):
+    """Search windows beyond 256 lags (the reference has no limit, pi4cxpsk.c:184-201): the correlation accumulator is sized
+    by the call.  Demodulation of DC2 with 400 lags and NT3 speech with 700, and detection between the two NT3 formats."""
+    rng = np.random.default_rng(77)
+    for name, win in (("dc2", 400), ("nt3_speech", 700)):
+        fmt = pkg.api.burst_format(name)
+        n = 12
+        ebits = rng.integers(0, 2, size=(n, fmt.ebits), dtype=np.uint8)
+        bb = pkg.synth.synth_windows(fmt, pkg.synth.map_symbols(fmt, ebits), 4, win, rng, toa_jitter=win // 3, frac=True,
+                                     cfo_hz_std=20.0, esn0_db=20.0)
+        assert bb.in_len - fmt.length * 4 + 1 > 256
+        offset = (np.arange(n) * bb.stride).astype(np.uint64)
+        got = gpu_api.demod_batch(name, bb.iq, offset, bb.in_len, sps=4)
+        for i in range(n):
+            o = orc.demod(name, bb.iq[i, :bb.in_len], 4)
+            assert got["rv"][i] == o["rv"] == 0, name
+            assert abs(got["toa"][i] - o["toa"]) < 16 / 1024, name
+            if got["toa"][i] == o["toa"]:
+                assert np.abs(got["ebits"][i].astype(int) - o["ebits"].astype(int)).max() <= 1
+        assert ((got["ebits"] < 0).astype(np.uint8) != ebits).mean() < 0.02
+        if name == "nt3_speech":
+            d = gpu_api.detect_batch(["nt3_speech", "nt3_facch"], bb.iq.reshape(-1), offset, bb.in_len, sps=4)
+            for i in range(n):
+                o = orc.detect(["nt3_speech", "nt3_facch"], -1.0, bb.iq[i, :bb.in_len], 4)
+                assert d["rv"][i] == o["rv"] and d["bt_id"][i] == o["bt_id"] and d["sync_id"][i] == o["sync_id"]
+
+
 @pytest.mark.parametrize("sps", [2, 3, 5, 8, 10, 16])
 def test_fused_rx_other_oversampling(gpu_api, orc, pkg, sps, decoder):
     """The fused path at sps != 4 (generic k_rx4 instantiation; windows of 234 sps + 20 sps / 10 sps samples; below 4 and
