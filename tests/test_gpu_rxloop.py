@@ -124,6 +124,31 @@ def test_rx_loop_more_chains_than_compute_units(gpu_api, orc, pkg):
         assert got == [k[1:] for k in refs[a % 3]], a
 
 
+def test_rx_loop_carriers_of_very_different_lengths(gpu_api, orc, pkg):
+    """The loop walks its chains in time slices (k_rx_chain launched several times, the CCCH batch of one slice under the
+    next): a chain that reaches the end of its capture in the first slice sits out the others, a long one uses them all,
+    and one too short to hold a frame yields nothing - each carrier's records are the oracle's."""
+    secs = [0.9, 7.0, 0.25, 2.0]
+    xs = [workloads.bcch_carrier(pkg, 120 + i, seconds=sec, sps=SPS, stn=(3 * i) % 24, delay=i, cfo_hz=35.0 * i)[0]
+          for i, sec in enumerate(secs)]
+    length = np.array([x.size for x in xs], np.uint64)
+    offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.uint64)
+    rec, status, chains, found = gpu_api.rx_run(np.concatenate(xs), offset, length, sps=SPS, arfcn=np.arange(4, dtype=np.uint16))
+    assert found == len(rec)
+    n_tot = 0
+    for i, x in enumerate(xs):
+        orv, orec, och = orc.rx_run(x, sps=SPS, arfcn=i)
+        assert (status[i] == 0) == (orv == 0), (i, status[i], orv)
+        mine = rec[rec["arfcn"] == i]
+        if orv:
+            assert len(mine) == 0
+            continue
+        assert chains[i] == och
+        assert _key(mine) == _key(orec), f"carrier {i}"
+        n_tot += len(orec)
+    assert n_tot > 150
+
+
 def test_rx_loop_rejects_bad_arguments(gpu_api):
     x = np.zeros(1000, np.complex64)
     with pytest.raises(Exception):
