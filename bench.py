@@ -73,9 +73,17 @@ def parse():
     ap.add_argument("--shard-timeout", type=float, default=240.0,
                     help="N > 1: if the sharded config-4 run has not finished after this many seconds, the headline line is "
                          "printed without it (with the reason) instead of hanging the job")
-    ap.add_argument("--conv-decoder", default="generic", choices=["generic", "acc"],
-                    help="which libosmocore Viterbi decoder the layer-1 chains reproduce (gmr1_hip_set_conv_decoder): its generic "
-                         "one (default) or osmo_conv_decode_acc; the CPU oracle beside it runs the same one")
+    ap.add_argument("--conv-decoder", default="acc", choices=["generic", "acc"],
+                    help="which libosmocore Viterbi decoder the layer-1 chains reproduce (gmr1_hip_set_conv_decoder): "
+                         "osmo_conv_decode_acc (default, as in the library: what every libosmocore since 2017 runs for these "
+                         "codes) or its generic one; the CPU oracle beside it runs the same one")
+    ap.add_argument("--layout", default="interleaved", choices=["interleaved", "planar"],
+                    help="bursts workload: sample layout the TIMED step reads. interleaved (default) is the layout BASELINE "
+                         "describes and the one `value` is quoted on; the default run also times the opt-in polyphase-planar "
+                         "entry point afterwards and reports it as `roofline_planar`. --layout planar makes the planar call the "
+                         "timed step itself (a side measurement for the profiler: config.layout says so)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="bursts workload: skip the measurements after the timed region (planar layout, the other decoder)")
     args = ap.parse_args()
     # read by the library on first use and by tests/oracle_lib.py when it loads the oracle; inherited by spawned ranks
     os.environ["GMR1_HIP_CONV_DECODER"] = args.conv_decoder
@@ -86,7 +94,7 @@ def parse():
 def emit(out, **kw):
     """Print the one JSON line; every line names the Viterbi decoder the run reproduced."""
     if isinstance(out.get("config"), dict):
-        out["config"]["conv_decoder"] = os.environ.get("GMR1_HIP_CONV_DECODER", "generic")
+        out["config"]["conv_decoder"] = os.environ.get("GMR1_HIP_CONV_DECODER", "acc")
     print(json.dumps(out), **kw)
 
 
@@ -1013,10 +1021,38 @@ def main():
     rv = torch.zeros(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
-    def step():
+    # the same samples polyphase-planar (sample s at planes[(s & 3) * P + (s >> 2)]): what the opt-in entry point reads
+    n_samp = wl["iq"].size
+    P = -(-n_samp // 4)
+    want_planar = args.layout == "planar" or not args.no_extras
+    planes = None
+    if want_planar:
+        planes = torch.zeros(4 * P * 2, dtype=torch.float32, device=dev)
+        api.iq_to_planar_dev(stream.cuda_stream, 4, n_samp, iq.data_ptr(), planes.data_ptr(), P)
+
+    def step_interleaved():
         api.rx_bcch_ccch_batch_dev(stream.cuda_stream, n, 4, iq.data_ptr(), offset.data_ptr(), kind.data_ptr(),
                                    None, l2.data_ptr(), crc.data_ptr(), conv.data_ptr(), toa.data_ptr(),
                                    ferr.data_ptr(), None, None, rv.data_ptr())
+
+    def step_planar():
+        api.rx_bcch_ccch_batch_planar_dev(stream.cuda_stream, n, 4, planes.data_ptr(), P, offset.data_ptr(), kind.data_ptr(),
+                                          None, l2.data_ptr(), crc.data_ptr(), conv.data_ptr(), toa.data_ptr(),
+                                          ferr.data_ptr(), None, None, rv.data_ptr())
+    step = step_planar if args.layout == "planar" else step_interleaved
+
+    def time_steps(fn, k):
+        """K launches of `fn` between two events on the launch stream -> ms per launch (after the timed region only)."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(max(3, args.warmup)):
+            fn()
+        torch.cuda.synchronize()
+        e0.record(stream)
+        for _ in range(k):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / k
 
     def barrier():
         if grouped:
@@ -1056,6 +1092,23 @@ def main():
     good = h_crc == 0
     payload_ok = bool(np.array_equal(h_l2[good], wl["l2"][good]))
     decoded_frac = float(good.mean())
+
+    # ---- after the timed region, outside `value`: the opt-in planar layout and the other Viterbi decoder ----------
+    extras = {}
+    if not args.no_extras and args.layout == "interleaved":
+        h_all = [t.cpu().numpy().copy() for t in (crc, conv, toa, ferr, rv)]
+        ms_pl = time_steps(step_planar, args.steps)
+        same = bool(np.array_equal(l2.cpu().numpy(), h_l2) and
+                    all(np.array_equal(t.cpu().numpy().view(np.uint8), h.view(np.uint8)) for t, h in zip((crc, conv, toa, ferr, rv), h_all)))
+        extras["planar"] = (ms_pl, same)
+        cur = api.get_conv_decoder()
+        other = api.CONV_GENERIC if cur == api.CONV_ACC else api.CONV_ACC
+        with api.conv_decoder(other):
+            ms_other = time_steps(step_interleaved, args.steps)
+            ms_other_pl = time_steps(step_planar, args.steps)
+        extras["other_decoder"] = ("acc" if other == api.CONV_ACC else "generic", ms_other, ms_other_pl)
+        step_interleaved()                       # leave the default decoder's results in the buffers
+        torch.cuda.synchronize()
 
     # ---- N > 1: the north star's exchange (scatter of IQ slices, receive loop, gather of frames) ----
     # Extra keys only, after the timed region.  A watchdog prints the headline line without them if the exchange
@@ -1098,7 +1151,7 @@ def main():
     n_bcch = int((wl["kind"] == 0).sum())
     bytes_per_launch = n_bcch * BYTES_BCCH + (n - n_bcch) * BYTES_CCCH
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    traffic, traffic_note = None, "profiles/hbm_traffic.json missing"
+    traffic, traffic_planar, traffic_note = None, None, "profiles/hbm_traffic.json missing"
     tf = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tf):
         try:
@@ -1108,7 +1161,8 @@ def main():
             elif n != 100_000:
                 traffic_note = "profiles/hbm_traffic.json is per 100000 bursts"
             else:
-                traffic = tj.get("k_rx_bytes_per_launch_100k")
+                traffic = tj.get("k_rx_planar_bytes_per_launch_100k" if args.layout == "planar" else "k_rx_bytes_per_launch_100k")
+                traffic_planar = tj.get("k_rx_planar_bytes_per_launch_100k")
                 traffic_note = f"PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, build {tj.get('tag')}"
         except Exception as e:
             traffic_note = f"profiles/hbm_traffic.json unreadable: {e!r}"
@@ -1126,12 +1180,30 @@ def main():
                    "bursts_per_gpu": n, "global_bursts": world * n, "sps": 4, "untimed_preroll_s": args.preroll_s,
                    "parallelism": f"bursts sharded over {world} rank(s), no collective"},
         "iq_msamp_per_s": world * (n_bcch * 1016 + (n - n_bcch) * 976) * args.steps / wall / 1e6,
-        "roofline": {"bound": "hbm", "kernel": "k_rx4<16,4>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_rx4<16,4>" + (" (planar)" if args.layout == "planar" else ""), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         "checks": {"crc_pass_frac": decoded_frac, "payloads_match_sent": payload_ok,
                    "workload_gen_s": round(t_gen, 1)},
     }
+    out["config"]["layout"] = args.layout
+    if "planar" in extras:
+        ms_pl, same = extras["planar"]
+        ach = bytes_per_launch / (ms_pl * 1e-3) / 1e9
+        out["roofline_planar"] = {"what": "the same step through gmr1_hip_rx_bcch_ccch_batch_planar_dev on the same samples stored "
+                                          "polyphase-planar (opt-in layout; the conversion is outside the step, as the channelizer "
+                                          "can write the layout directly); never part of `value`",
+                                  "bound": "hbm", "kernel": "k_rx4<16,4> (planar)", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": ach / HBM_PEAK_GBS, "traffic": traffic_planar, "kernel_ms": ms_pl,
+                                  "algorithmic_bytes_per_launch": bytes_per_launch,
+                                  "outputs_bit_identical_to_interleaved": same}
+    if "other_decoder" in extras:
+        name, ms_o, ms_o_pl = extras["other_decoder"]
+        out["other_decoder"] = {"conv_decoder": name, "kernel_ms": ms_o, "frac": bytes_per_launch / (ms_o * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "planar_kernel_ms": ms_o_pl, "planar_frac": bytes_per_launch / (ms_o_pl * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "what": "the same step with gmr1_hip_set_conv_decoder set to the other libosmocore decoder, timed "
+                                        "after the timed region on the same box (boxes differ by a few per cent, the two modes on "
+                                        "one box do not)"}
 
     # ---- CPU baseline: the oracle (a port, 1 core) on a bounded sample ----------------------
     if world == 1 and not args.no_cpu:

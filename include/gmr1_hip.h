@@ -88,8 +88,10 @@ int         gmr1_hip_burst_info(int burst_id, struct gmr1_hip_burst_flat *out);
  * N in {2, 3, 4}: every chain above except xCH (K = 9) and TCH9 2k4 (N = 5) -- osmo_conv_decode_acc (src/conv_acc.c).
  * The two differ in metric quantisation, start states, flush steps and the tail-biting end state, so near the decoding
  * threshold they return different frames, and the accelerated one returns 0 where the generic one returns the path
- * metric (`conv_rv`).  Pick the one the replaced build used.  Process-wide; takes effect with the next call; the
- * default is GMR1_HIP_CONV_GENERIC unless the environment says GMR1_HIP_CONV_DECODER=acc when the library is first used. */
+ * metric (`conv_rv`).  Pick the one the replaced build used.  Process-wide; takes effect with the next call.  The
+ * DEFAULT is GMR1_HIP_CONV_ACC -- what a build against any libosmocore released since 2017 ran (configure.ac:23 only
+ * asks for >= 0.4.1, but no distribution has shipped anything older than 1.x for years) -- unless the environment says
+ * GMR1_HIP_CONV_DECODER=generic when the library is first used; gmr1_hip_version() names the decoder in force. */
 enum gmr1_hip_conv_decoder {
 	GMR1_HIP_CONV_GENERIC = 0,   /* osmo_conv_decode's generic path for every code */
 	GMR1_HIP_CONV_ACC     = 1,   /* osmo_conv_decode_acc where libosmocore >= 0.10 dispatches to it, generic elsewhere */
@@ -148,6 +150,25 @@ int gmr1_hip_rx_bcch_ccch_batch(int n, int sps,
                                 uint8_t *l2, int32_t *crc, int32_t *conv,
                                 float *toa, float *freq_err,
                                 int8_t *ebits, float *ssyms, int32_t *rv);
+
+/* The same call on a POLYPHASE-PLANAR sample array (opt-in, 4 samples per symbol only): sample s of the flat array the
+ * offsets count in is stored at iq_planes[(s % sps) * plane_stride + s / sps] (complex samples; plane_stride >=
+ * ceil(total samples / sps)).  Nothing but addresses changes -- every output is bit-identical to the interleaved call's
+ * on the same samples -- but the samples gmr1_pi4cxpsk_demod keeps after timing recovery (one per symbol from sample
+ * round(toa) on, src/sdr/pi4cxpsk.c:292-295) are then 234 CONSECUTIVE samples of one plane instead of every fourth
+ * sample of the whole window, which cuts the second read of a burst from every 128-byte line of its window to 15 of
+ * them.  gmr1_hip_iq_to_planar_dev converts an interleaved array (any sps 1..16); the channelizer writes the layout
+ * directly when asked (gmr1_hip_channelize_planar_dev). */
+int gmr1_hip_rx_bcch_ccch_batch_planar_dev(void *stream, int n, int sps,
+                                           const float *iq_planes, uint64_t plane_stride,
+                                           const uint64_t *offset, const uint8_t *kind,
+                                           const float *freq_shift,
+                                           uint8_t *l2 /* n x 24 */, int32_t *crc, int32_t *conv,
+                                           float *toa, float *freq_err,
+                                           int8_t *ebits /* n x 432, optional */,
+                                           float *ssyms /* n x 234, optional */, int32_t *rv);
+int gmr1_hip_iq_to_planar_dev(void *stream, int sps, uint64_t n_samples, const float *iq /* interleaved, device */,
+                              float *iq_planes /* device, sps x plane_stride complex samples */, uint64_t plane_stride);
 
 /* ---- traffic channel layer 1 -------------------------------------------------
  * FACCH3: n frames, each 4 bursts x 104 soft bits (n x 416) -> l2 n x 10, optional

@@ -24,6 +24,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_hip_bcch_decode_batch_dev", "gmr1_hip_ccch_decode_batch_dev",
     "gmr1_hip_bcch_decode_batch", "gmr1_hip_ccch_decode_batch",
     "gmr1_hip_rx_bcch_ccch_batch_dev", "gmr1_hip_rx_bcch_ccch_batch",
+    "gmr1_hip_rx_bcch_ccch_batch_planar_dev", "gmr1_hip_iq_to_planar_dev",
     "gmr1_pi4cxpsk_demod", "gmr1_bcch_decode", "gmr1_ccch_decode",
     "gmr1_hip_fcch_rough_batch_dev", "gmr1_hip_fcch_rough_batch",
     "gmr1_hip_fcch_fine_batch_dev", "gmr1_hip_fcch_fine_batch",
@@ -318,6 +319,26 @@ def rx_bcch_ccch_batch_dev(stream, n, sps, iq, offset, kind, freq_shift, l2, crc
     rc = f(vp(stream), C.c_int(n), C.c_int(sps), vp(iq), vp(offset), vp(kind), vp(freq_shift),
            vp(l2), vp(crc), vp(conv), vp(toa), vp(freq_err), vp(ebits), vp(ssyms), vp(rv))
     _check(rc, "gmr1_hip_rx_bcch_ccch_batch_dev")
+
+
+def rx_bcch_ccch_batch_planar_dev(stream, n, sps, iq_planes, plane_stride, offset, kind, freq_shift, l2, crc, conv, toa,
+                                  freq_err, ebits, ssyms, rv):
+    """The same call on a polyphase-planar sample array (include/gmr1_hip.h); device pointers (ints) or None."""
+    f = load().gmr1_hip_rx_bcch_ccch_batch_planar_dev
+    f.restype = C.c_int
+    vp = lambda x: C.c_void_p(x) if x else None
+    rc = f(vp(stream), C.c_int(n), C.c_int(sps), vp(iq_planes), C.c_uint64(plane_stride), vp(offset), vp(kind), vp(freq_shift),
+           vp(l2), vp(crc), vp(conv), vp(toa), vp(freq_err), vp(ebits), vp(ssyms), vp(rv))
+    _check(rc, "gmr1_hip_rx_bcch_ccch_batch_planar_dev")
+
+
+def iq_to_planar_dev(stream, sps, n_samples, iq, iq_planes, plane_stride):
+    """Interleaved device sample array -> polyphase-planar (sample s to iq_planes[(s % sps) * plane_stride + s // sps])."""
+    f = load().gmr1_hip_iq_to_planar_dev
+    f.restype = C.c_int
+    vp = lambda x: C.c_void_p(x) if x else None
+    rc = f(vp(stream), C.c_int(sps), C.c_uint64(n_samples), vp(iq), vp(iq_planes), C.c_uint64(plane_stride))
+    _check(rc, "gmr1_hip_iq_to_planar_dev")
 
 
 # ---------------------------------------------------------------------------

@@ -50,8 +50,10 @@ int conv_acc()
 {
 	int v = g_conv_decoder.load(std::memory_order_relaxed);
 	if (v < 0) {
+		// default: what osmo_conv_decode() of every libosmocore since 0.10 (2017) runs for the K = 5 / 7, N <= 4 codes
+		// (INTEGRATION.md "Which Viterbi decoder"); GMR1_HIP_CONV_DECODER=generic selects the older behaviour
 		const char *e = getenv("GMR1_HIP_CONV_DECODER");
-		v = (e && (!strcmp(e, "acc") || !strcmp(e, "1"))) ? GMR1_HIP_CONV_ACC : GMR1_HIP_CONV_GENERIC;
+		v = (e && (!strcmp(e, "generic") || !strcmp(e, "0"))) ? GMR1_HIP_CONV_GENERIC : GMR1_HIP_CONV_ACC;
 		int expect = -1;
 		if (!g_conv_decoder.compare_exchange_strong(expect, v))
 			v = expect;
@@ -149,7 +151,11 @@ extern "C" {
 // ---------------------------------------------------------------------------
 // library / device
 // ---------------------------------------------------------------------------
-const char *gmr1_hip_version(void) { return "gmr1-hip 0.1 (gfx950)"; }
+const char *gmr1_hip_version(void)
+{
+	// names the Viterbi decoder in force at the time of the call (gmr1_hip_set_conv_decoder)
+	return conv_acc() ? "gmr1-hip 0.2 (gfx950; conv decoder: acc)" : "gmr1-hip 0.2 (gfx950; conv decoder: generic)";
+}
 const char *gmr1_hip_last_error(void) { return last_error(); }
 
 int gmr1_hip_set_conv_decoder(int decoder)
@@ -777,10 +783,12 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           const float *freq_shift,
                           uint8_t *l2, int32_t *crc, int32_t *conv,
                           float *toa, float *freq_err, float *energy,
-                          int8_t *ebits, float *ssyms, int32_t *rv)
+                          int8_t *ebits, float *ssyms, int32_t *rv, long long plane_stride)
 {
 	if (n < 0 || !iq || !offset || !kind || !l2 || !crc || !conv || !rv)
 		return fail(-EINVAL, "rx_bcch_ccch: iq/offset/kind/l2/crc/conv/rv are required");
+	if (plane_stride < 0 || (plane_stride && (sps != 4 || energy)))
+		return fail(-EINVAL, "rx_bcch_ccch: the polyphase-planar sample layout exists at 4 samples per symbol (sps=%d)", sps);
 	DevState *s;
 	int r = dev_state(&s);
 	if (r) return r;
@@ -788,6 +796,7 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 	r = rx_base_args(sps, iq, &a, 1);
 	if (r) return r;
 	a.n = n;
+	a.plane_stride = plane_stride;
 	a.dbg_stop = dbg_stop_env();
 	{
 		static int impl = -1;
@@ -800,6 +809,8 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 		// (pi4cxpsk.c:298-343) instead of picking samples: the one-burst-at-a-time body has that branch, the row-batched one not
 		if (sps < 4)
 			a.impl = 1;
+		if (plane_stride)
+			a.impl = 0;
 	}
 	a.offset = offset; a.kind = kind; a.freq_shift = freq_shift;
 	a.l2 = l2; a.crc = crc; a.conv = conv; a.toa = toa; a.freq_err = freq_err;
@@ -838,7 +849,34 @@ int gmr1_hip_rx_bcch_ccch_batch_dev(void *stream, int n, int sps,
                                     int8_t *ebits, float *ssyms, int32_t *rv)
 {
 	return rx_bcch_ccch_dev_impl((hipStream_t)stream, n, sps, iq, offset, kind, freq_shift, l2, crc, conv,
-	                             toa, freq_err, nullptr, ebits, ssyms, rv);
+	                             toa, freq_err, nullptr, ebits, ssyms, rv, 0);
+}
+
+int gmr1_hip_rx_bcch_ccch_batch_planar_dev(void *stream, int n, int sps,
+                                           const float *iq_planes, uint64_t plane_stride,
+                                           const uint64_t *offset, const uint8_t *kind,
+                                           const float *freq_shift,
+                                           uint8_t *l2, int32_t *crc, int32_t *conv,
+                                           float *toa, float *freq_err,
+                                           int8_t *ebits, float *ssyms, int32_t *rv)
+{
+	if (plane_stride == 0 || plane_stride > (uint64_t)1 << 40)
+		return fail(-EINVAL, "rx_bcch_ccch planar: plane_stride is required");
+	return rx_bcch_ccch_dev_impl((hipStream_t)stream, n, sps, iq_planes, offset, kind, freq_shift, l2, crc, conv,
+	                             toa, freq_err, nullptr, ebits, ssyms, rv, (long long)plane_stride);
+}
+
+int gmr1_hip_iq_to_planar_dev(void *stream, int sps, uint64_t n_samples, const float *iq,
+                              float *iq_planes, uint64_t plane_stride)
+{
+	if (sps < 1 || sps > 16 || !iq || !iq_planes || plane_stride < (n_samples + (uint64_t)sps - 1) / (uint64_t)sps)
+		return fail(-EINVAL, "iq_to_planar: sps 1..16, both arrays, plane_stride >= ceil(n_samples / sps)");
+	DevState *s;
+	int r = dev_state(&s);
+	if (r) return r;
+	HIP_TRY(launch_to_planar(reinterpret_cast<const float2 *>(iq), reinterpret_cast<float2 *>(iq_planes), n_samples, sps,
+	                         (long long)plane_stride, (hipStream_t)stream));
+	return 0;
 }
 
 int gmr1_hip_rx_bcch_ccch_batch(int n, int sps,

@@ -50,7 +50,7 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           const float *freq_shift,
                           uint8_t *l2, int32_t *crc, int32_t *conv,
                           float *toa, float *freq_err, float *energy,
-                          int8_t *ebits, float *ssyms, int32_t *rv);
+                          int8_t *ebits, float *ssyms, int32_t *rv, long long plane_stride = 0);
 
 // process_bcch of n_chains chains in one launch (capi.cpp / launch_rx_loop); every pointer in `la` is device memory
 int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la);

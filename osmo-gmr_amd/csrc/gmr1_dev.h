@@ -59,6 +59,8 @@ struct RxArgs {
 	const int32_t *seg_first;   // optional, with seg_count: only the slots from seg_first[s] (rounded up to a multiple of 4) on are this launch's
 	int seg_groups;             // with seg_first: groups of four slots the launch covers per segment (its grid is n_segments x seg_groups)
 	const float2 *iq;
+	long long plane_stride;     // 0: iq is the interleaved sample array.  > 0 (fused batch kernel, sps 4): polyphase-planar,
+	                            // sample s at iq[(s & 3) * plane_stride + (s >> 2)]
 	const uint64_t *offset;
 	const uint8_t *kind;
 	const float *freq_shift;
@@ -419,6 +421,8 @@ hipError_t launch_rx_tch3(const RxArgs &a, const Tch3Args &t, hipStream_t stream
 // descriptors live in __constant__ memory of the current device
 hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream);
 hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t stream);
+// interleaved sample array -> polyphase-planar (sample s to out[(s % sps) * plane_stride + s / sps])
+hipError_t launch_to_planar(const float2 *in, float2 *out, unsigned long long n, int sps, long long plane_stride, hipStream_t stream);
 hipError_t launch_l1(const L1Args &a, hipStream_t stream);
 hipError_t launch_detect(const DetectArgs &a, hipStream_t stream);
 hipError_t launch_mod_order(const ModOrderArgs &a, hipStream_t stream);

@@ -495,26 +495,36 @@ __device__ __forceinline__ void load_normalise_stats(const float2 *__restrict__ 
 // window statistics only (mean, 1/sigma); the samples stay in registers and are dropped
 // NFULL >= 0: the caller knows in_len >> 6 at compile time (the fused sps = 4 path: 1016 and 976
 // samples both have 15 whole rows), which removes the per-row branches
-template <int NPL, int NFULL = -1>
+// RS = 64: `in` is the window, lane l takes samples l + 64 k.  RS = 16 (polyphase-planar array at 4 samples per symbol,
+// rx4_body's PL): `in` is already this lane's first sample in its plane, sample l + 64 k is 16 k places further on.
+template <int NPL, int NFULL = -1, int RS = 64>
 __device__ __forceinline__ void window_fetch(const float2 *__restrict__ in, int in_len, int lane, float2 (&v)[NPL])
 {
 	const int nfull = NFULL >= 0 ? NFULL : (in_len >> 6);
 	const bool tail = (lane + 64 * nfull) < in_len;
+	const int l0 = RS == 64 ? lane : 0;
 #pragma unroll
 	for (int k = 0; k < NPL; k++) {
 		if (k < nfull)
-			v[k] = in[lane + 64 * k];
+			v[k] = in[l0 + RS * k];
 		else if (k == nfull && tail)
-			v[k] = in[lane + 64 * k];
+			v[k] = in[l0 + RS * k];
 		else
 			v[k] = make_float2(0.f, 0.f);
 	}
 }
 
+// perm_src >= 0 (rx4_body's PL): this lane holds the samples of ANOTHER lane of the usual assignment (`lane` names that
+// one); the per-lane partial sums -- formed over the same samples in the same order -- are first moved to the lane that
+// usually forms them (every lane fetches from lane perm_src), so the cross-lane sums add the same numbers in the same
+// order and the statistics come out bit-identical.
 template <int NPL, int NFULL = -1>
 __device__ __forceinline__ void window_stats(const float2 (&v)[NPL], int in_len, int lane,
-                                             float &avr_o, float &avi_o, float &inv_o)
+                                             float &avr_o, float &avi_o, float &inv_o, int perm_src = -1)
 {
+	auto home = [&](float x) {
+		return perm_src < 0 ? x : __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src << 2, __builtin_bit_cast(int, x)));
+	};
 	// (re, im) pairs through the packed FP32 pipe: one v_pk_add_f32 per sample for the sums, one v_pk_add_f32 and
 	// one v_pk_fma_f32 for the variance (re and im are summed in separate chains, as they are in the mean)
 	v2f s2 = {0.f, 0.f};
@@ -523,8 +533,8 @@ __device__ __forceinline__ void window_stats(const float2 (&v)[NPL], int in_len,
 #pragma unroll
 	for (int k = 0; k < NPL; k++)
 		s2 += (v2f){v[k].x, v[k].y};
-	const float sr = wave_sum(s2.x);
-	const float si = wave_sum(s2.y);
+	const float sr = wave_sum(home(s2.x));
+	const float si = wave_sum(home(s2.y));
 	const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
 	const float avr = sr / (float)in_len, avi = si / (float)in_len;     // true division, see load_normalise
 	const v2f av = {avr, avi};
@@ -536,7 +546,7 @@ __device__ __forceinline__ void window_stats(const float2 (&v)[NPL], int in_len,
 			acc2 = __builtin_elementwise_fma(d, d, acc2);
 		}
 	}
-	float stddev = __builtin_amdgcn_sqrtf(wave_sum(acc2.x + acc2.y) * inv_n);
+	float stddev = __builtin_amdgcn_sqrtf(wave_sum(home(acc2.x + acc2.y)) * inv_n);
 	if (stddev == 0.0f)
 		stddev = 1.0f;
 	avr_o = avr;
@@ -1994,7 +2004,13 @@ __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int k
 // A template parameter because keeping the window registers alive for it costs the headline instantiation its sixth wave
 // (80 VGPRs with 2 spilled against 78 with none: 0.257 -> 0.265 ms per 100 k bursts, and the spill stores tripled the kernel's
 // write traffic -- which is how it was found).
-template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false, bool EN = true>
+// PL (fused batch kernel at 4 samples per symbol only): the sample array is stored POLYPHASE-PLANAR -- sample s of the flat
+// array sits at iq[(s & 3) * plane_stride + (s >> 2)] (include/gmr1_hip.h, gmr1_hip_rx_bcch_ccch_batch_planar_dev).  Only
+// addresses change: lane l still holds samples l, l + 64, ... of the window in pass 1 (four runs of 16 consecutive
+// samples of one plane each per load instead of one run of 64), so every sum is formed in the same order and every
+// result is bit-identical; pass 2's 234 samples at stride 4 from sample d (pi4cxpsk.c:292-295) are 234 CONSECUTIVE
+// samples of plane (offset + d) & 3 -- 15 lines of 128 bytes instead of every line of the window.
+template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false, bool EN = true, bool PL = false>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
                                          unsigned char *__restrict__ lds_raw, int lane, LatPre<NPL, SPS> *pre = nullptr)
 {
@@ -2004,6 +2020,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// <= 16 symbols whose window is <= 64 samples: NT3 speech, DC2) drops the unrolled work the long bursts need
 	constexpr bool SMALL = GEN && NPL == 8;
 	static_assert(!FAC || SMALL, "the two-sequence variant builds on the small generic one");
+	static_assert(!PL || (SPS == 4 && !GEN && !LAT && !EN), "the planar layout exists for the fused batch kernel at sps 4");
 	const int cwh = FAC ? cw / 2 : cw;                // lags per correlation array
 	// The next burst's window in flight during this burst's correlation costs 32 registers at the body's peak.  The fused
 	// kernel does without: 78 instead of 87 VGPRs is the step from five to six waves per SIMD, and the sixth wave hides more
@@ -2164,6 +2181,17 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const float fs = (fsh - F::rotation(bt)) / (float)sps;
 
 		const float2 *__restrict__ in = a.iq + io.offset[g];
+		// PL: lanes 16 p .. 16 p + 15 read 16 consecutive places of ONE plane per load (a full 128-byte line; with lane l
+		// on samples l + 64 k, as in the interleaved layout, adjacent lanes would sit in four different lines and a load
+		// would cost sixteen times the tag look-ups): lane (p, j) holds window samples 64 k + 4 j + p -- those of lane
+		// sl = 4 j + p of the usual assignment, row for row, so only the cross-lane sums need to know (window_stats).
+		const float2 *__restrict__ pl_in = nullptr;
+		const int sl = PL ? 4 * (lane & 15) + (lane >> 4) : lane;
+		if constexpr (PL) {
+			const uint64_t o = io.offset[g];
+			const int t = (int)(o & 3) + (lane >> 4);
+			pl_in = a.iq + (o >> 2) + ((long long)(t & 3) * a.plane_stride + (t >> 2) + (lane & 15));
+		}
 		const int tl = F::tl(bt, kind);
 		const int nch = F::nch(bt);
 		constexpr int NFULL = (!GEN && SPS == 4 && NPL == 16) ? 15 : -1;
@@ -2199,6 +2227,19 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (!prepared)
 				fetch_window(in);
 		} else {
+			if constexpr (PL) {
+				window_fetch<NPL, NFULL, 16>(pl_in, in_len, sl, wv);
+#pragma unroll
+				for (int c = 0; c < NCHK; c++) {
+					const int wl = F::clen(bt, kind, c) * sps + w - 1;
+					const float2 *__restrict__ src = pl_in + F::cpos(bt, c);
+#pragma unroll
+					for (int h = 0; h < SIT; h++) {
+						const int sidx = sl + 64 * h;
+						sv[c][h] = sidx < wl ? src[16 * h] : make_float2(0.f, 0.f);
+					}
+				}
+			} else {
 			if (q == 0 || !PREFETCH_NEXT)
 				window_fetch<NPL, NFULL>(in, in_len, lane, wv);
 #pragma unroll
@@ -2210,6 +2251,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 					const int sidx = lane + 64 * h;
 					sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
 				}
+			}
 			}
 		}
 		// rotated reference of the (single) sync sequence: without a caller-supplied frequency shift it only depends on
@@ -2245,7 +2287,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (io.energy && lane == 0)
 				io.energy[g] = pre->h_stat[3];
 		} else {
-		window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
+		window_stats<NPL, NFULL>(wv, in_len, sl, avr, avi, inv, PL ? 16 * (lane & 3) + (lane >> 2) : -1);
 		if ((LAT || !PREFETCH_NEXT) && EN && io.energy) {
 			// burst_energy() while the window is still in registers
 			const float e = window_energy_regs<NPL>(wv, in_len, lane);
@@ -2274,7 +2316,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const int wl = c < nch ? F::clen(bt, kind, c) * sps + w - 1 : 0;
 #pragma unroll
 				for (int h = 0; h < SIT; h++) {
-					const int sidx = lane + 64 * h;
+					const int sidx = sl + 64 * h;
 					if (sidx < wl) {
 						const v2f nv = ((v2f){sv[c][h].x, sv[c][h].y} - (v2f){avr, avi}) * (v2f){inv, inv};
 						L.x[wb + sidx] = make_float2(nv.x, nv.y);
@@ -2583,12 +2625,17 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int d = __builtin_amdgcn_readlane(d_r, src);
 		const float2 *__restrict__ in = a.iq + io.offset[g];
 		const int blen = F::len(bt);
+		if constexpr (PL) {
+			// the kept samples d, d + 4, ... are consecutive in plane (offset + d) & 3
+			const long long sr = (long long)io.offset[g] + d;
+			in = a.iq + (sr & 3) * a.plane_stride + (sr >> 2);
+		}
 #pragma unroll
 		for (int r = 0; r < NSYM; r++) {
 			const int i = lane + 64 * r;
 			const int j = i * sps + d;
 			if (i < blen && j >= 0 && j < in_len) {
-				o.x[r] = in[j];
+				o.x[r] = PL ? in[i] : in[j];
 				o.ok |= 1 << r;
 			}
 		}
@@ -2626,6 +2673,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				if (idx >= 0 && idx < in_len_r) {
 					// LAT, the wave's one burst: its sync-chunk windows are still staged (normalised, which no angle
 					// below notices) -- no second trip to L2
+					if constexpr (PL) {
+						// sample sp sps + d of the window = place sp of the plane the kept samples lie in
+						const long long sr = (long long)(row_live ? io.offset[g_row] : 0) + d_r;
+						xr[h] = (a.iq + (sr & 3) * a.plane_stride + (sr >> 2))[sp];
+					} else
 					xr[h] = LAT ? xst_lat[wb + nn * sps + d_r] : in_r[idx];
 				}
 				chn[h] = ch;
@@ -2881,7 +2933,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 template <int NPL, int SPS, bool EN = false>
 constexpr int kRx4Waves = NPL > 16 ? 3 : ((SPS == 4 && !EN) ? 6 : 5);
 
-template <int NPL, int SPS, bool ACC = false, bool EN = false>
+template <int NPL, int SPS, bool ACC = false, bool EN = false, bool PL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS, EN>, kRx4Waves<NPL, SPS, EN>)))
 void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 {
@@ -2915,7 +2967,7 @@ void k_rx4(RxArgs a, int stage_samples, int cw, int bpw)
 #endif
 	                 a.offset, a.kind, a.freq_shift, a.l2, a.crc, a.conv, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
-	rx4_body<NPL, SPS, false, false, false, ACC, EN>(a, io, stage_samples, cw, g0, n_end, lds_raw, (int)threadIdx.x);
+	rx4_body<NPL, SPS, false, false, false, ACC, EN, PL>(a, io, stage_samples, cw, g0, n_end, lds_raw, (int)threadIdx.x);
 }
 
 // demodulation only, one burst format per launch, four bursts per wavefront (rx4_body<..., GEN>)
@@ -3586,6 +3638,18 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 			const int grid4 = sliced ? (a.n / a.seg_stride) * a.seg_groups : (a.n + bpw - 1) / bpw;
 			// (the instantiation with the burst energy and the segment bound is the receive loop's: see rx4_body's EN)
 			const bool en = a.energy != nullptr || a.seg_count != nullptr;
+			if (a.plane_stride) {
+				// polyphase-planar sample array: the fused batch kernel at 4 samples per symbol (the host refuses anything else)
+				if constexpr (NPL == 16 && SPS == 4) {
+					if (en)
+						return hipErrorInvalidValue;
+					if (a.conv_acc)
+						hipLaunchKernelGGL((k_rx4<16, 4, true, false, true>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+					else
+						hipLaunchKernelGGL((k_rx4<16, 4, false, false, true>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
+				} else
+					return hipErrorInvalidValue;
+			} else
 			if (a.conv_acc) {
 				if (en)
 					hipLaunchKernelGGL((k_rx4<NPL, SPS, true, true>), dim3(grid4), dim3(64), lds4 + pad, stream, a, a.stage_samples, cw, bpw);
@@ -3642,6 +3706,41 @@ hipError_t launch_rx(const RxArgs &a, bool decode, int max_in_len, hipStream_t s
 		return launch_rx_t<32, 0>(a, decode, max_in_len, max_len, stream);
 	}
 	return launch_rx_t<64, 0>(a, decode, max_in_len, max_len, stream);
+}
+
+// Interleaved sample array -> polyphase-planar (what gmr1_hip_rx_bcch_ccch_batch_planar_dev reads): a work-group takes 256 sps
+// consecutive samples; thread t of it reads samples t, t + 256, ... (coalesced) and, through LDS, writes place t of each of
+// the sps planes (coalesced again).  HBM-bound by construction: every sample read once, written once.
+constexpr int kPlanarTile = 256;
+__global__ __launch_bounds__(256) void k_to_planar(const float2 *__restrict__ in, float2 *__restrict__ out, unsigned long long n,
+                                                   int sps, long long plane_stride)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float2 *t = reinterpret_cast<float2 *>(lds_raw);
+	const unsigned long long p0 = (unsigned long long)blockIdx.x * kPlanarTile;     // first place of the tile in every plane
+	const unsigned long long s0 = p0 * (unsigned long long)sps;
+	for (int k = 0; k < sps; k++) {
+		const unsigned long long s = s0 + (unsigned long long)(k * kPlanarTile + (int)threadIdx.x);
+		t[k * kPlanarTile + threadIdx.x] = s < n ? in[s] : make_float2(0.f, 0.f);
+	}
+	__syncthreads();
+	for (int ph = 0; ph < sps; ph++) {
+		const unsigned long long s = s0 + (unsigned long long)((int)threadIdx.x * sps + ph);
+		if (s < n)
+			out[(long long)ph * plane_stride + (long long)(p0 + threadIdx.x)] = t[(int)threadIdx.x * sps + ph];
+	}
+}
+
+hipError_t launch_to_planar(const float2 *in, float2 *out, unsigned long long n, int sps, long long plane_stride, hipStream_t stream)
+{
+	if (n == 0)
+		return hipSuccess;
+	const unsigned long long places = (n + (unsigned long long)sps - 1) / (unsigned long long)sps;
+	const unsigned long long grid = (places + kPlanarTile - 1) / kPlanarTile;
+	if (grid > 0x7fffffffull)
+		return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_to_planar, dim3((unsigned)grid), dim3(256), (size_t)sps * kPlanarTile * 8, stream, in, out, n, sps, plane_stride);
+	return hipGetLastError();
 }
 
 #ifdef GMR1_HIP_PROFILE

@@ -57,8 +57,9 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_burst_get.restype = C.POINTER(Burst)
         _lib.orc_burst_get.argtypes = [C.c_int]
-        if os.environ.get("ORC_CONV_MODE") == "1":          # bench.py --conv-decoder acc: the checker runs decision D1b
-            _lib.orc_conv_set_mode(C.c_int(1))
+        # the checker follows the product's default: decision D1b (libosmocore's accelerated decoder where it dispatches
+        # to it); ORC_CONV_MODE=0 (bench.py --conv-decoder generic) restates the generic decoder everywhere (D1)
+        _lib.orc_conv_set_mode(C.c_int(0 if os.environ.get("ORC_CONV_MODE") == "0" else 1))
     return _lib
 
 

@@ -385,3 +385,89 @@ def test_empty_batches_are_no_ops(gpu_api):
     rec, status, chains, found = gpu_api.rx_run(x, [], [], sps=4)
     assert found == 0 and len(rec) == 0
     assert gpu_api.channelize(np.zeros(6400, np.complex64), 2.0e6, []).shape[0] == 0
+
+
+def _to_planar_numpy(iq, sps, plane_stride):
+    """Sample s of the flat array at planes[(s % sps) * plane_stride + s // sps] (include/gmr1_hip.h)."""
+    out = np.zeros(sps * plane_stride, np.complex64)
+    s = np.arange(iq.size)
+    out[(s % sps) * plane_stride + s // sps] = iq
+    return out
+
+
+@pytest.mark.parametrize("sps,n", [(4, 4099), (1, 1000), (3, 777), (16, 70000), (7, 5)])
+def test_iq_to_planar_layout(gpu_api, sps, n):
+    import torch
+    rng = np.random.default_rng(sps * 1000 + n)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    P = -(-n // sps) + 3                                     # a stride with slack: the slack is left alone
+    d_in = torch.from_numpy(x.view(np.float32)).cuda()
+    d_out = torch.full((sps * P * 2,), 7.0, dtype=torch.float32, device="cuda")
+    gpu_api.iq_to_planar_dev(None, sps, n, d_in.data_ptr(), d_out.data_ptr(), P)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.complex64)
+    want = np.full(sps * P, 7.0 + 7.0j, np.complex64)
+    s = np.arange(n)
+    want[(s % sps) * P + s // sps] = x
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n,align", [(6000, 16), (6001, 1), (300, 1)])
+def test_fused_rx_planar_layout_bit_identical(gpu_api, pkg, decoder, n, align):
+    """gmr1_hip_rx_bcch_ccch_batch_planar_dev: the polyphase-planar sample layout changes addresses only -- every output
+    (payload, CRC, conv, toa, freq_err, rv, all soft bits, all soft symbols) equals the interleaved call's bit for bit, for
+    windows starting anywhere (align 1: offsets of every residue mod 4), in the four-bursts-per-wave shape (n > 4096)
+    and the one-burst-per-wave shape, in both decoder modes."""
+    import torch
+    wl = workloads.bcch_ccch_mix(pkg, n=n, seed=41 + n, stride_align=align)
+    if align == 1:
+        # re-pack with 0..4 samples of slack in front of every window: offsets of every residue mod 4
+        lens = np.where(wl["kind"] == 0, 1016, 976)
+        pad = np.arange(n) % 5
+        new_off = np.cumsum(np.concatenate([[0], (lens + pad)[:-1]])) + pad
+        iq2 = np.zeros(int(new_off[-1] + lens[-1]) + 4, np.complex64)
+        for i in range(n):
+            iq2[new_off[i]:new_off[i] + lens[i]] = wl["iq"][int(wl["offset"][i]):int(wl["offset"][i]) + lens[i]]
+        wl["iq"], wl["offset"] = iq2, new_off.astype(np.uint64)
+        assert len(set(int(o) & 3 for o in wl["offset"])) == 4
+    total = wl["iq"].size
+    P = -(-total // 4)
+    d_iq = torch.from_numpy(wl["iq"].view(np.float32)).cuda()
+    d_pl = torch.zeros(4 * P * 2, dtype=torch.float32, device="cuda")
+    gpu_api.iq_to_planar_dev(None, 4, total, d_iq.data_ptr(), d_pl.data_ptr(), P)
+    d_off = torch.from_numpy(wl["offset"].astype(np.int64)).cuda()
+    d_kind = torch.from_numpy(wl["kind"]).cuda()
+
+    def run(planar):
+        o = dict(l2=torch.zeros((n, 24), dtype=torch.uint8, device="cuda"), crc=torch.zeros(n, dtype=torch.int32, device="cuda"),
+                 conv=torch.zeros(n, dtype=torch.int32, device="cuda"), toa=torch.zeros(n, dtype=torch.float32, device="cuda"),
+                 fe=torch.zeros(n, dtype=torch.float32, device="cuda"), eb=torch.zeros((n, 432), dtype=torch.int8, device="cuda"),
+                 ss=torch.zeros((n, 234), dtype=torch.float32, device="cuda"), rv=torch.zeros(n, dtype=torch.int32, device="cuda"))
+        tail = (d_off.data_ptr(), d_kind.data_ptr(), None, o["l2"].data_ptr(), o["crc"].data_ptr(), o["conv"].data_ptr(),
+                o["toa"].data_ptr(), o["fe"].data_ptr(), o["eb"].data_ptr(), o["ss"].data_ptr(), o["rv"].data_ptr())
+        if planar:
+            gpu_api.rx_bcch_ccch_batch_planar_dev(None, n, 4, d_pl.data_ptr(), P, *tail)
+        else:
+            gpu_api.rx_bcch_ccch_batch_dev(None, n, 4, d_iq.data_ptr(), *tail)
+        torch.cuda.synchronize()
+        return {k: v.cpu().numpy() for k, v in o.items()}
+
+    a, b = run(False), run(True)
+    assert (a["crc"] == 0).mean() > 0.9
+    good = a["crc"] == 0
+    assert np.array_equal(a["l2"][good], wl["l2"][good])
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), f"{k} differs between the two sample layouts"
+
+
+def test_fused_rx_planar_layout_refusals(gpu_api):
+    import torch
+    z = torch.zeros(64, dtype=torch.float32, device="cuda")
+    with pytest.raises(RuntimeError):         # another oversampling: the planar kernel is built for 4 samples per symbol
+        gpu_api.rx_bcch_ccch_batch_planar_dev(None, 1, 8, z.data_ptr(), 8, z.data_ptr(), z.data_ptr(), None, z.data_ptr(),
+                                              z.data_ptr(), z.data_ptr(), None, None, None, None, z.data_ptr())
+    with pytest.raises(RuntimeError):         # no stride
+        gpu_api.rx_bcch_ccch_batch_planar_dev(None, 1, 4, z.data_ptr(), 0, z.data_ptr(), z.data_ptr(), None, z.data_ptr(),
+                                              z.data_ptr(), z.data_ptr(), None, None, None, None, z.data_ptr())
+    with pytest.raises(RuntimeError):         # planes shorter than the samples
+        gpu_api.iq_to_planar_dev(None, 4, 100, z.data_ptr(), z.data_ptr(), 24)

@@ -6,7 +6,9 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 tag=$1
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic_${tag}_$n -- python3 bench.py --no-cpu --preroll-s 0.05 --steps 10 > gpurun_out/traffic_${tag}_$n.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic_${tag}_$n -- python3 bench.py --no-cpu --no-extras --preroll-s 0.05 --steps 10 > gpurun_out/traffic_${tag}_$n.log 2>&1
+  # the same three passes with the opt-in polyphase-planar layout as the timed step (bench.py --layout planar)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/traffic_${tag}_pl_$n -- python3 bench.py --no-cpu --layout planar --preroll-s 0.05 --steps 10 > gpurun_out/traffic_${tag}_pl_$n.log 2>&1
 done
 python3 - $tag <<'PY'
 import csv, glob, hashlib, json, os, sys
@@ -22,6 +24,10 @@ fetch, n = mean("FETCH_SIZE", "FETCH_SIZE")
 write, _ = mean("WRITE_SIZE", "WRITE_SIZE")
 hit, _ = mean("TCC_HIT_sum", "TCC_HIT_sum")
 miss, _ = mean("TCC_MISS_sum", "TCC_HIT_sum")
+pfetch, pn = mean("FETCH_SIZE", "pl_FETCH_SIZE")
+pwrite, _ = mean("WRITE_SIZE", "pl_WRITE_SIZE")
+phit, _ = mean("TCC_HIT_sum", "pl_TCC_HIT_sum")
+pmiss, _ = mean("TCC_MISS_sum", "pl_TCC_HIT_sum")
 sys.path.insert(0, ".")
 import bench
 out = {"_comment": "Fabric-side bytes per launch of k_rx4<16,4> over 100000 bursts: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
@@ -31,6 +37,10 @@ out = {"_comment": "Fabric-side bytes per launch of k_rx4<16,4> over 100000 burs
        "tag": tag, "launches_averaged": n, "fetch_size_raw_kb": fetch, "write_size_raw_kb": write,
        "tcc_hit_rate": hit / (hit + miss) if hit + miss else None,
        "k_rx_bytes_per_launch_100k": int(2 * fetch * 1024 + write * 1024),
+       "planar": {"_comment": "the same counters for k_rx4<16,4,*,false,true> (gmr1_hip_rx_bcch_ccch_batch_planar_dev, bench.py --layout planar)",
+                  "launches_averaged": pn, "fetch_size_raw_kb": pfetch, "write_size_raw_kb": pwrite,
+                  "tcc_hit_rate": phit / (phit + pmiss) if phit + pmiss else None},
+       "k_rx_planar_bytes_per_launch_100k": int(2 * pfetch * 1024 + pwrite * 1024),
        "kernel_sources_sha256": bench.kernel_sources_hash()}
 json.dump(out, open("gpurun_out/hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out))
