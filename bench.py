@@ -391,13 +391,13 @@ def run_side_workload(args):
     from __graft_entry__ import load_package
     import workloads
     import oracle_lib
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    rank, world, backend, dev, dev_index, grouped = init_ranks()     # (only tch3 comes here with more than one rank)
     pkg = load_package()
     api = pkg.api
     api.load()
-    api.init(0)
+    api.init(dev_index)
     stream = torch.cuda.current_stream(dev)
+    n_global = None
     if args.workload == "fcch":
         n = args.streams
         wl = workloads.fcch_streams(pkg, n, seed=2)
@@ -428,8 +428,14 @@ def run_side_workload(args):
         workload = (f"configs[1]: FCCH rough + fine, {n} x 1-s streams @ 93.6 ksps (rough: 23 284 lags x 117 taps each; "
                     "fine: 117-point DFT of the found burst)")
     else:
-        n = args.bursts * 10
-        wl = workloads.tch3_bursts(pkg, n, seed=5)
+        # N GPUs: ONE global workload, rank r decodes the contiguous block shard.partition_contiguous gives it (edges on
+        # multiples of 4 as for the FACCH3 groups of the from-samples workload); strong scaling, no collective
+        n_global = args.bursts * 10
+        wl = workloads.tch3_bursts(pkg, n_global, seed=5)
+        g0, g1 = pkg.shard.partition_contiguous(n_global, world, rank, group=4)
+        n = g1 - g0
+        eb_all = wl["ebits"]
+        wl = dict(wl, ebits=eb_all[g0:g1])
         eb = torch.from_numpy(wl["ebits"]).to(dev)
         frames = torch.zeros((n, 2, 10), dtype=torch.uint8, device=dev)
         st = torch.zeros((n, 4), dtype=torch.uint8, device=dev)
@@ -441,35 +447,66 @@ def run_side_workload(args):
             rc = f(C.c_void_p(stream.cuda_stream), C.c_int(n), C.c_int(0), C.c_void_p(eb.data_ptr()), None,
                    C.c_void_p(frames.data_ptr()), C.c_void_p(st.data_ptr()), C.c_void_p(conv.data_ptr()))
             assert rc == 0
-        units, unit = n / 1e6, "Mbursts/s"
+        units, unit = n_global / 1e6, "Mbursts/s"
         bytes_per_launch = n * (212 + 24 + 8)
         kernel = "k_tch3"
-        workload = f"configs[4] l1-only: {n} NT3 speech bursts, descramble + 104-perm + punctured K=7 tail-biting Viterbi"
+        workload = (f"configs[4] l1-only: {n_global} NT3 speech bursts, descramble + 104-perm + punctured K=7 tail-biting Viterbi"
+                    + (f"; contiguous blocks over {world} ranks, no collective" if world > 1 else ""))
+
+    def barrier():
+        if grouped:
+            import torch.distributed as dist
+            dist.barrier()
     preroll(step, args.preroll_s)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
         step()
     ev1.record(stream)
     torch.cuda.synchronize()
+    barrier()
     wall = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps
+    sharded_same = None
+    if grouped:
+        import torch.distributed as dist
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+        if world > 1:
+            got = gather_bytes(frames.cpu().numpy(), rank, world, backend, dev)
+            if rank == 0:
+                # ONE run over the whole workload on this GPU: what the ranks' blocks, concatenated, must equal
+                eb1 = torch.from_numpy(eb_all).to(dev)
+                fr1 = torch.zeros((n_global, 2, 10), dtype=torch.uint8, device=dev)
+                rc = f(C.c_void_p(stream.cuda_stream), C.c_int(n_global), C.c_int(0), C.c_void_p(eb1.data_ptr()), None,
+                       C.c_void_p(fr1.data_ptr()), None, None)
+                assert rc == 0
+                torch.cuda.synchronize()
+                sharded_same = bool(np.array_equal(got, fr1.cpu().numpy().reshape(-1)))
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     out = {"metric": "Mbursts/s demod+Viterbi (and IQ Msamp/s), 1/2/4/8 MI355X", "value": units * args.steps / wall,
-           "unit": unit, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
            "vs_baseline": None, "dtype": "f32" if args.workload == "fcch" else "i32", "data": "synthetic",
            "config": {"workload": workload},
            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                         "algorithmic_bytes_per_launch": bytes_per_launch}}
+    if sharded_same is not None:
+        out["checks"] = {"sharded_outputs_identical_to_single_gpu_run": sharded_same}
     # CPU baseline + parity on a bounded sample
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:
         oracle_lib.lib()
         if args.workload == "fcch":
             m = min(n, 24)
@@ -491,82 +528,101 @@ def run_side_workload(args):
             out["checks"] = {"frames_identical_to_oracle": bool(np.array_equal(g0[:, 0], ref[0]) and
                                                                  np.array_equal(g0[:, 1], ref[1])),
                              "conv_identical": bool(np.array_equal(conv.cpu().numpy()[:m, 0], ref[3]))}
-    emit(out)
+    emit(out, flush=True)
+    if grouped:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def run_nt3_workload(args):
-    """BASELINE.md configs[4] from samples (SURVEY.md section 8d, config 5): NT3 bursts, 90 % speech and 10 % FACCH3 in
-    groups of four, window 474 samples; per step: demodulate the speech bursts, decode them (TCH3), demodulate the FACCH3
-    bursts, decode the groups -- four launches, everything resident in HBM.  100 k distinct bursts are generated on the
-    host and tiled in HBM to the requested size (distinct memory, so the tiles are not cache hits of each other)."""
+    """BASELINE.md configs[4] from samples (SURVEY.md section 8d / 8e, config 5): NT3 bursts, 90 % speech and 10 % FACCH3 in
+    groups of four, window 474 samples; per step: speech bursts from samples to speech frames (one launch), FACCH3 bursts
+    demodulated and their groups decoded -- everything resident in HBM.  100 k distinct bursts are generated on the host
+    (the same on every rank: one seed) and global burst g is distinct burst g mod 100 k, each in its own memory (the tiles
+    are not cache hits of each other).
+    N GPUs: ONE global workload of --bursts x 10 bursts, rank r takes the contiguous block
+    shard.partition_contiguous(n, N, r, group=4) -- block edges on FACCH3 groups, which decode as a unit
+    (facch3.c:121-158) -- no data-path collective, barrier + max-over-ranks timing, `scaling: strong`; after the timed
+    region rank 0 gathers every rank's speech frames and FACCH3 results and compares them with ONE run over the whole
+    workload on its own GPU."""
     import ctypes as C
     import torch
     from __graft_entry__ import load_package
     import workloads
-    import oracle_lib
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
+    rank, world, backend, dev, dev_index, grouped = init_ranks()
     pkg = load_package()
     api = pkg.api
     api.load()
-    api.init(0)
+    api.init(dev_index)
     L = api.load()
     stream = torch.cuda.current_stream(dev)
     n = args.bursts * 10
     base = min(n, 100_000)
     base -= base % 40
     reps = max(1, n // base)
-    n = base * reps
+    n = base * reps                                    # the global workload
     t_gen = time.time()
     wl = workloads.nt3_mix(pkg, base, seed=5)
     t_gen = time.time() - t_gen
     stride = wl["stride"]
-    iq = torch.from_numpy(wl["iq"].view(np.float32)).to(dev).repeat(reps)
-
-    def tiled(idx):            # burst indices of one kind in every tile -> sample offsets
-        off = np.concatenate([(idx + r * base) for r in range(reps)]).astype(np.int64) * stride
-        return torch.from_numpy(off).to(dev)
-
-    off_s, off_f = tiled(wl["speech"]), tiled(wl["facch"])
-    fs_s = torch.from_numpy(np.tile(wl["freq_shift"][wl["speech"]], reps)).to(dev)
-    fs_f = torch.from_numpy(np.tile(wl["freq_shift"][wl["facch"]], reps)).to(dev)
-    n_s, n_f = off_s.numel(), off_f.numel()
-    eb_s = torch.zeros((n_s, 212), dtype=torch.int8, device=dev)
-    eb_f = torch.zeros((n_f, 104), dtype=torch.int8, device=dev)
-    sid_s = torch.zeros(n_s, dtype=torch.int32, device=dev)
-    sid_f = torch.zeros(n_f, dtype=torch.int32, device=dev)
-    toa_s = torch.zeros(n_s, dtype=torch.float32, device=dev)
-    toa_f = torch.zeros(n_f, dtype=torch.float32, device=dev)
-    rv_s = torch.zeros(n_s, dtype=torch.int32, device=dev)
-    rv_f = torch.zeros(n_f, dtype=torch.int32, device=dev)
-    frames = torch.zeros((n_s, 2, 10), dtype=torch.uint8, device=dev)
-    st = torch.zeros((n_s, 4), dtype=torch.uint8, device=dev)
-    conv_s = torch.zeros((n_s, 2), dtype=torch.int32, device=dev)
-    l2f = torch.zeros((n_f // 4, 10), dtype=torch.uint8, device=dev)
-    bs_f = torch.zeros((n_f // 4, 32), dtype=torch.uint8, device=dev)
-    crc_f = torch.zeros(n_f // 4, dtype=torch.int32, device=dev)
-    conv_f = torch.zeros(n_f // 4, dtype=torch.int32, device=dev)
+    base_dev = torch.from_numpy(wl["iq"].view(np.float32)).to(dev).view(base, stride * 2)
     P = lambda t: C.c_void_p(t.data_ptr())
     sp = C.c_void_p(stream.cuda_stream)
-    id_s, id_f = api.BURST_IDS.index("nt3_speech"), api.BURST_IDS.index("nt3_facch")
+    id_f = api.BURST_IDS.index("nt3_facch")
 
-    want_eb = [False]
+    def resident(g0, g1):
+        """Inputs and result buffers of the global bursts [g0, g1) in this rank's HBM."""
+        gi = np.arange(g0, g1, dtype=np.int64)
+        bi = gi % base
+        W = {"n": g1 - g0, "iq": base_dev.index_select(0, torch.from_numpy(bi).to(dev)).reshape(-1)}
+        fac = (gi % 40) >= 36
+        loc = np.arange(g1 - g0, dtype=np.int64)
+        W["off_s"] = torch.from_numpy(loc[~fac] * stride).to(dev)
+        W["off_f"] = torch.from_numpy(loc[fac] * stride).to(dev)
+        W["fs_s"] = torch.from_numpy(wl["freq_shift"][bi[~fac]]).to(dev)
+        W["fs_f"] = torch.from_numpy(wl["freq_shift"][bi[fac]]).to(dev)
+        n_s, n_f = W["off_s"].numel(), W["off_f"].numel()
+        assert n_f % 4 == 0
+        W["n_s"], W["n_f"] = n_s, n_f
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        W.update(eb_s=z((n_s, 212), torch.int8), eb_f=z((n_f, 104), torch.int8), sid_s=z(n_s, torch.int32), sid_f=z(n_f, torch.int32),
+                 toa_s=z(n_s, torch.float32), toa_f=z(n_f, torch.float32), rv_s=z(n_s, torch.int32), rv_f=z(n_f, torch.int32),
+                 frames=z((n_s, 2, 10), torch.uint8), st=z((n_s, 4), torch.uint8), conv_s=z((n_s, 2), torch.int32),
+                 l2f=z((n_f // 4, 10), torch.uint8), bs_f=z((n_f // 4, 32), torch.uint8), crc_f=z(n_f // 4, torch.int32),
+                 conv_f=z(n_f // 4, torch.int32))
+        return W
 
-    def step():
-        if args.nt3_two_launches:
-            rc = L.gmr1_hip_demod_batch_dev(sp, C.c_int(id_s), C.c_int(n_s), C.c_int(4), C.c_int(474), P(iq), P(off_s), P(fs_s),
-                                            P(eb_s), C.c_int(212), P(sid_s), P(toa_s), None, None, P(rv_s))
-            rc |= L.gmr1_hip_tch3_decode_batch_dev(sp, C.c_int(n_s), C.c_int(0), P(eb_s), None, P(frames), P(st), P(conv_s))
-        else:
+    def run_step(W, want_eb=False):
+        n_s, n_f = W["n_s"], W["n_f"]
+        rc = 0
+        if n_s and args.nt3_two_launches:
+            id_s = api.BURST_IDS.index("nt3_speech")
+            rc = L.gmr1_hip_demod_batch_dev(sp, C.c_int(id_s), C.c_int(n_s), C.c_int(4), C.c_int(474), P(W["iq"]), P(W["off_s"]),
+                                            P(W["fs_s"]), P(W["eb_s"]), C.c_int(212), P(W["sid_s"]), P(W["toa_s"]), None, None, P(W["rv_s"]))
+            rc |= L.gmr1_hip_tch3_decode_batch_dev(sp, C.c_int(n_s), C.c_int(0), P(W["eb_s"]), None, P(W["frames"]), P(W["st"]),
+                                                   P(W["conv_s"]))
+        elif n_s:
             # rx_tch3's burst step as one call (one launch: the soft bits stay in LDS and, in the timed steps, are not
             # written out -- rx_tch3 has no use for them either; the one step after the timed ones asks for them, for the checks)
-            rc = L.gmr1_hip_tch3_rx_batch_dev(sp, C.c_int(n_s), C.c_int(4), C.c_int(474), P(iq), P(off_s), P(fs_s), C.c_int(0),
-                                              None, P(eb_s) if want_eb[0] else None, P(sid_s), P(toa_s), P(rv_s), P(frames), P(st),
-                                              P(conv_s))
-        rc |= L.gmr1_hip_demod_batch_dev(sp, C.c_int(id_f), C.c_int(n_f), C.c_int(4), C.c_int(474), P(iq), P(off_f), P(fs_f),
-                                         P(eb_f), C.c_int(104), P(sid_f), P(toa_f), None, None, P(rv_f))
-        rc |= L.gmr1_hip_facch3_decode_batch_dev(sp, C.c_int(n_f // 4), P(eb_f), None, P(l2f), P(bs_f), P(crc_f), P(conv_f))
+            rc = L.gmr1_hip_tch3_rx_batch_dev(sp, C.c_int(n_s), C.c_int(4), C.c_int(474), P(W["iq"]), P(W["off_s"]), P(W["fs_s"]),
+                                              C.c_int(0), None, P(W["eb_s"]) if want_eb else None, P(W["sid_s"]), P(W["toa_s"]),
+                                              P(W["rv_s"]), P(W["frames"]), P(W["st"]), P(W["conv_s"]))
+        if n_f:
+            rc |= L.gmr1_hip_demod_batch_dev(sp, C.c_int(id_f), C.c_int(n_f), C.c_int(4), C.c_int(474), P(W["iq"]), P(W["off_f"]),
+                                             P(W["fs_f"]), P(W["eb_f"]), C.c_int(104), P(W["sid_f"]), P(W["toa_f"]), None, None, P(W["rv_f"]))
+            rc |= L.gmr1_hip_facch3_decode_batch_dev(sp, C.c_int(n_f // 4), P(W["eb_f"]), None, P(W["l2f"]), P(W["bs_f"]),
+                                                     P(W["crc_f"]), P(W["conv_f"]))
         assert rc == 0, L.gmr1_hip_last_error()
+
+    g0, g1 = pkg.shard.partition_contiguous(n, world, rank, group=4)
+    W = resident(g0, g1)
+    n_s, n_f = W["n_s"], W["n_f"]
+    step = lambda: run_step(W)
+
+    def barrier():
+        if grouped:
+            import torch.distributed as dist
+            dist.barrier()
 
     preroll(step, args.preroll_s)
     for _ in range(args.warmup):
@@ -574,41 +630,80 @@ def run_nt3_workload(args):
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
+    barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
         step()
     ev1.record(stream)
     torch.cuda.synchronize()
+    barrier()
     wall = time.perf_counter() - t0
     step_ms = ev0.elapsed_time(ev1) / args.steps
-    want_eb[0] = True
-    step()
+    if grouped:
+        import torch.distributed as dist
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    run_step(W, want_eb=True)
     torch.cuda.synchronize()
+    # ---- N > 1: every rank's results to rank 0, compared with one run over the whole workload on rank 0's GPU ----
+    sharded_same = None
+    if world > 1:
+        got = [gather_bytes(W[k].cpu().numpy(), rank, world, backend, dev) for k in ("frames", "st", "l2f", "crc_f")]
+        if rank == 0:
+            Wall = resident(0, n)
+            run_step(Wall)
+            torch.cuda.synchronize()
+            sharded_same = all(np.array_equal(g, Wall[k].cpu().numpy().reshape(-1).view(np.uint8))
+                               for g, k in zip(got, ("frames", "st", "l2f", "crc_f")))
+            del Wall
+    if grouped:
+        import torch.distributed as dist
+        if rank != 0:
+            dist.destroy_process_group()
+            return
     # speech 474 x 8 + 20 + 4 + 12 = 3 828 B, FACCH3 474 x 8 per burst + (10 + 32 + 8) per group
     bytes_per_step = n_s * 3828 + n_f * 3792 + (n_f // 4) * 50
     achieved = bytes_per_step / (step_ms * 1e-3) / 1e9
     out = {"metric": "Mbursts/s demod+Viterbi (and IQ Msamp/s), 1/2/4/8 MI355X", "value": n * args.steps / wall / 1e6,
-           "unit": "Mbursts/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "unit": "Mbursts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+           "vs_baseline": None,
            "dtype": "f32+i32", "data": "synthetic",
-           "config": {"workload": f"configs[4] from samples: {n} NT3 bursts ({n_s} speech + {n_f} FACCH3 in groups of 4, "
-                                  f"{base} distinct, tiled x{reps}), window 474 @ sps 4: pi4cxpsk demod + TCH3 / FACCH3 layer 1"},
+           "config": {"workload": f"configs[4] from samples: {n} NT3 bursts ({n * 9 // 10} speech + {n // 10} FACCH3 in groups of 4, "
+                                  f"{base} distinct, each in its own memory), window 474 @ sps 4: pi4cxpsk demod + TCH3 / FACCH3 layer 1",
+                      "global_bursts": n, "bursts_on_rank_0": g1 - g0,
+                      "parallelism": f"contiguous blocks of the one workload over {world} rank(s), edges on FACCH3 groups of 4, no collective"},
            "iq_msamp_per_s": n * 474 * args.steps / wall / 1e6,
-           "roofline": {"bound": "hbm", "kernel": ("k_rx4g<8,4> + k_tch3" if args.nt3_two_launches else "k_rx4g_tch3") + " + k_rx4g<8,4,FAC> + k_facch3 (whole step)", "achieved": achieved,
+           "roofline": {"bound": "hbm", "kernel": ("k_rx4g<8,4> + k_tch3" if args.nt3_two_launches else "k_rx4g_tch3") + " + k_rx4g<8,4,FAC> + k_facch3 (whole step, rank 0's block)", "achieved": achieved,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                         "kernel_ms": step_ms, "algorithmic_bytes_per_launch": bytes_per_step},
            "checks": {"workload_gen_s": round(t_gen, 1)}}
-    # what came back, against what was sent (class-1 speech bits are protected, the 32 class-2 bits of a frame are not)
-    h_fr = frames.cpu().numpy()[:wl["speech"].size]
-    c1 = (h_fr[:, :, :6] == wl["frames"][:, :, :6]).all(axis=(1, 2))
-    h_l2, h_crc = l2f.cpu().numpy()[:wl["l2"].shape[0]], crc_f.cpu().numpy()[:wl["l2"].shape[0]]
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic_nt3.json")
+    if os.path.exists(tfile) and world == 1 and n == 1_000_000 and not args.nt3_two_launches:
+        tj = json.load(open(tfile))
+        if tj.get("kernel_sources_sha256") == kernel_sources_hash():
+            out["roofline"]["traffic"] = tj.get("step_bytes_1M")
+            out["roofline"]["traffic_source"] = f"PMC FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels, separate passes, build {tj.get('tag')}"
+        else:
+            out["roofline"]["traffic_source"] = "profiles/hbm_traffic_nt3.json was taken on other kernel sources: not reported"
+    if sharded_same is not None:
+        out["checks"]["sharded_outputs_identical_to_single_gpu_run"] = bool(sharded_same)
+    # what came back, against what was sent (class-1 speech bits are protected, the 32 class-2 bits of a frame are not);
+    # rank 0's block starts at global burst 0, so its first bursts are the distinct ones in their order
+    m_sp, m_fg = min(n_s, wl["speech"].size), min(n_f // 4, wl["l2"].shape[0])
+    h_fr = W["frames"].cpu().numpy()[:m_sp]
+    c1 = (h_fr[:, :, :6] == wl["frames"][:m_sp, :, :6]).all(axis=(1, 2))
+    h_l2, h_crc = W["l2f"].cpu().numpy()[:m_fg], W["crc_f"].cpu().numpy()[:m_fg]
     good = h_crc == 0
     out["checks"].update(speech_class1_recovered_frac=float(c1.mean()), facch3_crc_pass_frac=float(good.mean()),
-                         facch3_payloads_match_sent=bool(np.array_equal(h_l2[good], wl["l2"][good])))
-    if not args.no_cpu:
+                         facch3_payloads_match_sent=bool(np.array_equal(h_l2[good], wl["l2"][:m_fg][good])))
+    if not args.no_cpu and world == 1:
+        import oracle_lib
         oracle_lib.lib()
-        m_s, m_g = min(90_000, wl["speech"].size), min(2_500, wl["l2"].shape[0])   # the first 100 000 bursts: about 10 s
+        m_s, m_g = min(90_000, m_sp), min(2_500, m_fg)   # the first 100 000 bursts: about 10 s
         w_iq = wl["iq"].reshape(-1, stride)
         tc = time.perf_counter()
         ref_fr = np.zeros((m_s, 2, 10), np.uint8)
@@ -626,7 +721,7 @@ def run_nt3_workload(args):
                        (np.abs(np.abs(got_eb[bad].astype(np.int32)) - 63) <= 1).all())
             return n_off + 1, n_mid + int(mid)
 
-        h_eb = eb_s.cpu().numpy()
+        h_eb = W["eb_s"].cpu().numpy()
         for k in range(m_s):
             i = wl["speech"][k]
             r = oracle_lib.demod("nt3_speech", w_iq[i, :474], 4, float(wl["freq_shift"][i]))
@@ -636,7 +731,7 @@ def run_nt3_workload(args):
             ref_fr[k, 0], ref_fr[k, 1] = f0[0], f1[0]
         ref_l2 = np.zeros((m_g, 10), np.uint8)
         ref_crc = np.zeros(m_g, np.int32)
-        h_ebf = eb_f.cpu().numpy()
+        h_ebf = W["eb_f"].cpu().numpy()
         for g in range(m_g):
             for j in range(4):
                 i = wl["facch"][4 * g + j]
@@ -655,7 +750,10 @@ def run_nt3_workload(args):
                              speech_frames_identical_to_oracle=bool(np.array_equal(h_fr[:m_s], ref_fr)),
                              facch3_identical_to_oracle=bool(np.array_equal(h_crc[:m_g], ref_crc) and
                                                              np.array_equal(h_l2[:m_g][ref_crc == 0], ref_l2[ref_crc == 0])))
-    emit(out)
+    emit(out, flush=True)
+    if grouped:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def time_legacy_calls(api, wl, oracle_lib, m=600):
@@ -945,36 +1043,13 @@ def _sharded_summary(args, dist, host, out, tt, A, ns, seconds, distinct, world,
     return res
 
 
-def main():
-    args = parse()
-    env_world = os.environ.get("WORLD_SIZE")
-    if args.workload != "bursts" and (args.gpus > 1 or int(env_world or "1") > 1):
-        raise SystemExit(f"bench.py: --workload {args.workload} is a one-GPU side measurement; the N-GPU line is the "
-                         "headline workload's (drop --workload)")
-    if env_world is None and args.gpus > 1:
-        # no launcher: start the N ranks ourselves, before anything in this process touches the GPU
-        raise SystemExit(spawn_ranks(args.gpus))
-    if env_world is not None and int(env_world) != args.gpus:
-        raise SystemExit(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}: refusing to report a line for the "
-                         "wrong number of GPUs (start it as `python bench.py --gpus N`, or with a launcher whose world "
-                         "size equals N)")
-    if args.workload == "nt3":
-        return run_nt3_workload(args)
-    if args.workload == "rx":
-        return run_rx_workload(args)
-    if args.workload == "chan":
-        return run_chan_workload(args)
-    if args.workload == "ambe":
-        return run_ambe_workload(args)
-    if args.workload != "bursts":
-        return run_side_workload(args)
+def init_ranks():
+    """One process per GPU: rank / world from the launcher's (or spawn_ranks') environment, the device of this rank, and
+    the process group when there is more than one rank.  Returns (rank, world, backend, device, device index, grouped)."""
     import torch
-    from __graft_entry__ import load_package
-    import workloads
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(env_world or "1")
+    world = int(os.environ.get("WORLD_SIZE") or "1")
     # GMR1_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks
     # (ranks then share devices and the exchanges run over gloo on host tensors); the driver never sets it
     backend = os.environ.get("GMR1_BENCH_BACKEND", "nccl")
@@ -998,6 +1073,56 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, backend, dev, dev_index, grouped
+
+
+def gather_bytes(arr, rank, world, backend, dev):
+    """Concatenation over the ranks (in rank order) of a uint8 array of any per-rank length, on rank 0 (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    flat = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)
+    tdev = dev if backend == "nccl" else "cpu"
+    sizes = [torch.zeros(1, dtype=torch.int64, device=tdev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([flat.size], dtype=torch.int64, device=tdev))
+    sizes = [int(x.item()) for x in sizes]
+    m = max(sizes + [1])
+    buf = torch.zeros(m, dtype=torch.uint8, device=tdev)
+    buf[:flat.size] = torch.from_numpy(flat.copy()).to(tdev)
+    parts = [torch.zeros(m, dtype=torch.uint8, device=tdev) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    if rank != 0:
+        return None
+    return np.concatenate([p[:k].cpu().numpy() for p, k in zip(parts, sizes)])
+
+
+def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.workload not in ("bursts", "nt3", "tch3") and (args.gpus > 1 or int(env_world or "1") > 1):
+        raise SystemExit(f"bench.py: --workload {args.workload} is a one-GPU side measurement; N-GPU lines exist for the "
+                         "headline workload (drop --workload) and for configs[4] (--workload nt3 | tch3)")
+    if env_world is None and args.gpus > 1:
+        # no launcher: start the N ranks ourselves, before anything in this process touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus))
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}: refusing to report a line for the "
+                         "wrong number of GPUs (start it as `python bench.py --gpus N`, or with a launcher whose world "
+                         "size equals N)")
+    if args.workload == "nt3":
+        return run_nt3_workload(args)
+    if args.workload == "rx":
+        return run_rx_workload(args)
+    if args.workload == "chan":
+        return run_chan_workload(args)
+    if args.workload == "ambe":
+        return run_ambe_workload(args)
+    if args.workload != "bursts":
+        return run_side_workload(args)
+    import torch
+    from __graft_entry__ import load_package
+    import workloads
+
+    rank, world, backend, dev, dev_index, grouped = init_ranks()
 
     pkg = load_package()
     api = pkg.api

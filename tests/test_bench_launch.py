@@ -67,6 +67,68 @@ def test_bench_gpus2_fails_loudly_without_a_gpu():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_gather_bytes_and_block_partition_world2(tmp_path):
+    """What `bench.py --workload nt3|tch3 --gpus N` does around its kernels, over gloo with two ranks: every rank takes
+    shard.partition_contiguous(n, N, r, group=4) of one global list (block edges on FACCH3 groups) and rank 0 gets the
+    ranks' result bytes back concatenated in rank order (bench.gather_bytes), ragged lengths included."""
+    child = tmp_path / "child.py"
+    child.write_text(textwrap.dedent("""
+        import json, os, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        import bench
+        from __graft_entry__ import load_package
+        pkg = load_package()
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n = 1000 * 40 + 36                                   # a ragged global count
+        g0, g1 = pkg.shard.partition_contiguous(n, world, rank, group=4)
+        assert g0 %% 4 == 0 and (g1 %% 4 == 0 or g1 == n)
+        glob = (np.arange(n, dtype=np.uint32) * 2654435761).astype(np.uint32)      # stands for per-burst results
+        mine = glob[g0:g1]
+        got = bench.gather_bytes(mine, rank, world, "gloo", torch.device("cpu"))
+        if rank == 0:
+            print(json.dumps({"same": bool(np.array_equal(got.view(np.uint32), glob)), "blocks": [g0, g1]}), flush=True)
+        else:
+            assert got is None
+        dist.destroy_process_group()
+    """ % ROOT))
+    code = ("import sys; sys.path.insert(0, %r); import bench; "
+            "sys.exit(bench.spawn_ranks(2, argv=[], script=%r, timeout=150))" % (ROOT, str(child)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["same"] and out["blocks"] == [0, 20020]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload", ["nt3", "tch3"])
+def test_bench_configs4_gpus2_over_gloo_on_one_gpu(workload):
+    """`GMR1_BENCH_BACKEND=gloo python bench.py --workload nt3|tch3 --gpus 2`: BASELINE configs[4] on more than one rank --
+    one global workload in contiguous blocks, the line says n_gpus 2 / scaling strong, and rank 0 found the ranks'
+    concatenated speech frames and FACCH3 results equal to ONE run over the whole workload."""
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has already initialised the GPU: not starting child processes from it")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["GMR1_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, BENCH, "--workload", workload, "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--bursts", "1204", "--preroll-s", "0", "--no-cpu"],
+                       capture_output=True, text=True, timeout=550, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["unit"] == "Mbursts/s"
+    assert out["checks"]["sharded_outputs_identical_to_single_gpu_run"] is True
+    if workload == "nt3":
+        assert out["config"]["global_bursts"] == 12040 and out["config"]["bursts_on_rank_0"] == 6020
+        assert out["checks"]["facch3_payloads_match_sent"]
+
+
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
 def test_bench_gpus2_over_gloo_on_one_gpu():

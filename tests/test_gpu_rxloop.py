@@ -369,3 +369,47 @@ def test_rx_loop_survives_hostile_samples(gpu_api, pkg):
     iq[rng.choice(iq.size, 2000, replace=False)] = np.nan
     got = gpu_api.rx_bcch_ccch_batch(iq, wl["offset"], wl["kind"], sps=SPS)
     assert got["rv"].shape == (n,)
+
+
+@pytest.mark.timeout(900)
+def test_rx_loop_production_length_64_carriers_60_s(gpu_api, orc, pkg, decoder):
+    """BASELINE configs[3] at its size: 64 carriers x 60 s (eight distinct, tiled -- as bench.py --workload rx runs it), one
+    gmr1_hip_rx_run_dev call.  187 feedback rounds per chain, the four slice hand-overs at production length, a minute of
+    float freq_err accumulation (gmr1_rx.c:782-789): EVERY distinct carrier's record sequence is the oracle loop's
+    (gmr1_rx.c:852-895), every tile of a carrier equals it, in both decoder modes."""
+    import torch
+    A, seconds, distinct = 64, 60.0, 8
+    host = [workloads.bcch_carrier(pkg, 700 + a, seconds=seconds, sps=SPS, stn=(5 * a) % 24, delay=a % 8,
+                                   cfo_hz=40.0 * (a - 3), esn0_db=10.0 + a)[0] for a in range(distinct)]
+    ns = host[0].size
+    base = torch.from_numpy(np.concatenate(host).view(np.float32)).cuda()
+    iq = torch.cat([base] * (A // distinct)).contiguous()
+    offset = np.arange(A, dtype=np.uint64) * np.uint64(ns)
+    length = np.full(A, ns, np.uint64)
+    rec, status, chains, found = gpu_api.rx_run_dev(None, iq.data_ptr(), offset, length, sps=SPS, max_records=A * 4096)
+    assert not status.any() and found == len(rec)
+    bounds = np.searchsorted(rec["arfcn"], np.arange(A + 1))
+    total = 0
+    for a in range(distinct):
+        orv, orec, och = orc.rx_run(host[a], sps=SPS, arfcn=a)
+        assert orv == 0 and len(orec) > 1000                   # a carrier-minute: 187 BCCH + the CCCH bursts that decode
+        want = [k[1:] for k in _key(orec)]
+        for t in range(a, A, distinct):
+            got = [k[1:] for k in _key(rec[bounds[t]:bounds[t + 1]])]
+            assert got == want, f"carrier {t} (tile of {a}): records differ from the oracle's loop"
+            assert chains[t] == och
+        total += len(orec)
+    assert found == total * (A // distinct)
+
+
+@pytest.mark.timeout(900)
+def test_rx_loop_tch3_follow_up_production_length(gpu_api, orc, pkg, decoder):
+    """gmr1_hip_rx_run_tch on one 60-s BCCH + traffic carrier pair (IMM.ASS early, ciphering switched on later): the
+    record sequence -- BCCH / CCCH, DKAB, speech, FACCH3 over a minute of a call -- is the oracle's (gmr1_rx.c:355-600)."""
+    kc = np.array([9, 8, 7, 6, 5, 4, 3, 2], np.uint8)
+    b, t, s_b, s_t = workloads.bcch_tch_pair(pkg, 61, seconds=60.0, kc=kc, cipher_after=400, k_ass=25)
+    rec, status, chains, found = gpu_api.rx_run_tch(b, t, [0], [b.size], sps=SPS, kc=kc[None, :])
+    orv, orec, och = orc.rx_run_tch(b, t, sps=SPS, arfcn=0, kc=kc)
+    assert orv == 0 and not status.any() and chains[0] == och
+    assert int(np.sum(orec["type"] >= 0x10)) > 500
+    assert _key_n(rec) == _key_n(orec)
