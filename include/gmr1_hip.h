@@ -348,10 +348,16 @@ int gmr1_hip_ddc(double samp_rate, int sps, const float *wide, uint64_t n_in, in
  * Channel k is the carrier k x 31.25 kHz above the centre (k >= n_chans / 2: below, freq2index :478-485).
  * rotation: optional pre-rotation in rad / sample (:444-448).  chan_idx: n_sel channel numbers (host);
  * out: n_sel streams, out_stride complex samples apart; *n_out = samples written per stream.
- * Built for sample rates that are n_chans x 31.25 kHz, n_chans even and <= 256 (64 channels / 2.0 Msps is
- * the fast path); other rates return -EINVAL: the pre-resampler (:451-459, which cannot run in the reference
- * either) and the multi-ARFCN synthesizer (:567-576) are not built.
- * gmr1_hip_channelize_plan reports sizes: n_mid = 2x oversampled samples per channel. */
+ * n_chans even and <= 256 (64 channels / 2.0 Msps is the fast path).  A sample rate (whole Hz) that is not
+ * n_chans x 31.25 kHz is first resampled to that rate by a 32-phase arbitrary resampler (:413-417, :453-461:
+ * pfb.arb_resampler_ccf(rate, taps=None, flt_size=32)) -- a branch that cannot run in the reference as written
+ * (it reads self.samp_rate before anything sets it); built to its evident intent, with the library's own
+ * prototype for the resampler (GNU Radio's default design is not restatable: csrc/capi_chan.cpp,
+ * design_pre_resampler).  The multi-ARFCN synthesizer (:567-576) is not built.
+ * gmr1_hip_channelize_plan reports sizes: n_mid = 2x oversampled samples per channel.
+ * gmr1_hip_channelize_planar_dev writes the n_sel streams POLYPHASE-PLANAR, the layout
+ * gmr1_hip_rx_bcch_ccch_batch_planar_dev reads: sample m of stream i is flat sample g = i x out_stride + m and
+ * goes to out_planes[(g % sps) * plane_stride + g / sps]  (plane_stride >= ceil(n_sel x out_stride / sps)). */
 int gmr1_hip_channelize_plan(double samp_rate, int sps, uint64_t n_in,
                              int32_t *n_chans, uint64_t *n_mid, uint64_t *n_out);
 int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in,
@@ -359,6 +365,9 @@ int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float
                             float *out, uint64_t out_stride, uint64_t *n_out);
 int gmr1_hip_channelize(double samp_rate, int sps, const float *wide, uint64_t n_in, float rotation,
                         int n_sel, const int32_t *chan_idx, float *out, uint64_t out_stride, uint64_t *n_out);
+int gmr1_hip_channelize_planar_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in,
+                                   float rotation, int n_sel, const int32_t *chan_idx,
+                                   float *out_planes, uint64_t out_stride, uint64_t plane_stride, uint64_t *n_out);
 
 /* ------------------------------------------------------------------------
  * The gmr1_rx receive loop over many BCCH carriers (reference src/gmr1_rx.c:605-895 and

@@ -81,6 +81,33 @@ def firdes_rrc(gain: float, fs: float, sym_rate: float, alpha: float, ntaps: int
     return (taps * gain / scale).astype(np.float32)
 
 
+def blackman_harris(ntaps: int) -> np.ndarray:
+    """Four-term Blackman-Harris window (92 dB side lobes), the window firdes' WIN_BLACKMAN_HARRIS names."""
+    n = np.arange(ntaps, dtype=np.float64)
+    a = 2.0 * np.pi * n / (ntaps - 1)
+    return 0.35875 - 0.48829 * np.cos(a) + 0.14128 * np.cos(2 * a) - 0.01168 * np.cos(3 * a)
+
+
+def pre_resampler_taps(nfilt: int = 32) -> np.ndarray:
+    """Prototype of the 32-phase PRE-resampler in front of the filterbank (gmr1_rx_sdr.py:453-461:
+    pfb.arb_resampler_ccf(rate, taps=None, flt_size=32), rate = n_chans x chan_width / samp_rate, always > 1).
+    With taps=None GNU Radio designs the prototype itself -- for rates >= 1 with its Parks-McClellan routine
+    (optfir.low_pass, pass band 0.8 x half the input band, transition 0.4 x half the input band, 100 dB), whose
+    iteration is not restatable here.  OWN DESIGN, same band edges (flat to 0.4 of the input rate, stop band from
+    0.6), window method: a Blackman-Harris windowed sinc, gain nfilt, at nfilt x the input rate, the -6 dB point in the
+    middle of that transition band (0.5), transition width 0.2, tap count int(100 fs / (22 tw)) | 1 = 727 (23 taps per
+    phase) -- firdes.low_pass_2's recipe."""
+    fs, cutoff, tw, atten = float(nfilt), 0.5, 0.2, 100.0
+    ntaps = int(atten * fs / (22.0 * tw)) | 1
+    M = (ntaps - 1) // 2
+    n = np.arange(-M, M + 1, dtype=np.float64)
+    fw = 2.0 * np.pi * cutoff / fs
+    with np.errstate(invalid="ignore", divide="ignore"):
+        taps = np.where(n == 0, fw / np.pi, np.sin(n * fw) / (n * np.pi)) * blackman_harris(ntaps)
+    fmax = taps[M] + 2.0 * taps[M + 1:].sum()
+    return (taps * (nfilt / fmax)).astype(np.float32)
+
+
 # --------------------------------------------------------------------------- plan
 class Plan:
     """Numbers gmr1_rx_sdr.py derives before it builds the flowgraph (PFBBase.__init__ :393-437,
@@ -92,9 +119,20 @@ class Plan:
         self.chan_width = chan_width
         self.n_chans = (int(math.ceil(samp_rate / chan_width)) + 1) & ~1        # :408
         resamp = (self.n_chans * chan_width) / samp_rate                        # :411
-        if abs(resamp - 1.0) >= 1e-5:
-            raise ValueError("sample rate is not n_chans x chan_width: the pre-resampler is not restated")
-        self.taps = firdes_low_pass(1.0, samp_rate, chan_width * 0.50, chan_width * 0.25)   # :432-437
+        # Off the 31.25 kHz grid the script resamples the capture to n_chans x chan_width first (:413-417, :453-461).
+        # (As written that branch cannot run in the reference: it reads self.samp_rate, which nothing has set, :416.
+        # Restated to its evident intent: the argument samp_rate.)
+        from fractions import Fraction
+        if abs(resamp - 1.0) < 1e-5:
+            self.pre_rate = None
+            mid_samp_rate = samp_rate
+        else:
+            if samp_rate != int(samp_rate):
+                raise ValueError("the sample rate must be a whole number of Hz")
+            self.pre_rate = Fraction(int(self.n_chans * chan_width), int(samp_rate))
+            self.taps_pre = pre_resampler_taps(32)
+            mid_samp_rate = math.ceil(samp_rate / chan_width) * chan_width       # :416 (not n_chans x chan_width when that count is odd)
+        self.taps = firdes_low_pass(1.0, mid_samp_rate, chan_width * 0.50, chan_width * 0.25)   # :432-437
         chan_rate = chan_width
         self.oversample = 2                                                     # :495
         self.resamp = (SYM_RATE * sps) / (chan_rate * self.oversample)          # :522
@@ -143,7 +181,7 @@ def pfb_channelizer_2x(x: np.ndarray, taps: np.ndarray, n_chans: int, rotation: 
     return out
 
 
-def arb_resampler(x: np.ndarray, rate: float, taps: np.ndarray, nfilt: int = 32, n_out: int | None = None) -> np.ndarray:
+def arb_resampler(x: np.ndarray, rate, taps: np.ndarray, nfilt: int = 32, n_out: int | None = None) -> np.ndarray:
     """gr::filter::kernel::pfb_arb_resampler_ccf: filter bank j = taps[j::nfilt], derivative bank from the
     first difference of the prototype, out[n] = f_j(x) + acc * f'_j(x) with the phase (in 1 / nfilt input
     samples) advancing by nfilt / rate per output, starting at filter (ntaps / 2) % nfilt.
@@ -161,7 +199,7 @@ def arb_resampler(x: np.ndarray, rate: float, taps: np.ndarray, nfilt: int = 32,
     # exact fraction num / den below, kept in integers so that no output lands on the wrong side of a
     # filter boundary (GNU Radio accumulates it in a float and lets it drift)
     from fractions import Fraction
-    step = Fraction(nfilt) / Fraction(rate).limit_denominator(1 << 20)
+    step = Fraction(nfilt) / (rate if isinstance(rate, Fraction) else Fraction(rate).limit_denominator(1 << 20))
     num, den = step.numerator, step.denominator
     j0 = (ntaps // 2) % nfilt
     if n_out is None:
@@ -184,6 +222,12 @@ def arb_resampler(x: np.ndarray, rate: float, taps: np.ndarray, nfilt: int = 32,
 
 def channelize(x: np.ndarray, plan: Plan, channels, rotation: float = 0.0, n_out: int | None = None):
     """Wideband capture -> {channel index: stream at sym_rate * sps}."""
+    if plan.pre_rate is not None:
+        # the script rotates first, then resamples (:444-461)
+        if rotation:
+            x = np.asarray(x, np.complex128) * np.exp(1j * rotation * np.arange(np.asarray(x).size))
+            rotation = 0.0
+        x = arb_resampler(x, plan.pre_rate, plan.taps_pre, 32)
     y = pfb_channelizer_2x(x, plan.taps, plan.n_chans, rotation)
     return {int(k): arb_resampler(y[int(k)], plan.resamp, plan.taps_resamp, plan.nfilt, n_out) for k in channels}
 

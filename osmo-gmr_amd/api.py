@@ -39,7 +39,7 @@ EXPORTED_FUNCTIONS = [
     "gmr1_pi4cxpsk_detect", "gmr1_pi4cxpsk_mod_order",
     "gmr1_hip_rx_run_dev", "gmr1_hip_rx_run", "gmr1_hip_gsmtap_pack",
     "gmr1_hip_rx_run_tch_dev", "gmr1_hip_rx_run_tch", "gmr1_hip_rx_run_full_dev", "gmr1_hip_rx_run_full", "gmr1_hip_gsmtap_pack_big",
-    "gmr1_hip_channelize_plan", "gmr1_hip_channelize_dev", "gmr1_hip_channelize",
+    "gmr1_hip_channelize_plan", "gmr1_hip_channelize_dev", "gmr1_hip_channelize", "gmr1_hip_channelize_planar_dev",
     "gmr1_hip_facch9_decode_batch_dev", "gmr1_hip_facch9_decode_batch", "gmr1_facch9_decode",
     "gmr1_hip_tch9_decode_batch_dev", "gmr1_hip_tch9_decode_batch",
     "gmr1_tch9_decode", "gmr1_interleaver_init", "gmr1_interleaver_fini",
@@ -913,6 +913,20 @@ def channelize_dev(stream, wide_ptr, n_in, samp_rate, channels, out_ptr, out_str
            C.c_uint64(n_in), C.c_float(rotation), C.c_int(ch.size), p_ch, C.c_void_p(out_ptr), C.c_uint64(out_stride),
            C.byref(no))
     _check(rc, "gmr1_hip_channelize_dev")
+    return no.value
+
+
+def channelize_planar_dev(stream, wide_ptr, n_in, samp_rate, channels, out_ptr, out_stride, plane_stride, sps=4, rotation=0.0):
+    """gmr1_hip_channelize_planar_dev: the streams written polyphase-planar (sample m of stream i at flat index
+    g = i * out_stride + m -> out[(g % sps) * plane_stride + g // sps])."""
+    ch, p_ch = _np(channels, np.int32)
+    no = C.c_uint64()
+    f = load().gmr1_hip_channelize_planar_dev
+    f.restype = C.c_int
+    rc = f(C.c_void_p(stream) if stream else None, C.c_double(samp_rate), C.c_int(sps), C.c_void_p(wide_ptr),
+           C.c_uint64(n_in), C.c_float(rotation), C.c_int(ch.size), p_ch, C.c_void_p(out_ptr), C.c_uint64(out_stride),
+           C.c_uint64(plane_stride), C.byref(no))
+    _check(rc, "gmr1_hip_channelize_planar_dev")
     return no.value
 
 

@@ -94,7 +94,47 @@ struct ChanPlan {
 	long long num = 0, den = 1;
 	float *d_taps = nullptr;
 	float2 *d_bank = nullptr;
+	// off the 31.25 kHz grid: the 32-phase pre-resampler to n_chans x 31250 Hz in front of the filterbank
+	bool pre = false;
+	int pre_j0 = 0;
+	long long pre_num = 0, pre_den = 1;      // phase step 32 / rate in 1 / 32 input samples, reduced
+	float2 *d_pre_bank = nullptr;            // 32 x 30 (tap, derivative tap)
+	// samples the filterbank sees for n_in wideband samples
+	uint64_t mid_samples(uint64_t n_in) const
+	{
+		if (!pre)
+			return n_in;
+		const long long v = ((long long)n_in * kNfilt - pre_j0) * pre_den;
+		return v > 0 ? (uint64_t)(v / pre_num) : 0;
+	}
 };
+
+// The prototype of the pre-resampler (utils/gmr1_rx_sdr.py:453-461: pfb.arb_resampler_ccf(rate, taps=None, flt_size=32)).
+// With taps=None GNU Radio designs it itself, for rates >= 1 -- the only case here: n_chans x 31250 >= samp_rate -- with
+// its Parks-McClellan routine (pass band to 0.4 of the input rate, stop band from 0.6, 100 dB), which cannot be
+// restated without gr-filter.  OWN DESIGN with the same band edges by the window method (firdes.low_pass_2's recipe):
+// Blackman-Harris windowed sinc at 32 x the input rate, gain 32, -6 dB at 0.5, transition width 0.2,
+// int(100 fs / (22 tw)) | 1 = 727 taps.  oracle/orc_chan.py: pre_resampler_taps.
+std::vector<float> design_pre_resampler(int nfilt)
+{
+	const double fs = nfilt, cutoff = 0.5, tw = 0.2, atten = 100.0;
+	const int ntaps = (int)(atten * fs / (22.0 * tw)) | 1;
+	const int M = (ntaps - 1) / 2;
+	std::vector<double> t(ntaps);
+	const double fw = 2.0 * M_PI * cutoff / fs;
+	for (int n = -M; n <= M; n++) {
+		const double a = 2.0 * M_PI * (double)(n + M) / (double)(ntaps - 1);
+		const double w = 0.35875 - 0.48829 * std::cos(a) + 0.14128 * std::cos(2 * a) - 0.01168 * std::cos(3 * a);
+		t[n + M] = (n == 0 ? fw / M_PI : std::sin(n * fw) / (n * M_PI)) * w;
+	}
+	double fmax = t[M];
+	for (int n = 1; n <= M; n++)
+		fmax += 2.0 * t[n + M];
+	std::vector<float> out(ntaps);
+	for (int i = 0; i < ntaps; i++)
+		out[i] = (float)(t[i] * ((double)nfilt / fmax));
+	return out;
+}
 
 std::mutex g_plan_mu;
 std::deque<ChanPlan> g_plans;       // addresses stay valid as plans are added
@@ -114,11 +154,37 @@ int get_plan(double samp_rate, int sps, const ChanPlan **out)
 	p.samp_rate = samp_rate; p.sps = sps; p.device = dev;
 	p.n_chans = ((int)std::ceil(samp_rate / kChanWidth) + 1) & ~1;
 	const double resamp = (p.n_chans * kChanWidth) / samp_rate;
-	if (std::fabs(resamp - 1.0) >= 1e-5)
-		return fail(-EINVAL, "channelize: sample rate %.1f is not n_chans x 31250 Hz (the pre-resampler is not built)", samp_rate);
 	if (p.n_chans > kPfbMaxChans)
 		return fail(-EINVAL, "channelize: %d channels (at most %d)", p.n_chans, kPfbMaxChans);
-	const std::vector<float> taps = design_low_pass(1.0, samp_rate, kChanWidth * 0.5, kChanWidth * 0.25);
+	// Off the grid the script resamples the capture to n_chans x 31250 Hz first and designs the filterbank's prototype
+	// for ceil(samp_rate / 31250) x 31250 Hz (:413-417; as written that branch reads self.samp_rate before anything
+	// sets it and cannot run -- built to its evident intent, the constructor's argument)
+	double mid_rate = samp_rate;
+	std::vector<float2> pre_bank;
+	if (std::fabs(resamp - 1.0) >= 1e-5) {
+		if ((double)std::llround(samp_rate) != samp_rate)
+			return fail(-EINVAL, "channelize: the sample rate must be a whole number of Hz");
+		p.pre = true;
+		mid_rate = std::ceil(samp_rate / kChanWidth) * kChanWidth;
+		const std::vector<float> pt = design_pre_resampler(kNfilt);
+		const int nt = (int)pt.size();
+		const int tpf = (nt + kNfilt - 1) / kNfilt;
+		if (tpf > 30)
+			return fail(-EINVAL, "channelize: pre-resampler of %d taps per phase", tpf);
+		p.pre_j0 = (nt / 2) % kNfilt;
+		long long num = (long long)kNfilt * std::llround(samp_rate), den = (long long)p.n_chans * (long long)kChanWidth;
+		const long long g = gcdll(num, den);
+		p.pre_num = num / g; p.pre_den = den / g;
+		pre_bank.assign((size_t)kNfilt * 30, make_float2(0.f, 0.f));
+		for (int j = 0; j < kNfilt; j++)
+			for (int k = 0; k < tpf; k++) {
+				const int i = j + k * kNfilt;
+				const float b = i < nt ? pt[i] : 0.0f;
+				const float d = (i + 1 < nt) ? (pt[i + 1] - pt[i]) : 0.0f;
+				pre_bank[(size_t)j * 30 + k] = make_float2(b, d);
+			}
+	}
+	const std::vector<float> taps = design_low_pass(1.0, mid_rate, kChanWidth * 0.5, kChanWidth * 0.25);
 	p.ntaps = (int)taps.size();
 	p.n_blocks = (p.ntaps + p.n_chans - 1) / p.n_chans + 1;
 	if (p.n_chans == 64 && p.n_blocks > kPfbMaxBlocks)
@@ -145,6 +211,10 @@ int get_plan(double samp_rate, int sps, const ChanPlan **out)
 	HIP_TRY(hipMalloc(&p.d_bank, bank.size() * sizeof(float2)));
 	HIP_TRY(hipMemcpy(p.d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
 	HIP_TRY(hipMemcpy(p.d_bank, bank.data(), bank.size() * sizeof(float2), hipMemcpyHostToDevice));
+	if (p.pre) {
+		HIP_TRY(hipMalloc(&p.d_pre_bank, pre_bank.size() * sizeof(float2)));
+		HIP_TRY(hipMemcpy(p.d_pre_bank, pre_bank.data(), pre_bank.size() * sizeof(float2), hipMemcpyHostToDevice));
+	}
 	g_plans.push_back(p);
 	*out = &g_plans.back();
 	return 0;
@@ -404,7 +474,7 @@ int gmr1_hip_channelize_plan(double samp_rate, int sps, uint64_t n_in,
 	const ChanPlan *p;
 	r = get_plan(samp_rate, sps, &p);
 	if (r) return r;
-	const uint64_t T = n_in / (uint64_t)(p->n_chans / 2);
+	const uint64_t T = p->mid_samples(n_in) / (uint64_t)(p->n_chans / 2);
 	if (n_chans) *n_chans = p->n_chans;
 	if (n_mid) *n_mid = T;
 	if (n_out) {
@@ -414,12 +484,14 @@ int gmr1_hip_channelize_plan(double samp_rate, int sps, uint64_t n_in,
 	return 0;
 }
 
-int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in,
-                            float rotation, int n_sel, const int32_t *chan_idx,
-                            float *out, uint64_t out_stride, uint64_t *n_out_p)
+static int channelize_dev_impl(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in,
+                               float rotation, int n_sel, const int32_t *chan_idx,
+                               float *out, uint64_t out_stride, uint64_t plane_stride, bool planar, uint64_t *n_out_p)
 {
 	if (!wide || n_sel < 0 || (n_sel && (!chan_idx || !out)))
 		return fail(-EINVAL, "channelize: wide / chan_idx / out are required");
+	if (planar && plane_stride < ((uint64_t)n_sel * out_stride + (uint64_t)sps - 1) / (uint64_t)(sps > 0 ? sps : 1))
+		return fail(-EINVAL, "channelize: plane_stride %llu < ceil(n_sel x out_stride / sps)", (unsigned long long)plane_stride);
 	int32_t nch;
 	uint64_t T, n_out;
 	int r = gmr1_hip_channelize_plan(samp_rate, sps, n_in, &nch, &T, &n_out);
@@ -445,22 +517,37 @@ int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float
 	DevState *s;
 	r = dev_state(&s);
 	if (r) return r;
-	// scratch: slot table + the 2x oversampled channel streams
+	// scratch: slot table + the 2x oversampled channel streams (+ the pre-resampled capture, off the grid)
 	const size_t slot_bytes = 2 * kPfbMaxChans * 4;          // slot[n_chans], then sel[n_sel]
+	const uint64_t n_pre = p->mid_samples(n_in);
+	const size_t mid_bytes = up_to((size_t)n_sel * T * sizeof(float2), 256);
 	void *ws;
-	r = dev_workspace(s, slot_bytes + (size_t)n_sel * T * sizeof(float2), &ws);
+	r = dev_workspace(s, slot_bytes + mid_bytes + (p->pre ? (size_t)n_pre * sizeof(float2) : 0), &ws);
 	if (r) return r;
 	int32_t *d_slot = static_cast<int32_t *>(ws);
 	float2 *d_mid = reinterpret_cast<float2 *>(static_cast<char *>(ws) + slot_bytes);
+	float2 *d_pre = reinterpret_cast<float2 *>(static_cast<char *>(ws) + slot_bytes + mid_bytes);
 	int32_t *d_sel = d_slot + kPfbMaxChans;
 	HIP_TRY(hipMemcpyAsync(d_slot, slot.data(), (size_t)nch * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipMemcpyAsync(d_sel, chan_idx, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
 	HIP_TRY(hipStreamSynchronize(st));      // slot[] is a host temporary
+	const float2 *pfb_in = reinterpret_cast<const float2 *>(wide);
+	if (p->pre) {
+		// rotator (if any), then pfb.arb_resampler_ccf to n_chans x 31250 Hz (gmr1_rx_sdr.py:444-461): one stream
+		ResampArgs rp;
+		std::memset(&rp, 0, sizeof(rp));
+		rp.n_slots = 1; rp.nfilt = kNfilt; rp.tpf = 30; rp.j0 = p->pre_j0; rp.num = p->pre_num; rp.den = p->pre_den;
+		rp.T = (long long)n_in; rp.n_out = (long long)n_pre; rp.out_stride = (long long)n_pre;
+		rp.y = pfb_in; rp.bank = p->d_pre_bank; rp.out = d_pre; rp.rotation = rotation;
+		HIP_TRY(launch_resamp(rp, st));
+		pfb_in = d_pre;
+		rotation = 0.0f;
+	}
 	PfbArgs pa;
 	std::memset(&pa, 0, sizeof(pa));
 	pa.n_chans = nch; pa.n_blocks = p->n_blocks; pa.ntaps = p->ntaps;
-	pa.n_in = (long long)n_in; pa.T = (long long)T; pa.rotation = rotation;
-	pa.x = reinterpret_cast<const float2 *>(wide); pa.taps = p->d_taps; pa.slot = d_slot; pa.y = d_mid;
+	pa.n_in = (long long)n_pre; pa.T = (long long)T; pa.rotation = rotation;
+	pa.x = pfb_in; pa.taps = p->d_taps; pa.slot = d_slot; pa.y = d_mid;
 	pa.sel = d_sel; pa.n_sel = n_sel;
 	HIP_TRY(launch_pfb(pa, st));
 	ResampArgs ra;
@@ -468,8 +555,27 @@ int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float
 	ra.n_slots = n_sel; ra.nfilt = kNfilt; ra.tpf = p->tpf; ra.j0 = p->j0; ra.num = p->num; ra.den = p->den;
 	ra.T = (long long)T; ra.n_out = (long long)n_out; ra.out_stride = (long long)out_stride;
 	ra.y = d_mid; ra.bank = p->d_bank; ra.out = reinterpret_cast<float2 *>(out);
+	if (planar) {
+		ra.planar_sps = sps;
+		ra.plane_stride = (long long)plane_stride;
+	}
 	HIP_TRY(launch_resamp(ra, st));
 	return 0;
+}
+
+int gmr1_hip_channelize_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in,
+                            float rotation, int n_sel, const int32_t *chan_idx,
+                            float *out, uint64_t out_stride, uint64_t *n_out_p)
+{
+	return channelize_dev_impl(stream, samp_rate, sps, wide, n_in, rotation, n_sel, chan_idx, out, out_stride, 0, false, n_out_p);
+}
+
+int gmr1_hip_channelize_planar_dev(void *stream, double samp_rate, int sps, const float *wide, uint64_t n_in,
+                                   float rotation, int n_sel, const int32_t *chan_idx,
+                                   float *out_planes, uint64_t out_stride, uint64_t plane_stride, uint64_t *n_out_p)
+{
+	return channelize_dev_impl(stream, samp_rate, sps, wide, n_in, rotation, n_sel, chan_idx, out_planes, out_stride, plane_stride,
+	                           true, n_out_p);
 }
 
 int gmr1_hip_channelize(double samp_rate, int sps, const float *wide, uint64_t n_in, float rotation,

@@ -282,7 +282,9 @@ static constexpr int kRsTapsShort = 30, kRsTapsLong = 96;
 static constexpr int kRsPeriods = 32;        // periods one wave walks
 static constexpr int kRsWinShort = 256, kRsWinLong = 512;     // LDS window (samples) per wave, >= span
 
-template <int kRsTaps, int kRsWin>
+// EXT: the instantiation that can rotate its input (the pre-resampler of an off-grid capture) and write polyphase-planar
+// output; the plain one does neither and keeps its registers
+template <int kRsTaps, int kRsWin, bool EXT = false>
 __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long long Q, int span)
 {
 	__shared__ float2 xs[kRsWin];
@@ -319,8 +321,27 @@ __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long l
 			const int w = lane + 64 * h;
 			const long long s = i_first + m * Q + w;
 			nx[h] = (w < span && s >= 0 && s < a.T) ? y[s] : make_float2(0.f, 0.f);
+			if (EXT && a.rotation != 0.0f) {
+				// e^{j rotation s}, the angle reduced in double as in k_pfb64 (long captures keep their phase)
+				const double ph = (double)a.rotation * (double)s;
+				const float fr = (float)(ph - 6.283185307179586 * rint(ph * 0.15915494309189535));
+				float sn, cs;
+				__sincosf(fr, &sn, &cs);
+				nx[h] = make_float2(nx[h].x * cs - nx[h].y * sn, nx[h].x * sn + nx[h].y * cs);
+			}
 		}
 	};
+	// polyphase-planar output: flat index g = slot out_stride + n -> plane g % sps, place g / sps; n advances by P per
+	// period, so plane and place are carried along instead of divided out per sample
+	long long pl_q = 0, pl_dq = 0;
+	int pl_r = 0, pl_dr = 0;
+	if (EXT && a.planar_sps > 0) {
+		const long long g0 = (long long)sl * a.out_stride + m0 * P + p;
+		pl_q = g0 / a.planar_sps;
+		pl_r = (int)(g0 % a.planar_sps);
+		pl_dq = P / a.planar_sps;
+		pl_dr = (int)(P % a.planar_sps);
+	}
 	fetch(m0);
 	for (int mm = 0; mm < kRsPeriods; mm++) {
 		const long long m = m0 + mm;
@@ -342,8 +363,20 @@ __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long l
 			oi = fmaf(e[k], s.y, oi);
 		}
 		const long long n = m * P + p;
-		if (live && n < a.n_out)
-			out[n] = make_float2(orr, oi);
+		if (live && n < a.n_out) {
+			if (EXT && a.planar_sps > 0)
+				a.out[(long long)pl_r * a.plane_stride + pl_q] = make_float2(orr, oi);
+			else
+				out[n] = make_float2(orr, oi);
+		}
+		if constexpr (EXT) {
+			pl_q += pl_dq;
+			pl_r += pl_dr;
+			if (pl_r >= a.planar_sps && a.planar_sps > 0) {
+				pl_r -= a.planar_sps;
+				pl_q++;
+			}
+		}
 	}
 }
 
@@ -430,8 +463,13 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 		return hipErrorInvalidValue;
 	const long long periods = (a.n_out + P - 1) / P;
 	const unsigned gx = (unsigned)((P + 63) / 64), gz = (unsigned)((periods + kRsPeriods - 1) / kRsPeriods);
+	const bool ext = a.rotation != 0.0f || a.planar_sps > 0;
+	if (lng && ext)
+		return hipErrorInvalidValue;             // (the long bank is the direct mode's: neither option reaches it)
 	if (lng)
 		hipLaunchKernelGGL((k_resamp<kRsTapsLong, kRsWinLong>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
+	else if (ext)
+		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinShort, true>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	else
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinShort>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	return hipGetLastError();

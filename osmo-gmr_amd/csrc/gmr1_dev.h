@@ -296,6 +296,10 @@ struct ResampArgs {
 	const float2 *y;           // n_slots x T
 	const float2 *bank;        // nfilt x tpf (tap, derivative tap) pairs
 	float2 *out;
+	float rotation;            // != 0: input sample s is multiplied by e^{j rotation s} as it is read (the pre-resampler
+	                           // of an off-grid capture: the script rotates first, utils/gmr1_rx_sdr.py:444-461)
+	int planar_sps;            // > 0: `out` is polyphase-planar -- sample g = slot out_stride + n of the flat output array
+	long long plane_stride;    // goes to out[(g % planar_sps) * plane_stride + g / planar_sps] (include/gmr1_hip.h)
 };
 hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream);
 hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream);

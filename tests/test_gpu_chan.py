@@ -22,8 +22,13 @@ def test_plan_matches_the_reference_formulas(gpu_api):
     n_chans, n_mid, n_out = gpu_api.channelize_plan(FS, 4, 200000)
     assert n_chans == pl.n_chans == 64 and n_mid == 200000 // 32
     assert n_out == ((n_mid * 32 - (pl.taps_resamp.size // 2) % 32) * 117) // 2500
+    # not n_chans x 31.25 kHz: the pre-resampler comes first (2.048 Msps -> 66 channels, rate 4125 / 4096)
+    po = orc_chan.Plan(2.048e6)
+    n_chans, n_mid, n_out = gpu_api.channelize_plan(2.048e6, 4, 204800)
+    n_pre = ((204800 * 32 - (po.taps_pre.size // 2) % 32) * 4125) // (32 * 4096)
+    assert n_chans == po.n_chans == 66 and n_mid == n_pre // 33
     with pytest.raises(Exception):
-        gpu_api.channelize_plan(1.9e6, 4, 1000)            # not n_chans x 31.25 kHz: needs the pre-resampler (broken in the reference too)
+        gpu_api.channelize_plan(1.9e6 + 0.5, 4, 1000)      # off the grid and not a whole number of Hz
 
 
 def test_channelizer_matches_oracle(gpu_api):
@@ -209,3 +214,76 @@ def test_direct_mode_decodes_end_to_end(gpu_api, pkg):
         n_c = sum(s["type"] == "ccch" for s in sents[c])
         assert nbc >= n_b - 3 and mp == nbc, (c, nbc, n_b, mp)
         assert nc >= 0.7 * n_c and mc >= nc - 1, (c, nc, n_c, mc)     # (the three filters' start-up costs the first frames)
+
+
+@pytest.mark.parametrize("fs", [2.048e6, 1.92e6, 2.4e6])
+def test_off_grid_sample_rates_pre_resampler(gpu_api, fs):
+    """Sample rates off the 31.25 kHz grid (gmr1_rx_sdr.py:413-417, :453-461): the capture is resampled to n_chans x 31.25
+    kHz by the 32-phase pre-resampler, then channelized.  Against the numpy oracle, and analytically: a tone placed on
+    ARFCN k (+ an offset) at the off-grid rate comes out of channel k at that offset at 4 samples per symbol; with a
+    pre-rotation of one raster step it comes out of channel k + 1."""
+    import orc_chan
+    pl = orc_chan.Plan(fs)
+    assert pl.pre_rate is not None
+    M = pl.n_chans
+    rng = np.random.default_rng(int(fs) % 1000)
+    n = int(0.12 * fs)
+    x = (rng.standard_normal((n, 2)) * 0.1).astype(np.float32).view(np.complex64).reshape(-1)
+    s = np.arange(n)
+    # (carriers beyond 0.4 x the sample rate from the centre sit in the pre-resampler's transition band, as with GNU
+    # Radio's default prototype: none of the test tones does)
+    tones = ((5, 1000.0, 1.0), (M - 9, -4000.0, 0.5), (M // 4 + 3, 6000.0, 1.5))
+    for k, f, a in tones:
+        kk = k if k < M // 2 else k - M
+        x += (a * np.exp(2j * np.pi * ((kk * 31250.0 + f) / fs) * s)).astype(np.complex64)
+    chans = [t[0] for t in tones] + [0, M - 1]
+    got = gpu_api.channelize(x, fs, chans)
+    ref = orc_chan.channelize(x, pl, chans)
+    for i, k in enumerate(chans):
+        r = ref[k]
+        assert got[i].size == r.size and abs(r.size - n / fs * 93600) < 40
+        err = np.max(np.abs(got[i] - r))
+        assert err < 2e-4 * max(1.0, float(np.sqrt(np.mean(np.abs(r) ** 2)))), (k, err)
+    for i, (k, f, a) in enumerate(tones):
+        z = got[i][2000:9000].astype(np.complex128)
+        fest = np.angle(np.mean(z[1:] * np.conj(z[:-1]))) / (2 * np.pi) * 93600.0
+        assert abs(fest - f) < 30.0, (k, fest, f)
+        assert abs(np.sqrt(np.mean(np.abs(z) ** 2)) - a) < 0.25 * a
+    rot = float(np.float32(2 * np.pi * 31250.0 / fs))          # the C API takes the rotation as a float
+    shifted = gpu_api.channelize(x, fs, [6], rotation=rot)
+    ref_rot = orc_chan.channelize(x, pl, [6], rotation=rot)[6]
+    assert np.max(np.abs(shifted[0] - ref_rot)) < 2e-4 * max(1.0, float(np.sqrt(np.mean(np.abs(ref_rot) ** 2))))
+    # one raster step up: channel 6 now carries what channel 5 carried -- up to the constant phase the rotation picks up
+    # over the pre-resampler's delay (the rotator runs at the capture's rate, the filterbank's mixers after the resampler)
+    a, b = got[0][3000:].astype(np.complex128), shifted[0][3000:].astype(np.complex128)
+    c = np.vdot(a, b)
+    c /= abs(c)
+    assert np.max(np.abs(b - c * a)) < 5e-3
+
+
+def test_channelizer_planar_output_feeds_planar_receive(gpu_api, pkg):
+    """gmr1_hip_channelize_planar_dev writes the streams polyphase-planar; the same samples as the interleaved call, at
+    out_planes[(g % sps) * plane_stride + g // sps] for flat index g = stream * out_stride + m."""
+    import torch
+    rng = np.random.default_rng(8)
+    n = 200000
+    x = rng.standard_normal((n, 2)).astype(np.float32)
+    t = torch.from_numpy(x).cuda()
+    chans = [3, 60, 17]
+    for sps in (4, 3):
+        _, _, n_out = gpu_api.channelize_plan(FS, sps, n)
+        stride = n_out + 7
+        flat = torch.zeros((len(chans), stride, 2), dtype=torch.float32, device="cuda")
+        gpu_api.channelize_dev(None, t.data_ptr(), n, FS, chans, flat.data_ptr(), stride, sps=sps)
+        P = -(-len(chans) * stride // sps) + 2
+        planes = torch.zeros((sps * P, 2), dtype=torch.float32, device="cuda")
+        w = gpu_api.channelize_planar_dev(None, t.data_ptr(), n, FS, chans, planes.data_ptr(), stride, P, sps=sps)
+        assert w == n_out
+        torch.cuda.synchronize()
+        a = flat.cpu().numpy().view(np.complex64).reshape(len(chans), stride)
+        b = planes.cpu().numpy().view(np.complex64).reshape(-1)
+        g = (np.arange(len(chans))[:, None] * stride + np.arange(n_out)[None, :])
+        assert np.array_equal(b[(g % sps) * P + g // sps], a[:, :n_out])
+        assert np.abs(a[:, :n_out]).max() > 0
+    with pytest.raises(Exception):
+        gpu_api.channelize_planar_dev(None, t.data_ptr(), n, FS, chans, planes.data_ptr(), stride, 10, sps=4)

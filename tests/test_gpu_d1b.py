@@ -1,9 +1,9 @@
 """The decoder-choice sensitivity (decision D1 vs D1b, tests/test_oracle_d1b.py) on the benchmark workloads at full
 size, from the soft bits the GPU demodulator produced: configs[2] (100 000 BCCH / CCCH bursts) and configs[4]'s NT3 mix
-(100 000 bursts: 90 000 speech + 2 500 FACCH3 groups).  The GPU decodes with D1 (bit-exact with the oracle's D1, other
-tests); here the oracle decodes the SAME soft bits with D1b and the differences are counted.  Round 3: the product decodes
-with D1b too (gmr1_hip_set_conv_decoder(GMR1_HIP_CONV_ACC)), and at these sizes it must return exactly what the oracle's D1b
-returns -- from the fused kernel and from the stand-alone layer-1 kernels."""
+(100 000 bursts: 90 000 speech + 2 500 FACCH3 groups).  The GPU decodes with D1 (gmr1_hip_set_conv_decoder(GMR1_HIP_CONV_GENERIC);
+bit-exact with the oracle's D1, other tests); the oracle decodes the SAME soft bits with D1b and the differences are
+counted.  The product decodes with D1b too (GMR1_HIP_CONV_ACC, its default since round 4), and at these sizes it must
+return exactly what the oracle's D1b returns -- from the fused kernel and from the stand-alone layer-1 kernels."""
 import numpy as np
 import pytest
 
@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_bench_bursts_100k_decoder_choice(gpu_api, orc, pkg):
     wl = workloads.bcch_ccch_mix(pkg, n=100_000, seed=3)              # bench.py's configs[2] workload (rank 0)
-    got = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4, want_ssyms=False)
+    with gpu_api.conv_decoder(gpu_api.CONV_GENERIC):                  # D1: the generic decoder (not the default any more)
+        got = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4, want_ssyms=False)
     found = got["rv"] == 0
     l2 = np.zeros((wl["kind"].size, 24), np.uint8)
     crc = np.full(wl["kind"].size, -1, np.int32)
@@ -55,8 +56,9 @@ def test_bench_nt3_100k_decoder_choice(gpu_api, orc, pkg):
                              want_ssyms=False)
     df = gpu_api.demod_batch("nt3_facch", wl["iq"], wl["offset"][fa], 474, sps=4, freq_shift=wl["freq_shift"][fa],
                              want_ssyms=False)
-    g_fr = gpu_api.tch3_decode_batch(ds["ebits"], 0)
-    g_fa = gpu_api.facch3_decode_batch(df["ebits"].reshape(-1, 4, 104))
+    with gpu_api.conv_decoder(gpu_api.CONV_GENERIC):                  # D1
+        g_fr = gpu_api.tch3_decode_batch(ds["ebits"], 0)
+        g_fa = gpu_api.facch3_decode_batch(df["ebits"].reshape(-1, 4, 104))
     with orc.conv_mode(1):
         o_fr = orc.tch3_decode(ds["ebits"], 0)
         o_fa = orc.facch3_decode(df["ebits"].reshape(-1, 4, 104))

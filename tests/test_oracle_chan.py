@@ -96,3 +96,30 @@ def test_direct_mode_brings_a_tone_to_baseband():
     f_est = (ph[-1] - ph[0]) / (2 * np.pi * (seg.size - 1)) * 93600.0
     assert abs(f_est - df) < 1.0                          # the wanted tone at its offset ...
     assert abs(np.abs(seg).mean() - 1.0) < 0.02 and np.abs(seg).std() < 0.02      # ... alone (the far carrier is gone)
+
+
+@pytest.mark.parametrize("fs", [2.048e6, 1.92e6])
+def test_off_grid_rate_pre_resampler_tone(fs):
+    """Off the 31.25 kHz grid (gmr1_rx_sdr.py:413-417, 453-461) the capture is resampled to n_chans x 31.25 kHz first:
+    a tone on ARFCN k at the off-grid rate lands in channel k at its offset, at 4 samples per symbol."""
+    import orc_chan
+    from fractions import Fraction
+    pl = orc_chan.Plan(fs)
+    M = pl.n_chans
+    assert pl.pre_rate == Fraction(int(M * 31250), int(fs)) and pl.pre_rate > 1
+    t = pl.taps_pre.astype(np.float64)
+    assert t.size == 727 and np.allclose(t, t[::-1], atol=1e-6) and abs(t.sum() - 32.0) < 1e-3
+    H = np.abs(np.fft.rfft(t / 32.0, 1 << 16))
+    f = np.fft.rfftfreq(1 << 16, 1 / 32.0)
+    assert H[np.searchsorted(f, 0.4)] > 0.98 and H[np.searchsorted(f, 0.65):].max() < 10 ** (-70 / 20)
+    n = int(0.05 * fs)
+    s = np.arange(n)
+    for k, fo in ((7, 2500.0), (M - 4, -3000.0)):
+        kk = k if k < M // 2 else k - M
+        x = np.exp(2j * np.pi * ((kk * 31250.0 + fo) / fs) * s).astype(np.complex64)
+        out = orc_chan.channelize(x, pl, [k, (k + 2) % M])
+        z = out[k][600:3500].astype(np.complex128)
+        fest = np.angle(np.mean(z[1:] * np.conj(z[:-1]))) / (2 * np.pi) * 93600.0
+        assert abs(fest - fo) < 5.0 and abs(np.mean(np.abs(z)) - 1.0) < 0.05
+        assert abs(out[k].size - n / fs * 93600) < 40
+        assert np.mean(np.abs(out[(k + 2) % M][600:]) ** 2) < 1e-4

@@ -87,7 +87,8 @@ def test_bcch_ccch_frames_under_the_other_decoder(orc, pkg, name, enc, dec, nbyt
     for amp, sigma in LEVELS:
         l2 = rng.integers(0, 256, (n_per, nbytes), dtype=np.uint8)
         eb = _soft(getattr(pkg.synth, enc)(l2), rng, amp, sigma, erase=0.02)
-        a = getattr(orc, dec)(eb)
+        with orc.conv_mode(0):
+            a = getattr(orc, dec)(eb)
         with orc.conv_mode(1):
             b = getattr(orc, dec)(eb)
         both, only_a, only_b, clash = _compare(a[0], a[1], b[0], b[1])
@@ -115,7 +116,8 @@ def test_facch3_tch3_frames_under_the_other_decoder(orc, pkg):
         l2[:, 9] &= 0x0f
         bs = rng.integers(0, 2, (n, 32), dtype=np.uint8)
         eb = _soft(pkg.synth.facch3_encode(l2, bs), rng, amp, sigma, erase=0.02).reshape(n, 4, 104)
-        a = orc.facch3_decode(eb)
+        with orc.conv_mode(0):
+            a = orc.facch3_decode(eb)
         with orc.conv_mode(1):
             b = orc.facch3_decode(eb)
         both, only_a, only_b, clash = _compare(a[0], a[2], b[0], b[2])
@@ -130,7 +132,8 @@ def test_facch3_tch3_frames_under_the_other_decoder(orc, pkg):
     differ = recovered = one_sided = total = 0
     for sigma in (12.0, 40.0, 55.0, 70.0):
         wl = workloads.tch3_bursts(pkg, n, seed=int(sigma), sigma=sigma)
-        a = orc.tch3_decode(wl["ebits"], 0)
+        with orc.conv_mode(0):
+            a = orc.tch3_decode(wl["ebits"], 0)
         with orc.conv_mode(1):
             b = orc.tch3_decode(wl["ebits"], 0)
         for k, sent in ((0, wl["frame0"]), (1, wl["frame1"])):
