@@ -74,8 +74,13 @@ struct gmr1_hip_burst_flat {
 /* ---- library / device ----------------------------------------------------
  * Threads: gmr1_hip_last_error() is per thread; the burst-level _batch / _batch_dev calls keep no state
  * between calls and may run from several threads on different streams.  The calls that use the library's
- * grow-only device workspace -- gmr1_hip_fcch_rough*_batch*, gmr1_hip_channelize*, gmr1_hip_rx_run* -- must not
- * run concurrently on the same device (one receiver per GPU, as in the reference: one process per capture). */
+ * grow-only per-device workspace -- gmr1_hip_fcch_rough*_batch*, gmr1_hip_channelize*, gmr1_hip_ddc*,
+ * gmr1_hip_rx_run*, gmr1_hip_detect_batch* with more than four candidates, and gmr1_hip_tch3_rx_batch* where it
+ * runs as two launches without a caller's soft-bit buffer -- may ALSO be called from several threads and streams:
+ * they take turns.  The host part of such a call runs under a per-device lock (a second thread waits), and a call
+ * on another stream first makes its stream wait, on the device, for the previous user's kernels; nothing is
+ * refused and no result depends on the interleaving (tests/test_gpu_threads.py).  They do not run in PARALLEL
+ * with each other on one device: one receiver per GPU, as in the reference (one process per capture). */
 int         gmr1_hip_init(int device);          /* optional; selects the HIP device     */
 const char *gmr1_hip_last_error(void);
 const char *gmr1_hip_version(void);

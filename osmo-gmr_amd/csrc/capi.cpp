@@ -120,6 +120,32 @@ int dev_state(DevState **out)
 	return 0;
 }
 
+int WsLease::acquire(DevState *s, hipStream_t st)
+{
+	s->ws_mu.lock();
+	s_ = s;
+	st_ = st;
+	if (s->ws_depth++ == 0 && s->ws_ev) {
+		const hipError_t e = hipStreamWaitEvent(st, s->ws_ev, 0);
+		if (e != hipSuccess)
+			return fail(-EIO, "workspace lease: hipStreamWaitEvent: %s", hipGetErrorString(e));
+	}
+	return 0;
+}
+
+WsLease::~WsLease()
+{
+	if (!s_)
+		return;
+	if (--s_->ws_depth == 0) {
+		if (!s_->ws_ev && hipEventCreateWithFlags(&s_->ws_ev, hipEventDisableTiming) != hipSuccess)
+			s_->ws_ev = nullptr;
+		if (s_->ws_ev)
+			(void)hipEventRecord(s_->ws_ev, st_);
+	}
+	s_->ws_mu.unlock();
+}
+
 int dev_workspace(DevState *s, size_t bytes, void **out)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -327,8 +353,10 @@ int gmr1_hip_tch3_rx_batch_dev(void *stream, int n, int sps, int in_len,
 		return 0;
 	}
 	// two launches; the soft bits pass through the caller's buffer or the library's workspace
+	WsLease lease;
 	if (!ebits) {
 		void *ws;
+		if ((r = lease.acquire(s, (hipStream_t)stream))) return r;
 		r = dev_workspace(s, (size_t)n * 212, &ws);
 		if (r) return r;
 		a.ebits = reinterpret_cast<int8_t *>(ws);

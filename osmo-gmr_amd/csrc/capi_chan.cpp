@@ -390,6 +390,8 @@ int gmr1_hip_ddc_dev(void *stream, double samp_rate, int sps, const float *wide,
 	const size_t b_y1 = up_to(sizeof(float2) * (size_t)n_sel * (size_t)n1, 256);
 	const size_t b_y2 = p->d2 > 1 ? up_to(sizeof(float2) * (size_t)n_sel * (size_t)n2, 256) : 0;
 	void *ws;
+	WsLease lease;
+	if ((r = lease.acquire(s, st))) return r;
 	r = dev_workspace(s, b_t1 + b_rot + b_y1 + b_y2, &ws);
 	if (r) return r;
 	char *w = static_cast<char *>(ws);
@@ -522,6 +524,8 @@ static int channelize_dev_impl(void *stream, double samp_rate, int sps, const fl
 	const uint64_t n_pre = p->mid_samples(n_in);
 	const size_t mid_bytes = up_to((size_t)n_sel * T * sizeof(float2), 256);
 	void *ws;
+	WsLease lease;
+	if ((r = lease.acquire(s, st))) return r;
 	r = dev_workspace(s, slot_bytes + mid_bytes + (p->pre ? (size_t)n_pre * sizeof(float2) : 0), &ws);
 	if (r) return r;
 	int32_t *d_slot = static_cast<int32_t *>(ws);

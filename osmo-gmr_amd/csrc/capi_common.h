@@ -32,6 +32,28 @@ struct DevState {
 	bool ready = false;       // constant tables uploaded to this device
 	void *ws = nullptr;       // grow-only scratch for kernels that need workspace
 	size_t ws_bytes = 0;
+	// users of the workspace (and of the receive loop's side stream and events) take turns: WsLease
+	std::recursive_mutex ws_mu;
+	hipEvent_t ws_ev = nullptr;   // recorded behind the last user's kernels
+	int ws_depth = 0;
+};
+
+// One user of the device's shared workspace at a time, from any thread on any stream.  The host part of a call runs under
+// the device's lock (a second thread waits its turn); the device part is ordered by an event: a call on another stream
+// first makes ITS stream wait for the kernels of the previous user, so nobody's scratch is overwritten or freed under
+// running kernels.  Re-entrant (a workspace user may call another one on the same stream: the receive loop calls the
+// FCCH sweeps).  Calls that need no workspace (every burst-level _batch_dev entry in its usual shape) take no lease.
+class WsLease {
+public:
+	WsLease() = default;
+	WsLease(const WsLease &) = delete;
+	WsLease &operator=(const WsLease &) = delete;
+	~WsLease();
+	int acquire(DevState *s, hipStream_t st);
+
+private:
+	DevState *s_ = nullptr;
+	hipStream_t st_ = nullptr;
 };
 
 extern DevBurst g_host_types[kNumTypes];
@@ -41,7 +63,7 @@ std::mutex &custom_slots_mutex();
 int host_types();
 // state of the CURRENT device; uploads the constant tables on first use
 int dev_state(DevState **out);
-// grow-only device scratch of the current device (not for concurrent streams)
+// grow-only device scratch of the current device; the caller holds a WsLease from here to its last launch
 int dev_workspace(DevState *s, size_t bytes, void **out);
 
 // fused BCCH / CCCH receive with the optional burst_energy() output (capi.cpp)

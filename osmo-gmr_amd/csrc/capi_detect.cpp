@@ -47,9 +47,11 @@ static int detect_dev_impl(hipStream_t stream, int n_types, const int *slots, co
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.freq_shift = freq_shift; a.e_toa = e_toa;
 	a.bt_id = bt_id; a.sync_id = sync_id; a.toa = toa; a.rv = rv;
+	WsLease lease;
 	if (n_types > 4) {
 		// the carry needs every output: the library's workspace stands in for the ones the caller left out
 		void *ws = nullptr;
+		if ((r = lease.acquire(s, stream))) return r;
 		r = dev_workspace(s, (size_t)(n > 0 ? n : 1) * 16, &ws);
 		if (r) return r;
 		int32_t *w32 = static_cast<int32_t *>(ws);

@@ -47,6 +47,8 @@ int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq,
 	const size_t b_par = (((size_t)n * a.n_stat_tiles * 16) + 255) & ~(size_t)255;
 	const size_t b_best = (((size_t)n * a.n_lag_tiles * 32) + 255) & ~(size_t)255;
 	void *ws;
+	WsLease lease;
+	if ((r = lease.acquire(s, st))) return r;
 	r = dev_workspace(s, b_dec + b_par + b_best, &ws);
 	if (r) return r;
 	a.dec = static_cast<float2 *>(ws);
@@ -223,6 +225,8 @@ int gmr1_hip_fcch_rough_multi_batch_dev(void *stream, int fcch_type, int n, int 
 	const size_t b_best = (((size_t)n * fcch_lag_tiles(nlags) * 32) + 255) & ~(size_t)255;
 	const size_t b_rough = b_dec + b_par + b_best;
 	void *ws;
+	WsLease lease;
+	if ((r = lease.acquire(s, (hipStream_t)stream))) return r;
 	r = dev_workspace(s, b_rough + (size_t)n * estride * 4, &ws);
 	if (r) return r;
 	float *energy = reinterpret_cast<float *>(static_cast<char *>(ws) + b_rough);

@@ -1027,6 +1027,9 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	int r = dev_state(&ds);
 	if (r) return r;
 	if (n_arfcn == 0) return 0;
+	// the whole call holds the device's workspace, the loop's side stream and its events: calls from other threads wait
+	WsLease lease;
+	if ((r = lease.acquire(ds, st))) return r;
 	for (int i = 0; i < n_arfcn; i++)
 		if (length[i] > 0x7fffffffull)
 			return fail(-EINVAL, "rx_run: carrier %d longer than 2^31-1 samples", i);
