@@ -300,7 +300,10 @@ def run_rx_workload(args):
     length = np.full(A, ns, np.uint64)
     stream = torch.cuda.current_stream(dev)
     res = [None]
-    rec_buf = np.zeros(1 << 18, api.RX_RECORD)       # the caller's record buffer, reused across steps
+    # the caller's record buffer, reused across steps: pinned host memory, which the library copies the records into
+    # directly (a pageable buffer costs one more host copy of the records, include/gmr1_hip.h)
+    rec_pin = torch.empty((1 << 18) * api.RX_RECORD.itemsize, dtype=torch.uint8, pin_memory=True)
+    rec_buf = rec_pin.numpy().view(api.RX_RECORD)
 
     def step():
         res[0] = api.rx_run_dev(stream.cuda_stream, iq.data_ptr(), offset, length, sps=sps, out=rec_buf)

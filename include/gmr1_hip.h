@@ -388,7 +388,11 @@ int gmr1_hip_channelize_planar_dev(void *stream, double samp_rate, int sps, cons
  * time.  n_records = records found (only the first max_records are stored).
  * status[i] = 0 or the negative value main() would have exited with for that carrier;
  * n_chains[i] = FCCH chains followed.  TCH follow-up after IMM.ASS is not performed.
- * arfcn may be NULL (records then carry the carrier index). */
+ * arfcn may be NULL (records then carry the carrier index).
+ * `out` of gmr1_hip_rx_run_dev may be pageable host memory, pinned / registered host memory (hipHostMalloc,
+ * hipHostRegister) or DEVICE memory: the records are closed up on the device in the order above and copied once,
+ * exactly as many as there are -- straight into a pinned or device buffer (no staging copy; a device buffer is what
+ * gmr1_hip_rx_run_sharded sends from), through the library's pinned block for pageable memory. */
 struct gmr1_hip_rx_record {
 	uint16_t arfcn;
 	uint8_t  chain;      /* FCCH chain within the carrier          */

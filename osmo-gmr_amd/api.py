@@ -743,6 +743,27 @@ def rx_run_dev(stream, iq_ptr, offset, length, sps=4, arfcn=None, max_records=1 
     return _rx_run_call("gmr1_hip_rx_run_dev", head, n, offset, length, arfcn, max_records, out)
 
 
+def rx_run_dev_raw(stream, iq_ptr, offset, length, out_ptr, max_records, sps=4, arfcn=None):
+    """gmr1_hip_rx_run_dev with the record buffer given as an address -- device memory or pinned host memory, which the
+    library copies into directly.  Returns (n_found, status[n], n_chains[n])."""
+    n = len(offset)
+    offset, p_off = _np(offset, np.uint64)
+    length, p_len = _np(length, np.uint64)
+    p_arfcn = None
+    if arfcn is not None:
+        arfcn, p_arfcn = _np(arfcn, np.uint16)
+    n_rec = C.c_int(0)
+    status = np.zeros(max(n, 1), np.int32)
+    chains = np.zeros(max(n, 1), np.int32)
+    f = load().gmr1_hip_rx_run_dev
+    f.restype = C.c_int
+    rc = f(C.c_void_p(stream) if stream else None, C.c_int(n), C.c_int(sps), C.c_void_p(iq_ptr), p_off, p_len, p_arfcn,
+           C.c_void_p(out_ptr), C.c_int(max_records), C.byref(n_rec), status.ctypes.data_as(C.c_void_p),
+           chains.ctypes.data_as(C.c_void_p))
+    _check(rc, "gmr1_hip_rx_run_dev")
+    return n_rec.value, status[:n], chains[:n]
+
+
 def gsmtap_pack(record, with_arfcn=False) -> bytes:
     """gmr1_hip_gsmtap_pack: the GSMTAP packet the reference would send for one RX_RECORD (src/gsmtap.c:43-71)."""
     rec = np.ascontiguousarray(np.asarray(record, RX_RECORD).reshape(1))

@@ -53,8 +53,6 @@ struct RxChain {
 	float bcch_energy;
 	bool done;
 	std::vector<gmr1_hip_rx_record> rec;
-	const gmr1_hip_rx_record *rec_view = nullptr;   // without a traffic pass the loop's records stay where the copy from the
-	int rec_view_n = 0;                             // device put them (pinned host log) until they are handed back
 	std::vector<int> rec_frame;          // frame (index into log) each record belongs to
 	std::vector<FrameCtx> log;           // one entry per loop iteration of process_bcch (only with a traffic carrier)
 	std::vector<AssEvt> events;
@@ -185,6 +183,13 @@ struct RxRun {
 	std::vector<float> ferr;
 	std::vector<RxChain> chains;
 	double t_loop_gpu_us = 0;                // profiling: launch to log-on-host
+	// hand-back of a plain BCCH / CCCH run (no traffic follow-up): the records are closed up on the device in the order
+	// they are returned in (k_rx_pack) and copied ONCE, as many as there are -- straight into the caller's buffer when
+	// that is device memory or pinned host memory, else through the library's pinned block
+	gmr1_hip_rx_record *out = nullptr;
+	int max_records = 0;
+	bool direct = false;
+	int direct_total = 0;
 
 	int acquire();        // fcch_single_init + fcch_multi_process
 	int frame_loop();     // process_bcch: BCCH / CCCH, in rounds
@@ -414,7 +419,8 @@ int RxRun::frame_loop()
 	// one block of device memory and its mirror in pinned host memory:
 	// [records | counters (n_rounds, n_rec, n_frames) | states | frame index + gate level per record | frame log]
 	const size_t rec_bytes = up128((size_t)nc * rec_stride * sizeof(gmr1_hip_rx_record));
-	const size_t cnt_bytes = up128((size_t)nc * 3 * 4);
+	const size_t cnt_bytes = up128(((size_t)nc * 3 + 1) * 4);      // + the packed total
+	const bool pack = !tch && !csd;
 	const size_t st_bytes = up128((size_t)nc * sizeof(RxLoopState));
 	const size_t rf_bytes = want_ctx ? up128((size_t)nc * rec_stride * 4) : 0;
 	const size_t fl_bytes = want_ctx ? up128((size_t)nc * max_frames * sizeof(RxLoopFrame)) : 0;
@@ -431,7 +437,7 @@ int RxRun::frame_loop()
 	r = dev_state(&ds);
 	if (r) return r;
 	void *ws;
-	r = dev_workspace(ds, total + scratch + 128, &ws);
+	r = dev_workspace(ds, total + scratch + (pack ? rec_bytes : 0) + 128, &ws);
 	if (r) return r;
 	unsigned char *d = reinterpret_cast<unsigned char *>(((uintptr_t)ws + 127) & ~(uintptr_t)127);
 	unsigned char *h;
@@ -471,12 +477,45 @@ int RxRun::frame_loop()
 		la.c_conv = reinterpret_cast<int32_t *>(take(s4));
 		la.c_rv = reinterpret_cast<int32_t *>(take(s4));
 		la.c_en = reinterpret_cast<float *>(take(s4));
+		if (pack) {
+			la.packed = reinterpret_cast<gmr1_hip_rx_record *>(take(rec_bytes));
+			la.n_packed = la.n_frames + nc;
+		}
 	}
 	HIP_TRY(hipMemcpyAsync(la.state, st0.data(), (size_t)nc * sizeof(RxLoopState), hipMemcpyHostToDevice, st));
 	r = rx_loop_dev_impl(st, nc, sps, iq, la);
 	if (r) return r;
-	HIP_TRY(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	if (pack) {
+		// counters and states first (a few KB), then exactly the records there are
+		HIP_TRY(hipMemcpyAsync(h + o_cnt, d + o_cnt, cnt_bytes + st_bytes, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		const int n_total = reinterpret_cast<const int32_t *>(h + o_cnt)[3 * nc];
+		if (n_total < 0 || (size_t)n_total > (size_t)nc * rec_stride)
+			return fail(-EIO, "rx loop: packed record count %d out of range", n_total);
+		const int fit = std::max(0, std::min(n_total, max_records));
+		if (fit) {
+			// device memory and pinned / registered host memory take the copy directly; pageable memory goes through the pinned block
+			hipPointerAttribute_t at;
+			const bool known = hipPointerGetAttributes(&at, out) == hipSuccess &&
+			                   (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged);
+			if (!known)
+				(void)hipGetLastError();
+			const size_t nb = (size_t)fit * sizeof(gmr1_hip_rx_record);
+			if (known) {
+				HIP_TRY(hipMemcpyAsync(out, la.packed, nb, hipMemcpyDefault, st));
+				HIP_TRY(hipStreamSynchronize(st));
+			} else {
+				HIP_TRY(hipMemcpyAsync(h, la.packed, nb, hipMemcpyDeviceToHost, st));
+				HIP_TRY(hipStreamSynchronize(st));
+				std::memcpy(out, h, nb);
+			}
+		}
+		direct = true;
+		direct_total = n_total;
+	} else {
+		HIP_TRY(hipMemcpyAsync(h, d, total, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+	}
 	t_loop_gpu_us = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count() / 1e3;
 
 	const int32_t *h_nr = reinterpret_cast<const int32_t *>(h + o_cnt), *h_nrec = h_nr + nc, *h_nfr = h_nrec + nc;
@@ -492,12 +531,8 @@ int RxRun::frame_loop()
 			continue;
 		}
 		const gmr1_hip_rx_record *rp = reinterpret_cast<const gmr1_hip_rx_record *>(h) + (size_t)ci * rec_stride;
-		if (!tch && !csd) {
-			c.rec_view = rp;
-			c.rec_view_n = h_nrec[ci];
-		} else {
+		if (!pack)
 			c.rec.assign(rp, rp + h_nrec[ci]);
-		}
 		if (want_ctx) {
 			const int32_t *fp = reinterpret_cast<const int32_t *>(h + o_rf) + (size_t)ci * rec_stride;
 			const float *mp = reinterpret_cast<const float *>(h + o_me) + (size_t)ci * rec_stride;
@@ -512,7 +547,7 @@ int RxRun::frame_loop()
 				if (rp[k].type == 2 && l2[1] == 0x06 && l2[2] == 0x3f)
 					c.events.push_back({fp[k], ((l2[8] & 0x03) << 3) | (l2[9] >> 5), (l2[8] & 0xfc) >> 2, mp[k]});
 			}
-		} else if (!c.rec_view) {
+		} else if (!pack) {
 			c.rec_frame.assign((size_t)h_nrec[ci], 0);
 		}
 		const RxLoopState &s = h_st[ci];
@@ -1038,6 +1073,7 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	run.st = st; run.sps = sps; run.iq = iq; run.tch = tch; run.csd = csd;
 	run.offset = offset; run.length = length; run.arfcn = arfcn; run.kc = kc;
 	run.A = n_arfcn;
+	run.out = out; run.max_records = max_records;
 	run.flen = kFcchLen * sps;
 	run.stat.assign(n_arfcn, 0); run.nch.assign(n_arfcn, 0);
 	run.align.assign(n_arfcn, kStartDiscard); run.base_align.assign(n_arfcn, 0);
@@ -1063,13 +1099,16 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 
 	// ---- hand back: carriers in order, chains in order, frames in order -------------------------
 	int total = 0;
-	for (const RxChain &c : chains) {       // chains were created carrier by carrier, chain by chain
-		const gmr1_hip_rx_record *src = c.rec_view ? c.rec_view : c.rec.data();
-		const int cnt = c.rec_view ? c.rec_view_n : (int)c.rec.size();
-		const int fit = std::max(0, std::min(cnt, max_records - total));
-		if (fit)
-			std::memcpy(out + total, src, (size_t)fit * sizeof(gmr1_hip_rx_record));
-		total += cnt;
+	if (run.direct) {
+		total = run.direct_total;            // already in the caller's buffer, in this very order (k_rx_pack)
+	} else {
+		for (const RxChain &c : chains) {       // chains were created carrier by carrier, chain by chain
+			const int cnt = (int)c.rec.size();
+			const int fit = std::max(0, std::min(cnt, max_records - total));
+			if (fit)
+				std::memcpy(out + total, c.rec.data(), (size_t)fit * sizeof(gmr1_hip_rx_record));
+			total += cnt;
+		}
 	}
 	*n_records = total;
 	if (n_big) {

@@ -233,9 +233,11 @@ int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool 
 	const int per = (n_arfcn + world - 1) / world;          // carriers a rank owns at most: a = rank, rank + world, ...
 	if (per > 65535)
 		return fail(-EINVAL, "rx_run_sharded: %d carriers per rank (records label their carrier with 16 bits)", per);
+	// (make() allocates the status block the agreement points exchange on every rank, or fails on every rank alike)
+	if (world > 1 && !sh->d_flag)
+		return fail(-EIO, "rx_run_sharded: the shard has no status block");
 	hipStream_t st = (hipStream_t)stream;
 	const Rccl &R = rccl();
-	auto t0 = std::chrono::steady_clock::now();
 	int32_t bad_rank = -1;
 
 	// ---- what only this rank can know: its own arguments and allocations.  From here on a local failure is CARRIED
@@ -263,13 +265,13 @@ int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool 
 	}
 	for (int k = 0; k < nm; k++)
 		lname[k] = arfcn ? arfcn[mine[k]] : (uint16_t)mine[k];
-	if (!err && world > 1 && !sh->d_flag)
-		err = fail(-EIO, "rx_run_sharded: the shard has no status block");
 	{
 		const int rc = agree(sh, st, err, &bad_rank);
 		if (rc)
 			return err ? err : fail(rc, "rx_run_sharded: rank %d cannot take part (%d)", bad_rank, rc);
 	}
+	// (the clock of the scatter starts behind the first agreement: its all-gather and stream synchronise are no transfer)
+	auto t0 = std::chrono::steady_clock::now();
 
 	// ---- scatter: carrier a -> rank a mod world, all transfers in one group --------------------------------------
 	if (scatter && world > 1) {

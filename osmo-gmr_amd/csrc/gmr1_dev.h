@@ -101,6 +101,10 @@ struct RxLoopArgs {
 	int rec_stride, flog_stride;
 	int max_rounds;
 	int32_t *n_rounds, *n_rec, *n_frames;   // n_chains each
+	// optional: the records of all chains back to back in chain order (the order gmr1_hip_rx_run hands them back in),
+	// chains that outgrew their buffers left out; *n_packed = how many
+	gmr1_hip_rx_record *packed;
+	int32_t *n_packed;
 	// between the three launches (device scratch)
 	RxLoopRound *rounds;           // n_chains x max_rounds
 	int c_stride;                  // CCCH list slots per chain (a multiple of 4, >= the frames of the longest chain + 4 per time slice)

@@ -3381,6 +3381,36 @@ __global__ __launch_bounds__(64 * kMergeWaves) void k_rx_merge(RxLoopArgs la)
 // normalise once with the rotation of the first candidate type, run the sync search of
 // every candidate, weight the power by 1/|e_toa - toa|, keep the strongest.
 // ---------------------------------------------------------------------------
+// 4. (optional) the chains' record blocks closed up into one array in chain order: what the caller gets is then ONE copy of
+// exactly the records there are, not of every chain's whole block.  One work-group per chain: its offset is the sum of
+// the counts before it (a few hundred integers), its records move as dwords.
+__global__ __launch_bounds__(256) void k_rx_pack(RxLoopArgs la, int n_chains)
+{
+	__shared__ int s_part[4];
+	const int chain = blockIdx.x, tid = (int)threadIdx.x;
+	auto count = [&](int c) {
+		const int n = la.n_rec[c];
+		return (la.n_rounds[c] >= la.max_rounds || n > la.rec_stride) ? 0 : n;     // (such a chain is reported, not returned)
+	};
+	int part = 0;
+	for (int c = tid; c < chain; c += 256)
+		part += count(c);
+	for (int o = 32; o; o >>= 1)
+		part += __shfl_xor(part, o);
+	if ((tid & 63) == 0)
+		s_part[tid >> 6] = part;
+	__syncthreads();
+	const int off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+	const int n = count(chain);
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(la.rec + (size_t)chain * la.rec_stride);
+	uint32_t *dst = reinterpret_cast<uint32_t *>(la.packed + off);
+	constexpr int W = (int)(sizeof(gmr1_hip_rx_record) / 4);
+	for (int i = tid; i < n * W; i += 256)
+		dst[i] = src[i];
+	if (chain == n_chains - 1 && tid == 0)
+		*la.n_packed = off + n;
+}
+
 template <int NPL, int SPS>
 __global__ __launch_bounds__(64) void k_detect(DetectArgs a, int max_in_len)
 {
@@ -3899,6 +3929,8 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	if ((e = hipEventRecord(ls->side_done, ls->side)) != hipSuccess) return e;
 	if ((e = hipStreamWaitEvent(stream, ls->side_done, 0)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_rx_merge, grid, dim3(64 * kMergeWaves), 0, stream, la);
+	if (la.packed && la.n_packed)
+		hipLaunchKernelGGL(k_rx_pack, grid, dim3(256), 0, stream, la, n_chains);
 	return hipGetLastError();
 }
 

@@ -413,3 +413,30 @@ def test_rx_loop_tch3_follow_up_production_length(gpu_api, orc, pkg, decoder):
     assert orv == 0 and not status.any() and chains[0] == och
     assert int(np.sum(orec["type"] >= 0x10)) > 500
     assert _key_n(rec) == _key_n(orec)
+
+
+def test_rx_loop_record_buffer_in_pinned_and_device_memory(gpu_api, orc, pkg):
+    """gmr1_hip_rx_run_dev closes the records up on the device and copies them once: into pageable host memory through the
+    library's pinned block, straight into a pinned or a DEVICE buffer.  The same records every way, also when the buffer
+    holds fewer than there are."""
+    import torch
+    xs = [workloads.bcch_carrier(pkg, 41 + a, seconds=2.2, sps=SPS, stn=4 * a, delay=a, cfo_hz=70.0 * a)[0] for a in range(3)]
+    n = xs[0].size
+    t = torch.from_numpy(np.concatenate(xs).view(np.float32)).cuda()
+    offset, length = [0, n, 2 * n], [n, n, n]
+    rec, status, chains, found = gpu_api.rx_run_dev(None, t.data_ptr(), offset, length, sps=SPS)       # pageable
+    assert found == len(rec) > 60 and not status.any()
+    want = np.concatenate([orc.rx_run(x, sps=SPS, arfcn=a)[1] for a, x in enumerate(xs)])
+    assert _key(rec) == _key(want)
+    isz = gpu_api.RX_RECORD.itemsize
+    for cap in (found + 10, found, 17):
+        pin = torch.zeros(cap * isz, dtype=torch.uint8, pin_memory=True)
+        dev = torch.zeros(cap * isz, dtype=torch.uint8, device="cuda")
+        for buf in (pin, dev):
+            got, st2, ch2 = gpu_api.rx_run_dev_raw(None, t.data_ptr(), offset, length, buf.data_ptr(), cap, sps=SPS)
+            torch.cuda.synchronize()
+            assert got == found and np.array_equal(st2, status) and np.array_equal(ch2, chains)
+            back = buf.cpu().numpy().view(gpu_api.RX_RECORD)
+            k = min(cap, found)
+            assert back[:k].tobytes() == rec[:k].tobytes()
+            assert not back[k:].view(np.uint8).any()                 # nothing written past what fits
