@@ -95,6 +95,11 @@ def emit(out, **kw):
     """Print the one JSON line; every line names the Viterbi decoder the run reproduced."""
     if isinstance(out.get("config"), dict):
         out["config"]["conv_decoder"] = os.environ.get("GMR1_HIP_CONV_DECODER", "acc")
+        # which build answered: the product library unless a profiling script pointed GMR1_HIP_LIBRARY elsewhere
+        lib = os.environ.get("GMR1_HIP_LIBRARY")
+        out["config"]["library"] = os.path.basename(lib) if lib else "libgmr1_hip.so"
+        if lib and "prof" in os.path.basename(lib):
+            out["config"]["profiling_build"] = True
     print(json.dumps(out), **kw)
 
 
@@ -979,7 +984,8 @@ def _sharded_native(pkg, dist, dev, rank, world, A, ns, distinct, sps, base, tor
     api = pkg.api
     ids = [api.Shard.unique_id() if rank == 0 else None]
     dist.broadcast_object_list(ids, src=0)
-    sh = api.Shard(ids[0], rank, world)
+    with stdout_to_stderr():                       # a communicator of the library's own: its banner goes to stderr too
+        sh = api.Shard(ids[0], rank, world)
     try:
         iq_all = torch.cat([torch.view_as_real(b).reshape(-1) for b in base]).contiguous() if rank == 0 else None
         offset = (np.arange(A, dtype=np.uint64) % np.uint64(distinct)) * np.uint64(ns)      # tiles share their samples
@@ -1046,6 +1052,20 @@ def _sharded_summary(args, dist, host, out, tt, A, ns, seconds, distinct, world,
     return res
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator comes up; the contract is ONE JSON line there.  Inside
+    this block file descriptor 1 points at stderr (native writes included)."""
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def init_ranks():
     """One process per GPU: rank / world from the launcher's (or spawn_ranks') environment, the device of this rank, and
     the process group when there is more than one rank.  Returns (rank, world, backend, device, device index, grouped)."""
@@ -1072,10 +1092,12 @@ def init_ranks():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.barrier()                # the communicator (and its banner) comes up with the first collective
     return rank, world, backend, dev, dev_index, grouped
 
 

@@ -57,26 +57,45 @@ def build(force: bool = False, verbose: bool = False, profile: bool = False) -> 
     """profile=True: the same sources with -DGMR1_HIP_PROFILE into libgmr1_hip_prof.so -- the only build in which the
     GMR1_HIP_DBG_STOP / _AMBE_DBG / _RX_IMPL / ... switches exist (tools/ load it through GMR1_HIP_LIBRARY)."""
     if profile:
-        return _build(PROFILE_LIB, ["-DGMR1_HIP_PROFILE"], ".prof.o", verbose)
+        return _build(PROFILE_LIB, ["-DGMR1_HIP_PROFILE"], ".prof.o", verbose, force)
     if not force and not needs_build():
         return LIB
-    return _build(LIB, [], ".o", verbose)
+    return _build(LIB, [], ".o", verbose, force)
 
 
-def _build(lib: str, extra, suffix: str, verbose: bool) -> str:
+def _toolchain_id() -> str:
+    """What an object file depends on besides its sources: the compiler and the command line (kept next to each object)."""
+    try:
+        ver = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        ver = ""
+    return ver + "\n" + " ".join(COMMON) + "\n" + ARCH
+
+
+def _build(lib: str, extra, suffix: str, verbose: bool, force: bool = False) -> str:
     LIB = lib
     from concurrent.futures import ThreadPoolExecutor
+    import hashlib
+    tool = _toolchain_id()
 
     def compile_one(src):
         obj = os.path.splitext(src)[0] + suffix
-        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in [src] + headers):
-            return obj
         cmd = [hipcc()] + COMMON + extra + ["--offload-arch=" + ARCH, "-c", src, "-o", obj]
         if src.endswith(".hip"):
             cmd.insert(1, "-xhip")
+        # an object is reused only if it is newer than its source and every header AND was made by this compiler with this
+        # command line (the .flags file next to it); force rebuilds everything
+        stamp = obj + ".flags"
+        want = hashlib.sha256((tool + "\n" + " ".join(cmd)).encode()).hexdigest()
+        have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+        if (not force and have == want and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in [src] + headers)):
+            return obj
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(stamp, "w") as fh:
+            fh.write(want + "\n")
         return obj
 
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]

@@ -77,6 +77,12 @@ int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
 // process_bcch of n_chains chains in one launch (capi.cpp / launch_rx_loop); every pointer in `la` is device memory
 int rx_loop_dev_impl(hipStream_t stream, int n_chains, int sps, const float *iq, const RxLoopArgs &la);
 
+// gmr1_hip_rx_run_dev that also reports how many records each carrier contributed (capi_rx.cpp; the sharded entry keeps
+// the records on the device and still needs the per-carrier counts)
+int rx_run_dev_counted(void *stream, int n_arfcn, int sps, const float *iq, const uint64_t *offset, const uint64_t *length,
+                       const uint16_t *arfcn, struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                       int32_t *status, int32_t *n_chains, int32_t *rec_per_carrier);
+
 // TCH9 bursts of several interleaver runs of unequal length in one launch (capi_nt9.cpp)
 int tch9_runs_dev_impl(hipStream_t st, int mode, int n, const int32_t *seq_pos, const int8_t *ebits, const uint8_t *ciph,
                        uint8_t *l2, int32_t *conv);

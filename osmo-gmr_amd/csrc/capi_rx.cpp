@@ -53,6 +53,7 @@ struct RxChain {
 	float bcch_energy;
 	bool done;
 	std::vector<gmr1_hip_rx_record> rec;
+	int n_rec = 0;                       // records of the chain when they went straight to the caller (RxRun::direct)
 	std::vector<int> rec_frame;          // frame (index into log) each record belongs to
 	std::vector<FrameCtx> log;           // one entry per loop iteration of process_bcch (only with a traffic carrier)
 	std::vector<AssEvt> events;
@@ -533,6 +534,7 @@ int RxRun::frame_loop()
 		const gmr1_hip_rx_record *rp = reinterpret_cast<const gmr1_hip_rx_record *>(h) + (size_t)ci * rec_stride;
 		if (!pack)
 			c.rec.assign(rp, rp + h_nrec[ci]);
+		c.n_rec = h_nrec[ci];
 		if (want_ctx) {
 			const int32_t *fp = reinterpret_cast<const int32_t *>(h + o_rf) + (size_t)ci * rec_stride;
 			const float *mp = reinterpret_cast<const float *>(h + o_me) + (size_t)ci * rec_stride;
@@ -1038,16 +1040,13 @@ int RxRun::tch9_pass()
 	return 0;
 }
 
-}  // namespace
-
-extern "C" {
-
-int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
-                             const float *csd, const uint64_t *offset, const uint64_t *length,
-                             const uint16_t *arfcn, const uint8_t *kc,
-                             struct gmr1_hip_rx_record *out, int max_records, int *n_records,
-                             struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
-                             int32_t *status, int32_t *n_chains)
+// gmr1_hip_rx_run_full_dev, plus (optional) how many of the records each carrier contributed
+int rx_run_full_impl(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
+                     const float *csd, const uint64_t *offset, const uint64_t *length,
+                     const uint16_t *arfcn, const uint8_t *kc,
+                     struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                     struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
+                     int32_t *status, int32_t *n_chains, int32_t *rec_per_carrier)
 {
 	hipStream_t st = (hipStream_t)stream_;
 	if (n_records) *n_records = 0;
@@ -1124,8 +1123,37 @@ int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *i
 	for (int i = 0; i < A; i++) {
 		if (status) status[i] = stat[i];
 		if (n_chains) n_chains[i] = nch[i];
+		if (rec_per_carrier) rec_per_carrier[i] = 0;
 	}
+	if (rec_per_carrier)
+		for (const RxChain &c : chains)
+			rec_per_carrier[c.a] += run.direct ? c.n_rec : (int)c.rec.size();
 	return 0;
+}
+
+}  // namespace
+
+namespace gmr1 {
+int rx_run_dev_counted(void *stream, int n_arfcn, int sps, const float *iq, const uint64_t *offset, const uint64_t *length,
+                       const uint16_t *arfcn, struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                       int32_t *status, int32_t *n_chains, int32_t *rec_per_carrier)
+{
+	return rx_run_full_impl(stream, n_arfcn, sps, iq, nullptr, nullptr, offset, length, arfcn, nullptr, out, max_records, n_records,
+	                        nullptr, 0, nullptr, status, n_chains, rec_per_carrier);
+}
+}  // namespace gmr1
+
+extern "C" {
+
+int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
+                             const float *csd, const uint64_t *offset, const uint64_t *length,
+                             const uint16_t *arfcn, const uint8_t *kc,
+                             struct gmr1_hip_rx_record *out, int max_records, int *n_records,
+                             struct gmr1_hip_rx_big_record *big_out, int max_big, int *n_big,
+                             int32_t *status, int32_t *n_chains)
+{
+	return rx_run_full_impl(stream_, n_arfcn, sps, iq, tch, csd, offset, length, arfcn, kc, out, max_records, n_records,
+	                        big_out, max_big, n_big, status, n_chains, nullptr);
 }
 
 int gmr1_hip_rx_run_tch_dev(void *stream, int n_arfcn, int sps, const float *iq, const float *tch,

@@ -71,7 +71,8 @@ struct gmr1_hip_shard {
 	int rank = 0, world = 1;
 	// grow-only device staging: received carriers; records / counts on their way
 	void *d_iq = nullptr;   size_t iq_bytes = 0;
-	void *d_rec = nullptr;  size_t rec_bytes = 0;
+	void *d_rec = nullptr;  size_t rec_bytes = 0;    // this rank's records, as the receive loop left them (device)
+	void *d_all = nullptr;  size_t all_bytes = 0;    // root: every rank's records
 	void *d_meta = nullptr; size_t meta_bytes = 0;
 	void *d_flag = nullptr;                       // 1 + world status words: "can every rank go on?" (allocated with the shard)
 };
@@ -154,6 +155,7 @@ void gmr1_hip_shard_destroy(struct gmr1_hip_shard *sh)
 		return;
 	if (sh->d_iq) (void)hipFree(sh->d_iq);
 	if (sh->d_rec) (void)hipFree(sh->d_rec);
+	if (sh->d_all) (void)hipFree(sh->d_all);
 	if (sh->d_meta) (void)hipFree(sh->d_meta);
 	if (sh->d_flag) (void)hipFree(sh->d_flag);
 	if (sh->own && sh->comm && rccl().ok)
@@ -303,19 +305,21 @@ int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool 
 	for (int k = 0; k < nm; k++)
 		if (llen[k] > longest) longest = llen[k];
 	const size_t cap_per = (size_t)(longest / ((uint64_t)sps * 39 * 24) + 64);
-	std::vector<gmr1_hip_rx_record> rec;
-	std::vector<int32_t> lstat((size_t)per + 1, 0), lnch((size_t)per + 1, 0);
+	// The records stay on the device from the loop to the send: the loop closes them up in sh->d_rec (device memory is a
+	// legal record buffer of gmr1_hip_rx_run_dev), labelled with the caller's carrier names, and reports how many each
+	// carrier contributed; only counts travel through the host.
+	std::vector<int32_t> lstat((size_t)per + 1, 0), lnch((size_t)per + 1, 0), lcnt((size_t)per + 1, 0);
 	int nrec = 0;
 	if (!err && nm > 0) {
-		std::vector<uint16_t> lidx((size_t)nm);
-		for (int k = 0; k < nm; k++)
-			lidx[k] = (uint16_t)k;
 		size_t cap = (size_t)nm * cap_per * 2;
 		for (int attempt = 0; attempt < 2 && !err; attempt++) {
 			if (cap > (size_t)INT32_MAX) cap = INT32_MAX;
-			rec.assign(cap, gmr1_hip_rx_record{});
-			err = gmr1_hip_rx_run_dev(stream, nm, sps, liq, loff.data(), llen.data(), lidx.data(), rec.data(), (int)cap, &nrec,
-			                          lstat.data(), lnch.data());
+			err = grow(&sh->d_rec, &sh->rec_bytes, cap * sizeof(gmr1_hip_rx_record));
+			if (err)
+				break;
+			err = rx_run_dev_counted(stream, nm, sps, liq, loff.data(), llen.data(), lname.data(),
+			                         static_cast<gmr1_hip_rx_record *>(sh->d_rec), (int)cap, &nrec, lstat.data(), lnch.data(),
+			                         lcnt.data());
 			if (err || (size_t)nrec <= cap)
 				break;
 			cap = (size_t)nrec;
@@ -334,13 +338,7 @@ int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool 
 	// per rank: [records of local carrier 0..per-1 | status | chains | total | this rank's error], gathered everywhere
 	const int mw = 3 * per + 2;
 	std::vector<int32_t> meta((size_t)mw, 0), all((size_t)mw * world, 0);
-	// (the loop labelled its records with the local carrier index: counted per carrier here, then given the caller's labels)
-	for (int i = 0; i < nrec; i++) {
-		const int k = rec[i].arfcn;
-		meta[k]++;
-		rec[i].arfcn = lname[k];
-	}
-	for (int k = 0; k < nm; k++) { meta[per + k] = lstat[k]; meta[2 * per + k] = lnch[k]; }
+	for (int k = 0; k < nm; k++) { meta[k] = err ? 0 : lcnt[k]; meta[per + k] = lstat[k]; meta[2 * per + k] = lnch[k]; }
 	meta[3 * per] = nrec;
 	if (world > 1) {
 		// (an allocation failure here is carried in the status word like any other: the block below is then skipped by
@@ -370,25 +368,30 @@ int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool 
 		if (e2)
 			return err ? err : fail(e2, "rx_run_sharded: the receive loop failed on rank %d (%d)", r2, e2);
 	}
-	// records: every rank's block to root
+	// records: every rank's block to root, device to device (root's own block by a copy on its stream)
 	std::vector<size_t> base((size_t)world + 1, 0);
 	for (int r = 0; r < world; r++)
 		base[r + 1] = base[r] + (size_t)all[(size_t)r * mw + 3 * per];
 	const size_t total = base[world];
 	std::vector<gmr1_hip_rx_record> gathered;
-	if (world > 1) {
-		const size_t need = (is_root ? total : (size_t)nrec) * sizeof(gmr1_hip_rx_record);
-		int aerr = grow(&sh->d_rec, &sh->rec_bytes, need ? need : 1);
-		{
+	{
+		int aerr = 0;
+		if (is_root)
+			aerr = grow(&sh->d_all, &sh->all_bytes, (total ? total : 1) * sizeof(gmr1_hip_rx_record));
+		if (world > 1) {
 			const int rc = agree(sh, st, aerr, &bad_rank);
 			if (rc)
-				return aerr ? aerr : fail(rc, "rx_run_sharded: rank %d could not stage its records (%d)", bad_rank, rc);
+				return aerr ? aerr : fail(rc, "rx_run_sharded: rank %d could not stage the records (%d)", bad_rank, rc);
+		} else if (aerr) {
+			return aerr;
 		}
-		unsigned char *d = static_cast<unsigned char *>(sh->d_rec);
+		unsigned char *d_mine = static_cast<unsigned char *>(sh->d_rec);
+		unsigned char *d = static_cast<unsigned char *>(sh->d_all);
 		hipError_t e = hipSuccess;
-		if (!is_root && nrec)
-			e = hipMemcpyAsync(d, rec.data(), (size_t)nrec * sizeof(gmr1_hip_rx_record), hipMemcpyHostToDevice, st);
-		{
+		if (is_root && nrec)
+			e = hipMemcpyAsync(d + base[root] * sizeof(gmr1_hip_rx_record), d_mine, (size_t)nrec * sizeof(gmr1_hip_rx_record),
+			                   hipMemcpyDeviceToDevice, st);
+		if (world > 1) {
 			Group g(R);
 			if (is_root) {
 				for (int r2 = 0; r2 < world; r2++) {
@@ -398,12 +401,12 @@ int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool 
 						              sh->comm, st), "ncclRecv (records)");
 				}
 			} else if (nrec) {
-				g.note(R.Send(d, (size_t)nrec * sizeof(gmr1_hip_rx_record), ncclUint8, root, sh->comm, st), "ncclSend (records)");
+				g.note(R.Send(d_mine, (size_t)nrec * sizeof(gmr1_hip_rx_record), ncclUint8, root, sh->comm, st), "ncclSend (records)");
 			}
 			err = g.end();
 		}
 		if (!err && e != hipSuccess)
-			err = fail(-EIO, "rx_run_sharded: staging the records failed (%s)", hipGetErrorString(e));
+			err = fail(-EIO, "rx_run_sharded: placing the root's own records failed (%s)", hipGetErrorString(e));
 		if (is_root && !err) {
 			gathered.resize(total ? total : 1);
 			if (total && hipMemcpyAsync(gathered.data(), d, total * sizeof(gmr1_hip_rx_record), hipMemcpyDeviceToHost, st) != hipSuccess)
@@ -413,11 +416,6 @@ int rx_run_sharded_impl(struct gmr1_hip_shard *sh, void *stream, int root, bool 
 			err = fail(-EIO, "rx_run_sharded: stream synchronise after the gather failed");
 		if (err)
 			return err;
-		if (is_root)                                  // root's own block did not travel
-			for (int i = 0; i < nrec; i++)
-				gathered[base[root] + i] = rec[i];
-	} else {
-		gathered.assign(rec.begin(), rec.begin() + nrec);
 	}
 	if (is_root) {
 		// carrier order: carrier a is local carrier a / world of rank a mod world; inside a carrier the owner's order

@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the tests check the PRODUCT build: a GMR1_HIP_LIBRARY left in the environment by a profiling script (it points at
+    # libgmr1_hip_prof.so, whose debug switches change results) must not redirect them
+    os.environ.pop("GMR1_HIP_LIBRARY", None)
     # A fresh checkout has no built artefacts (they are git-ignored): compile the HIP library (hipcc cross-compiles
     # without a GPU) and the CPU oracle once, before collection -- what __graft_entry__.build() does.  The product API
     # itself never builds or falls back: without the .so it raises.
