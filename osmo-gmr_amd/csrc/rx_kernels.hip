@@ -1805,7 +1805,7 @@ struct Lds4 {
 	uint32_t *ubits;
 };
 
-__host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t *off, bool gen = false)
+__host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t *off, bool gen = false, bool ub_over = false)
 {
 	// pass 1 keeps only the sync-chunk windows of the burst in LDS (everything else it needs is in
 	// registers; pass 2 re-reads from L2).  Decode-time data overlays all of it:
@@ -1814,7 +1814,9 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
 	//   table (2 KB, g_sb_lut) sits where the branch metrics will go
 	// (the 13 x 64 halfwords of window decisions overlay the soft-bit rows, which are dead once the
 	// branch metrics exist)
-	const size_t dec_bytes = 4 * kSteps12 * 4 + 4 * 8 * 4;
+	// (ub_over, the batch kernel: the decoded words go where the branch metrics were -- all of them are consumed by the time
+	// the survivor walk writes -- which brings the headline shape to 5 120 B, the LDS of eight waves per SIMD)
+	const size_t dec_bytes = 4 * kSteps12 * 4 + (ub_over ? 0 : 4 * 8 * 4);
 	const size_t stage_bytes = align16((size_t)stage_samples * 8);
 	const size_t corr_bytes = align16((size_t)4 * cw * 4);
 	off[0] = 0;
@@ -2010,7 +2012,10 @@ __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int k
 // samples of one plane each per load instead of one run of 64), so every sum is formed in the same order and every
 // result is bit-identical; pass 2's 234 samples at stride 4 from sample d (pi4cxpsk.c:292-295) are 234 CONSECUTIVE
 // samples of plane (offset + d) & 3 -- 15 lines of 128 bytes instead of every line of the window.
-template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false, bool EN = true, bool PL = false>
+// EBROW (GEN only): bytes between the four bursts' soft-bit rows in LDS.  432 holds any format; the kernel that decodes NT3
+// speech bursts right behind the demodulator (k_rx4g_tch3) packs its 212-byte rows at 216 to leave the decoder its tables.
+template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false, bool EN = true, bool PL = false,
+          int EBROW = 432>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
                                          unsigned char *__restrict__ lds_raw, int lane, LatPre<NPL, SPS> *pre = nullptr)
 {
@@ -2030,7 +2035,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	constexpr int NCHK = SMALL ? 1 : 3;               // sync chunks
 	constexpr int NSH = SMALL ? 1 : 2;                // 16-symbol pieces of the sync sequence
 	size_t off[4];
-	lds4_layout(stage_samples, cw, off, GEN);
+	constexpr bool UB_OVER = !LAT && !GEN;
+	lds4_layout(stage_samples, cw, off, GEN, UB_OVER);
 	Lds4 L;
 	L.x = reinterpret_cast<float2 *>(lds_raw + off[0]);
 	L.corr = reinterpret_cast<float *>(lds_raw + off[1]);
@@ -2038,7 +2044,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	L.eb = reinterpret_cast<int8_t *>(lds_raw + off[3]);
 	L.bm = reinterpret_cast<uint32_t *>(lds_raw + off[0]);
 	L.surv = reinterpret_cast<uint64_t *>(lds_raw + off[3]);
-	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + 4 * kSteps12 * 4);
+	L.ubits = reinterpret_cast<uint32_t *>(lds_raw + off[0] + (UB_OVER ? 0 : 4 * kSteps12 * 4));
 
 	const int g_row = g0 + row;                       // this row's burst
 	const bool row_live = g_row < n_end;
@@ -2762,13 +2768,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// =========================== pass 2: soft symbols / soft bits ===========================
 	// the soft-bit table overlays the pass-1 data (fused: where the branch metrics go after pass 2; demodulation
 	// only: behind the soft-bit rows, which themselves overlay the correlation the rows above were reading)
-	const unsigned char *lut = lds_raw + (GEN ? 4 * 432 : 0);
+	const unsigned char *lut = lds_raw + (GEN ? 4 * EBROW : 0);
 	if constexpr (LAT) {
 		lut = pre->lut;                             // the work-group's resident copy
 		WSYNC();
 	} else {
 		// the soft-bit table (2 KB, L2-resident) goes to LDS now that the rows are done with the pass-1 data it overlays
-		unsigned char *const lutw = lds_raw + (GEN ? 4 * 432 : 0);
+		unsigned char *const lutw = lds_raw + (GEN ? 4 * EBROW : 0);
 		const uint4 *__restrict__ lut_src = reinterpret_cast<const uint4 *>(FAC ? g_sb_lut1.v : g_sb_lut.v);
 		const uint4 lut_a = lut_src[lane], lut_b = lut_src[lane + 64];
 		WSYNC();
@@ -2805,14 +2811,14 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const float avr = lane_val(avr_r, src), avi = lane_val(avi_r, src);
 		const int blen = F::len(bt), nbits = F::nbits(bt);
 		float *gss = io.ssyms ? io.ssyms + (size_t)g * a.ssyms_stride : nullptr;
-		int8_t *eb = L.eb + q * 432;
+		int8_t *eb = L.eb + q * (GEN ? EBROW : 432);
 		row_chain |= kind << q;
 		if (!found) {
 			if (io.ebits)
 				for (int i = lane; i < a.ebits_stride; i += 64)
 					io.ebits[(size_t)g * a.ebits_stride + i] = 0;
 			if constexpr (GEN)                                  // (a fused decoder reads the LDS row)
-				for (int i = lane; i < 108; i += 64)
+				for (int i = lane; i < EBROW / 4; i += 64)
 					reinterpret_cast<uint32_t *>(eb)[i] = 0;
 			if (gss)
 				for (int i = lane; i < blen; i += 64)
@@ -2931,7 +2937,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 // without spilling, the run-time-sps one five; the long windows (sps 8: 32 samples per lane) need the registers of three
 // (the receive loop's instantiation, EN, keeps the window registers for the burst energy: five)
 template <int NPL, int SPS, bool EN = false>
-constexpr int kRx4Waves = NPL > 16 ? 3 : ((SPS == 4 && !EN) ? 6 : 5);
+constexpr int kRx4Waves = NPL > 16 ? 3 : ((SPS == 4 && !EN) ? 6 : 5);   // (seven: 72 VGPRs; measured again in round 4 with the LDS of seven -- no gain interleaved, spills and 4 % slower planar)
 
 template <int NPL, int SPS, bool ACC = false, bool EN = false, bool PL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS, EN>, kRx4Waves<NPL, SPS, EN>)))
@@ -2990,8 +2996,12 @@ __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw
 // decoder (tch3_body.h) on each of the four while their soft bits are still in the wave's LDS rows -- no 212-byte trip to
 // HBM and back per burst, one launch, and a compute unit always holds wavefronts in the traffic-bound half next to
 // wavefronts in the issue-bound half.
+// (resident waves per SIMD: the accelerated decoder's instantiation fits seven -- 72 VGPRs, 5 024 B of LDS -- and gains 2.4 %
+// over six; the generic one needs the registers of six)
 template <bool ACC>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_rx4g_tch3(RxArgs a, Tch3Args t, int stage_samples, int cw)
+constexpr int kRx4gTch3Waves = ACC ? 7 : 6;
+template <bool ACC>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4gTch3Waves<ACC>, kRx4gTch3Waves<ACC>))) void k_rx4g_tch3(RxArgs a, Tch3Args t, int stage_samples, int cw)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int g0 = blockIdx.x * 4;
@@ -3003,16 +3013,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 #endif
 	                 a.offset, nullptr, a.freq_shift, nullptr, nullptr, nullptr, a.rv, a.sync_id, a.toa, a.freq_err, a.energy,
 	                 a.ebits, a.ssyms};
-	rx4_body<8, 4, false, true, false>(a, io, stage_samples, cw, g0, n_end, lds_raw, lane);
-	// soft-bit rows of the four bursts at the front of the wave's LDS (432 bytes apart, lds4_layout), the decoder's behind them
-	t3::Tch3Lds *S = reinterpret_cast<t3::Tch3Lds *>(lds_raw + 4 * 432);
+	constexpr int kRow = 216;                    // 212 soft bits + the zero a punctured position reads
+	rx4_body<8, 4, false, true, false, false, true, false, kRow>(a, io, stage_samples, cw, g0, n_end, lds_raw, lane);
+	// soft-bit rows of the four bursts at the front of the wave's LDS (kRow bytes apart), the decoder's tables behind them
+	t3::Tch3Lds *S = reinterpret_cast<t3::Tch3Lds *>(lds_raw + 4 * kRow);
 	WSYNC();
 	t3::tch3_fill_locof(S, lane);
 	if (lane < 4)
-		*reinterpret_cast<uint32_t *>(lds_raw + lane * 432 + 212) = 0;      // byte 212: what a punctured position reads
+		*reinterpret_cast<uint32_t *>(lds_raw + lane * kRow + 212) = 0;      // byte 212: what a punctured position reads
 	WSYNC();
 	for (int q = 0; q < 4 && g0 + q < n_end; q++) {
-		t3::tch3_burst<ACC>(t, g0 + q, lane, reinterpret_cast<const int8_t *>(lds_raw + q * 432), S);
+		t3::tch3_burst<ACC>(t, g0 + q, lane, reinterpret_cast<const int8_t *>(lds_raw + q * kRow), S);
 		WSYNC();
 	}
 }
@@ -3652,7 +3663,7 @@ static hipError_t launch_rx_t(const RxArgs &a, bool decode, int max_in_len, int 
 		} else if constexpr (NPL <= 32) {
 			const int cw = (max_len + 15) & ~15;
 			size_t off4[4];
-			const size_t lds4 = lds4_layout(a.stage_samples, cw, off4);
+			const size_t lds4 = lds4_layout(a.stage_samples, cw, off4, false, true);
 			static size_t pad = (size_t)-1;     // profiling only: extra LDS per wave to cap the occupancy
 			if (pad == (size_t)-1) {
 				const char *e = profile_env("GMR1_HIP_LDS_PAD");
@@ -3792,10 +3803,24 @@ hipError_t launch_rx_tch3(const RxArgs &a, const Tch3Args &t, hipStream_t stream
 		return hipErrorInvalidValue;
 	const int cw = (a.in_len[0] - a.ssyms_stride * 4 + 1 + 15) & ~15;          // lags (ssyms_stride = symbols per burst)
 	size_t off4[4];
-	size_t lds = lds4_layout(a.stage_samples, cw, off4, true);
-	const size_t need = 4 * 432 + sizeof(t3::Tch3Lds);
+	// the demodulator's phases (pass 1: staged windows, correlation, coefficients; pass 2: four 216-byte soft-bit rows and
+	// the soft-bit table) and, after them, the rows + the decoder's tables
+	size_t lds = 4 * 64 * 8 + 4 * 128 * 4 + 4 * 16 * 8;                  // rx4_body's small-format pass 1 (lds4_layout, gen)
+	const size_t p2 = 4 * 216 + kSbLutBytes;
+	if (lds < p2)
+		lds = p2;
+	const size_t need = 4 * 216 + sizeof(t3::Tch3Lds);
 	if (lds < need)
 		lds = need;
+	(void)off4;
+	{
+		static size_t pad = (size_t)-1;     // profiling only: extra LDS per wave to cap the occupancy
+		if (pad == (size_t)-1) {
+			const char *e = profile_env("GMR1_HIP_LDS_PAD");
+			pad = e ? (size_t)atoi(e) : 0;
+		}
+		lds += pad;
+	}
 	const int grid4 = (a.n + 3) / 4;
 	if (t.conv_acc)
 		hipLaunchKernelGGL(k_rx4g_tch3<true>, dim3(grid4), dim3(64), lds, stream, a, t, a.stage_samples, cw);

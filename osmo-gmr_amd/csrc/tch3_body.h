@@ -349,7 +349,8 @@ __device__ __forceinline__ void tch3_burst(const Tch3Args &a, int g, int lane, c
 			}
 			const uint32_t A = ct[ia], B = ct[ib];
 			const int da = (int)(int16_t)A, db = (int)(int16_t)B;
-			ksp += ((A >> 16) + (B >> 16)) << (16 * f);
+			if constexpr (!ACC)                                          // (the accelerated decoder returns no metric: nothing to sum)
+				ksp += ((A >> 16) + (B >> 16)) << (16 * f);
 			const int sum = da + db, dif = da - db;
 			*reinterpret_cast<uint4 *>(&s_tab[f][4 * s]) =
 			    make_uint4((uint32_t)(-sum) << 16, (uint32_t)(-dif) << 16, (uint32_t)dif << 16, (uint32_t)sum << 16);
@@ -364,13 +365,16 @@ __device__ __forceinline__ void tch3_burst(const Tch3Args &a, int g, int lane, c
 		}
 	}
 	// both sums over the wave at once: rows by DPP, the four row totals through the scalar unit
-	ksp += dpp<0xB1>(ksp);
-	ksp += dpp<0x4E>(ksp);
-	ksp += dpp<0x141>(ksp);
-	ksp += dpp<0x140>(ksp);
-	const uint32_t ks_all = (uint32_t)__builtin_amdgcn_readlane((int)ksp, 0) + (uint32_t)__builtin_amdgcn_readlane((int)ksp, 16) +
-	                        (uint32_t)__builtin_amdgcn_readlane((int)ksp, 32) + (uint32_t)__builtin_amdgcn_readlane((int)ksp, 48);
-	const int ksum = (int)(fr ? ks_all >> 16 : ks_all & 0xffffu);
+	int ksum = 0;
+	if constexpr (!ACC) {
+		ksp += dpp<0xB1>(ksp);
+		ksp += dpp<0x4E>(ksp);
+		ksp += dpp<0x141>(ksp);
+		ksp += dpp<0x140>(ksp);
+		const uint32_t ks_all = (uint32_t)__builtin_amdgcn_readlane((int)ksp, 0) + (uint32_t)__builtin_amdgcn_readlane((int)ksp, 16) +
+		                        (uint32_t)__builtin_amdgcn_readlane((int)ksp, 32) + (uint32_t)__builtin_amdgcn_readlane((int)ksp, 48);
+		ksum = (int)(fr ? ks_all >> 16 : ks_all & 0xffffu);
+	}
 	WSYNC();
 
 	// ---- per-lane constants
