@@ -35,7 +35,7 @@ def kernel_sources_hash():
     PMC counters were taken on, and a traffic figure from another build is not reported."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("rx_kernels.hip", "gmr1_dev.h", "rx_loop.h"):
+    for f in ("rx_kernels.hip", "tch3_body.h", "gmr1_dev.h", "rx_loop.h"):
         with open(os.path.join(ROOT, "osmo-gmr_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -511,6 +511,33 @@ def run_side_workload(args):
            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                         "algorithmic_bytes_per_launch": bytes_per_launch}}
+    if args.workload == "fcch":
+        # The sweep is a sliding correlation: every lag of every stream takes 117 complex multiply-adds (8 flops) on the
+        # FP32 vector pipe -- no contraction shape for MFMA (one stream against 117 taps at 23 284 lags).  Besides the HBM
+        # fraction of the whole step above: the rough sweep alone (k_fcch_stats + k_fcch_corr + k_fcch_pick, timed here
+        # after the timed region) against the FP32 vector peak.
+        def rough_only():
+            api.fcch_rough_batch_dev(stream.cuda_stream, "fcch", n, 4, ns, iq.data_ptr(), offset.data_ptr(), None,
+                                     toa.data_ptr(), rv.data_ptr())
+        for _ in range(5):
+            rough_only()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            rough_only()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        rough_ms = e0.elapsed_time(e1) / args.steps
+        nlags = ns // 4 - 117 + 1
+        flops = float(n) * nlags * 117 * 8
+        peak_tf = 157.3                      # MI355X FP32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
+        out["roofline_valu"] = {"bound": "valu_fp32", "kernel": "k_fcch_stats + k_fcch_corr<117> + k_fcch_pick (rough sweep alone)",
+                                "achieved": flops / (rough_ms * 1e-3) / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                                "frac": flops / (rough_ms * 1e-3) / 1e12 / peak_tf, "kernel_ms": rough_ms,
+                                "algorithmic_flops_per_launch": flops,
+                                "note": "the time includes the statistics / decimation pass (HBM-bound) and the peak pick; the "
+                                        "correlation kernel alone is about 0.19 of the 0.25 ms (profiles/*kernel_stats*)"}
     if sharded_same is not None:
         out["checks"] = {"sharded_outputs_identical_to_single_gpu_run": sharded_same}
     # CPU baseline + parity on a bounded sample
