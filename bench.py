@@ -512,8 +512,9 @@ def run_side_workload(args):
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                         "algorithmic_bytes_per_launch": bytes_per_launch}}
     if args.workload == "fcch":
-        # The sweep is a sliding correlation: every lag of every stream takes 117 complex multiply-adds (8 flops) on the
-        # FP32 vector pipe -- no contraction shape for MFMA (one stream against 117 taps at 23 284 lags).  Besides the HBM
+        # The sweep is a sliding correlation: every lag of every stream takes 117 multiply-adds of a complex sample with a
+        # REAL tap (the dual chirp is real: 2 FMA = 4 flops executed; the reference's generic complex correlation spends 8)
+        # on the FP32 vector pipe -- no contraction shape for MFMA (one stream against 117 taps at 23 284 lags).  Besides the HBM
         # fraction of the whole step above: the rough sweep alone (k_fcch_stats + k_fcch_corr + k_fcch_pick, timed here
         # after the timed region) against the FP32 vector peak.
         def rough_only():
@@ -530,14 +531,15 @@ def run_side_workload(args):
         torch.cuda.synchronize()
         rough_ms = e0.elapsed_time(e1) / args.steps
         nlags = ns // 4 - 117 + 1
-        flops = float(n) * nlags * 117 * 8
+        flops = float(n) * nlags * 117 * 4
         peak_tf = 157.3                      # MI355X FP32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
         out["roofline_valu"] = {"bound": "valu_fp32", "kernel": "k_fcch_stats + k_fcch_corr<117> + k_fcch_pick (rough sweep alone)",
                                 "achieved": flops / (rough_ms * 1e-3) / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                                 "frac": flops / (rough_ms * 1e-3) / 1e12 / peak_tf, "kernel_ms": rough_ms,
                                 "algorithmic_flops_per_launch": flops,
-                                "note": "the time includes the statistics / decimation pass (HBM-bound) and the peak pick; the "
-                                        "correlation kernel alone is about 0.19 of the 0.25 ms (profiles/*kernel_stats*)"}
+                                "note": "executed flops (real taps); the time includes the statistics / decimation pass (HBM-bound, about "
+                                        "half of it) and the peak pick: the correlation kernel alone runs at twice this fraction "
+                                        "(profiles/*kernel_stats_fcch*)"}
     if sharded_same is not None:
         out["checks"] = {"sharded_outputs_identical_to_single_gpu_run": sharded_same}
     # CPU baseline + parity on a bounded sample
