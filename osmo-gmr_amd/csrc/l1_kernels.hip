@@ -342,8 +342,10 @@ __global__ __launch_bounds__(64) void k_tch3(Tch3Args a)
 		if (lane == 53)
 			dst[53] = 0;                             // byte 212: what a punctured position reads
 	}
+	Tch3Lane lc;
+	tch3_lane(lc, &s_t3, lane);
 	WSYNC();
-	tch3_burst<ACC>(a, g, lane, s_e, &s_t3);
+	tch3_burst<ACC>(a, g, lane, s_e, &s_t3, lc);
 }
 
 // ---------------------------------------------------------------------------

@@ -2491,6 +2491,18 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (b < 0) b = 0;
 			if (e >= w_p) e = w_p - 1;
 			float acc = 0.f;
+			if (SMALL && w_p <= 8) {
+				// A search window of at most eight lags (NT3: seven) has at most seven correlation values to interpolate
+				// over: lane sub takes the ONE value cr[sub] with the weight of tap k = sub - ib, instead of three of the
+				// 21 tap places of which most lie outside the array (a third of the instructions of the timing rows).
+				const int k = isub - ib;
+				const float sg = (k & 1) ? S : -S;
+				const float xx = kPif * ((float)k - f);
+				const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
+				const bool valid = isub >= b && isub < e;          // (|k| <= 10 follows from b and e)
+				const float c = cr[isub];
+				acc = valid ? c * wgt : 0.0f;
+			} else
 	#pragma unroll
 			for (int t = 0; t < 3; t++) {
 				const int k = 3 * isub - 10 + t;
@@ -3021,9 +3033,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4gTch3Wav
 	t3::tch3_fill_locof(S, lane);
 	if (lane < 4)
 		*reinterpret_cast<uint32_t *>(lds_raw + lane * kRow + 212) = 0;      // byte 212: what a punctured position reads
+	t3::Tch3Lane lc;
+	t3::tch3_lane(lc, S, lane);
 	WSYNC();
 	for (int q = 0; q < 4 && g0 + q < n_end; q++) {
-		t3::tch3_burst<ACC>(t, g0 + q, lane, reinterpret_cast<const int8_t *>(lds_raw + q * kRow), S);
+		t3::tch3_burst<ACC>(t, g0 + q, lane, reinterpret_cast<const int8_t *>(lds_raw + q * kRow), S, lc);
 		WSYNC();
 	}
 }

@@ -305,8 +305,43 @@ __device__ __forceinline__ void tch3_fill_locof(Tch3Lds *S, int lane)
 	S->locof[c_k7.st[1][p]] = (uint8_t)(32 + p);
 }
 
+// What a lane needs for every burst and that depends on nothing but the lane and where the tables sit: computed once per
+// wave (tch3_lane), kept in registers over the bursts a wave decodes.  The values pass through an empty asm so that the
+// compiler keeps them instead of recomputing them burst after burst (it did: 36 VALU per burst).
+struct Tch3Lane {
+	uint32_t ad[6][2];       // LDS byte address of the position's table value in step 0, per phase and state of the lane
+	uint32_t hi[5];          // the position's own predecessor is the high one, per phase
+};
+__device__ __forceinline__ void tch3_lane(Tch3Lane &L, const Tch3Lds *S, int lane)
+{
+	const int fr = lane >> 5, p = lane & 31;
+	{
+		uint32_t x = (uint32_t)p & 7u;
+		L.hi[0] = ((uint32_t)p >> 4) & 1u;
+		L.hi[1] = ((uint32_t)p >> 3) & 1u;
+		L.hi[2] = (x >> 2) & 1u;
+		x ^= L.hi[2] ? 7u : 0u;
+		L.hi[3] = (x >> 1) & 1u;
+		L.hi[4] = x & 1u;
+	}
+	// (the tables are 16-byte aligned: the code word's four bytes are the address's low bits, and the lane's second state has
+	// the first one's code word xor the phase's constant, k7_pair_mask)
+	const uint32_t tab_base = (uint32_t)(uintptr_t)(t3_lds_cu32 *)S->tab_all[fr];
+	const uint32_t e4 = (uint32_t)c_k7.o[0][p] << 2;
+#pragma unroll
+	for (int ph = 0; ph < 6; ph++) {
+		L.ad[ph][0] = tab_base + ((e4 >> (2 * ph)) & 12u);
+		L.ad[ph][1] = L.ad[ph][0] ^ (4u * k7_pair_mask(ph));
+		asm volatile("" : "+v"(L.ad[ph][0]), "+v"(L.ad[ph][1]));
+	}
+#pragma unroll
+	for (int i = 0; i < 5; i++)
+		asm volatile("" : "+v"(L.hi[i]));
+}
+
 template <bool ACC>
-__device__ __forceinline__ void tch3_burst(const Tch3Args &a, int g, int lane, const int8_t *__restrict__ s_e, Tch3Lds *S)
+__device__ __forceinline__ void tch3_burst(const Tch3Args &a, int g, int lane, const int8_t *__restrict__ s_e, Tch3Lds *S,
+                                           const Tch3Lane &LC)
 {
 	uint32_t (*s_tab_all)[kT3Steps * 4] = S->tab_all;
 	uint32_t (*s_tab)[kT3Steps * 4] = s_tab_all;
@@ -377,31 +412,16 @@ __device__ __forceinline__ void tch3_burst(const Tch3Args &a, int g, int lane, c
 	}
 	WSYNC();
 
-	// ---- per-lane constants
-	uint32_t hi[5];
-	{
-		uint32_t x = (uint32_t)p & 7u;
-		hi[0] = ((uint32_t)p >> 4) & 1u;
-		hi[1] = ((uint32_t)p >> 3) & 1u;
-		hi[2] = (x >> 2) & 1u;
-		x ^= hi[2] ? 7u : 0u;
-		hi[3] = (x >> 1) & 1u;
-		hi[4] = x & 1u;
-	}
-	const uint32_t tab_base = (uint32_t)(uintptr_t)(t3_lds_cu32 *)s_tab[fr];
-	uint32_t ad[6][2];
+	// ---- per-lane constants (tch3_lane)
+	const uint32_t (&hi)[5] = LC.hi;
+	const uint32_t (&ad)[6][2] = LC.ad;
 	uint32_t w[2];
 	constexpr uint32_t kSent = 0xF000u;           // unreachable (libosmocore: MAX_AE)
 	constexpr uint32_t kBias = 0x4000u;           // |2 cost - K| <= 252 (ACC: 256) per step, 48 steps: stays inside 16 bits
 #pragma unroll
-	for (int r = 0; r < 2; r++) {
-		const uint32_t e = c_k7.o[r][p];
-#pragma unroll
-		for (int ph = 0; ph < 6; ph++)
-			ad[ph][r] = tab_base + 4u * ((e >> (2 * ph)) & 3u);
+	for (int r = 0; r < 2; r++)
 		// pass 1 starts from state 0 (D4); conv_acc.c: from every state alike
 		w[r] = (!ACC && c_k7.st[r][p] ? kSent : kBias) << 16;
-	}
 
 	// pass 1 (warm-up): only the metrics matter - both states of the lane in one register (k7_step_pk)
 	{

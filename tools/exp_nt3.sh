@@ -1,9 +1,7 @@
 cd $GRAFT_REPO_ROOT
 E=$GRAFT_REPO_ROOT/osmo-gmr_amd/libgmr1_hip_exp.so
-run() { python3 bench.py --workload nt3 --no-cpu --steps 50 $2 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); print('$1', d['ms_per_step'], d['roofline']['frac'])"; }
-for i in 1 2; do
-GMR1_HIP_LIBRARY=$E run base_acc
-run new_acc
-GMR1_HIP_LIBRARY=$E run base_generic "--conv-decoder generic"
-run new_generic "--conv-decoder generic"
+run() { python3 bench.py --workload nt3 --steps 50 --no-cpu $2 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][0]); print('$1', d['ms_per_step'], d['roofline']['frac'])"; }
+for i in 1 2 3; do
+GMR1_HIP_LIBRARY=$E run base
+run new
 done
