@@ -3011,7 +3011,7 @@ __global__ __launch_bounds__(64) void k_rx4g(RxArgs a, int stage_samples, int cw
 // (resident waves per SIMD: the accelerated decoder's instantiation fits seven -- 72 VGPRs, 5 024 B of LDS -- and gains 2.4 %
 // over six; the generic one needs the registers of six)
 template <bool ACC>
-constexpr int kRx4gTch3Waves = ACC ? 7 : 6;
+constexpr int kRx4gTch3Waves = 7;
 template <bool ACC>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4gTch3Waves<ACC>, kRx4gTch3Waves<ACC>))) void k_rx4g_tch3(RxArgs a, Tch3Args t, int stage_samples, int cw)
 {
