@@ -437,13 +437,24 @@ def test_fused_rx_planar_layout_bit_identical(gpu_api, pkg, decoder, n, align):
     gpu_api.iq_to_planar_dev(None, 4, total, d_iq.data_ptr(), d_pl.data_ptr(), P)
     d_off = torch.from_numpy(wl["offset"].astype(np.int64)).cuda()
     d_kind = torch.from_numpy(wl["kind"]).cuda()
+    # with and without a caller-supplied frequency shift per burst (rx_ccch hands -freq_err over, gmr1_rx.c:821-823): the
+    # rotated sync reference is then computed per burst instead of read from the zero-shift table
+    fs_host = (np.random.default_rng(n).standard_normal(n) * 0.01).astype(np.float32)
+    d_fs = torch.from_numpy(fs_host).cuda()
+    for shift in (None, d_fs):
+        _planar_vs_interleaved(gpu_api, wl, n, P, d_iq, d_pl, d_off, d_kind, shift)
+
+
+def _planar_vs_interleaved(gpu_api, wl, n, P, d_iq, d_pl, d_off, d_kind, d_fs):
+    import torch
 
     def run(planar):
         o = dict(l2=torch.zeros((n, 24), dtype=torch.uint8, device="cuda"), crc=torch.zeros(n, dtype=torch.int32, device="cuda"),
                  conv=torch.zeros(n, dtype=torch.int32, device="cuda"), toa=torch.zeros(n, dtype=torch.float32, device="cuda"),
                  fe=torch.zeros(n, dtype=torch.float32, device="cuda"), eb=torch.zeros((n, 432), dtype=torch.int8, device="cuda"),
                  ss=torch.zeros((n, 234), dtype=torch.float32, device="cuda"), rv=torch.zeros(n, dtype=torch.int32, device="cuda"))
-        tail = (d_off.data_ptr(), d_kind.data_ptr(), None, o["l2"].data_ptr(), o["crc"].data_ptr(), o["conv"].data_ptr(),
+        tail = (d_off.data_ptr(), d_kind.data_ptr(), d_fs.data_ptr() if d_fs is not None else None, o["l2"].data_ptr(),
+                o["crc"].data_ptr(), o["conv"].data_ptr(),
                 o["toa"].data_ptr(), o["fe"].data_ptr(), o["eb"].data_ptr(), o["ss"].data_ptr(), o["rv"].data_ptr())
         if planar:
             gpu_api.rx_bcch_ccch_batch_planar_dev(None, n, 4, d_pl.data_ptr(), P, *tail)
@@ -455,7 +466,8 @@ def test_fused_rx_planar_layout_bit_identical(gpu_api, pkg, decoder, n, align):
     a, b = run(False), run(True)
     assert (a["crc"] == 0).mean() > 0.9
     good = a["crc"] == 0
-    assert np.array_equal(a["l2"][good], wl["l2"][good])
+    if d_fs is None:
+        assert np.array_equal(a["l2"][good], wl["l2"][good])
     for k in a:
         assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), f"{k} differs between the two sample layouts"
 
