@@ -1226,6 +1226,9 @@ def main():
     def time_steps(fn, k):
         """K launches of `fn` between two events on the launch stream -> ms per launch (after the timed region only)."""
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # the same untimed pre-roll as the headline's timed region: the result checks before this left the GPU idle, and
+        # a measurement that starts at idle clocks reads about 4 % slow
+        preroll(fn, args.preroll_s)
         for _ in range(max(3, args.warmup)):
             fn()
         torch.cuda.synchronize()
