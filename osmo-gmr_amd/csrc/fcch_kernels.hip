@@ -337,14 +337,20 @@ __global__ __launch_bounds__(64) void k_fcch_pick(FcchRoughArgs a)
 // fine acquisition / SNR: one wavefront per burst of exactly len*sps samples
 // ---------------------------------------------------------------------------
 // mode 0: gmr1_fcch_fine (toa, freq_error) ; mode 1: gmr1_fcch_snr
+// kFineWaves wavefronts per burst share the DFT's bins (a 117-point burst: one bin per lane of two waves instead of two
+// passes of one -- the acquisition chain of the receive loop is a handful of these small dependent launches, so their
+// latency counts); the statistics are formed by every wave for itself, lane for lane as before, and the ordered tail
+// (peak search, centroid) is wave 0's: every sum keeps its order, the results are bit for bit those of one wave.
+constexpr int kFineWaves = 2;
 template <int N>
-__global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
+__global__ __launch_bounds__(64 * kFineWaves) void k_fcch_fine(FcchFineArgs a)
 {
-	constexpr int PER = (N + 63) / 64;       // bins / symbols per lane
+	constexpr int NT = 64 * kFineWaves;
+	constexpr int PER = (N + NT - 1) / NT;   // bins per thread
 	__shared__ float2 s_up[N], s_dn[N];
 	__shared__ float2 s_tw[N];               // the DFT's twiddles: read N times per bin, so from LDS, not from memory
 	__shared__ float s_e[2][N];
-	const int b = blockIdx.x, lane = threadIdx.x;
+	const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const int sps = a.sps, nraw = N * sps;
 	const float2 *__restrict__ in = a.iq + a.offset[b];
 	const float fs = a.freq_shift ? a.freq_shift[b] : 0.0f;
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 	const float inv = 1.0f / sd;
 
 	// normalise, shift, mix
-	for (int i = lane; i < N; i += 64) {
+	for (int i = tid; i < N; i += NT) {
 		s_tw[i] = c_fcch.twid[a.tab][i];
 		float2 v = in[i * sps];
 		v.x = (v.x - avr) * inv;
@@ -392,11 +398,11 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 	}
 	__syncthreads();
 
-	// direct DFT, bins lane, lane+64, ...
+	// direct DFT, bins tid, tid + NT, ...
 	float2 xu[PER], xd[PER];
 #pragma unroll
 	for (int p = 0; p < PER; p++) {
-		const int k = lane + 64 * p;
+		const int k = tid + NT * p;
 		float2 au = make_float2(0.f, 0.f), ad = make_float2(0.f, 0.f);
 		if (k < N) {
 			int idx = 0;
@@ -421,6 +427,8 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 	__syncthreads();
 
 	if (a.mode == 0) {
+		if (wave != 0)
+			return;                          // (no barrier below in this branch)
 		// 5-bin energy window centroid of both spectra (PEAK_WEIGH_WIN)
 		float peak[2];
 #pragma unroll
@@ -466,6 +474,7 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 		for (int r = 0; r < 6; r++) {
 			float bv = -1.0f;
 			int bi = 0x7fffffff;
+			// (every wave scans all bins, lane for lane as one wave would: the barriers below are the work-group's)
 			for (int k = lane; k < N; k += 64) {
 				const float e = s_e[0][k];
 				if (e > bv) { bv = e; bi = k; }
@@ -478,11 +487,11 @@ __global__ __launch_bounds__(64) void k_fcch_fine(FcchFineArgs a)
 			}
 			top[r] = bv;
 			__syncthreads();
-			if (lane == 0 && bi != 0x7fffffff)
+			if (tid == 0 && bi != 0x7fffffff)
 				s_e[0][bi] = -2.0f;          // taken
 			__syncthreads();
 		}
-		if (lane == 0)
+		if (tid == 0)
 			a.snr[b] = (top[0] + top[1]) / (top[4] + top[5]);      // fcch.c:701-702
 	}
 	(void)xu; (void)xd;
@@ -534,23 +543,37 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 	}
 	if (lane == 0) { s_bv[wv] = bv; s_bi[wv] = bi; }
 	__syncthreads();
-	if (tid == 0) {
+	if (wv == 0) {
 		for (int q = 1; q < 4; q++)
 			if (s_bv[q] > bv || (s_bv[q] == bv && s_bi[q] < bi)) { bv = s_bv[q]; bi = s_bi[q]; }
 		const int pwr_max_idx = (bi == 0x7fffffff) ? 0 : bi;
-		// the twin peak one BCCH period later (fcch.c:398-430)
-		float pwrs0 = 0.f, pwrs1 = 0.f, pk0 = 0.f, pk1 = 0.f;
-		for (int i = -10; i <= 10; i++) {
-			int j = pwr_max_idx + i;
-			if (j > 0 && j < cl) { pwrs0 += cp[j]; pk0 += cp[j] * (float)j; }
-			j += Lp;
-			if (j > 0 && j < cl) { pwrs1 += cp[j]; pk1 += cp[j] * (float)j; }
+		// the twin peak one BCCH period later (fcch.c:398-430): lanes 0..20 fetch the 2 x 21 values at once (this kernel sits
+		// in the receive loop's acquisition chain: its latency counts), the sums are then formed in the reference's order
+		float c0 = 0.f, c1 = 0.f;
+		int j0 = 0, j1 = 0;
+		bool ok0 = false, ok1 = false;
+		if (lane <= 20) {
+			j0 = pwr_max_idx + lane - 10;
+			j1 = j0 + Lp;
+			ok0 = j0 > 0 && j0 < cl;
+			ok1 = j1 > 0 && j1 < cl;
+			c0 = ok0 ? cp[j0] : 0.f;
+			c1 = ok1 ? cp[j1] : 0.f;
 		}
-		pk0 /= pwrs0;
-		pk1 /= pwrs1;
-		const int nLp = (int)round((double)(pk1 - pk0));
-		s_scal[0] = nLp;
-		s_scal[1] = (abs(nLp - Lp) > 10) ? 1 : 0;       // also true for NaN -> INT_MIN
+		const float w0 = c0 * (float)j0, w1 = c1 * (float)j1;
+		float pwrs0 = 0.f, pwrs1 = 0.f, pk0 = 0.f, pk1 = 0.f;
+		for (int i = 0; i <= 20; i++) {
+			// (a lag outside the sweep contributes nothing: the reference skips it, here it adds +0)
+			if (__shfl((int)ok0, i)) { pwrs0 += __shfl(c0, i); pk0 += __shfl(w0, i); }
+			if (__shfl((int)ok1, i)) { pwrs1 += __shfl(c1, i); pk1 += __shfl(w1, i); }
+		}
+		if (tid == 0) {
+			pk0 /= pwrs0;
+			pk1 /= pwrs1;
+			const int nLp = (int)round((double)(pk1 - pk0));
+			s_scal[0] = nLp;
+			s_scal[1] = (abs(nLp - Lp) > 10) ? 1 : 0;       // also true for NaN -> INT_MIN
+		}
 	}
 	__syncthreads();
 	if (s_scal[1]) {
@@ -590,6 +613,16 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 	__syncthreads();
 
 	// ---- ordered tail: rising edges, 3-point interpolation, ranked de-duplicated list
+	// (wave 0 finds the words that have a flag at all -- a handful of 234 -- by four ballots; lane 0 then walks only those,
+	// in order; a word's first flag is a rising edge unless the word before it ended on a flag)
+	unsigned long long nzm[4] = {0, 0, 0, 0};
+	if (wv == 0) {
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			const int wd = lane + 64 * c;
+			nzm[c] = __ballot(wd * 32 < Lw && s_flags[wd] != 0u);
+		}
+	}
 	if (tid == 0) {
 		int *toa = a.toa + (size_t)s * a.N;
 		float pwr[32];
@@ -597,10 +630,11 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 		int n = 0;
 		const int sps = a.sps;
 		const int half = (a.burst_len * sps) >> 1;
-		bool prev = false;
-		for (int wd = 0; wd * 32 < Lw; wd++) {
-			unsigned int f = s_flags[wd];
-			if (!f) { prev = false; continue; }
+		for (int c = 0; c < 4; c++)
+		for (unsigned long long left = nzm[c]; left; left &= left - 1ull) {
+			const int wd = 64 * c + __builtin_ctzll(left);
+			const unsigned int f = s_flags[wd];
+			bool prev = wd > 0 && (s_flags[wd - 1] >> 31) != 0u;
 			for (int b = 0; b < 32; b++) {
 				const bool cur = (f >> b) & 1u;
 				if (cur && !prev) {
@@ -685,9 +719,9 @@ hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t st)
 	if (a.n <= 0)
 		return hipSuccess;
 	if (nsym == 117)
-		hipLaunchKernelGGL((k_fcch_fine<117>), dim3(a.n), dim3(64), 0, st, a);
+		hipLaunchKernelGGL((k_fcch_fine<117>), dim3(a.n), dim3(64 * kFineWaves), 0, st, a);
 	else if (nsym == 468)
-		hipLaunchKernelGGL((k_fcch_fine<468>), dim3(a.n), dim3(64), 0, st, a);
+		hipLaunchKernelGGL((k_fcch_fine<468>), dim3(a.n), dim3(64 * kFineWaves), 0, st, a);
 	else
 		return hipErrorInvalidValue;
 	return hipGetLastError();
