@@ -248,10 +248,12 @@ int RxRun::acquire()
 	// one block, device and pinned host mirror: [per carrier ... | per slot ...]
 	size_t o = 0;
 	auto take = [&](size_t bytes) { const size_t at = o; o += up128(bytes); return at; };
+	// (what the host sends first -- the carriers' parameters, the first sweep's windows and a zeroed peak list -- in front,
+	// so that ONE copy starts the chain; what comes back -- toa1 .. snr -- contiguous behind it)
 	const size_t o_base = take(n * 8), o_len = take(n * 8), o_stat = take(n * 4), o_align = take(n * 4), o_ba = take(n * 4),
-	             o_ferr = take(n * 4), o_can3 = take(n * 4), o_toa1 = take(n * 4), o_rv1 = take(n * 4), o_ftoa = take(n * 4),
-	             o_fe = take(n * 4), o_count = take(n * 4), o_peaks = take(S * 4), o_ctoa = take(S * 4), o_cfe = take(S * 4),
-	             o_snr = take(S * 4), o_live = take(S * 4), o_off = take(S * 8), o_fs = take(S * 4);
+	             o_ferr = take(n * 4), o_can3 = take(n * 4), o_off = take(S * 8), o_peaks = take(S * 4), o_toa1 = take(n * 4),
+	             o_rv1 = take(n * 4), o_ftoa = take(n * 4), o_fe = take(n * 4), o_count = take(n * 4), o_ctoa = take(S * 4),
+	             o_cfe = take(S * 4), o_snr = take(S * 4), o_live = take(S * 4), o_fs = take(S * 4);
 	const size_t total = o;
 	unsigned char *d, *h;
 	if ((r = acq_scratch(total, &d))) return r;
@@ -269,11 +271,10 @@ int RxRun::acquire()
 		reinterpret_cast<int32_t *>(H(o_can3))[k] = length[i] >= (uint64_t)wl3 ? 1 : 0;
 		reinterpret_cast<uint64_t *>(H(o_off))[k] = offset[i] + (uint64_t)align[i];
 	}
-	// inputs: everything up to can3, and the first sweep's windows
-	HIP_TRY(hipMemcpyAsync(d, h, o_toa1, hipMemcpyHostToDevice, st));
-	HIP_TRY(hipMemcpyAsync(D(o_off), H(o_off), (size_t)n * 8, hipMemcpyHostToDevice, st));
 	// rough_multi leaves slots past `count` unwritten: the copy back must not carry stale numbers
-	HIP_TRY(hipMemsetAsync(D(o_peaks), 0, S * 4, st));
+	std::memset(H(o_off) + (size_t)n * 8, 0, (o_toa1 - o_off) - (size_t)n * 8);
+	// inputs: everything up to can3, the first sweep's windows, the zeroed peak list -- one copy
+	HIP_TRY(hipMemcpyAsync(d, h, o_toa1, hipMemcpyHostToDevice, st));
 
 	AcqArgs g;
 	std::memset(&g, 0, sizeof(g));
@@ -330,7 +331,8 @@ int RxRun::acquire()
 	                                      reinterpret_cast<float *>(D(o_cfe))))) return r;
 	HIP_TRY(launch_acq_glue(4, g, st));
 	if ((r = gmr1_hip_fcch_snr_batch_dev(st, 0, (int)S, sps, iq, d_off, d_fs, reinterpret_cast<float *>(D(o_snr))))) return r;
-	HIP_TRY(hipMemcpyAsync(H(o_toa1), D(o_toa1), o_live - o_toa1, hipMemcpyDeviceToHost, st));
+	// results back: the peak list (in front of toa1) and toa1 .. snr
+	HIP_TRY(hipMemcpyAsync(H(o_peaks), D(o_peaks), o_live - o_peaks, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 
 	// ---- the decisions, from the raw sweep results, in the reference's order ------------------------------------

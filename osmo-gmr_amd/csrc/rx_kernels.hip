@@ -3135,9 +3135,13 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	// this launch walks the chain through one time slice: rounds [round0, round_end) -- it picks up where the previous
 	// slice left the chain (state, counters) and, at its end, notes how long the CCCH list has become (slice_end); the next
 	// slice's entries start at the next multiple of four, so that the batch kernel's groups of four never straddle two slices
-	const int round0 = la.n_rounds[chain];
+	// (the first slice starts every counter at zero -- rounds, frames, list length, the finished flag -- and writes the zeroth
+	// row of slice_end for the batch kernel of its slice; nothing clears them beforehand)
+	const int round0 = slice ? la.n_rounds[chain] : 0;
 	const int round_end = min(round0 + slice_rounds, la.max_rounds);
-	if (la.fin[chain]) {
+	if (slice == 0 && threadIdx.x == 0)
+		la.slice_end[chain] = 0;
+	if (slice && la.fin[chain]) {
 		if (threadIdx.x == 0)
 			la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = la.slice_end[(size_t)slice * gridDim.x + chain];
 		return;
@@ -3166,7 +3170,7 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
 	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
 	const size_t c_base = (size_t)chain * la.c_stride;
-	int n_frames = la.n_frames[chain], n_ccch = (la.slice_end[(size_t)slice * gridDim.x + chain] + 3) & ~3;
+	int n_frames = slice ? la.n_frames[chain] : 0, n_ccch = slice ? (la.slice_end[(size_t)slice * gridDim.x + chain] + 3) & ~3 : 0;
 	auto on_frame = [&](const RxLoopState &x) {
 		if (flog && lane == 0 && n_frames < la.flog_stride)
 			flog[n_frames] = {x.align, x.freq_err, x.fn};
@@ -3407,8 +3411,10 @@ __global__ __launch_bounds__(64 * kMergeWaves) void k_rx_merge(RxLoopArgs la)
 // every candidate, weight the power by 1/|e_toa - toa|, keep the strongest.
 // ---------------------------------------------------------------------------
 // 4. (optional) the chains' record blocks closed up into one array in chain order: what the caller gets is then ONE copy of
-// exactly the records there are, not of every chain's whole block.  One work-group per chain: its offset is the sum of
-// the counts before it (a few hundred integers), its records move as dwords.
+// exactly the records there are, not of every chain's whole block.  kPackParts work-groups per chain (the chain's records
+// dealt out among them: with one, 64 chains would occupy a quarter of the CUs for 14 us at the very end of the call): the
+// chain's offset is the sum of the counts before it (a few hundred integers), its records move as dwords.
+constexpr int kPackParts = 8;
 __global__ __launch_bounds__(256) void k_rx_pack(RxLoopArgs la, int n_chains)
 {
 	__shared__ int s_part[4];
@@ -3430,9 +3436,9 @@ __global__ __launch_bounds__(256) void k_rx_pack(RxLoopArgs la, int n_chains)
 	const uint32_t *src = reinterpret_cast<const uint32_t *>(la.rec + (size_t)chain * la.rec_stride);
 	uint32_t *dst = reinterpret_cast<uint32_t *>(la.packed + off);
 	constexpr int W = (int)(sizeof(gmr1_hip_rx_record) / 4);
-	for (int i = tid; i < n * W; i += 256)
+	for (int i = (int)blockIdx.y * 256 + tid; i < n * W; i += 256 * kPackParts)
 		dst[i] = src[i];
-	if (chain == n_chains - 1 && tid == 0)
+	if (chain == n_chains - 1 && blockIdx.y == 0 && tid == 0)
 		*la.n_packed = off + n;
 }
 
@@ -3896,12 +3902,8 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	// the helper wave's two staged windows, then the latency decoder's operand table
 	const size_t lds_h = one ? 0 : 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
 	hipError_t e;
-	// counters of the walk: rounds, CCCH list lengths, frames, finished flags, slice ends
-	if ((e = hipMemsetAsync(la.n_rounds, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(la.n_ccch, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(la.n_frames, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(la.fin, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
-	if ((e = hipMemsetAsync(la.slice_end, 0, (size_t)n_chains * 4, stream)) != hipSuccess) return e;
+	// (the counters of the walk -- rounds, CCCH list lengths, frames, finished flags, slice ends -- start at zero: the first
+	// slice's k_rx_chain takes them as zero and writes them, no launch of their own)
 	const int slice_rounds = (la.max_rounds + kLoopSlices - 1) / kLoopSlices;
 #define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                \
 	do {                                                                                                         \
@@ -3969,7 +3971,7 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	if ((e = hipStreamWaitEvent(stream, ls->side_done, 0)) != hipSuccess) return e;
 	hipLaunchKernelGGL(k_rx_merge, grid, dim3(64 * kMergeWaves), 0, stream, la);
 	if (la.packed && la.n_packed)
-		hipLaunchKernelGGL(k_rx_pack, grid, dim3(256), 0, stream, la, n_chains);
+		hipLaunchKernelGGL(k_rx_pack, dim3((unsigned)n_chains, kPackParts), dim3(256), 0, stream, la, n_chains);
 	return hipGetLastError();
 }
 
