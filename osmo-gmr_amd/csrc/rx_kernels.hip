@@ -246,12 +246,15 @@ __device__ __forceinline__ float dppf(float v)
 	return __builtin_bit_cast(float, dpp<CTRL>(__builtin_bit_cast(uint32_t, v)));
 }
 
-// value of lane (l ^ X) within a 16-lane row, X in {8,4,2,1}
+// the partner's value in the steps 1, 2, 4, 8 of a reduction over a 16-lane row (every use in this file is such a
+// reduction by a commutative operation, run in that order): lane l ^ X for X in {8, 2, 1}; for X = 4 lane 7 - (l & 7) of
+// the half -- a lane of the half's OTHER quad, whose four lanes all hold that quad's value after steps 1 and 2 -- which is
+// one DPP operand instead of the two moves an exact l ^ 4 takes, with the same result bit for bit
 template <int X>
 __device__ __forceinline__ uint32_t row_xor(uint32_t v)
 {
 	if constexpr (X == 8) return dpp<0x128>(v);                    // row_ror:8
-	else if constexpr (X == 4) return dpp<0x1B>(dpp<0x141>(v));    // half_mirror, then quad [3,2,1,0]
+	else if constexpr (X == 4) return dpp<0x141>(v);               // row_half_mirror
 	else if constexpr (X == 2) return dpp<0x4E>(v);                // quad_perm [2,3,0,1]
 	else return dpp<0xB1>(v);                                      // quad_perm [1,0,3,2]
 }
@@ -2052,6 +2055,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
 	const float2 *xst_lat = L.x;                       // LAT: where the one burst's sync-chunk windows are staged
 
+	// KEEP: the window of the wave's LAST burst stays in registers through the timing rows, and its kept samples (and sync
+	// symbols) reach pass 2 through 2 KB of LDS instead of a second trip to memory -- a quarter of the second read's
+	// bytes never travels.  (One window is what the register budget of six waves holds; the interleaved layout only:
+	// the planar one's second read is compact already.)
+	constexpr bool KEEP = !GEN && !LAT && !PL && !EN && SPS == 4 && NPL == 16;
+	const bool keep3 = KEEP && g0 + 3 < n_end;
+	float2 wv_own[NPL];
 	GMR1_STAMP(0);
 	// =========================== pass 1: correlation magnitudes ===========================
 	if constexpr (SMALL) {
@@ -2171,7 +2181,6 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 	} else {
-	float2 wv_own[NPL];
 	float2 (&wv)[NPL] = wv_own;
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
@@ -2407,6 +2416,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const int tl_p = LAT ? F::tl(c_types[__builtin_amdgcn_readlane(type_r, 0)], __builtin_amdgcn_readlane(kind_r, 0)) : F::tl(bt_r, kind_r);
 	// (LAT: the loop's windows have 10 * sps + 1 or 20 * sps + 1 lags -- a constant lets the two little loops below unroll)
 	const int win = LAT ? 3 : (w_p < 3 ? w_p : 3);
+	const bool w3 = !LAT && __ballot(win != 3) == 0;   // (wave-uniform) every row's energy window is three lags
 	float toa_r = 0.f, p_pwr = 0.f;                    // pi4cxpsk.c:227-237: the best sequence so far
 	int sid_r = -1;
 	for (int sq = 0; sq < (FAC ? 2 : 1); sq++) {
@@ -2450,6 +2460,35 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 					mi = 64 * h + __builtin_ctzll(bh);
 			}
 		} else {
+		if (w3) {
+			// every row's window energy is over three lags (any search window of >= 3 lags): per lane the best of its lags
+			// m = col, col + 16, ... in ascending order (a later one must be strictly larger), then over the row the largest
+			// energy as a 32-bit maximum (a non-negative float's bits order like its value) and the LOWEST lag that has it --
+			// what the 64-bit (energy, ~lag) keys below decide, in a third of the instructions
+			uint32_t be = 0;
+			int bl = 0x7fffffff;
+			for (int m = col; m + 3 <= w_p; m += 16) {
+				const float c0 = cr[m], c1 = cr[m + 1], c2 = cr[m + 2];
+				float e = c0 * c0;                           // (0 + c0^2 is c0^2)
+				e += c1 * c1;
+				e += c2 * c2;
+				const uint32_t eb = __builtin_bit_cast(uint32_t, e);
+				const bool better = bl == 0x7fffffff || eb > be;
+				be = better ? eb : be;
+				bl = better ? m : bl;
+			}
+			uint32_t mx = be, o;
+			o = dpp<0xB1>(mx); mx = o > mx ? o : mx;
+			o = dpp<0x4E>(mx); mx = o > mx ? o : mx;
+			o = dpp<0x141>(mx); mx = o > mx ? o : mx;
+			o = dpp<0x140>(mx); mx = o > mx ? o : mx;
+			uint32_t lo = (bl != 0x7fffffff && be == mx) ? (uint32_t)bl : 0x7fffffffu;
+			o = dpp<0xB1>(lo); lo = o < lo ? o : lo;
+			o = dpp<0x4E>(lo); lo = o < lo ? o : lo;
+			o = dpp<0x141>(lo); lo = o < lo ? o : lo;
+			o = dpp<0x140>(lo); lo = o < lo ? o : lo;
+			mi = lo == 0x7fffffffu ? -1 : (int)lo;
+		} else {
 		unsigned long long key = 0;
 		for (int m = col; m + win <= w_p; m += 16) {
 			float e = 0.f;
@@ -2466,11 +2505,22 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		key = row_max_u64<8>(key);
 		mi = (int)(~(uint32_t)key);
 		}
+		}
 		if (mi < 0 || mi + win > w_p)
 			mi = 0;
 		GMR1_STAMP(11);
 		int p = mi;
-		{
+		if (w3 || LAT) {
+			float pe = -1.f;
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				const float c = cr[mi + k];
+				const float e = c * c;
+				const bool up = e > pe;
+				pe = up ? e : pe;
+				p = up ? mi + k : p;
+			}
+		} else {
 			float pe = -1.f;
 			for (int k = 0; k < win; k++) {
 				const float c = cr[mi + k];
@@ -2482,19 +2532,29 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		// interpolated correlation at `pos` (lanes 0-7 of the row) and at `pos + 2` (lanes 8-15): same
 		// fractional part, so the same 21 weights; lane sub = col & 7 holds taps k = 3 sub - 10 + {0,1,2}
 		const int ipt = col >> 3, isub = col & 7;
-		auto interp2 = [&](float pos, float &se, float &sl) {
+		// what the evaluations below share: the lane's first tap, as an index offset and as the float the weight needs, the
+		// sign bit sin(pi (k - f)) = -(-1)^k sin(pi f) sets for an even first tap, whether the lane has taps at all (sub 7
+		// would hold k = 11, 12, 13) and the one bound an array index has to be checked against: i = ib + k with |k| <= 10
+		// lies in [max(ib - 10, 0), min(ib + 11, w - 1)) exactly if 0 <= i < w - 1
+		const int k0 = 3 * isub - 10;
+		const float kf0 = (float)k0, kf1 = (float)(k0 + 1), kf2 = (float)(k0 + 2);
+		const uint32_t sgn0 = (isub & 1) ? 0u : 0x80000000u;
+		const bool has_taps = isub != 7;
+		const uint32_t wlim = (uint32_t)(w_p - 1);
+		// -> acc: the lane's own half-row sum (at `pos` in lanes 0-7, at `pos + 2` in lanes 8-15), oth: the other half's
+		auto interp2 = [&](float pos, float &acc_o, float &oth_o) {
 			const float fl = floorf(pos);
 			const int ib = (int)fl + 2 * ipt;
 			const float f = pos - fl;
-			const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
-			int b = ib - 10, e = ib + 11;
-			if (b < 0) b = 0;
-			if (e >= w_p) e = w_p - 1;
+			const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f)
 			float acc = 0.f;
 			if (SMALL && w_p <= 8) {
 				// A search window of at most eight lags (NT3: seven) has at most seven correlation values to interpolate
 				// over: lane sub takes the ONE value cr[sub] with the weight of tap k = sub - ib, instead of three of the
 				// 21 tap places of which most lie outside the array (a third of the instructions of the timing rows).
+				int b = ib - 10, e = ib + 11;
+				if (b < 0) b = 0;
+				if (e >= w_p) e = w_p - 1;
 				const int k = isub - ib;
 				const float sg = (k & 1) ? S : -S;
 				const float xx = kPif * ((float)k - f);
@@ -2502,24 +2562,29 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const bool valid = isub >= b && isub < e;          // (|k| <= 10 follows from b and e)
 				const float c = cr[isub];
 				acc = valid ? c * wgt : 0.0f;
-			} else
-	#pragma unroll
-			for (int t = 0; t < 3; t++) {
-				const int k = 3 * isub - 10 + t;
-				const float sg = ((isub + t) & 1) ? S : -S;
-				const float xx = kPif * ((float)k - f);
-				const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
-				const int i = ib + k;
-				const bool valid = k <= 10 && i >= b && i < e;
-				const float c = cr[valid ? i : 0];
-				acc += valid ? c * wgt : 0.0f;
+			} else {
+				// (the three values are read whether or not they lie in the array -- an LDS address outside it is harmless --
+				// and dropped by the select)
+				const int i0 = ib + k0;
+				const float *cp = cr + i0;
+				const float c0 = cp[0], c1 = cp[1], c2 = cp[2];
+				const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
+				const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
+				const float w0 = (x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
+				const float w1 = (x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
+				const float w2 = (x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
+				const bool v0 = has_taps && (uint32_t)i0 < wlim;
+				const bool v1 = has_taps && (uint32_t)(i0 + 1) < wlim;
+				const bool v2 = has_taps && (uint32_t)(i0 + 2) < wlim;
+				acc += v0 ? c0 * w0 : 0.0f;
+				acc += v1 ? c1 * w1 : 0.0f;
+				acc += v2 ? c2 * w2 : 0.0f;
 			}
 			acc += row_xorf<1>(acc);
 			acc += row_xorf<2>(acc);
 			acc += row_xorf<4>(acc);
-			const float oth = row_xorf<8>(acc);
-			se = ipt ? oth : acc;
-			sl = ipt ? acc : oth;
+			acc_o = acc;
+			oth_o = row_xorf<8>(acc);
 		};
 		float early = (float)p - 1.0f, incr = 0.5f;
 		bool active = true;
@@ -2595,24 +2660,29 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 			toa_s = early + 1.0f;
 			GMR1_STAMP(9);
-			float dummy;
-			interp2(toa_s, pk_s, dummy);
+			float pa, po;
+			interp2(toa_s, pa, po);
+			pk_s = ipt ? po : pa;
 		} else {
+			// early energy ee > late energy le: early -= incr, ee < le: early += incr.  Lanes 8-15 hold the late sum as their
+			// own, so they see the two energies swapped and step by -incr instead: the same decisions without the selects
+			float sincr = ipt ? -incr : incr;
 	#pragma unroll 1
 			for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
-				float se, sl;
-				interp2(early, se, sl);
-				const float ee = se * se, le = sl * sl;
+				float sa, so;
+				interp2(early, sa, so);
+				const float ea = sa * sa, eo = so * so;
 				if (active) {
-					if (ee > le) early -= incr;
-					else if (ee < le) early += incr;
+					if (ea > eo) early -= sincr;
+					else if (ea < eo) early += sincr;
 					else active = false;
 				}
-				incr *= 0.5f;
+				sincr *= 0.5f;
 			}
 			toa_s = early + 1.0f;
-			float dummy;
-			interp2(toa_s, pk_s, dummy);
+			float pa, po;
+			interp2(toa_s, pa, po);
+			pk_s = ipt ? po : pa;
 		}
 		pk_s = pk_s * __builtin_amdgcn_rcpf((float)tl_p);
 		if (pk_s * pk_s > p_pwr) {                      // needs strictly more than what is there (0 at first)
@@ -2625,6 +2695,25 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	GMR1_STAMP(3);
 	if (a.dbg_stop == 3) return;
 	const int d_r = (int)roundf(toa_r);
+
+	// KEEP: samples d, d + 4, ... of burst 3's window are registers k = 0..15 of the lanes with lane = d (mod 4) (lane l
+	// holds samples l + 64 k): they go to slots i = (l + 64 k - d) / 4 of an exchange buffer over the staged windows and
+	// the correlation, which nothing reads any more
+	float2 *const exch = reinterpret_cast<float2 *>(lds_raw);
+	if constexpr (KEEP) {
+		if (keep3) {
+			const int d3 = __builtin_amdgcn_readlane(d_r, 48);
+			WSYNC();
+			if (((lane - d3) & 3) == 0) {
+				const int i0 = (lane - d3) >> 2;
+#pragma unroll
+				for (int k = 0; k < NPL; k++)
+					if ((unsigned)(i0 + 16 * k) < 256u)
+						exch[i0 + 16 * k] = wv_own[k];
+			}
+			WSYNC();
+		}
+	}
 
 	// pass-2 operands of a burst (its 234 symbols at stride sps from sample d, re-read from
 	// L2 / Infinity Cache): fetched two bursts ahead of their use
@@ -2648,12 +2737,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			const long long sr = (long long)io.offset[g] + d;
 			in = a.iq + (sr & 3) * a.plane_stride + (sr >> 2);
 		}
+		const bool from_exch = KEEP && q == 3 && keep3;
 #pragma unroll
 		for (int r = 0; r < NSYM; r++) {
 			const int i = lane + 64 * r;
 			const int j = i * sps + d;
 			if (i < blen && j >= 0 && j < in_len) {
-				o.x[r] = PL ? in[i] : in[j];
+				if (KEEP && from_exch)
+					o.x[r] = exch[i];
+				else
+					o.x[r] = PL ? in[i] : in[j];
 				o.ok |= 1 << r;
 			}
 		}
@@ -2695,6 +2788,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 						// sample sp sps + d of the window = place sp of the plane the kept samples lie in
 						const long long sr = (long long)(row_live ? io.offset[g_row] : 0) + d_r;
 						xr[h] = (a.iq + (sr & 3) * a.plane_stride + (sr >> 2))[sp];
+					} else if (KEEP && keep3 && row == 3) {
+						xr[h] = exch[sp];           // sample sp sps + d = slot sp
 					} else
 					xr[h] = LAT ? xst_lat[wb + nn * sps + d_r] : in_r[idx];
 				}
