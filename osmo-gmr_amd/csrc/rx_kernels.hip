@@ -1732,6 +1732,9 @@ __device__ __forceinline__ float2 sync_coef_seq1(const DevBurst &bt, int sq, int
 // the same for freq_shift = 0, every burst format, sps 1..16: [sps][type][n < 32]
 constexpr int kCoef0MaxSps = 16;
 __device__ float2 g_coef0[kCoef0MaxSps + 1][kNumTypes][32];
+// ... and a copy in the constant address space (made on the device after every k_coef0 run), which a wave-uniform index
+// reads with scalar loads -- from the writable array above the compiler issues one vector load per value
+__constant__ float2 c_coef0[kCoef0MaxSps + 1][kNumTypes][32];
 
 __global__ __launch_bounds__(64) void k_coef0(int first, int count)
 {
@@ -1755,40 +1758,66 @@ hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t 
 		return e;
 	// the zero-shift sync references of the uploaded formats (same stream: ordered before any burst kernel)
 	hipLaunchKernelGGL(k_coef0, dim3((unsigned)count, kCoef0MaxSps), dim3(64), 0, stream, first, count);
-	return hipGetLastError();
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return e;
+	void *src = nullptr;
+	e = hipGetSymbolAddress(&src, HIP_SYMBOL(g_coef0));
+	if (e != hipSuccess)
+		return e;
+	return hipMemcpyToSymbolAsync(HIP_SYMBOL(c_coef0), src, sizeof(g_coef0), 0, hipMemcpyDeviceToDevice, stream);
 }
 
 // Sync correlation of the fused path's two formats with everything static: chunks of T0, T1, T2 training symbols
-// (BCCH 11 + 3 + 3, DC6 7 + 3 + 3; nb.c:36-41, 94-99).  Lane n holds rotated reference value n; the taps are read
-// out into scalar registers once per burst (v_readlane) and feed the packed FMAs as scalar operands, so a tap costs one
-// LDS read and two v_pk_fma_f32, all reads of a lag issued back to back.  xs: the staged chunk windows, window c =
-// samples [pos_c sps, pos_c sps + T_c sps + w - 1).  corr[j] = sum over chunks of |sum_n c_n x[j + n sps]|.
+// (BCCH 11 + 3 + 3, DC6 7 + 3 + 3; nb.c:36-41, 94-99).  The rotated reference values sit in scalar registers, one pair
+// (re, im) per tap -- read straight from the table with scalar loads when no frequency shift was given (`ctab`), else
+// out of lane n of `cfl` (v_readlane) -- and feed the packed FMAs as scalar operands, so a tap costs one LDS read and two
+// v_pk_fma_f32, all reads of a lag issued back to back.  xs: the staged chunk windows, window c = samples
+// [pos_c sps, pos_c sps + T_c sps + w - 1).  corr[j] = sum over chunks of |sum_n c_n x[j + n sps]|.
+//
+// (ar, ai) += c x as two packed FMAs: (-c.im x.im, c.im x.re) first, then c.re (x.re, x.im) -- the order of the scalar
+// chains ar = fma(c.re, x.re, fma(-c.im, x.im, ar)), ai = fma(c.re, x.im, fma(c.im, x.re, ai)).  Written out with the
+// operand selects and the sign on the ONE pair: the compiler builds (-c.im, c.im) and (c.re, c.re) as pairs of their own,
+// four scalar registers a tap, and spills what they displace.  (s_nop: a packed result needs one wait state before its
+// next use, which the compiler's own sequences carry as well.)
+__device__ __forceinline__ void pk_cmac(v2f &acc, unsigned long long c, v2f x)
+{
+	asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]\n\ts_nop 0\n\t"
+	    "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\ts_nop 0"
+	    : "+v"(acc)
+	    : "s"(c), "v"(x));
+}
+
 template <int SPS, int T0, int T1, int T2>
-__device__ __forceinline__ void corr_fixed(const float2 *__restrict__ xs, int sps_rt, int w, int lane, float2 cfl,
-                                           float *__restrict__ corr)
+__device__ __forceinline__ void corr_fixed(const float2 *__restrict__ xs, int sps_rt, int w, int lane,
+                                           const float2 *__restrict__ ctab, float2 cfl, float *__restrict__ corr)
 {
 	constexpr int T[3] = {T0, T1, T2};
 	constexpr int NT = T0 + T1 + T2;
 	const int sps = SPS ? SPS : sps_rt;
-	v2f cf[NT];
+	unsigned long long cf[NT];
+	if (ctab) {
+		const unsigned long long *__restrict__ ct = reinterpret_cast<const unsigned long long *>(ctab);
 #pragma unroll
-	for (int n = 0; n < NT; n++)
-		cf[n] = (v2f){lane_val(cfl.x, n), lane_val(cfl.y, n)};
+		for (int n = 0; n < NT; n++)
+			cf[n] = ct[n];
+	} else {
+#pragma unroll
+		for (int n = 0; n < NT; n++)
+			cf[n] = (unsigned long long)__builtin_bit_cast(uint32_t, lane_val(cfl.x, n)) |
+			        ((unsigned long long)__builtin_bit_cast(uint32_t, lane_val(cfl.y, n)) << 32);
+	}
 	for (int j = lane; j < w; j += 64) {
 		float cj = 0.f;
 		int wb = 0, base = 0;
 #pragma unroll
 		for (int ch = 0; ch < 3; ch++) {
 			const float2 *xp = xs + wb + j;
-			// (ar, ai) += c x as two packed FMAs: (-c.im x.im, c.im x.re) first, then c.re (x.re, x.im) -- the order of the
-			// scalar chains ar = fma(c.re, x.re, fma(-c.im, x.im, ar)), ai = fma(c.re, x.im, fma(c.im, x.re, ai))
 			v2f acc = {0.f, 0.f};
 #pragma unroll
 			for (int n = 0; n < T[ch]; n++) {
 				const float2 x = xp[n * sps];
-				const v2f c = cf[base + n];
-				acc = __builtin_elementwise_fma((v2f){-c.y, c.y}, (v2f){x.y, x.x}, acc);
-				acc = __builtin_elementwise_fma((v2f){c.x, c.x}, (v2f){x.x, x.y}, acc);
+				pk_cmac(acc, cf[base + n], (v2f){x.x, x.y});
 			}
 			base += T[ch];
 			wb += T[ch] * sps + w - 1;
@@ -2273,8 +2302,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		// the burst format and sps -- a table built once with this same arithmetic (g_coef0)
 		// (lane n keeps value n: tl <= 32 for every format this body is launched for)
 		float2 cfl = make_float2(0.f, 0.f);
+		// (!GEN: the table row itself, read by scalar loads in corr_fixed -- a wave-uniform pointer, so set outside the
+		// lane-dependent branches below)
+		const float2 *__restrict__ ctab = (!GEN && io.freq_shift == nullptr) ? c_coef0[sps][type] : nullptr;
 		if (io.freq_shift == nullptr) {
-			if (lane < 32)
+			if (GEN && lane < 32)
 				cfl = g_coef0[sps][type][lane];
 		} else if (lane < tl) {
 			if constexpr (GEN) {
@@ -2345,9 +2377,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		if constexpr (!GEN) {
 			// BCCH / DC6: static tap structure (the host refuses to start this kernel if the tables say otherwise)
 			if (kind == 0)
-				corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, cfl, corr);
+				corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, ctab, cfl, corr);
 			else
-				corr_fixed<SPS, 7, 3, 3>(xst, sps, w, lane, cfl, corr);
+				corr_fixed<SPS, 7, 3, 3>(xst, sps, w, lane, ctab, cfl, corr);
 		} else if constexpr (FAC) {
 			const int len = bt.sync[0][0].len;
 			for (int j = lane; j < w; j += 64) {
