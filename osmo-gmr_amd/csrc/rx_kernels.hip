@@ -523,7 +523,7 @@ __device__ __forceinline__ void window_fetch(const float2 *__restrict__ in, int 
 // order and the statistics come out bit-identical.
 template <int NPL, int NFULL = -1>
 __device__ __forceinline__ void window_stats(const float2 (&v)[NPL], int in_len, int lane,
-                                             float &avr_o, float &avi_o, float &inv_o, int perm_src = -1)
+                                             float &avr_o, float &avi_o, float &inv_o, int perm_src = -1, int odd_src = 1)
 {
 	auto home = [&](float x) {
 		return perm_src < 0 ? x : __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm_src << 2, __builtin_bit_cast(int, x)));
@@ -539,7 +539,10 @@ __device__ __forceinline__ void window_stats(const float2 (&v)[NPL], int in_len,
 	const float sr = wave_sum(home(s2.x));
 	const float si = wave_sum(home(s2.y));
 	const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
-	const float avr = sr / (float)in_len, avi = si / (float)in_len;     // true division, see load_normalise
+	// true division, see load_normalise -- ONE division sequence for the two wave-uniform sums: lanes with an even `lane`
+	// divide the real sum, those with an odd one (wave lane odd_src is one) the imaginary sum
+	const float quot = ((lane & 1) ? si : sr) / (float)in_len;
+	const float avr = lane_val(quot, 0), avi = lane_val(quot, odd_src);
 	const v2f av = {avr, avi};
 	v2f acc2 = {0.f, 0.f};
 #pragma unroll
@@ -2334,7 +2337,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (io.energy && lane == 0)
 				io.energy[g] = pre->h_stat[3];
 		} else {
-		window_stats<NPL, NFULL>(wv, in_len, sl, avr, avi, inv, PL ? 16 * (lane & 3) + (lane >> 2) : -1);
+		window_stats<NPL, NFULL>(wv, in_len, sl, avr, avi, inv, PL ? 16 * (lane & 3) + (lane >> 2) : -1, PL ? 16 : 1);
 		if ((LAT || !PREFETCH_NEXT) && EN && io.energy) {
 			// burst_energy() while the window is still in registers
 			const float e = window_energy_regs<NPL>(wv, in_len, lane);
@@ -2738,10 +2741,21 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			WSYNC();
 			if (((lane - d3) & 3) == 0) {
 				const int i0 = (lane - d3) >> 2;
+				if (d3 >= 0 && d3 < 128) {
+					// (-32 <= i0 <= 15: only registers 0 and 1 can fall before slot 0, none behind slot 255)
+					if (i0 >= 0)
+						exch[i0] = wv_own[0];
+					if (i0 >= -16)
+						exch[i0 + 16] = wv_own[1];
 #pragma unroll
-				for (int k = 0; k < NPL; k++)
-					if ((unsigned)(i0 + 16 * k) < 256u)
+					for (int k = 2; k < NPL; k++)
 						exch[i0 + 16 * k] = wv_own[k];
+				} else {
+#pragma unroll
+					for (int k = 0; k < NPL; k++)
+						if ((unsigned)(i0 + 16 * k) < 256u)
+							exch[i0 + 16 * k] = wv_own[k];
+				}
 			}
 			WSYNC();
 		}
@@ -2855,10 +2869,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 		// chunk sums (pi4cxpsk.c:381-389); the window scale 1/sigma is irrelevant to every angle
+		constexpr int NCS = GEN ? 4 : 3;                // chunks a format can have (the fused formats: three)
 		if constexpr (!SMALL) if (nch_r > 1) {
-			float sumr[4], sumi[4];
+			float sumr[NCS], sumi[NCS];
 #pragma unroll
-			for (int c = 0; c < 4; c++) {
+			for (int c = 0; c < NCS; c++) {
 				const float pr = (chn[0] == c ? t0[0].x : 0.f) + (chn[1] == c ? t0[1].x : 0.f);
 				const float pi = (chn[0] == c ? t0[0].y : 0.f) + (chn[1] == c ? t0[1].y : 0.f);
 				sumr[c] = row_sum(pr);
@@ -2866,7 +2881,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 			float f = 0.f;
 #pragma unroll
-			for (int i = 1; i < 4; i++) {
+			for (int i = 1; i < NCS; i++) {
 				if (i < nch_r) {
 					const float ppos = (float)F::cpos(bt_r, i - 1) + (float)F::clen(bt_r, kind_r, i - 1) / 2.0f;
 					const float cpos = (float)F::cpos(bt_r, i) + (float)F::clen(bt_r, kind_r, i) / 2.0f;
@@ -2986,13 +3001,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			const int i = lane + 64 * r;
 			if (i >= blen)
 				continue;
+			// (a sample outside the window counts as 0 + 0j, not as minus the mean: the subtraction runs for every lane
+			// and the zero test knows which lanes had a sample)
 			float2 x = cur.x[r];
-			if (cur.ok & (1 << r)) {
-				x.x -= avr;
-				x.y -= avi;
-			}
+			x.x -= avr;
+			x.y -= avi;
 			const float th2 = fmaf(A2, (float)i, fmaf(atan2_turns(x.y, x.x), 2048.0f, B2));
-			const bool zero = x.x == 0.0f && x.y == 0.0f;                   // cargf(0) = 0
+			const bool zero = !(cur.ok & (1 << r)) || (x.x == 0.0f && x.y == 0.0f);   // cargf(0) = 0
 			if (gss) {
 				float th = th2 * (1.0f / 2048.0f);
 				th -= rintf(th);
