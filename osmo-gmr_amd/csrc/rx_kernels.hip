@@ -279,10 +279,16 @@ __device__ __forceinline__ float lane_val(float v, int l)
 	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// (r0 + r16) + (r32 + r48) of the four row sums, wave-uniform.  The two cross-row steps are DPP row broadcasts: lane 15 of
+// every row into the next row (row 1 then holds r16 + r0, row 3 r48 + r32), then lane 31 into rows 2 and 3 (row 3:
+// (r48 + r32) + (r16 + r0)) -- the same three additions, operands swapped, so the same float; one readlane instead of four
+// and no moves back from scalar registers.
 __device__ __forceinline__ float wave_sum(float v)
 {
 	v = row_sum(v);
-	return (lane_val(v, 0) + lane_val(v, 16)) + (lane_val(v, 32) + lane_val(v, 48));
+	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xf, 0xf, true));   // row_bcast:15
+	v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xf, 0xf, true));   // row_bcast:31 (rows 0, 1: + 0)
+	return lane_val(v, 63);
 }
 
 // ---------------------------------------------------------------------------
@@ -2702,8 +2708,21 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			// early energy ee > late energy le: early -= incr, ee < le: early += incr.  Lanes 8-15 hold the late sum as their
 			// own, so they see the two energies swapped and step by -incr instead: the same decisions without the selects
 			float sincr = ipt ? -incr : incr;
+			{
+				// the first level sits on a whole lag (early = p - 1): sin(pi f) = 0, so tap 0 has the weight 1 and the twenty
+				// others (+-)0 -- the two sums ARE cr[p - 1] and cr[p + 1] (0 outside the array), no interpolation to run
+				const int io = p - 1 + 2 * ipt;
+				const float c = cr[io];
+				const float sa = (uint32_t)io < wlim ? c : 0.0f;
+				const float so = row_xorf<8>(sa);
+				const float ea = sa * sa, eo = so * so;
+				if (ea > eo) early -= sincr;
+				else if (ea < eo) early += sincr;
+				else active = false;
+				sincr *= 0.5f;
+			}
 	#pragma unroll 1
-			for (int it = 0; it < 9; it++) {              // incr = 0.5 ... 1/512 (> 1/1024)
+			for (int it = 1; it < 9; it++) {              // incr = 0.25 ... 1/512 (> 1/1024)
 				float sa, so;
 				interp2(early, sa, so);
 				const float ea = sa * sa, eo = so * so;
