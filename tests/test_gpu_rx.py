@@ -120,6 +120,40 @@ def test_fused_rx_parity_small(gpu_api, orc, pkg, decoder):
     assert (got["crc"] == 0).mean() > 0.9
 
 
+def test_fused_rx_bursts_at_the_window_edges(gpu_api, orc, pkg):
+    """Bursts anywhere in the search window, its first and last lags included (the estimator itself pulls the outermost
+    ones a lag inward: picks d = round(toa) of 0 ... 39 in the CCCH window's 41 lags): the fourth burst of a wave -- whose
+    window the kernel keeps in registers and hands to pass 2 through LDS instead of reading it again -- must see exactly
+    what a re-read would have at either end.  The oracle is the checker, burst by burst."""
+    wl = workloads.bcch_ccch_mix(pkg, n=6001, seed=41, esn0_db=(8.0, 20.0), toa_jitter=20)
+    got = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4)
+    ref = orc.demod_decode_batch(wl["iq"], wl["offset"], wl["kind"], sps=4)
+    assert np.array_equal(got["rv"], ref["rv"])
+    d_ref = np.round(ref["toa"]).astype(int)
+    fourth = (np.arange(wl["kind"].size) % 4) == 3
+    # the edge picks occur, on fourth bursts too
+    ccch = wl["kind"] == 1
+    assert (d_ref[ccch & fourth] <= 1).sum() > 10 and (d_ref[ccch & fourth] >= 38).sum() > 10 and d_ref.min() == 0
+    dtoa = np.abs(got["toa"] - ref["toa"])
+    flip = np.round(got["toa"]) != np.round(ref["toa"])
+    assert dtoa.max() < 16.0 / 1024.0 and flip.mean() <= 0.01
+    same = ~flip & (dtoa == 0)
+    dss = np.abs(got["ssyms"][same] - ref["ssyms"][same])
+    dss = np.minimum(dss, np.abs(dss - 4.0))
+    assert dss.max() < 1e-4
+    deb = np.abs(got["ebits"][same].astype(int) - ref["ebits"][same].astype(int))
+    assert (deb > 1).mean() < 2e-5 and ((deb != 0)).mean() < 1e-3
+    eq = same & np.all(got["ebits"] == ref["ebits"], axis=1)
+    assert eq.mean() > 0.75
+    for k in ("l2", "crc", "conv"):
+        assert np.array_equal(got[k][eq], ref[k][eq]), k
+    # and the bursts at the edges are in that set in proportion (nothing edge-specific hides in the excluded ones)
+    edge = (d_ref <= 1) | (ccch & (d_ref >= 38))
+    assert eq[edge & fourth].mean() > 0.6
+    ok = (got["crc"] == 0) | (ref["crc"] == 0)
+    assert np.array_equal(got["l2"][ok], ref["l2"][ok]) and np.array_equal(got["crc"][ok], ref["crc"][ok])
+
+
 def test_fused_rx_clean_exact_payload(gpu_api, orc, pkg, decoder):
     """Config 1 flavour: noiseless bursts, integer TOA -> every payload recovered, toa == 40 / 20."""
     wl = workloads.bcch_ccch_mix(pkg, n=70, seed=1, esn0_db=(200.0,), toa_jitter=0, frac=False,
