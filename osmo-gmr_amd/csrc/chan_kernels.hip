@@ -280,14 +280,43 @@ hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream)
 // resamples DOWN (rate 0.468) and its root-raised cosine is 95 taps per phase long -- a second instantiation
 static constexpr int kRsTapsShort = 30, kRsTapsLong = 96;
 static constexpr int kRsPeriods = 32;        // periods one wave walks
-static constexpr int kRsWinShort = 256, kRsWinLong = 512;     // LDS window (samples) per wave, >= span
+static constexpr int kRsWinTight = 128, kRsWinShort = 256, kRsWinLong = 512;     // LDS window (samples) per wave, >= span
+
+// acc += e (s.re, s.im) for the real tap e that sits in the LOW (HI = false) or HIGH half of the register pair `ee`: one
+// v_pk_fma_f32 with the half picked by the operand selects.  The compiler's own code for the two scalar chains
+// orr = fma(e, s.re, orr), oi = fma(e, s.im, oi) is the same packed FMA, but on a pair (e, e) it builds for every tap -- 60
+// registers of taps instead of 30 and five waves per SIMD instead of eight, with two LDS reads in flight per wave.
+// (s_nop: a packed result needs one wait state before its next use.)
+typedef float rs_v2f __attribute__((ext_vector_type(2)));
+template <bool HI>
+__device__ __forceinline__ void rs_mac(rs_v2f &acc, rs_v2f ee, rs_v2f s)
+{
+	if constexpr (HI)
+		asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\ts_nop 0" : "+v"(acc) : "v"(ee), "v"(s));
+	else
+		asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\ts_nop 0" : "+v"(acc) : "v"(ee), "v"(s));
+}
 
 // EXT: the instantiation that can rotate its input (the pre-resampler of an off-grid capture) and write polyphase-planar
 // output; the plain one does neither and keeps its registers
+// (the 30-tap instantiations are compiled for at least five waves per SIMD: the compiler otherwise keeps all thirty samples
+// of a period in flight at once)
+template <int kRsTaps, bool EXT>
+constexpr int kRsWaves = kRsTaps <= 32 ? 5 : 2;
 template <int kRsTaps, int kRsWin, bool EXT = false>
-__global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long long Q, int span)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRsWaves<kRsTaps, EXT>)))
+void k_resamp(ResampArgs a, long long P, long long Q, int span)
 {
-	__shared__ float2 xs[kRsWin];
+	static_assert(kRsTaps % 2 == 0, "taps are kept two to a register pair");
+	// D periods are handled as one block: their windows are written to LDS together, the next block's windows are requested,
+	// then the block's arithmetic runs and its outputs are stored.  On this ISA loads and stores share one counter and complete
+	// out of order with respect to each other, so a wait for a window is a wait for EVERYTHING outstanding, the stores just
+	// issued included; in the block form whatever the wait covers was issued a whole block of arithmetic earlier.  (Two periods
+	// per block for the 128-sample window = every plan that raises the rate: 80 registers, six waves; four periods per block
+	// cost the sixth wave and gain nothing, and an aligned ds_read_b128 per two taps out of a doubled window is no faster than
+	// the two 8-byte reads: what bounds the kernel after this is LDS bytes, 240 per output.)
+	constexpr int D = kRsWin <= 128 ? 2 : 1;
+	__shared__ float2 xsb[D][kRsWin];
 	constexpr int NH = kRsWin / 64;
 	const int lane = threadIdx.x;
 	const int sl = blockIdx.y;
@@ -303,19 +332,20 @@ __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long l
 	const long long N0 = (long long)a.j0 * a.den + p0 * a.num;
 	const long long i_first = (N0 / a.den) / a.nfilt - (kRsTaps - 1);   // first input the wave needs (period 0)
 	const int base = (int)(ip - i_first);                               // window index of this lane's newest sample
-	float e[kRsTaps];
+	rs_v2f e2[kRsTaps / 2];                                             // taps 2 i, 2 i + 1
 #pragma unroll
-	for (int k = 0; k < kRsTaps; k++) {
-		const float2 bd = a.bank[j * kRsTaps + k];
-		e[k] = fmaf(frac, bd.y, bd.x);
+	for (int k = 0; k < kRsTaps; k += 2) {
+		const float2 b0 = a.bank[j * kRsTaps + k], b1 = a.bank[j * kRsTaps + k + 1];
+		e2[k / 2] = (rs_v2f){fmaf(frac, b0.y, b0.x), fmaf(frac, b1.y, b1.x)};
 	}
 	const float2 *__restrict__ y = a.y + (long long)sl * a.T;
 	float2 *__restrict__ out = a.out + (long long)sl * a.out_stride;
 	const long long m0 = (long long)blockIdx.z * kRsPeriods;
 
 	// window of period m: inputs i_first + m Q + [0, span)
-	float2 nx[NH];
-	auto fetch = [&](long long m) {
+	static_assert(kRsPeriods % D == 0, "the period loop runs in blocks of D");
+	float2 ring[D][NH];
+	auto fetch = [&](long long m, float2 (&nx)[NH]) {
 #pragma unroll
 		for (int h = 0; h < NH; h++) {
 			const int w = lane + 64 * h;
@@ -342,39 +372,55 @@ __global__ __launch_bounds__(64) void k_resamp(ResampArgs a, long long P, long l
 		pl_dq = P / a.planar_sps;
 		pl_dr = (int)(P % a.planar_sps);
 	}
-	fetch(m0);
-	for (int mm = 0; mm < kRsPeriods; mm++) {
-		const long long m = m0 + mm;
-		if (m * P >= a.n_out)
-			break;
+#pragma unroll
+	for (int d = 0; d < D; d++)
+		fetch(m0 + d, ring[d]);
+	for (int mm = 0; mm < kRsPeriods; mm += D) {
+		if ((m0 + mm) * P >= a.n_out)
+			return;
 		WSYNC();
 #pragma unroll
-		for (int h = 0; h < NH; h++)
-			if (lane + 64 * h < span)
-				xs[lane + 64 * h] = nx[h];
-		WSYNC();
-		if (mm + 1 < kRsPeriods)
-			fetch(m + 1);                       // next period's window travels during this one's arithmetic
-		float orr = 0.f, oi = 0.f;
+		for (int d = 0; d < D; d++)
 #pragma unroll
-		for (int k = 0; k < kRsTaps; k++) {
-			const float2 s = xs[base - k];
-			orr = fmaf(e[k], s.x, orr);
-			oi = fmaf(e[k], s.y, oi);
+			for (int h = 0; h < NH; h++)
+				if (lane + 64 * h < span)
+					xsb[d][lane + 64 * h] = ring[d][h];
+		WSYNC();
+		if (mm + D < kRsPeriods) {
+#pragma unroll
+			for (int d = 0; d < D; d++)
+				fetch(m0 + mm + D + d, ring[d]);    // the next block's windows travel during this block's arithmetic
 		}
-		const long long n = m * P + p;
-		if (live && n < a.n_out) {
-			if (EXT && a.planar_sps > 0)
-				a.out[(long long)pl_r * a.plane_stride + pl_q] = make_float2(orr, oi);
-			else
-				out[n] = make_float2(orr, oi);
+		rs_v2f res[D];
+#pragma unroll
+		for (int d = 0; d < D; d++) {
+			const float2 *xs = xsb[d];
+			// (tap order 0, 1, 2, ... as the scalar chains had it)
+			rs_v2f acc = {0.f, 0.f};
+#pragma unroll
+			for (int k = 0; k < kRsTaps; k += 2) {
+				const float2 s0 = xs[base - k], s1 = xs[base - k - 1];
+				rs_mac<false>(acc, e2[k / 2], (rs_v2f){s0.x, s0.y});
+				rs_mac<true>(acc, e2[k / 2], (rs_v2f){s1.x, s1.y});
+			}
+			res[d] = acc;
 		}
-		if constexpr (EXT) {
-			pl_q += pl_dq;
-			pl_r += pl_dr;
-			if (pl_r >= a.planar_sps && a.planar_sps > 0) {
-				pl_r -= a.planar_sps;
-				pl_q++;
+#pragma unroll
+		for (int d = 0; d < D; d++) {
+			const long long n = (m0 + mm + d) * P + p;
+			if (live && n < a.n_out) {
+				if (EXT && a.planar_sps > 0)
+					a.out[(long long)pl_r * a.plane_stride + pl_q] = make_float2(res[d].x, res[d].y);
+				else
+					out[n] = make_float2(res[d].x, res[d].y);
+			}
+			if constexpr (EXT) {
+				pl_q += pl_dq;
+				pl_r += pl_dr;
+				if (pl_r >= a.planar_sps && a.planar_sps > 0) {
+					pl_r -= a.planar_sps;
+					pl_q++;
+				}
 			}
 		}
 	}
@@ -468,8 +514,12 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 		return hipErrorInvalidValue;             // (the long bank is the direct mode's: neither option reaches it)
 	if (lng)
 		hipLaunchKernelGGL((k_resamp<kRsTapsLong, kRsWinLong>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
+	else if (ext && span <= kRsWinTight)
+		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinTight, true>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	else if (ext)
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinShort, true>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
+	else if (span <= kRsWinTight)
+		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinTight>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	else
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinShort>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	return hipGetLastError();
