@@ -68,7 +68,9 @@ template <bool ROT>
 __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 {
 	__shared__ float2 tile[64 * (kPfbTile + 1)];
+	__shared__ int slot_of[64];                  // output slot of every channel: the write-out loop asks for one per store
 	const int r = threadIdx.x;
+	slot_of[r] = a.slot[r];
 	const long long t0 = (long long)blockIdx.x * kPfbSteps;       // first instant of this wave (even)
 	const int NB = a.n_blocks;
 
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 		// write-out: 16 instants x 8 bytes = one 128-byte run per kept channel
 		for (int e = r; e < 64 * kPfbTile; e += 64) {
 			const int c = e / kPfbTile, u = e % kPfbTile;
-			const int sl = a.slot[c];
+			const int sl = slot_of[c];
 			const long long t = t0 + tt + u;
 			if (sl >= 0 && t < a.T)
 				a.y[(long long)sl * a.T + t] = tile[c * (kPfbTile + 1) + u];
