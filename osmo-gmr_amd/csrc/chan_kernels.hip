@@ -51,17 +51,17 @@ __device__ __forceinline__ float lane_xor(float v)
 	else return dppf<0xB1>(v);
 }
 
-// one decimation-in-frequency stage over the lanes: pairs (l, l ^ SPAN); the lane without the bit
-// keeps a + b, the other (a - b) * w, w = e^{-j 2 pi (l mod SPAN) / (2 SPAN)} (held in wr / wi)
+// one decimation-in-frequency stage over the lanes: pairs (l, l ^ SPAN); the lane without the bit keeps a + b, the other
+// (a - b) * w, w = e^{-j 2 pi (l mod SPAN) / (2 SPAN)}.  Without selects: every lane forms partner + sg * own (sg = +1 in
+// the lane without the bit, -1 in the other: exact, a product with +-1) and multiplies by (wr, wi), which is (1, 0) in the
+// lanes without the bit -- the same values as choosing between the two forms afterwards, down to the sign of a zero.
 template <int SPAN>
-__device__ __forceinline__ void dif_stage(float &re, float &im, bool hi, float wr, float wi)
+__device__ __forceinline__ void dif_stage(float &re, float &im, float sg, float wr, float wi)
 {
 	const float pr = lane_xor<SPAN>(re), pi = lane_xor<SPAN>(im);
-	const float sr = re + pr, si = im + pi;
-	const float dr = pr - re, di = pi - im;         // (a - b) seen from the hi lane: partner is a
-	const float tr = dr * wr - di * wi, ti = dr * wi + di * wr;
-	re = hi ? tr : sr;
-	im = hi ? ti : si;
+	const float dr = fmaf(re, sg, pr), di = fmaf(im, sg, pi);
+	re = dr * wr - di * wi;
+	im = dr * wi + di * wr;
 }
 
 template <bool ROT>
@@ -83,15 +83,15 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 		ho[q] = (q < NB && io >= 0 && io < a.ntaps) ? a.taps[io] : 0.0f;
 	}
 	// twiddles of the six stages and the channel this lane ends up holding
-	float wr[6], wi[6];
-	bool hb[6];
+	float wr[6], wi[6], hb[6];                   // (hb: -1 in the lanes that hold the second element of the stage's pairs, else +1)
 #pragma unroll
 	for (int s = 0; s < 6; s++) {
 		const int span = 32 >> s;
 		const float ang = -kPif * (float)(r & (span - 1)) / (float)span;
-		wr[s] = __cosf(ang);
-		wi[s] = __sinf(ang);
-		hb[s] = (r & span) != 0;
+		const bool hi = (r & span) != 0;
+		wr[s] = hi ? __cosf(ang) : 1.0f;
+		wi[s] = hi ? __sinf(ang) : 0.0f;
+		hb[s] = hi ? -1.0f : 1.0f;
 	}
 	const int chan = (int)(__brev((unsigned)r) >> 26);
 	const int slot = a.slot[chan];
