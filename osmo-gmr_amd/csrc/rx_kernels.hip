@@ -2638,30 +2638,32 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			// level-by-level walk performs and summed in its order, so the decisions are its decisions; the walk itself is
 			// scalar work on two ballots.  Nine levels = three evaluations, then the peak value at the point reached.
 			const int grp = lane >> 3, isub8 = lane & 7;
+			// (index checks and tap signs as in interp2 above: 0 <= i < w - 1 is the whole bound, one XOR sets the sign)
+			const int k08 = 3 * isub8 - 10;
+			const float kg0 = (float)k08, kg1 = (float)(k08 + 1), kg2 = (float)(k08 + 2);
+			const uint32_t sgn8 = (isub8 & 1) ? 0u : 0x80000000u;
+			const bool taps8 = isub8 != 7;
 			auto interp_pair = [&](float pos, float &se, float &sl) {
 				const float fl = floorf(pos);
 				const int ib = (int)fl;
 				const float f = pos - fl;
 				const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f); sin(pi (k - f)) = -(-1)^k sin(pi f)
-				int be = ib - 10, ee = ib + 11, bl = ib - 8, el = ib + 13;
-				if (be < 0) be = 0;
-				if (bl < 0) bl = 0;
-				if (ee >= w_p) ee = w_p - 1;
-				if (el >= w_p) el = w_p - 1;
+				const int i0 = ib + k08;
+				const float *cp = cr + i0;
+				// early sum over i0 + {0, 1, 2}, late sum two lags further up: five values, whether or not they lie in the array
+				const float c0 = cp[0], c1 = cp[1], c2 = cp[2], c3 = cp[3], c4 = cp[4];
+				const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn8);
+				const float x0 = kPif * (kg0 - f), x1 = kPif * (kg1 - f), x2 = kPif * (kg2 - f);
+				const float w0 = (x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
+				const float w1 = (x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
+				const float w2 = (x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
 				float ae = 0.f, al = 0.f;
-	#pragma unroll
-				for (int tt = 0; tt < 3; tt++) {
-					const int k = 3 * isub8 - 10 + tt;
-					const float sg = ((isub8 + tt) & 1) ? S : -S;
-					const float xx = kPif * ((float)k - f);
-					const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
-					const int ie = ib + k, il = ib + 2 + k;
-					const bool ve = k <= 10 && ie >= be && ie < ee;
-					const bool vl = k <= 10 && il >= bl && il < el;
-					const float ce = cr[ve ? ie : 0], cl = cr[vl ? il : 0];
-					ae += ve ? ce * wgt : 0.0f;
-					al += vl ? cl * wgt : 0.0f;
-				}
+				ae += (taps8 && (uint32_t)i0 < wlim) ? c0 * w0 : 0.0f;
+				al += (taps8 && (uint32_t)(i0 + 2) < wlim) ? c2 * w0 : 0.0f;
+				ae += (taps8 && (uint32_t)(i0 + 1) < wlim) ? c1 * w1 : 0.0f;
+				al += (taps8 && (uint32_t)(i0 + 3) < wlim) ? c3 * w1 : 0.0f;
+				ae += (taps8 && (uint32_t)(i0 + 2) < wlim) ? c2 * w2 : 0.0f;
+				al += (taps8 && (uint32_t)(i0 + 4) < wlim) ? c4 * w2 : 0.0f;
 				ae += row_xorf<1>(ae);
 				ae += row_xorf<2>(ae);
 				ae += row_xorf<4>(ae);
