@@ -1982,13 +1982,20 @@ struct LatPre {
 	uint32_t *vtab = nullptr;              // LDS: the decoder's per-step operand table (decode1_k5_12_lat), kLatTabBytes
 	uint32_t dc = 0;
 	uint4 sy0, sy1;
+	// (3) The pipelined loop (k_rx_chain, PART): the burst is cut where its feedback exists -- after the sync-symbol terms
+	// (pi4cxpsk.c:547-575: toa, freq_err) --, the FRONT half on one wave, the BACK half (soft bits, layer 1) on another a
+	// round later.  What crosses the cut: `cut`; the burst's raw window stays in LDS for the back half's kept samples.
+	struct Cut { int found, d, sid; float toa, ffe, psi, avr, avi; };
+	Cut *cut = nullptr;                    // LDS
+	float2 *win_w = nullptr;               // LDS, front half: where the window goes if the front had to fetch it itself
+	const float2 *win_r = nullptr;         // LDS, back half: the burst's raw window (lane l's samples l + 64 k as fetched)
 };
 
 // The position-only part of a fused-format burst's pass 1 (rx4_body does the same, operation for operation): window,
 // statistics, burst energy, normalised sync-chunk windows.
 template <int NPL, int SPS>
 __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int kind, int lane, float2 *__restrict__ hx,
-                                            float *__restrict__ hs)
+                                            float *__restrict__ hs, float2 *__restrict__ win = nullptr)
 {
 	const int sps = SPS ? SPS : a.sps;
 	const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
@@ -2010,6 +2017,12 @@ __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int k
 			const int sidx = lane + 64 * h;
 			sv[c][h] = sidx < wl ? src[sidx] : make_float2(0.f, 0.f);
 		}
+	}
+	if (win) {
+		// the whole raw window, as fetched (lane l's samples l + 64 k): the back half of the burst takes its kept samples here
+#pragma unroll
+		for (int k = 0; k < NPL; k++)
+			win[lane + 64 * k] = wv[k];
 	}
 	float avr, avi, inv;
 	window_stats<NPL, NFULL>(wv, in_len, lane, avr, avi, inv);
@@ -2055,8 +2068,11 @@ __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int k
 // samples of plane (offset + d) & 3 -- 15 lines of 128 bytes instead of every line of the window.
 // EBROW (GEN only): bytes between the four bursts' soft-bit rows in LDS.  432 holds any format; the kernel that decodes NT3
 // speech bursts right behind the demodulator (k_rx4g_tch3) packs its 212-byte rows at 216 to leave the decoder its tables.
+// PART (LAT only): 0 the whole burst; 1 its front half -- pass 1, timing, sync-symbol terms; rv / toa / freq_err / energy to
+// `io`, the rest of what the back half needs to pre->cut --; 2 its back half -- pass 2 out of pre->win_r, layer 1; l2 / crc /
+// conv to `io` (see LatPre (3))
 template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false, bool EN = true, bool PL = false,
-          int EBROW = 432>
+          int EBROW = 432, int PART = 0>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
                                          unsigned char *__restrict__ lds_raw, int lane, LatPre<NPL, SPS> *pre = nullptr)
 {
@@ -2067,6 +2083,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	constexpr bool SMALL = GEN && NPL == 8;
 	static_assert(!FAC || SMALL, "the two-sequence variant builds on the small generic one");
 	static_assert(!PL || (SPS == 4 && !GEN && !LAT && !EN), "the planar layout exists for the fused batch kernel at sps 4");
+	static_assert(PART == 0 || LAT, "only the receive loop's burst is cut in two");
 	const int cwh = FAC ? cw / 2 : cw;                // lags per correlation array
 	// The next burst's window in flight during this burst's correlation costs 32 registers at the body's peak.  The fused
 	// kernel does without: 78 instead of 87 VGPRs is the step from five to six waves per SIMD, and the sixth wave hides more
@@ -2102,6 +2119,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	float2 wv_own[NPL];
 	GMR1_STAMP(0);
 	// =========================== pass 1: correlation magnitudes ===========================
+	if constexpr (PART != 2) {
 	if constexpr (SMALL) {
 		// The short formats (<= 512 samples, one sync chunk of <= 16 symbols, <= 64 lags) take pass 1 with ONE BURST PER ROW
 		// as well: lane `col` of a row reads samples col, col + 16, ... of the row's burst (16 lanes x 8 B = one 128-byte
@@ -2344,6 +2362,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				io.energy[g] = pre->h_stat[3];
 		} else {
 		window_stats<NPL, NFULL>(wv, in_len, sl, avr, avi, inv, PL ? 16 * (lane & 3) + (lane >> 2) : -1, PL ? 16 : 1);
+		if constexpr (LAT && PART == 1) {
+			if (pre->win_w) {
+#pragma unroll
+				for (int k = 0; k < NPL; k++)
+					pre->win_w[lane + 64 * k] = wv[k];
+			}
+		}
 		if ((LAT || !PREFETCH_NEXT) && EN && io.energy) {
 			// burst_energy() while the window is still in registers
 			const float e = window_energy_regs<NPL>(wv, in_len, lane);
@@ -2437,6 +2462,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	WSYNC();
 	GMR1_STAMP(2);
 	if (a.dbg_stop == 2) return;
+	}
 
 	// per-row (lane-resident) burst parameters: looked up here, not before pass 1, which has no register to spare for them
 	const int kind_r = (!GEN && row_live) ? (io.kind[g_row] ? 1 : 0) : 0;
@@ -2460,7 +2486,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const bool w3 = !LAT && __ballot(win != 3) == 0;   // (wave-uniform) every row's energy window is three lags
 	float toa_r = 0.f, p_pwr = 0.f;                    // pi4cxpsk.c:227-237: the best sequence so far
 	int sid_r = -1;
-	for (int sq = 0; sq < (FAC ? 2 : 1); sq++) {
+	if constexpr (PART == 2) {
+		toa_r = pre->cut->toa;
+		sid_r = pre->cut->sid;
+		avr_r = pre->cut->avr;
+		avi_r = pre->cut->avi;
+	}
+	for (int sq = 0; sq < (PART == 2 ? 0 : (FAC ? 2 : 1)); sq++) {
 		if (FAC)
 			cr = L.corr + row * cw + sq * cwh;
 		GMR1_STAMP(10);
@@ -2748,8 +2780,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 	}
 	const bool found_r = sid_r >= 0;
-	GMR1_STAMP(3);
-	if (a.dbg_stop == 3) return;
+	if constexpr (PART != 2) {
+		GMR1_STAMP(3);
+		if (a.dbg_stop == 3) return;
+	}
 	const int d_r = (int)roundf(toa_r);
 
 	// KEEP: samples d, d + 4, ... of burst 3's window are registers k = 0..15 of the lanes with lane = d (mod 4) (lane l
@@ -2812,6 +2846,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (i < blen && j >= 0 && j < in_len) {
 				if (KEEP && from_exch)
 					o.x[r] = exch[i];
+				else if (LAT && PART == 2)
+					o.x[r] = pre->win_r[j];
 				else
 					o.x[r] = PL ? in[i] : in[j];
 				o.ok |= 1 << r;
@@ -2828,7 +2864,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const int nch_r = F::nch(bt_r);
 	const int tl_r = F::tl(bt_r, kind_r);
 	float ffe_r = 0.f, psi_r = 0.f;
-	{
+	if constexpr (PART == 2) {
+		ffe_r = pre->cut->ffe;
+		psi_r = pre->cut->psi;
+		fetch(0, first);
+	} else {
 		// lane col holds sync symbols n = col and n = col + 16 (< tl <= 32); their samples are asked for first (loads
 		// come back in order), then pass 2's
 		float2 t0[NSH], xr[NSH];
@@ -2867,7 +2907,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 		if constexpr (LAT) {
-			fetch(0, first);            // the one burst's kept samples travel during the whole sync-term phase
+			if constexpr (PART == 0)
+				fetch(0, first);        // the one burst's kept samples travel during the whole sync-term phase
 		} else {
 			fetch(3, first);
 			fetch(2, second);
@@ -2928,6 +2969,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 		psi_r = atan2_fast(row_sum(ti), row_sum(tr));
 	}
+	if constexpr (PART != 2) {
 	GMR1_STAMP(4);
 	if (a.dbg_stop == 5) return;
 
@@ -2938,6 +2980,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		if (io.sync_id) io.sync_id[g_row] = found_r ? sid_r : -1;
 		if (io.toa) io.toa[g_row] = found_r ? toa_r : 0.f;
 		if (io.freq_err) io.freq_err[g_row] = found_r ? ffe_r : 0.f;
+	}
+	}
+	if constexpr (PART == 1) {
+		if (lane == 0)
+			*pre->cut = {found_r ? 1 : 0, d_r, sid_r, toa_r, ffe_r, psi_r, avr_r, avi_r};
+		return;
 	}
 
 	// =========================== pass 2: soft symbols / soft bits ===========================
@@ -3488,6 +3536,403 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 		n_ccch += n_c;
 		WSYNC();
 	}
+	if (lane == 0) {
+		la.n_rounds[chain] = round;
+		la.n_ccch[chain] = n_ccch;
+		la.n_frames[chain] = n_frames;
+		la.state[chain] = st;
+		la.fin[chain] = finished ? 1 : 0;
+		la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = min(n_ccch, la.c_stride);
+	}
+}
+
+// ---------------------------------------------------------------------------
+// The same walk, SOFTWARE-PIPELINED ACROSS ROUNDS (4 ... 8 samples per symbol).  The reference applies a BCCH burst's feedback
+// only `if (!crc)` (gmr1_rx.c:782-791): align += round(toa) - e_toa, freq_err += freq_err, then bcch_tdma_align (:194-233).
+// toa and freq_err exist once the demodulator's front half is through (sync search, timing, sync-symbol terms,
+// pi4cxpsk.c:547-575); the back half (soft bits :577-600, Viterbi and CRC bcch.c:83-103) contributes a binary verdict and
+// the SI1 fields, which repeat once a chain is aligned.  So a work-group of three waves on three SIMDs:
+//
+//   F (wave 0)  the FRONT half of round r's burst, then the feedback AS IF the CRC will pass and SI1 will move nothing,
+//               the frames up to the next BCCH burst listed from that assumed state, and straight on to round r + 1;
+//   B (wave 1)  the BACK half of round r - 1's burst meanwhile, out of the burst's window in LDS; then the real feedback
+//               (rx_loop_bcch_result) on the state F started from -- if that is not bit for bit the state F assumed, the
+//               verdict is SQUASH and carries the true state;
+//   H (wave 2)  fetches, a round ahead, the window of round r + 1's burst at the place the schedule predicts (statistics,
+//               energy, normalised sync-chunk windows as before -- and now the whole raw window into LDS, which is where
+//               the back half takes its 234 kept samples from: no phase of a round goes back to global memory).
+//
+// One work-group barrier per round ("tick").  A verdict reaches F two barriers after the hand-over, i.e. when it has run ONE
+// front half on the assumption: on SQUASH that half and everything listed from the assumed state are dropped (the CCCH list
+// and frame-log entries are overwritten, the counters restored from a checkpoint), F restarts from the true state and B
+// skips the stale hand-over.  The same float operations run on the same inputs as in the serial walk, so every record is
+// bit-identical to it; a chain whose every burst fails runs at the serial walk's speed.
+// Buffers H fills are indexed by tick mod 3 (H writes slot t, F reads t - 1, B reads the window of t - 2).
+// ---------------------------------------------------------------------------
+struct LoopHand {                  // F -> B, one per tick parity
+	RxLoopState pre;               // the chain as the burst's feedback finds it (this burst's energy already in)
+	RxLoopState spec;              // ... and as F assumed it comes out
+	int valid, round, e_toa, win;
+	float toa, ffe, fsh;
+	uint64_t off;
+#ifdef GMR1_HIP_PROFILE
+	unsigned long long *stamp;
+#endif
+};
+enum { kVdNone = 0, kVdOk = 1, kVdSquash = 2 };
+
+template <int NPL, int SPS, bool ACC = false>
+__global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body, int slice,
+                                                       int slice_rounds)
+{
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	const int stage_al = (stage_samples + 15) & ~15;
+	constexpr int kWin = NPL * 64;                     // samples of a window buffer
+	// dynamic LDS: [F's body | B's body | 3 staged sync-chunk windows | B's operand table | 3 raw windows]
+	unsigned char *const body_f = lds_raw, *const body_b = lds_raw + lds_body;
+	float2 *const hx0 = reinterpret_cast<float2 *>(lds_raw + 2 * (size_t)lds_body);
+	uint32_t *const vtab = reinterpret_cast<uint32_t *>(hx0 + 3 * stage_al);
+	float2 *const win0 = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(vtab) + kLatTabBytes);
+	__shared__ uint64_t h_off[3], s_pred[2];
+	__shared__ int h_kind[3], s_go[2];               // s_go, s_pred: F -> B, H, by tick parity
+	__shared__ float h_stat[3][4];
+	__shared__ LoopHand s_hand[2];
+	__shared__ typename LatPre<NPL, SPS>::Cut s_cut[2];
+	__shared__ int s_vd[2];                    // B -> F, by the parity of the tick B wrote it in
+	__shared__ RxLoopState s_true[2];
+	// F's burst operands and results
+	__shared__ uint64_t s_off[1];
+	__shared__ float s_fs[1];
+	__shared__ uint8_t s_kind[1];
+	__shared__ RxLoopItem s_items[kLoopPerRound];
+	__shared__ int32_t s_rv[1];
+	__shared__ float s_toa[1], s_fe[1], s_en[1];
+	// B's results
+	__shared__ __align__(8) uint8_t b_l2[24];
+	__shared__ int32_t b_crc[1], b_conv[1], b_rv[1];
+	__shared__ uint8_t b_kind[1];
+	// LDS copies of the constant tables every burst reads (see LatPre)
+	__shared__ __align__(16) uint16_t s_lut[1024];
+	__shared__ uint32_t s_steps[2 * kSteps12];
+	__shared__ uint32_t s_cost_a[512], s_cost_b[512];
+
+	const int wave = (int)threadIdx.x >> 6;
+	const int chain = blockIdx.x;
+	const int lane = (int)threadIdx.x & 63;
+	const int sps = a.sps;
+	if (threadIdx.x < 3)
+		h_off[threadIdx.x] = ~0ull;
+	if (threadIdx.x == 0) {
+		s_hand[0].valid = s_hand[1].valid = 0;
+		s_vd[0] = s_vd[1] = kVdNone;
+		b_kind[0] = 0;
+	}
+	const int round0 = slice ? la.n_rounds[chain] : 0;
+	const int round_end = min(round0 + slice_rounds, la.max_rounds);
+	if (slice == 0 && threadIdx.x == 0)
+		la.slice_end[chain] = 0;
+	if (slice && la.fin[chain]) {
+		if (threadIdx.x == 0)
+			la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = la.slice_end[(size_t)slice * gridDim.x + chain];
+		return;
+	}
+	__builtin_amdgcn_s_setprio(3);
+	{
+		const CostTable &ctab = ACC ? c_cost_acc : c_cost;
+		for (int i = (int)threadIdx.x; i < 1024; i += 192)
+			s_lut[i] = g_sb_lut.v[i];
+		for (int i = (int)threadIdx.x; i < 2 * kSteps12; i += 192)
+			s_steps[i] = c_steps.w[i / kSteps12][i % kSteps12];
+		for (int i = (int)threadIdx.x; i < 512; i += 192) {
+			s_cost_a[i] = ctab.a[i];
+			s_cost_b[i] = ctab.b[i];
+		}
+	}
+	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
+
+	// ------------------------------------------------------------------ H: the next burst's window
+	if (wave == 2) {
+		for (int t = 0;; t++) {
+			__syncthreads();
+			if (!s_go[t & 1])
+				break;
+			const uint64_t pred = s_pred[t & 1];
+			const int slot = t % 3;
+			if (pred != ~0ull)
+				lat_prepare<NPL, SPS>(a, pred, 0, lane, hx0 + slot * stage_al, h_stat[slot], win0 + slot * kWin);
+			if (lane == 0) {
+				h_off[slot] = pred;
+				h_kind[slot] = 0;
+			}
+		}
+		return;
+	}
+
+	// ------------------------------------------------------------------ B: the back half, a round behind
+	if (wave == 1) {
+		LatPre<NPL, SPS> pre;
+		pre.lut = reinterpret_cast<const unsigned char *>(s_lut);
+		pre.steps = s_steps;
+		pre.cost_a = s_cost_a;
+		pre.cost_b = s_cost_b;
+		pre.vtab = vtab;
+		pre.dc = c_dec.v[lane & 15];
+		pre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
+		pre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
+		bool squashed = false;                     // the last verdict: the hand-over that follows it is stale
+		for (int t = 0;; t++) {
+			__syncthreads();
+			if (!s_go[t & 1])
+				break;
+			if (t == 0)
+				continue;
+			const LoopHand &h = s_hand[(t - 1) & 1];
+			const bool work = h.valid != 0 && !squashed;
+			squashed = false;
+			if (!work) {
+				if (lane == 0)
+					s_vd[t & 1] = kVdNone;
+				continue;
+			}
+			pre.cut = &s_cut[(t - 1) & 1];
+			pre.win_r = win0 + h.win * kWin;
+			const RxIo io = {
+#ifdef GMR1_HIP_PROFILE
+			                 h.stamp,
+#endif
+			                 &h.off, b_kind, &h.fsh, b_l2, b_crc, b_conv, b_rv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+			rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 2>(a, io, stage_samples, cw, 0, 1, body_b, lane, &pre);
+			WSYNC();
+			// the feedback as the reference applies it (rx_bcch, gmr1_rx.c:782-791), on the state F started from
+			RxLoopState st = h.pre;
+			const int emit = rx_loop_bcch_result(st, sps, 0, b_crc[0], h.toa, h.ffe, b_l2, h.e_toa);
+			const RxLoopState &sp = h.spec;
+			const bool same = st.align == sp.align && __float_as_uint(st.freq_err) == __float_as_uint(sp.freq_err) &&
+			                  st.fn == sp.fn && st.delay == sp.delay && st.stn == sp.stn;
+			{
+				// the burst's part of the round's log entry (F wrote c_first, c_n, minen, b_frame)
+				uint32_t *d = reinterpret_cast<uint32_t *>(rlog + h.round);
+				const uint32_t *l2w = reinterpret_cast<const uint32_t *>(b_l2);
+				uint32_t v = 0;
+				switch (lane) {
+				case 3: v = (uint32_t)emit; break;
+				case 4: v = (uint32_t)st.fn; break;
+				case 5: v = (uint32_t)st.stn; break;
+				case 6: v = (uint32_t)b_conv[0]; break;
+				default: v = (lane >= 8 && lane < 14) ? l2w[lane - 8] : 0u; break;
+				}
+				if ((lane >= 3 && lane <= 6) || (lane >= 8 && lane < 14))
+					d[lane] = v;
+			}
+			if (lane == 0) {
+				s_true[t & 1] = st;
+				s_vd[t & 1] = same ? kVdOk : kVdSquash;
+			}
+			squashed = !same;
+		}
+		return;
+	}
+
+	// ------------------------------------------------------------------ F: the front half and the walk
+	RxLoopState st = la.state[chain];          // every lane computes the same
+	const uint64_t lim = st.base + (uint64_t)st.len;
+	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
+	const size_t c_base = (size_t)chain * la.c_stride;
+	int n_frames = slice ? la.n_frames[chain] : 0, n_ccch = slice ? (la.slice_end[(size_t)slice * gridDim.x + chain] + 3) & ~3 : 0;
+	auto on_frame = [&](const RxLoopState &x) {
+		if (flog && lane == 0 && n_frames < la.flog_stride)
+			flog[n_frames] = {x.align, x.freq_err, x.fn};
+		n_frames++;
+	};
+	LatPre<NPL, SPS> pre;
+	int round = round0;
+	// the round's bursts from the chain's position: rx_loop_build_round frame after frame, for the usual case (the next
+	// sixteen frames all lie inside the capture) with one frame per lane.  -> s_items, the number of items
+	int frames_at_round = 0;
+	float minen = 0.f;
+	auto list_round = [&]() -> int {
+		frames_at_round = n_frames;
+		minen = st.bcch_energy / 2.0f;                          // the gate level the round starts with
+		int n;
+		const int frame_len = sps * 24 * 39;
+		const int j = lane & 15;
+		const int fn_j = st.fn + j, align_j = st.align + j * frame_len;
+		const bool inside = !st.done && st.align + 17 * frame_len <= st.len;   // frames 0..15 are all reached
+		const int m = (fn_j - st.delay) & 7;
+		const int tn_off = sps * st.stn * 39;
+		const int b_b = align_j + tn_off - 10 * sps, b_c = align_j + tn_off - 5 * sps;   // burst_map, e_toa = win / 2
+		const bool ok_b = b_b >= 0 && b_b + 234 * sps + 20 * sps <= st.len;
+		const bool ok_c = b_c >= 0 && b_c + 234 * sps + 10 * sps <= st.len;
+		const uint32_t mb = (uint32_t)__ballot(lane < 16 && m == 2 && ok_b) & 0xffffu;
+		const uint32_t mc = (uint32_t)__ballot(lane < 16 && m != 0 && m != 2 && ok_c) & 0xffffu;
+		const int jb = mb ? __builtin_ctz(mb) : 16;             // the first BCCH burst
+		const uint32_t before = mc & ((1u << jb) - 1u);
+		WSYNC();
+		if (inside && mb && __popc(before) < kLoopPerRound - 1) {
+			// CCCH bursts of frames 0 .. jb-1, then the BCCH burst of frame jb (which stays the current frame)
+			const uint32_t items = before | (1u << jb);
+			if (lane < 16 && ((items >> j) & 1u)) {
+				const int idx = __popc(items & ((1u << j) - 1u));
+				const bool is_b = j == jb;
+				s_items[idx] = {is_b ? b_b : b_c, is_b ? 1 : 0, fn_j, st.stn, is_b ? 10 * sps : 5 * sps, j};
+			}
+			if (flog && lane < jb && n_frames + lane < la.flog_stride)
+				flog[n_frames + lane] = {align_j, st.freq_err, fn_j};
+			n_frames += jb;
+			st.fn += jb;
+			st.align += jb * frame_len;
+			n = __popc(items);
+		} else {
+			n = rx_loop_build_round(st, sps, s_items, on_frame);
+		}
+		WSYNC();
+		return n;
+	};
+	// checkpoints of the rounds handed to B, by tick parity: what a SQUASH restores
+	int cp_round[2] = {0, 0}, cp_frames[2] = {0, 0}, cp_ccch[2] = {0, 0};
+	bool age1 = false, age2 = false;           // a hand-over written one tick ago (B is at it) / two ticks ago (verdict due)
+	int n = round < round_end ? list_round() : 0;
+	bool finished = false;
+	int t = 0;
+	for (;; t++) {
+		if (lane == 0) {
+			// where the burst of the round AFTER the one about to run will most likely sit: eight frames on
+			// (a round's BCCH burst is always its last item)
+			uint64_t pred = ~0ull;
+			if (n > 0 && s_items[n - 1].is_bcch != 0) {
+				pred = st.base + (uint64_t)s_items[n - 1].begin + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
+				if (pred + (uint64_t)a.in_len[0] > lim)
+					pred = ~0ull;
+			}
+			s_pred[t & 1] = pred;
+			s_go[t & 1] = 1;
+		}
+		__syncthreads();
+		// ---- the verdict on the hand-over of two ticks ago (B worked on it during the last tick)
+		if (age2 && s_vd[(t - 1) & 1] == kVdSquash) {
+			// the front half just run and everything listed since started from a state that never came to be: back to the
+			// checkpoint of the round B judged, its true feedback, and on from there within this tick (B skips the stale
+			// hand-over of the last tick by itself; what H has prepared is checked against the burst's place as always)
+			const int p = t & 1;
+			st = s_true[(t - 1) & 1];
+			n_frames = cp_frames[p];
+			n_ccch = cp_ccch[p];
+			round = cp_round[p] + 1;
+			on_frame(st);
+			rx_loop_advance(st, sps);
+			age1 = false;
+			n = round < round_end ? list_round() : 0;
+		}
+		age2 = age1;
+		age1 = false;
+		if (n == 0 || round >= round_end) {
+			// nothing (more) to start in this launch: wait for what B still holds
+			if (!age2) {
+				finished = n == 0 && round < round_end;
+				break;
+			}
+			if (lane == 0)
+				s_hand[t & 1].valid = 0;
+			continue;
+		}
+		const bool has_b = s_items[n - 1].is_bcch != 0;
+		const int n_c = has_b ? n - 1 : n;
+		// the CCCH bursts: listed for the batch that follows
+		if (lane < n_c && n_ccch + lane < la.c_stride) {
+			const RxLoopItem it = s_items[lane];
+			const size_t k = c_base + (size_t)(n_ccch + lane);
+			la.c_off[k] = st.base + (uint64_t)it.begin;
+			la.c_fs[k] = -st.freq_err;
+			la.c_kind[k] = 1;
+			la.c_meta[k] = {it.fn, it.tn, frames_at_round + it.frames_before};
+		}
+		int b_fn = 0, b_tn = 0, b_frame = 0;
+		bool handed = false;
+		if (has_b) {
+			const RxLoopItem it = s_items[n - 1];
+			if (lane == 0) {
+				s_off[0] = st.base + (uint64_t)it.begin;
+				s_fs[0] = -st.freq_err;
+				s_kind[0] = 0;
+			}
+			WSYNC();
+			const int slot = (t + 2) % 3;                // what H prepared during the last tick
+			pre.h_off = &h_off[slot];
+			pre.h_kind = &h_kind[slot];
+			pre.h_stat = h_stat[slot];
+			pre.h_x = hx0 + slot * stage_al;
+			pre.win_w = win0 + slot * kWin;
+			pre.cut = &s_cut[t & 1];
+#ifdef GMR1_HIP_PROFILE
+			unsigned long long *const stamp = (chain == 0 && round == kStampRound) ? g_stamp : nullptr;
+#endif
+			const RxIo io = {
+#ifdef GMR1_HIP_PROFILE
+			                 stamp,
+#endif
+			                 s_off, s_kind, s_fs, nullptr, nullptr, nullptr, s_rv, nullptr, s_toa, s_fe, s_en, nullptr, nullptr};
+			rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 1>(a, io, stage_samples, cw, 0, 1, body_f, lane, &pre);
+			WSYNC();
+			b_frame = frames_at_round + it.frames_before;
+			if (!s_rv[0]) {
+				// found: the feedback as if the CRC passes and SI1 moves nothing -- B will tell (gmr1_rx.c:782-795)
+				st.bcch_energy = s_en[0];
+				const RxLoopState before = st;
+				st.align += (int)roundf(s_toa[0]) - it.e_toa;
+				st.freq_err += s_fe[0];
+				if (lane == 0) {
+					LoopHand &h = s_hand[t & 1];
+					h.pre = before;
+					h.spec = st;
+					h.round = round;
+					h.e_toa = it.e_toa;
+					h.win = slot;
+					h.toa = s_toa[0];
+					h.ffe = s_fe[0];
+					h.fsh = s_fs[0];
+					h.off = s_off[0];
+#ifdef GMR1_HIP_PROFILE
+					h.stamp = stamp;
+#endif
+					h.valid = 1;
+				}
+				cp_round[t & 1] = round;
+				cp_frames[t & 1] = n_frames;
+				cp_ccch[t & 1] = n_ccch + n_c;
+				handed = true;
+			}
+			b_fn = st.fn;
+			b_tn = st.stn;
+			on_frame(st);                                        // rx_tch3 of this frame sees the updated state
+			rx_loop_advance(st, sps);
+		}
+		if (!handed && lane == 0)
+			s_hand[t & 1].valid = 0;
+		{
+			// the round's log entry, 14 words: all of it for a round without a burst that was found, else the walk's part
+			uint32_t *d = reinterpret_cast<uint32_t *>(rlog + round);
+			uint32_t v = 0;
+			switch (lane) {
+			case 0: v = (uint32_t)n_ccch; break;
+			case 1: v = (uint32_t)n_c; break;
+			case 2: v = __float_as_uint(minen); break;
+			case 4: v = (uint32_t)b_fn; break;
+			case 5: v = (uint32_t)b_tn; break;
+			case 7: v = (uint32_t)b_frame; break;
+			default: v = 0u; break;
+			}
+			if (lane < 14 && (!handed || lane < 3 || lane == 7))
+				d[lane] = v;
+		}
+		n_ccch += n_c;
+		round++;
+		age1 = handed;
+		n = round < round_end ? list_round() : 0;
+	}
+	t++;                                        // one more barrier: B and H leave
+	if (lane == 0)
+		s_go[t & 1] = 0;
+	__syncthreads();
 	if (lane == 0) {
 		la.n_rounds[chain] = round;
 		la.n_ccch[chain] = n_ccch;
@@ -4064,13 +4509,41 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	const dim3 grid((unsigned)n_chains), block(128);
 	// the helper wave's two staged windows, then the latency decoder's operand table
 	const size_t lds_h = one ? 0 : 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
+	// the pipelined walk (k_rx_chain_pipe): two bodies, three staged windows, the operand table, three raw windows
+	const int npl = a.in_len[0] <= 1024 ? 16 : 32;
+	const size_t lds_p = one ? 0 : 2 * lds + 3 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes +
+	                               3 * (size_t)npl * 64 * sizeof(float2);
+	static const bool serial = profile_env("GMR1_HIP_LOOP_SERIAL") != nullptr;     // (profiling build: the walk of round 4, for A/B)
 	hipError_t e;
+	if (!one && !serial) {
+		// more dynamic LDS than the default limit of a work-group: say so once per kernel
+		static std::mutex mu;
+		static bool told[4][2] = {};
+		const int ki = (npl == 32 ? 2 : 0) + (a.sps == 4 ? 0 : 1);
+		std::lock_guard<std::mutex> lk(mu);
+		if (!told[ki][a.conv_acc ? 1 : 0]) {
+			const void *fn = nullptr;
+#define GMR1_PIPE_FN(NPL, SPS) (a.conv_acc ? (const void *)k_rx_chain_pipe<NPL, SPS, true> : (const void *)k_rx_chain_pipe<NPL, SPS, false>)
+			fn = npl == 16 ? (a.sps == 4 ? GMR1_PIPE_FN(16, 4) : GMR1_PIPE_FN(16, 0)) : (a.sps == 4 ? GMR1_PIPE_FN(32, 4) : GMR1_PIPE_FN(32, 0));
+#undef GMR1_PIPE_FN
+			if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p)) != hipSuccess)
+				return e;
+			told[ki][a.conv_acc ? 1 : 0] = true;
+		}
+	}
 	// (the counters of the walk -- rounds, CCCH list lengths, frames, finished flags, slice ends -- start at zero: the first
 	// slice's k_rx_chain takes them as zero and writes them, no launch of their own)
 	const int slice_rounds = (la.max_rounds + kLoopSlices - 1) / kLoopSlices;
 #define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                \
 	do {                                                                                                         \
-		if (a.conv_acc)                                                                                          \
+		if (!serial) {                                                                                           \
+			if (a.conv_acc)                                                                                      \
+				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, true>), grid, dim3(192), lds_p, stream, a, la, a.stage_samples, cw, \
+				                   (int)lds, sl, slice_rounds);                                                  \
+			else                                                                                                 \
+				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, false>), grid, dim3(192), lds_p, stream, a, la, a.stage_samples, cw, \
+				                   (int)lds, sl, slice_rounds);                                                  \
+		} else if (a.conv_acc)                                                                                   \
 			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds, \
 			                   sl, slice_rounds);                                                                \
 		else                                                                                                     \
