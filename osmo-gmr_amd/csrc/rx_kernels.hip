@@ -1982,9 +1982,9 @@ struct LatPre {
 	uint32_t *vtab = nullptr;              // LDS: the decoder's per-step operand table (decode1_k5_12_lat), kLatTabBytes
 	uint32_t dc = 0;
 	uint4 sy0, sy1;
-	// (3) The pipelined loop (k_rx_chain, PART): the burst is cut where its feedback exists -- after the sync-symbol terms
-	// (pi4cxpsk.c:547-575: toa, freq_err) --, the FRONT half on one wave, the BACK half (soft bits, layer 1) on another a
-	// round later.  What crosses the cut: `cut`; the burst's raw window stays in LDS for the back half's kept samples.
+	// (3) The pipelined loop (k_rx_chain_pipe, PART): the burst is cut where its feedback exists -- after the sync-symbol
+	// terms (pi4cxpsk.c:547-575: toa, freq_err) --, the FRONT on one wave, the rest (soft bits, layer 1) on others, rounds
+	// later.  What crosses the cut: `cut`; the burst's raw window stays in LDS for the kept samples of pass 2.
 	struct Cut { int found, d, sid; float toa, ffe, psi, avr, avi; };
 	Cut *cut = nullptr;                    // LDS
 	float2 *win_w = nullptr;               // LDS, front half: where the window goes if the front had to fetch it itself
@@ -2068,9 +2068,9 @@ __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int k
 // samples of plane (offset + d) & 3 -- 15 lines of 128 bytes instead of every line of the window.
 // EBROW (GEN only): bytes between the four bursts' soft-bit rows in LDS.  432 holds any format; the kernel that decodes NT3
 // speech bursts right behind the demodulator (k_rx4g_tch3) packs its 212-byte rows at 216 to leave the decoder its tables.
-// PART (LAT only): 0 the whole burst; 1 its front half -- pass 1, timing, sync-symbol terms; rv / toa / freq_err / energy to
-// `io`, the rest of what the back half needs to pre->cut --; 2 its back half -- pass 2 out of pre->win_r, layer 1; l2 / crc /
-// conv to `io` (see LatPre (3))
+// PART (LAT only): 0 the whole burst; 1 its front -- pass 1, timing, sync-symbol terms; rv / toa / freq_err / energy to
+// `io`, the rest of what the middle needs to pre->cut --; 2 its middle -- pass 2 out of pre->win_r, then the decoder's
+// operand table into pre->vtab; the decoder itself is the caller's third stage (see LatPre (3))
 template <int NPL, int SPS, bool LAT = false, bool GEN = false, bool FAC = false, bool ACC = false, bool EN = true, bool PL = false,
           int EBROW = 432, int PART = 0>
 __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int stage_samples, int cw, int g0, int n_end,
@@ -2117,7 +2117,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	constexpr bool KEEP = !GEN && !LAT && !PL && !EN && SPS == 4 && NPL == 16;
 	const bool keep3 = KEEP && g0 + 3 < n_end;
 	float2 wv_own[NPL];
-	GMR1_STAMP(0);
+	if constexpr (PART == 2)
+		GMR1_STAMP(14);
+	else
+		GMR1_STAMP(0);
 	// =========================== pass 1: correlation magnitudes ===========================
 	if constexpr (PART != 2) {
 	if constexpr (SMALL) {
@@ -3133,6 +3136,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	GMR1_STAMP(6);
 	if (a.dbg_stop == 7)
 		return;
+	if constexpr (PART == 2)
+		return;                                     // (the decoder runs on another wave, a round later: k_rx_chain_pipe)
 	uint32_t syn, fae;
 	if constexpr (LAT)
 		decode1_k5_12_lat<ACC>(pre->vtab, L.surv, L.ubits, lane, syn, fae, &dpre);
@@ -3549,27 +3554,28 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 // ---------------------------------------------------------------------------
 // The same walk, SOFTWARE-PIPELINED ACROSS ROUNDS (4 ... 8 samples per symbol).  The reference applies a BCCH burst's feedback
 // only `if (!crc)` (gmr1_rx.c:782-791): align += round(toa) - e_toa, freq_err += freq_err, then bcch_tdma_align (:194-233).
-// toa and freq_err exist once the demodulator's front half is through (sync search, timing, sync-symbol terms,
-// pi4cxpsk.c:547-575); the back half (soft bits :577-600, Viterbi and CRC bcch.c:83-103) contributes a binary verdict and
-// the SI1 fields, which repeat once a chain is aligned.  So a work-group of three waves on three SIMDs:
+// toa and freq_err exist once the demodulator's front is through (sync search, timing, sync-symbol terms,
+// pi4cxpsk.c:547-575); the rest of the burst (soft bits :577-600, Viterbi and CRC bcch.c:83-103) contributes a binary verdict
+// and the SI1 fields, which repeat once a chain is aligned.  So a work-group of three waves on three SIMDs, each a stage:
 //
-//   F (wave 0)  the FRONT half of round r's burst, then the feedback AS IF the CRC will pass and SI1 will move nothing,
+//   F (wave 0)  tick t: the FRONT of round r's burst, then the feedback AS IF the CRC will pass and SI1 will move nothing,
 //               the frames up to the next BCCH burst listed from that assumed state, and straight on to round r + 1;
-//   B (wave 1)  the BACK half of round r - 1's burst meanwhile, out of the burst's window in LDS; then the real feedback
-//               (rx_loop_bcch_result) on the state F started from -- if that is not bit for bit the state F assumed, the
-//               verdict is SQUASH and carries the true state;
-//   H (wave 2)  fetches, a round ahead, the window of round r + 1's burst at the place the schedule predicts (statistics,
-//               energy, normalised sync-chunk windows as before -- and now the whole raw window into LDS, which is where
-//               the back half takes its 234 kept samples from: no phase of a round goes back to global memory).
+//   P (wave 2)  tick t + 1: pass 2 of that burst out of its window in LDS and the decoder's operand table (branch metrics);
+//               then the window of the burst F will need at tick t + 2, fetched where the schedule predicts it
+//               (statistics, energy, normalised sync-chunk windows as before -- and the whole raw window into LDS: no
+//               phase of a round goes back to global memory);
+//   V (wave 1)  tick t + 2: Viterbi, survivor walk, CRC; then the real feedback (rx_loop_bcch_result) on the state F started
+//               from -- if that is not bit for bit the state F assumed, the verdict is SQUASH and carries the true state.
 //
-// One work-group barrier per round ("tick").  A verdict reaches F two barriers after the hand-over, i.e. when it has run ONE
-// front half on the assumption: on SQUASH that half and everything listed from the assumed state are dropped (the CCCH list
-// and frame-log entries are overwritten, the counters restored from a checkpoint), F restarts from the true state and B
-// skips the stale hand-over.  The same float operations run on the same inputs as in the serial walk, so every record is
-// bit-identical to it; a chain whose every burst fails runs at the serial walk's speed.
-// Buffers H fills are indexed by tick mod 3 (H writes slot t, F reads t - 1, B reads the window of t - 2).
+// One work-group barrier per tick.  A verdict reaches F three barriers after the hand-over, i.e. when it has run TWO fronts
+// on the assumption: on SQUASH those and everything listed from the assumed state are dropped (the CCCH list and frame-log
+// entries are overwritten, the counters restored from a checkpoint), F restarts from the true state and V skips the two
+// stale hand-overs in flight.  The same float operations run on the same inputs as in the serial walk, so every record is
+// bit-identical to it; a chain whose every burst fails runs at about the serial walk's speed.
+// What F hands over is indexed by tick mod 3 (read by P a tick, by V two ticks later); the buffers P fills for F likewise (P
+// writes slot t, F reads slot t - 1, P's pass 2 reads the window of t - 2); operand tables and verdicts by tick parity.
 // ---------------------------------------------------------------------------
-struct LoopHand {                  // F -> B, one per tick parity
+struct LoopHand {                  // F -> P, V
 	RxLoopState pre;               // the chain as the burst's feedback finds it (this burst's energy already in)
 	RxLoopState spec;              // ... and as F assumed it comes out
 	int valid, round, e_toa, win;
@@ -3588,17 +3594,17 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	const int stage_al = (stage_samples + 15) & ~15;
 	constexpr int kWin = NPL * 64;                     // samples of a window buffer
-	// dynamic LDS: [F's body | B's body | 3 staged sync-chunk windows | B's operand table | 3 raw windows]
-	unsigned char *const body_f = lds_raw, *const body_b = lds_raw + lds_body;
+	// dynamic LDS: [F's body | P's body | 3 staged sync-chunk windows | 2 operand tables | 3 raw windows]
+	unsigned char *const body_f = lds_raw, *const body_p = lds_raw + lds_body;
 	float2 *const hx0 = reinterpret_cast<float2 *>(lds_raw + 2 * (size_t)lds_body);
-	uint32_t *const vtab = reinterpret_cast<uint32_t *>(hx0 + 3 * stage_al);
-	float2 *const win0 = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(vtab) + kLatTabBytes);
+	uint32_t *const vtab0 = reinterpret_cast<uint32_t *>(hx0 + 3 * stage_al);
+	float2 *const win0 = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(vtab0) + 2 * kLatTabBytes);
 	__shared__ uint64_t h_off[3], s_pred[2];
-	__shared__ int h_kind[3], s_go[2];               // s_go, s_pred: F -> B, H, by tick parity
+	__shared__ int h_kind[3], s_go[2];               // s_go, s_pred: F -> P, V, by tick parity
 	__shared__ float h_stat[3][4];
-	__shared__ LoopHand s_hand[2];
-	__shared__ typename LatPre<NPL, SPS>::Cut s_cut[2];
-	__shared__ int s_vd[2];                    // B -> F, by the parity of the tick B wrote it in
+	__shared__ LoopHand s_hand[3];
+	__shared__ typename LatPre<NPL, SPS>::Cut s_cut[3];
+	__shared__ int s_vd[2];                    // V -> F, by the parity of the tick V wrote it in
 	__shared__ RxLoopState s_true[2];
 	// F's burst operands and results
 	__shared__ uint64_t s_off[1];
@@ -3607,10 +3613,11 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	__shared__ RxLoopItem s_items[kLoopPerRound];
 	__shared__ int32_t s_rv[1];
 	__shared__ float s_toa[1], s_fe[1], s_en[1];
-	// B's results
-	__shared__ __align__(8) uint8_t b_l2[24];
-	__shared__ int32_t b_crc[1], b_conv[1], b_rv[1];
+	// P's operands, V's survivor words and results
 	__shared__ uint8_t b_kind[1];
+	__shared__ int32_t b_rv[1];
+	__shared__ __align__(16) uint64_t v_surv[13 * 16];
+	__shared__ uint32_t v_ubits[4 * 8];
 	// LDS copies of the constant tables every burst reads (see LatPre)
 	__shared__ __align__(16) uint16_t s_lut[1024];
 	__shared__ uint32_t s_steps[2 * kSteps12];
@@ -3620,10 +3627,11 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	const int chain = blockIdx.x;
 	const int lane = (int)threadIdx.x & 63;
 	const int sps = a.sps;
-	if (threadIdx.x < 3)
+	if (threadIdx.x < 3) {
 		h_off[threadIdx.x] = ~0ull;
+		s_hand[threadIdx.x].valid = 0;
+	}
 	if (threadIdx.x == 0) {
-		s_hand[0].valid = s_hand[1].valid = 0;
 		s_vd[0] = s_vd[1] = kVdNone;
 		b_kind[0] = 0;
 	}
@@ -3650,12 +3658,30 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	}
 	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
 
-	// ------------------------------------------------------------------ H: the next burst's window
+	// ------------------------------------------------------------------ P: pass 2 + operand table, then the next window
 	if (wave == 2) {
+		LatPre<NPL, SPS> pre;
+		pre.lut = reinterpret_cast<const unsigned char *>(s_lut);
+		pre.steps = s_steps;
+		pre.cost_a = s_cost_a;
+		pre.cost_b = s_cost_b;
 		for (int t = 0;; t++) {
 			__syncthreads();
 			if (!s_go[t & 1])
 				break;
+			// (a hand-over made stale by a SQUASH is worked on all the same -- everything it names is in LDS --; V skips it)
+			const LoopHand &h = s_hand[(t + 2) % 3];          // F's of the last tick
+			if (t > 0 && h.valid) {
+				pre.cut = &s_cut[(t + 2) % 3];
+				pre.win_r = win0 + h.win * kWin;
+				pre.vtab = vtab0 + (t & 1) * (kLatTabBytes / 4);
+				const RxIo io = {
+#ifdef GMR1_HIP_PROFILE
+				                 h.stamp,
+#endif
+				                 &h.off, b_kind, &h.fsh, nullptr, nullptr, nullptr, b_rv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+				rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 2>(a, io, stage_samples, cw, 0, 1, body_p, lane, &pre);
+			}
 			const uint64_t pred = s_pred[t & 1];
 			const int slot = t % 3;
 			if (pred != ~0ull)
@@ -3668,58 +3694,53 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		return;
 	}
 
-	// ------------------------------------------------------------------ B: the back half, a round behind
+	// ------------------------------------------------------------------ V: the decoder and the verdict, two rounds behind
 	if (wave == 1) {
-		LatPre<NPL, SPS> pre;
-		pre.lut = reinterpret_cast<const unsigned char *>(s_lut);
-		pre.steps = s_steps;
-		pre.cost_a = s_cost_a;
-		pre.cost_b = s_cost_b;
-		pre.vtab = vtab;
-		pre.dc = c_dec.v[lane & 15];
-		pre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
-		pre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
-		bool squashed = false;                     // the last verdict: the hand-over that follows it is stale
+		DecPre dpre;
+		dpre.dc = c_dec.v[lane & 15];
+		dpre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
+		dpre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
+		int skip = 0;                              // hand-overs in flight that a SQUASH made stale
 		for (int t = 0;; t++) {
 			__syncthreads();
 			if (!s_go[t & 1])
 				break;
-			if (t == 0)
-				continue;
-			const LoopHand &h = s_hand[(t - 1) & 1];
-			const bool work = h.valid != 0 && !squashed;
-			squashed = false;
+			const LoopHand &h = s_hand[(t + 1) % 3];          // F's of two ticks ago, P's of the last
+			const bool work = t > 1 && h.valid != 0 && skip == 0;
+			if (skip)
+				skip--;
 			if (!work) {
 				if (lane == 0)
 					s_vd[t & 1] = kVdNone;
 				continue;
 			}
-			pre.cut = &s_cut[(t - 1) & 1];
-			pre.win_r = win0 + h.win * kWin;
-			const RxIo io = {
 #ifdef GMR1_HIP_PROFILE
-			                 h.stamp,
+			dpre.stamp = h.stamp;
+			GMR1_DSTAMP(&dpre, 15, lane);
 #endif
-			                 &h.off, b_kind, &h.fsh, b_l2, b_crc, b_conv, b_rv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-			rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 2>(a, io, stage_samples, cw, 0, 1, body_b, lane, &pre);
-			WSYNC();
+			uint32_t syn, fae;
+			decode1_k5_12_lat<ACC>(vtab0 + ((t - 1) & 1) * (kLatTabBytes / 4), v_surv, v_ubits, lane, syn, fae, &dpre);
+			GMR1_DSTAMP(&dpre, 7, lane);
+			// (row 0 holds the burst: its syndrome and metric, for every lane)
+			syn = (uint32_t)__builtin_amdgcn_readfirstlane((int)syn);
+			fae = (uint32_t)__builtin_amdgcn_readfirstlane((int)fae);
+			const int crc = syn ? 1 : 0;
 			// the feedback as the reference applies it (rx_bcch, gmr1_rx.c:782-791), on the state F started from
 			RxLoopState st = h.pre;
-			const int emit = rx_loop_bcch_result(st, sps, 0, b_crc[0], h.toa, h.ffe, b_l2, h.e_toa);
+			const int emit = rx_loop_bcch_result(st, sps, 0, crc, h.toa, h.ffe, reinterpret_cast<const uint8_t *>(v_ubits), h.e_toa);
 			const RxLoopState &sp = h.spec;
 			const bool same = st.align == sp.align && __float_as_uint(st.freq_err) == __float_as_uint(sp.freq_err) &&
 			                  st.fn == sp.fn && st.delay == sp.delay && st.stn == sp.stn;
 			{
 				// the burst's part of the round's log entry (F wrote c_first, c_n, minen, b_frame)
 				uint32_t *d = reinterpret_cast<uint32_t *>(rlog + h.round);
-				const uint32_t *l2w = reinterpret_cast<const uint32_t *>(b_l2);
 				uint32_t v = 0;
 				switch (lane) {
 				case 3: v = (uint32_t)emit; break;
 				case 4: v = (uint32_t)st.fn; break;
 				case 5: v = (uint32_t)st.stn; break;
-				case 6: v = (uint32_t)b_conv[0]; break;
-				default: v = (lane >= 8 && lane < 14) ? l2w[lane - 8] : 0u; break;
+				case 6: v = fae; break;
+				default: v = (lane >= 8 && lane < 14) ? v_ubits[lane - 8] : 0u; break;
 				}
 				if ((lane >= 3 && lane <= 6) || (lane >= 8 && lane < 14))
 					d[lane] = v;
@@ -3728,12 +3749,14 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 				s_true[t & 1] = st;
 				s_vd[t & 1] = same ? kVdOk : kVdSquash;
 			}
-			squashed = !same;
+			if (!same)
+				skip = 2;
+			WSYNC();
 		}
 		return;
 	}
 
-	// ------------------------------------------------------------------ F: the front half and the walk
+	// ------------------------------------------------------------------ F: the front and the walk
 	RxLoopState st = la.state[chain];          // every lane computes the same
 	const uint64_t lim = st.base + (uint64_t)st.len;
 	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
@@ -3788,9 +3811,9 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		WSYNC();
 		return n;
 	};
-	// checkpoints of the rounds handed to B, by tick parity: what a SQUASH restores
-	int cp_round[2] = {0, 0}, cp_frames[2] = {0, 0}, cp_ccch[2] = {0, 0};
-	bool age1 = false, age2 = false;           // a hand-over written one tick ago (B is at it) / two ticks ago (verdict due)
+	// checkpoints of the rounds handed over, by tick mod 3: what a SQUASH restores
+	int cp_round[3] = {0, 0, 0}, cp_frames[3] = {0, 0, 0}, cp_ccch[3] = {0, 0, 0};
+	bool age1 = false, age2 = false, age3 = false;   // a hand-over of one (P is at it) / two (V is) / three ticks ago (verdict due)
 	int n = round < round_end ? list_round() : 0;
 	bool finished = false;
 	int t = 0;
@@ -3808,31 +3831,32 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			s_go[t & 1] = 1;
 		}
 		__syncthreads();
-		// ---- the verdict on the hand-over of two ticks ago (B worked on it during the last tick)
-		if (age2 && s_vd[(t - 1) & 1] == kVdSquash) {
-			// the front half just run and everything listed since started from a state that never came to be: back to the
-			// checkpoint of the round B judged, its true feedback, and on from there within this tick (B skips the stale
-			// hand-over of the last tick by itself; what H has prepared is checked against the burst's place as always)
-			const int p = t & 1;
+		const int t3 = t % 3;
+		// ---- the verdict on the hand-over of three ticks ago (V worked on it during the last tick)
+		if (age3 && s_vd[(t - 1) & 1] == kVdSquash) {
+			// the two fronts run since and everything listed since started from a state that never came to be: back to the
+			// checkpoint of the round V judged, its true feedback, and on from there within this tick (V skips the two stale
+			// hand-overs in flight by itself; what P has prepared is checked against the burst's place as always)
 			st = s_true[(t - 1) & 1];
-			n_frames = cp_frames[p];
-			n_ccch = cp_ccch[p];
-			round = cp_round[p] + 1;
+			n_frames = cp_frames[t3];
+			n_ccch = cp_ccch[t3];
+			round = cp_round[t3] + 1;
 			on_frame(st);
 			rx_loop_advance(st, sps);
-			age1 = false;
+			age1 = age2 = false;
 			n = round < round_end ? list_round() : 0;
 		}
+		age3 = age2;
 		age2 = age1;
 		age1 = false;
 		if (n == 0 || round >= round_end) {
-			// nothing (more) to start in this launch: wait for what B still holds
-			if (!age2) {
+			// nothing (more) to start in this launch: wait for what P and V still hold
+			if (lane == 0)
+				s_hand[t3].valid = 0;
+			if (!age2 && !age3) {
 				finished = n == 0 && round < round_end;
 				break;
 			}
-			if (lane == 0)
-				s_hand[t & 1].valid = 0;
 			continue;
 		}
 		const bool has_b = s_items[n - 1].is_bcch != 0;
@@ -3856,13 +3880,13 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 				s_kind[0] = 0;
 			}
 			WSYNC();
-			const int slot = (t + 2) % 3;                // what H prepared during the last tick
+			const int slot = (t + 2) % 3;                // what P prepared during the last tick
 			pre.h_off = &h_off[slot];
 			pre.h_kind = &h_kind[slot];
 			pre.h_stat = h_stat[slot];
 			pre.h_x = hx0 + slot * stage_al;
 			pre.win_w = win0 + slot * kWin;
-			pre.cut = &s_cut[t & 1];
+			pre.cut = &s_cut[t3];
 #ifdef GMR1_HIP_PROFILE
 			unsigned long long *const stamp = (chain == 0 && round == kStampRound) ? g_stamp : nullptr;
 #endif
@@ -3875,13 +3899,13 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			WSYNC();
 			b_frame = frames_at_round + it.frames_before;
 			if (!s_rv[0]) {
-				// found: the feedback as if the CRC passes and SI1 moves nothing -- B will tell (gmr1_rx.c:782-795)
+				// found: the feedback as if the CRC passes and SI1 moves nothing -- V will tell (gmr1_rx.c:782-795)
 				st.bcch_energy = s_en[0];
 				const RxLoopState before = st;
 				st.align += (int)roundf(s_toa[0]) - it.e_toa;
 				st.freq_err += s_fe[0];
 				if (lane == 0) {
-					LoopHand &h = s_hand[t & 1];
+					LoopHand &h = s_hand[t3];
 					h.pre = before;
 					h.spec = st;
 					h.round = round;
@@ -3896,9 +3920,9 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 #endif
 					h.valid = 1;
 				}
-				cp_round[t & 1] = round;
-				cp_frames[t & 1] = n_frames;
-				cp_ccch[t & 1] = n_ccch + n_c;
+				cp_round[t3] = round;
+				cp_frames[t3] = n_frames;
+				cp_ccch[t3] = n_ccch + n_c;
 				handed = true;
 			}
 			b_fn = st.fn;
@@ -3907,7 +3931,7 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			rx_loop_advance(st, sps);
 		}
 		if (!handed && lane == 0)
-			s_hand[t & 1].valid = 0;
+			s_hand[t3].valid = 0;
 		{
 			// the round's log entry, 14 words: all of it for a round without a burst that was found, else the walk's part
 			uint32_t *d = reinterpret_cast<uint32_t *>(rlog + round);
@@ -3929,7 +3953,7 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		age1 = handed;
 		n = round < round_end ? list_round() : 0;
 	}
-	t++;                                        // one more barrier: B and H leave
+	t++;                                        // one more barrier: P and V leave
 	if (lane == 0)
 		s_go[t & 1] = 0;
 	__syncthreads();
@@ -4509,9 +4533,9 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	const dim3 grid((unsigned)n_chains), block(128);
 	// the helper wave's two staged windows, then the latency decoder's operand table
 	const size_t lds_h = one ? 0 : 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
-	// the pipelined walk (k_rx_chain_pipe): two bodies, three staged windows, the operand table, three raw windows
+	// the pipelined walk (k_rx_chain_pipe): two bodies, three staged windows, two operand tables, three raw windows
 	const int npl = a.in_len[0] <= 1024 ? 16 : 32;
-	const size_t lds_p = one ? 0 : 2 * lds + 3 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes +
+	const size_t lds_p = one ? 0 : 2 * lds + 3 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + 2 * (size_t)kLatTabBytes +
 	                               3 * (size_t)npl * 64 * sizeof(float2);
 	static const bool serial = profile_env("GMR1_HIP_LOOP_SERIAL") != nullptr;     // (profiling build: the walk of round 4, for A/B)
 	hipError_t e;

@@ -428,7 +428,8 @@ def si1_payload(rng: np.random.Generator, fn: np.ndarray, delay: int, stn: int) 
 def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: int, sps: int,
                        rng: np.random.Generator, *, stn: int = 3, delay: int = 2, fn0: int | None = None,
                        t0: int | None = None, frac: float = 0.0, esn0_db: float = 15.0, cfo_hz: float = 0.0,
-                       p_idle: float = 0.15, fcch_db: float = 0.0, imm_ass=(), pulse: str = "rc", span: int = 5):
+                       p_idle: float = 0.15, fcch_db: float = 0.0, imm_ass=(), pulse: str = "rc", span: int = 5,
+                       other_first: int = 0, si1_lie=None, absent_bcch=()):
     """One ARFCN of BASELINE.md config 4: FCCH + BCCH (SI1 w/ Seg 2A bis) + CCCH on the
     24-slot / 40 ms TDMA grid (reference src/gmr1_rx.c:852-895 schedule).
 
@@ -436,6 +437,9 @@ def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: i
     sirfn = (fn - delay) & 63:  sirfn % 8 == 0 -> FCCH, == 2 -> BCCH, else CCCH (DC6) unless idle;
     all on timeslot stn.  imm_ass = [(k, tn, p), ...]: the first CCCH burst sent at frame index >= k
     carries an IMMEDIATE ASSIGNMENT to timeslot tn with DKAB position p (gmr1_rx.c:235-246).
+    What a receiver's feedback loop has to survive (counted over the carrier's BCCH bursts in order): the first
+    other_first of them carry another SI (no TDMA position: the first SI1 arrives late); si1_lie = {i: (delay, stn)}:
+    burst i's SI1 claims that TDMA position instead of the true one; absent_bcch: bursts not transmitted at all.
     Returns (stream complex64, list of dicts describing what was sent)."""
     frame_len = 24 * 39 * sps
     if t0 is None:
@@ -461,10 +465,18 @@ def synth_bcch_carrier(fmt_bcch: BurstFormat, fmt_dc6: BurstFormat, n_samples: i
     if kb.size:
         l2 = si1_payload(rng, fns[kb], delay, stn)
         other = rng.random(kb.size) < 0.25            # some BCCH bursts carry another SI: no TDMA info
+        other[:other_first] = True
+        for i, (d_l, s_l) in (si1_lie or {}).items():
+            if i < kb.size:
+                l2[i] = si1_payload(rng, fns[kb[i]:kb[i] + 1] - delay + d_l, d_l, s_l)[0]
+                other[i] = False
         l2[other, 0] = 0x10 | (l2[other, 0] & 0x07)
         body = shape_bursts(map_symbols(fmt_bcch, bcch_encode(l2)), sps, frac, span, pulse)
+        gone = set(int(i) for i in absent_bcch)
         for i, k in enumerate(kb):
             pos = t0 + k * frame_len + stn * 39 * sps - span * sps
+            if i in gone:
+                continue
             if pos >= 0 and pos + body.shape[1] <= n_samples:
                 x[pos:pos + body.shape[1]] += body[i]
                 sent.append(dict(type="bcch", fn=int(fns[k]), pos=pos + span * sps, l2=l2[i].copy()))

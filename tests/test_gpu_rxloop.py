@@ -371,6 +371,57 @@ def test_rx_loop_survives_hostile_samples(gpu_api, pkg):
     assert got["rv"].shape == (n,)
 
 
+@pytest.mark.timeout(300)
+def test_rx_loop_forced_mis_speculation(gpu_api, orc, pkg, decoder):
+    """The loop's front stage runs two rounds ahead of the decoder on the assumption that the BCCH burst will pass its CRC
+    and that its SI1 will leave the TDMA position alone (k_rx_chain_pipe).  Carriers on which that assumption fails again
+    and again - a third or more of the bursts failing the CRC, bursts that are not there, a first SI1 that arrives after
+    many other-SI bursts, SI1s that re-label the timeslot or the frame count in mid-capture, stretches of strong noise -
+    must give exactly the oracle's records: a squashed round is redone from the true state."""
+    seconds = 12.0
+    specs = [
+        dict(seed=301, stn=4, delay=1, cfo_hz=70.0, esn0_db=4.0),                               # many CRC failures
+        dict(seed=302, stn=7, delay=3, cfo_hz=-150.0, esn0_db=3.3),                             # more of them
+        dict(seed=303, stn=11, delay=6, cfo_hz=30.0, esn0_db=14.0, absent_bcch=range(2, 36, 3)),   # every third burst missing
+        dict(seed=304, stn=19, delay=2, cfo_hz=200.0, esn0_db=14.0, other_first=14),            # the first SI1 arrives late
+        dict(seed=305, stn=5, delay=4, cfo_hz=-40.0, esn0_db=16.0, si1_lie={12: (4, 9), 13: (4, 9)}),   # SI1 re-labels the timeslot
+        dict(seed=306, stn=2, delay=0, cfo_hz=10.0, esn0_db=16.0, si1_lie={9: (3, 2)}),         # SI1 changes the frame count
+        dict(seed=307, stn=13, delay=5, cfo_hz=0.0, esn0_db=5.0, absent_bcch=(5, 6, 7, 20), other_first=6),
+    ]
+    streams, sents = [], []
+    for sp in specs:
+        sp = dict(sp)
+        x, sent = workloads.bcch_carrier(pkg, sp.pop("seed"), seconds=seconds, sps=SPS, **sp)
+        streams.append(x)
+        sents.append(sent)
+    # hostile samples on top of a weak carrier: stretches of the capture replaced by strong noise, at BCCH bursts and between
+    rng = np.random.default_rng(5)
+    x = streams[0].copy()
+    for pos in rng.integers(0, x.size - 6000, 25):
+        x[pos:pos + 5000] = rng.standard_normal((5000, 2), dtype=np.float32).view(np.complex64).reshape(-1) * np.float32(3.0)
+    streams.append(x)
+    sents.append(sents[0])
+    length = np.array([s.size for s in streams], np.uint64)
+    offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.uint64)
+    arfcn = np.arange(len(streams), dtype=np.uint16) + 40
+    rec, status, chains, found = gpu_api.rx_run(np.concatenate(streams), offset, length, sps=SPS, arfcn=arfcn)
+    assert found == len(rec)
+    fail_frac = []
+    for i, x in enumerate(streams):
+        orv, orec, och = orc.rx_run(x, sps=SPS, arfcn=int(arfcn[i]))
+        mine = rec[rec["arfcn"] == arfcn[i]]
+        assert (status[i] == 0) == (orv == 0), (i, status[i], orv)
+        assert chains[i] == och
+        assert _key(mine) == _key(orec), f"carrier {i}: records differ from the oracle's"
+        n_sent = sum(1 for s_ in sents[i] if s_["type"] == "bcch")
+        n_got = int((orec["type"] == 1).sum()) if len(orec) else 0
+        fail_frac.append(1.0 - n_got / max(n_sent, 1))
+    print("BCCH bursts sent but not emitted, per carrier:", " ".join("%.2f" % f for f in fail_frac))
+    # the assumption did fail often enough to mean something (carrier 2: a third of its bursts were never sent)
+    assert fail_frac[0] >= 0.2 and fail_frac[1] >= 0.2 and fail_frac[7] >= 0.2, fail_frac
+    assert all(len(rec[rec["arfcn"] == a]) > 100 for a in arfcn[2:7])
+
+
 @pytest.mark.timeout(900)
 def test_rx_loop_production_length_64_carriers_60_s(gpu_api, orc, pkg, decoder):
     """BASELINE configs[3] at its size: 64 carriers x 60 s (eight distinct, tiled -- as bench.py --workload rx runs it), one

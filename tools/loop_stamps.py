@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Cycle stamps of one BCCH burst inside the receive loop (chain 0, round 55): where a round's 19 microseconds go.
+"""Cycle stamps of one BCCH burst inside the pipelined receive loop (chain 0, round 55): what each of its three stages takes.
 Needs the profiling build (python osmo-gmr_amd/build.py --profile).  Run on the GPU box from the repo root."""
 import ctypes as C
 import os
@@ -43,12 +43,16 @@ print(f"{A} carriers x {seconds} s: {e0.elapsed_time(e1) / 5:.3f} ms per run (ac
 out = (C.c_ulonglong * 16)()
 assert L.gmr1_hip_prof_stamps(out) == 0
 t = np.array(list(out), np.int64)
-names = ["start", "window loaded + statistics", "staging + correlation", "peak + timing bisection", "sync terms (frequency, phase)",
-         "pass 2 (soft bits)", "branch metrics", "Viterbi + survivors + CRC"]
-print("cycles since the burst started (shader clock), and per phase:")
-for k in range(1, 8):
-    print(f"  {names[k]:34s} {t[k] - t[0]:8d}  (+{t[k] - t[k - 1]})")
-print(f"  inside the timing phase: coarse peak found at {t[8] - t[0]} (+{t[8] - t[2]}), nine halvings done at {t[9] - t[0]} (+{t[9] - t[8]}), "
-      f"peak value + bookkeeping +{t[3] - t[9]}")
-print(f"  finer: parameters looked up at +{t[10] - t[2]} of the timing phase, window argmax reduced at +{t[11] - t[2]}, coarse peak at +{t[8] - t[2]}; "
-      f"decoder: forward pass {t[12] - t[6]}, survivor walk {t[13] - t[12]}, CRC + results {t[7] - t[13]}")
+print("cycle stamps of chain 0's round 55 (shader clock).  The burst runs on three waves, a tick apart: F = front, P = pass 2 + operand table, V = decoder")
+f = [("window (prepared: statistics only)", 1, 0), ("staging + correlation", 2, 1), ("parameters looked up", 10, 2), ("window argmax reduced", 11, 10),
+     ("coarse peak", 8, 11), ("nine halvings", 9, 8), ("peak value + bookkeeping", 3, 9), ("sync terms (frequency, phase)", 4, 3)]
+print(f"F: front, {t[4] - t[0]} cycles")
+for name, k, k0 in f:
+    print(f"  {name:38s} +{t[k] - t[k0]:6d}")
+print(f"P: pass 2 + operand table, {t[6] - t[14]} cycles (starts {t[14] - t[0]} after F's start)")
+print(f"  {'pass 2 (soft bits)':38s} +{t[5] - t[14]:6d}")
+print(f"  {'branch metrics -> operand table':38s} +{t[6] - t[5]:6d}")
+print(f"V: decoder, {t[7] - t[15]} cycles (starts {t[15] - t[0]} after F's start)")
+print(f"  {'forward pass':38s} +{t[12] - t[15]:6d}")
+print(f"  {'survivor walk':38s} +{t[13] - t[12]:6d}")
+print(f"  {'CRC':38s} +{t[7] - t[13]:6d}")
