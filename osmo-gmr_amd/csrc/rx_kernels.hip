@@ -1797,9 +1797,11 @@ __device__ __forceinline__ void pk_cmac(v2f &acc, unsigned long long c, v2f x)
 	    : "s"(c), "v"(x));
 }
 
+// (lags [j_begin, j_end) of the w there are; j_end < 0: all)
 template <int SPS, int T0, int T1, int T2>
 __device__ __forceinline__ void corr_fixed(const float2 *__restrict__ xs, int sps_rt, int w, int lane,
-                                           const float2 *__restrict__ ctab, float2 cfl, float *__restrict__ corr)
+                                           const float2 *__restrict__ ctab, float2 cfl, float *__restrict__ corr,
+                                           int j_begin = 0, int j_end = -1)
 {
 	constexpr int T[3] = {T0, T1, T2};
 	constexpr int NT = T0 + T1 + T2;
@@ -1816,7 +1818,8 @@ __device__ __forceinline__ void corr_fixed(const float2 *__restrict__ xs, int sp
 			cf[n] = (unsigned long long)__builtin_bit_cast(uint32_t, lane_val(cfl.x, n)) |
 			        ((unsigned long long)__builtin_bit_cast(uint32_t, lane_val(cfl.y, n)) << 32);
 	}
-	for (int j = lane; j < w; j += 64) {
+	const int j_stop = j_end < 0 ? w : j_end;
+	for (int j = j_begin + lane; j < j_stop; j += 64) {
 		float cj = 0.f;
 		int wb = 0, base = 0;
 #pragma unroll
@@ -1905,7 +1908,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 // at the current round's log blocks (by value: they stay in scalar registers)
 #ifdef GMR1_HIP_PROFILE
 // cycle stamps of ONE burst of the receive loop (chain 0, the BCCH burst of round kStampRound): tools/loop_stamps.py
-__device__ unsigned long long g_stamp[16];
+__device__ unsigned long long g_stamp[32];
 __device__ int g_prof_flag;              // experiments of the profiling build (gmr1_hip_prof_flag)
 constexpr int kStampRound = 55;    // (late in a time slice: its first rounds share the CU with the previous slice's CCCH batch)
 #define GMR1_STAMP(k)                                                        \
@@ -1970,6 +1973,32 @@ struct Fmt {
 // trip to the L2 (each of these sat at the head of a phase of every burst of every round): the soft-bit table, the
 // trellis-step descriptors and the cost words of the branch metrics (work-group copies), the decoder's per-lane
 // constants and CRC syndrome words (registers).
+struct LoopCo {                    // front wave <-> helper wave, within a tick (flags carry the tick's job id)
+	int job;                       // F -> S, before the tick's barrier: id (> 0) of the job, 0: none
+	float fsh;                     // the burst: frequency shift ...
+	uint64_t off;                  // ... and first sample (S helps only if that is the window prepared)
+	int p_id, p;                   // F -> S: the coarse peak (p < 0: never mind)
+	int c_id;                      // S -> F: the correlation's tail is in place
+	int s_id;                      // S -> F: ffe / psi of the three candidates are in place
+	float ffe[3], psi[3];
+	float tail[64];                // the correlation of the last partial round of lags (F copies it in: a front that was
+	                               // squashed meanwhile never looks at it)
+};
+// (bounded: a wave that gives up does the work itself -- no hand-shake can hang the work-group)
+__device__ __forceinline__ bool lds_wait_eq(const int *flag, int want)
+{
+	for (int i = 0; i < (1 << 16); i++) {
+		if (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == want)
+			return true;
+		__builtin_amdgcn_s_sleep(1);
+	}
+	return false;
+}
+__device__ __forceinline__ void lds_post(int *flag, int v)
+{
+	__hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int NPL, int SPS>
 struct LatPre {
 	const uint64_t *h_off = nullptr;       // LDS: first sample of the window prepared (~0: none)
@@ -1987,9 +2016,142 @@ struct LatPre {
 	// later.  What crosses the cut: `cut`; the burst's raw window stays in LDS for the kept samples of pass 2.
 	struct Cut { int found, d, sid; float toa, ffe, psi, avr, avi; };
 	Cut *cut = nullptr;                    // LDS
+	Cut out;                               // front: the same in (scalar) registers, for the walk
+	float out_energy = 0.f;                // front: burst_energy() of the window
+	// (4) The front's helper wave (k_rx_chain_pipe's S): for a burst whose window was prepared it correlates the last
+	// partial round of lags while the front wave does the whole rounds, and, once the front has posted the coarse peak p,
+	// forms the sync-symbol terms for the three values round(toa) can take (p - 1, p, p + 1: the bisection starts at p - 1
+	// and moves less than one lag) while the front wave bisects.
+	LoopCo *co = nullptr;                  // LDS; null: the front works alone
+	int co_id = 0;
 	float2 *win_w = nullptr;               // LDS, front half: where the window goes if the front had to fetch it itself
 	const float2 *win_r = nullptr;         // LDS, back half: the burst's raw window (lane l's samples l + 64 k as fetched)
 };
+
+// rotated reference of a fused format's training sequence under a caller-supplied frequency shift: value n in lane n
+__device__ __forceinline__ float2 lat_coef(int kind, int lane, float fs, int sps)
+{
+	float2 cfl = make_float2(0.f, 0.f);
+	if (lane < (kind ? 13 : 17)) {
+		const int l0 = kind ? 7 : 11;
+		const int nn = lane < l0 ? lane : (lane < l0 + 3 ? lane - l0 : lane - l0 - 3);
+		float sn, cs;
+		sincos_fast(fs * (float)(nn * sps), sn, cs);
+		cfl = conj_ref_mul(2, (int)(((kind ? kFusedSymsDc6 : kFusedSymsBcch) >> (2 * lane)) & 3ull), make_float2(cs, sn));
+	}
+	return cfl;
+}
+
+// The sync-symbol terms of a fused-format burst whose sync-chunk windows are staged in LDS (the receive loop's bursts): fine
+// frequency from the chunk sums, then the carrier phase (pi4cxpsk.c:381-433, 574-575) -- one burst, or one candidate
+// timing d of a burst, per 16-lane row; lane col holds sync symbols n = col and n = col + 16.  The window scale 1 / sigma
+// is irrelevant to every angle.
+__device__ __forceinline__ void lat_sync_terms(const float2 *__restrict__ xst, int kind, int d, bool live, float fs, int sps, int w,
+                                               int in_len, int col, float &ffe_o, float &psi_o)
+{
+	typedef Fmt<false> F;
+	const DevBurst &bt = c_types[GMR1_HIP_BCCH];      // (Fmt<false> carries the numbers itself)
+	const int tl = F::tl(bt, kind);
+	float2 t0[2], xr[2];
+	int chn[2], spos[2], idxv[2];
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+		const int n = col + 16 * h;
+		t0[h] = xr[h] = make_float2(0.f, 0.f);
+		chn[h] = -1;
+		spos[h] = idxv[h] = 0;
+		if (n < tl && live) {
+			int ch = 0, base = 0, cum = 0, wb = 0;
+			for (int c = 0; c < 2; c++) {
+				cum += F::clen(bt, kind, c);
+				if (n >= cum) { base = cum; ch = c + 1; wb += F::clen(bt, kind, c) * sps + w - 1; }
+			}
+			const int nn = n - base;
+			const int sp = F::cpos(bt, ch) + nn;
+			const int idx = sp * sps + d;
+			if (idx >= 0 && idx < in_len)
+				xr[h] = xst[wb + nn * sps + d];
+			chn[h] = ch;
+			spos[h] = sp;
+			idxv[h] = idx;
+		}
+	}
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+		if (chn[h] >= 0) {
+			float sn, cs;
+			sincos_fast(fs * (float)idxv[h], sn, cs);
+			const float2 x = cmul(xr[h], make_float2(cs, sn));
+			t0[h] = conj_ref_mul(2, F::sym(bt, kind, 0, 0, 0, col + 16 * h), x);
+		}
+	}
+	float ffe = 0.f;
+	{
+		float sumr[3], sumi[3];
+#pragma unroll
+		for (int c = 0; c < 3; c++) {
+			const float pr = (chn[0] == c ? t0[0].x : 0.f) + (chn[1] == c ? t0[1].x : 0.f);
+			const float pi = (chn[0] == c ? t0[0].y : 0.f) + (chn[1] == c ? t0[1].y : 0.f);
+			sumr[c] = row_sum(pr);
+			sumi[c] = row_sum(pi);
+		}
+		float f = 0.f;
+#pragma unroll
+		for (int i = 1; i < 3; i++) {
+			const float ppos = (float)F::cpos(bt, i - 1) + (float)F::clen(bt, kind, i - 1) / 2.0f;
+			const float cpos = (float)F::cpos(bt, i) + (float)F::clen(bt, kind, i) / 2.0f;
+			const float re = sumr[i] * sumr[i - 1] - sumi[i] * (-sumi[i - 1]);
+			const float im = sumr[i] * (-sumi[i - 1]) + sumi[i] * sumr[i - 1];
+			f += atan2_fast(im, re) / (cpos - ppos);
+		}
+		ffe = f / (float)(3 - 1);
+	}
+	float tr = 0.f, ti = 0.f;
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+		float2 tt = t0[h];
+		if (ffe != 0.0f) {
+			float sn, cs;
+			sincos_fast(-ffe * (float)spos[h], sn, cs);
+			tt = cmul(tt, make_float2(cs, sn));
+		}
+		tr += tt.x;
+		ti += tt.y;
+	}
+	ffe_o = ffe;
+	psi_o = atan2_fast(row_sum(ti), row_sum(tr));
+}
+
+// What the front's helper wave does for one BCCH burst of the loop whose window was prepared (LatPre (4)).
+template <int SPS>
+__device__ __forceinline__ void loop_front_helper(const RxArgs &a, LoopCo *co, int id, const float2 *__restrict__ xst, int lane)
+{
+	const int sps = SPS ? SPS : a.sps;
+	const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[0]);
+	const int w = in_len - 234 * sps + 1;
+	const float fs = (co->fsh - kPif / 4.0f) / (float)sps;              // as rx4_body: (shift - rotation) / sps
+	const float2 cfl = lat_coef(0, lane, fs, sps);
+	const int j0 = ((w - 1) >> 6) << 6;                                 // the last, partial round of lags
+	corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, nullptr, cfl, co->tail - j0, j0, w);
+	WSYNC();
+	if (lane == 0)
+		lds_post(&co->c_id, id);
+	if (!lds_wait_eq(&co->p_id, id))
+		return;
+	const int p = co->p;
+	if (p < 0)
+		return;
+	const int row = lane >> 4, col = lane & 15;
+	float ffe, psi;
+	lat_sync_terms(xst, 0, p - 1 + row, row < 3, fs, sps, w, in_len, col, ffe, psi);
+	if (col == 0 && row < 3) {
+		co->ffe[row] = ffe;
+		co->psi[row] = psi;
+	}
+	WSYNC();
+	if (lane == 0)
+		lds_post(&co->s_id, id);
+}
 
 // The position-only part of a fused-format burst's pass 1 (rx4_body does the same, operation for operation): window,
 // statistics, burst energy, normalised sync-chunk windows.
@@ -2117,6 +2279,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	constexpr bool KEEP = !GEN && !LAT && !PL && !EN && SPS == 4 && NPL == 16;
 	const bool keep3 = KEEP && g0 + 3 < n_end;
 	float2 wv_own[NPL];
+	bool co_on = false;                                // (LAT, PART 1) the helper wave shares this burst's front (LatPre (4))
+	int co_p = 0;
 	if constexpr (PART == 2)
 		GMR1_STAMP(14);
 	else
@@ -2296,6 +2460,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			prepared = *pre->h_off == io.offset[g] && *pre->h_kind == kind;
 			if (prepared)
 				xst = xst_lat = pre->h_x;
+			if constexpr (PART == 1)
+				co_on = prepared && pre->co != nullptr && kind == 0;
 		}
 		if (LAT) {
 			if (!prepared)
@@ -2343,11 +2509,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				cfl = sync_coef0(bt, lane, sps, fs);
 			} else {
 				// the same with the fused formats' numbers (Fmt<false>): no table walk
-				const int l0 = kind ? 7 : 11;
-				const int nn = lane < l0 ? lane : (lane < l0 + 3 ? lane - l0 : lane - l0 - 3);
-				float sn, cs;
-				sincos_fast(fs * (float)(nn * sps), sn, cs);
-				cfl = conj_ref_mul(2, F::sym(bt, kind, 0, 0, 0, lane), make_float2(cs, sn));
+				cfl = lat_coef(kind, lane, fs, sps);
 			}
 		}
 		WSYNC();
@@ -2361,6 +2523,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			avr = pre->h_stat[0];
 			avi = pre->h_stat[1];
 			inv = pre->h_stat[2];
+			if constexpr (PART == 1)
+				pre->out_energy = pre->h_stat[3];
 			if (io.energy && lane == 0)
 				io.energy[g] = pre->h_stat[3];
 		} else {
@@ -2372,7 +2536,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 					pre->win_w[lane + 64 * k] = wv[k];
 			}
 		}
-		if ((LAT || !PREFETCH_NEXT) && EN && io.energy) {
+		if constexpr (LAT && PART == 1) {
+			const float e = window_energy_regs<NPL>(wv, in_len, lane);
+			pre->out_energy = e;
+			if (io.energy && lane == 0)
+				io.energy[g] = e;
+		} else if ((LAT || !PREFETCH_NEXT) && EN && io.energy) {
 			// burst_energy() while the window is still in registers
 			const float e = window_energy_regs<NPL>(wv, in_len, lane);
 			if (lane == 0)
@@ -2413,7 +2582,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		float *corr = L.corr + q * cw;
 		if constexpr (!GEN) {
 			// BCCH / DC6: static tap structure (the host refuses to start this kernel if the tables say otherwise)
-			if (kind == 0)
+			if (LAT && PART == 1 && co_on) {
+				// the whole rounds of lags here, the last partial one on the helper wave
+				const int j0 = ((w - 1) >> 6) << 6;
+				corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, ctab, cfl, corr, 0, j0);
+				if (lds_wait_eq(&pre->co->c_id, pre->co_id)) {
+					if (lane < w - j0)
+						corr[j0 + lane] = pre->co->tail[lane];
+				} else
+					corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, ctab, cfl, corr, j0, w);
+			} else if (kind == 0)
 				corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, ctab, cfl, corr);
 			else
 				corr_fixed<SPS, 7, 3, 3>(xst, sps, w, lane, ctab, cfl, corr);
@@ -2605,6 +2783,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 		}
 		GMR1_STAMP(8);
+		if constexpr (LAT && PART == 1) {
+			if (co_on) {
+				// the helper wave starts on the sync-symbol terms of round(toa) = p - 1, p, p + 1
+				co_p = __builtin_amdgcn_readfirstlane(p);
+				if (lane == 0) {
+					pre->co->p = co_p;
+					lds_post(&pre->co->p_id, pre->co_id);
+				}
+			}
+		}
 		// interpolated correlation at `pos` (lanes 0-7 of the row) and at `pos + 2` (lanes 8-15): same
 		// fractional part, so the same 21 weights; lane sub = col & 7 holds taps k = 3 sub - 10 + {0,1,2}
 		const int ipt = col >> 3, isub = col & 7;
@@ -2871,6 +3059,23 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		ffe_r = pre->cut->ffe;
 		psi_r = pre->cut->psi;
 		fetch(0, first);
+	} else if constexpr (LAT) {
+		if constexpr (PART == 0)
+			fetch(0, first);            // the one burst's kept samples travel during the whole sync-term phase
+		bool have = false;
+		if constexpr (PART == 1) {
+			if (co_on) {
+				// what the helper wave made of the candidate that round(toa) turned out to be
+				const int k = __builtin_amdgcn_readfirstlane(d_r) - (co_p - 1);
+				if ((unsigned)k < 3u && lds_wait_eq(&pre->co->s_id, pre->co_id)) {
+					ffe_r = pre->co->ffe[k];
+					psi_r = pre->co->psi[k];
+					have = true;
+				}
+			}
+		}
+		if (!have)
+			lat_sync_terms(xst_lat, kind_r, d_r, row_live, fs_r, sps, w_r, in_len_r, col, ffe_r, psi_r);
 	} else {
 		// lane col holds sync symbols n = col and n = col + 16 (< tl <= 32); their samples are asked for first (loads
 		// come back in order), then pass 2's
@@ -2977,7 +3182,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	if (a.dbg_stop == 5) return;
 
 	// per-burst results
-	if (col == 0 && row_live) {
+	if (col == 0 && row_live && (PART != 1 || io.rv)) {
 		const int rv = found_r ? 0 : -1;
 		io.rv[g_row] = rv;
 		if (io.sync_id) io.sync_id[g_row] = found_r ? sid_r : -1;
@@ -2986,6 +3191,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 	}
 	if constexpr (PART == 1) {
+		// (row 0 holds the burst: lane 0's values, for every lane)
+		auto first_f = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+		pre->out = {__builtin_amdgcn_readfirstlane(found_r ? 1 : 0), __builtin_amdgcn_readfirstlane(d_r), __builtin_amdgcn_readfirstlane(sid_r),
+		            first_f(found_r ? toa_r : 0.f), first_f(found_r ? ffe_r : 0.f), first_f(psi_r), first_f(avr_r), first_f(avi_r)};
 		if (lane == 0)
 			*pre->cut = {found_r ? 1 : 0, d_r, sid_r, toa_r, ffe_r, psi_r, avr_r, avi_r};
 		return;
@@ -3556,7 +3765,8 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 // only `if (!crc)` (gmr1_rx.c:782-791): align += round(toa) - e_toa, freq_err += freq_err, then bcch_tdma_align (:194-233).
 // toa and freq_err exist once the demodulator's front is through (sync search, timing, sync-symbol terms,
 // pi4cxpsk.c:547-575); the rest of the burst (soft bits :577-600, Viterbi and CRC bcch.c:83-103) contributes a binary verdict
-// and the SI1 fields, which repeat once a chain is aligned.  So a work-group of three waves on three SIMDs, each a stage:
+// and the SI1 fields, which repeat once a chain is aligned.  So a work-group of four waves on the CU's four SIMDs, three of
+// them pipeline stages:
 //
 //   F (wave 0)  tick t: the FRONT of round r's burst, then the feedback AS IF the CRC will pass and SI1 will move nothing,
 //               the frames up to the next BCCH burst listed from that assumed state, and straight on to round r + 1;
@@ -3567,6 +3777,10 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 //   V (wave 1)  tick t + 2: Viterbi, survivor walk, CRC; then the real feedback (rx_loop_bcch_result) on the state F started
 //               from -- if that is not bit for bit the state F assumed, the verdict is SQUASH and carries the true state.
 //
+//   S (wave 3)  within tick t, beside F: the last partial round of the correlation's lags, then -- once F has the coarse
+//               peak p -- the sync-symbol terms for the three values round(toa) can take, while F bisects (LatPre (4));
+//               hand-shakes through LDS flags, every wait bounded with the waiting wave doing the work itself on time-out.
+//
 // One work-group barrier per tick.  A verdict reaches F three barriers after the hand-over, i.e. when it has run TWO fronts
 // on the assumption: on SQUASH those and everything listed from the assumed state are dropped (the CCCH list and frame-log
 // entries are overwritten, the counters restored from a checkpoint), F restarts from the true state and V skips the two
@@ -3575,20 +3789,39 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 // What F hands over is indexed by tick mod 3 (read by P a tick, by V two ticks later); the buffers P fills for F likewise (P
 // writes slot t, F reads slot t - 1, P's pass 2 reads the window of t - 2); operand tables and verdicts by tick parity.
 // ---------------------------------------------------------------------------
-struct LoopHand {                  // F -> P, V
+struct LoopHand {                  // F -> P, V: 32 words, written one per lane
 	RxLoopState pre;               // the chain as the burst's feedback finds it (this burst's energy already in)
-	RxLoopState spec;              // ... and as F assumed it comes out
+	int spec_align;                // ... and what F assumed it makes of it
+	float spec_ferr;
 	int valid, round, e_toa, win;
 	float toa, ffe, fsh;
-	uint64_t off;
-#ifdef GMR1_HIP_PROFILE
-	unsigned long long *stamp;
-#endif
+	int c_first, c_n;              // the walk's part of the round's log entry (V writes the entry)
+	float minen;
+	int b_frame;
+	uint32_t stamp_lo, stamp_hi;   // (profiling build: where this round's cycle stamps go)
+	uint32_t pad[5];
 };
+static_assert(sizeof(RxLoopState) == 48 && sizeof(LoopHand) == 128, "the hand-over is written as 32 words");
+__device__ __forceinline__ uint32_t loop_state_word(const RxLoopState &x, int i)
+{
+	switch (i) {
+	case 0: return (uint32_t)x.base;
+	case 1: return (uint32_t)(x.base >> 32);
+	case 2: return (uint32_t)x.len;
+	case 3: return (uint32_t)x.align;
+	case 4: return __float_as_uint(x.freq_err);
+	case 5: return (uint32_t)x.fn;
+	case 6: return (uint32_t)x.delay;
+	case 7: return (uint32_t)x.stn;
+	case 8: return (uint32_t)x.done;
+	case 9: return __float_as_uint(x.bcch_energy);
+	default: return (uint32_t)x.arfcn | ((uint32_t)x.chain << 16);
+	}
+}
 enum { kVdNone = 0, kVdOk = 1, kVdSquash = 2 };
 
 template <int NPL, int SPS, bool ACC = false>
-__global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body, int slice,
+__global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body, int slice,
                                                        int slice_rounds)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -3606,13 +3839,12 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	__shared__ typename LatPre<NPL, SPS>::Cut s_cut[3];
 	__shared__ int s_vd[2];                    // V -> F, by the parity of the tick V wrote it in
 	__shared__ RxLoopState s_true[2];
+	__shared__ LoopCo s_co[2];                 // F <-> S, by tick parity
 	// F's burst operands and results
 	__shared__ uint64_t s_off[1];
 	__shared__ float s_fs[1];
 	__shared__ uint8_t s_kind[1];
 	__shared__ RxLoopItem s_items[kLoopPerRound];
-	__shared__ int32_t s_rv[1];
-	__shared__ float s_toa[1], s_fe[1], s_en[1];
 	// P's operands, V's survivor words and results
 	__shared__ uint8_t b_kind[1];
 	__shared__ int32_t b_rv[1];
@@ -3635,6 +3867,10 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		s_vd[0] = s_vd[1] = kVdNone;
 		b_kind[0] = 0;
 	}
+	if (threadIdx.x < 2) {
+		LoopCo &c = s_co[threadIdx.x];
+		c.job = c.p_id = c.c_id = c.s_id = 0;
+	}
 	const int round0 = slice ? la.n_rounds[chain] : 0;
 	const int round_end = min(round0 + slice_rounds, la.max_rounds);
 	if (slice == 0 && threadIdx.x == 0)
@@ -3647,16 +3883,32 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	__builtin_amdgcn_s_setprio(3);
 	{
 		const CostTable &ctab = ACC ? c_cost_acc : c_cost;
-		for (int i = (int)threadIdx.x; i < 1024; i += 192)
+		for (int i = (int)threadIdx.x; i < 1024; i += 256)
 			s_lut[i] = g_sb_lut.v[i];
-		for (int i = (int)threadIdx.x; i < 2 * kSteps12; i += 192)
+		for (int i = (int)threadIdx.x; i < 2 * kSteps12; i += 256)
 			s_steps[i] = c_steps.w[i / kSteps12][i % kSteps12];
-		for (int i = (int)threadIdx.x; i < 512; i += 192) {
+		for (int i = (int)threadIdx.x; i < 512; i += 256) {
 			s_cost_a[i] = ctab.a[i];
 			s_cost_b[i] = ctab.b[i];
 		}
 	}
 	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
+
+	// ------------------------------------------------------------------ S: the front's helper (LatPre (4))
+	if (wave == 3) {
+		for (int t = 0;; t++) {
+			__syncthreads();
+			if (!s_go[t & 1])
+				break;
+			LoopCo *const co = &s_co[t & 1];
+			const int id = t + 1;
+			const int slot = (t + 2) % 3;                // what P prepared during the last tick
+			if (co->job != id || h_off[slot] != co->off)
+				continue;                                // no burst this tick, or not where it was expected: F works alone
+			loop_front_helper<SPS>(a, co, id, hx0 + slot * stage_al, lane);
+		}
+		return;
+	}
 
 	// ------------------------------------------------------------------ P: pass 2 + operand table, then the next window
 	if (wave == 2) {
@@ -3677,9 +3929,9 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 				pre.vtab = vtab0 + (t & 1) * (kLatTabBytes / 4);
 				const RxIo io = {
 #ifdef GMR1_HIP_PROFILE
-				                 h.stamp,
+				                 reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo),
 #endif
-				                 &h.off, b_kind, &h.fsh, nullptr, nullptr, nullptr, b_rv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+				                 &h.pre.base, b_kind, &h.fsh, nullptr, nullptr, nullptr, b_rv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 				rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 2>(a, io, stage_samples, cw, 0, 1, body_p, lane, &pre);
 			}
 			const uint64_t pred = s_pred[t & 1];
@@ -3715,7 +3967,7 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 				continue;
 			}
 #ifdef GMR1_HIP_PROFILE
-			dpre.stamp = h.stamp;
+			dpre.stamp = reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo);
 			GMR1_DSTAMP(&dpre, 15, lane);
 #endif
 			uint32_t syn, fae;
@@ -3728,22 +3980,25 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			// the feedback as the reference applies it (rx_bcch, gmr1_rx.c:782-791), on the state F started from
 			RxLoopState st = h.pre;
 			const int emit = rx_loop_bcch_result(st, sps, 0, crc, h.toa, h.ffe, reinterpret_cast<const uint8_t *>(v_ubits), h.e_toa);
-			const RxLoopState &sp = h.spec;
-			const bool same = st.align == sp.align && __float_as_uint(st.freq_err) == __float_as_uint(sp.freq_err) &&
-			                  st.fn == sp.fn && st.delay == sp.delay && st.stn == sp.stn;
-			{
-				// the burst's part of the round's log entry (F wrote c_first, c_n, minen, b_frame)
-				uint32_t *d = reinterpret_cast<uint32_t *>(rlog + h.round);
-				uint32_t v = 0;
-				switch (lane) {
-				case 3: v = (uint32_t)emit; break;
-				case 4: v = (uint32_t)st.fn; break;
-				case 5: v = (uint32_t)st.stn; break;
-				case 6: v = fae; break;
-				default: v = (lane >= 8 && lane < 14) ? v_ubits[lane - 8] : 0u; break;
-				}
-				if ((lane >= 3 && lane <= 6) || (lane >= 8 && lane < 14))
-					d[lane] = v;
+			// (F assumed: time and frequency applied, nothing else moved)
+			const bool same = st.align == h.spec_align && __float_as_uint(st.freq_err) == __float_as_uint(h.spec_ferr) &&
+			                  st.fn == h.pre.fn && st.delay == h.pre.delay && st.stn == h.pre.stn;
+			if (lane == 0) {
+				// the round's log entry (the walk's part came with the hand-over)
+				RxLoopRound e;
+				e.c_first = h.c_first;
+				e.c_n = h.c_n;
+				e.minen = h.minen;
+				e.b_emit = emit;
+				e.b_fn = st.fn;
+				e.b_tn = st.stn;
+				e.b_conv = (int32_t)fae;
+				e.b_frame = h.b_frame;
+				uint32_t *l2w = reinterpret_cast<uint32_t *>(e.b_l2);
+#pragma unroll
+				for (int i = 0; i < 6; i++)
+					l2w[i] = v_ubits[i];
+				rlog[h.round] = e;
 			}
 			if (lane == 0) {
 				s_true[t & 1] = st;
@@ -3817,7 +4072,17 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	int n = round < round_end ? list_round() : 0;
 	bool finished = false;
 	int t = 0;
+#ifdef GMR1_HIP_PROFILE
+#define GMR1_FSTAMP(k)                                                             \
+	do {                                                                          \
+		if (chain == 0 && round == kStampRound && lane == 0)                      \
+			g_stamp[k] = __builtin_readcyclecounter();                            \
+	} while (0)
+#else
+#define GMR1_FSTAMP(k) do { } while (0)
+#endif
 	for (;; t++) {
+		GMR1_FSTAMP(16);
 		if (lane == 0) {
 			// where the burst of the round AFTER the one about to run will most likely sit: eight frames on
 			// (a round's BCCH burst is always its last item)
@@ -3829,8 +4094,16 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			}
 			s_pred[t & 1] = pred;
 			s_go[t & 1] = 1;
+			// the helper wave's job of this tick: the burst about to run, if there is one
+			LoopCo &c = s_co[t & 1];
+			const bool job = n > 0 && round < round_end && s_items[n - 1].is_bcch != 0;
+			c.off = job ? st.base + (uint64_t)s_items[n - 1].begin : 0;
+			c.fsh = -st.freq_err;
+			c.job = job ? t + 1 : 0;
 		}
+		bool co_job = n > 0 && round < round_end && s_items[n - 1].is_bcch != 0;
 		__syncthreads();
+		GMR1_FSTAMP(17);
 		const int t3 = t % 3;
 		// ---- the verdict on the hand-over of three ticks ago (V worked on it during the last tick)
 		if (age3 && s_vd[(t - 1) & 1] == kVdSquash) {
@@ -3845,6 +4118,12 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			rx_loop_advance(st, sps);
 			age1 = age2 = false;
 			n = round < round_end ? list_round() : 0;
+			// (the helper wave may have taken up the burst listed before: it is to stop waiting for that front)
+			if (co_job && lane == 0) {
+				s_co[t & 1].p = -1;
+				lds_post(&s_co[t & 1].p_id, t + 1);
+			}
+			co_job = false;
 		}
 		age3 = age2;
 		age2 = age1;
@@ -3859,6 +4138,7 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			}
 			continue;
 		}
+		GMR1_FSTAMP(18);
 		const bool has_b = s_items[n - 1].is_bcch != 0;
 		const int n_c = has_b ? n - 1 : n;
 		// the CCCH bursts: listed for the batch that follows
@@ -3872,6 +4152,7 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		}
 		int b_fn = 0, b_tn = 0, b_frame = 0;
 		bool handed = false;
+		GMR1_FSTAMP(19);
 		if (has_b) {
 			const RxLoopItem it = s_items[n - 1];
 			if (lane == 0) {
@@ -3887,6 +4168,8 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			pre.h_x = hx0 + slot * stage_al;
 			pre.win_w = win0 + slot * kWin;
 			pre.cut = &s_cut[t3];
+			pre.co = co_job ? &s_co[t & 1] : nullptr;
+			pre.co_id = t + 1;
 #ifdef GMR1_HIP_PROFILE
 			unsigned long long *const stamp = (chain == 0 && round == kStampRound) ? g_stamp : nullptr;
 #endif
@@ -3894,37 +4177,50 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 #ifdef GMR1_HIP_PROFILE
 			                 stamp,
 #endif
-			                 s_off, s_kind, s_fs, nullptr, nullptr, nullptr, s_rv, nullptr, s_toa, s_fe, s_en, nullptr, nullptr};
+			                 s_off, s_kind, s_fs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 			rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 1>(a, io, stage_samples, cw, 0, 1, body_f, lane, &pre);
-			WSYNC();
 			b_frame = frames_at_round + it.frames_before;
-			if (!s_rv[0]) {
+			if (pre.out.found) {
 				// found: the feedback as if the CRC passes and SI1 moves nothing -- V will tell (gmr1_rx.c:782-795)
-				st.bcch_energy = s_en[0];
+				st.bcch_energy = pre.out_energy;
 				const RxLoopState before = st;
-				st.align += (int)roundf(s_toa[0]) - it.e_toa;
-				st.freq_err += s_fe[0];
+				st.align += (int)roundf(pre.out.toa) - it.e_toa;
+				st.freq_err += pre.out.ffe;
 				if (lane == 0) {
-					LoopHand &h = s_hand[t3];
-					h.pre = before;
-					h.spec = st;
-					h.round = round;
-					h.e_toa = it.e_toa;
-					h.win = slot;
-					h.toa = s_toa[0];
-					h.ffe = s_fe[0];
-					h.fsh = s_fs[0];
-					h.off = s_off[0];
+					// the hand-over (one lane, wide stores: a value picked per lane compiles to a tree of branches)
+					LoopHand hv;
+					hv.pre = before;
+					hv.spec_align = st.align;
+					hv.spec_ferr = st.freq_err;
+					hv.valid = 1;
+					hv.round = round;
+					hv.e_toa = it.e_toa;
+					hv.win = slot;
+					hv.toa = pre.out.toa;
+					hv.ffe = pre.out.ffe;
+					hv.fsh = -before.freq_err;
+					hv.c_first = n_ccch;
+					hv.c_n = n_c;
+					hv.minen = minen;
+					hv.b_frame = b_frame;
 #ifdef GMR1_HIP_PROFILE
-					h.stamp = stamp;
+					hv.stamp_lo = (uint32_t)(uintptr_t)stamp;
+					hv.stamp_hi = (uint32_t)((uintptr_t)stamp >> 32);
+#else
+					hv.stamp_lo = hv.stamp_hi = 0;
 #endif
-					h.valid = 1;
+					uint4 *dst = reinterpret_cast<uint4 *>(&s_hand[t3]);
+					const uint4 *src = reinterpret_cast<const uint4 *>(&hv);
+#pragma unroll
+					for (int i = 0; i < 7; i++)
+						dst[i] = src[i];
 				}
 				cp_round[t3] = round;
 				cp_frames[t3] = n_frames;
 				cp_ccch[t3] = n_ccch + n_c;
 				handed = true;
 			}
+			GMR1_FSTAMP(20);
 			b_fn = st.fn;
 			b_tn = st.stn;
 			on_frame(st);                                        // rx_tch3 of this frame sees the updated state
@@ -3932,26 +4228,27 @@ __global__ __launch_bounds__(192) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		}
 		if (!handed && lane == 0)
 			s_hand[t3].valid = 0;
-		{
-			// the round's log entry, 14 words: all of it for a round without a burst that was found, else the walk's part
-			uint32_t *d = reinterpret_cast<uint32_t *>(rlog + round);
-			uint32_t v = 0;
-			switch (lane) {
-			case 0: v = (uint32_t)n_ccch; break;
-			case 1: v = (uint32_t)n_c; break;
-			case 2: v = __float_as_uint(minen); break;
-			case 4: v = (uint32_t)b_fn; break;
-			case 5: v = (uint32_t)b_tn; break;
-			case 7: v = (uint32_t)b_frame; break;
-			default: v = 0u; break;
-			}
-			if (lane < 14 && (!handed || lane < 3 || lane == 7))
-				d[lane] = v;
+		GMR1_FSTAMP(21);
+		if (!handed && lane == 0) {
+			// the log entry of a round without a burst that was found (V writes the others)
+			RxLoopRound e = {};
+			e.c_first = n_ccch;
+			e.c_n = n_c;
+			e.minen = minen;
+			e.b_fn = b_fn;
+			e.b_tn = b_tn;
+			e.b_frame = b_frame;
+			rlog[round] = e;
 		}
+		GMR1_FSTAMP(22);
 		n_ccch += n_c;
 		round++;
 		age1 = handed;
 		n = round < round_end ? list_round() : 0;
+#ifdef GMR1_HIP_PROFILE
+		if (chain == 0 && round == kStampRound + 1 && lane == 0)
+			g_stamp[23] = __builtin_readcyclecounter();
+#endif
 	}
 	t++;                                        // one more barrier: P and V leave
 	if (lane == 0)
@@ -4562,10 +4859,10 @@ hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, h
 	do {                                                                                                         \
 		if (!serial) {                                                                                           \
 			if (a.conv_acc)                                                                                      \
-				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, true>), grid, dim3(192), lds_p, stream, a, la, a.stage_samples, cw, \
+				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, true>), grid, dim3(256), lds_p, stream, a, la, a.stage_samples, cw, \
 				                   (int)lds, sl, slice_rounds);                                                  \
 			else                                                                                                 \
-				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, false>), grid, dim3(192), lds_p, stream, a, la, a.stage_samples, cw, \
+				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, false>), grid, dim3(256), lds_p, stream, a, la, a.stage_samples, cw, \
 				                   (int)lds, sl, slice_rounds);                                                  \
 		} else if (a.conv_acc)                                                                                   \
 			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds, \

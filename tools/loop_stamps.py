@@ -40,7 +40,7 @@ for _ in range(5):
 e1.record()
 torch.cuda.synchronize()
 print(f"{A} carriers x {seconds} s: {e0.elapsed_time(e1) / 5:.3f} ms per run (acquisition + loop)")
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 assert L.gmr1_hip_prof_stamps(out) == 0
 t = np.array(list(out), np.int64)
 print("cycle stamps of chain 0's round 55 (shader clock).  The burst runs on three waves, a tick apart: F = front, P = pass 2 + operand table, V = decoder")
@@ -56,3 +56,8 @@ print(f"V: decoder, {t[7] - t[15]} cycles (starts {t[15] - t[0]} after F's start
 print(f"  {'forward pass':38s} +{t[12] - t[15]:6d}")
 print(f"  {'survivor walk':38s} +{t[13] - t[12]:6d}")
 print(f"  {'CRC':38s} +{t[7] - t[13]:6d}")
+print(f"F's tick around that front (walk, hand-over, listing): {t[23] - t[16]} cycles")
+for name, k, k0 in [("pred published, barrier passed", 17, 16), ("verdict checked", 18, 17), ("CCCH bursts listed (global)", 19, 18),
+                    ("burst operands set, front started", 0, 19), ("front", 4, 0), ("results read, feedback assumed, hand-over written", 20, 4),
+                    ("frame logged, chain advanced", 21, 20), ("round logged (global)", 22, 21), ("next round listed", 23, 22)]:
+    print(f"  {name:50s} +{t[k] - t[k0]:6d}")
