@@ -325,6 +325,7 @@ def run_rx_workload(args):
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     rec, status, chains, found = res[0]
+    phases = api.rx_run_last_timing()            # of the last step (the library's own clock around its phases)
     out = {"metric": "Mbursts/s demod+Viterbi (and IQ Msamp/s), 1/2/4/8 MI355X", "value": A * ns * args.steps / wall / 1e6,
            "unit": "Msamp/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -344,6 +345,7 @@ def run_rx_workload(args):
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                        "kernel_ms": step_s * 1e3, "algorithmic_bytes_per_launch": alg,
                        "note": "latency-bound feedback chain: 187 dependent BCCH bursts per carrier-minute"}
+    out["phases_ms"] = {k: round(v, 4) for k, v in phases.items()}
     if not args.no_cpu:
         oracle_lib.lib()
         tc = time.perf_counter()
@@ -740,6 +742,17 @@ def run_nt3_workload(args):
     good = h_crc == 0
     out["checks"].update(speech_class1_recovered_frac=float(c1.mean()), facch3_crc_pass_frac=float(good.mean()),
                          facch3_payloads_match_sent=bool(np.array_equal(h_l2[good], wl["l2"][:m_fg][good])))
+    # ~59 % at every SNR is not a decoder defect: it is the reference's sync search, reproduced on purpose
+    sent1 = wl["sync_id"][:m_fg] == 1
+    out["checks"].update(
+        facch3_crc_pass_frac_groups_sent_with_sequence_0=float(good[~sent1].mean()) if (~sent1).any() else None,
+        facch3_crc_pass_frac_groups_sent_with_sequence_1=float(good[sent1].mean()) if sent1.any() else None,
+        facch3_pass_explained="the reference never clears its sync-correlation accumulator between training sequences "
+                              "(pi4cxpsk.c:206-237): the NT3 FACCH format's second sequence is ranked on |c0| + |c1| and always "
+                              "wins, so the groups SENT with sequence 0 (half of this workload) are demodulated against the "
+                              "wrong phase reference and mostly fail; oracle and product reproduce that bit for bit.  With the "
+                              "sent sequence forced both decode ~100 % at 20 dB: "
+                              "tests/test_gpu_l1_tch.py::test_facch3_pass_rate_is_the_reference_sync_ranking_not_the_decoder")
     if not args.no_cpu and world == 1:
         import oracle_lib
         oracle_lib.lib()
@@ -842,6 +855,66 @@ def time_legacy_calls(api, wl, oracle_lib, m=600):
     return {"us_per_demod_decode_pair": t_gpu / m * 1e6, "oracle_us_per_pair": t_cpu / m * 1e6, "bursts": m,
             "identical_to_oracle": bool(np.array_equal(crc, ref_crc) and np.array_equal(l2[ok], ref_l2[ok])),
             "note": "blocking one-burst calls with host pointers, through ctypes on both sides; a carrier-minute is about 1300 pairs"}
+
+
+def rocm_smi_state(dev_index):
+    """Clocks, power and performance level as rocm-smi reports them (None where the tool is absent or refuses)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "-d", str(dev_index), "--showclocks", "--showpower", "--showperflevel", "--showmaxpower", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        js = json.loads(r.stdout)
+        card = next(iter(js.values())) if js else {}
+        keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "power", "performance level"))}
+        return keep or None
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+SIDE_WORKLOADS = (
+    # key, bench arguments, what "identical to the oracle" means in that workload's checks
+    ("nt3", ["--workload", "nt3"], lambda c: bool(c.get("speech_frames_identical_to_oracle") and c.get("facch3_identical_to_oracle"))),
+    ("tch3", ["--workload", "tch3"], lambda c: bool(c.get("frames_identical_to_oracle") and c.get("conv_identical"))),
+    ("rx_64x60s", ["--workload", "rx"], lambda c: bool(c.get("frames_identical_to_oracle"))),
+    ("fcch", ["--workload", "fcch"], lambda c: bool(c.get("toa_identical_to_oracle"))),
+    ("chan", ["--workload", "chan"], lambda c: c.get("max_abs_err_vs_oracle") is not None and c["max_abs_err_vs_oracle"] < 2e-4),
+)
+
+
+def side_workloads(args):
+    """The other BASELINE configs at their full sizes, each as `python bench.py --workload X` in a child process (the GPU is
+    idle by now; one child at a time): {ms, frac, identical_to_oracle, ...} per workload."""
+    import subprocess
+    side = {}
+    t_all = time.perf_counter()
+    for key, argv, same in SIDE_WORKLOADS:
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(min(args.steps, 50)), "--warmup", "3",
+                                                                    "--preroll-s", str(min(args.preroll_s, 0.2)),
+                                                                    "--conv-decoder", args.conv_decoder]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=100)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rf = d.get("roofline") or {}
+            side[key] = {"ms": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "frac": rf.get("frac"), "bound": rf.get("bound"),
+                         "identical_to_oracle": same(d.get("checks") or {}), "workload": (d.get("config") or {}).get("workload"),
+                         "wall_s": round(time.perf_counter() - t0, 1)}
+            for k in ("gpu_vs_all_cores", "phases_ms"):
+                if k in d:
+                    side[key][k] = d[k]
+            if key == "chan":
+                side[key]["max_abs_err_vs_oracle"] = (d.get("checks") or {}).get("max_abs_err_vs_oracle")
+                side[key]["identical_to_oracle_means"] = "within 2e-4 of the numpy oracle (floating point)"
+        except Exception as e:
+            side[key] = {"error": repr(e), "wall_s": round(time.perf_counter() - t0, 1)}
+    side["wall_s"] = round(time.perf_counter() - t_all, 1)
+    side["what"] = ("every other BASELINE config on this box, after the timed region, one `python bench.py --workload X` child "
+                    "each: ms per step, fraction of the 8 TB/s roof, and whether the outputs equal the CPU oracle's")
+    return side
 
 
 def free_port():
@@ -1248,6 +1321,14 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    clock = {}
+    try:
+        clock["shader_mhz_before_timed_region"] = round(api.clock_probe_dev(stream.cuda_stream, 100)[0], 1)
+        for _ in range(3):                      # (the probe idled the GPU for 0.1 ms: back to the steady state)
+            step()
+        torch.cuda.synchronize()
+    except Exception as e:
+        clock["error"] = repr(e)
 
     # ---- timed region ---------------------------------------------------------------------
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -1264,6 +1345,18 @@ def main():
     t1 = time.perf_counter()
     wall = t1 - t0
     kern_ms = ev0.elapsed_time(ev1) / args.steps      # one launch per step
+    # the shader clock the steps just ran at, read on the device right behind them (DVFS moves in milliseconds), and what
+    # the driver says about the part: boxes of the pool hold different clocks under this load
+    try:
+        mhz, wall_mhz = api.clock_probe_dev(stream.cuda_stream, 100)
+        clock["shader_mhz_after_timed_region"] = round(mhz, 1)
+        clock["wall_counter_mhz"] = wall_mhz
+        props = torch.cuda.get_device_properties(dev)
+        clock["device"] = props.name
+        clock["max_shader_mhz"] = getattr(props, "clock_rate", 0) / 1e3 or None
+        clock["compute_units"] = props.multi_processor_count
+    except Exception as e:
+        clock["error"] = repr(e)
 
     if grouped:
         import torch.distributed as dist
@@ -1370,7 +1463,11 @@ def main():
                      "traffic_source": traffic_note, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         "checks": {"crc_pass_frac": decoded_frac, "payloads_match_sent": payload_ok,
                    "workload_gen_s": round(t_gen, 1)},
+        "clock": clock,
     }
+    smi = rocm_smi_state(dev_index)
+    if smi:
+        out["clock"]["rocm_smi"] = smi
     out["config"]["layout"] = args.layout
     if "planar" in extras:
         ms_pl, same = extras["planar"]
@@ -1432,6 +1529,10 @@ def main():
         out["checks"]["gpu_vs_oracle_crc_identical"] = same_crc
         out["checks"]["gpu_vs_oracle_payloads_identical"] = same_l2
         out["legacy_one_burst_calls"] = time_legacy_calls(api, wl, oracle_lib)
+    # ---- every other BASELINE config in the same record (never part of `value`): one subprocess each, after everything
+    # above; what each reports is its own bench line's ms per step, roofline fraction and oracle comparison
+    if world == 1 and not args.no_extras and not args.no_cpu and not grouped:
+        out["side"] = side_workloads(args)
     if dog is not None:
         line.update(out)
         dog.start()

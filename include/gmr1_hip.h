@@ -85,6 +85,10 @@ int         gmr1_hip_init(int device);          /* optional; selects the HIP dev
 const char *gmr1_hip_last_error(void);
 const char *gmr1_hip_version(void);
 int         gmr1_hip_burst_info(int burst_id, struct gmr1_hip_burst_flat *out);
+/* Measurement aid (no counterpart in the reference): the shader clock the device holds right now, in MHz -- one wave on
+ * `stream` compares the shader-clock counter with the constant-rate wall counter over `micros` microseconds (blocking).
+ * Launched behind a timed region it tells what clock that region ran at.  wall_mhz (optional): the wall counter's rate. */
+int         gmr1_hip_clock_probe_dev(void *stream, int micros, double *core_mhz, double *wall_mhz);
 
 /* ---- which Viterbi decoder of libosmocore the layer-1 chains reproduce ------
  * The reference hands every channel to osmo_conv_decode() (src/l1/bcch.c:94, ccch.c:98, facch3.c:160, tch3.c:174,
@@ -449,6 +453,12 @@ struct gmr1_hip_rx_big_record {
 	int32_t  conv;
 	uint8_t  l2[64];
 };
+/* Measurement aid: wall time, in microseconds, of the phases of the calling thread's last gmr1_hip_rx_run* call --
+ * [0] FCCH acquisition (main() -> fcch_single_init / fcch_multi_process, gmr1_rx.c:605-744) incl. its decisions on the host,
+ * [1] the frame loop (process_bcch, :852-895) from its first launch until its kernels are through, [2] the records to the
+ * caller's buffer, [3] host work around the loop, [4] the traffic-channel passes. */
+int gmr1_hip_rx_run_last_timing(double *us5);
+
 int gmr1_hip_rx_run_full_dev(void *stream, int n_arfcn, int sps, const float *iq, const float *tch,
                              const float *csd, const uint64_t *offset, const uint64_t *length,
                              const uint16_t *arfcn, const uint8_t *kc,

@@ -92,20 +92,20 @@ def pre_resampler_taps(nfilt: int = 32) -> np.ndarray:
     """Prototype of the 32-phase PRE-resampler in front of the filterbank (gmr1_rx_sdr.py:453-461:
     pfb.arb_resampler_ccf(rate, taps=None, flt_size=32), rate = n_chans x chan_width / samp_rate, always > 1).
     With taps=None GNU Radio designs the prototype itself -- for rates >= 1 with its Parks-McClellan routine
-    (optfir.low_pass, pass band 0.8 x half the input band, transition 0.4 x half the input band, 100 dB), whose
-    iteration is not restatable here.  OWN DESIGN, same band edges (flat to 0.4 of the input rate, stop band from
-    0.6), window method: a Blackman-Harris windowed sinc, gain nfilt, at nfilt x the input rate, the -6 dB point in the
-    middle of that transition band (0.5), transition width 0.2, tap count int(100 fs / (22 tw)) | 1 = 727 (23 taps per
-    phase) -- firdes.low_pass_2's recipe."""
-    fs, cutoff, tw, atten = float(nfilt), 0.5, 0.2, 100.0
-    ntaps = int(atten * fs / (22.0 * tw)) | 1
+    (optfir.low_pass, pass band 0.8 x half the input band, transition 0.4 x half the input band, 0.1 dB / 100 dB), whose
+    iteration is not restatable here.  OWN DESIGN to the same specification (within 0.1 dB to 0.4 of the input rate, at
+    least 100 dB down from 0.6; tests/test_oracle_chan.py holds it), window method: a Kaiser-windowed sinc (beta 11), gain
+    nfilt, at nfilt x the input rate, 30 taps per phase (959), the -6 dB point at 0.482.  Same specification, not the
+    same taps: comparable with a GNU Radio run in spectrum, not sample by sample."""
+    fs, cutoff, beta = float(nfilt), 0.482, 11.0
+    ntaps = 30 * nfilt - 1
     M = (ntaps - 1) // 2
     n = np.arange(-M, M + 1, dtype=np.float64)
     fw = 2.0 * np.pi * cutoff / fs
+    win = np.i0(beta * np.sqrt(np.maximum(0.0, 1.0 - (n / M) ** 2))) / np.i0(beta)
     with np.errstate(invalid="ignore", divide="ignore"):
-        taps = np.where(n == 0, fw / np.pi, np.sin(n * fw) / (n * np.pi)) * blackman_harris(ntaps)
-    fmax = taps[M] + 2.0 * taps[M + 1:].sum()
-    return (taps * (nfilt / fmax)).astype(np.float32)
+        taps = np.where(n == 0, fw / np.pi, np.sin(n * fw) / (n * np.pi)) * win
+    return (taps * (nfilt / taps.sum())).astype(np.float32)
 
 
 # --------------------------------------------------------------------------- plan

@@ -19,7 +19,7 @@ BURST_IDS = ["bcch", "dc2", "dc6", "dc12", "nt3_speech", "nt3_facch", "nt6", "nt
 # every symbol include/gmr1_hip.h and include/osmocom/gmr1/**.h declare
 EXPORTED_FUNCTIONS = [
     "gmr1_hip_init", "gmr1_hip_last_error", "gmr1_hip_version", "gmr1_hip_burst_info",
-    "gmr1_hip_set_conv_decoder", "gmr1_hip_get_conv_decoder",
+    "gmr1_hip_set_conv_decoder", "gmr1_hip_get_conv_decoder", "gmr1_hip_clock_probe_dev", "gmr1_hip_rx_run_last_timing",
     "gmr1_hip_demod_batch_dev", "gmr1_hip_demod_batch",
     "gmr1_hip_bcch_decode_batch_dev", "gmr1_hip_ccch_decode_batch_dev",
     "gmr1_hip_bcch_decode_batch", "gmr1_hip_ccch_decode_batch",
@@ -197,6 +197,15 @@ def init(device: int = 0):
     _check(load().gmr1_hip_init(C.c_int(device)), "gmr1_hip_init")
 
 
+def clock_probe_dev(stream, micros=200):
+    """(shader clock held right now in MHz, wall counter rate in MHz), measured on the device behind what `stream` holds."""
+    core, wall = C.c_double(), C.c_double()
+    f = load().gmr1_hip_clock_probe_dev
+    f.restype = C.c_int
+    _check(f(C.c_void_p(stream), C.c_int(micros), C.byref(core), C.byref(wall)), "gmr1_hip_clock_probe_dev")
+    return core.value, wall.value
+
+
 # ---------------------------------------------------------------------------
 # host-pointer batch calls (numpy in, numpy out)
 # ---------------------------------------------------------------------------
@@ -273,18 +282,22 @@ def rx_bcch_ccch_batch(iq, offset, kind, sps=4, freq_shift=None, want_ebits=True
 # ---------------------------------------------------------------------------
 # reference-style single-burst calls (the legacy C API, through ctypes)
 # ---------------------------------------------------------------------------
-def pi4cxpsk_demod(burst_name: str, iq, sps=4, freq_shift=0.0):
-    """gmr1_pi4cxpsk_demod(&gmr1_<name>_burst, cxvec, ...) exactly as C callers use it."""
+def pi4cxpsk_demod(burst_name, iq, sps=4, freq_shift=0.0):
+    """gmr1_pi4cxpsk_demod(&gmr1_<name>_burst, cxvec, ...) exactly as C callers use it; burst_name may also be a
+    CallerBurst (the caller's own description of a format)."""
     L = load()
-    bt = C.c_void_p.in_dll(L, f"gmr1_{burst_name}_burst")   # address of the exported struct
-    info = burst_info(burst_name)
+    if isinstance(burst_name, CallerBurst):
+        bt_addr, n_eb = burst_name.address, int(burst_name.burst.ebits)
+    else:
+        bt = C.c_void_p.in_dll(L, f"gmr1_{burst_name}_burst")   # address of the exported struct
+        bt_addr, n_eb = C.addressof(bt), burst_info(burst_name).ebits
     iq = np.ascontiguousarray(iq, np.complex64)
     vec = CxVec(iq.size, iq.size, 0, iq.ctypes.data_as(C.c_void_p))
-    eb = np.zeros(info.ebits, np.int8)
+    eb = np.zeros(n_eb, np.int8)
     sid, toa, fe = C.c_int(-1), C.c_float(), C.c_float()
     f = L.gmr1_pi4cxpsk_demod
     f.restype = C.c_int
-    rv = f(C.c_void_p(C.addressof(bt)), C.byref(vec), C.c_int(sps), C.c_float(freq_shift),
+    rv = f(C.c_void_p(bt_addr), C.byref(vec), C.c_int(sps), C.c_float(freq_shift),
            eb.ctypes.data_as(C.c_void_p), C.byref(sid), C.byref(toa), C.byref(fe))
     return dict(rv=rv, ebits=eb, sync_id=sid.value, toa=toa.value, freq_err=fe.value)
 
@@ -772,6 +785,14 @@ def rx_run_dev_prepared(stream, iq_ptr, offset, length, out, sps=4, arfcn=None):
         return out[:min(n_rec.value, out.size)], status[:n], chains[:n], n_rec.value
     call.keep = keep
     return call
+
+
+def rx_run_last_timing():
+    """Phases of this thread's last rx_run* call in ms: acquisition, frame loop (kernels), records hand-back, host work around
+    the loop, traffic-channel passes."""
+    us = (C.c_double * 5)()
+    _check(load().gmr1_hip_rx_run_last_timing(us), "gmr1_hip_rx_run_last_timing")
+    return dict(zip(("acquisition_ms", "chain_ms", "handback_ms", "host_ms", "traffic_passes_ms"), [v / 1e3 for v in us]))
 
 
 def rx_run_dev_raw(stream, iq_ptr, offset, length, out_ptr, max_records, sps=4, arfcn=None):

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgmr1_hip.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["rx_kernels.hip", "fcch_kernels.hip", "l1_kernels.hip", "tch_kernels.hip", "chan_kernels.hip", "nt9_kernels.hip", "xch_kernels.hip", "tx_kernels.hip", "ambe_kernels.hip"]
+HIP_SOURCES = ["rx_kernels.hip", "fcch_kernels.hip", "l1_kernels.hip", "tch_kernels.hip", "chan_kernels.hip", "nt9_kernels.hip", "xch_kernels.hip", "tx_kernels.hip", "ambe_kernels.hip", "util_kernels.hip"]
 CXX_SOURCES = ["capi.cpp", "capi_fcch.cpp", "capi_l1.cpp", "capi_detect.cpp", "capi_rx.cpp", "capi_tch.cpp", "capi_chan.cpp", "capi_nt9.cpp", "capi_xch.cpp", "capi_tx.cpp", "host_tables.cpp", "l1_tables.cpp", "l1_punct.cpp", "capi_shard.cpp", "capi_ambe.cpp", "ambe_tables.cpp"]
 
 COMMON = [
@@ -40,8 +40,18 @@ def sources():
     return out
 
 
+def _lib_stamp(lib: str) -> str:
+    return lib + ".flags"
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
+        return True
+    # built by another compiler or with other flags: rebuild even if no source changed
+    import hashlib
+    want = hashlib.sha256(_toolchain_id().encode()).hexdigest()
+    stamp = _lib_stamp(LIB)
+    if not os.path.exists(stamp) or open(stamp).read().strip() != want:
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
@@ -107,6 +117,8 @@ def _build(lib: str, extra, suffix: str, verbose: bool, force: bool = False) -> 
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(_lib_stamp(LIB), "w") as fh:
+        fh.write(hashlib.sha256(tool.encode()).hexdigest() + "\n")
     return LIB
 
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <strings.h>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -52,8 +53,16 @@ int conv_acc()
 	if (v < 0) {
 		// default: what osmo_conv_decode() of every libosmocore since 0.10 (2017) runs for the K = 5 / 7, N <= 4 codes
 		// (INTEGRATION.md "Which Viterbi decoder"); GMR1_HIP_CONV_DECODER=generic selects the older behaviour
+		// Accepted spellings, case-insensitive: "generic" / "0", "acc" / "1"; anything else is reported once on stderr and
+		// the default stands (a misspelt "Generic" must not silently select the other decoder).
 		const char *e = getenv("GMR1_HIP_CONV_DECODER");
-		v = (e && (!strcmp(e, "generic") || !strcmp(e, "0"))) ? GMR1_HIP_CONV_GENERIC : GMR1_HIP_CONV_ACC;
+		v = GMR1_HIP_CONV_ACC;
+		if (e && *e) {
+			if (!strcasecmp(e, "generic") || !strcmp(e, "0"))
+				v = GMR1_HIP_CONV_GENERIC;
+			else if (strcasecmp(e, "acc") && strcmp(e, "1"))
+				fprintf(stderr, "libgmr1_hip: GMR1_HIP_CONV_DECODER=\"%s\" is neither generic / 0 nor acc / 1: using acc\n", e);
+		}
 		int expect = -1;
 		if (!g_conv_decoder.compare_exchange_strong(expect, v))
 			v = expect;
@@ -180,7 +189,7 @@ extern "C" {
 const char *gmr1_hip_version(void)
 {
 	// names the Viterbi decoder in force at the time of the call (gmr1_hip_set_conv_decoder)
-	return conv_acc() ? "gmr1-hip 0.2 (gfx950; conv decoder: acc)" : "gmr1-hip 0.2 (gfx950; conv decoder: generic)";
+	return conv_acc() ? "gmr1-hip 0.3 (gfx950; conv decoder: acc)" : "gmr1-hip 0.3 (gfx950; conv decoder: generic)";
 }
 const char *gmr1_hip_last_error(void) { return last_error(); }
 

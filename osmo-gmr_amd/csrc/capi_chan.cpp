@@ -112,27 +112,40 @@ struct ChanPlan {
 // The prototype of the pre-resampler (utils/gmr1_rx_sdr.py:453-461: pfb.arb_resampler_ccf(rate, taps=None, flt_size=32)).
 // With taps=None GNU Radio designs it itself, for rates >= 1 -- the only case here: n_chans x 31250 >= samp_rate -- with
 // its Parks-McClellan routine (pass band to 0.4 of the input rate, stop band from 0.6, 100 dB), which cannot be
-// restated without gr-filter.  OWN DESIGN with the same band edges by the window method (firdes.low_pass_2's recipe):
-// Blackman-Harris windowed sinc at 32 x the input rate, gain 32, -6 dB at 0.5, transition width 0.2,
-// int(100 fs / (22 tw)) | 1 = 727 taps.  oracle/orc_chan.py: pre_resampler_taps.
+// restated without gr-filter.  OWN DESIGN to the same specification by the window method, at 32 x the input rate, gain 32
+// (round 5: the Blackman-Harris design of round 4 had its -6 dB point at 0.5 and was only 36 dB down at 0.6 -- found by
+// the test that now holds the specification).  oracle/orc_chan.py: pre_resampler_taps.
 std::vector<float> design_pre_resampler(int nfilt)
 {
-	const double fs = nfilt, cutoff = 0.5, tw = 0.2, atten = 100.0;
-	const int ntaps = (int)(atten * fs / (22.0 * tw)) | 1;
+	// Kaiser-windowed sinc, 30 taps per phase (what k_resamp<30, ...> holds), beta = 11, -6 dB point at 0.482 of the input
+	// rate: within 0.06 dB up to 0.4 and more than 107 dB down from 0.6 (tests/test_oracle_chan.py checks the specification
+	// GNU Radio runs its Parks-McClellan design with: 0.1 dB / 100 dB at those edges)
+	const double fs = nfilt, cutoff = 0.482, beta = 11.0;
+	const int ntaps = 30 * nfilt - 1;
 	const int M = (ntaps - 1) / 2;
+	auto bessel_i0 = [](double x) {
+		double sum = 1.0, term = 1.0;
+		const double q = x * x / 4.0;
+		for (int k = 1; k < 200; k++) {
+			term *= q / ((double)k * (double)k);
+			sum += term;
+			if (term < 1e-18 * sum)
+				break;
+		}
+		return sum;
+	};
 	std::vector<double> t(ntaps);
-	const double fw = 2.0 * M_PI * cutoff / fs;
+	const double fw = 2.0 * M_PI * cutoff / fs, i0b = bessel_i0(beta);
+	double sum = 0.0;
 	for (int n = -M; n <= M; n++) {
-		const double a = 2.0 * M_PI * (double)(n + M) / (double)(ntaps - 1);
-		const double w = 0.35875 - 0.48829 * std::cos(a) + 0.14128 * std::cos(2 * a) - 0.01168 * std::cos(3 * a);
+		const double r = (double)n / (double)M;
+		const double w = bessel_i0(beta * std::sqrt(std::max(0.0, 1.0 - r * r))) / i0b;
 		t[n + M] = (n == 0 ? fw / M_PI : std::sin(n * fw) / (n * M_PI)) * w;
+		sum += t[n + M];
 	}
-	double fmax = t[M];
-	for (int n = 1; n <= M; n++)
-		fmax += 2.0 * t[n + M];
 	std::vector<float> out(ntaps);
 	for (int i = 0; i < ntaps; i++)
-		out[i] = (float)(t[i] * ((double)nfilt / fmax));
+		out[i] = (float)(t[i] * ((double)nfilt / sum));
 	return out;
 }
 

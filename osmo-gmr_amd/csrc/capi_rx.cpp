@@ -183,7 +183,8 @@ struct RxRun {
 	std::vector<int> align, base_align;
 	std::vector<float> ferr;
 	std::vector<RxChain> chains;
-	double t_loop_gpu_us = 0;                // profiling: launch to log-on-host
+	double t_loop_gpu_us = 0;                // launch to log-on-host
+	double t_chain_us = 0;                   // ... of which: launches until the loop's kernels are through (counters on the host)
 	// hand-back of a plain BCCH / CCCH run (no traffic follow-up): the records are closed up on the device in the order
 	// they are returned in (k_rx_pack) and copied ONCE, as many as there are -- straight into the caller's buffer when
 	// that is device memory or pinned host memory, else through the library's pinned block
@@ -226,6 +227,9 @@ static int acq_scratch(size_t bytes, unsigned char **out)
 	*out = static_cast<unsigned char *>(b.p);
 	return 0;
 }
+
+// wall time of the phases of this thread's last gmr1_hip_rx_run* call, microseconds (gmr1_hip_rx_run_last_timing)
+static thread_local double t_last_timing[5] = {0, 0, 0, 0, 0};
 
 int RxRun::acquire()
 {
@@ -492,6 +496,7 @@ int RxRun::frame_loop()
 		// counters and states first (a few KB), then exactly the records there are
 		HIP_TRY(hipMemcpyAsync(h + o_cnt, d + o_cnt, cnt_bytes + st_bytes, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
+		t_chain_us = (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_start).count() / 1e3;
 		const int n_total = reinterpret_cast<const int32_t *>(h + o_cnt)[3 * nc];
 		if (n_total < 0 || (size_t)n_total > (size_t)nc * rec_stride)
 			return fail(-EIO, "rx loop: packed record count %d out of range", n_total);
@@ -1089,6 +1094,15 @@ int rx_run_full_impl(void *stream_, int n_arfcn, int sps, const float *iq, const
 	const auto t2 = now();
 	if (tch && (r = run.tch3_pass())) return r;
 	if (csd && (r = run.tch9_pass())) return r;
+	{
+		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+		const double chain = run.t_chain_us > 0 ? run.t_chain_us : run.t_loop_gpu_us;
+		t_last_timing[0] = us(t0, t1);                              // FCCH acquisition incl. its decisions on the host
+		t_last_timing[1] = chain;                                   // frame loop: launches until its kernels are through
+		t_last_timing[2] = run.t_loop_gpu_us - chain;               // records to the caller's buffer
+		t_last_timing[3] = us(t1, t2) - run.t_loop_gpu_us;          // host work around the loop (chains set up, states read)
+		t_last_timing[4] = us(t2, now());                           // traffic-channel passes
+	}
 	if (timing) {
 		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
 		fprintf(stderr, "rx_run: acquire %.0f us, frame loop %.0f us (launch+copy %.0f, collect %.0f), traffic passes %.0f us\n",
@@ -1146,6 +1160,15 @@ int rx_run_dev_counted(void *stream, int n_arfcn, int sps, const float *iq, cons
 }  // namespace gmr1
 
 extern "C" {
+
+int gmr1_hip_rx_run_last_timing(double *us5)
+{
+	if (!us5)
+		return -EINVAL;
+	for (int i = 0; i < 5; i++)
+		us5[i] = t_last_timing[i];
+	return 0;
+}
 
 int gmr1_hip_rx_run_full_dev(void *stream_, int n_arfcn, int sps, const float *iq, const float *tch,
                              const float *csd, const uint64_t *offset, const uint64_t *length,

@@ -54,7 +54,11 @@ __device__ __forceinline__ float lane_xor(float v)
 // one decimation-in-frequency stage over the lanes: pairs (l, l ^ SPAN); the lane without the bit keeps a + b, the other
 // (a - b) * w, w = e^{-j 2 pi (l mod SPAN) / (2 SPAN)}.  Without selects: every lane forms partner + sg * own (sg = +1 in
 // the lane without the bit, -1 in the other: exact, a product with +-1) and multiplies by (wr, wi), which is (1, 0) in the
-// lanes without the bit -- the same values as choosing between the two forms afterwards, down to the sign of a zero.
+// lanes without the bit -- for finite samples the same values as choosing between the two forms afterwards (a sum's -0
+// can come out +0).  NOT for non-finite ones: dr * 1 - di * 0 turns an Inf or NaN in ONE component of a clipped or
+// corrupt sample into NaNs in BOTH (Inf * 0), where a select would have passed the other component through; such a
+// sample poisons the output instants its filter taps reach either way (tests/test_gpu_chan.py: the other instants stay
+// exact).
 template <int SPAN>
 __device__ __forceinline__ void dif_stage(float &re, float &im, float sg, float wr, float wi)
 {

@@ -1849,7 +1849,9 @@ struct Lds4 {
 	uint32_t *ubits;
 };
 
-__host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t *off, bool gen = false, bool ub_over = false)
+// (ebrow, gen only: bytes between the four soft-bit rows -- rx4_body's EBROW)
+__host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t *off, bool gen = false, bool ub_over = false,
+                                              int ebrow = 432)
 {
 	// pass 1 keeps only the sync-chunk windows of the burst in LDS (everything else it needs is in
 	// registers; pass 2 re-reads from L2).  Decode-time data overlays all of it:
@@ -1871,7 +1873,7 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
 		// demodulation only (k_rx4g): no layer-1 data; the soft-bit rows overlay the pass-1 data, which is dead by then
 		off[3] = 0;
 		const size_t p1 = stage_bytes + corr_bytes + 18 * 8;
-		const size_t p2 = 4 * 432 + kSbLutBytes;      // pass 2: soft-bit rows, then the soft-bit table
+		const size_t p2 = 4 * (size_t)ebrow + kSbLutBytes;      // pass 2: soft-bit rows, then the soft-bit table
 		// the small formats' pass 1 (one burst per row): 4 x 64 staged samples, 4 x <= 128 correlation values, 4 x 16 coefficients
 		const size_t p3 = 4 * 64 * 8 + 4 * 128 * 4 + 4 * 16 * 8;
 		const size_t m = p1 > p2 ? p1 : p2;
@@ -2256,7 +2258,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	constexpr int NSH = SMALL ? 1 : 2;                // 16-symbol pieces of the sync sequence
 	size_t off[4];
 	constexpr bool UB_OVER = !LAT && !GEN;
-	lds4_layout(stage_samples, cw, off, GEN, UB_OVER);
+	lds4_layout(stage_samples, cw, off, GEN, UB_OVER, EBROW);
 	Lds4 L;
 	L.x = reinterpret_cast<float2 *>(lds_raw + off[0]);
 	L.corr = reinterpret_cast<float *>(lds_raw + off[1]);
@@ -4752,16 +4754,13 @@ hipError_t launch_rx_tch3(const RxArgs &a, const Tch3Args &t, hipStream_t stream
 		return hipErrorInvalidValue;
 	const int cw = (a.in_len[0] - a.ssyms_stride * 4 + 1 + 15) & ~15;          // lags (ssyms_stride = symbols per burst)
 	size_t off4[4];
-	// the demodulator's phases (pass 1: staged windows, correlation, coefficients; pass 2: four 216-byte soft-bit rows and
-	// the soft-bit table) and, after them, the rows + the decoder's tables
-	size_t lds = 4 * 64 * 8 + 4 * 128 * 4 + 4 * 16 * 8;                  // rx4_body's small-format pass 1 (lds4_layout, gen)
-	const size_t p2 = 4 * 216 + kSbLutBytes;
-	if (lds < p2)
-		lds = p2;
+	// the demodulator's phases as rx4_body<8, 4, GEN, ..., EBROW = 216> carves them (pass 1: staged windows, correlation,
+	// coefficients; pass 2: four 216-byte soft-bit rows and the soft-bit table) -- the same function sizes them here --
+	// and, after them, the rows + the decoder's tables
+	size_t lds = lds4_layout(a.stage_samples, cw, off4, true, false, 216);
 	const size_t need = 4 * 216 + sizeof(t3::Tch3Lds);
 	if (lds < need)
 		lds = need;
-	(void)off4;
 	{
 		static size_t pad = (size_t)-1;     // profiling only: extra LDS per wave to cap the occupancy
 		if (pad == (size_t)-1) {

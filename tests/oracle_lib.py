@@ -231,8 +231,9 @@ def deinterleave_intra(x, N):
 
 # ---- sdr ----------------------------------------------------------------------
 def demod(bt, iq, sps, freq_shift=0.0):
-    """single-burst demod -> dict(rv, ebits, sync_id, toa, freq_err, ssyms)."""
-    b = burst(bt)
+    """single-burst demod -> dict(rv, ebits, sync_id, toa, freq_err, ssyms).  bt: a name / id of the oracle's table, or a
+    Burst structure of the caller's (pointer)."""
+    b = burst(bt) if isinstance(bt, (str, int)) else bt
     iq = np.ascontiguousarray(iq, np.complex64)
     eb = np.zeros(b.contents.ebits, np.int8)
     ss = np.zeros(b.contents.len, np.float32)

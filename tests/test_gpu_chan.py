@@ -287,3 +287,27 @@ def test_channelizer_planar_output_feeds_planar_receive(gpu_api, pkg):
         assert np.abs(a[:, :n_out]).max() > 0
     with pytest.raises(Exception):
         gpu_api.channelize_planar_dev(None, t.data_ptr(), n, FS, chans, planes.data_ptr(), stride, 10, sps=4)
+
+
+def test_non_finite_sample_poisons_only_the_instants_its_taps_reach(gpu_api):
+    """A clipped / corrupt capture: one sample with an Inf in one component and a NaN in the other.  The filterbank's
+    select-free DFT stages spread a non-finite component over both components of what they touch (chan_kernels.hip:
+    dif_stage) -- but only over the output instants whose filter taps reach that sample: everything before and well after
+    it is bit-identical to the clean capture's output."""
+    rng = np.random.default_rng(8)
+    n = 400000
+    x = (rng.standard_normal((n, 2)) * 0.3).astype(np.float32).view(np.complex64).reshape(-1)
+    bad = x.copy()
+    k = n // 2
+    bad[k] = np.complex64(complex(np.inf, np.nan))
+    chans = [3, 40, 63]
+    good = gpu_api.channelize(x, FS, chans)
+    got = gpu_api.channelize(bad, FS, chans)
+    for g, b in zip(good, got):
+        m = g.size
+        centre = int(k * m / n)
+        # filter spans: 1025-tap prototype at 2 Msps + the resampler's 11 symbols -- a few hundred output samples at most
+        lo, hi = centre - 400, centre + 400
+        assert np.array_equal(g[:lo], b[:lo]) and np.array_equal(g[hi:], b[hi:])
+        assert not np.isfinite(b[lo:hi]).all()
+        assert np.isfinite(b[:lo]).all() and np.isfinite(b[hi:]).all()

@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+import workloads
+
 pytestmark = pytest.mark.gpu
 
 
@@ -220,3 +222,65 @@ def test_tch3_rx_one_launch_equals_demod_then_decode(gpu_api, orc, pkg, decoder)
     lean = gpu_api.tch3_rx_batch(iq, off, 474, sps=4, freq_shift=fs, m=0, want_ebits=False)
     full = gpu_api.tch3_rx_batch(iq, off, 474, sps=4, freq_shift=fs, m=0)
     assert np.array_equal(lean["frame0"], full["frame0"]) and np.array_equal(lean["frame1"], full["frame1"])
+
+
+def test_facch3_pass_rate_is_the_reference_sync_ranking_not_the_decoder(gpu_api, orc, pkg):
+    """`bench.py --workload nt3` reports that only ~59 % of the FACCH3 groups pass their CRC, at any SNR.  That is the
+    reference's sync search, reproduced on purpose: _sync_find zeroes its correlation accumulator once and never between
+    training sequences (pi4cxpsk.c:206-237), so for the two-sequence NT3 FACCH format the second sequence is ranked on
+    |c0| + |c1| and always wins -- every burst SENT with sequence 0 is demodulated against the wrong phase reference.
+    The genie check that separates this from a bug shared by the oracle and the product: with the SENT sequence as the
+    format's only one (a caller-defined burst description) nearly every group passes at 20 dB, on both sides; with the
+    reference's ranking both sides pick sequence 1 throughout and lose the groups sent with sequence 0."""
+    import ctypes as C
+    import oracle_lib
+    wl = workloads.nt3_mix(pkg, n=3200, seed=77, esn0_db=(20.0,))
+    fac = wl["facch"].reshape(-1, 4)
+    ng = fac.shape[0]
+    in_len, sps = wl["in_len"], 4
+    iq = wl["iq"].reshape(-1, wl["stride"])[:, :in_len]
+
+    def caller_format(sid):                      # the product's: struct gmr1_pi4cxpsk_burst with one training sequence
+        c = gpu_api.CallerBurst("nt3_facch")
+        if sid:
+            c.burst.sync[0] = c.burst.sync[1]
+        c.burst.sync[1] = type(c.burst.sync[1])()
+        return c
+
+    def oracle_format(sid):                      # the oracle's: struct orc_burst with one training sequence
+        b = oracle_lib.Burst()
+        C.memmove(C.byref(b), oracle_lib.burst("nt3_facch"), C.sizeof(b))
+        if sid:
+            C.memmove(C.byref(b.sync[0]), C.byref(b.sync[1]), C.sizeof(b.sync[0]))
+            b.n_sync_chunks[0] = b.n_sync_chunks[1]
+        b.n_sync = 1
+        return C.pointer(b)
+
+    cf, of = [caller_format(0), caller_format(1)], [oracle_format(0), oracle_format(1)]
+    eb = {k: np.zeros((ng, 4, 104), np.int8) for k in ("g_ref", "g_genie", "o_ref", "o_genie")}
+    sid_g, sid_o = np.zeros((ng, 4), int), np.zeros((ng, 4), int)
+    for g in range(ng):
+        sent = int(wl["sync_id"][g])
+        for q in range(4):
+            i = fac[g, q]
+            fsh = float(wl["freq_shift"][i])
+            a = gpu_api.pi4cxpsk_demod("nt3_facch", iq[i], sps, fsh)
+            b = gpu_api.pi4cxpsk_demod(cf[sent], iq[i], sps, fsh)
+            c = orc.demod("nt3_facch", iq[i], sps, fsh)
+            d = orc.demod(of[sent], iq[i], sps, fsh)
+            assert a["rv"] == b["rv"] == c["rv"] == d["rv"] == 0
+            eb["g_ref"][g, q], eb["g_genie"][g, q], eb["o_ref"][g, q], eb["o_genie"][g, q] = a["ebits"], b["ebits"], c["ebits"], d["ebits"]
+            sid_g[g, q], sid_o[g, q] = a["sync_id"], c["sync_id"]
+    crc = {k: (gpu_api.facch3_decode_batch(v) if k[0] == "g" else orc.facch3_decode(v)) for k, v in eb.items()}
+    rate = {k: float((v[2] == 0).mean()) for k, v in crc.items()}
+    print("FACCH3 groups passing their CRC at 20 dB:", rate, "; sequence 1 picked on", float((sid_g == 1).mean()), "of the bursts")
+    # the reference's ranking: sequence 1 nearly always, so about half the groups (those sent with sequence 0) are lost
+    assert np.array_equal(sid_g, sid_o)
+    assert (sid_g == 1).mean() > 0.9
+    sent0 = wl["sync_id"][:ng] == 0
+    assert (crc["g_ref"][2][sent0] == 0).mean() < 0.5 and (crc["g_ref"][2][~sent0] == 0).mean() > 0.95
+    assert 0.4 < rate["g_ref"] < 0.75 and abs(rate["g_ref"] - rate["o_ref"]) < 0.05
+    # the sent sequence forced: the algorithm itself loses next to nothing
+    assert rate["g_genie"] > 0.97 and rate["o_genie"] > 0.97
+    good = crc["g_genie"][2] == 0
+    assert np.array_equal(crc["g_genie"][0][good], wl["l2"][:ng][good])

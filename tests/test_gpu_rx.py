@@ -22,7 +22,13 @@ def _compare_fused(got, ref, wl, *, label):
     # a few steps of 1/1024 without flipping the pick; both must stay rare and small
     assert dtoa.max() < 16.0 / 1024.0, f"{label}: toa differs by {dtoa.max()}"
     assert flip.mean() <= 0.01, f"{label}: {flip.sum()} / {n} sample-pick flips"
-    same = ~flip & (dtoa == 0)
+    # at >= 4 samples per symbol everything behind the timing depends on the pick round(toa) alone (pi4cxpsk.c:292-295):
+    # soft symbols, frequency error and soft bits are compared on EVERY burst whose pick did not flip; bursts whose toa
+    # differs by a bisection step or two without flipping must be rare
+    near = (dtoa != 0) & ~flip
+    print(f"{label}: toa differs without a flip on {near.mean():.4f} of the bursts, picks flipped on {flip.mean():.4f}")
+    assert near.mean() < 0.01, f"{label}: toa differs on {near.mean():.4f} of the bursts"
+    same = ~flip
     dss = np.abs(got["ssyms"][same] - ref["ssyms"][same])
     # phase wraps at +-2 (QPSK soft symbol range): compare modulo 4
     dss = np.minimum(dss, np.abs(dss - 4.0))
@@ -137,7 +143,10 @@ def test_fused_rx_bursts_at_the_window_edges(gpu_api, orc, pkg):
     dtoa = np.abs(got["toa"] - ref["toa"])
     flip = np.round(got["toa"]) != np.round(ref["toa"])
     assert dtoa.max() < 16.0 / 1024.0 and flip.mean() <= 0.01
-    same = ~flip & (dtoa == 0)
+    near = (dtoa != 0) & ~flip
+    print(f"window edges: toa differs without a flip on {near.mean():.4f} of the bursts, picks flipped on {flip.mean():.4f}")
+    assert near.mean() < 0.01
+    same = ~flip
     dss = np.abs(got["ssyms"][same] - ref["ssyms"][same])
     dss = np.minimum(dss, np.abs(dss - 4.0))
     assert dss.max() < 1e-4

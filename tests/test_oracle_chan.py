@@ -108,7 +108,7 @@ def test_off_grid_rate_pre_resampler_tone(fs):
     M = pl.n_chans
     assert pl.pre_rate == Fraction(int(M * 31250), int(fs)) and pl.pre_rate > 1
     t = pl.taps_pre.astype(np.float64)
-    assert t.size == 727 and np.allclose(t, t[::-1], atol=1e-6) and abs(t.sum() - 32.0) < 1e-3
+    assert t.size == 959 and np.allclose(t, t[::-1], atol=1e-6) and abs(t.sum() - 32.0) < 1e-3
     H = np.abs(np.fft.rfft(t / 32.0, 1 << 16))
     f = np.fft.rfftfreq(1 << 16, 1 / 32.0)
     assert H[np.searchsorted(f, 0.4)] > 0.98 and H[np.searchsorted(f, 0.65):].max() < 10 ** (-70 / 20)
@@ -123,3 +123,25 @@ def test_off_grid_rate_pre_resampler_tone(fs):
         assert abs(fest - fo) < 5.0 and abs(np.mean(np.abs(z)) - 1.0) < 0.05
         assert abs(out[k].size - n / fs * 93600) < 40
         assert np.mean(np.abs(out[(k + 2) % M][600:]) ** 2) < 1e-4
+
+
+def test_pre_resampler_prototype_meets_the_reference_design_spec():
+    """The off-grid pre-resampler's prototype is this library's own design (window method), because GNU Radio's
+    arb_resampler_ccf(taps=None) designs its filter with Parks-McClellan, which cannot be restated without gr-filter.
+    What CAN be pinned is the specification that design is run with (gr-filter's pfb.arb_resampler for rates >= 1: pass
+    band 0.8 x half the input band = 0.4 of the input rate, stop band from 0.6, 100 dB): the prototype here meets it --
+    at most 0.1 dB of ripple up to 0.4, at least 100 dB down from 0.6 (frequencies in units of the INPUT sample rate;
+    the prototype runs at 32 x that rate).  Same band edges, not the same taps: outputs for off-grid capture rates are
+    comparable with a GNU Radio run in spectrum, not sample by sample."""
+    import orc_chan
+    nfilt = 32
+    t = orc_chan.pre_resampler_taps(nfilt).astype(np.float64)
+    assert t.size == 959 and np.allclose(t, t[::-1])
+    nfft = 1 << 18
+    H = np.abs(np.fft.rfft(t, nfft)) / nfilt
+    f = np.arange(H.size) / nfft * nfilt            # in units of the input sample rate
+    pb = H[f <= 0.4]
+    assert 20 * np.log10(pb.max()) < 0.1 and 20 * np.log10(pb.min()) > -0.1
+    sb = H[f >= 0.6]
+    assert 20 * np.log10(sb.max()) < -100.0
+    assert abs(H[0] - 1.0) < 1e-6
