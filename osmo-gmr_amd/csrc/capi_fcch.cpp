@@ -40,8 +40,9 @@ int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq,
 	a.n = n; a.len = len; a.sps = sps; a.tab = tab;
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.freq_shift = freq_shift;
-	a.n_stat_tiles = fcch_stat_tiles(len);
 	a.n_lag_tiles = fcch_lag_tiles(nlags);
+	// the one-pass sweep keeps its statistics partials per lag tile (fcch_kernels.hip: k_fcch_sweep)
+	a.n_stat_tiles = fcch_one_pass() ? a.n_lag_tiles : fcch_stat_tiles(len);
 	a.dec_stride = ((size_t)ndec + 15) & ~(size_t)15;
 	const size_t b_dec = (size_t)n * a.dec_stride * 8;
 	const size_t b_par = (((size_t)n * a.n_stat_tiles * 16) + 255) & ~(size_t)255;

@@ -17,6 +17,7 @@
 // stream (14.6 flop/B), so the sweep sits near the HBM / fp32-VALU ridge; no MFMA (real x complex
 // FIR, "do not reshape into GEMMs").
 #include "gmr1_dev.h"
+#include "profile_env.h"
 
 namespace gmr1 {
 
@@ -296,6 +297,305 @@ __global__ __launch_bounds__(256) void k_fcch_corr(FcchRoughArgs a)
 			for (int k = 0; k < 5; k++)
 				o[2 + k] = en[bi - m0 + k];
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// The rough sweep in ONE pass over the raw samples (round 5; replaces k_fcch_stats + k_fcch_corr, which stay for A/B in the
+// profiling build).  osmo_cxvec_sig_normalize is linear: with mean mu and deviation sigma of the whole window,
+//     sum_n r[n] (x[m + n] - mu) / sigma  =  (sum_n r[n] x[m + n]  -  mu sum_n r[n]) / sigma
+// (and with a frequency shift: x[i] e^{j fs i} in the first sum, mu e^{j fs m} sum_n r[n] e^{j fs n} for the second), so the
+// correlation of the RAW decimated samples does not have to wait for the statistics of the whole window:
+//
+//   k_fcch_sweep   one work-group per tile of 2044 lags: the tile's raw samples once from HBM (16-byte non-temporal loads)
+//                  -> sum x, sum |x|^2 partials of the tile's own span AND the decimated samples into LDS -> raw correlation
+//                  of 2048 lags, 8 bytes per lag back to HBM (the place the decimated copy used to take).  The streaming
+//                  read and the arithmetic now overlap inside one kernel instead of following each other in two.
+//   k_fcch_energy  per tile: mean / deviation from the partials, the correction above, |.|^2 per lag (optionally stored:
+//                  gmr1_fcch_rough_multi), best 5-lag energy window of the tile -- what the second half of k_fcch_corr did.
+//
+// The correlation itself runs on the matrix cores.  **This is the one place in the library that does, and it is an
+// experiment the round-4 review asked for, outside north_star's "no MFMA"**: 16 consecutive lags of a real 117-tap FIR are a
+// 16 x 132 banded Toeplitz matrix T[i][k] = r[k - i] times the 132 samples under them, and 16 such blocks side by side
+// (lags m, m + 16, ...) make the other operand a 132 x 16 matrix W[k][j] = x[m + 16 j + k]: D = T W is
+// v_mfma_f32_16x16x4_f32, 33 of them per 256 lags and component (re, im).  The FP32 matrix peak equals the FP32 vector peak
+// on this part, so nothing is gained in arithmetic rate -- but one MFMA issues 1 024 multiply-adds from ONE issue slot,
+// where the vector form spent 30 % of its issue slots on loads, staging and address arithmetic beside its FMAs (88 % VALU
+// busy, profiles/r04v).  11 % of the multiply-adds hit the zeros of the band.  The sums are formed in the MFMA's order (k
+// in fours), not the reference's n = 0 ... 116: energies differ in the last bits, `toa` does not (asserted on every stream
+// of tests/test_gpu_fcch.py and of the bench).
+//
+// A non-finite sample now reaches the lags of its whole 16-lag block (0 x Inf), not only the lags whose taps cover it.
+// ---------------------------------------------------------------------------
+typedef float v4f __attribute__((ext_vector_type(4)));
+__host__ __device__ __forceinline__ constexpr int pad16(int i) { return i + (i >> 4); }
+template <int NT>
+struct SweepDims {
+	static constexpr int KP = ((NT + 15 + 3) / 4) * 4;              // Toeplitz width, a whole number of MFMA k-steps (132 / 484)
+	static constexpr int NS = kTileLags + KP + 16;                  // decimated samples a tile stages
+	static constexpr int RT = KP + 20;                              // chirp with 15 zeros in front, zeros behind
+	static constexpr size_t lds = (size_t)pad16(NS) * 8 + (size_t)RT * 4;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a)
+{
+	typedef SweepDims<NT> D;
+	extern __shared__ __align__(16) unsigned char lds_raw[];
+	float2 *xs = reinterpret_cast<float2 *>(lds_raw);                   // pad16(NS) samples
+	float *rt = reinterpret_cast<float *>(xs + pad16(D::NS));           // RT floats
+	const int s = blockIdx.y, tile = blockIdx.x;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int sps = a.sps;
+	const int ndec = a.len / sps;
+	const int nlags = ndec - NT + 1;
+	const int m0 = tile * kTileStep;
+	const float2 *__restrict__ in = a.iq + a.offset[s];
+	const float fs = a.freq_shift ? a.freq_shift[s] : 0.0f;
+	const bool last = tile == (int)gridDim.x - 1;
+
+	for (int i = tid; i < D::RT; i += 256) {
+		const int n = i - 15;
+		rt[i] = (n >= 0 && n < NT) ? c_fcch.dual[a.tab][n] : 0.0f;
+	}
+	// (slots past the window's last decimated sample are read by the MFMAs -- against zero taps, or for lags that are not
+	// kept -- and must hold zeros, not whatever the LDS held: only the window's last tiles have any)
+	for (int i = max(ndec - m0, 0) + tid; i < D::NS; i += 256)
+		xs[pad16(i)] = make_float2(0.f, 0.f);
+
+	// ---- the tile's raw samples: statistics over its own span, every sps-th sample to LDS
+	const long long raw0 = (long long)m0 * sps;
+	const long long own_end = last ? (long long)a.len : (long long)(m0 + kTileStep) * sps;
+	const long long raw_end = min((long long)(m0 + D::NS) * sps, (long long)a.len);
+	float sr = 0.f, si = 0.f, sq = 0.f;
+	auto take = [&](long long j, float2 v) {
+		if (j < own_end) {
+			sr += v.x;
+			si += v.y;
+			sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
+		}
+	};
+	auto keep = [&](int di, float2 v) {          // decimated sample di of the window
+		if (di < ndec) {
+			if (fs != 0.0f) {
+				float sn, cs;
+				sincos_fast(fs * (float)di, sn, cs);
+				v = cmul(v, make_float2(cs, sn));
+			}
+			xs[pad16(di - m0)] = v;
+		}
+	};
+	if (sps == 4 && ((a.offset[s] & 1ull) == 0)) {
+		// 16-byte loads, two samples each; of a pair (2 t, 2 t + 1) counted from the tile's first sample (a multiple of 4
+		// from the window's) sample 2 t is a kept one on even t
+		const v4f *in4 = reinterpret_cast<const v4f *>(in + raw0);
+		const long long npair = (raw_end - raw0) >> 1;
+		constexpr int NB = 9;
+		for (long long b0 = 0; b0 < npair; b0 += (long long)NB * 256) {
+			v4f p[NB];
+#pragma unroll
+			for (int it = 0; it < NB; it++) {
+				const long long t = b0 + (long long)it * 256 + tid;
+				p[it] = t < npair ? __builtin_nontemporal_load(&in4[t]) : (v4f){0.f, 0.f, 0.f, 0.f};
+			}
+#pragma unroll
+			for (int it = 0; it < NB; it++) {
+				const long long t = b0 + (long long)it * 256 + tid;
+				if (t < npair) {
+					const long long j = raw0 + 2 * t;
+					take(j, make_float2(p[it].x, p[it].y));
+					take(j + 1, make_float2(p[it].z, p[it].w));
+					if ((t & 1) == 0)
+						keep((int)(j >> 2), make_float2(p[it].x, p[it].y));
+				}
+			}
+		}
+		if (((raw_end - raw0) & 1) && tid == 0) {
+			const long long j = raw_end - 1;
+			const float2 v = in[j];
+			take(j, v);
+			if ((j & 3) == 0)
+				keep((int)(j >> 2), v);
+		}
+	} else {
+		for (long long j = raw0 + tid; j < raw_end; j += 256) {
+			const float2 v = in[j];
+			take(j, v);
+			if (j % sps == 0)
+				keep((int)(j / sps), v);
+		}
+	}
+	__shared__ float red[3][4];
+	sr = wave_sum(sr); si = wave_sum(si); sq = wave_sum(sq);
+	if (lane == 0) { red[0][wv] = sr; red[1][wv] = si; red[2][wv] = sq; }
+	__syncthreads();
+	if (tid == 0) {
+		float *p = a.partial + ((size_t)s * a.n_stat_tiles + tile) * 4;
+		p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+		p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+		p[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+		p[3] = 0.f;
+	}
+
+	// ---- raw correlation of lags m0 ... m0 + 2047: wave wv takes the sets wv and wv + 4 of 256 lags each
+	// A (16 x 4 per step): lane (li, lk) holds T[li][k0 + lk] = r[k0 + lk - li]; B (4 x 16): lane (li, lk) holds
+	// x[set + 16 li + k0 + lk]; D: lane (li, lk), register v = lag set + 16 li + 4 lk + v
+	const int li = lane & 15, lk = lane >> 4;
+	const float *rp = rt + 15 + lk - li;
+	const float2 *xp0 = xs + pad16(256 * wv) + 17 * li + lk;             // (k0 + lk) >> 4 == k0 >> 4: lk < 4, k0 in fours
+	const float2 *xp1 = xs + pad16(256 * (wv + 4)) + 17 * li + lk;
+	v4f dr0 = {0.f, 0.f, 0.f, 0.f}, di0 = dr0, dr1 = dr0, di1 = dr0;
+	constexpr int NG = D::KP / 16, REM = (D::KP % 16) / 4;               // groups of four k-steps (16 samples = 17 padded slots)
+#pragma unroll 2
+	for (int g = 0; g < NG; g++) {
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const float r = rp[16 * g + 4 * u];
+			const float2 x0 = xp0[17 * g + 4 * u], x1 = xp1[17 * g + 4 * u];
+			dr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x0.x, dr0, 0, 0, 0);
+			di0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x0.y, di0, 0, 0, 0);
+			dr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x1.x, dr1, 0, 0, 0);
+			di1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x1.y, di1, 0, 0, 0);
+		}
+	}
+#pragma unroll
+	for (int u = 0; u < REM; u++) {
+		const float r = rp[16 * NG + 4 * u];
+		const float2 x0 = xp0[17 * NG + 4 * u], x1 = xp1[17 * NG + 4 * u];
+		dr0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x0.x, dr0, 0, 0, 0);
+		di0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x0.y, di0, 0, 0, 0);
+		dr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x1.x, dr1, 0, 0, 0);
+		di1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x1.y, di1, 0, 0, 0);
+	}
+	// each lane holds four consecutive lags: 32 bytes; the tile's own lags only (the next tile writes the four beyond)
+	float2 *__restrict__ acc = a.dec + (size_t)s * a.dec_stride;
+#pragma unroll
+	for (int h = 0; h < 2; h++) {
+		const v4f dr = h ? dr1 : dr0, di = h ? di1 : di0;
+		const int i0 = 256 * (wv + 4 * h) + 16 * li + 4 * lk;
+#pragma unroll
+		for (int v = 0; v < 4; v++) {
+			const int i = i0 + v, m = m0 + i;
+			if (i < kTileStep && m < nlags)
+				acc[m] = make_float2(dr[v], di[v]);
+		}
+	}
+}
+
+// second half: the normalisation applied to the raw correlation, energies, the tile's best 5-lag window
+constexpr int kEnergyTiles = 4;
+template <int NT>
+__global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a)
+{
+	__shared__ float en[kTileLags];
+	__shared__ float s_stat[8];
+	__shared__ float s_best[4];
+	__shared__ int s_bidx[4];
+	const int s = blockIdx.y;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int ndec = a.len / a.sps;
+	const int nlags = ndec - NT + 1;
+	const float fs = a.freq_shift ? a.freq_shift[s] : 0.0f;
+	if (wv == 0) {
+		double dr = 0.0, di = 0.0, dq = 0.0;
+		for (int t = lane; t < a.n_stat_tiles; t += 64) {
+			const float *p = a.partial + ((size_t)s * a.n_stat_tiles + t) * 4;
+			dr += p[0]; di += p[1]; dq += p[2];
+		}
+		dr = wave_sum_d(dr); di = wave_sum_d(di); dq = wave_sum_d(dq);
+		// sum_n r[n] e^{j fs n}: what the mean contributes to every lag (times e^{j fs m})
+		float rr = 0.f, ri = 0.f;
+		for (int n = lane; n < NT; n += 64) {
+			const float r = c_fcch.dual[a.tab][n];
+			float sn = 0.f, cs = 1.f;
+			if (fs != 0.0f)
+				sincos_fast(fs * (float)n, sn, cs);
+			rr = fmaf(r, cs, rr);
+			ri = fmaf(r, sn, ri);
+		}
+		rr = wave_sum(rr); ri = fs != 0.0f ? wave_sum(ri) : 0.0f;
+		if (lane == 0) {
+			const double n = (double)a.len;
+			const double ar = dr / n, ai = di / n;
+			double var = dq / n - (ar * ar + ai * ai);
+			if (var < 0.0) var = 0.0;
+			float sd = sqrtf((float)var);
+			if (sd == 0.0f) sd = 1.0f;
+			s_stat[2] = 1.0f / sd;
+			// mu * sum_n r[n] e^{j fs n}
+			s_stat[0] = (float)ar * rr - (float)ai * ri;
+			s_stat[1] = (float)ar * ri + (float)ai * rr;
+		}
+	}
+	__syncthreads();
+	const float mr = s_stat[0], mi = s_stat[1], inv = s_stat[2];
+	const float2 *__restrict__ acc = a.dec + (size_t)s * a.dec_stride;
+	// (kEnergyTiles lag tiles per work-group: the statistics above are formed once for them)
+	for (int tile = blockIdx.x * kEnergyTiles; tile < min(((int)blockIdx.x + 1) * kEnergyTiles, a.n_lag_tiles); tile++) {
+	const int m0 = tile * kTileStep;
+	__syncthreads();
+	// two lags per lane and load: 16 bytes (the stream's array, the tile's first lag and 2 tid are all even)
+	for (int i = 2 * tid; i < kTileLags; i += 512) {
+		const int m = m0 + i;
+		float2 c2[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+		if (m + 1 < nlags) {
+			const float4 q = *reinterpret_cast<const float4 *>(acc + m);
+			c2[0] = make_float2(q.x, q.y);
+			c2[1] = make_float2(q.z, q.w);
+		} else if (m < nlags) {
+			c2[0] = acc[m];
+		}
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			float e = -1.0f;
+			if (m + h < nlags) {
+				float2 mu = make_float2(mr, mi);
+				if (fs != 0.0f) {
+					float sn, cs;
+					sincos_fast(fs * (float)(m + h), sn, cs);
+					mu = cmul(mu, make_float2(cs, sn));
+				}
+				const float cx = (c2[h].x - mu.x) * inv, cy = (c2[h].y - mu.y) * inv;
+				e = fmaf(cx, cx, cy * cy);
+				if (a.energy && i + h < kTileStep)
+					a.energy[(size_t)s * a.energy_stride + m + h] = e;
+			}
+			en[i + h] = e;
+		}
+	}
+	__syncthreads();
+	// ---- best 5-sample window starting inside this tile (first maximum wins)
+	float bv = -1.0f;
+	int bi = 0x7fffffff;
+	for (int i = tid; i < kTileStep; i += 256) {
+		const int m = m0 + i;
+		if (m + 5 <= nlags) {
+			float e = 0.f;
+#pragma unroll
+			for (int k = 0; k < 5; k++)
+				e += en[i + k];
+			if (e > bv) { bv = e; bi = m; }
+		}
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const float ov = __shfl_xor(bv, o);
+		const int oi = __shfl_xor(bi, o);
+		if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+	}
+	if (lane == 0) { s_best[wv] = bv; s_bidx[wv] = bi; }
+	__syncthreads();
+	if (tid == 0) {
+		for (int q = 1; q < 4; q++)
+			if (s_best[q] > bv || (s_best[q] == bv && s_bidx[q] < bi)) { bv = s_best[q]; bi = s_bidx[q]; }
+		float *o = a.tile_best + ((size_t)s * a.n_lag_tiles + tile) * 8;
+		o[0] = bv;
+		o[1] = __builtin_bit_cast(float, bi);
+		if (bi != 0x7fffffff) {
+			for (int k = 0; k < 5; k++)
+				o[2 + k] = en[bi - m0 + k];
+		}
+	}
 	}
 }
 
@@ -695,17 +995,43 @@ static void launch_corr(const FcchRoughArgs &a, hipStream_t st)
 	hipLaunchKernelGGL((k_fcch_corr<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), lds, st, a);
 }
 
+bool fcch_one_pass() { return profile_env("GMR1_HIP_FCCH_TWO_PASS") == nullptr; }
+
+template <int NT>
+static hipError_t launch_sweep(const FcchRoughArgs &a, hipStream_t st)
+{
+	static bool told = false;
+	if (!told) {
+		hipError_t e = hipFuncSetAttribute((const void *)k_fcch_sweep<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SweepDims<NT>::lds);
+		if (e != hipSuccess)
+			return e;
+		told = true;
+	}
+	hipLaunchKernelGGL((k_fcch_sweep<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
+	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + kEnergyTiles - 1) / kEnergyTiles, a.n), dim3(256), 0, st, a);
+	return hipGetLastError();
+}
+
 hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t st)
 {
 	if (a.n <= 0)
 		return hipSuccess;
+	if (ntaps != 117 && ntaps != 468)
+		return hipErrorInvalidValue;
+	if (fcch_one_pass()) {
+		// (the partials are per lag tile in this form: the host sized them so, capi_fcch.cpp)
+		if (a.n_stat_tiles != a.n_lag_tiles)
+			return hipErrorInvalidValue;
+		const hipError_t e = ntaps == 117 ? launch_sweep<117>(a, st) : launch_sweep<468>(a, st);
+		if (e != hipSuccess)
+			return e;
+	} else {
 	hipLaunchKernelGGL(k_fcch_stats, dim3(a.n_stat_tiles, a.n), dim3(256), 0, st, a);
 	if (ntaps == 117)
 		launch_corr<117>(a, st);
-	else if (ntaps == 468)
-		launch_corr<468>(a, st);
 	else
-		return hipErrorInvalidValue;
+		launch_corr<468>(a, st);
+	}
 	if (a.toa)
 		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a);
 	return hipGetLastError();

@@ -198,6 +198,7 @@ struct FcchFineArgs {
 
 hipError_t upload_fcch_tables(const FcchTables *host, hipStream_t stream);
 int fcch_stat_tiles(int len);
+bool fcch_one_pass();      // the rough sweep as k_fcch_sweep + k_fcch_energy (profiling build: GMR1_HIP_FCCH_TWO_PASS selects the old pair)
 int fcch_lag_tiles(int nlags);
 hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t stream);
 hipError_t launch_fcch_multi(const FcchMultiArgs &a, hipStream_t stream);
