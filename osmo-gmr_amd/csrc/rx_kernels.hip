@@ -2026,6 +2026,10 @@ struct LatPre {
 	// and moves less than one lag) while the front wave bisects.
 	LoopCo *co = nullptr;                  // LDS; null: the front works alone
 	int co_id = 0;
+	// (5) PART 1 / 2: the one burst's operands in registers of the caller (a BCCH burst) -- not through the arrays of `io`,
+	// whose every read would be an LDS round trip in front of the phase that needs it
+	uint64_t b_off = 0;
+	float b_fsh = 0.f;
 	float2 *win_w = nullptr;               // LDS, front half: where the window goes if the front had to fetch it itself
 	const float2 *win_r = nullptr;         // LDS, back half: the burst's raw window (lane l's samples l + 64 k as fetched)
 };
@@ -2280,6 +2284,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// the planar one's second read is compact already.)
 	constexpr bool KEEP = !GEN && !LAT && !PL && !EN && SPS == 4 && NPL == 16;
 	const bool keep3 = KEEP && g0 + 3 < n_end;
+	// a burst's operands: the arrays of `io`, or (the loop's pipeline stages) the caller's registers (LatPre (5))
+	auto op_kind = [&](int g) -> int {
+		if constexpr (LAT && PART != 0) return 0; else return io.kind[g] ? 1 : 0;
+	};
+	auto op_fsh = [&](int g) -> float {
+		if constexpr (LAT && PART != 0) return pre->b_fsh; else return io.freq_shift ? io.freq_shift[g] : 0.0f;
+	};
+	auto op_off = [&](int g) -> uint64_t {
+		if constexpr (LAT && PART != 0) return pre->b_off; else return io.offset[g];
+	};
 	float2 wv_own[NPL];
 	bool co_on = false;                                // (LAT, PART 1) the helper wave shares this burst's front (LatPre (4))
 	int co_p = 0;
@@ -2411,16 +2425,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int g = g0 + q;
 		if (g >= n_end)
 			break;
-		const int kind = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g] ? 1 : 0);
+		const int kind = GEN ? 0 : __builtin_amdgcn_readfirstlane(op_kind(g));
 		const int type = GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
 		const DevBurst &bt = c_types[type];
 		typedef Fmt<GEN> F;
 		const int w = in_len - F::len(bt) * sps + 1;
-		const float fsh = io.freq_shift ? io.freq_shift[g] : 0.0f;
+		const float fsh = op_fsh(g);
 		const float fs = (fsh - F::rotation(bt)) / (float)sps;
 
-		const float2 *__restrict__ in = a.iq + io.offset[g];
+		const float2 *__restrict__ in = a.iq + op_off(g);
 		// PL: lanes 16 p .. 16 p + 15 read 16 consecutive places of ONE plane per load (a full 128-byte line; with lane l
 		// on samples l + 64 k, as in the interleaved layout, adjacent lanes would sit in four different lines and a load
 		// would cost sixteen times the tag look-ups): lane (p, j) holds window samples 64 k + 4 j + p -- those of lane
@@ -2459,7 +2473,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		bool prepared = false;
 		const float2 *__restrict__ xst = L.x;
 		if constexpr (LAT) {
-			prepared = *pre->h_off == io.offset[g] && *pre->h_kind == kind;
+			prepared = *pre->h_off == op_off(g) && *pre->h_kind == kind;
 			if (prepared)
 				xst = xst_lat = pre->h_x;
 			if constexpr (PART == 1)
@@ -2648,15 +2662,15 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 
 	// per-row (lane-resident) burst parameters: looked up here, not before pass 1, which has no register to spare for them
-	const int kind_r = (!GEN && row_live) ? (io.kind[g_row] ? 1 : 0) : 0;
+	const int kind_r = (!GEN && row_live) ? op_kind(g_row) : 0;
 	const int type_r = GEN ? a.fixed_type : (kind_r ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 	typedef Fmt<GEN> F;
 	const int in_len_r = kind_r ? a.in_len[1] : a.in_len[0];
-	const float fsh_r = (row_live && io.freq_shift) ? io.freq_shift[g_row] : 0.0f;
+	const float fsh_r = row_live ? op_fsh(g_row) : 0.0f;
 	const DevBurst &bt_r = c_types[type_r];
 	const float fs_r = (fsh_r - F::rotation(bt_r)) / (float)sps;     // pi4cxpsk.c:539
 	const int w_r = in_len_r - F::len(bt_r) * sps + 1;
-	const float2 *__restrict__ in_r = a.iq + (row_live ? io.offset[g_row] : 0);
+	const float2 *__restrict__ in_r = a.iq + (row_live ? op_off(g_row) : 0);
 
 	// =========================== rows: peak + early/late timing ===========================
 	// osmo_cxvec_peak_energy_find(corr, 3, PEAK_EARLY_LATE, &peak), pi4cxpsk.c:240
@@ -3024,7 +3038,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const DevBurst &bt = c_types[GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH)];
 		const int in_len = __builtin_amdgcn_readlane(in_len_r, src);
 		const int d = __builtin_amdgcn_readlane(d_r, src);
-		const float2 *__restrict__ in = a.iq + io.offset[g];
+		const float2 *__restrict__ in = a.iq + op_off(g);
 		const int blen = F::len(bt);
 		if constexpr (PL) {
 			// the kept samples d, d + 4, ... are consecutive in plane (offset + d) & 3
@@ -3929,6 +3943,7 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 				pre.cut = &s_cut[(t + 2) % 3];
 				pre.win_r = win0 + h.win * kWin;
 				pre.vtab = vtab0 + (t & 1) * (kLatTabBytes / 4);
+				pre.b_fsh = h.fsh;
 				const RxIo io = {
 #ifdef GMR1_HIP_PROFILE
 				                 reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo),
@@ -4030,6 +4045,8 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	// sixteen frames all lie inside the capture) with one frame per lane.  -> s_items, the number of items
 	int frames_at_round = 0;
 	float minen = 0.f;
+	// the round's BCCH burst (always its last item), in registers: every use of it sits on the tick's critical path
+	int rb_has = 0, rb_begin = 0, rb_etoa = 0, rb_fb = 0;
 	auto list_round = [&]() -> int {
 		frames_at_round = n_frames;
 		minen = st.bcch_energy / 2.0f;                          // the gate level the round starts with
@@ -4058,14 +4075,25 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			}
 			if (flog && lane < jb && n_frames + lane < la.flog_stride)
 				flog[n_frames + lane] = {align_j, st.freq_err, fn_j};
+			rb_has = 1;
+			rb_begin = st.align + jb * frame_len + tn_off - 10 * sps;
+			rb_etoa = 10 * sps;
+			rb_fb = jb;
 			n_frames += jb;
 			st.fn += jb;
 			st.align += jb * frame_len;
 			n = __popc(items);
+			WSYNC();
 		} else {
 			n = rx_loop_build_round(st, sps, s_items, on_frame);
+			WSYNC();
+			rb_has = n > 0 && s_items[n - 1].is_bcch != 0;
+			if (rb_has) {
+				rb_begin = s_items[n - 1].begin;
+				rb_etoa = s_items[n - 1].e_toa;
+				rb_fb = s_items[n - 1].frames_before;
+			}
 		}
-		WSYNC();
 		return n;
 	};
 	// checkpoints of the rounds handed over, by tick mod 3: what a SQUASH restores
@@ -4089,8 +4117,8 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			// where the burst of the round AFTER the one about to run will most likely sit: eight frames on
 			// (a round's BCCH burst is always its last item)
 			uint64_t pred = ~0ull;
-			if (n > 0 && s_items[n - 1].is_bcch != 0) {
-				pred = st.base + (uint64_t)s_items[n - 1].begin + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
+			if (n > 0 && rb_has) {
+				pred = st.base + (uint64_t)rb_begin + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
 				if (pred + (uint64_t)a.in_len[0] > lim)
 					pred = ~0ull;
 			}
@@ -4098,12 +4126,12 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			s_go[t & 1] = 1;
 			// the helper wave's job of this tick: the burst about to run, if there is one
 			LoopCo &c = s_co[t & 1];
-			const bool job = n > 0 && round < round_end && s_items[n - 1].is_bcch != 0;
-			c.off = job ? st.base + (uint64_t)s_items[n - 1].begin : 0;
+			const bool job = n > 0 && round < round_end && rb_has;
+			c.off = job ? st.base + (uint64_t)rb_begin : 0;
 			c.fsh = -st.freq_err;
 			c.job = job ? t + 1 : 0;
 		}
-		bool co_job = n > 0 && round < round_end && s_items[n - 1].is_bcch != 0;
+		bool co_job = n > 0 && round < round_end && rb_has;
 		__syncthreads();
 		GMR1_FSTAMP(17);
 		const int t3 = t % 3;
@@ -4141,7 +4169,7 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			continue;
 		}
 		GMR1_FSTAMP(18);
-		const bool has_b = s_items[n - 1].is_bcch != 0;
+		const bool has_b = rb_has != 0;
 		const int n_c = has_b ? n - 1 : n;
 		// the CCCH bursts: listed for the batch that follows
 		if (lane < n_c && n_ccch + lane < la.c_stride) {
@@ -4156,13 +4184,9 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		bool handed = false;
 		GMR1_FSTAMP(19);
 		if (has_b) {
-			const RxLoopItem it = s_items[n - 1];
-			if (lane == 0) {
-				s_off[0] = st.base + (uint64_t)it.begin;
-				s_fs[0] = -st.freq_err;
-				s_kind[0] = 0;
-			}
-			WSYNC();
+			struct { int e_toa, frames_before; } it = {rb_etoa, rb_fb};
+			pre.b_off = st.base + (uint64_t)rb_begin;
+			pre.b_fsh = -st.freq_err;
 			const int slot = (t + 2) % 3;                // what P prepared during the last tick
 			pre.h_off = &h_off[slot];
 			pre.h_kind = &h_kind[slot];
