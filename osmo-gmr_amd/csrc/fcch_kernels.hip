@@ -483,9 +483,10 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a)
 }
 
 // second half: the normalisation applied to the raw correlation, energies, the tile's best 5-lag window
-constexpr int kEnergyTiles = 4;
+// (tiles: lag tiles per work-group -- several where there are thousands of them, so that the statistics are formed once for
+// all; one where the launch is small and its latency is what counts: the receive loop's acquisition)
 template <int NT>
-__global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a)
+__global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnergyTiles)
 {
 	__shared__ float en[kTileLags];
 	__shared__ float s_stat[8];
@@ -1008,7 +1009,8 @@ static hipError_t launch_sweep(const FcchRoughArgs &a, hipStream_t st)
 		told = true;
 	}
 	hipLaunchKernelGGL((k_fcch_sweep<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
-	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + kEnergyTiles - 1) / kEnergyTiles, a.n), dim3(256), 0, st, a);
+	const int tiles = (long long)a.n_lag_tiles * a.n >= 4096 ? 4 : 1;
+	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles);
 	return hipGetLastError();
 }
 

@@ -1376,7 +1376,9 @@ __device__ __forceinline__ void lat_expand_step(uint32_t *__restrict__ tab, int 
 	d[3 * kSteps12] = make_uint4(c3, c0 | bit, c3 | bit, c0);
 }
 
-template <bool ACC = false>
+// TAIL = false: the forward pass alone -- window words to `surv`, the final metric returned; the survivor walk and the CRC
+// (k5_12_survivors_crc_lat) are the caller's, on another wave (k_rx_chain_pipe)
+template <bool ACC = false, bool TAIL = true>
 __device__ void decode1_k5_12_lat(const uint32_t *__restrict__ tab, uint64_t *__restrict__ surv,
                                   uint32_t *__restrict__ ubits, int lane, uint32_t &syn_o, uint32_t &final_ae,
                                   const DecPre *dp)
@@ -1442,7 +1444,10 @@ __device__ void decode1_k5_12_lat(const uint32_t *__restrict__ tab, uint64_t *__
 	dump[12 * 64] = (uint16_t)w;
 	final_ae = ACC ? 0u : w >> 16;
 	GMR1_DSTAMP(dp, 12, lane);
-	k5_12_survivors_crc_lat(surv, ubits, lane, syn_o, dp);
+	if constexpr (TAIL)
+		k5_12_survivors_crc_lat(surv, ubits, lane, syn_o, dp);
+	else
+		syn_o = 0;
 }
 
 // Tail of the decoder shaped for the LATENCY of one burst (the receive loop: one burst per wave, nothing to overlap with):
@@ -1980,6 +1985,7 @@ struct LoopCo {                    // front wave <-> helper wave, within a tick 
 	float fsh;                     // the burst: frequency shift ...
 	uint64_t off;                  // ... and first sample (S helps only if that is the window prepared)
 	int p_id, p;                   // F -> S: the coarse peak (p < 0: never mind)
+	int p_pred;                    // F -> S with the job: where the peak is expected (e_toa) -- S works that case out ahead
 	int c_id;                      // S -> F: the correlation's tail is in place
 	int s_id;                      // S -> F: ffe / psi of the three candidates are in place
 	float ffe[3], psi[3];
@@ -2130,7 +2136,7 @@ __device__ __forceinline__ void lat_sync_terms(const float2 *__restrict__ xst, i
 
 // What the front's helper wave does for one BCCH burst of the loop whose window was prepared (LatPre (4)).
 template <int SPS>
-__device__ __forceinline__ void loop_front_helper(const RxArgs &a, LoopCo *co, int id, const float2 *__restrict__ xst, int lane)
+__device__ __forceinline__ void loop_front_helper_corr(const RxArgs &a, LoopCo *co, int id, const float2 *__restrict__ xst, int lane)
 {
 	const int sps = SPS ? SPS : a.sps;
 	const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[0]);
@@ -2142,11 +2148,15 @@ __device__ __forceinline__ void loop_front_helper(const RxArgs &a, LoopCo *co, i
 	WSYNC();
 	if (lane == 0)
 		lds_post(&co->c_id, id);
-	if (!lds_wait_eq(&co->p_id, id))
-		return;
-	const int p = co->p;
-	if (p < 0)
-		return;
+}
+// the sync-symbol terms of the three timing candidates p - 1, p, p + 1 -> co->ffe / psi
+template <int SPS>
+__device__ __forceinline__ void loop_front_helper_sync(const RxArgs &a, LoopCo *co, const float2 *__restrict__ xst, int lane, int p)
+{
+	const int sps = SPS ? SPS : a.sps;
+	const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[0]);
+	const int w = in_len - 234 * sps + 1;
+	const float fs = (co->fsh - kPif / 4.0f) / (float)sps;
 	const int row = lane >> 4, col = lane & 15;
 	float ffe, psi;
 	lat_sync_terms(xst, 0, p - 1 + row, row < 3, fs, sps, w, in_len, col, ffe, psi);
@@ -2155,8 +2165,6 @@ __device__ __forceinline__ void loop_front_helper(const RxArgs &a, LoopCo *co, i
 		co->psi[row] = psi;
 	}
 	WSYNC();
-	if (lane == 0)
-		lds_post(&co->s_id, id);
 }
 
 // The position-only part of a fused-format burst's pass 1 (rx4_body does the same, operation for operation): window,
@@ -2912,8 +2920,14 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				se = ae;
 				sl = al;
 			};
+			// The loop's front (PART 1) stops after the FIRST evaluation.  Everything it hands on depends on the timing through
+			// the pick round(toa) alone (pi4cxpsk.c:292-295; the feedback is align += round(toa) - e_toa, gmr1_rx.c:782; no
+			// record carries toa), and round(toa) is settled by the first two levels: the walk starts on the whole lag p - 1
+			// and steps by 1/2, 1/4, ... 1/512, so after two levels toa = early + 1 is p -+ 1/4 or p -+ 3/4 and the seven levels
+			// left move it by less than 1/4 in all -- never across p -+ 1/2; a level that ties ends the walk in both forms.
+			constexpr int kEvals = PART == 1 ? 1 : 3;
 	#pragma unroll 1
-			for (int it = 0; it < 3; it++) {
+			for (int it = 0; it < kEvals; it++) {
 				const float half = incr * 0.5f, quarter = incr * 0.25f;
 				float pos = early;
 				if (grp == 1) {
@@ -3790,20 +3804,22 @@ __global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int s
 //               then the window of the burst F will need at tick t + 2, fetched where the schedule predicts it
 //               (statistics, energy, normalised sync-chunk windows as before -- and the whole raw window into LDS: no
 //               phase of a round goes back to global memory);
-//   V (wave 1)  tick t + 2: Viterbi, survivor walk, CRC; then the real feedback (rx_loop_bcch_result) on the state F started
-//               from -- if that is not bit for bit the state F assumed, the verdict is SQUASH and carries the true state.
+//   V (wave 1)  tick t + 2: the Viterbi decoder's forward pass;
+//   S (wave 3)  tick t + 3: survivor walk, CRC; then the real feedback (rx_loop_bcch_result) on the state F started from -- if
+//               that is not bit for bit the state F assumed, the verdict is SQUASH and carries the true state;
 //
-//   S (wave 3)  within tick t, beside F: the last partial round of the correlation's lags, then -- once F has the coarse
-//               peak p -- the sync-symbol terms for the three values round(toa) can take, while F bisects (LatPre (4));
+//               and within every tick, beside F: the last partial round of the correlation's lags, then -- once F has the
+//               coarse peak p -- the sync-symbol terms for the three values round(toa) can take, while F bisects (LatPre (4));
 //               hand-shakes through LDS flags, every wait bounded with the waiting wave doing the work itself on time-out.
 //
-// One work-group barrier per tick.  A verdict reaches F three barriers after the hand-over, i.e. when it has run TWO fronts
+// One work-group barrier per tick.  A verdict reaches F four barriers after the hand-over, i.e. when it has run THREE fronts
 // on the assumption: on SQUASH those and everything listed from the assumed state are dropped (the CCCH list and frame-log
-// entries are overwritten, the counters restored from a checkpoint), F restarts from the true state and V skips the two
-// stale hand-overs in flight.  The same float operations run on the same inputs as in the serial walk, so every record is
+// entries are overwritten, the counters restored from a checkpoint), F restarts from the true state in a new epoch and the
+// judge skips the hand-overs of the old one still in flight.  The same float operations run on the same inputs as in the serial walk, so every record is
 // bit-identical to it; a chain whose every burst fails runs at about the serial walk's speed.
-// What F hands over is indexed by tick mod 3 (read by P a tick, by V two ticks later); the buffers P fills for F likewise (P
-// writes slot t, F reads slot t - 1, P's pass 2 reads the window of t - 2); operand tables and verdicts by tick parity.
+// What F hands over is indexed by tick mod 4 (read by P a tick, by V two, by S three ticks later); the buffers P fills for F
+// by tick mod 3 (P writes slot t, F reads slot t - 1, P's pass 2 reads the window of t - 2); operand tables, survivor words
+// and verdicts by tick parity.
 // ---------------------------------------------------------------------------
 struct LoopHand {                  // F -> P, V: 32 words, written one per lane
 	RxLoopState pre;               // the chain as the burst's feedback finds it (this burst's energy already in)
@@ -3815,7 +3831,8 @@ struct LoopHand {                  // F -> P, V: 32 words, written one per lane
 	float minen;
 	int b_frame;
 	uint32_t stamp_lo, stamp_hi;   // (profiling build: where this round's cycle stamps go)
-	uint32_t pad[5];
+	int epoch;                     // squashes F had seen when it wrote this: the judge skips hand-overs of earlier epochs
+	uint32_t pad[4];
 };
 static_assert(sizeof(RxLoopState) == 48 && sizeof(LoopHand) == 128, "the hand-over is written as 32 words");
 __device__ __forceinline__ uint32_t loop_state_word(const RxLoopState &x, int i)
@@ -3851,8 +3868,8 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	__shared__ uint64_t h_off[3], s_pred[2];
 	__shared__ int h_kind[3], s_go[2];               // s_go, s_pred: F -> P, V, by tick parity
 	__shared__ float h_stat[3][4];
-	__shared__ LoopHand s_hand[3];
-	__shared__ typename LatPre<NPL, SPS>::Cut s_cut[3];
+	__shared__ LoopHand s_hand[4];
+	__shared__ typename LatPre<NPL, SPS>::Cut s_cut[4];
 	__shared__ int s_vd[2];                    // V -> F, by the parity of the tick V wrote it in
 	__shared__ RxLoopState s_true[2];
 	__shared__ LoopCo s_co[2];                 // F <-> S, by tick parity
@@ -3864,7 +3881,8 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	// P's operands, V's survivor words and results
 	__shared__ uint8_t b_kind[1];
 	__shared__ int32_t b_rv[1];
-	__shared__ __align__(16) uint64_t v_surv[13 * 16];
+	__shared__ __align__(16) uint64_t v_surv[2][13 * 16];     // V -> S, by tick parity
+	__shared__ uint32_t v_fae[2];
 	__shared__ uint32_t v_ubits[4 * 8];
 	// LDS copies of the constant tables every burst reads (see LatPre)
 	__shared__ __align__(16) uint16_t s_lut[1024];
@@ -3875,10 +3893,10 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	const int chain = blockIdx.x;
 	const int lane = (int)threadIdx.x & 63;
 	const int sps = a.sps;
-	if (threadIdx.x < 3) {
+	if (threadIdx.x < 3)
 		h_off[threadIdx.x] = ~0ull;
+	if (threadIdx.x < 4)
 		s_hand[threadIdx.x].valid = 0;
-	}
 	if (threadIdx.x == 0) {
 		s_vd[0] = s_vd[1] = kVdNone;
 		b_kind[0] = 0;
@@ -3910,8 +3928,13 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 	}
 	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
 
-	// ------------------------------------------------------------------ S: the front's helper (LatPre (4))
+	// ------------------------------------------------------------------ S: the front's helper (LatPre (4)) and the judge
 	if (wave == 3) {
+		DecPre dpre;
+		dpre.dc = 0;
+		dpre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
+		dpre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
+		int epoch = 0;                             // squashes issued: hand-overs F wrote before it learnt of the last are stale
 		for (int t = 0;; t++) {
 			__syncthreads();
 			if (!s_go[t & 1])
@@ -3919,9 +3942,71 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			LoopCo *const co = &s_co[t & 1];
 			const int id = t + 1;
 			const int slot = (t + 2) % 3;                // what P prepared during the last tick
-			if (co->job != id || h_off[slot] != co->off)
-				continue;                                // no burst this tick, or not where it was expected: F works alone
-			loop_front_helper<SPS>(a, co, id, hx0 + slot * stage_al, lane);
+			// no burst this tick, or not where it was expected: F works alone
+			const bool helps = co->job == id && h_off[slot] == co->off;
+			// (1) first what F will wait for soonest: the last round of the correlation's lags
+			const int p_pred = co->p_pred;
+			if (helps) {
+				loop_front_helper_corr<SPS>(a, co, id, hx0 + slot * stage_al, lane);
+				// ... and, ahead of F's peak search, the sync-symbol terms for the peak an aligned chain will find
+				loop_front_helper_sync<SPS>(a, co, hx0 + slot * stage_al, lane, p_pred);
+			}
+			// (2) the tail of the burst V ran its forward pass on during the last tick -- survivor walk, CRC -- and the
+			// verdict: the feedback as the reference applies it (rx_bcch, gmr1_rx.c:782-791), on the state F started from
+			const LoopHand &h = s_hand[(t + 1) & 3];          // F's of three ticks ago
+			if (t > 2 && h.valid != 0 && h.epoch == epoch) {
+#ifdef GMR1_HIP_PROFILE
+				dpre.stamp = reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo);
+#endif
+				uint32_t syn;
+				GMR1_DSTAMP(&dpre, 24, lane);
+				k5_12_survivors_crc_lat(v_surv[(t - 1) & 1], v_ubits, lane, syn, &dpre);
+				GMR1_DSTAMP(&dpre, 7, lane);
+				// (row 0 holds the burst: its syndrome, for every lane)
+				syn = (uint32_t)__builtin_amdgcn_readfirstlane((int)syn);
+				const uint32_t fae = v_fae[(t - 1) & 1];
+				const int crc = syn ? 1 : 0;
+				RxLoopState st = h.pre;
+				const int emit = rx_loop_bcch_result(st, sps, 0, crc, h.toa, h.ffe, reinterpret_cast<const uint8_t *>(v_ubits), h.e_toa);
+				// (F assumed: time and frequency applied, nothing else moved)
+				const bool same = st.align == h.spec_align && __float_as_uint(st.freq_err) == __float_as_uint(h.spec_ferr) &&
+				                  st.fn == h.pre.fn && st.delay == h.pre.delay && st.stn == h.pre.stn;
+				if (lane == 0) {
+					// the round's log entry (the walk's part came with the hand-over)
+					RxLoopRound e;
+					e.c_first = h.c_first;
+					e.c_n = h.c_n;
+					e.minen = h.minen;
+					e.b_emit = emit;
+					e.b_fn = st.fn;
+					e.b_tn = st.stn;
+					e.b_conv = (int32_t)fae;
+					e.b_frame = h.b_frame;
+					uint32_t *l2w = reinterpret_cast<uint32_t *>(e.b_l2);
+#pragma unroll
+					for (int i = 0; i < 6; i++)
+						l2w[i] = v_ubits[i];
+					rlog[h.round] = e;
+					s_true[t & 1] = st;
+					s_vd[t & 1] = same ? kVdOk : kVdSquash;
+				}
+				if (!same)
+					epoch++;
+				WSYNC();
+			} else if (lane == 0) {
+				s_vd[t & 1] = kVdNone;
+			}
+			// (3) once F has the coarse peak: the sync-symbol terms of its three candidates -- already there if the peak is
+			// where it was expected
+			if (helps && lds_wait_eq(&co->p_id, id)) {
+				const int p = co->p;
+				if (p >= 0) {
+					if (p != p_pred)
+						loop_front_helper_sync<SPS>(a, co, hx0 + slot * stage_al, lane, p);
+					if (lane == 0)
+						lds_post(&co->s_id, id);
+				}
+			}
 		}
 		return;
 	}
@@ -3937,10 +4022,10 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			__syncthreads();
 			if (!s_go[t & 1])
 				break;
-			// (a hand-over made stale by a SQUASH is worked on all the same -- everything it names is in LDS --; V skips it)
-			const LoopHand &h = s_hand[(t + 2) % 3];          // F's of the last tick
+			// (a hand-over made stale by a SQUASH is worked on all the same -- everything it names is in LDS --; the judge skips it)
+			const LoopHand &h = s_hand[(t + 3) & 3];          // F's of the last tick
 			if (t > 0 && h.valid) {
-				pre.cut = &s_cut[(t + 2) % 3];
+				pre.cut = &s_cut[(t + 3) & 3];
 				pre.win_r = win0 + h.win * kWin;
 				pre.vtab = vtab0 + (t & 1) * (kLatTabBytes / 4);
 				pre.b_fsh = h.fsh;
@@ -3963,67 +4048,27 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		return;
 	}
 
-	// ------------------------------------------------------------------ V: the decoder and the verdict, two rounds behind
+	// ------------------------------------------------------------------ V: the decoder's forward pass, two rounds behind
 	if (wave == 1) {
 		DecPre dpre;
 		dpre.dc = c_dec.v[lane & 15];
-		dpre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
-		dpre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
-		int skip = 0;                              // hand-overs in flight that a SQUASH made stale
+		dpre.sy0 = dpre.sy1 = make_uint4(0, 0, 0, 0);
 		for (int t = 0;; t++) {
 			__syncthreads();
 			if (!s_go[t & 1])
 				break;
-			const LoopHand &h = s_hand[(t + 1) % 3];          // F's of two ticks ago, P's of the last
-			const bool work = t > 1 && h.valid != 0 && skip == 0;
-			if (skip)
-				skip--;
-			if (!work) {
-				if (lane == 0)
-					s_vd[t & 1] = kVdNone;
+			const LoopHand &h = s_hand[(t + 2) & 3];          // F's of two ticks ago, P's of the last
+			if (!(t > 1 && h.valid != 0))
 				continue;
-			}
 #ifdef GMR1_HIP_PROFILE
 			dpre.stamp = reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo);
 			GMR1_DSTAMP(&dpre, 15, lane);
 #endif
 			uint32_t syn, fae;
-			decode1_k5_12_lat<ACC>(vtab0 + ((t - 1) & 1) * (kLatTabBytes / 4), v_surv, v_ubits, lane, syn, fae, &dpre);
-			GMR1_DSTAMP(&dpre, 7, lane);
-			// (row 0 holds the burst: its syndrome and metric, for every lane)
-			syn = (uint32_t)__builtin_amdgcn_readfirstlane((int)syn);
-			fae = (uint32_t)__builtin_amdgcn_readfirstlane((int)fae);
-			const int crc = syn ? 1 : 0;
-			// the feedback as the reference applies it (rx_bcch, gmr1_rx.c:782-791), on the state F started from
-			RxLoopState st = h.pre;
-			const int emit = rx_loop_bcch_result(st, sps, 0, crc, h.toa, h.ffe, reinterpret_cast<const uint8_t *>(v_ubits), h.e_toa);
-			// (F assumed: time and frequency applied, nothing else moved)
-			const bool same = st.align == h.spec_align && __float_as_uint(st.freq_err) == __float_as_uint(h.spec_ferr) &&
-			                  st.fn == h.pre.fn && st.delay == h.pre.delay && st.stn == h.pre.stn;
-			if (lane == 0) {
-				// the round's log entry (the walk's part came with the hand-over)
-				RxLoopRound e;
-				e.c_first = h.c_first;
-				e.c_n = h.c_n;
-				e.minen = h.minen;
-				e.b_emit = emit;
-				e.b_fn = st.fn;
-				e.b_tn = st.stn;
-				e.b_conv = (int32_t)fae;
-				e.b_frame = h.b_frame;
-				uint32_t *l2w = reinterpret_cast<uint32_t *>(e.b_l2);
-#pragma unroll
-				for (int i = 0; i < 6; i++)
-					l2w[i] = v_ubits[i];
-				rlog[h.round] = e;
-			}
-			if (lane == 0) {
-				s_true[t & 1] = st;
-				s_vd[t & 1] = same ? kVdOk : kVdSquash;
-			}
-			if (!same)
-				skip = 2;
-			WSYNC();
+			decode1_k5_12_lat<ACC, false>(vtab0 + ((t - 1) & 1) * (kLatTabBytes / 4), v_surv[t & 1], nullptr, lane, syn, fae, &dpre);
+			// (row 0 holds the burst: location 0 of it the end state's metric)
+			if (lane == 0)
+				v_fae[t & 1] = fae;
 		}
 		return;
 	}
@@ -4097,8 +4142,10 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 		return n;
 	};
 	// checkpoints of the rounds handed over, by tick mod 3: what a SQUASH restores
-	int cp_round[3] = {0, 0, 0}, cp_frames[3] = {0, 0, 0}, cp_ccch[3] = {0, 0, 0};
-	bool age1 = false, age2 = false, age3 = false;   // a hand-over of one (P is at it) / two (V is) / three ticks ago (verdict due)
+	int cp_round[4] = {0, 0, 0, 0}, cp_frames[4] = {0, 0, 0, 0}, cp_ccch[4] = {0, 0, 0, 0};
+	// a hand-over of one (P is at it) / two (V is) / three (the judge is) / four ticks ago (verdict due)
+	bool age1 = false, age2 = false, age3 = false, age4 = false;
+	int epoch = 0;                                   // squashes seen
 	int n = round < round_end ? list_round() : 0;
 	bool finished = false;
 	int t = 0;
@@ -4129,24 +4176,26 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			const bool job = n > 0 && round < round_end && rb_has;
 			c.off = job ? st.base + (uint64_t)rb_begin : 0;
 			c.fsh = -st.freq_err;
+			c.p_pred = rb_etoa;
 			c.job = job ? t + 1 : 0;
 		}
 		bool co_job = n > 0 && round < round_end && rb_has;
 		__syncthreads();
 		GMR1_FSTAMP(17);
-		const int t3 = t % 3;
-		// ---- the verdict on the hand-over of three ticks ago (V worked on it during the last tick)
-		if (age3 && s_vd[(t - 1) & 1] == kVdSquash) {
-			// the two fronts run since and everything listed since started from a state that never came to be: back to the
-			// checkpoint of the round V judged, its true feedback, and on from there within this tick (V skips the two stale
-			// hand-overs in flight by itself; what P has prepared is checked against the burst's place as always)
+		const int t3 = t & 3;
+		// ---- the verdict on the hand-over of four ticks ago (the judge worked on it during the last tick)
+		if (age4 && s_vd[(t - 1) & 1] == kVdSquash) {
+			// the three fronts run since and everything listed since started from a state that never came to be: back to the
+			// checkpoint of the round judged, its true feedback, and on from there within this tick (the hand-overs in flight
+			// carry the old epoch: the judge skips them; what P has prepared is checked against the burst's place as always)
 			st = s_true[(t - 1) & 1];
 			n_frames = cp_frames[t3];
 			n_ccch = cp_ccch[t3];
 			round = cp_round[t3] + 1;
 			on_frame(st);
 			rx_loop_advance(st, sps);
-			age1 = age2 = false;
+			age1 = age2 = age3 = false;
+			epoch++;
 			n = round < round_end ? list_round() : 0;
 			// (the helper wave may have taken up the burst listed before: it is to stop waiting for that front)
 			if (co_job && lane == 0) {
@@ -4155,6 +4204,7 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			}
 			co_job = false;
 		}
+		age4 = age3;
 		age3 = age2;
 		age2 = age1;
 		age1 = false;
@@ -4162,7 +4212,7 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 			// nothing (more) to start in this launch: wait for what P and V still hold
 			if (lane == 0)
 				s_hand[t3].valid = 0;
-			if (!age2 && !age3) {
+			if (!age2 && !age3 && !age4) {
 				finished = n == 0 && round < round_end;
 				break;
 			}
@@ -4235,11 +4285,13 @@ __global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, 
 #else
 					hv.stamp_lo = hv.stamp_hi = 0;
 #endif
+					hv.epoch = epoch;
 					uint4 *dst = reinterpret_cast<uint4 *>(&s_hand[t3]);
 					const uint4 *src = reinterpret_cast<const uint4 *>(&hv);
 #pragma unroll
 					for (int i = 0; i < 7; i++)
 						dst[i] = src[i];
+					static_assert(offsetof(LoopHand, epoch) < 7 * 16, "the words copied hold every field");
 				}
 				cp_round[t3] = round;
 				cp_frames[t3] = n_frames;

@@ -142,7 +142,7 @@ def test_the_reference_program_running_on_this_library(gold):
     sources are: oracle/_ref/gmr1_ambe_decode_hip) reads a file of frames and writes the file the reference writes.
     It is a second GPU process started from this one, so it only runs on request and on its own, before this process
     has touched the GPU:  GMR1_RUN_REF_PROGRAM=1 python -m pytest tests/test_gpu_ambe.py -m gpu -k running_on_this_library
-    (profiles/r02r_ref_program_on_hip.log is such a run)."""
+    (profiles/archive/r02r_ref_program_on_hip.log is such a run)."""
     import ref_codec
     if os.environ.get("GMR1_RUN_REF_PROGRAM") != "1":
         pytest.skip("set GMR1_RUN_REF_PROGRAM=1 and select this test alone")

@@ -43,7 +43,7 @@ print(f"{A} carriers x {seconds} s: {e0.elapsed_time(e1) / 5:.3f} ms per run (ac
 out = (C.c_ulonglong * 32)()
 assert L.gmr1_hip_prof_stamps(out) == 0
 t = np.array(list(out), np.int64)
-print("cycle stamps of chain 0's round 55 (shader clock).  The burst runs on three waves, a tick apart: F = front, P = pass 2 + operand table, V = decoder")
+print("cycle stamps of chain 0's round 55 (shader clock).  The burst runs through four stages, a tick apart: F = front (S beside it), P = pass 2 + operand table, V = decoder forward pass, S = decoder tail + verdict")
 f = [("window (prepared: statistics only)", 1, 0), ("staging + correlation", 2, 1), ("parameters looked up", 10, 2), ("window argmax reduced", 11, 10),
      ("coarse peak", 8, 11), ("nine halvings", 9, 8), ("peak value + bookkeeping", 3, 9), ("sync terms (frequency, phase)", 4, 3)]
 print(f"F: front, {t[4] - t[0]} cycles")
@@ -52,9 +52,9 @@ for name, k, k0 in f:
 print(f"P: pass 2 + operand table, {t[6] - t[14]} cycles (starts {t[14] - t[0]} after F's start)")
 print(f"  {'pass 2 (soft bits)':38s} +{t[5] - t[14]:6d}")
 print(f"  {'branch metrics -> operand table':38s} +{t[6] - t[5]:6d}")
-print(f"V: decoder, {t[7] - t[15]} cycles (starts {t[15] - t[0]} after F's start)")
-print(f"  {'forward pass':38s} +{t[12] - t[15]:6d}")
-print(f"  {'survivor walk':38s} +{t[13] - t[12]:6d}")
+print(f"V: decoder's forward pass, {t[12] - t[15]} cycles (starts {t[15] - t[0]} after F's start)")
+print(f"S: the decoder's tail a tick later (beside its help to F): survivor walk + CRC {t[7] - t[24]} cycles (starts {t[24] - t[0]} after F's start)")
+print(f"  {'survivor walk':38s} +{t[13] - t[24]:6d}")
 print(f"  {'CRC':38s} +{t[7] - t[13]:6d}")
 print(f"F's tick around that front (walk, hand-over, listing): {t[23] - t[16]} cycles")
 for name, k, k0 in [("pred published, barrier passed", 17, 16), ("verdict checked", 18, 17), ("CCCH bursts listed (global)", 19, 18),
