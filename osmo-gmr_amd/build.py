@@ -54,7 +54,7 @@ def needs_build() -> bool:
     if not os.path.exists(stamp) or open(stamp).read().strip() != want:
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     for d, _, files in os.walk(os.path.join(ROOT, "include")):
         deps += [os.path.join(d, f) for f in files]
     return any(os.path.getmtime(p) > t for p in deps)
@@ -108,7 +108,7 @@ def _build(lib: str, extra, suffix: str, verbose: bool, force: bool = False) -> 
             fh.write(want + "\n")
         return obj
 
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     for d, _, files in os.walk(os.path.join(ROOT, "include")):
         headers += [os.path.join(d, f) for f in files]
     with ThreadPoolExecutor(max(1, min(6, os.cpu_count() or 1))) as ex:

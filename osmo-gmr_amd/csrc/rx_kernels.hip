@@ -3497,958 +3497,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4gTch3Wav
 	}
 }
 
-// The receive loop's BCCH burst where rx4_body has no instantiation -- below 4 samples per symbol (the sinc fractional
-// delay of pi4cxpsk.c:298-343) and above 8 (windows beyond 2048 samples): the one-burst-at-a-time body of k_rx on the one
-// burst, operands and results in the chain's LDS slots (io).  Not shaped for latency; the reference's program accepts
-// 1..16 samples per symbol (gmr1_rx.c:919-922) and so does the loop.
-template <int NPL, int SPS, bool ACC>
-__device__ void rx1_lat_body(const RxArgs &a, const RxIo io, int max_in_len, int max_len, unsigned char *lds_raw, int lane)
-{
-	const Lds L = lds_carve(lds_raw, max_in_len, max_len, true);
-	const int kind = __builtin_amdgcn_readfirstlane(io.kind[0] ? 1 : 0);
-	const int type = kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH;
-	const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
-	const float fsh = io.freq_shift ? io.freq_shift[0] : 0.0f;
-	const float2 *__restrict__ in = a.iq + io.offset[0];
-	int sid = -1;
-	float toa = 0.f, fe = 0.f;
-	WSYNC();
-	const int rv = demod_one<NPL, SPS>(type, in, in_len, a.sps, fsh, L, L.eb, lane, 0, sid, toa, fe, nullptr);
-	const float e = window_energy<NPL>(in, in_len, lane);
-	if (lane == 0) {
-		io.rv[0] = rv;
-		io.toa[0] = rv ? 0.f : toa;
-		io.freq_err[0] = rv ? 0.f : fe;
-		if (io.energy)
-			io.energy[0] = e;
-	}
-	WSYNC();     // x is dead from here on: bm / surv / ubits overlay it
-	if (rv == 0)
-		branch_metrics_k5_12<ACC>(L.eb, kind, L.bm, lane);
-	for (int k = lane + (rv == 0 ? kSteps12 : 0); k < 4 * kSteps12; k += 64)
-		L.bm[k] = 0;
-	WSYNC();
-	uint32_t syn, fae;
-	decode4_k5_12<ACC>(L.bm, L.surv, L.ubits, lane, syn, fae);
-	if (lane == 0) {
-		uint32_t *l2w = reinterpret_cast<uint32_t *>(io.l2);
-#pragma unroll
-		for (int i = 0; i < 6; i++)
-			l2w[i] = rv == 0 ? L.ubits[i] : 0u;
-		io.crc[0] = rv == 0 ? (syn ? 1 : 0) : -1;
-		io.conv[0] = rv == 0 ? (int32_t)fae : 0;
-	}
-	WSYNC();
-}
-
-// ---------------------------------------------------------------------------
-// The receive loop -- process_bcch (reference src/gmr1_rx.c:852-895) of every chain, from its first frame to the end of the
-// capture, without leaving the GPU.  The feedback of the loop only crosses a BCCH burst (time, frequency, SI1 TDMA
-// position, gmr1_rx.c:782-791); nothing a CCCH burst yields is read by a later burst.  So the loop runs as
-//
-//   k_rx_chain   one wavefront per chain, ALONE on its SIMD: list the frames up to and including the next BCCH burst
-//                (rx_loop_build_round, rx_loop.h), demodulate and decode that burst (rx4_body, the burst kernel itself, at
-//                its latency shape), apply its result, log the round; the round's CCCH bursts are only listed -- where they
-//                sit, the frequency shift and the energy gate level of the moment.  A round is one burst's latency; with
-//                the CCCH bursts on the same work-group's other waves (the previous form) it was 1.2 x that, the BCCH wave
-//                sharing its SIMD's issue slots with a CCCH wave, and the round waited for the slowest of seven;
-//   k_rx4        the listed CCCH bursts of all chains as one batch, four per wavefront (the throughput shape);
-//   k_rx_merge   one wavefront per chain: the records, in frame order, exactly as rx_bcch / rx_ccch emit them (energy gate
-//                first, then found, then CRC; gmr1_rx.c:746-850).
-//
-// What goes to HBM in between is a few dozen bytes per burst (RxLoopRound, RxLoopCcch, the burst kernel's own outputs).
-// ---------------------------------------------------------------------------
-// ONE: the one-burst generic body (rx1_lat_body) instead of rx4_body's latency shape; stage_samples / cw then carry the
-// window length and the lag count its LDS layout is sized by, and nothing is prepared ahead
-template <int NPL, int SPS, bool ACC = false, bool ONE = false>
-__global__ __launch_bounds__(128) void k_rx_chain(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body, int slice,
-                                                   int slice_rounds)
-{
-	extern __shared__ __align__(16) unsigned char lds_raw[];
-	// wave 0 walks the chain; wave 1 (another SIMD) prepares, a round ahead, what depends only on where the next BCCH
-	// burst sits (LatPre, lat_prepare): the two meet at one barrier per round
-	__shared__ uint64_t h_off[2], s_pred;
-	__shared__ int h_kind[2], s_go;
-	__shared__ float h_stat[2][4];
-	float2 *h_x[2] = {reinterpret_cast<float2 *>(lds_raw + lds_body),
-	                  reinterpret_cast<float2 *>(lds_raw + lds_body) + ((stage_samples + 15) & ~15)};
-	uint32_t *vtab = reinterpret_cast<uint32_t *>(h_x[1] + ((stage_samples + 15) & ~15));      // the decoder's operand table
-	const int wave = (int)threadIdx.x >> 6;
-	// operands and results of the round's BCCH burst
-	__shared__ uint64_t s_off[1];
-	__shared__ float s_fs[1];
-	__shared__ uint8_t s_kind[1];
-	__shared__ RxLoopItem s_items[kLoopPerRound];
-	__shared__ __align__(8) uint8_t s_l2[24];
-	__shared__ int32_t s_crc[1], s_conv[1], s_rv[1];
-	__shared__ float s_toa[1], s_fe[1], s_en[1];
-	const int chain = blockIdx.x;
-	const int lane = (int)threadIdx.x & 63;
-	const int sps = a.sps;
-	if (threadIdx.x < 2)
-		h_off[threadIdx.x] = ~0ull;
-	// this launch walks the chain through one time slice: rounds [round0, round_end) -- it picks up where the previous
-	// slice left the chain (state, counters) and, at its end, notes how long the CCCH list has become (slice_end); the next
-	// slice's entries start at the next multiple of four, so that the batch kernel's groups of four never straddle two slices
-	// (the first slice starts every counter at zero -- rounds, frames, list length, the finished flag -- and writes the zeroth
-	// row of slice_end for the batch kernel of its slice; nothing clears them beforehand)
-	const int round0 = slice ? la.n_rounds[chain] : 0;
-	const int round_end = min(round0 + slice_rounds, la.max_rounds);
-	if (slice == 0 && threadIdx.x == 0)
-		la.slice_end[chain] = 0;
-	if (slice && la.fin[chain]) {
-		if (threadIdx.x == 0)
-			la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = la.slice_end[(size_t)slice * gridDim.x + chain];
-		return;
-	}
-	// (alone on its SIMD only until the previous slice's CCCH batch arrives on the same CU: the chain goes first)
-	__builtin_amdgcn_s_setprio(3);
-	if (wave == 1) {
-		for (int round = round0; round < round_end; round++) {
-			__syncthreads();
-			if (!s_go)
-				break;
-			const uint64_t pred = s_pred;
-			const int nb = (round + 1) & 1;
-			if constexpr (!ONE)
-				if (pred != ~0ull)
-					lat_prepare<NPL, SPS>(a, pred, 0, lane, h_x[nb], h_stat[nb]);
-			if (lane == 0) {
-				h_off[nb] = pred;
-				h_kind[nb] = 0;
-			}
-		}
-		return;
-	}
-	RxLoopState st = la.state[chain];          // every lane computes the same
-	const uint64_t lim = st.base + (uint64_t)st.len;
-	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
-	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
-	const size_t c_base = (size_t)chain * la.c_stride;
-	int n_frames = slice ? la.n_frames[chain] : 0, n_ccch = slice ? (la.slice_end[(size_t)slice * gridDim.x + chain] + 3) & ~3 : 0;
-	auto on_frame = [&](const RxLoopState &x) {
-		if (flog && lane == 0 && n_frames < la.flog_stride)
-			flog[n_frames] = {x.align, x.freq_err, x.fn};
-		n_frames++;
-	};
-	// LDS copies of the constant tables every burst reads (see LatPre)
-	__shared__ __align__(16) uint16_t s_lut[1024];
-	__shared__ uint32_t s_steps[2 * kSteps12];
-	__shared__ uint32_t s_cost_a[512], s_cost_b[512];
-	if constexpr (!ONE) {
-		const CostTable &ctab = ACC ? c_cost_acc : c_cost;
-		for (int i = lane; i < 1024; i += 64)
-			s_lut[i] = g_sb_lut.v[i];
-		for (int i = lane; i < 2 * kSteps12; i += 64)
-			s_steps[i] = c_steps.w[i / kSteps12][i % kSteps12];
-		for (int i = lane; i < 512; i += 64) {
-			s_cost_a[i] = ctab.a[i];
-			s_cost_b[i] = ctab.b[i];
-		}
-	}
-	LatPre<NPL, SPS> pre;
-	pre.lut = reinterpret_cast<const unsigned char *>(s_lut);
-	pre.steps = s_steps;
-	pre.cost_a = s_cost_a;
-	pre.cost_b = s_cost_b;
-	pre.vtab = vtab;
-	pre.dc = c_dec.v[lane & 15];
-	pre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
-	pre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
-	WSYNC();
-	int round = round0;
-	bool finished = false;
-	for (; round < round_end; round++) {
-		const int frames_at_round = n_frames;
-		const float minen = st.bcch_energy / 2.0f;              // the gate level the round starts with
-		// ---- the round: what rx_loop_build_round does frame after frame, for the usual case (the next sixteen frames all
-		// lie inside the capture) with one frame per lane
-		int n;
-		{
-			const int frame_len = sps * 24 * 39;
-			const int j = lane & 15;
-			const int fn_j = st.fn + j, align_j = st.align + j * frame_len;
-			const bool inside = !st.done && st.align + 17 * frame_len <= st.len;   // frames 0..15 are all reached
-			const int m = (fn_j - st.delay) & 7;
-			const int tn_off = sps * st.stn * 39;
-			const int b_b = align_j + tn_off - 10 * sps, b_c = align_j + tn_off - 5 * sps;   // burst_map, e_toa = win / 2
-			const bool ok_b = b_b >= 0 && b_b + 234 * sps + 20 * sps <= st.len;
-			const bool ok_c = b_c >= 0 && b_c + 234 * sps + 10 * sps <= st.len;
-			const uint32_t mb = (uint32_t)__ballot(lane < 16 && m == 2 && ok_b) & 0xffffu;
-			const uint32_t mc = (uint32_t)__ballot(lane < 16 && m != 0 && m != 2 && ok_c) & 0xffffu;
-			const int jb = mb ? __builtin_ctz(mb) : 16;             // the first BCCH burst
-			const uint32_t before = mc & ((1u << jb) - 1u);
-			if (inside && mb && __popc(before) < kLoopPerRound - 1) {
-				// CCCH bursts of frames 0 .. jb-1, then the BCCH burst of frame jb (which stays the current frame)
-				const uint32_t items = before | (1u << jb);
-				if (lane < 16 && ((items >> j) & 1u)) {
-					const int idx = __popc(items & ((1u << j) - 1u));
-					const bool is_b = j == jb;
-					s_items[idx] = {is_b ? b_b : b_c, is_b ? 1 : 0, fn_j, st.stn, is_b ? 10 * sps : 5 * sps, j};
-				}
-				if (flog && lane < jb && n_frames + lane < la.flog_stride)
-					flog[n_frames + lane] = {align_j, st.freq_err, fn_j};
-				n_frames += jb;
-				st.fn += jb;
-				st.align += jb * frame_len;
-				n = __popc(items);
-			} else {
-				n = rx_loop_build_round(st, sps, s_items, on_frame);
-			}
-		}
-		WSYNC();
-		const bool has_b = n > 0 && s_items[n - 1].is_bcch != 0;  // always the round's last item
-		if (lane == 0) {
-			// where the next round's BCCH burst will most likely sit: eight frames on
-			uint64_t pred = ~0ull;
-			if (has_b && !ONE) {
-				pred = st.base + (uint64_t)s_items[n - 1].begin + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
-				if (pred + (uint64_t)a.in_len[0] > lim)
-					pred = ~0ull;
-			}
-			s_pred = pred;
-			s_go = n > 0;
-		}
-		__syncthreads();
-		if (n == 0) {
-			finished = true;
-			break;
-		}
-		const int n_c = has_b ? n - 1 : n;
-		// the CCCH bursts: listed for the batch that follows
-		if (lane < n_c && n_ccch + lane < la.c_stride) {
-			const RxLoopItem it = s_items[lane];
-			const size_t k = c_base + (size_t)(n_ccch + lane);
-			la.c_off[k] = st.base + (uint64_t)it.begin;
-			la.c_fs[k] = -st.freq_err;
-			la.c_kind[k] = 1;
-			la.c_meta[k] = {it.fn, it.tn, frames_at_round + it.frames_before};
-		}
-		int b_emit = 0, b_fn = 0, b_tn = 0, b_frame = 0;
-		if (has_b) {
-			const RxLoopItem it = s_items[n - 1];
-			if (lane == 0) {
-				s_off[0] = st.base + (uint64_t)it.begin;
-				s_fs[0] = -st.freq_err;
-				s_kind[0] = 0;
-			}
-			WSYNC();
-			pre.h_off = &h_off[round & 1];
-			pre.h_kind = &h_kind[round & 1];
-			pre.h_stat = h_stat[round & 1];
-			pre.h_x = h_x[round & 1];
-			const RxIo io = {
-#ifdef GMR1_HIP_PROFILE
-			                 (chain == 0 && round == kStampRound) ? g_stamp : nullptr,
-#endif
-			                 s_off, s_kind, s_fs, s_l2, s_crc, s_conv, s_rv, nullptr, s_toa, s_fe, s_en, nullptr, nullptr};
-			if constexpr (ONE)
-				rx1_lat_body<NPL, SPS, ACC>(a, io, stage_samples, cw, lds_raw, lane);
-			else
-				rx4_body<NPL, SPS, true, false, false, ACC>(a, io, stage_samples, cw, 0, 1, lds_raw, lane, &pre);
-			WSYNC();
-			// the BCCH burst feeds back before the next round is listed (rx_bcch, gmr1_rx.c:782-795)
-			b_frame = frames_at_round + it.frames_before;
-			if (!s_rv[0]) {
-				st.bcch_energy = s_en[0];
-				b_emit = rx_loop_bcch_result(st, sps, s_rv[0], s_crc[0], s_toa[0], s_fe[0], s_l2, it.e_toa);
-			}
-			b_fn = st.fn;
-			b_tn = st.stn;
-			on_frame(st);                                        // rx_tch3 of this frame sees the updated state
-			rx_loop_advance(st, sps);
-		}
-		{
-			// the round's log entry: 14 words
-			uint32_t *d = reinterpret_cast<uint32_t *>(rlog + round);
-			const uint32_t *l2w = reinterpret_cast<const uint32_t *>(s_l2);
-			uint32_t v = 0;
-			switch (lane) {
-			case 0: v = (uint32_t)n_ccch; break;
-			case 1: v = (uint32_t)n_c; break;
-			case 2: v = __float_as_uint(minen); break;
-			case 3: v = (uint32_t)b_emit; break;
-			case 4: v = (uint32_t)b_fn; break;
-			case 5: v = (uint32_t)b_tn; break;
-			case 6: v = has_b ? (uint32_t)s_conv[0] : 0u; break;
-			case 7: v = (uint32_t)b_frame; break;
-			default: v = (has_b && lane < 14) ? l2w[lane - 8] : 0u; break;
-			}
-			if (lane < 14)
-				d[lane] = v;
-		}
-		n_ccch += n_c;
-		WSYNC();
-	}
-	if (lane == 0) {
-		la.n_rounds[chain] = round;
-		la.n_ccch[chain] = n_ccch;
-		la.n_frames[chain] = n_frames;
-		la.state[chain] = st;
-		la.fin[chain] = finished ? 1 : 0;
-		la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = min(n_ccch, la.c_stride);
-	}
-}
-
-// ---------------------------------------------------------------------------
-// The same walk, SOFTWARE-PIPELINED ACROSS ROUNDS (4 ... 8 samples per symbol).  The reference applies a BCCH burst's feedback
-// only `if (!crc)` (gmr1_rx.c:782-791): align += round(toa) - e_toa, freq_err += freq_err, then bcch_tdma_align (:194-233).
-// toa and freq_err exist once the demodulator's front is through (sync search, timing, sync-symbol terms,
-// pi4cxpsk.c:547-575); the rest of the burst (soft bits :577-600, Viterbi and CRC bcch.c:83-103) contributes a binary verdict
-// and the SI1 fields, which repeat once a chain is aligned.  So a work-group of four waves on the CU's four SIMDs, three of
-// them pipeline stages:
-//
-//   F (wave 0)  tick t: the FRONT of round r's burst, then the feedback AS IF the CRC will pass and SI1 will move nothing,
-//               the frames up to the next BCCH burst listed from that assumed state, and straight on to round r + 1;
-//   P (wave 2)  tick t + 1: pass 2 of that burst out of its window in LDS and the decoder's operand table (branch metrics);
-//               then the window of the burst F will need at tick t + 2, fetched where the schedule predicts it
-//               (statistics, energy, normalised sync-chunk windows as before -- and the whole raw window into LDS: no
-//               phase of a round goes back to global memory);
-//   V (wave 1)  tick t + 2: the Viterbi decoder's forward pass;
-//   S (wave 3)  tick t + 3: survivor walk, CRC; then the real feedback (rx_loop_bcch_result) on the state F started from -- if
-//               that is not bit for bit the state F assumed, the verdict is SQUASH and carries the true state;
-//
-//               and within every tick, beside F: the last partial round of the correlation's lags, then -- once F has the
-//               coarse peak p -- the sync-symbol terms for the three values round(toa) can take, while F bisects (LatPre (4));
-//               hand-shakes through LDS flags, every wait bounded with the waiting wave doing the work itself on time-out.
-//
-// One work-group barrier per tick.  A verdict reaches F four barriers after the hand-over, i.e. when it has run THREE fronts
-// on the assumption: on SQUASH those and everything listed from the assumed state are dropped (the CCCH list and frame-log
-// entries are overwritten, the counters restored from a checkpoint), F restarts from the true state in a new epoch and the
-// judge skips the hand-overs of the old one still in flight.  The same float operations run on the same inputs as in the serial walk, so every record is
-// bit-identical to it; a chain whose every burst fails runs at about the serial walk's speed.
-// What F hands over is indexed by tick mod 4 (read by P a tick, by V two, by S three ticks later); the buffers P fills for F
-// by tick mod 3 (P writes slot t, F reads slot t - 1, P's pass 2 reads the window of t - 2); operand tables, survivor words
-// and verdicts by tick parity.
-// ---------------------------------------------------------------------------
-struct LoopHand {                  // F -> P, V: 32 words, written one per lane
-	RxLoopState pre;               // the chain as the burst's feedback finds it (this burst's energy already in)
-	int spec_align;                // ... and what F assumed it makes of it
-	float spec_ferr;
-	int valid, round, e_toa, win;
-	float toa, ffe, fsh;
-	int c_first, c_n;              // the walk's part of the round's log entry (V writes the entry)
-	float minen;
-	int b_frame;
-	uint32_t stamp_lo, stamp_hi;   // (profiling build: where this round's cycle stamps go)
-	int epoch;                     // squashes F had seen when it wrote this: the judge skips hand-overs of earlier epochs
-	uint32_t pad[4];
-};
-static_assert(sizeof(RxLoopState) == 48 && sizeof(LoopHand) == 128, "the hand-over is written as 32 words");
-__device__ __forceinline__ uint32_t loop_state_word(const RxLoopState &x, int i)
-{
-	switch (i) {
-	case 0: return (uint32_t)x.base;
-	case 1: return (uint32_t)(x.base >> 32);
-	case 2: return (uint32_t)x.len;
-	case 3: return (uint32_t)x.align;
-	case 4: return __float_as_uint(x.freq_err);
-	case 5: return (uint32_t)x.fn;
-	case 6: return (uint32_t)x.delay;
-	case 7: return (uint32_t)x.stn;
-	case 8: return (uint32_t)x.done;
-	case 9: return __float_as_uint(x.bcch_energy);
-	default: return (uint32_t)x.arfcn | ((uint32_t)x.chain << 16);
-	}
-}
-enum { kVdNone = 0, kVdOk = 1, kVdSquash = 2 };
-
-template <int NPL, int SPS, bool ACC = false>
-__global__ __launch_bounds__(256) void k_rx_chain_pipe(RxArgs a, RxLoopArgs la, int stage_samples, int cw, int lds_body, int slice,
-                                                       int slice_rounds)
-{
-	extern __shared__ __align__(16) unsigned char lds_raw[];
-	const int stage_al = (stage_samples + 15) & ~15;
-	constexpr int kWin = NPL * 64;                     // samples of a window buffer
-	// dynamic LDS: [F's body | P's body | 3 staged sync-chunk windows | 2 operand tables | 3 raw windows]
-	unsigned char *const body_f = lds_raw, *const body_p = lds_raw + lds_body;
-	float2 *const hx0 = reinterpret_cast<float2 *>(lds_raw + 2 * (size_t)lds_body);
-	uint32_t *const vtab0 = reinterpret_cast<uint32_t *>(hx0 + 3 * stage_al);
-	float2 *const win0 = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(vtab0) + 2 * kLatTabBytes);
-	__shared__ uint64_t h_off[3], s_pred[2];
-	__shared__ int h_kind[3], s_go[2];               // s_go, s_pred: F -> P, V, by tick parity
-	__shared__ float h_stat[3][4];
-	__shared__ LoopHand s_hand[4];
-	__shared__ typename LatPre<NPL, SPS>::Cut s_cut[4];
-	__shared__ int s_vd[2];                    // V -> F, by the parity of the tick V wrote it in
-	__shared__ RxLoopState s_true[2];
-	__shared__ LoopCo s_co[2];                 // F <-> S, by tick parity
-	// F's burst operands and results
-	__shared__ uint64_t s_off[1];
-	__shared__ float s_fs[1];
-	__shared__ uint8_t s_kind[1];
-	__shared__ RxLoopItem s_items[kLoopPerRound];
-	// P's operands, V's survivor words and results
-	__shared__ uint8_t b_kind[1];
-	__shared__ int32_t b_rv[1];
-	__shared__ __align__(16) uint64_t v_surv[2][13 * 16];     // V -> S, by tick parity
-	__shared__ uint32_t v_fae[2];
-	__shared__ uint32_t v_ubits[4 * 8];
-	// LDS copies of the constant tables every burst reads (see LatPre)
-	__shared__ __align__(16) uint16_t s_lut[1024];
-	__shared__ uint32_t s_steps[2 * kSteps12];
-	__shared__ uint32_t s_cost_a[512], s_cost_b[512];
-
-	const int wave = (int)threadIdx.x >> 6;
-	const int chain = blockIdx.x;
-	const int lane = (int)threadIdx.x & 63;
-	const int sps = a.sps;
-	if (threadIdx.x < 3)
-		h_off[threadIdx.x] = ~0ull;
-	if (threadIdx.x < 4)
-		s_hand[threadIdx.x].valid = 0;
-	if (threadIdx.x == 0) {
-		s_vd[0] = s_vd[1] = kVdNone;
-		b_kind[0] = 0;
-	}
-	if (threadIdx.x < 2) {
-		LoopCo &c = s_co[threadIdx.x];
-		c.job = c.p_id = c.c_id = c.s_id = 0;
-	}
-	const int round0 = slice ? la.n_rounds[chain] : 0;
-	const int round_end = min(round0 + slice_rounds, la.max_rounds);
-	if (slice == 0 && threadIdx.x == 0)
-		la.slice_end[chain] = 0;
-	if (slice && la.fin[chain]) {
-		if (threadIdx.x == 0)
-			la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = la.slice_end[(size_t)slice * gridDim.x + chain];
-		return;
-	}
-	__builtin_amdgcn_s_setprio(3);
-	{
-		const CostTable &ctab = ACC ? c_cost_acc : c_cost;
-		for (int i = (int)threadIdx.x; i < 1024; i += 256)
-			s_lut[i] = g_sb_lut.v[i];
-		for (int i = (int)threadIdx.x; i < 2 * kSteps12; i += 256)
-			s_steps[i] = c_steps.w[i / kSteps12][i % kSteps12];
-		for (int i = (int)threadIdx.x; i < 512; i += 256) {
-			s_cost_a[i] = ctab.a[i];
-			s_cost_b[i] = ctab.b[i];
-		}
-	}
-	RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
-
-	// ------------------------------------------------------------------ S: the front's helper (LatPre (4)) and the judge
-	if (wave == 3) {
-		DecPre dpre;
-		dpre.dc = 0;
-		dpre.sy0 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][0]);
-		dpre.sy1 = *reinterpret_cast<const uint4 *>(&c_syn_rows.w[lane & 15][4]);
-		int epoch = 0;                             // squashes issued: hand-overs F wrote before it learnt of the last are stale
-		for (int t = 0;; t++) {
-			__syncthreads();
-			if (!s_go[t & 1])
-				break;
-			LoopCo *const co = &s_co[t & 1];
-			const int id = t + 1;
-			const int slot = (t + 2) % 3;                // what P prepared during the last tick
-			// no burst this tick, or not where it was expected: F works alone
-			const bool helps = co->job == id && h_off[slot] == co->off;
-			// (1) first what F will wait for soonest: the last round of the correlation's lags
-			const int p_pred = co->p_pred;
-			if (helps) {
-				loop_front_helper_corr<SPS>(a, co, id, hx0 + slot * stage_al, lane);
-				// ... and, ahead of F's peak search, the sync-symbol terms for the peak an aligned chain will find
-				loop_front_helper_sync<SPS>(a, co, hx0 + slot * stage_al, lane, p_pred);
-			}
-			// (2) the tail of the burst V ran its forward pass on during the last tick -- survivor walk, CRC -- and the
-			// verdict: the feedback as the reference applies it (rx_bcch, gmr1_rx.c:782-791), on the state F started from
-			const LoopHand &h = s_hand[(t + 1) & 3];          // F's of three ticks ago
-			if (t > 2 && h.valid != 0 && h.epoch == epoch) {
-#ifdef GMR1_HIP_PROFILE
-				dpre.stamp = reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo);
-#endif
-				uint32_t syn;
-				GMR1_DSTAMP(&dpre, 24, lane);
-				k5_12_survivors_crc_lat(v_surv[(t - 1) & 1], v_ubits, lane, syn, &dpre);
-				GMR1_DSTAMP(&dpre, 7, lane);
-				// (row 0 holds the burst: its syndrome, for every lane)
-				syn = (uint32_t)__builtin_amdgcn_readfirstlane((int)syn);
-				const uint32_t fae = v_fae[(t - 1) & 1];
-				const int crc = syn ? 1 : 0;
-				RxLoopState st = h.pre;
-				const int emit = rx_loop_bcch_result(st, sps, 0, crc, h.toa, h.ffe, reinterpret_cast<const uint8_t *>(v_ubits), h.e_toa);
-				// (F assumed: time and frequency applied, nothing else moved)
-				const bool same = st.align == h.spec_align && __float_as_uint(st.freq_err) == __float_as_uint(h.spec_ferr) &&
-				                  st.fn == h.pre.fn && st.delay == h.pre.delay && st.stn == h.pre.stn;
-				if (lane == 0) {
-					// the round's log entry (the walk's part came with the hand-over)
-					RxLoopRound e;
-					e.c_first = h.c_first;
-					e.c_n = h.c_n;
-					e.minen = h.minen;
-					e.b_emit = emit;
-					e.b_fn = st.fn;
-					e.b_tn = st.stn;
-					e.b_conv = (int32_t)fae;
-					e.b_frame = h.b_frame;
-					uint32_t *l2w = reinterpret_cast<uint32_t *>(e.b_l2);
-#pragma unroll
-					for (int i = 0; i < 6; i++)
-						l2w[i] = v_ubits[i];
-					rlog[h.round] = e;
-					s_true[t & 1] = st;
-					s_vd[t & 1] = same ? kVdOk : kVdSquash;
-				}
-				if (!same)
-					epoch++;
-				WSYNC();
-			} else if (lane == 0) {
-				s_vd[t & 1] = kVdNone;
-			}
-			// (3) once F has the coarse peak: the sync-symbol terms of its three candidates -- already there if the peak is
-			// where it was expected
-			if (helps && lds_wait_eq(&co->p_id, id)) {
-				const int p = co->p;
-				if (p >= 0) {
-					if (p != p_pred)
-						loop_front_helper_sync<SPS>(a, co, hx0 + slot * stage_al, lane, p);
-					if (lane == 0)
-						lds_post(&co->s_id, id);
-				}
-			}
-		}
-		return;
-	}
-
-	// ------------------------------------------------------------------ P: pass 2 + operand table, then the next window
-	if (wave == 2) {
-		LatPre<NPL, SPS> pre;
-		pre.lut = reinterpret_cast<const unsigned char *>(s_lut);
-		pre.steps = s_steps;
-		pre.cost_a = s_cost_a;
-		pre.cost_b = s_cost_b;
-		for (int t = 0;; t++) {
-			__syncthreads();
-			if (!s_go[t & 1])
-				break;
-			// (a hand-over made stale by a SQUASH is worked on all the same -- everything it names is in LDS --; the judge skips it)
-			const LoopHand &h = s_hand[(t + 3) & 3];          // F's of the last tick
-			if (t > 0 && h.valid) {
-				pre.cut = &s_cut[(t + 3) & 3];
-				pre.win_r = win0 + h.win * kWin;
-				pre.vtab = vtab0 + (t & 1) * (kLatTabBytes / 4);
-				pre.b_fsh = h.fsh;
-				const RxIo io = {
-#ifdef GMR1_HIP_PROFILE
-				                 reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo),
-#endif
-				                 &h.pre.base, b_kind, &h.fsh, nullptr, nullptr, nullptr, b_rv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-				rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 2>(a, io, stage_samples, cw, 0, 1, body_p, lane, &pre);
-			}
-			const uint64_t pred = s_pred[t & 1];
-			const int slot = t % 3;
-			if (pred != ~0ull)
-				lat_prepare<NPL, SPS>(a, pred, 0, lane, hx0 + slot * stage_al, h_stat[slot], win0 + slot * kWin);
-			if (lane == 0) {
-				h_off[slot] = pred;
-				h_kind[slot] = 0;
-			}
-		}
-		return;
-	}
-
-	// ------------------------------------------------------------------ V: the decoder's forward pass, two rounds behind
-	if (wave == 1) {
-		DecPre dpre;
-		dpre.dc = c_dec.v[lane & 15];
-		dpre.sy0 = dpre.sy1 = make_uint4(0, 0, 0, 0);
-		for (int t = 0;; t++) {
-			__syncthreads();
-			if (!s_go[t & 1])
-				break;
-			const LoopHand &h = s_hand[(t + 2) & 3];          // F's of two ticks ago, P's of the last
-			if (!(t > 1 && h.valid != 0))
-				continue;
-#ifdef GMR1_HIP_PROFILE
-			dpre.stamp = reinterpret_cast<unsigned long long *>(((unsigned long long)h.stamp_hi << 32) | h.stamp_lo);
-			GMR1_DSTAMP(&dpre, 15, lane);
-#endif
-			uint32_t syn, fae;
-			decode1_k5_12_lat<ACC, false>(vtab0 + ((t - 1) & 1) * (kLatTabBytes / 4), v_surv[t & 1], nullptr, lane, syn, fae, &dpre);
-			// (row 0 holds the burst: location 0 of it the end state's metric)
-			if (lane == 0)
-				v_fae[t & 1] = fae;
-		}
-		return;
-	}
-
-	// ------------------------------------------------------------------ F: the front and the walk
-	RxLoopState st = la.state[chain];          // every lane computes the same
-	const uint64_t lim = st.base + (uint64_t)st.len;
-	RxLoopFrame *flog = la.flog ? la.flog + (size_t)chain * la.flog_stride : nullptr;
-	const size_t c_base = (size_t)chain * la.c_stride;
-	int n_frames = slice ? la.n_frames[chain] : 0, n_ccch = slice ? (la.slice_end[(size_t)slice * gridDim.x + chain] + 3) & ~3 : 0;
-	auto on_frame = [&](const RxLoopState &x) {
-		if (flog && lane == 0 && n_frames < la.flog_stride)
-			flog[n_frames] = {x.align, x.freq_err, x.fn};
-		n_frames++;
-	};
-	LatPre<NPL, SPS> pre;
-	int round = round0;
-	// the round's bursts from the chain's position: rx_loop_build_round frame after frame, for the usual case (the next
-	// sixteen frames all lie inside the capture) with one frame per lane.  -> s_items, the number of items
-	int frames_at_round = 0;
-	float minen = 0.f;
-	// the round's BCCH burst (always its last item), in registers: every use of it sits on the tick's critical path
-	int rb_has = 0, rb_begin = 0, rb_etoa = 0, rb_fb = 0;
-	auto list_round = [&]() -> int {
-		frames_at_round = n_frames;
-		minen = st.bcch_energy / 2.0f;                          // the gate level the round starts with
-		int n;
-		const int frame_len = sps * 24 * 39;
-		const int j = lane & 15;
-		const int fn_j = st.fn + j, align_j = st.align + j * frame_len;
-		const bool inside = !st.done && st.align + 17 * frame_len <= st.len;   // frames 0..15 are all reached
-		const int m = (fn_j - st.delay) & 7;
-		const int tn_off = sps * st.stn * 39;
-		const int b_b = align_j + tn_off - 10 * sps, b_c = align_j + tn_off - 5 * sps;   // burst_map, e_toa = win / 2
-		const bool ok_b = b_b >= 0 && b_b + 234 * sps + 20 * sps <= st.len;
-		const bool ok_c = b_c >= 0 && b_c + 234 * sps + 10 * sps <= st.len;
-		const uint32_t mb = (uint32_t)__ballot(lane < 16 && m == 2 && ok_b) & 0xffffu;
-		const uint32_t mc = (uint32_t)__ballot(lane < 16 && m != 0 && m != 2 && ok_c) & 0xffffu;
-		const int jb = mb ? __builtin_ctz(mb) : 16;             // the first BCCH burst
-		const uint32_t before = mc & ((1u << jb) - 1u);
-		WSYNC();
-		if (inside && mb && __popc(before) < kLoopPerRound - 1) {
-			// CCCH bursts of frames 0 .. jb-1, then the BCCH burst of frame jb (which stays the current frame)
-			const uint32_t items = before | (1u << jb);
-			if (lane < 16 && ((items >> j) & 1u)) {
-				const int idx = __popc(items & ((1u << j) - 1u));
-				const bool is_b = j == jb;
-				s_items[idx] = {is_b ? b_b : b_c, is_b ? 1 : 0, fn_j, st.stn, is_b ? 10 * sps : 5 * sps, j};
-			}
-			if (flog && lane < jb && n_frames + lane < la.flog_stride)
-				flog[n_frames + lane] = {align_j, st.freq_err, fn_j};
-			rb_has = 1;
-			rb_begin = st.align + jb * frame_len + tn_off - 10 * sps;
-			rb_etoa = 10 * sps;
-			rb_fb = jb;
-			n_frames += jb;
-			st.fn += jb;
-			st.align += jb * frame_len;
-			n = __popc(items);
-			WSYNC();
-		} else {
-			n = rx_loop_build_round(st, sps, s_items, on_frame);
-			WSYNC();
-			rb_has = n > 0 && s_items[n - 1].is_bcch != 0;
-			if (rb_has) {
-				rb_begin = s_items[n - 1].begin;
-				rb_etoa = s_items[n - 1].e_toa;
-				rb_fb = s_items[n - 1].frames_before;
-			}
-		}
-		return n;
-	};
-	// checkpoints of the rounds handed over, by tick mod 3: what a SQUASH restores
-	int cp_round[4] = {0, 0, 0, 0}, cp_frames[4] = {0, 0, 0, 0}, cp_ccch[4] = {0, 0, 0, 0};
-	// a hand-over of one (P is at it) / two (V is) / three (the judge is) / four ticks ago (verdict due)
-	bool age1 = false, age2 = false, age3 = false, age4 = false;
-	int epoch = 0;                                   // squashes seen
-	int n = round < round_end ? list_round() : 0;
-	bool finished = false;
-	int t = 0;
-#ifdef GMR1_HIP_PROFILE
-#define GMR1_FSTAMP(k)                                                             \
-	do {                                                                          \
-		if (chain == 0 && round == kStampRound && lane == 0)                      \
-			g_stamp[k] = __builtin_readcyclecounter();                            \
-	} while (0)
-#else
-#define GMR1_FSTAMP(k) do { } while (0)
-#endif
-	for (;; t++) {
-		GMR1_FSTAMP(16);
-		if (lane == 0) {
-			// where the burst of the round AFTER the one about to run will most likely sit: eight frames on
-			// (a round's BCCH burst is always its last item)
-			uint64_t pred = ~0ull;
-			if (n > 0 && rb_has) {
-				pred = st.base + (uint64_t)rb_begin + (uint64_t)(8 * 24 * 39) * (uint64_t)sps;
-				if (pred + (uint64_t)a.in_len[0] > lim)
-					pred = ~0ull;
-			}
-			s_pred[t & 1] = pred;
-			s_go[t & 1] = 1;
-			// the helper wave's job of this tick: the burst about to run, if there is one
-			LoopCo &c = s_co[t & 1];
-			const bool job = n > 0 && round < round_end && rb_has;
-			c.off = job ? st.base + (uint64_t)rb_begin : 0;
-			c.fsh = -st.freq_err;
-			c.p_pred = rb_etoa;
-			c.job = job ? t + 1 : 0;
-		}
-		bool co_job = n > 0 && round < round_end && rb_has;
-		__syncthreads();
-		GMR1_FSTAMP(17);
-		const int t3 = t & 3;
-		// ---- the verdict on the hand-over of four ticks ago (the judge worked on it during the last tick)
-		if (age4 && s_vd[(t - 1) & 1] == kVdSquash) {
-			// the three fronts run since and everything listed since started from a state that never came to be: back to the
-			// checkpoint of the round judged, its true feedback, and on from there within this tick (the hand-overs in flight
-			// carry the old epoch: the judge skips them; what P has prepared is checked against the burst's place as always)
-			st = s_true[(t - 1) & 1];
-			n_frames = cp_frames[t3];
-			n_ccch = cp_ccch[t3];
-			round = cp_round[t3] + 1;
-			on_frame(st);
-			rx_loop_advance(st, sps);
-			age1 = age2 = age3 = false;
-			epoch++;
-			n = round < round_end ? list_round() : 0;
-			// (the helper wave may have taken up the burst listed before: it is to stop waiting for that front)
-			if (co_job && lane == 0) {
-				s_co[t & 1].p = -1;
-				lds_post(&s_co[t & 1].p_id, t + 1);
-			}
-			co_job = false;
-		}
-		age4 = age3;
-		age3 = age2;
-		age2 = age1;
-		age1 = false;
-		if (n == 0 || round >= round_end) {
-			// nothing (more) to start in this launch: wait for what P and V still hold
-			if (lane == 0)
-				s_hand[t3].valid = 0;
-			if (!age2 && !age3 && !age4) {
-				finished = n == 0 && round < round_end;
-				break;
-			}
-			continue;
-		}
-		GMR1_FSTAMP(18);
-		const bool has_b = rb_has != 0;
-		const int n_c = has_b ? n - 1 : n;
-		// the CCCH bursts: listed for the batch that follows
-		if (lane < n_c && n_ccch + lane < la.c_stride) {
-			const RxLoopItem it = s_items[lane];
-			const size_t k = c_base + (size_t)(n_ccch + lane);
-			la.c_off[k] = st.base + (uint64_t)it.begin;
-			la.c_fs[k] = -st.freq_err;
-			la.c_kind[k] = 1;
-			la.c_meta[k] = {it.fn, it.tn, frames_at_round + it.frames_before};
-		}
-		int b_fn = 0, b_tn = 0, b_frame = 0;
-		bool handed = false;
-		GMR1_FSTAMP(19);
-		if (has_b) {
-			struct { int e_toa, frames_before; } it = {rb_etoa, rb_fb};
-			pre.b_off = st.base + (uint64_t)rb_begin;
-			pre.b_fsh = -st.freq_err;
-			const int slot = (t + 2) % 3;                // what P prepared during the last tick
-			pre.h_off = &h_off[slot];
-			pre.h_kind = &h_kind[slot];
-			pre.h_stat = h_stat[slot];
-			pre.h_x = hx0 + slot * stage_al;
-			pre.win_w = win0 + slot * kWin;
-			pre.cut = &s_cut[t3];
-			pre.co = co_job ? &s_co[t & 1] : nullptr;
-			pre.co_id = t + 1;
-#ifdef GMR1_HIP_PROFILE
-			unsigned long long *const stamp = (chain == 0 && round == kStampRound) ? g_stamp : nullptr;
-#endif
-			const RxIo io = {
-#ifdef GMR1_HIP_PROFILE
-			                 stamp,
-#endif
-			                 s_off, s_kind, s_fs, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-			rx4_body<NPL, SPS, true, false, false, ACC, true, false, 432, 1>(a, io, stage_samples, cw, 0, 1, body_f, lane, &pre);
-			b_frame = frames_at_round + it.frames_before;
-			if (pre.out.found) {
-				// found: the feedback as if the CRC passes and SI1 moves nothing -- V will tell (gmr1_rx.c:782-795)
-				st.bcch_energy = pre.out_energy;
-				const RxLoopState before = st;
-				st.align += (int)roundf(pre.out.toa) - it.e_toa;
-				st.freq_err += pre.out.ffe;
-				if (lane == 0) {
-					// the hand-over (one lane, wide stores: a value picked per lane compiles to a tree of branches)
-					LoopHand hv;
-					hv.pre = before;
-					hv.spec_align = st.align;
-					hv.spec_ferr = st.freq_err;
-					hv.valid = 1;
-					hv.round = round;
-					hv.e_toa = it.e_toa;
-					hv.win = slot;
-					hv.toa = pre.out.toa;
-					hv.ffe = pre.out.ffe;
-					hv.fsh = -before.freq_err;
-					hv.c_first = n_ccch;
-					hv.c_n = n_c;
-					hv.minen = minen;
-					hv.b_frame = b_frame;
-#ifdef GMR1_HIP_PROFILE
-					hv.stamp_lo = (uint32_t)(uintptr_t)stamp;
-					hv.stamp_hi = (uint32_t)((uintptr_t)stamp >> 32);
-#else
-					hv.stamp_lo = hv.stamp_hi = 0;
-#endif
-					hv.epoch = epoch;
-					uint4 *dst = reinterpret_cast<uint4 *>(&s_hand[t3]);
-					const uint4 *src = reinterpret_cast<const uint4 *>(&hv);
-#pragma unroll
-					for (int i = 0; i < 7; i++)
-						dst[i] = src[i];
-					static_assert(offsetof(LoopHand, epoch) < 7 * 16, "the words copied hold every field");
-				}
-				cp_round[t3] = round;
-				cp_frames[t3] = n_frames;
-				cp_ccch[t3] = n_ccch + n_c;
-				handed = true;
-			}
-			GMR1_FSTAMP(20);
-			b_fn = st.fn;
-			b_tn = st.stn;
-			on_frame(st);                                        // rx_tch3 of this frame sees the updated state
-			rx_loop_advance(st, sps);
-		}
-		if (!handed && lane == 0)
-			s_hand[t3].valid = 0;
-		GMR1_FSTAMP(21);
-		if (!handed && lane == 0) {
-			// the log entry of a round without a burst that was found (V writes the others)
-			RxLoopRound e = {};
-			e.c_first = n_ccch;
-			e.c_n = n_c;
-			e.minen = minen;
-			e.b_fn = b_fn;
-			e.b_tn = b_tn;
-			e.b_frame = b_frame;
-			rlog[round] = e;
-		}
-		GMR1_FSTAMP(22);
-		n_ccch += n_c;
-		round++;
-		age1 = handed;
-		n = round < round_end ? list_round() : 0;
-#ifdef GMR1_HIP_PROFILE
-		if (chain == 0 && round == kStampRound + 1 && lane == 0)
-			g_stamp[23] = __builtin_readcyclecounter();
-#endif
-	}
-	t++;                                        // one more barrier: P and V leave
-	if (lane == 0)
-		s_go[t & 1] = 0;
-	__syncthreads();
-	if (lane == 0) {
-		la.n_rounds[chain] = round;
-		la.n_ccch[chain] = n_ccch;
-		la.n_frames[chain] = n_frames;
-		la.state[chain] = st;
-		la.fin[chain] = finished ? 1 : 0;
-		la.slice_end[(size_t)(slice + 1) * gridDim.x + chain] = min(n_ccch, la.c_stride);
-	}
-}
-
-// records of a chain from its rounds' logs and the CCCH batch's results (rx_ccch gmr1_rx.c:800-850, rx_bcch :746-798),
-// compacted in burst order: 128 rounds per step of the work-group, thread = round x 8 + burst (a round's BCCH burst is its
-// last); the slots come from a ballot per wave and the waves' counts summed through LDS
-constexpr int kMergeWaves = 16;
-__global__ __launch_bounds__(64 * kMergeWaves) void k_rx_merge(RxLoopArgs la)
-{
-	__shared__ int s_cnt[2][kMergeWaves];
-	const int chain = blockIdx.x;
-	const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
-	const RxLoopState st = la.state[chain];
-	const int nr = min(la.n_rounds[chain], la.max_rounds);
-	const int n_c = min(la.n_ccch[chain], la.c_stride);
-	const RxLoopRound *rlog = la.rounds + (size_t)chain * la.max_rounds;
-	const size_t c_base = (size_t)chain * la.c_stride;
-	gmr1_hip_rx_record *rec = la.rec + (size_t)chain * la.rec_stride;
-	int32_t *rec_frame = la.rec_frame ? la.rec_frame + (size_t)chain * la.rec_stride : nullptr;
-	float *rec_minen = la.rec_minen ? la.rec_minen + (size_t)chain * la.rec_stride : nullptr;
-	int n_rec = 0;
-	for (int r0 = 0, step = 0; r0 < nr; r0 += 8 * kMergeWaves, step++) {
-		const int r = r0 + (tid >> 3), it = tid & 7;
-		bool emit = false;
-		RxLoopRound rl = {};
-		size_t k = 0;
-		if (r < nr) {
-			rl = rlog[r];
-			if (it == 7) {
-				emit = rl.b_emit != 0;
-			} else if (it < rl.c_n && rl.c_first + it < n_c) {
-				k = c_base + (size_t)(rl.c_first + it);
-				emit = !(la.c_en[k] < rl.minen) && !la.c_rv[k] && !la.c_crc[k];     // energy gate first (:813-816)
-			}
-		}
-		const unsigned long long mask = __ballot(emit);
-		if (lane == 0)
-			s_cnt[step & 1][wave] = __popcll(mask);
-		__syncthreads();
-		int before = 0, total = 0;
-#pragma unroll
-		for (int v = 0; v < kMergeWaves; v++) {
-			const int c = s_cnt[step & 1][v];
-			before += v < wave ? c : 0;
-			total += c;
-		}
-		if (emit) {
-			const int slot = n_rec + before + __popcll(mask & ((1ull << lane) - 1ull));
-			if (slot < la.rec_stride) {
-				const bool is_b = it == 7;
-				uint32_t *d = reinterpret_cast<uint32_t *>(rec + slot);
-				const uint32_t *l2w = is_b ? reinterpret_cast<const uint32_t *>(rlog[r].b_l2)
-				                           : reinterpret_cast<const uint32_t *>(la.c_l2 + k * 24);
-				const RxLoopCcch cm = is_b ? RxLoopCcch{rl.b_fn, rl.b_tn, rl.b_frame} : la.c_meta[k];
-				d[0] = (uint32_t)st.arfcn | ((uint32_t)st.chain << 16) | ((is_b ? 1u : 2u) << 24);
-				d[1] = (uint32_t)cm.fn;
-				d[2] = ((uint32_t)cm.tn & 0xffu) | (24u << 16);                // crc = 0, len = 24
-				d[3] = (uint32_t)(is_b ? rl.b_conv : la.c_conv[k]);
-#pragma unroll
-				for (int i = 0; i < 6; i++)
-					d[4 + i] = l2w[i];
-				if (rec_frame) {
-					rec_frame[slot] = cm.frame;
-					rec_minen[slot] = rl.minen;
-				}
-			}
-		}
-		n_rec += total;
-	}
-	if (tid == 0)
-		la.n_rec[chain] = n_rec;
-}
-
 // ---------------------------------------------------------------------------
 // burst type detection (reference src/sdr/pi4cxpsk.c:617-682 gmr1_pi4cxpsk_detect):
 // normalise once with the rotation of the first candidate type, run the sync search of
 // every candidate, weight the power by 1/|e_toa - toa|, keep the strongest.
 // ---------------------------------------------------------------------------
-// 4. (optional) the chains' record blocks closed up into one array in chain order: what the caller gets is then ONE copy of
-// exactly the records there are, not of every chain's whole block.  kPackParts work-groups per chain (the chain's records
-// dealt out among them: with one, 64 chains would occupy a quarter of the CUs for 14 us at the very end of the call): the
-// chain's offset is the sum of the counts before it (a few hundred integers), its records move as dwords.
-constexpr int kPackParts = 8;
-__global__ __launch_bounds__(256) void k_rx_pack(RxLoopArgs la, int n_chains)
-{
-	__shared__ int s_part[4];
-	const int chain = blockIdx.x, tid = (int)threadIdx.x;
-	auto count = [&](int c) {
-		const int n = la.n_rec[c];
-		return (la.n_rounds[c] >= la.max_rounds || n > la.rec_stride) ? 0 : n;     // (such a chain is reported, not returned)
-	};
-	int part = 0;
-	for (int c = tid; c < chain; c += 256)
-		part += count(c);
-	for (int o = 32; o; o >>= 1)
-		part += __shfl_xor(part, o);
-	if ((tid & 63) == 0)
-		s_part[tid >> 6] = part;
-	__syncthreads();
-	const int off = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-	const int n = count(chain);
-	const uint32_t *src = reinterpret_cast<const uint32_t *>(la.rec + (size_t)chain * la.rec_stride);
-	uint32_t *dst = reinterpret_cast<uint32_t *>(la.packed + off);
-	constexpr int W = (int)(sizeof(gmr1_hip_rx_record) / 4);
-	for (int i = (int)blockIdx.y * 256 + tid; i < n * W; i += 256 * kPackParts)
-		dst[i] = src[i];
-	if (chain == n_chains - 1 && blockIdx.y == 0 && tid == 0)
-		*la.n_packed = off + n;
-}
-
 template <int NPL, int SPS>
 __global__ __launch_bounds__(64) void k_detect(DetectArgs a, int max_in_len)
 {
@@ -4853,159 +3906,7 @@ hipError_t launch_rx_tch3(const RxArgs &a, const Tch3Args &t, hipStream_t stream
 	return hipGetLastError();
 }
 
-// the side stream and the events the loop's time slices are chained with, per device (created on first use, kept)
-struct LoopStreams {
-	hipStream_t side = nullptr;
-	hipEvent_t chain_done[kLoopSlices] = {}, side_done = nullptr;
-	bool ok = false;
-};
-static LoopStreams *loop_streams()
-{
-	static LoopStreams per_dev[64];
-	static std::mutex mu;
-	int dev = 0;
-	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
-		return nullptr;
-	std::lock_guard<std::mutex> lk(mu);
-	LoopStreams &s = per_dev[dev];
-	if (!s.ok) {
-		if (hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking) != hipSuccess)
-			return nullptr;
-		for (int i = 0; i < kLoopSlices; i++)
-			if (hipEventCreateWithFlags(&s.chain_done[i], hipEventDisableTiming) != hipSuccess)
-				return nullptr;
-		if (hipEventCreateWithFlags(&s.side_done, hipEventDisableTiming) != hipSuccess)
-			return nullptr;
-		s.ok = true;
-	}
-	return &s;
-}
-
-// The chains are walked in kLoopSlices time slices (launches of k_rx_chain on the caller's stream, each picking up where the
-// previous one left its chains); the CCCH bursts a slice listed run as a k_rx4 batch on a side stream WHILE the next slice
-// walks on -- the chain kernel keeps one wave per chain busy, the rest of the machine is free --, and the record writer waits
-// for both.  Only the last slice's batch (the shortest: the slices are cut by rounds, and the last one holds what is left)
-// is not hidden.  One call at a time per device (the side stream and its events are the device's).
-hipError_t launch_rx_loop(const RxArgs &a, const RxLoopArgs &la, int n_chains, hipStream_t stream)
-{
-	if (n_chains <= 0)
-		return hipSuccess;
-	if (a.in_len[0] > kMaxInLen || a.dbg_stop || la.c_stride < 4 || (la.c_stride & 3) || !la.fin || !la.slice_end)
-		return hipErrorInvalidValue;
-	LoopStreams *ls = loop_streams();
-	if (!ls)
-		return hipErrorInvalidValue;
-	const int max_len = 20 * a.sps + 1;
-	const int cw = (max_len + 15) & ~15;
-	// below 4 and above 8 samples per symbol: the one-burst generic body (k_rx_chain<..., ONE>, rx1_lat_body)
-	const bool one = a.sps < 4 || a.sps > 8 || a.in_len[0] > 2048;
-	size_t off4[4], off3[3];
-	const size_t lds = one ? (lds_layout(a.in_len[0], max_len, true, off3) + 127) & ~(size_t)127
-	                       : (lds4_layout(a.stage_samples, cw, off4) + 127) & ~(size_t)127;
-	const dim3 grid((unsigned)n_chains), block(128);
-	// the helper wave's two staged windows, then the latency decoder's operand table
-	const size_t lds_h = one ? 0 : 2 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + (size_t)kLatTabBytes;
-	// the pipelined walk (k_rx_chain_pipe): two bodies, three staged windows, two operand tables, three raw windows
-	const int npl = a.in_len[0] <= 1024 ? 16 : 32;
-	const size_t lds_p = one ? 0 : 2 * lds + 3 * (size_t)((a.stage_samples + 15) & ~15) * sizeof(float2) + 2 * (size_t)kLatTabBytes +
-	                               3 * (size_t)npl * 64 * sizeof(float2);
-	static const bool serial = profile_env("GMR1_HIP_LOOP_SERIAL") != nullptr;     // (profiling build: the walk of round 4, for A/B)
-	hipError_t e;
-	if (!one && !serial) {
-		// more dynamic LDS than the default limit of a work-group: say so once per kernel
-		static std::mutex mu;
-		static bool told[4][2] = {};
-		const int ki = (npl == 32 ? 2 : 0) + (a.sps == 4 ? 0 : 1);
-		std::lock_guard<std::mutex> lk(mu);
-		if (!told[ki][a.conv_acc ? 1 : 0]) {
-			const void *fn = nullptr;
-#define GMR1_PIPE_FN(NPL, SPS) (a.conv_acc ? (const void *)k_rx_chain_pipe<NPL, SPS, true> : (const void *)k_rx_chain_pipe<NPL, SPS, false>)
-			fn = npl == 16 ? (a.sps == 4 ? GMR1_PIPE_FN(16, 4) : GMR1_PIPE_FN(16, 0)) : (a.sps == 4 ? GMR1_PIPE_FN(32, 4) : GMR1_PIPE_FN(32, 0));
-#undef GMR1_PIPE_FN
-			if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p)) != hipSuccess)
-				return e;
-			told[ki][a.conv_acc ? 1 : 0] = true;
-		}
-	}
-	// (the counters of the walk -- rounds, CCCH list lengths, frames, finished flags, slice ends -- start at zero: the first
-	// slice's k_rx_chain takes them as zero and writes them, no launch of their own)
-	const int slice_rounds = (la.max_rounds + kLoopSlices - 1) / kLoopSlices;
-#define GMR1_LOOP_LAUNCH(NPL, SPS)                                                                                \
-	do {                                                                                                         \
-		if (!serial) {                                                                                           \
-			if (a.conv_acc)                                                                                      \
-				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, true>), grid, dim3(256), lds_p, stream, a, la, a.stage_samples, cw, \
-				                   (int)lds, sl, slice_rounds);                                                  \
-			else                                                                                                 \
-				hipLaunchKernelGGL((k_rx_chain_pipe<NPL, SPS, false>), grid, dim3(256), lds_p, stream, a, la, a.stage_samples, cw, \
-				                   (int)lds, sl, slice_rounds);                                                  \
-		} else if (a.conv_acc)                                                                                   \
-			hipLaunchKernelGGL((k_rx_chain<NPL, SPS, true>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds, \
-			                   sl, slice_rounds);                                                                \
-		else                                                                                                     \
-			hipLaunchKernelGGL((k_rx_chain<NPL, SPS>), grid, block, lds + lds_h, stream, a, la, a.stage_samples, cw, (int)lds, \
-			                   sl, slice_rounds);                                                                \
-	} while (0)
-#define GMR1_LOOP_LAUNCH_ONE(NPL)                                                                                 \
-	do {                                                                                                         \
-		if (a.conv_acc)                                                                                          \
-			hipLaunchKernelGGL((k_rx_chain<NPL, 0, true, true>), grid, block, lds, stream, a, la, a.in_len[0], max_len, (int)lds, \
-			                   sl, slice_rounds);                                                                \
-		else                                                                                                     \
-			hipLaunchKernelGGL((k_rx_chain<NPL, 0, false, true>), grid, block, lds, stream, a, la, a.in_len[0], max_len, (int)lds, \
-			                   sl, slice_rounds);                                                                \
-	} while (0)
-	for (int sl = 0; sl < kLoopSlices; sl++) {
-		// 1. the feedback chains, one time slice
-		if (one) {
-			if (a.in_len[0] <= 1024)
-				GMR1_LOOP_LAUNCH_ONE(16);
-			else if (a.in_len[0] <= 2048)
-				GMR1_LOOP_LAUNCH_ONE(32);
-			else
-				GMR1_LOOP_LAUNCH_ONE(64);
-		} else if (a.in_len[0] <= 1024) {
-			if (a.sps == 4)
-				GMR1_LOOP_LAUNCH(16, 4);
-			else
-				GMR1_LOOP_LAUNCH(16, 0);
-		} else {
-			if (a.sps == 4)
-				GMR1_LOOP_LAUNCH(32, 4);
-			else
-				GMR1_LOOP_LAUNCH(32, 0);
-		}
-		if ((e = hipGetLastError()) != hipSuccess) return e;
-		// 2. the CCCH bursts it listed, on the side stream
-		if ((e = hipEventRecord(ls->chain_done[sl], stream)) != hipSuccess) return e;
-		if ((e = hipStreamWaitEvent(ls->side, ls->chain_done[sl], 0)) != hipSuccess) return e;
-		RxArgs b = a;
-		b.n = n_chains * la.c_stride;
-		b.impl = one ? 1 : 0;
-		b.seg_stride = la.c_stride;
-		b.seg_first = la.slice_end + (size_t)sl * n_chains;
-		b.seg_groups = (slice_rounds * (kLoopPerRound - 1) + 3) / 4 + 1;       // <= 7 CCCH bursts per round
-		b.seg_count = la.slice_end + (size_t)(sl + 1) * n_chains;
-		b.offset = la.c_off;
-		b.kind = la.c_kind;
-		b.freq_shift = la.c_fs;
-		b.l2 = la.c_l2;
-		b.crc = la.c_crc;
-		b.conv = la.c_conv;
-		b.rv = la.c_rv;
-		b.energy = la.c_en;
-		if ((e = launch_rx(b, true, b.in_len[0], ls->side)) != hipSuccess) return e;
-	}
-#undef GMR1_LOOP_LAUNCH
-#undef GMR1_LOOP_LAUNCH_ONE
-	// 3. the records, once both streams are through
-	if ((e = hipEventRecord(ls->side_done, ls->side)) != hipSuccess) return e;
-	if ((e = hipStreamWaitEvent(stream, ls->side_done, 0)) != hipSuccess) return e;
-	hipLaunchKernelGGL(k_rx_merge, grid, dim3(64 * kMergeWaves), 0, stream, la);
-	if (la.packed && la.n_packed)
-		hipLaunchKernelGGL(k_rx_pack, dim3((unsigned)n_chains, kPackParts), dim3(256), 0, stream, la, n_chains);
-	return hipGetLastError();
-}
+#include "rx_loop_kernels.inc"
 
 hipError_t launch_detect(const DetectArgs &a, hipStream_t stream)
 {

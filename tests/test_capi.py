@@ -163,7 +163,7 @@ def test_product_does_not_reference_oracle():
     bad = []
     for d in ("osmo-gmr_amd", "include"):
         for path in glob.glob(os.path.join(ROOT, d, "**", "*"), recursive=True):
-            if os.path.isfile(path) and path.endswith((".py", ".h", ".hip", ".cpp", ".c")):
+            if os.path.isfile(path) and path.endswith((".py", ".h", ".hip", ".cpp", ".c", ".inc")):
                 txt = open(path, errors="replace").read()
                 if re.search(r"oracle_lib|liborc|import\s+orc_chan|from\s+orc_chan|orc_[a-z0-9_]+\(|#include\s+\"orc_", txt):
                     bad.append(path)
