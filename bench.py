@@ -82,6 +82,7 @@ def parse():
                          "describes and the one `value` is quoted on; the default run also times the opt-in polyphase-planar "
                          "entry point afterwards and reports it as `roofline_planar`. --layout planar makes the planar call the "
                          "timed step itself (a side measurement for the profiler: config.layout says so)")
+    ap.add_argument("--side-runner", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-extras", action="store_true",
                     help="bursts workload: skip the measurements after the timed region (planar layout, the other decoder)")
     args = ap.parse_args()
@@ -858,21 +859,36 @@ def time_legacy_calls(api, wl, oracle_lib, m=600):
 
 
 def rocm_smi_state(dev_index):
-    """Clocks, power and performance level as rocm-smi reports them (None where the tool is absent or refuses)."""
-    import shutil
-    import subprocess
-    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(exe):
+    """Clocks, power and performance level as the amdgpu driver reports them -- the sysfs files rocm-smi itself reads (no child
+    process: a program that has touched the GPU must not start one that execs).  None where nothing is readable."""
+    import glob
+    out = {}
+
+    def rd(path):
+        try:
+            with open(path) as fh:
+                return fh.read().strip()
+        except OSError:
+            return None
+    cards = sorted(c for c in glob.glob("/sys/class/drm/card[0-9]*/device") if rd(os.path.join(c, "vendor")) == "0x1002")
+    if dev_index >= len(cards):
         return None
-    try:
-        r = subprocess.run([exe, "-d", str(dev_index), "--showclocks", "--showpower", "--showperflevel", "--showmaxpower", "--json"],
-                           capture_output=True, text=True, timeout=20)
-        js = json.loads(r.stdout)
-        card = next(iter(js.values())) if js else {}
-        keep = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "power", "performance level"))}
-        return keep or None
-    except Exception as e:
-        return {"error": repr(e)}
+    dev = cards[dev_index]
+    for key, name in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk")):
+        txt = rd(os.path.join(dev, name))
+        if txt:
+            cur = [ln.split(":")[1].strip().rstrip("*").strip() for ln in txt.splitlines() if ln.rstrip().endswith("*")]
+            out[key + "_current"] = cur[0] if cur else None
+            out[key + "_levels"] = [ln.split(":")[1].strip().rstrip("*").strip() for ln in txt.splitlines() if ":" in ln]
+    lvl = rd(os.path.join(dev, "power_dpm_force_performance_level"))
+    if lvl:
+        out["performance_level"] = lvl
+    for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+        for key, name in (("power_average_w", "power1_average"), ("power_cap_w", "power1_cap"), ("power_input_w", "power1_input")):
+            v = rd(os.path.join(hw, name))
+            if v and v.isdigit():
+                out[key] = int(v) / 1e6
+    return out or None
 
 
 SIDE_WORKLOADS = (
@@ -883,6 +899,41 @@ SIDE_WORKLOADS = (
     ("fcch", ["--workload", "fcch"], lambda c: bool(c.get("toa_identical_to_oracle"))),
     ("chan", ["--workload", "chan"], lambda c: c.get("max_abs_err_vs_oracle") is not None and c["max_abs_err_vs_oracle"] < 2e-4),
 )
+
+
+def start_side_runner(args):
+    """A helper process that will run the side workloads when told to.  It is started BEFORE this process touches the GPU
+    (a process that has initialised the GPU must not exec another program, nor should its forked children) and never touches
+    the GPU itself: it only starts `python bench.py --workload X` children, one at a time, after the timed region."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--side-runner", "--steps", str(args.steps), "--preroll-s", str(args.preroll_s),
+           "--conv-decoder", args.conv_decoder]
+    try:
+        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    except OSError as e:
+        print(f"bench.py: no side-workload runner: {e!r}", file=sys.stderr)
+        return None
+
+
+def collect_side(runner, timeout=400):
+    if runner is None:
+        return {"error": "the side-workload runner could not be started"}
+    try:
+        out, _ = runner.communicate("go\n", timeout=timeout)
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception as e:
+        try:
+            runner.kill()
+        except Exception:
+            pass
+        return {"error": repr(e)}
+
+
+def side_runner_main(args):
+    """`bench.py --side-runner`: wait for "go" on stdin, run the side workloads, print their JSON."""
+    if sys.stdin.readline().strip() != "go":
+        return
+    print(json.dumps(side_workloads(args)), flush=True)
 
 
 def side_workloads(args):
@@ -1238,6 +1289,8 @@ def main():
         raise SystemExit(f"bench.py: WORLD_SIZE={env_world} but --gpus {args.gpus}: refusing to report a line for the "
                          "wrong number of GPUs (start it as `python bench.py --gpus N`, or with a launcher whose world "
                          "size equals N)")
+    if args.side_runner:
+        return side_runner_main(args)
     if args.workload == "nt3":
         return run_nt3_workload(args)
     if args.workload == "rx":
@@ -1248,6 +1301,10 @@ def main():
         return run_ambe_workload(args)
     if args.workload != "bursts":
         return run_side_workload(args)
+    # every other BASELINE config goes into the same record (`side`): their runner starts now, before the GPU is touched
+    side_runner = None
+    if env_world is None and args.gpus == 1 and not args.no_extras and not args.no_cpu and not os.environ.get("GMR1_BENCH_FORCE_GROUP"):
+        side_runner = start_side_runner(args)
     import torch
     from __graft_entry__ import load_package
     import workloads
@@ -1467,7 +1524,7 @@ def main():
     }
     smi = rocm_smi_state(dev_index)
     if smi:
-        out["clock"]["rocm_smi"] = smi
+        out["clock"]["driver"] = smi
     out["config"]["layout"] = args.layout
     if "planar" in extras:
         ms_pl, same = extras["planar"]
@@ -1531,8 +1588,8 @@ def main():
         out["legacy_one_burst_calls"] = time_legacy_calls(api, wl, oracle_lib)
     # ---- every other BASELINE config in the same record (never part of `value`): one subprocess each, after everything
     # above; what each reports is its own bench line's ms per step, roofline fraction and oracle comparison
-    if world == 1 and not args.no_extras and not args.no_cpu and not grouped:
-        out["side"] = side_workloads(args)
+    if side_runner is not None:
+        out["side"] = collect_side(side_runner)
     if dog is not None:
         line.update(out)
         dog.start()
