@@ -1526,6 +1526,24 @@ def main():
     if smi:
         out["clock"]["driver"] = smi
     out["config"]["layout"] = args.layout
+    # What the HBM fraction above is up against: the kernel's vector ALUs (PMC summary of the same kernel on the same sources,
+    # tools/pmc_rx4.sh -> tools/valu_summary.py; like the traffic figure it is reported only while the sources' hash matches)
+    vf = os.path.join(ROOT, "profiles", "valu_k_rx4.json")
+    if os.path.exists(vf) and args.layout == "interleaved":
+        try:
+            vj = json.load(open(vf))
+            if vj.get("kernel_sources_sha256") == kernel_sources_hash():
+                busy = float(vj["valu_busy"])
+                out["roofline_valu"] = {"bound": "valu_issue", "kernel": "k_rx4<16,4>", "valu_busy": busy,
+                                        "valu_insts_per_wave_of_4_bursts": vj["valu_insts_per_wave"], "waves_per_simd": vj["waves_per_simd"],
+                                        "hbm_frac_if_valu_were_100pct_busy": achieved / HBM_PEAK_GBS / busy,
+                                        "source": f"{vj.get('source')} (build {vj.get('tag')})",
+                                        "note": "the kernel is bound by vector-instruction issue, not by HBM: at this instruction count "
+                                                "the HBM fraction cannot pass the figure above; the 8 TB/s roof is nominal for it"}
+            else:
+                out["roofline_valu"] = {"note": "profiles/valu_k_rx4.json was taken on other kernel sources: not reported"}
+        except Exception as e:
+            out["roofline_valu"] = {"note": f"profiles/valu_k_rx4.json unreadable: {e!r}"}
     if "planar" in extras:
         ms_pl, same = extras["planar"]
         ach = bytes_per_launch / (ms_pl * 1e-3) / 1e9

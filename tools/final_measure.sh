@@ -36,6 +36,7 @@ for lay in interleaved planar; do
   bash tools/pmc_rx4.sh ${t}_$lay --layout $lay > /dev/null 2>&1; cp gpurun_out/pmc_${t}_$lay.txt $o/pmc_sq_k_rx4_$lay.txt
   python3 tools/phase_times.py --no-extras --layout $lay > $o/phase_times_$lay.txt 2>&1
 done
+python3 tools/valu_summary.py $o/pmc_sq_k_rx4_interleaved.txt $t > $o/valu_k_rx4.log 2>&1     # -> profiles/valu_k_rx4.json
 bash tools/pmc_nt3.sh ${t}_pmc_nt3 > /dev/null 2>&1; cp gpurun_out/${t}_pmc_nt3_kernels.txt $o/pmc_nt3_kernels.txt
 python3 tools/loop_stamps.py > $o/loop_stamps.txt 2>&1
 python3 tools/time_legacy.py > $o/legacy_one_burst_calls.json 2> $o/legacy.err
