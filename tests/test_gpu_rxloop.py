@@ -491,3 +491,23 @@ def test_rx_loop_record_buffer_in_pinned_and_device_memory(gpu_api, orc, pkg):
             k = min(cap, found)
             assert back[:k].tobytes() == rec[:k].tobytes()
             assert not back[k:].view(np.uint8).any()                 # nothing written past what fits
+
+
+def test_measurement_aids(gpu_api, pkg):
+    """gmr1_hip_clock_probe_dev reads a plausible shader clock on the device; gmr1_hip_rx_run_last_timing returns the phases of
+    the calling thread's last receive-loop call, and they add up to less than the call took."""
+    import time
+    import torch
+    mhz, wall = gpu_api.clock_probe_dev(torch.cuda.current_stream().cuda_stream, 200)
+    assert 300.0 < mhz < 3500.0 and 10.0 <= wall <= 1000.0, (mhz, wall)
+    with pytest.raises(Exception):
+        gpu_api.clock_probe_dev(None, 0)
+    x, _ = workloads.bcch_carrier(pkg, 31, seconds=2.5, sps=SPS, stn=5, delay=4, cfo_hz=40.0)
+    t0 = time.perf_counter()
+    rec, status, chains, found = gpu_api.rx_run(x, [0], [x.size], sps=SPS)
+    dt_ms = (time.perf_counter() - t0) * 1e3
+    ph = gpu_api.rx_run_last_timing()
+    assert found > 10 and not status.any()
+    assert all(v >= 0.0 for v in ph.values()), ph
+    assert ph["acquisition_ms"] > 0.01 and ph["chain_ms"] > 0.01
+    assert sum(ph.values()) <= dt_ms * 1.05, (ph, dt_ms)
