@@ -1001,13 +1001,7 @@ bool fcch_one_pass() { return profile_env("GMR1_HIP_FCCH_TWO_PASS") == nullptr; 
 template <int NT>
 static hipError_t launch_sweep(const FcchRoughArgs &a, hipStream_t st)
 {
-	static bool told = false;
-	if (!told) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_fcch_sweep<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SweepDims<NT>::lds);
-		if (e != hipSuccess)
-			return e;
-		told = true;
-	}
+	static_assert(SweepDims<NT>::lds <= 64 * 1024, "above the default dynamic LDS limit the launch would need hipFuncSetAttribute");
 	hipLaunchKernelGGL((k_fcch_sweep<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
 	const int tiles = (long long)a.n_lag_tiles * a.n >= 4096 ? 4 : 1;
 	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles);

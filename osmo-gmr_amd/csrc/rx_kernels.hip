@@ -12,16 +12,18 @@
 //   k_rx4                  : the default fused BCCH / CCCH kernel: the same arithmetic with the
 //                            serial phases (timing bisection, sync-symbol terms) done once for
 //                            the four bursts of a wave, one burst per 16-lane row.
-//   k_rx_chain, k_rx_merge : the frame loop of gmr1_rx (process_bcch, src/gmr1_rx.c:852-895): k_rx_chain walks the
-//                            BCCH feedback chain of one chain per work-group (rx4_body in its latency shape) and
-//                            lists the CCCH bursts, k_rx4 takes those as one batch, k_rx_merge writes the records.
+//   k_rx_chain_pipe, k_rx_chain, k_rx_merge, k_rx_pack (rx_loop_kernels.inc, included below): the frame loop of gmr1_rx
+//                            (process_bcch, src/gmr1_rx.c:852-895): the chain kernel walks the BCCH feedback chain of one
+//                            chain per work-group -- rx4_body in its latency shape, cut into pipeline stages (PART) that
+//                            run rounds apart on the work-group's waves -- and lists the CCCH bursts, k_rx4 takes those
+//                            as one batch, k_rx_merge writes the records.
 //   k_rx4g, k_rx4g_tch3    : demodulation only, four bursts per wave; with the TCH3 decoder behind it (tch3_body.h).
 //   k_detect, k_mod_order  : gmr1_pi4cxpsk_detect / _mod_order (pi4cxpsk.c:617-729).
 //   k_l1                   : the layer-1 chain alone on soft bits read from HBM.
 //
 // Design notes (DESIGN.md has the long form):
 //   * Work-groups are single 64-lane wavefronts: every hand-off goes through the
-//     wave's own LDS slice and needs no s_barrier (k_rx_chain: two waves, one barrier per round).
+//     wave's own LDS slice and needs no s_barrier (the loop's chain kernels: several waves, one barrier per round).
 //   * Samples are loaded once from HBM with coalesced 8-byte-per-lane loads, DC /
 //     power normalised in registers and parked in LDS; everything else reads LDS.
 //   * Burst formats live in __constant__ memory and are read with scalar loads.
