@@ -1303,7 +1303,11 @@ def main():
         return run_side_workload(args)
     # every other BASELINE config goes into the same record (`side`): their runner starts now, before the GPU is touched
     side_runner = None
-    if env_world is None and args.gpus == 1 and not args.no_extras and not args.no_cpu and not os.environ.get("GMR1_BENCH_FORCE_GROUP"):
+    # (not under a profiler: its preloaded library initialises the GPU in every process before main(), and a process that has
+    # done so must not start children that exec)
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if (env_world is None and args.gpus == 1 and not args.no_extras and not args.no_cpu and not profiled
+            and not os.environ.get("GMR1_BENCH_FORCE_GROUP")):
         side_runner = start_side_runner(args)
     import torch
     from __graft_entry__ import load_package
