@@ -162,3 +162,15 @@ def test_bench_gpus2_over_gloo_on_one_gpu():
     assert sh["resident"]["records_identical_to_scattered_run"] and sh["resident"]["rx_loop_ms"] > 0
     lo, hi = sh["rx_loop_ms_per_rank_min_max"]
     assert 0 < lo <= hi
+
+
+def test_side_runner_protocol():
+    """`bench.py --side-runner` is the helper the default run starts before it touches the GPU: it waits for "go" on stdin and
+    leaves without doing anything if its parent goes away first (stdin closes) -- it must never touch the GPU by itself."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--side-runner"], input="", capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == ""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def side_runner_main"):src.index("def side_workloads")]
+    assert "torch" not in body and "api." not in body
