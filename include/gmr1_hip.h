@@ -119,6 +119,18 @@ int gmr1_hip_demod_batch(int burst_id, int n, int sps, int in_len,
                          const float *iq, uint64_t iq_len, const uint64_t *offset, const float *freq_shift,
                          int8_t *ebits, int ebits_stride, int32_t *sync_id,
                          float *toa, float *freq_err, float *ssyms, int32_t *rv);
+/* Debugging aid (the reference's ENABLE_DEBUG_SIGNAL dumps, include/osmocom/gmr1/sdr/defs.h:35-39): ONE burst,
+ * demodulated as above (host pointers, blocking), plus the four intermediate vectors of gmr1_pi4cxpsk_demod --
+ *   corr   [in_len - symbols*sps + 1] float    "pi4cxpsk_corr"  (pi4cxpsk.c:251)  sync correlation magnitude per lag
+ *                                              (formats with several training sequences: summed over them)
+ *   burst  [in_len]  complex                   "pi4cxpsk_burst" (pi4cxpsk.c:545)  normalised, de-rotated window
+ *   align  [symbols] complex                   "pi4cxpsk_align" (pi4cxpsk.c:345)  one sample per symbol at the found timing
+ *   final  [symbols] complex                   "pi4cxpsk_final" (pi4cxpsk.c:582)  after fine-frequency + carrier correction
+ * Any output but rv may be NULL.  The production kernels work on phases and never form three of these; this entry
+ * rebuilds them from the same demodulation (rx_debug_kernels.inc), so ssyms / ebits / toa here ARE the batch entry's. */
+int gmr1_hip_demod_taps(int burst_id, int sps, int in_len, const float *iq, float freq_shift,
+                        float *corr, float *burst, float *align, float *final_,
+                        int8_t *ebits, int32_t *sync_id, float *toa, float *freq_err, float *ssyms, int32_t *rv);
 
 /* ---- burst type detection / modulation order -------------------------------
  * burst_ids: any number of candidate types (same length / modulation family; more than four run as several launches

@@ -20,7 +20,7 @@ BURST_IDS = ["bcch", "dc2", "dc6", "dc12", "nt3_speech", "nt3_facch", "nt6", "nt
 EXPORTED_FUNCTIONS = [
     "gmr1_hip_init", "gmr1_hip_last_error", "gmr1_hip_version", "gmr1_hip_burst_info",
     "gmr1_hip_set_conv_decoder", "gmr1_hip_get_conv_decoder", "gmr1_hip_clock_probe_dev", "gmr1_hip_rx_run_last_timing",
-    "gmr1_hip_demod_batch_dev", "gmr1_hip_demod_batch",
+    "gmr1_hip_demod_batch_dev", "gmr1_hip_demod_batch", "gmr1_hip_demod_taps",
     "gmr1_hip_bcch_decode_batch_dev", "gmr1_hip_ccch_decode_batch_dev",
     "gmr1_hip_bcch_decode_batch", "gmr1_hip_ccch_decode_batch",
     "gmr1_hip_rx_bcch_ccch_batch_dev", "gmr1_hip_rx_bcch_ccch_batch",
@@ -231,6 +231,29 @@ def demod_batch(burst, iq, offset, in_len, sps=4, freq_shift=None, want_ssyms=Tr
         ss.ctypes.data_as(C.c_void_p) if ss is not None else None, rv.ctypes.data_as(C.c_void_p))
     _check(rc, "gmr1_hip_demod_batch")
     return dict(rv=rv, ebits=eb, sync_id=sid, toa=toa, freq_err=fe, ssyms=ss)
+
+
+def demod_taps(burst, iq, sps=4, freq_shift=0.0):
+    """One burst through gmr1_hip_demod_taps: the batch entry's outputs plus the four vectors the reference dumps under
+    ENABLE_DEBUG_SIGNAL (sdr/defs.h:35-39): corr (pi4cxpsk.c:251), burst (:545), align (:345), final (:582)."""
+    bid = BURST_IDS.index(burst) if isinstance(burst, str) else int(burst)
+    info = burst_info(bid)
+    iq, p_iq = _np(np.asarray(iq).reshape(-1), np.complex64)
+    in_len = iq.size
+    w = in_len - info.len * sps + 1
+    out = dict(corr=np.zeros(max(w, 0), np.float32), burst=np.zeros(in_len, np.complex64),
+               align=np.zeros(info.len, np.complex64), final=np.zeros(info.len, np.complex64),
+               ebits=np.zeros(info.ebits, np.int8), sync_id=np.zeros(1, np.int32), toa=np.zeros(1, np.float32),
+               freq_err=np.zeros(1, np.float32), ssyms=np.zeros(info.len, np.float32), rv=np.zeros(1, np.int32))
+    ptr = lambda k: out[k].ctypes.data_as(C.c_void_p)
+    rc = load().gmr1_hip_demod_taps(
+        C.c_int(bid), C.c_int(sps), C.c_int(in_len), p_iq, C.c_float(freq_shift),
+        ptr("corr"), ptr("burst"), ptr("align"), ptr("final"),
+        ptr("ebits"), ptr("sync_id"), ptr("toa"), ptr("freq_err"), ptr("ssyms"), ptr("rv"))
+    _check(rc, "gmr1_hip_demod_taps")
+    for k in ("sync_id", "toa", "freq_err", "rv"):
+        out[k] = out[k][0]
+    return out
 
 
 def _l1_batch(fn, ebits, neb):

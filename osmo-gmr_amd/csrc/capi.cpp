@@ -19,6 +19,7 @@
 #include <osmocom/gmr1/l1/ccch.h>
 
 #include "capi_common.h"
+#include "rx_debug.h"
 
 namespace gmr1 {
 
@@ -509,6 +510,81 @@ int gmr1_hip_demod_batch(int burst_id, int n, int sps, int in_len,
 	if (r) return r;
 	return demod_host_impl(burst_id, g_host_types[burst_id], nullptr, n, sps, in_len, iq, iq_len, offset,
 	                       freq_shift, ebits, ebits_stride, sync_id, toa, freq_err, ssyms, rv);
+}
+
+// Debugging aid: one burst demodulated exactly as gmr1_hip_demod_batch does, plus the four intermediate vectors the
+// reference writes out under ENABLE_DEBUG_SIGNAL (include/osmocom/gmr1/sdr/defs.h:35-39; pi4cxpsk.c:251,345,545,582).
+// Host pointers, blocking, one wave: for looking at ONE burst of a capture that decodes differently, not a data path.
+int gmr1_hip_demod_taps(int burst_id, int sps, int in_len, const float *iq, float freq_shift,
+                        float *corr, float *burst, float *align, float *final_,
+                        int8_t *ebits, int32_t *sync_id, float *toa, float *freq_err, float *ssyms, int32_t *rv)
+{
+	if (burst_id < 0 || burst_id >= GMR1_HIP_N_BURSTS)
+		return fail(-EINVAL, "bad burst id %d", burst_id);
+	int r = host_types();
+	if (r) return r;
+	const DevBurst &ht = g_host_types[burst_id];
+	if (!iq || !rv)
+		return fail(-EINVAL, "demod taps: iq and rv are required");
+	if (sps < 1 || sps > 16)
+		return fail(-EINVAL, "demod taps: sps=%d out of range (1..16)", sps);
+	const int w = in_len - ht.len * sps + 1;
+	if (w < 1 || in_len > kMaxInLen)
+		return fail(-EINVAL, "demod taps: window of %d samples gives %d lags (>= 1, <= %d samples supported)", in_len, w, kMaxInLen);
+	DevState *s;
+	r = dev_state(&s);
+	if (r) return r;
+	DBuf d_iq, d_off, d_fs, d_eb, d_sid, d_toa, d_fe, d_ss, d_rv, d_taps;
+	const uint64_t zero = 0;
+	const size_t n_taps = (size_t)w + 2 * (size_t)in_len + 4 * (size_t)ht.len;     // floats: corr, burst, align, final
+	HIP_TRY(d_iq.alloc((size_t)in_len * 8));
+	HIP_TRY(d_off.alloc(8));
+	HIP_TRY(d_fs.alloc(4));
+	HIP_TRY(d_eb.alloc(ht.ebits));
+	HIP_TRY(d_sid.alloc(4));
+	HIP_TRY(d_toa.alloc(4));
+	HIP_TRY(d_fe.alloc(4));
+	HIP_TRY(d_ss.alloc((size_t)ht.len * 4));
+	HIP_TRY(d_rv.alloc(4));
+	HIP_TRY(d_taps.alloc(n_taps * 4 + 16));
+	HIP_TRY(hipMemcpy(d_iq.p, iq, (size_t)in_len * 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_off.p, &zero, 8, hipMemcpyHostToDevice));
+	HIP_TRY(hipMemcpy(d_fs.p, &freq_shift, 4, hipMemcpyHostToDevice));
+	RxArgs a;
+	std::memset(&a, 0, sizeof(a));
+	a.n = 1; a.sps = sps; a.in_len[0] = a.in_len[1] = in_len;
+	a.fixed_type = burst_id;
+	a.ebits_stride = ht.ebits;
+	a.ssyms_stride = ht.len;
+	a.iq = d_iq.as<float2>();
+	a.offset = d_off.as<uint64_t>();
+	a.freq_shift = d_fs.as<float>();
+	a.ebits = d_eb.as<int8_t>();
+	a.sync_id = d_sid.as<int32_t>();
+	a.toa = d_toa.as<float>();
+	a.freq_err = d_fe.as<float>();
+	a.ssyms = d_ss.as<float>();
+	a.rv = d_rv.as<int32_t>();
+	// (burst / align / final are complex: they come first so that they sit on 8-byte boundaries)
+	float *t = d_taps.as<float>();
+	RxTapsOut o;
+	o.burst = reinterpret_cast<float2 *>(t);
+	o.align = o.burst + in_len;
+	o.final_ = o.align + ht.len;
+	o.corr = reinterpret_cast<float *>(o.final_ + ht.len);
+	HIP_TRY(launch_rx_taps(a, o, nullptr));
+	HIP_TRY(hipStreamSynchronize(nullptr));
+	HIP_TRY(hipMemcpy(rv, d_rv.p, 4, hipMemcpyDeviceToHost));
+	if (corr) HIP_TRY(hipMemcpy(corr, o.corr, (size_t)w * 4, hipMemcpyDeviceToHost));
+	if (burst) HIP_TRY(hipMemcpy(burst, o.burst, (size_t)in_len * 8, hipMemcpyDeviceToHost));
+	if (align) HIP_TRY(hipMemcpy(align, o.align, (size_t)ht.len * 8, hipMemcpyDeviceToHost));
+	if (final_) HIP_TRY(hipMemcpy(final_, o.final_, (size_t)ht.len * 8, hipMemcpyDeviceToHost));
+	if (ebits) HIP_TRY(hipMemcpy(ebits, d_eb.p, ht.ebits, hipMemcpyDeviceToHost));
+	if (sync_id) HIP_TRY(hipMemcpy(sync_id, d_sid.p, 4, hipMemcpyDeviceToHost));
+	if (toa) HIP_TRY(hipMemcpy(toa, d_toa.p, 4, hipMemcpyDeviceToHost));
+	if (freq_err) HIP_TRY(hipMemcpy(freq_err, d_fe.p, 4, hipMemcpyDeviceToHost));
+	if (ssyms) HIP_TRY(hipMemcpy(ssyms, d_ss.p, (size_t)ht.len * 4, hipMemcpyDeviceToHost));
+	return 0;
 }
 
 // ---------------------------------------------------------------------------

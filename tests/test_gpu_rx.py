@@ -526,3 +526,82 @@ def test_fused_rx_planar_layout_refusals(gpu_api):
                                               z.data_ptr(), z.data_ptr(), None, None, None, None, z.data_ptr())
     with pytest.raises(RuntimeError):         # planes shorter than the samples
         gpu_api.iq_to_planar_dev(None, 4, 100, z.data_ptr(), z.data_ptr(), 24)
+
+
+def test_demod_taps_are_the_reference_debug_signals(gpu_api, orc, pkg):
+    """gmr1_hip_demod_taps: the four vectors the reference dumps under ENABLE_DEBUG_SIGNAL (sdr/defs.h:35-39), rebuilt
+    from the production demodulation, against a float64 restatement of pi4cxpsk.c's own steps (corr :207-237,
+    burst :539-545, align :280-348, final :574-582) -- and its ordinary outputs against the batch entry's."""
+    rng = np.random.default_rng(77)
+    for sps, name, win, fsh in ((4, "bcch", 20, 0.0), (4, "dc6", 20, 0.05), (4, "nt3_speech", 6, -0.02), (4, "rach", 40, 0.0),
+                                (8, "dc2", 32, 0.01), (2, "bcch", 20, 0.0), (16, "dc6", 64, 0.0)):
+        fmt = pkg.api.burst_format(name)
+        ebits = rng.integers(0, 2, size=(4, fmt.ebits), dtype=np.uint8)
+        sym = pkg.synth.map_symbols(fmt, ebits)
+        bb = pkg.synth.synth_windows(fmt, sym, sps, win, rng, toa_jitter=1, frac=sps > 1, cfo_hz_std=20.0, esn0_db=15.0)
+        n_frac = 0
+        for i in range(4):
+            x = bb.iq[i, :bb.in_len]
+            t = gpu_api.demod_taps(name, x, sps=sps, freq_shift=fsh)
+            b = gpu_api.demod_batch(name, x, np.zeros(1, np.uint64), bb.in_len, sps=sps, freq_shift=np.float32([fsh]))
+            assert t["rv"] == b["rv"][0] == 0
+            assert t["toa"] == b["toa"][0] and t["sync_id"] == b["sync_id"][0] and t["freq_err"] == b["freq_err"][0]
+            assert np.array_equal(t["ssyms"], b["ssyms"][0]) and np.array_equal(t["ebits"], b["ebits"][0]), (sps, name)
+            o = orc.demod(name, x, sps, freq_shift=fsh) if fsh else orc.demod(name, x, sps)
+            assert abs(t["toa"] - o["toa"]) < 16 / 1024
+            # burst: normalised over the whole window, then de-rotated
+            x64 = x.astype(np.complex128)
+            nrm = (x64 - x64.mean()) / np.sqrt((np.abs(x64 - x64.mean()) ** 2).mean())
+            fs = (fsh - fmt.rotation) / sps
+            burst = nrm * np.exp(1j * fs * np.arange(bb.in_len))
+            assert np.abs(t["burst"] - burst).max() < 2e-4 * (1 + bb.in_len * abs(fs) / 50), (sps, name)
+            # corr: magnitudes summed over every chunk of every training sequence (the accumulator is never cleared)
+            w = bb.in_len - fmt.length * sps + 1
+            corr = np.zeros(w)
+            for seq in fmt.sync:
+                for pos, syms in seq:
+                    ref = np.exp(2j * np.pi * np.asarray(syms) / 2 ** fmt.nbits)
+                    idx = pos * sps + np.arange(w)[:, None] + sps * np.arange(len(syms))[None, :]
+                    corr += np.abs((np.conj(ref)[None, :] * burst[idx]).sum(axis=1))
+            assert t["corr"].shape == (w,)
+            assert np.abs(t["corr"] - corr).max() < 1e-3 * corr.max(), (sps, name)
+            assert abs(int(np.argmax(t["corr"])) - t["toa"]) <= 1.0
+            # align: one sample per symbol at the rounded timing (sps >= 4), else through the 21-tap fractional delay
+            d = int(np.round(t["toa"]))
+            frac = float(t["toa"]) - d
+            j = np.arange(fmt.length) * sps + d
+            ok = (j >= 0) & (j < bb.in_len)
+            if sps >= 4 or abs(frac) <= 0.1:
+                align = np.where(ok, burst[np.clip(j, 0, bb.in_len - 1)], 0)
+            else:
+                n_frac += 1
+                k = np.arange(21)
+                xx = np.pi * ((k - 10) + frac)
+                taps = np.where(np.abs(xx) >= 0.01, np.sin(xx) / np.where(xx == 0, 1, xx), 1.0)
+                pad = np.concatenate([np.zeros(32), burst, np.zeros(32)])
+                align = np.array([(taps * pad[32 + jj + 10 - k]).sum() if o_ else 0 for jj, o_ in zip(j, ok)])
+            assert np.abs(t["align"] - align).max() < 1e-3, (sps, name, np.abs(t["align"] - align).max())
+            # final: align after the fine-frequency and carrier rotations -- same magnitudes, phases = the soft symbols
+            assert np.abs(np.abs(t["final"]) - np.abs(t["align"])).max() < 1e-5
+            ph = np.angle(t["final"]) * 2 ** fmt.nbits / (2 * np.pi)
+            dph = np.abs(ph - t["ssyms"])
+            dph = np.minimum(dph, np.abs(dph - 2 ** fmt.nbits))
+            assert dph[np.abs(t["final"]) > 1e-3].max() < 1e-3
+            #   ... and they ARE the reference's rotations: align[i] e^{-j (ffe i + psi)} with psi fitted on the sync symbols
+            rot = t["align"].astype(np.complex128) * np.exp(-1j * float(t["freq_err"]) * np.arange(fmt.length))
+            sq = fmt.sync[int(t["sync_id"])]
+            ph0 = sum((np.conj(np.exp(2j * np.pi * np.asarray(s) / 2 ** fmt.nbits)) * rot[p:p + len(s)]).sum() for p, s in sq)
+            fin = rot * np.exp(-1j * np.angle(ph0))
+            assert np.abs(t["final"] - fin).max() < 2e-3 * np.abs(fin).max(), (sps, name)
+        if sps == 2:
+            assert n_frac >= 1, "the fractional-delay branch was not exercised"
+
+
+def test_demod_taps_refusals_and_no_power(gpu_api, pkg):
+    x = np.zeros(234 * 4 + 20, np.complex64)
+    t = gpu_api.demod_taps("bcch", x, sps=4)
+    assert t["rv"] == -1 and not t["align"].any() and not t["final"].any() and not t["ssyms"].any()
+    with pytest.raises(Exception):
+        gpu_api.demod_taps("bcch", x[:100], sps=4)
+    with pytest.raises(Exception):
+        gpu_api.demod_taps("bcch", x, sps=0)
