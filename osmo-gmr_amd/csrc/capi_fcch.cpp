@@ -1,5 +1,6 @@
 // capi_fcch.cpp -- C-ABI entry points of the FCCH acquisition kernels.
 #include "capi_common.h"
+#include "fcch_acq.h"
 
 using namespace gmr1;
 
@@ -17,8 +18,15 @@ int fcch_tab_of(const struct gmr1_fcch_burst *bt)
 	return -1;
 }
 
+const AcqTail &no_tail()
+{
+	static const AcqTail none = [] { AcqTail t; std::memset(&t, 0, sizeof(t)); return t; }();
+	return none;
+}
+
 int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq, const uint64_t *offset,
-              const float *freq_shift, int32_t *toa, int32_t *rv, float *energy, size_t energy_stride)
+              const float *freq_shift, int32_t *toa, int32_t *rv, float *energy, size_t energy_stride,
+              const AcqTail &tl = no_tail())
 {
 	if (tab < 0 || tab >= kFcchTabs)
 		return fail(-EINVAL, "fcch: unknown burst type");
@@ -57,12 +65,12 @@ int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq,
 	a.tile_best = reinterpret_cast<float *>(static_cast<char *>(ws) + b_dec + b_par);
 	a.energy = energy; a.energy_stride = energy_stride;
 	a.toa = toa; a.rv = rv;
-	HIP_TRY(launch_fcch_rough(a, ntaps, st));
+	HIP_TRY(launch_fcch_rough_tail(a, ntaps, tl, st));
 	return 0;
 }
 
 int fine_dev(hipStream_t st, int tab, int mode, int n, int sps, const float *iq, const uint64_t *offset,
-             const float *freq_shift, int32_t *toa, float *freq_err, float *snr)
+             const float *freq_shift, int32_t *toa, float *freq_err, float *snr, const AcqTail &tl = no_tail())
 {
 	if (tab < 0 || tab >= kFcchTabs)
 		return fail(-EINVAL, "fcch: unknown burst type");
@@ -79,7 +87,7 @@ int fine_dev(hipStream_t st, int tab, int mode, int n, int sps, const float *iq,
 	a.iq = reinterpret_cast<const float2 *>(iq);
 	a.offset = offset; a.freq_shift = freq_shift;
 	a.toa = toa; a.freq_err = freq_err; a.snr = snr;
-	HIP_TRY(launch_fcch_fine(a, kFcchBuiltin[tab]->len, st));
+	HIP_TRY(launch_fcch_fine_tail(a, kFcchBuiltin[tab]->len, tl, st));
 	return 0;
 }
 
@@ -202,9 +210,25 @@ int gmr1_hip_fcch_snr_batch(int fcch_type, int n, int sps,
 	return 0;
 }
 
-int gmr1_hip_fcch_rough_multi_batch_dev(void *stream, int fcch_type, int n, int sps, int len,
-                                        const float *iq, const uint64_t *offset, const float *freq_shift,
-                                        int32_t *peaks_toa, int N, int32_t *count)
+}  // extern "C"
+
+namespace gmr1 {
+
+int fcch_rough_tail(hipStream_t st, int tab, int n, int sps, int len, const float *iq, const uint64_t *offset,
+                    const float *freq_shift, int32_t *toa, int32_t *rv, const AcqTail &t)
+{
+	return rough_dev(st, tab, n, sps, len, iq, offset, freq_shift, toa, rv, nullptr, 0, t);
+}
+
+int fcch_fine_tail(hipStream_t st, int tab, int mode, int n, int sps, const float *iq, const uint64_t *offset,
+                   const float *freq_shift, int32_t *toa, float *freq_err, float *snr, const AcqTail &t)
+{
+	return fine_dev(st, tab, mode, n, sps, iq, offset, freq_shift, toa, freq_err, snr, t);
+}
+
+int fcch_rough_multi_tail(hipStream_t stream, int fcch_type, int n, int sps, int len,
+                          const float *iq, const uint64_t *offset, const float *freq_shift,
+                          int32_t *peaks_toa, int N, int32_t *count, const AcqTail &tl)
 {
 	if (fcch_type < 0 || fcch_type >= kFcchTabs || !peaks_toa || !count || N < 1 || N > 32)
 		return fail(-EINVAL, "fcch_rough_multi: bad argument");
@@ -242,8 +266,20 @@ int gmr1_hip_fcch_rough_multi_batch_dev(void *stream, int fcch_type, int n, int 
 	m.Lw = m.Lp + blen;
 	m.energy = energy; m.energy_stride = estride;
 	m.toa = peaks_toa; m.count = count;
-	HIP_TRY(launch_fcch_multi(m, (hipStream_t)stream));
+	HIP_TRY(launch_fcch_multi_tail(m, tl, stream));
 	return 0;
+}
+
+}  // namespace gmr1
+
+extern "C" {
+
+int gmr1_hip_fcch_rough_multi_batch_dev(void *stream, int fcch_type, int n, int sps, int len,
+                                        const float *iq, const uint64_t *offset, const float *freq_shift,
+                                        int32_t *peaks_toa, int N, int32_t *count)
+{
+	return fcch_rough_multi_tail((hipStream_t)stream, fcch_type, n, sps, len, iq, offset, freq_shift, peaks_toa, N, count,
+	                             no_tail());
 }
 
 int gmr1_hip_fcch_rough_multi_batch(int fcch_type, int n, int sps, int len,

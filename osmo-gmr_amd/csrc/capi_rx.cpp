@@ -20,6 +20,7 @@
 // logging are out of scope; what GSMTAP would have carried comes back as records.
 
 #include "capi_common.h"
+#include "fcch_acq.h"
 
 #include <algorithm>
 #include <chrono>
@@ -239,6 +240,12 @@ int RxRun::acquire()
 	// without a candidate gets a harmless window).  One copy brings every raw sweep result back, and the decisions are
 	// then taken here exactly as before, from those numbers.
 	static_assert(kMaxPeaks == kAcqPeaks, "candidate slots");
+	// (profiling build, GMR1_HIP_RX_TIMING: host-side stamps of this call's stages on stderr)
+	static const bool timing = profile_env("GMR1_HIP_RX_TIMING") != nullptr;
+	std::chrono::steady_clock::time_point tp[6];
+	int n_tp = 0;
+	auto stamp = [&] { if (timing && n_tp < 6) tp[n_tp++] = std::chrono::steady_clock::now(); };
+	stamp();
 	const int wl1 = (330 * kSymRate * sps) / 1000, wl3 = (650 * kSymRate * sps) / 1000;
 	std::vector<int> idx;
 	for (int i = 0; i < A; i++) {
@@ -279,6 +286,7 @@ int RxRun::acquire()
 	std::memset(H(o_off) + (size_t)n * 8, 0, (o_toa1 - o_off) - (size_t)n * 8);
 	// inputs: everything up to can3, the first sweep's windows, the zeroed peak list -- one copy
 	HIP_TRY(hipMemcpyAsync(d, h, o_toa1, hipMemcpyHostToDevice, st));
+	stamp();
 
 	AcqArgs g;
 	std::memset(&g, 0, sizeof(g));
@@ -304,13 +312,27 @@ int RxRun::acquire()
 	uint64_t *d_off = g.off;
 	float *d_fs = g.fs;
 
+	// What the reference does between two sweeps (k_acq_glue's steps) is done by the producing sweep's last thread
+	// (AcqTail, fcch_acq.h) -- four launches fewer in a chain of small dependent ones; the profiling build keeps the
+	// other form for the comparison (GMR1_HIP_ACQ_UNFUSED).
+	static const bool unfused = profile_env("GMR1_HIP_ACQ_UNFUSED") != nullptr;
+	auto tail = [&](int step, bool skip_dead) {
+		AcqTail t;
+		std::memset(&t, 0, sizeof(t));
+		if (!unfused) {
+			t.step = step;
+			t.skip_dead = skip_dead ? g.live : nullptr;
+			t.g = g;
+		}
+		return t;
+	};
 	// fcch_single_init (gmr1_rx.c:605-639): rough over 330 ms, then fine
-	if ((r = gmr1_hip_fcch_rough_batch_dev(st, 0, n, sps, wl1, iq, d_off, nullptr, reinterpret_cast<int32_t *>(D(o_toa1)),
-	                                       reinterpret_cast<int32_t *>(D(o_rv1))))) return r;
-	HIP_TRY(launch_acq_glue(1, g, st));
-	if ((r = gmr1_hip_fcch_fine_batch_dev(st, 0, n, sps, iq, d_off, nullptr, reinterpret_cast<int32_t *>(D(o_ftoa)),
-	                                      reinterpret_cast<float *>(D(o_fe))))) return r;
-	HIP_TRY(launch_acq_glue(2, g, st));
+	if ((r = fcch_rough_tail(st, 0, n, sps, wl1, iq, d_off, nullptr, reinterpret_cast<int32_t *>(D(o_toa1)),
+	                         reinterpret_cast<int32_t *>(D(o_rv1)), tail(1, false)))) return r;
+	if (unfused) HIP_TRY(launch_acq_glue(1, g, st));
+	if ((r = fcch_fine_tail(st, 0, 0, n, sps, iq, d_off, nullptr, reinterpret_cast<int32_t *>(D(o_ftoa)),
+	                        reinterpret_cast<float *>(D(o_fe)), nullptr, tail(2, false)))) return r;
+	if (unfused) HIP_TRY(launch_acq_glue(2, g, st));
 	// fcch_multi_process (gmr1_rx.c:643-744); a carrier shorter than 650 ms can only fail here, its dummy window would
 	// not fit either: the sweep runs over the others
 	std::vector<int> k3;
@@ -320,8 +342,8 @@ int RxRun::acquire()
 	const bool all3 = (int)k3.size() == n;
 	if (!k3.empty()) {
 		if (all3) {
-			if ((r = gmr1_hip_fcch_rough_multi_batch_dev(st, 0, n, sps, wl3, iq, d_off, d_fs, reinterpret_cast<int32_t *>(D(o_peaks)),
-			                                             kMaxPeaks, reinterpret_cast<int32_t *>(D(o_count))))) return r;
+			if ((r = fcch_rough_multi_tail(st, 0, n, sps, wl3, iq, d_off, d_fs, reinterpret_cast<int32_t *>(D(o_peaks)),
+			                               kMaxPeaks, reinterpret_cast<int32_t *>(D(o_count)), tail(3, false)))) return r;
 		} else {
 			// mixed lengths: the long-enough carriers one by one at their own slots (rare; captures come in equal lengths)
 			for (int k : k3)
@@ -330,14 +352,24 @@ int RxRun::acquire()
 				                                             reinterpret_cast<int32_t *>(D(o_count)) + k))) return r;
 		}
 	}
-	HIP_TRY(launch_acq_glue(3, g, st));
-	if ((r = gmr1_hip_fcch_fine_batch_dev(st, 0, (int)S, sps, iq, d_off, d_fs, reinterpret_cast<int32_t *>(D(o_ctoa)),
-	                                      reinterpret_cast<float *>(D(o_cfe))))) return r;
-	HIP_TRY(launch_acq_glue(4, g, st));
-	if ((r = gmr1_hip_fcch_snr_batch_dev(st, 0, (int)S, sps, iq, d_off, d_fs, reinterpret_cast<float *>(D(o_snr))))) return r;
+	// (mixed lengths, or no carrier long enough: the step that lays out the candidate slots runs as its own launch)
+	if (unfused || !all3) HIP_TRY(launch_acq_glue(3, g, st));
+	if ((r = fcch_fine_tail(st, 0, 0, (int)S, sps, iq, d_off, d_fs, reinterpret_cast<int32_t *>(D(o_ctoa)),
+	                        reinterpret_cast<float *>(D(o_cfe)), nullptr, tail(4, true)))) return r;
+	if (unfused) HIP_TRY(launch_acq_glue(4, g, st));
+	if ((r = fcch_fine_tail(st, 0, 1, (int)S, sps, iq, d_off, d_fs, nullptr, nullptr, reinterpret_cast<float *>(D(o_snr)),
+	                        tail(0, true)))) return r;
 	// results back: the peak list (in front of toa1) and toa1 .. snr
+	stamp();
 	HIP_TRY(hipMemcpyAsync(H(o_peaks), D(o_peaks), o_live - o_peaks, hipMemcpyDeviceToHost, st));
+	stamp();
 	HIP_TRY(hipStreamSynchronize(st));
+	stamp();
+	if (timing) {
+		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+		fprintf(stderr, "acquire: prepare + first copy %.1f us, launches %.1f us, copy back enqueued %.1f us, waited %.1f us\n",
+		        us(tp[0], tp[1]), us(tp[1], tp[2]), us(tp[2], tp[3]), us(tp[3], tp[4]));
+	}
 
 	// ---- the decisions, from the raw sweep results, in the reference's order ------------------------------------
 	const int32_t *toa1 = reinterpret_cast<const int32_t *>(H(o_toa1)), *rv1 = reinterpret_cast<const int32_t *>(H(o_rv1)),

@@ -16,7 +16,9 @@
 // read back, a few kB of partials: 1.5x the algorithmic bytes.  The correlation is 10.9 MFLOP per
 // stream (14.6 flop/B), so the sweep sits near the HBM / fp32-VALU ridge; no MFMA (real x complex
 // FIR, "do not reshape into GEMMs").
+#include <cstring>
 #include "gmr1_dev.h"
+#include "fcch_acq.h"
 #include "profile_env.h"
 
 namespace gmr1 {
@@ -482,13 +484,112 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a)
 	}
 }
 
+// ---------------------------------------------------------------------------
+// The arithmetic gmr1_rx's acquisition does between two sweeps (fcch_single_init gmr1_rx.c:605-639, fcch_multi_process
+// :643-702), per carrier `k` / candidate slot `t`, from the sweep's result the calling thread holds:
+//   step 1  after the 330 ms rough sweep : align += toa, bounds, window of the fine stage
+//   step 2  after the fine stage         : align += toa, freq_err, base_align, window + shift of the 650 ms sweep
+//   step 3  after rough_multi            : one window per candidate slot (bounds: a candidate outside drops the carrier)
+//   step 4  after fine over the slots    : refined window + shift of the SNR stage
+// Called by the producing sweep's last thread (AcqTail, fcch_acq.h) or, one launch each, by k_acq_glue.
+// ---------------------------------------------------------------------------
+__device__ inline void acq_step1(const AcqArgs &a, int k, int toa1, int rv1)
+{
+	const int64_t len = (int64_t)a.len[k];
+	int stat = a.stat[k];
+	if (!stat) {
+		if (rv1) {
+			stat = rv1;
+		} else {
+			a.align[k] += toa1;
+			if ((int64_t)a.align[k] + a.flen > len)
+				stat = -1;
+		}
+	}
+	a.stat[k] = stat;
+	a.off[k] = a.base[k] + (uint64_t)(stat ? 0 : a.align[k]);
+}
+
+__device__ inline void acq_step2(const AcqArgs &a, int k, int ftoa, float fe)
+{
+	const int64_t len = (int64_t)a.len[k];
+	int stat = a.stat[k];
+	float fs = 0.f;
+	if (!stat) {
+		a.align[k] += ftoa;
+		a.ferr[k] = fe;
+		int ba = a.align[k] - a.flen;
+		if (ba < 0) ba = 0;
+		a.base_align[k] = ba;
+		if (!a.can3[k] || (int64_t)ba + a.wl3 > len)
+			stat = -1;
+		fs = -fe;
+	}
+	a.stat[k] = stat;
+	a.off[k] = a.base[k] + (uint64_t)((stat || !a.can3[k]) ? 0 : a.base_align[k]);
+	a.fs[k] = fs;
+}
+
+// (peaks: the carrier's candidate list, kAcqPeaks wide -- global memory or LDS; cnt: rough_multi's count)
+__device__ inline void acq_step3(const AcqArgs &a, int k, int j, const int32_t *peaks, int cnt)
+{
+	const int t = k * kAcqPeaks + j;
+	const int64_t len = (int64_t)a.len[k];
+	int stat = a.stat[k];
+	bool live = false;
+	int64_t p = 0;
+	if (!stat) {
+		if (cnt < 0) {
+			stat = cnt;
+		} else {
+			// a carrier with any candidate outside its samples is dropped as a whole
+			bool ok = true;
+			for (int q = 0; q < cnt; q++) {
+				const int64_t pq = (int64_t)a.base_align[k] + peaks[q];
+				if (pq < 0 || pq + a.flen > len) ok = false;
+			}
+			if (!ok)
+				stat = -1;
+			else if (j < cnt) {
+				live = true;
+				p = (int64_t)a.base_align[k] + peaks[j];
+			}
+		}
+	}
+	a.live[t] = live ? 1 : 0;
+	a.off[t] = a.base[k] + (uint64_t)(live ? p : 0);
+	a.fs[t] = live ? -a.ferr[k] : 0.f;
+	// (every slot of the carrier computes the same verdict; slot 0 records it -- behind the others' reads of it only when
+	// they are lanes of one wave or threads of one launch that read before any writes: callers see to that)
+	if (j == 0 && stat)
+		a.stat[k] = stat;
+}
+
+__device__ inline void acq_step4(const AcqArgs &a, int t, int ctoa, float cfe)
+{
+	const int k = t / kAcqPeaks, j = t % kAcqPeaks;
+	const int64_t len = (int64_t)a.len[k];
+	const bool live = a.live[t] != 0;
+	int64_t p = 0;
+	if (live)
+		p = (int64_t)a.base_align[k] + a.peaks[(size_t)k * kAcqPeaks + j] + ctoa;
+	const bool inside = live && p >= 0 && p + a.flen <= len;
+	a.off[t] = a.base[k] + (uint64_t)(inside ? p : 0);
+	a.fs[t] = inside ? -(a.ferr[k] + cfe) : 0.f;
+}
+
 // second half: the normalisation applied to the raw correlation, energies, the tile's best 5-lag window
 // (tiles: lag tiles per work-group -- several where there are thousands of them, so that the statistics are formed once for
 // all; one where the launch is small and its latency is what counts: the receive loop's acquisition)
+__device__ inline void fcch_pick_body(const FcchRoughArgs &a, const AcqTail &tl, int s, int lane);      // (below)
+constexpr int kPickStreams = 1 << 16;
+__device__ unsigned int g_pick_count[kPickStreams];      // work-groups of the stream that are through (back to 0 by the last one)
+
 template <int NT>
-__global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnergyTiles)
+__global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnergyTiles, int pick, AcqTail tl)
 {
 	__shared__ float en[kTileLags];
+	__shared__ int s_last;
 	__shared__ float s_stat[8];
 	__shared__ float s_best[4];
 	__shared__ int s_bidx[4];
@@ -598,20 +699,41 @@ __global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnerg
 		}
 	}
 	}
+	if (!pick)
+		return;
+	// the stream's last work-group picks (thread 0 wrote this group's tiles: its fence, then its count)
+	if (tid == 0) {
+		__threadfence();
+		s_last = atomicAdd(&g_pick_count[s], 1u) == gridDim.x - 1 ? 1 : 0;
+	}
+	__syncthreads();
+	if (!s_last || wv != 0)
+		return;
+	if (lane == 0)
+		g_pick_count[s] = 0;
+	__threadfence();
+	fcch_pick_body(a, tl, s, lane);
 }
 
 // ---------------------------------------------------------------------------
 // pass 3: per stream, best tile -> centroid -> toa    (one wavefront per stream)
+// Run by the LAST work-group of k_fcch_energy to finish the stream (a counter per stream tells which: one launch fewer in
+// a chain of small dependent ones), or as the kernel k_fcch_pick.  The tiles' results were written by other work-groups of
+// the same launch: they are read with device-scope loads.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_fcch_pick(FcchRoughArgs a)
+__device__ __forceinline__ float ld_dev(const float *p)
 {
-	const int s = blockIdx.x, lane = threadIdx.x;
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline void fcch_pick_body(const FcchRoughArgs &a, const AcqTail &tl, int s, int lane)
+{
 	float bv = -1.0f;
 	int bi = 0x7fffffff, bt = 0;
 	for (int t = lane; t < a.n_lag_tiles; t += 64) {
 		const float *o = a.tile_best + ((size_t)s * a.n_lag_tiles + t) * 8;
-		const float v = o[0];
-		const int i = __builtin_bit_cast(int, o[1]);
+		const float v = ld_dev(o);
+		const int i = __builtin_bit_cast(int, ld_dev(o + 1));
 		if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; bt = t; }
 	}
 #pragma unroll
@@ -621,24 +743,34 @@ __global__ __launch_bounds__(64) void k_fcch_pick(FcchRoughArgs a)
 		const int ot = __shfl_xor(bt, o);
 		if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bt = ot; }
 	}
+	// PEAK_WEIGH_WIN: energy-weighted centroid of the 5 samples (lanes 0..4 fetch them at once, lane 0 sums in order)
+	float e5 = 0.f;
+	if (bi != 0x7fffffff && lane < 5)
+		e5 = ld_dev(a.tile_best + ((size_t)s * a.n_lag_tiles + bt) * 8 + 2 + lane);
+	float num = 0.f, den = 0.f;
+	for (int k = 0; k < 5; k++) {
+		const float e = __shfl(e5, k);
+		num += e * (float)(bi + k);
+		den += e;
+	}
 	if (lane == 0) {
 		int toa = 0, rv = 0;
 		if (bi == 0x7fffffff) {
 			rv = -22;
 		} else {
-			// PEAK_WEIGH_WIN: energy-weighted centroid of the 5 samples
-			const float *o = a.tile_best + ((size_t)s * a.n_lag_tiles + bt) * 8;
-			float num = 0.f, den = 0.f;
-			for (int k = 0; k < 5; k++) {
-				num += o[2 + k] * (float)(bi + k);
-				den += o[2 + k];
-			}
 			const float pos = num / den;
 			toa = (int)round((double)(pos * (float)a.sps));     // fcch.c:241
 		}
 		a.toa[s] = toa;
 		if (a.rv) a.rv[s] = rv;
+		if (tl.step == 1)
+			acq_step1(tl.g, s, toa, rv);
 	}
+}
+
+__global__ __launch_bounds__(64) void k_fcch_pick(FcchRoughArgs a, AcqTail tl)
+{
+	fcch_pick_body(a, tl, blockIdx.x, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -651,8 +783,10 @@ __global__ __launch_bounds__(64) void k_fcch_pick(FcchRoughArgs a)
 // (peak search, centroid) is wave 0's: every sum keeps its order, the results are bit for bit those of one wave.
 constexpr int kFineWaves = 2;
 template <int N>
-__global__ __launch_bounds__(64 * kFineWaves) void k_fcch_fine(FcchFineArgs a)
+__global__ __launch_bounds__(64 * kFineWaves) void k_fcch_fine(FcchFineArgs a, AcqTail tl)
 {
+	if (tl.skip_dead && !tl.skip_dead[blockIdx.x])
+		return;                              // a candidate slot without a candidate (the acquisition chain's lists)
 	constexpr int NT = 64 * kFineWaves;
 	constexpr int PER = (N + NT - 1) / NT;   // bins per thread
 	__shared__ float2 s_up[N], s_dn[N];
@@ -664,28 +798,79 @@ __global__ __launch_bounds__(64 * kFineWaves) void k_fcch_fine(FcchFineArgs a)
 	const float fs = a.freq_shift ? a.freq_shift[b] : 0.0f;
 	const int tab = a.tab;
 
-	// statistics over all raw samples (osmo_cxvec_sig_normalize)
+	// Everything this work-group reads from memory is asked for up front, in one round: the kernel sits in the receive
+	// loop's acquisition chain three times and its dependent memory round trips were most of its time.  Windows to 512
+	// samples (117 symbols at <= 4 samples per symbol) are held in registers for both statistics passes.
+	constexpr int kRawRegs = 8;
+	const bool in_regs = nraw <= 64 * kRawRegs;
+	float2 raw[kRawRegs];
+	if (in_regs) {
+#pragma unroll
+		for (int j = 0; j < kRawRegs; j++) {
+			const int i = lane + 64 * j;
+			raw[j] = i < nraw ? in[i] : make_float2(0.f, 0.f);
+		}
+	}
+	float2 mine[PER], t_tw[PER], t_up[PER], t_shf[PER];
+	float t_dual[PER];
+#pragma unroll
+	for (int p = 0; p < PER; p++) {
+		const int i = tid + NT * p;
+		mine[p] = t_tw[p] = t_up[p] = t_shf[p] = make_float2(0.f, 0.f);
+		t_dual[p] = 0.f;
+		if (i < N) {
+			mine[p] = in[i * sps];
+			t_tw[p] = c_fcch.twid[tab][i];
+			if (a.mode == 0) {
+				t_up[p] = c_fcch.up[tab][i];
+				t_shf[p] = c_fcch.shift[tab][i];
+			} else {
+				t_dual[p] = c_fcch.dual[tab][i];
+			}
+		}
+	}
+
+	// statistics over all raw samples (osmo_cxvec_sig_normalize): lane i takes samples i, i + 64, ... in that order
 	float sr = 0.f, si = 0.f;
-	for (int i = lane; i < nraw; i += 64) {
-		const float2 v = in[i];
-		sr += v.x; si += v.y;
+	if (in_regs) {
+#pragma unroll
+		for (int j = 0; j < kRawRegs; j++)
+			if (lane + 64 * j < nraw) { sr += raw[j].x; si += raw[j].y; }
+	} else {
+		for (int i = lane; i < nraw; i += 64) {
+			const float2 v = in[i];
+			sr += v.x; si += v.y;
+		}
 	}
 	sr = wave_sum(sr); si = wave_sum(si);
 	const float avr = sr / (float)nraw, avi = si / (float)nraw;
 	float sq = 0.f;
-	for (int i = lane; i < nraw; i += 64) {
-		const float2 v = in[i];
-		const float dx = v.x - avr, dy = v.y - avi;
-		sq = fmaf(dx, dx, fmaf(dy, dy, sq));
+	if (in_regs) {
+#pragma unroll
+		for (int j = 0; j < kRawRegs; j++)
+			if (lane + 64 * j < nraw) {
+				const float dx = raw[j].x - avr, dy = raw[j].y - avi;
+				sq = fmaf(dx, dx, fmaf(dy, dy, sq));
+			}
+	} else {
+		for (int i = lane; i < nraw; i += 64) {
+			const float2 v = in[i];
+			const float dx = v.x - avr, dy = v.y - avi;
+			sq = fmaf(dx, dx, fmaf(dy, dy, sq));
+		}
 	}
 	float sd = sqrtf(wave_sum(sq) / (float)nraw);
 	if (sd == 0.0f) sd = 1.0f;
 	const float inv = 1.0f / sd;
 
 	// normalise, shift, mix
-	for (int i = tid; i < N; i += NT) {
-		s_tw[i] = c_fcch.twid[a.tab][i];
-		float2 v = in[i * sps];
+#pragma unroll
+	for (int p = 0; p < PER; p++) {
+		const int i = tid + NT * p;
+		if (i >= N)
+			continue;
+		s_tw[i] = t_tw[p];
+		float2 v = mine[p];
 		v.x = (v.x - avr) * inv;
 		v.y = (v.y - avi) * inv;
 		if (fs != 0.0f) {
@@ -695,42 +880,51 @@ __global__ __launch_bounds__(64 * kFineWaves) void k_fcch_fine(FcchFineArgs a)
 		}
 		if (a.mode == 0) {
 			// burst * ref_up / ref_down, then centre the spectrum on bin N/2 (fcch.c:563-580)
-			const float2 shf = c_fcch.shift[tab][i];
-			s_up[i] = cmul(cmul(v, c_fcch.up[tab][i]), shf);
-			const float2 dn = make_float2(c_fcch.up[tab][i].x, -c_fcch.up[tab][i].y);   // down = conj(up)
+			const float2 shf = t_shf[p];
+			s_up[i] = cmul(cmul(v, t_up[p]), shf);
+			const float2 dn = make_float2(t_up[p].x, -t_up[p].y);   // down = conj(up)
 			s_dn[i] = cmul(cmul(v, dn), shf);
 		} else {
-			const float r = c_fcch.dual[tab][i];
+			const float r = t_dual[p];
 			s_up[i] = make_float2(v.x * r, v.y * r);
 		}
 	}
 	__syncthreads();
 
-	// direct DFT, bins tid, tid + NT, ...
-	float2 xu[PER], xd[PER];
+	// direct DFT, bins tid, tid + NT, ...   (sums over n ascending, per bin, as before; the two modes as loops of their own)
 #pragma unroll
 	for (int p = 0; p < PER; p++) {
 		const int k = tid + NT * p;
 		float2 au = make_float2(0.f, 0.f), ad = make_float2(0.f, 0.f);
 		if (k < N) {
 			int idx = 0;
-			for (int n = 0; n < N; n++) {
-				const float2 tw = s_tw[idx];
-				const float2 u = s_up[n];
-				au.x = fmaf(u.x, tw.x, fmaf(-u.y, tw.y, au.x));
-				au.y = fmaf(u.x, tw.y, fmaf(u.y, tw.x, au.y));
-				if (a.mode == 0) {
+			if (a.mode == 0) {
+#pragma unroll 9
+				for (int n = 0; n < N; n++) {
+					const float2 tw = s_tw[idx];
+					const float2 u = s_up[n];
 					const float2 dd = s_dn[n];
+					au.x = fmaf(u.x, tw.x, fmaf(-u.y, tw.y, au.x));
+					au.y = fmaf(u.x, tw.y, fmaf(u.y, tw.x, au.y));
 					ad.x = fmaf(dd.x, tw.x, fmaf(-dd.y, tw.y, ad.x));
 					ad.y = fmaf(dd.x, tw.y, fmaf(dd.y, tw.x, ad.y));
+					idx += k;
+					idx -= idx >= N ? N : 0;
 				}
-				idx += k;
-				if (idx >= N) idx -= N;
+			} else {
+#pragma unroll 9
+				for (int n = 0; n < N; n++) {
+					const float2 tw = s_tw[idx];
+					const float2 u = s_up[n];
+					au.x = fmaf(u.x, tw.x, fmaf(-u.y, tw.y, au.x));
+					au.y = fmaf(u.x, tw.y, fmaf(u.y, tw.x, au.y));
+					idx += k;
+					idx -= idx >= N ? N : 0;
+				}
 			}
 			s_e[0][k] = fmaf(au.x, au.x, au.y * au.y);
 			s_e[1][k] = fmaf(ad.x, ad.x, ad.y * ad.y);
 		}
-		xu[p] = au; xd[p] = ad;
 	}
 	__syncthreads();
 
@@ -770,11 +964,17 @@ __global__ __launch_bounds__(64 * kFineWaves) void k_fcch_fine(FcchFineArgs a)
 			const float pu = (peak[0] - (float)mid) * bin_hz;
 			const float pd = (peak[1] - (float)mid) * bin_hz;
 			const float ferr_hz = (pu + pd) / 2.0f;
-			a.freq_err[b] = (2.0f * kPif * ferr_hz) / 23400.0f;
+			a.freq_err[b] = (2.0f * kPif * ferr_hz) / 23400.0f;      // (fe below: the same expression)
 			const float chirp_rate = (2.0f * c_fcch.freq[tab] * 23400.0f * 23400.0f) / (float)(N * 1000);
 			const float toa_ms = ((pu - pd) / 2.0f) / chirp_rate;
 			const float toa_samples = (toa_ms * 23400.0f * (float)sps) / 1000.0f;
-			a.toa[b] = (int)round((double)toa_samples);
+			const int toa = (int)round((double)toa_samples);
+			const float fe = (2.0f * kPif * ferr_hz) / 23400.0f;
+			a.toa[b] = toa;
+			if (tl.step == 2)
+				acq_step2(tl.g, b, toa, fe);
+			else if (tl.step == 4)
+				acq_step4(tl.g, b, toa, fe);
 		}
 	} else {
 		// 6 largest bins, descending, first index wins ties (osmo_cxvec_peaks_scan)
@@ -802,7 +1002,6 @@ __global__ __launch_bounds__(64 * kFineWaves) void k_fcch_fine(FcchFineArgs a)
 		if (tid == 0)
 			a.snr[b] = (top[0] + top[1]) / (top[4] + top[5]);      // fcch.c:701-702
 	}
-	(void)xu; (void)xd;
 }
 
 // ---------------------------------------------------------------------------
@@ -820,7 +1019,7 @@ __device__ __forceinline__ float block_sum(float v, float *red, int tid)
 	return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
+__global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a, AcqTail tl)
 {
 	extern __shared__ __align__(16) unsigned char lds_raw[];
 	float *v = reinterpret_cast<float *>(lds_raw);          // Lw mixed-cycle values
@@ -829,6 +1028,11 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 	__shared__ int s_bi[4];
 	__shared__ int s_scal[4];
 	__shared__ unsigned int s_flags[256];                   // Lw <= 8192 threshold flags
+	// the ranked list while it is being kept: LDS, not the caller's array and not a private one -- lane 0 goes through it
+	// once per rising edge, and every trip to memory would be on the chain's critical path
+	__shared__ int s_toa[32];
+	__shared__ float s_pwr[32];
+	__shared__ int s_mod[32];                               // toa % Lp of the entries (what _peak_record compares)
 
 	const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const float *__restrict__ cp = a.energy + (size_t)s * a.energy_stride;
@@ -837,12 +1041,20 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 	int Lp = a.Lp;
 
 	// ---- strongest lag within the first Lw (first maximum, must exceed 0)
+	// (the thread's <= 32 energies of the first cycle are asked for in one round and kept: the mix below wants them again --
+	// a loop of dependent loads here was most of this kernel's time, and the kernel is on the receive loop's acquisition chain)
+	constexpr int kRegs = 32;                // Lw <= 8192 = 256 x 32 (launch_fcch_multi refuses more)
+	float e0[kRegs];
+#pragma unroll
+	for (int j = 0; j < kRegs; j++) {
+		const int i = tid + 256 * j;
+		e0[j] = (i < Lw && i < cl) ? cp[i] : 0.0f;
+	}
 	float bv = 0.0f;
 	int bi = 0x7fffffff;
-	for (int i = tid; i < Lw && i < cl; i += 256) {
-		const float e = cp[i];
-		if (e > bv) { bv = e; bi = i; }
-	}
+#pragma unroll
+	for (int j = 0; j < kRegs; j++)
+		if (e0[j] > bv) { bv = e0[j]; bi = tid + 256 * j; }
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
 		const float ov = __shfl_xor(bv, o);
@@ -887,36 +1099,52 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 	if (s_scal[1]) {
 		if (tid == 0)
 			a.count[s] = -22;
+		if (tl.step == 3 && tid < kAcqPeaks)
+			acq_step3(tl.g, s, tid, s_toa, -22);
 		return;
 	}
 	Lp = s_scal[0];
 
 	// ---- mix the two cycles, mean, standard deviation, threshold (fcch.c:435-454)
 	float sum = 0.f;
-	for (int i = tid; i < Lw; i += 256) {
-		// lags past the end of the sweep count as 0 (the reference over-reads there, fcch.c:438)
-		const float m = (i + Lp < cl) ? sqrtf(cp[i] * cp[i + Lp]) : 0.0f;
-		v[i] = m;
-		sum += m;
+	float e1[kRegs];
+#pragma unroll
+	for (int j = 0; j < kRegs; j++) {
+		const int i = tid + 256 * j;
+		e1[j] = (i < Lw && i + Lp < cl) ? cp[i + Lp] : 0.0f;
+	}
+#pragma unroll
+	for (int j = 0; j < kRegs; j++) {
+		const int i = tid + 256 * j;
+		if (i < Lw) {
+			// lags past the end of the sweep count as 0 (the reference over-reads there, fcch.c:438)
+			// (i + Lp < cl: then i < cl, so e0 holds cp[i] -- Lp is positive here, |Lp - 7488| <= 10)
+			const float m = (i + Lp < cl) ? sqrtf(e0[j] * e1[j]) : 0.0f;
+			v[i] = m;
+			sum += m;
+			e0[j] = m;                   // (the mixed value stays in the register: deviation and threshold below)
+		}
 	}
 	const float avg = block_sum(sum, red, tid) / (float)Lw;
 	float sq = 0.f;
-	for (int i = tid; i < Lw; i += 256) {
-		const float d = v[i] - avg;
-		sq = fmaf(d, d, sq);
-	}
+#pragma unroll
+	for (int j = 0; j < kRegs; j++)
+		if (tid + 256 * j < Lw) {
+			const float d = e0[j] - avg;
+			sq = fmaf(d, d, sq);
+		}
 	const float stddev = sqrtf(block_sum(sq, red, tid) / (float)Lw);
 	const float th = avg + 3.0f * stddev;
 
-	// ---- threshold flags, 32 lags per word
-	for (int wd = tid; wd < 256; wd += 256) {
-		unsigned int f = 0;
-		for (int b = 0; b < 32; b++) {
-			const int i = wd * 32 + b;
-			if (i >= 1 && i < Lw - 1 && v[i] > th)
-				f |= 1u << b;
+	// ---- threshold flags, 32 lags per word: a wave's 64 lags of round j are words 8 j + 2 wv and the next
+#pragma unroll
+	for (int j = 0; j < kRegs; j++) {
+		const int i = tid + 256 * j;
+		const unsigned long long f = __ballot(i >= 1 && i < Lw - 1 && e0[j] > th);
+		if (lane == 0) {
+			s_flags[8 * j + 2 * wv] = (unsigned int)f;
+			s_flags[8 * j + 2 * wv + 1] = (unsigned int)(f >> 32);
 		}
-		s_flags[wd] = f;
 	}
 	__syncthreads();
 
@@ -932,8 +1160,8 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 		}
 	}
 	if (tid == 0) {
-		int *toa = a.toa + (size_t)s * a.N;
-		float pwr[32];
+		int *toa = s_toa;
+		float *pwr = s_pwr;
 		const int N = a.N;
 		int n = 0;
 		const int sps = a.sps;
@@ -942,44 +1170,55 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a)
 		for (unsigned long long left = nzm[c]; left; left &= left - 1ull) {
 			const int wd = 64 * c + __builtin_ctzll(left);
 			const unsigned int f = s_flags[wd];
-			bool prev = wd > 0 && (s_flags[wd - 1] >> 31) != 0u;
-			for (int b = 0; b < 32; b++) {
-				const bool cur = (f >> b) & 1u;
-				if (cur && !prev) {
-					const int i = wd * 32 + b;
-					const float p_pwr = v[i - 1] + v[i] + v[i + 1];
-					const float p_fpos = (-v[i - 1] + v[i + 1]) / p_pwr;
-					const int p_pos = (int)round((double)(((float)i + p_fpos) * (float)sps));
-					// _peak_record
-					int has_dupe = 0;
-					for (int q = 0; q < n; q++) {
-						const int dd = (toa[q] % Lp) - (p_pos % Lp);
-						if (abs(dd) > half)
-							continue;
-						if (pwr[q] > p_pwr) {
-							if (!has_dupe) has_dupe = 1;
-							continue;
-						}
-						for (int j = q; j < n - 1; j++) { toa[j] = toa[j + 1]; pwr[j] = pwr[j + 1]; }
-						n--;
-						has_dupe = -1;
+			const unsigned int before = wd > 0 ? (s_flags[wd - 1] >> 31) : 0u;
+			// rising edges of the word: a flag whose lower neighbour (the word before's last, for bit 0) is not one
+			for (unsigned int edges = f & ~((f << 1) | before); edges; edges &= edges - 1u) {
+				const int i = wd * 32 + __builtin_ctz(edges);
+				const float p_pwr = v[i - 1] + v[i] + v[i + 1];
+				const float p_fpos = (-v[i - 1] + v[i + 1]) / p_pwr;
+				const int p_pos = (int)round((double)(((float)i + p_fpos) * (float)sps));
+				const int p_mod = p_pos % Lp;
+				// _peak_record
+				int has_dupe = 0;
+				for (int q = 0; q < n; q++) {
+					const int dd = s_mod[q] - p_mod;
+					if (abs(dd) > half)
+						continue;
+					if (pwr[q] > p_pwr) {
+						if (!has_dupe) has_dupe = 1;
+						continue;
 					}
-					if (has_dupe <= 0) {
-						int q = 0;
-						for (; q < n; q++)
-							if (p_pwr > pwr[q]) break;
-						if (q != N) {
-							for (int j = N - 1; j > q; j--) { toa[j] = toa[j - 1]; pwr[j] = pwr[j - 1]; }
-							toa[q] = p_pos;
-							pwr[q] = p_pwr;
-							if (n != N) n++;
-						}
+					for (int j = q; j < n - 1; j++) { toa[j] = toa[j + 1]; pwr[j] = pwr[j + 1]; s_mod[j] = s_mod[j + 1]; }
+					n--;
+					has_dupe = -1;
+				}
+				if (has_dupe <= 0) {
+					int q = 0;
+					for (; q < n; q++)
+						if (p_pwr > pwr[q]) break;
+					if (q != N) {
+						for (int j = N - 1; j > q; j--) { toa[j] = toa[j - 1]; pwr[j] = pwr[j - 1]; s_mod[j] = s_mod[j - 1]; }
+						toa[q] = p_pos;
+						pwr[q] = p_pwr;
+						s_mod[q] = p_mod;
+						if (n != N) n++;
 					}
 				}
-				prev = cur;
 			}
 		}
 		a.count[s] = n;
+		s_scal[2] = n;
+	}
+	__syncthreads();
+	if (wv != 0)
+		return;
+	const int n_found = s_scal[2];
+	// entries the reference's list operations touched: [0, n) hold the peaks; the caller's array beyond stays as it was
+	if (lane < n_found)
+		a.toa[(size_t)s * a.N + lane] = s_toa[lane];
+	if (tl.step == 3 && lane < kAcqPeaks) {
+		// (every lane reads the carrier's status before lane 0 may write it: one wave, lockstep up to the store)
+		acq_step3(tl.g, s, lane, s_toa, n_found);
 	}
 }
 
@@ -999,16 +1238,20 @@ static void launch_corr(const FcchRoughArgs &a, hipStream_t st)
 bool fcch_one_pass() { return profile_env("GMR1_HIP_FCCH_TWO_PASS") == nullptr; }
 
 template <int NT>
-static hipError_t launch_sweep(const FcchRoughArgs &a, hipStream_t st)
+static hipError_t launch_sweep(const FcchRoughArgs &a, const AcqTail &tl, hipStream_t st)
 {
 	static_assert(SweepDims<NT>::lds <= 64 * 1024, "above the default dynamic LDS limit the launch would need hipFuncSetAttribute");
 	hipLaunchKernelGGL((k_fcch_sweep<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
 	const int tiles = (long long)a.n_lag_tiles * a.n >= 4096 ? 4 : 1;
-	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles);
+	// the stream's last work-group picks its best tile itself (a counter per stream: as many as there are counters)
+	const int pick = (a.toa && a.n <= kPickStreams) ? 1 : 0;
+	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles, pick, tl);
+	if (a.toa && !pick)
+		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a, tl);
 	return hipGetLastError();
 }
 
-hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t st)
+hipError_t launch_fcch_rough_tail(const FcchRoughArgs &a, int ntaps, const AcqTail &tl, hipStream_t st)
 {
 	if (a.n <= 0)
 		return hipSuccess;
@@ -1018,51 +1261,65 @@ hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t st)
 		// (the partials are per lag tile in this form: the host sized them so, capi_fcch.cpp)
 		if (a.n_stat_tiles != a.n_lag_tiles)
 			return hipErrorInvalidValue;
-		const hipError_t e = ntaps == 117 ? launch_sweep<117>(a, st) : launch_sweep<468>(a, st);
-		if (e != hipSuccess)
-			return e;
-	} else {
+		return ntaps == 117 ? launch_sweep<117>(a, tl, st) : launch_sweep<468>(a, tl, st);
+	}
 	hipLaunchKernelGGL(k_fcch_stats, dim3(a.n_stat_tiles, a.n), dim3(256), 0, st, a);
 	if (ntaps == 117)
 		launch_corr<117>(a, st);
 	else
 		launch_corr<468>(a, st);
-	}
 	if (a.toa)
-		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a);
+		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a, tl);
+	return hipGetLastError();
+}
+
+hipError_t launch_fcch_rough(const FcchRoughArgs &a, int ntaps, hipStream_t st)
+{
+	AcqTail none;
+	std::memset(&none, 0, sizeof(none));
+	return launch_fcch_rough_tail(a, ntaps, none, st);
+}
+
+hipError_t launch_fcch_multi_tail(const FcchMultiArgs &a, const AcqTail &tl, hipStream_t st)
+{
+	if (a.n <= 0)
+		return hipSuccess;
+	if (a.Lw > 8192 || a.N > 32 || (tl.step == 3 && a.N != kAcqPeaks))
+		return hipErrorInvalidValue;
+	hipLaunchKernelGGL(k_fcch_multi, dim3(a.n), dim3(256), (size_t)a.Lw * 4, st, a, tl);
 	return hipGetLastError();
 }
 
 hipError_t launch_fcch_multi(const FcchMultiArgs &a, hipStream_t st)
 {
-	if (a.n <= 0)
-		return hipSuccess;
-	if (a.Lw > 8192 || a.N > 32)
-		return hipErrorInvalidValue;
-	hipLaunchKernelGGL(k_fcch_multi, dim3(a.n), dim3(256), (size_t)a.Lw * 4, st, a);
-	return hipGetLastError();
+	AcqTail none;
+	std::memset(&none, 0, sizeof(none));
+	return launch_fcch_multi_tail(a, none, st);
 }
 
-hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t st)
+hipError_t launch_fcch_fine_tail(const FcchFineArgs &a, int nsym, const AcqTail &tl, hipStream_t st)
 {
 	if (a.n <= 0)
 		return hipSuccess;
 	if (nsym == 117)
-		hipLaunchKernelGGL((k_fcch_fine<117>), dim3(a.n), dim3(64 * kFineWaves), 0, st, a);
+		hipLaunchKernelGGL((k_fcch_fine<117>), dim3(a.n), dim3(64 * kFineWaves), 0, st, a, tl);
 	else if (nsym == 468)
-		hipLaunchKernelGGL((k_fcch_fine<468>), dim3(a.n), dim3(64 * kFineWaves), 0, st, a);
+		hipLaunchKernelGGL((k_fcch_fine<468>), dim3(a.n), dim3(64 * kFineWaves), 0, st, a, tl);
 	else
 		return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 
+hipError_t launch_fcch_fine(const FcchFineArgs &a, int nsym, hipStream_t st)
+{
+	AcqTail none;
+	std::memset(&none, 0, sizeof(none));
+	return launch_fcch_fine_tail(a, nsym, none, st);
+}
+
 // ---------------------------------------------------------------------------
-// k_acq_glue -- the arithmetic gmr1_rx's acquisition does between two sweeps (fcch_single_init gmr1_rx.c:605-639,
-// fcch_multi_process :643-702), on the device so that the sweeps follow each other without the host:
-//   step 1  after the 330 ms rough sweep : align += toa, bounds, window of the fine stage
-//   step 2  after the fine stage         : align += toa, freq_err, base_align, window + shift of the 650 ms sweep
-//   step 3  after rough_multi            : one window per candidate slot (bounds: a candidate outside drops the carrier)
-//   step 4  after fine over the slots    : refined window + shift of the SNR stage
+// k_acq_glue -- the steps above as a launch of their own between two sweeps (what the chain was before the sweeps'
+// last threads took them over; kept as the other side of the comparison: profiling build, GMR1_HIP_ACQ_UNFUSED)
 // ---------------------------------------------------------------------------
 __global__ void k_acq_glue(int step, AcqArgs a)
 {
@@ -1070,81 +1327,22 @@ __global__ void k_acq_glue(int step, AcqArgs a)
 	if (step == 1 || step == 2) {
 		if (t >= a.n)
 			return;
-		const int k = t;
-		const int64_t len = (int64_t)a.len[k];
-		int stat = a.stat[k];
-		if (step == 1) {
-			if (!stat) {
-				if (a.rv1[k]) {
-					stat = a.rv1[k];
-				} else {
-					a.align[k] += a.toa1[k];
-					if ((int64_t)a.align[k] + a.flen > len)
-						stat = -1;
-				}
-			}
-			a.stat[k] = stat;
-			a.off[k] = a.base[k] + (uint64_t)(stat ? 0 : a.align[k]);
-		} else {
-			float fs = 0.f;
-			if (!stat) {
-				a.align[k] += a.ftoa[k];
-				a.ferr[k] = a.fe[k];
-				int ba = a.align[k] - a.flen;
-				if (ba < 0) ba = 0;
-				a.base_align[k] = ba;
-				if (!a.can3[k] || (int64_t)ba + a.wl3 > len)
-					stat = -1;
-				fs = -a.fe[k];
-			}
-			a.stat[k] = stat;
-			a.off[k] = a.base[k] + (uint64_t)((stat || !a.can3[k]) ? 0 : a.base_align[k]);
-			a.fs[k] = fs;
-		}
+		if (step == 1)
+			acq_step1(a, t, a.toa1[t], a.rv1[t]);
+		else
+			acq_step2(a, t, a.ftoa[t], a.fe[t]);
 		return;
 	}
 	if (t >= a.n * kAcqPeaks)
 		return;
-	const int k = t / kAcqPeaks, j = t % kAcqPeaks;
-	const int64_t len = (int64_t)a.len[k];
 	if (step == 3) {
-		int stat = a.stat[k];
-		bool live = false;
-		int64_t p = 0;
-		if (!stat) {
-			const int cnt = a.count[k];
-			if (cnt < 0) {
-				stat = cnt;
-			} else {
-				// a carrier with any candidate outside its samples is dropped as a whole
-				bool ok = true;
-				for (int q = 0; q < cnt; q++) {
-					const int64_t pq = (int64_t)a.base_align[k] + a.peaks[(size_t)k * kAcqPeaks + q];
-					if (pq < 0 || pq + a.flen > len) ok = false;
-				}
-				if (!ok)
-					stat = -1;
-				else if (j < cnt) {
-					live = true;
-					p = (int64_t)a.base_align[k] + a.peaks[(size_t)k * kAcqPeaks + j];
-				}
-			}
-		}
-		a.live[t] = live ? 1 : 0;
-		a.off[t] = a.base[k] + (uint64_t)(live ? p : 0);
-		a.fs[t] = live ? -a.ferr[k] : 0.f;
-		if (j == 0 && stat)
-			a.stat[k] = stat;          // (every thread of the carrier computed the same verdict; the others only read)
+		// (one wave covers whole carriers: 64 = 4 x kAcqPeaks, so a carrier's status is read by all its slots before slot 0
+		// stores it)
+		const int k = t / kAcqPeaks;
+		acq_step3(a, k, t % kAcqPeaks, a.peaks + (size_t)k * kAcqPeaks, a.count[k]);
 		return;
 	}
-	// step 4
-	const bool live = a.live[t] != 0;
-	int64_t p = 0;
-	if (live)
-		p = (int64_t)a.base_align[k] + a.peaks[(size_t)k * kAcqPeaks + j] + a.ctoa[t];
-	const bool inside = live && p >= 0 && p + a.flen <= len;
-	a.off[t] = a.base[k] + (uint64_t)(inside ? p : 0);
-	a.fs[t] = inside ? -(a.ferr[k] + a.cfe[t]) : 0.f;
+	acq_step4(a, t, a.ctoa[t], a.cfe[t]);
 }
 
 hipError_t launch_acq_glue(int step, const AcqArgs &a, hipStream_t st)
