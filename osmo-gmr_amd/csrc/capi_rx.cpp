@@ -426,6 +426,9 @@ int RxRun::acquire()
 			chains.push_back(std::move(c));
 		}
 	}
+	if (timing)
+		fprintf(stderr, "acquire: decisions %.1f us\n",
+		        (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tp[4]).count() / 1e3);
 	return 0;
 }
 
@@ -521,9 +524,17 @@ int RxRun::frame_loop()
 			la.n_packed = la.n_frames + nc;
 		}
 	}
+	static const bool timing = profile_env("GMR1_HIP_RX_TIMING") != nullptr;
+	const auto t_a = std::chrono::steady_clock::now();
 	HIP_TRY(hipMemcpyAsync(la.state, st0.data(), (size_t)nc * sizeof(RxLoopState), hipMemcpyHostToDevice, st));
+	const auto t_b = std::chrono::steady_clock::now();
 	r = rx_loop_dev_impl(st, nc, sps, iq, la);
 	if (r) return r;
+	if (timing) {
+		auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() / 1e3; };
+		fprintf(stderr, "frame loop: prepare %.1f us, states copy enqueued %.1f us, launches %.1f us\n", us(t_start, t_a), us(t_a, t_b),
+		        us(t_b, std::chrono::steady_clock::now()));
+	}
 	if (pack) {
 		// counters and states first (a few KB), then exactly the records there are
 		HIP_TRY(hipMemcpyAsync(h + o_cnt, d + o_cnt, cnt_bytes + st_bytes, hipMemcpyDeviceToHost, st));

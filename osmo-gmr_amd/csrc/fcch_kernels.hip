@@ -1243,8 +1243,11 @@ static hipError_t launch_sweep(const FcchRoughArgs &a, const AcqTail &tl, hipStr
 	static_assert(SweepDims<NT>::lds <= 64 * 1024, "above the default dynamic LDS limit the launch would need hipFuncSetAttribute");
 	hipLaunchKernelGGL((k_fcch_sweep<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
 	const int tiles = (long long)a.n_lag_tiles * a.n >= 4096 ? 4 : 1;
-	// the stream's last work-group picks its best tile itself (a counter per stream: as many as there are counters)
-	const int pick = (a.toa && a.n <= kPickStreams) ? 1 : 0;
+	// Small launches (the receive loop's acquisition: their latency is what counts): the stream's last work-group picks its
+	// best tile itself, one launch fewer.  Not for the large ones: the device-scope fence in front of the count writes the
+	// XCD's whole L2 back, which with thousands of work-groups in flight quadruples the kernel (0.041 -> 0.162 ms at
+	// 1024 streams of 93 600 samples, measured).
+	const int pick = (a.toa && tiles == 1 && a.n <= kPickStreams) ? 1 : 0;
 	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles, pick, tl);
 	if (a.toa && !pick)
 		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a, tl);
