@@ -20,7 +20,10 @@
 //
 // Both are HBM-streaming: 8 B in + 16 B out per wideband sample (all 64 channels kept), then
 // 8 B in + 12 B out per channel sample.
+#include <cstdint>
+#include <cstdlib>
 #include "gmr1_dev.h"
+#include "profile_env.h"
 
 namespace gmr1 {
 
@@ -286,6 +289,7 @@ hipError_t launch_pfb(const PfbArgs &a, hipStream_t stream)
 // resamples DOWN (rate 0.468) and its root-raised cosine is 95 taps per phase long -- a second instantiation
 static constexpr int kRsTapsShort = 30, kRsTapsLong = 96;
 static constexpr int kRsPeriods = 32;        // periods one wave walks
+static constexpr int kRsRing = 8;            // k_resamp2: ring slots of one period's window each (seven periods in flight)
 static constexpr int kRsWinTight = 128, kRsWinShort = 256, kRsWinLong = 512;     // LDS window (samples) per wave, >= span
 
 // acc += e (s.re, s.im) for the real tap e that sits in the LOW (HI = false) or HIGH half of the register pair `ee`: one
@@ -294,6 +298,7 @@ static constexpr int kRsWinTight = 128, kRsWinShort = 256, kRsWinLong = 512;    
 // registers of taps instead of 30 and five waves per SIMD instead of eight, with two LDS reads in flight per wave.
 // (s_nop: a packed result needs one wait state before its next use.)
 typedef float rs_v2f __attribute__((ext_vector_type(2)));
+typedef float rs_v4f __attribute__((ext_vector_type(4)));
 template <bool HI>
 __device__ __forceinline__ void rs_mac(rs_v2f &acc, rs_v2f ee, rs_v2f s)
 {
@@ -301,6 +306,19 @@ __device__ __forceinline__ void rs_mac(rs_v2f &acc, rs_v2f ee, rs_v2f s)
 		asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\ts_nop 0" : "+v"(acc) : "v"(ee), "v"(s));
 	else
 		asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\ts_nop 0" : "+v"(acc) : "v"(ee), "v"(s));
+}
+
+// the same for TWO accumulators (k_resamp2's two outputs, each with its own taps and its own view of the sample): the second
+// multiply-add is the wait state of the first and the other way round, in whatever order the statements end up
+template <bool HI>
+__device__ __forceinline__ void rs_mac2(rs_v2f &acc0, rs_v2f &acc1, rs_v2f e0, rs_v2f e1, rs_v2f s0, rs_v2f s1)
+{
+	if constexpr (HI)
+		asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\tv_pk_fma_f32 %1, %3, %5, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+		    : "+v"(acc0), "+v"(acc1) : "v"(e0), "v"(e1), "v"(s0), "v"(s1));
+	else
+		asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\tv_pk_fma_f32 %1, %3, %5, %1 op_sel:[0,0,0] op_sel_hi:[0,1,1]"
+		    : "+v"(acc0), "+v"(acc1) : "v"(e0), "v"(e1), "v"(s0), "v"(s1));
 }
 
 // EXT: the instantiation that can rotate its input (the pre-resampler of an off-grid capture) and write polyphase-planar
@@ -433,6 +451,207 @@ void k_resamp(ResampArgs a, long long P, long long Q, int span)
 }
 
 // ---------------------------------------------------------------------------
+// k_resamp2 -- the same resampler with TWO consecutive outputs per lane, for the plans that raise the rate.
+//
+// What bounds k_resamp is LDS delivery: 30 eight-byte reads per output, 240 bytes, 4 cycles per wave-wide read (0.42 ms of
+// its 0.51 ms on the bench's capture; SQ_LDS_IDX_ACTIVE says the same).  Where the rate goes up, consecutive outputs use
+// input windows that start at the same sample or one apart, so a lane that owns outputs p and p + 1 needs 31 samples for
+// the two.  It fetches them as SIXTEEN ALIGNED PAIRS (ds_read_b128: the 32 samples from the odd index T >= its newest one
+// down): half the read instructions per output, and conflict-free -- the eight lanes of a pass ask for five or six
+// consecutive 16-byte pairs, where 8-byte reads at this lane stride (4/3 of a sample) collide two ways (tried first:
+// SQ_LDS_BANK_CONFLICT 3 500 per wave, no gain).  The price is registers, two sets of taps, and that the windows'
+// offsets against T differ from lane to lane: an output's taps are therefore stored SHIFTED by its offset sh = T - (its
+// newest sample) in 0 .. 2 (E[i] = e[i - sh], zero outside; 30 + 2 = 32 entries = the 16 pairs), so that the multiply-adds
+// run over the shared sample index with static register numbers.  Per output the sum still runs over its own taps
+// k = 0 .. 29 in that order; at the four positions that can lie outside an output's taps (0, 1, 30, 31) the SAMPLE is
+// replaced by zero where it does (a per-lane select), so that neither a non-finite sample outside an output's thirty taps
+// nor the two unwritten slots at either end of the window reach it.  Results are bit for bit k_resamp's.
+// ---------------------------------------------------------------------------
+//
+// ... and that alone gained nothing (0.55 ms against 0.51): with the LDS reads halved the counters show neither pipe busy
+// (VALU 43 %, LDS 43 %) -- the kernel moves 1.6 GB at 3 TB/s because that is what the bytes it keeps IN FLIGHT allow (two
+// periods' windows per wave in registers: ~30 KB per CU against ~2.5 us of memory latency; the one-output form sits at the
+// same product with six waves).  So the windows come in by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = the
+// 128-sample window of one period in ONE instruction, no registers) into a ring of kRing slots, kRing - 1 periods ahead.
+//   * One counter covers loads and stores on this ISA and they complete out of order with respect to each other, but loads
+//     complete in order among themselves: with exactly kRing - 1 younger window loads behind the one about to be used,
+//     `s_waitcnt vmcnt(kRing - 1)` cannot be satisfied while that one is outstanding (it and all younger ones would make
+//     kRing) -- stores still in flight only make the wait longer, never too short.  Hence EXACTLY one DMA per iteration:
+//     windows that cross the stream's ends are fetched from clamped addresses and their outside samples zeroed in LDS
+//     afterwards; periods past the end fetch the last window again.
+//   * The compiler does not know what an LDS-DMA writes and answers any LDS read of its own with vmcnt(0), which would
+//     drain the ring every period: the window is read with inline ds_read_b128 and counted lgkmcnt waits (LDS operations of
+//     a wave complete in order), four pairs per batch, the next batch in flight while one is used.
+template <int kRsWin, int kRing>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+void k_resamp2(ResampArgs a, long long P, long long Q, int span)
+{
+	// (the body exists in the device pass only: the host pass drops the whole stub, silently, over the LDS-DMA builtin)
+#if defined(__HIP_DEVICE_COMPILE__)
+	constexpr int R = 2;
+	constexpr int kTaps = kRsTapsShort;
+	constexpr int L = kTaps + R;              // sample positions a lane walks (its pairs cover T - 31 .. T)
+	constexpr int LP = L / 2;
+	constexpr int kPad = 2;                   // window sample w sits in slot position w + 2: T - 31 >= -2
+	constexpr int kSlot = (kRsWin + kPad) / 2;          // 16-byte pairs per ring slot
+	static_assert(kRsWin == 128, "one global_load_lds_dwordx4 per window: 64 lanes x two samples");
+	static_assert(LP % 4 == 0, "batches of four pairs");
+	__shared__ float4 ring4[kRing][kSlot];
+	const int lane = threadIdx.x;
+	const int sl = blockIdx.y;
+	const long long p0 = (long long)blockIdx.x * 64 * R;
+	// phases of this lane's outputs: exact integer arithmetic, once (an output past the period's last takes the last one's
+	// phase: it is not stored, and its window stays inside the wave's)
+	long long ip[R];
+	int jf[R];
+	float frac[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const long long p = p0 + (long long)R * lane + r;
+		const long long Np = (long long)a.j0 * a.den + (p < P ? p : P - 1) * a.num;
+		const long long fl = Np / a.den;
+		frac[r] = (float)(Np - fl * a.den) / (float)a.den;
+		jf[r] = (int)(fl % a.nfilt);
+		ip[r] = fl / a.nfilt;
+	}
+	const long long N0 = (long long)a.j0 * a.den + p0 * a.num;
+	const long long i_first = (N0 / a.den) / a.nfilt - (kTaps - 1);     // first input the wave needs (period 0)
+	const int top = (int)(ip[R - 1] - i_first) + kPad;                  // slot position of the lane's newest sample
+	const int T = top | 1;                                              // the odd position at or above it: pairs are (T - 1, T), ...
+	int sh[R];
+	rs_v2f E[R][LP];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		sh[r] = T - ((int)(ip[r] - i_first) + kPad);                    // 0 .. 2: the rate goes up (the launcher checks)
+#pragma unroll
+		for (int i = 0; i < L; i += 2) {
+			float e[2];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				// (every lane loads, from a clamped index: the 64 loads are in flight together)
+				const int k = i + h - sh[r];
+				const bool in = k >= 0 && k < kTaps;
+				const float2 b = a.bank[jf[r] * kTaps + (k < 0 ? 0 : (k >= kTaps ? kTaps - 1 : k))];
+				e[h] = fmaf(frac[r], b.y, b.x) * (in ? 1.0f : 0.0f);      // (a product, not a select: the load stays unconditional)
+			}
+			E[r][i / 2] = (rs_v2f){e[0], e[1]};
+		}
+	}
+	// (the taps have arrived before the first window is asked for: no ordinary load is pending inside the loop, where the
+	// compiler would wait for it with vmcnt(0))
+#pragma unroll
+	for (int r = 0; r < R; r++)
+#pragma unroll
+		for (int q = 0; q < LP; q++)
+			asm volatile("" : "+v"(E[r][q]));
+	const float2 *__restrict__ y = a.y + (long long)sl * a.T;
+	float2 *__restrict__ out = a.out + (long long)sl * a.out_stride;
+	const long long m0 = (long long)blockIdx.z * kRsPeriods;
+	const long long periods = (a.n_out + P - 1) / P;                    // periods that have an output at all
+
+	// window of period m: inputs i_first + m Q + [0, 128), lane l brings samples 2 l and 2 l + 1
+	auto issue = [&](long long m, int slot) {
+		if (m >= periods)
+			m = periods - 1;
+		long long s0 = i_first + m * Q + 2 * lane;
+		s0 = s0 < 0 ? 0 : (s0 > a.T - 2 ? a.T - 2 : s0);                // (a stream has at least two samples: the launcher checks)
+		__builtin_amdgcn_global_load_lds(y + s0, &ring4[slot][kPad / 2], 16, 0, 0);
+	};
+	const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void *)&ring4[0][0]);
+	const unsigned rd0 = lds0 + (unsigned)(T >> 1) * 16u;               // pair q of slot s: rd0 + s * kSlot * 16 - q * 16
+
+#pragma unroll
+	for (int d = 0; d < kRing - 1; d++)
+		issue(m0 + d, d);
+	int slot = 0;
+	for (int mm = 0; mm < kRsPeriods; mm++) {
+		const long long m = m0 + mm;
+		if (m * P >= a.n_out)
+			break;
+		issue(m + kRing - 1, slot == 0 ? kRing - 1 : slot - 1);
+		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRing - 1) : "memory");
+		{
+			// a window that crosses the stream's ends: its outside samples are zeros (k_resamp's fetch), whatever the clamped
+			// addresses brought
+			const long long w0 = i_first + m * Q;
+			if (w0 < 0 || w0 + kRsWin > a.T) {
+				float2 *xs = reinterpret_cast<float2 *>(&ring4[slot][kPad / 2]);
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const long long sidx = w0 + 2 * lane + h;
+					float2 v = make_float2(0.f, 0.f);
+					if (sidx >= 0 && sidx < a.T)
+						v = y[sidx];
+					xs[2 * lane + h] = v;
+				}
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			}
+		}
+		const unsigned rd = rd0 + (unsigned)slot * (unsigned)(kSlot * 16);
+		rs_v2f acc[R];
+#pragma unroll
+		for (int r = 0; r < R; r++)
+			acc[r] = (rs_v2f){0.f, 0.f};
+		rs_v4f pr[2][4];
+		const unsigned rdb = rd - 16u * (unsigned)(LP - 1);            // lowest pair of the lane; pair q at offset 16 (LP - 1 - q)
+#define GMR1_RS_READ(dst, q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(rdb), "n"(16 * (LP - 1 - (q))))
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			GMR1_RS_READ(pr[0][q], q);
+#pragma unroll
+		for (int b = 0; b < LP / 4; b++) {
+			if (b + 1 < LP / 4) {
+#pragma unroll
+				for (int q = 0; q < 4; q++)
+					GMR1_RS_READ(pr[(b + 1) & 1][q], 4 * (b + 1) + q);
+				asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pr[b & 1][0]), "+v"(pr[b & 1][1]), "+v"(pr[b & 1][2]), "+v"(pr[b & 1][3]));
+			} else {
+				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[b & 1][0]), "+v"(pr[b & 1][1]), "+v"(pr[b & 1][2]), "+v"(pr[b & 1][3]));
+			}
+#pragma unroll
+			for (int qq = 0; qq < 4; qq++) {
+				const int q = 4 * b + qq;
+				const rs_v4f pq = pr[b & 1][qq];
+				// position i = 2 q is slot position T - 2 q (the pair's upper sample), i = 2 q + 1 the lower
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const int i = 2 * q + h;
+					rs_v2f sv[R];
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						sv[r] = h ? (rs_v2f){pq.x, pq.y} : (rs_v2f){pq.z, pq.w};
+						if (i < R || i >= kTaps) {
+							// a position outside this output's taps in some lanes (or one of the slot's unwritten ends)
+							const bool outside = i < sh[r] || i > sh[r] + kTaps - 1;
+							sv[r] = outside ? (rs_v2f){0.f, 0.f} : sv[r];
+						}
+					}
+					if (h)
+						rs_mac2<true>(acc[0], acc[1], E[0][q], E[1][q], sv[0], sv[1]);
+					else
+						rs_mac2<false>(acc[0], acc[1], E[0][q], E[1][q], sv[0], sv[1]);
+				}
+			}
+		}
+#undef GMR1_RS_READ
+		const long long pl = p0 + (long long)R * lane;
+		const long long n = m * P + pl;
+		if (pl + 1 < P && n + 1 < a.n_out && ((reinterpret_cast<uintptr_t>(out + n) & 15) == 0)) {
+			*reinterpret_cast<float4 *>(out + n) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+		} else {
+#pragma unroll
+			for (int r = 0; r < R; r++)
+				if (pl + r < P && n + r < a.n_out)
+					out[n + r] = make_float2(acc[r].x, acc[r].y);
+		}
+		slot = slot + 1 == kRing ? 0 : slot + 1;
+	}
+	// nothing of this wave is left in flight towards its LDS when it ends
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// ---------------------------------------------------------------------------
 // k_ddc_fir -- decimating FIR of the direct mode: y[s][m] = rot_s(m) * sum_k taps[s][k] x_s[m D - k].
 // One work-group = 256 consecutive outputs of one carrier: the 256 D + ntaps input samples they span are staged in
 // LDS with coalesced loads (the windows of neighbouring outputs overlap by ntaps - D samples), the carrier's taps too;
@@ -516,6 +735,11 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 	const long long periods = (a.n_out + P - 1) / P;
 	const unsigned gx = (unsigned)((P + 63) / 64), gz = (unsigned)((periods + kRsPeriods - 1) / kRsPeriods);
 	const bool ext = a.rotation != 0.0f || a.planar_sps > 0;
+	// two consecutive outputs per lane where the rate goes up (their windows then start at most one sample apart) and the
+	// 128 phases of a wave still fit the tight window (profiling build: GMR1_HIP_RESAMP_R=1 keeps one output per lane)
+	static const bool one_only = []{ const char *e = profile_env("GMR1_HIP_RESAMP_R"); return e && atoi(e) == 1; }();
+	const int span_r = (int)((127 * a.num) / (a.den * a.nfilt)) + taps + 2;
+	const int multi_r = (!lng && !ext && !one_only && a.num < a.den * a.nfilt && span_r <= kRsWinTight && P >= 2 && a.T >= 2) ? 2 : 1;
 	if (lng && ext)
 		return hipErrorInvalidValue;             // (the long bank is the direct mode's: neither option reaches it)
 	if (lng)
@@ -524,6 +748,8 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinTight, true>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	else if (ext)
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinShort, true>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
+	else if (multi_r > 1)
+		hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing>), dim3((unsigned)((P + 127) / 128), (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span_r);
 	else if (span <= kRsWinTight)
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinTight>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	else
