@@ -37,10 +37,11 @@ static constexpr float kPif = 3.14159265358979323846f;
 static constexpr int kPfbSteps = 64;        // output instants per wavefront (32 new blocks)
 static constexpr int kPfbTile = 16;         // instants per LDS transpose tile
 
+// (every lane of these permutations has a source lane: no "old" value is needed, and none is set up)
 template <int CTRL>
 __device__ __forceinline__ float dppf(float v)
 {
-	return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+	return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
 // value of lane (l ^ X)
@@ -71,6 +72,70 @@ __device__ __forceinline__ void dif_stage(float &re, float &im, float sg, float 
 	im = dr * wi + di * wr;
 }
 
+// ---- packed single precision (v_pk_*_f32: two multiply-adds per lane and instruction, the rate the vector peak is quoted
+// at).  The filterbank's arithmetic is complex-by-real and complex-by-complex throughout, so every step is a pair: with
+// scalar instructions the kernel issued 6 455 vector instructions per wave at 88 % VALU busy.  The operand selects pick the
+// half of a register pair a lane-wide "scalar" (a tap, a sign, a twiddle component) sits in, so none of them is duplicated.
+// A packed result needs one wait state before its next use: the helpers take the even and the odd instant together, each
+// one's instruction is the other's wait state.
+typedef float pf_v2f __attribute__((ext_vector_type(2)));
+
+// ae += taps.lo * w ; ao += taps.hi * w          (taps = (even instant's tap, odd instant's tap))
+__device__ __forceinline__ void pf_fir(pf_v2f &ae, pf_v2f &ao, pf_v2f taps, pf_v2f w)
+{
+	asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+	    "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+	    : "+v"(ae), "+v"(ao) : "v"(taps), "v"(w));
+}
+
+// the stage's butterfly and twiddle for both instants: d = partner + sg * own ; out = d * (wr + j wi)
+//   sgp: the pair holding this stage's sign in half SH ; w: (wr, wi)
+//   out.re = d.re wr - d.im wi, out.im = d.im wr + d.re wi, as  t = d * wr ; out = (-d.im, d.re) * wi + t
+template <int SH>
+__device__ __forceinline__ void pf_stage(pf_v2f &xe, pf_v2f &xo, pf_v2f pe, pf_v2f po, pf_v2f sgp, pf_v2f w)
+{
+	pf_v2f de, dq, te, to;
+	if constexpr (SH == 0)
+		asm("v_pk_fma_f32 %0, %2, %4, %5 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+		    "v_pk_fma_f32 %1, %3, %4, %6 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+		    : "=&v"(de), "=&v"(dq) : "v"(xe), "v"(xo), "v"(sgp), "v"(pe), "v"(po));
+	else
+		asm("v_pk_fma_f32 %0, %2, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+		    "v_pk_fma_f32 %1, %3, %4, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+		    : "=&v"(de), "=&v"(dq) : "v"(xe), "v"(xo), "v"(sgp), "v"(pe), "v"(po));
+	asm("v_pk_mul_f32 %0, %2, %4 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+	    "v_pk_mul_f32 %1, %3, %4 op_sel:[0,0] op_sel_hi:[1,0]"
+	    : "=&v"(te), "=&v"(to) : "v"(de), "v"(dq), "v"(w));
+	asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]\n\t"
+	    "v_pk_fma_f32 %1, %3, %4, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+	    : "+v"(te), "+v"(to) : "v"(de), "v"(dq), "v"(w));
+	xe = te;
+	xo = to;
+}
+
+// ... and the last stage (pairs of neighbouring lanes): its twiddle is 1 in every lane
+template <int SH>
+__device__ __forceinline__ void pf_stage_last(pf_v2f &xe, pf_v2f &xo, pf_v2f pe, pf_v2f po, pf_v2f sgp)
+{
+	pf_v2f de, dq;
+	if constexpr (SH == 0)
+		asm("v_pk_fma_f32 %0, %2, %4, %5 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+		    "v_pk_fma_f32 %1, %3, %4, %6 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+		    : "=&v"(de), "=&v"(dq) : "v"(xe), "v"(xo), "v"(sgp), "v"(pe), "v"(po));
+	else
+		asm("v_pk_fma_f32 %0, %2, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+		    "v_pk_fma_f32 %1, %3, %4, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+		    : "=&v"(de), "=&v"(dq) : "v"(xe), "v"(xo), "v"(sgp), "v"(pe), "v"(po));
+	xe = de;
+	xo = dq;
+}
+
+template <int SPAN>
+__device__ __forceinline__ pf_v2f pf_partner(pf_v2f v)
+{
+	return (pf_v2f){lane_xor<SPAN>(v.x), lane_xor<SPAN>(v.y)};
+}
+
 template <bool ROT>
 __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 {
@@ -82,31 +147,32 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 	const int NB = a.n_blocks;
 
 	// taps of this branch: even instants h[64 q - r], odd instants h[64 q + 32 - r]
-	float he[kPfbMaxBlocks], ho[kPfbMaxBlocks];
+	pf_v2f heo[kPfbMaxBlocks];                   // (even instant's tap, odd instant's tap) of block q
 #pragma unroll
 	for (int q = 0; q < kPfbMaxBlocks; q++) {
 		const int ie = 64 * q - r, io = 64 * q + 32 - r;
-		he[q] = (q < NB && ie >= 0 && ie < a.ntaps) ? a.taps[ie] : 0.0f;
-		ho[q] = (q < NB && io >= 0 && io < a.ntaps) ? a.taps[io] : 0.0f;
+		heo[q] = (pf_v2f){(q < NB && ie >= 0 && ie < a.ntaps) ? a.taps[ie] : 0.0f,
+		                  (q < NB && io >= 0 && io < a.ntaps) ? a.taps[io] : 0.0f};
 	}
 	// twiddles of the six stages and the channel this lane ends up holding
-	float wr[6], wi[6], hb[6];                   // (hb: -1 in the lanes that hold the second element of the stage's pairs, else +1)
+	pf_v2f tw[6];                                // (wr, wi)
+	float hb[6];                                 // (hb: -1 in the lanes that hold the second element of the stage's pairs, else +1)
 #pragma unroll
 	for (int s = 0; s < 6; s++) {
 		const int span = 32 >> s;
 		const float ang = -kPif * (float)(r & (span - 1)) / (float)span;
 		const bool hi = (r & span) != 0;
-		wr[s] = hi ? __cosf(ang) : 1.0f;
-		wi[s] = hi ? __sinf(ang) : 0.0f;
+		tw[s] = (pf_v2f){hi ? __cosf(ang) : 1.0f, hi ? __sinf(ang) : 0.0f};
 		hb[s] = hi ? -1.0f : 1.0f;
 	}
+	const pf_v2f sg01 = {hb[0], hb[1]}, sg23 = {hb[2], hb[3]}, sg45 = {hb[4], hb[5]};
 	const int chan = (int)(__brev((unsigned)r) >> 26);
 	const int slot = a.slot[chan];
 
 	// window of the lane's samples: w[q] = x[64 (b - q) + r] for the current block b
-	float2 w[kPfbMaxBlocks];
+	pf_v2f w[kPfbMaxBlocks];
 	const long long b0 = t0 / 2;                                   // block of the first instant
-	auto load_block = [&](long long b) -> float2 {
+	auto load_block = [&](long long b) -> pf_v2f {
 		const long long s = 64 * b + r;
 		float2 v = make_float2(0.f, 0.f);
 		if (b >= 0 && s < a.n_in) {
@@ -120,46 +186,47 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 				v = make_float2(v.x * cs - v.y * sn, v.x * sn + v.y * cs);
 			}
 		}
-		return v;
+		return (pf_v2f){v.x, v.y};
 	};
 #pragma unroll
 	for (int q = 1; q < kPfbMaxBlocks; q++)
 		w[q] = load_block(b0 - q);
 
-	float2 nxt = load_block(b0);
+	// (two blocks on their way: at half the instruction count a block's arithmetic no longer covers a trip to memory)
+	pf_v2f nxt = load_block(b0), nxt2 = load_block(b0 + 1);
+	constexpr int kBlk = kPfbTile / 2;           // new blocks per tile
 	for (int tt = 0; tt < kPfbSteps; tt += kPfbTile) {
-#pragma unroll 1
-		for (int u = 0; u < kPfbTile; u += 2) {
+		// The tile's eight blocks unrolled over ONE register array W: the window of block k is W[kBlk - 1 - k + q], the new
+		// block goes to W[kBlk - 1 - k] -- static indices, nothing is shifted per block; the window moves back up once per tile.
+		pf_v2f W[kBlk + kPfbMaxBlocks - 1];
+#pragma unroll
+		for (int q = 1; q < kPfbMaxBlocks; q++)
+			W[kBlk - 1 + q] = w[q];
+#pragma unroll
+		for (int k = 0; k < kBlk; k++) {
+			const int u = 2 * k;
 			const long long t = t0 + tt + u;
-			// new block: it serves instants t (even) and t + 1; the one after it is already on its way
-			w[0] = nxt;
-			nxt = load_block(t / 2 + 1);
-			float er = 0.f, ei = 0.f, orr = 0.f, oi = 0.f;
+			// new block: it serves instants t (even) and t + 1
+			W[kBlk - 1 - k] = nxt;
+			nxt = nxt2;
+			nxt2 = load_block(t / 2 + 2);
+			pf_v2f xe = {0.f, 0.f}, xo = {0.f, 0.f};
 #pragma unroll
-			for (int q = 0; q < kPfbMaxBlocks; q++) {
-				er = fmaf(he[q], w[q].x, er);
-				ei = fmaf(he[q], w[q].y, ei);
-				orr = fmaf(ho[q], w[q].x, orr);
-				oi = fmaf(ho[q], w[q].y, oi);
-			}
-#pragma unroll
-			for (int q = kPfbMaxBlocks - 1; q > 0; q--)
-				w[q] = w[q - 1];
-			dif_stage<32>(er, ei, hb[0], wr[0], wi[0]);
-			dif_stage<32>(orr, oi, hb[0], wr[0], wi[0]);
-			dif_stage<16>(er, ei, hb[1], wr[1], wi[1]);
-			dif_stage<16>(orr, oi, hb[1], wr[1], wi[1]);
-			dif_stage<8>(er, ei, hb[2], wr[2], wi[2]);
-			dif_stage<8>(orr, oi, hb[2], wr[2], wi[2]);
-			dif_stage<4>(er, ei, hb[3], wr[3], wi[3]);
-			dif_stage<4>(orr, oi, hb[3], wr[3], wi[3]);
-			dif_stage<2>(er, ei, hb[4], wr[4], wi[4]);
-			dif_stage<2>(orr, oi, hb[4], wr[4], wi[4]);
-			dif_stage<1>(er, ei, hb[5], wr[5], wi[5]);
-			dif_stage<1>(orr, oi, hb[5], wr[5], wi[5]);
-			tile[chan * (kPfbTile + 1) + u] = make_float2(er, ei);
-			tile[chan * (kPfbTile + 1) + u + 1] = make_float2(orr, oi);
+			for (int q = 0; q < kPfbMaxBlocks; q++)
+				pf_fir(xe, xo, heo[q], W[kBlk - 1 - k + q]);
+			pf_stage<0>(xe, xo, pf_partner<32>(xe), pf_partner<32>(xo), sg01, tw[0]);
+			pf_stage<1>(xe, xo, pf_partner<16>(xe), pf_partner<16>(xo), sg01, tw[1]);
+			pf_stage<0>(xe, xo, pf_partner<8>(xe), pf_partner<8>(xo), sg23, tw[2]);
+			pf_stage<1>(xe, xo, pf_partner<4>(xe), pf_partner<4>(xo), sg23, tw[3]);
+			pf_stage<0>(xe, xo, pf_partner<2>(xe), pf_partner<2>(xo), sg45, tw[4]);
+			pf_stage_last<1>(xe, xo, pf_partner<1>(xe), pf_partner<1>(xo), sg45);
+			tile[chan * (kPfbTile + 1) + u] = make_float2(xe.x, xe.y);
+			tile[chan * (kPfbTile + 1) + u + 1] = make_float2(xo.x, xo.y);
 		}
+		// (the next tile's "previous blocks": what the last block's window held, one further back)
+#pragma unroll
+		for (int q = 1; q < kPfbMaxBlocks; q++)
+			w[q] = W[q - 1];
 		WSYNC();
 		// write-out: 16 instants x 8 bytes = one 128-byte run per kept channel
 		for (int e = r; e < 64 * kPfbTile; e += 64) {
