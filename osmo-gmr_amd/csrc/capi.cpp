@@ -190,7 +190,7 @@ extern "C" {
 const char *gmr1_hip_version(void)
 {
 	// names the Viterbi decoder in force at the time of the call (gmr1_hip_set_conv_decoder)
-	return conv_acc() ? "gmr1-hip 0.3 (gfx950; conv decoder: acc)" : "gmr1-hip 0.3 (gfx950; conv decoder: generic)";
+	return conv_acc() ? "gmr1-hip 0.4 (gfx950; conv decoder: acc)" : "gmr1-hip 0.4 (gfx950; conv decoder: generic)";
 }
 const char *gmr1_hip_last_error(void) { return last_error(); }
 
