@@ -54,5 +54,5 @@ d=json.loads([l for l in open('$o/$f.json').read().splitlines() if l.startswith(
 r=d.get('roofline') or {}
 print(d['value'], d['unit'], 'ms/step', d['ms_per_step'], 'roofline', r.get('frac'), r.get('kernel_ms'), 'traffic', r.get('traffic'))
 if 'roofline_planar' in d: print('  planar', d['roofline_planar']['kernel_ms'], d['roofline_planar']['frac'], d['roofline_planar']['traffic'], d['roofline_planar']['outputs_bit_identical_to_interleaved']); print('  other', d['other_decoder'])
-if 'roofline_valu' in d: print('  valu', d['roofline_valu']['achieved'], d['roofline_valu']['frac'])
+if 'roofline_valu' in d: print('  valu', {k: v for k, v in d['roofline_valu'].items() if k in ('achieved', 'frac', 'valu_busy', 'hbm_frac_if_valu_were_100pct_busy')})
 "; done
