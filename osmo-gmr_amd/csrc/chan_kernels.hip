@@ -13,12 +13,18 @@
 //                six radix-2 stages across the LANES of the wave (DPP for spans 1..8, bpermute for
 //                16 and 32); results leave bit-reversed, are transposed through a wave-private LDS tile
 //                and written as 128-byte runs per channel.  Only the channels asked for are stored.
+//                All of its arithmetic is packed single precision (pf_fir, pf_stage).
 //   k_pfb_any  : the same filterbank for any even channel count (direct DFT of the selected channels).
 //   k_resamp   : out[n] = sum_k (b_j[k] + frac d_j[k]) y[i - k],  phase = j0 + n num/den in 1/32 input
 //                samples kept in integers (j = phase mod 32, i = phase / 32, frac = remainder / den).
-//                One output per lane; taps (b, d) pairs and the input span of the block sit in LDS.
+//                A lane owns one output phase of the plan's period: its effective taps in registers, its
+//                samples from a wave-private LDS window.
+//   k_resamp2  : the same sums with two consecutive outputs per lane sharing their window (aligned
+//                16-byte LDS reads) and the windows brought in by LDS-DMA into a ring, seven periods
+//                ahead; every plan that raises the rate.
+//   k_ddc_fir  : decimating FIR of the direct mode.
 //
-// Both are HBM-streaming: 8 B in + 16 B out per wideband sample (all 64 channels kept), then
+// HBM-streaming by construction: 8 B in + 16 B out per wideband sample (all 64 channels kept), then
 // 8 B in + 12 B out per channel sample.
 #include <cstdint>
 #include <cstdlib>

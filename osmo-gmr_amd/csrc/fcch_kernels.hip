@@ -1,21 +1,23 @@
 // fcch_kernels.hip -- FCCH acquisition kernels for gfx950 (MI355X).
 //
-//   k_fcch_stats  : one pass over the raw search window: complex sum and sum |x|^2 partials
-//                   per tile, and the sps-decimated samples written compactly
-//                   (osmo_cxvec_sig_normalize with decimation, reference src/sdr/fcch.c:230,366)
-//   k_fcch_corr   : normalise + frequency-shift on the way into LDS, 117-tap real dual-chirp
-//                   correlation with 8 lags per lane register blocking (sliding window in
-//                   registers, chirp taps from the scalar cache), energies, best 5-sample
-//                   energy window of the tile (fcch.c:233-238, osmo_cxvec_peak_energy_find)
+//   k_fcch_sweep  : the rough sweep in ONE pass over the raw search window: per lag tile, statistics partials of its own
+//                   span, every sps-th sample to LDS, the 117 / 468-tap real dual-chirp correlation of the RAW samples
+//                   as a banded-Toeplitz product on the matrix cores (v_mfma_f32_16x16x4_f32), written out per lag
+//                   (osmo_cxvec_sig_normalize is linear: the normalisation is applied afterwards; fcch.c:230-238)
+//   k_fcch_energy : mean / deviation from all tiles' partials, the correction mu * sum_n r[n] e^{j fs n}, |.|^2 per lag,
+//                   the tile's best 5-sample window (osmo_cxvec_peak_energy_find); in small launches the stream's last
+//                   work-group also picks (below)
 //   k_fcch_pick   : per stream: best window over tiles, energy centroid, toa (fcch.c:241)
-//   k_fcch_fine   : one wavefront per burst: normalise, mix with up / down chirp (or the dual
-//                   chirp for the SNR estimate), direct N-point DFT, 5-bin centroid / 6 largest
-//                   bins (fcch.c:512-628 gmr1_fcch_fine, fcch.c:643-708 gmr1_fcch_snr)
+//   k_fcch_multi  : gmr1_fcch_rough_multi's period fold, threshold and ranked de-duplicated peak list (fcch.c:341-496)
+//   k_fcch_fine   : two wavefronts per burst: normalise, mix with up / down chirp (or the dual chirp for the SNR
+//                   estimate), direct N-point DFT, 5-bin centroid / 6 largest bins (fcch.c:512-628 gmr1_fcch_fine,
+//                   fcch.c:643-708 gmr1_fcch_snr)
+//   k_fcch_stats, k_fcch_corr : the two-pass form of the rough sweep (round 4; profiling build, GMR1_HIP_FCCH_TWO_PASS)
+//   acq_step1..4, k_acq_glue  : what gmr1_rx does between two sweeps of its acquisition (gmr1_rx.c:605-702), run by the
+//                   producing sweep's last thread (AcqTail, fcch_acq.h) or as a launch of its own
 //
-// HBM traffic per 1-s stream (93 600 samples): 748.8 kB read once, 187 kB decimated written and
-// read back, a few kB of partials: 1.5x the algorithmic bytes.  The correlation is 10.9 MFLOP per
-// stream (14.6 flop/B), so the sweep sits near the HBM / fp32-VALU ridge; no MFMA (real x complex
-// FIR, "do not reshape into GEMMs").
+// HBM traffic per 1-s stream (93 600 samples): 748.8 kB read once (x 1.065: the tiles' overlap), 187 kB of raw correlation
+// written and read back, a few kB of partials.
 #include <cstring>
 #include "gmr1_dev.h"
 #include "fcch_acq.h"
