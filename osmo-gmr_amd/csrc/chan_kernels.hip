@@ -61,23 +61,6 @@ __device__ __forceinline__ float lane_xor(float v)
 	else return dppf<0xB1>(v);
 }
 
-// one decimation-in-frequency stage over the lanes: pairs (l, l ^ SPAN); the lane without the bit keeps a + b, the other
-// (a - b) * w, w = e^{-j 2 pi (l mod SPAN) / (2 SPAN)}.  Without selects: every lane forms partner + sg * own (sg = +1 in
-// the lane without the bit, -1 in the other: exact, a product with +-1) and multiplies by (wr, wi), which is (1, 0) in the
-// lanes without the bit -- for finite samples the same values as choosing between the two forms afterwards (a sum's -0
-// can come out +0).  NOT for non-finite ones: dr * 1 - di * 0 turns an Inf or NaN in ONE component of a clipped or
-// corrupt sample into NaNs in BOTH (Inf * 0), where a select would have passed the other component through; such a
-// sample poisons the output instants its filter taps reach either way (tests/test_gpu_chan.py: the other instants stay
-// exact).
-template <int SPAN>
-__device__ __forceinline__ void dif_stage(float &re, float &im, float sg, float wr, float wi)
-{
-	const float pr = lane_xor<SPAN>(re), pi = lane_xor<SPAN>(im);
-	const float dr = fmaf(re, sg, pr), di = fmaf(im, sg, pi);
-	re = dr * wr - di * wi;
-	im = dr * wi + di * wr;
-}
-
 // ---- packed single precision (v_pk_*_f32: two multiply-adds per lane and instruction, the rate the vector peak is quoted
 // at).  The filterbank's arithmetic is complex-by-real and complex-by-complex throughout, so every step is a pair: with
 // scalar instructions the kernel issued 6 455 vector instructions per wave at 88 % VALU busy.  The operand selects pick the
@@ -94,6 +77,14 @@ __device__ __forceinline__ void pf_fir(pf_v2f &ae, pf_v2f &ao, pf_v2f taps, pf_v
 	    : "+v"(ae), "+v"(ao) : "v"(taps), "v"(w));
 }
 
+// one decimation-in-frequency stage over the lanes: pairs (l, l ^ SPAN); the lane without the bit keeps a + b, the other
+// (a - b) * w, w = e^{-j 2 pi (l mod SPAN) / (2 SPAN)}.  Without selects: every lane forms partner + sg * own (sg = +1 in
+// the lane without the bit, -1 in the other: exact, a product with +-1) and multiplies by (wr, wi), which is (1, 0) in the
+// lanes without the bit -- for finite samples the same values as choosing between the two forms afterwards (a sum's -0
+// can come out +0).  NOT for non-finite ones: dr * 1 - di * 0 turns an Inf or NaN in ONE component of a clipped or
+// corrupt sample into NaNs in BOTH (Inf * 0), where a select would have passed the other component through; such a
+// sample poisons the output instants its filter taps reach either way (tests/test_gpu_chan.py: the other instants stay
+// exact).
 // the stage's butterfly and twiddle for both instants: d = partner + sg * own ; out = d * (wr + j wi)
 //   sgp: the pair holding this stage's sign in half SH ; w: (wr, wi)
 //   out.re = d.re wr - d.im wi, out.im = d.im wr + d.re wi, as  t = d * wr ; out = (-d.im, d.re) * wi + t

@@ -292,7 +292,7 @@ def test_channelizer_planar_output_feeds_planar_receive(gpu_api, pkg):
 def test_non_finite_sample_poisons_only_the_instants_its_taps_reach(gpu_api):
     """A clipped / corrupt capture: one sample with an Inf in one component and a NaN in the other.  The filterbank's
     select-free DFT stages spread a non-finite component over both components of what they touch (chan_kernels.hip:
-    dif_stage) -- but only over the output instants whose filter taps reach that sample: everything before and well after
+    pf_stage) -- but only over the output instants whose filter taps reach that sample: everything before and well after
     it is bit-identical to the clean capture's output."""
     rng = np.random.default_rng(8)
     n = 400000
