@@ -1248,8 +1248,9 @@ static hipError_t launch_sweep(const FcchRoughArgs &a, const AcqTail &tl, hipStr
 	// Small launches (the receive loop's acquisition: their latency is what counts): the stream's last work-group picks its
 	// best tile itself, one launch fewer.  Not for the large ones: the device-scope fence in front of the count writes the
 	// XCD's whole L2 back, which with thousands of work-groups in flight quadruples the kernel (0.041 -> 0.162 ms at
-	// 1024 streams of 93 600 samples, measured).
-	const int pick = (a.toa && tiles == 1 && a.n <= kPickStreams) ? 1 : 0;
+	// 1024 streams of 93 600 samples, measured; already at 2 048 work-groups -- 512 carriers' 330 ms windows -- it costs
+	// 40 us where the launch of its own costs 7).
+	const int pick = (a.toa && (long long)a.n_lag_tiles * a.n <= 512 && a.n <= kPickStreams) ? 1 : 0;
 	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles, pick, tl);
 	if (a.toa && !pick)
 		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a, tl);

@@ -9,7 +9,7 @@ export GMR1_HIP_LIBRARY=$GRAFT_REPO_ROOT/osmo-gmr_amd/libgmr1_hip_prof.so
 export GMR1_HIP_RX_TIMING=1
 for mode in fused; do
 	if [ $mode = unfused ]; then export GMR1_HIP_ACQ_UNFUSED=1; else unset GMR1_HIP_ACQ_UNFUSED; fi
-	timeout -k 10 300 python3 bench.py --workload rx --steps 20 --warmup 3 --no-cpu --no-extras > gpurun_out/acq_host_$mode.json 2> gpurun_out/acq_host_$mode.err
+	timeout -k 10 300 python3 bench.py --workload rx ${ACQ_ARGS} --steps 20 --warmup 3 --no-cpu --no-extras > gpurun_out/acq_host_$mode.json 2> gpurun_out/acq_host_$mode.err
 	echo "== $mode"
 	grep -E "^acquire|^frame loop" gpurun_out/acq_host_$mode.err | tail -6
 	python3 -c "
