@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <strings.h>
 #include <atomic>
 #include <mutex>
@@ -19,6 +20,7 @@
 #include <osmocom/gmr1/l1/ccch.h>
 
 #include "capi_common.h"
+#include "rx_server.h"
 #include "rx_debug.h"
 
 namespace gmr1 {
@@ -609,6 +611,10 @@ struct OneBurst {
 	int dev = -1;
 	hipStream_t st = nullptr;
 	unsigned char *h = nullptr, *d = nullptr;      // the block: host address, device address
+	// the resident server of the fused BCCH / DC6 call at 4 samples per symbol (rx_server.h)
+	hipStream_t srv_st = nullptr;
+	uint32_t seq = 0, gen = 0;
+	int srv_acc = -1;
 	bool memo = false;
 	int memo_chain = 0, memo_n = 0, memo_acc = 0;
 	int8_t memo_eb[432];
@@ -621,7 +627,8 @@ constexpr size_t kOneIq = 0;                        // kMaxInLen complex samples
 constexpr size_t kOneOff = (size_t)kMaxInLen * 8;   // uint64 offset (0), uint8 kind, float freq_shift
 constexpr size_t kOneOut = kOneOff + 64;            // rv, sync_id, toa, freq_err, crc, conv | l2[24] at +32 | soft bits at +64
 constexpr size_t kOneEb = kOneOut + 64;
-constexpr size_t kOneBytes = kOneEb + 1024;
+constexpr size_t kOneMail = kOneEb + 1024;          // OneMail
+constexpr size_t kOneBytes = kOneMail + 64;
 
 // g_one.mu held.  0, or -errno; *usable = false when the context belongs to another device (caller takes the slow path)
 int one_ready(bool *usable)
@@ -636,6 +643,7 @@ int one_ready(bool *usable)
 		void *h = nullptr, *d = nullptr;
 		HIP_TRY(hipHostMalloc(&h, kOneBytes, hipHostMallocMapped));
 		HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+		std::memset(h, 0, kOneBytes);               // (the mailbox: no request, no answer, generation 0 = no server yet)
 		g_one.h = static_cast<unsigned char *>(h);
 		g_one.d = static_cast<unsigned char *>(d);
 		g_one.dev = dev;
@@ -646,6 +654,57 @@ int one_ready(bool *usable)
 
 template <typename T> T *one_h(size_t off) { return reinterpret_cast<T *>(g_one.h + off); }
 template <typename T> T *one_d(size_t off) { return reinterpret_cast<T *>(g_one.d + off); }
+
+// The fused one-burst call through the resident server (rx_server_kernels.inc): the request is in the block; post its number,
+// start a server if none is alive (or the one alive decodes with the other Viterbi decoder), spin on the answer's number.
+// GMR1_HIP_ONE_BURST_SERVER=0 in the environment keeps the launch per call.  g_one.mu held.  0, 1 = not taken (the caller
+// launches as before), or -errno.
+constexpr unsigned kServerIdleUs = 200, kServerLifeUs = 500000;
+int one_server_call()
+{
+	static const bool enabled = [] { const char *e = getenv("GMR1_HIP_ONE_BURST_SERVER"); return !(e && e[0] == '0'); }();
+	if (!enabled)
+		return 1;
+	if (!g_one.srv_st)
+		HIP_TRY(hipStreamCreateWithFlags(&g_one.srv_st, hipStreamNonBlocking));
+	OneMail *mh = one_h<OneMail>(kOneMail);
+	volatile uint32_t *v_req = &mh->req, *v_done = &mh->done, *v_ended = &mh->ended, *v_gen = &mh->gen;
+	const uint32_t seq = ++g_one.seq;
+	std::atomic_thread_fence(std::memory_order_release);
+	*v_req = seq;
+	const auto t0 = std::chrono::steady_clock::now();
+	int launches = 0;
+	for (unsigned spins = 0;; spins++) {
+		if (*v_done == seq)
+			break;
+		if (*v_ended == g_one.gen || g_one.srv_acc != conv_acc()) {
+			// the current generation has ended (or none was started yet: both numbers 0; or it decodes with the other
+			// decoder): the next one, on the servers' one stream -- it starts when the last one has gone, so there is
+			// never more than one at work
+			if (launches++ >= 4)
+				return fail(-EIO, "one-burst server: ends without answering");
+			RxArgs a;
+			int r = rx_fused_base_args(4, one_d<float>(kOneIq), &a);
+			if (r) return r;
+			a.n = 1;
+			a.offset = one_d<uint64_t>(kOneOff); a.kind = one_d<uint8_t>(kOneOff + 8); a.freq_shift = one_d<float>(kOneOff + 12);
+			a.l2 = one_d<uint8_t>(kOneOut + 32); a.crc = one_d<int32_t>(kOneOut + 16); a.conv = one_d<int32_t>(kOneOut + 20);
+			a.toa = one_d<float>(kOneOut + 8); a.freq_err = one_d<float>(kOneOut + 12);
+			a.ebits = one_d<int8_t>(kOneEb); a.rv = one_d<int32_t>(kOneOut);
+			*v_gen = ++g_one.gen;
+			std::atomic_thread_fence(std::memory_order_seq_cst);
+			HIP_TRY(launch_one_server(a, one_d<OneMail>(kOneMail), g_one.gen, kServerIdleUs, kServerLifeUs, g_one.srv_st));
+			g_one.srv_acc = conv_acc();
+		}
+		if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
+			return fail(-ETIMEDOUT, "one-burst server: no answer");
+#if defined(__x86_64__)
+		__builtin_ia32_pause();
+#endif
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	return 0;
+}
 
 }  // namespace
 
@@ -690,7 +749,18 @@ int gmr1_pi4cxpsk_demod(struct gmr1_pi4cxpsk_burst *burst_type,
 			// the fused kernel takes the two formats of rx_bcch / rx_ccch at the window lengths they use (gmr1_rx.c:759, 809)
 			const int kind = type == GMR1_HIP_BCCH ? 0 : (type == GMR1_HIP_DC6 ? 1 : -1);
 			const bool fused = kind >= 0 && sps >= 4 && sps <= 8 && in_len == window_len(234, sps, (kind ? 10 : 20) * sps);
-			if (fused) {
+			bool served = false;
+			if (fused && sps == 4) {
+				*one_h<uint8_t>(kOneOff + 8) = (uint8_t)kind;
+				r = one_server_call();
+				if (r < 0) return r;
+				served = r == 0;
+				r = 0;
+				o[1] = 0;
+			}
+			if (served) {
+				// (answered by the resident server)
+			} else if (fused) {
 				*one_h<uint8_t>(kOneOff + 8) = (uint8_t)kind;
 				r = rx_bcch_ccch_dev_impl(g_one.st, 1, sps, one_d<float>(kOneIq), one_d<uint64_t>(kOneOff),
 				                          one_d<uint8_t>(kOneOff + 8), one_d<float>(kOneOff + 12), one_d<uint8_t>(kOneOut + 32),
@@ -704,7 +774,8 @@ int gmr1_pi4cxpsk_demod(struct gmr1_pi4cxpsk_burst *burst_type,
 				                   one_d<float>(kOneOut + 8), one_d<float>(kOneOut + 12), nullptr, one_d<int32_t>(kOneOut));
 			}
 			if (r) return r;
-			HIP_TRY(hipStreamSynchronize(g_one.st));
+			if (!served)
+				HIP_TRY(hipStreamSynchronize(g_one.st));
 			if (o[0]) return o[0];
 			std::memcpy(ebits, one_h<int8_t>(kOneEb), (size_t)ht.ebits);
 			if (sync_id_p) *sync_id_p = o[1];
@@ -890,6 +961,8 @@ int rx_base_args(int sps, const float *iq, RxArgs *out, int min_sps = 4)
 	return 0;
 }
 }  // namespace
+
+int rx_fused_base_args(int sps, const float *iq, RxArgs *out) { return rx_base_args(sps, iq, out, 4); }
 
 int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           const float *iq, const uint64_t *offset, const uint8_t *kind,

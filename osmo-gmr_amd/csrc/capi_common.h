@@ -67,6 +67,8 @@ int dev_state(DevState **out);
 int dev_workspace(DevState *s, size_t bytes, void **out);
 
 // fused BCCH / CCCH receive with the optional burst_energy() output (capi.cpp)
+// the fused BCCH / DC6 launch arguments without the per-call pointers (rx_base_args, capi.cpp): for the one-burst server
+int rx_fused_base_args(int sps, const float *iq, RxArgs *out);
 int rx_bcch_ccch_dev_impl(hipStream_t stream, int n, int sps,
                           const float *iq, const uint64_t *offset, const uint8_t *kind,
                           const float *freq_shift,

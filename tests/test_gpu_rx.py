@@ -605,3 +605,68 @@ def test_demod_taps_refusals_and_no_power(gpu_api, pkg):
         gpu_api.demod_taps("bcch", x[:100], sps=4)
     with pytest.raises(Exception):
         gpu_api.demod_taps("bcch", x, sps=0)
+
+
+def test_legacy_calls_through_the_resident_server(gpu_api, pkg):
+    """gmr1_pi4cxpsk_demod + gmr1_bcch_decode / gmr1_ccch_decode at 4 samples per symbol are answered by a resident one-wave
+    kernel that takes requests from a mailbox in pinned memory (rx_server_kernels.inc).  Every answer equals the batch entry
+    point's for the same burst -- across pauses longer than the server's idle time (it ends and is started again), switches
+    of the Viterbi decoder (a new server generation), calls of other kinds in between, a device-wide synchronisation while
+    it is resident, and more back-to-back calls than one server lifetime holds."""
+    import time
+    import torch
+    n = 64
+    wl = workloads.bcch_ccch_mix(pkg, n=n, seed=91, esn0_db=(7.0, 12.0))
+    ref = {}
+    for dec in (gpu_api.CONV_ACC, gpu_api.CONV_GENERIC):
+        with gpu_api.conv_decoder(dec):
+            ref[dec] = gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"], wl["kind"], sps=4)
+
+    def one(i, dec):
+        k = int(wl["kind"][i])
+        name = "dc6" if k else "bcch"
+        a = int(wl["offset"][i])
+        iq = wl["iq"][a:a + wl["in_len"][k]]
+        g = gpu_api.pi4cxpsk_demod(name, iq, 4, 0.0)
+        r = ref[dec]
+        assert g["rv"] == r["rv"][i], i
+        if g["rv"]:
+            return
+        assert g["toa"] == r["toa"][i] and g["freq_err"] == r["freq_err"][i], i
+        assert np.array_equal(g["ebits"], r["ebits"][i][:g["ebits"].size]), i
+        l2, crc, conv = (gpu_api.ccch_decode if k else gpu_api.bcch_decode)(g["ebits"])
+        assert crc == r["crc"][i] and conv == r["conv"][i], i
+        if crc == 0:
+            assert np.array_equal(l2, r["l2"][i][:l2.size]), i
+
+    with gpu_api.conv_decoder(gpu_api.CONV_ACC):
+        for i in range(8):
+            one(i, gpu_api.CONV_ACC)
+        time.sleep(0.02)                                   # the server has ended by now: the next call starts one
+        for i in range(8, 12):
+            one(i, gpu_api.CONV_ACC)
+            time.sleep(0.002)
+        torch.cuda.synchronize()                           # returns once the resident server has ended (its idle time)
+        # other calls in between: another format (a launch per call), a batch call
+        fmt = pkg.api.burst_format("nt3_speech")
+        rng = np.random.default_rng(5)
+        eb = rng.integers(0, 2, size=(1, fmt.ebits), dtype=np.uint8)
+        bb = pkg.synth.synth_windows(fmt, pkg.synth.map_symbols(fmt, eb), 4, 6, rng, toa_jitter=1, frac=True, esn0_db=15.0)
+        for i in range(12, 20):
+            one(i, gpu_api.CONV_ACC)
+            assert gpu_api.pi4cxpsk_demod("nt3_speech", bb.iq[0, :bb.in_len], 4, 0.0)["rv"] == 0
+            gpu_api.rx_bcch_ccch_batch(wl["iq"], wl["offset"][:3], wl["kind"][:3], sps=4)
+    for rep in range(3):                                   # the decoder mode changes under a live server
+        for dec in (gpu_api.CONV_GENERIC, gpu_api.CONV_ACC):
+            with gpu_api.conv_decoder(dec):
+                for i in range(20 + 4 * rep, 24 + 4 * rep):
+                    one(i, dec)
+    # 0.7 s of calls back to back: longer than a server lives
+    t0 = time.perf_counter()
+    m = 0
+    with gpu_api.conv_decoder(gpu_api.CONV_ACC):
+        while time.perf_counter() - t0 < 0.7:
+            one(m % n, gpu_api.CONV_ACC)
+            m += 1
+    assert m > 2000
+    torch.cuda.synchronize()
