@@ -5,7 +5,10 @@
  *
  *  1. The reference's own per-burst C API (declared in include/osmocom/gmr1/
  *     {sdr,l1}/.h of this repo, same names / argument meaning / return values
- *     as osmocom/osmo-gmr) -- each call is blocking: H2D, one kernel, D2H.
+ *     as osmocom/osmo-gmr) -- each call is blocking: H2D, one kernel, D2H.  (The BCCH / DC6 demodulation call at
+ *     4 samples per symbol is answered by a resident one-wave kernel fed from a mailbox in pinned memory instead of
+ *     a launch per call; it ends by itself 200 us after the last call.  GMR1_HIP_ONE_BURST_SERVER=0 in the
+ *     environment keeps the launch per call.  INTEGRATION.md, "What the unchanged application costs".)
  *
  *  2. The batched entry points below, which are what a high-rate caller binds.
  *     "_dev" variants take DEVICE pointers (inputs already resident in HBM) and
