@@ -19,7 +19,7 @@ api = pkg.api
 torch.cuda.init()
 L = api.load()
 api.init(0)
-A, sps, seconds = 64, 4, 20.0
+A, sps, seconds = 64, 4, 60.0      # (round 55 = the stamped one sits in the middle of the first time slice at this length)
 ns = int(seconds * 23400 * sps)
 host = [workloads.bcch_carrier(pkg, 700 + a, seconds=seconds, sps=sps, stn=(5 * a) % 24, delay=a % 8, cfo_hz=40.0 * (a - 3),
                                esn0_db=10.0 + a)[0] for a in range(8)]
