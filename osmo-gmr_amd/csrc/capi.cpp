@@ -660,6 +660,31 @@ template <typename T> T *one_d(size_t off) { return reinterpret_cast<T *>(g_one.
 // GMR1_HIP_ONE_BURST_SERVER=0 in the environment keeps the launch per call.  g_one.mu held.  0, 1 = not taken (the caller
 // launches as before), or -errno.
 constexpr unsigned kServerIdleUs = 200, kServerLifeUs = 500000;
+// the next server generation, on the servers' one stream: it starts when the last one has gone, so there is never more
+// than one at work.  The generation number is written BEFORE any request it is to answer, and a server reads the request
+// number before the generation: a superseded server cannot take a request posted behind the change.
+int one_server_start(OneMail *mh)
+{
+	RxArgs a;
+	int r = rx_fused_base_args(4, one_d<float>(kOneIq), &a);
+	if (r) return r;
+	a.n = 1;
+	a.offset = one_d<uint64_t>(kOneOff); a.kind = one_d<uint8_t>(kOneOff + 8); a.freq_shift = one_d<float>(kOneOff + 12);
+	a.l2 = one_d<uint8_t>(kOneOut + 32); a.crc = one_d<int32_t>(kOneOut + 16); a.conv = one_d<int32_t>(kOneOut + 20);
+	a.toa = one_d<float>(kOneOut + 8); a.freq_err = one_d<float>(kOneOut + 12);
+	a.ebits = one_d<int8_t>(kOneEb); a.rv = one_d<int32_t>(kOneOut);
+	volatile uint32_t *v_ended = &mh->ended, *v_gen = &mh->gen;
+	*v_gen = ++g_one.gen;
+	std::atomic_thread_fence(std::memory_order_seq_cst);
+	const hipError_t e = launch_one_server(a, one_d<OneMail>(kOneMail), g_one.gen, kServerIdleUs, kServerLifeUs, g_one.srv_st);
+	if (e != hipSuccess) {
+		*v_ended = g_one.gen;                     // it never ran: the next call starts another
+		return fail(-EIO, "one-burst server: launch failed: %s", hipGetErrorString(e));
+	}
+	g_one.srv_acc = conv_acc();
+	return 0;
+}
+
 int one_server_call()
 {
 	static const bool enabled = [] { const char *e = getenv("GMR1_HIP_ONE_BURST_SERVER"); return !(e && e[0] == '0'); }();
@@ -668,33 +693,26 @@ int one_server_call()
 	if (!g_one.srv_st)
 		HIP_TRY(hipStreamCreateWithFlags(&g_one.srv_st, hipStreamNonBlocking));
 	OneMail *mh = one_h<OneMail>(kOneMail);
-	volatile uint32_t *v_req = &mh->req, *v_done = &mh->done, *v_ended = &mh->ended, *v_gen = &mh->gen;
+	volatile uint32_t *v_req = &mh->req, *v_done = &mh->done, *v_ended = &mh->ended;
+	int launches = 0, r;
+	// a server that decodes with the other Viterbi decoder is retired before the request exists
+	if (g_one.gen != 0 && g_one.srv_acc != conv_acc()) {
+		launches++;
+		if ((r = one_server_start(mh))) return r;
+	}
 	const uint32_t seq = ++g_one.seq;
 	std::atomic_thread_fence(std::memory_order_release);
 	*v_req = seq;
 	const auto t0 = std::chrono::steady_clock::now();
-	int launches = 0;
 	for (unsigned spins = 0;; spins++) {
 		if (*v_done == seq)
 			break;
-		if (*v_ended == g_one.gen || g_one.srv_acc != conv_acc()) {
-			// the current generation has ended (or none was started yet: both numbers 0; or it decodes with the other
-			// decoder): the next one, on the servers' one stream -- it starts when the last one has gone, so there is
-			// never more than one at work
+		if (*v_ended == g_one.gen) {
+			// the current generation has ended (idle, lifetime; or none was ever started: both numbers 0): the next one
+			// finds the request waiting
 			if (launches++ >= 4)
 				return fail(-EIO, "one-burst server: ends without answering");
-			RxArgs a;
-			int r = rx_fused_base_args(4, one_d<float>(kOneIq), &a);
-			if (r) return r;
-			a.n = 1;
-			a.offset = one_d<uint64_t>(kOneOff); a.kind = one_d<uint8_t>(kOneOff + 8); a.freq_shift = one_d<float>(kOneOff + 12);
-			a.l2 = one_d<uint8_t>(kOneOut + 32); a.crc = one_d<int32_t>(kOneOut + 16); a.conv = one_d<int32_t>(kOneOut + 20);
-			a.toa = one_d<float>(kOneOut + 8); a.freq_err = one_d<float>(kOneOut + 12);
-			a.ebits = one_d<int8_t>(kOneEb); a.rv = one_d<int32_t>(kOneOut);
-			*v_gen = ++g_one.gen;
-			std::atomic_thread_fence(std::memory_order_seq_cst);
-			HIP_TRY(launch_one_server(a, one_d<OneMail>(kOneMail), g_one.gen, kServerIdleUs, kServerLifeUs, g_one.srv_st));
-			g_one.srv_acc = conv_acc();
+			if ((r = one_server_start(mh))) return r;
 		}
 		if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
 			return fail(-ETIMEDOUT, "one-burst server: no answer");
