@@ -1430,6 +1430,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
+    # profiling build only: how many bursts of one launch left the speculated-pick path of k_rx4
+    missed = None
+    try:
+        f_miss = api.load().gmr1_hip_prof_miss
+        f_miss()
+        step()
+        torch.cuda.synchronize()
+        missed = int(f_miss())
+    except AttributeError:
+        pass
+
     # ---- sanity on the produced results (outside the timed region) --------------------------
     h_crc = crc.cpu().numpy()
     h_l2 = l2.cpu().numpy()
@@ -1528,7 +1539,8 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_note, "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
         "checks": {"crc_pass_frac": decoded_frac, "payloads_match_sent": payload_ok,
-                   "workload_gen_s": round(t_gen, 1)},
+                   "workload_gen_s": round(t_gen, 1),
+                   **({"mis_speculated_picks_per_launch": missed} if missed is not None else {})},
         "clock": clock,
     }
     smi = rocm_smi_state(dev_index)

@@ -63,6 +63,13 @@ def needs_build() -> bool:
 PROFILE_LIB = os.path.join(HERE, "libgmr1_hip_prof.so")
 
 
+def build_variant(name: str, defines, profile: bool = True, verbose: bool = False) -> str:
+    """An experimental library libgmr1_hip_<name>.so: the same sources with extra -D switches (and, by default, the profiling
+    build's), for A/B runs on one GPU box through GMR1_HIP_LIBRARY (tools/exp).  Never loaded by the product."""
+    lib = os.path.join(HERE, "libgmr1_hip_%s.so" % name)
+    return _build(lib, (["-DGMR1_HIP_PROFILE"] if profile else []) + list(defines), ".%s.o" % name, verbose, False)
+
+
 def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
     """profile=True: the same sources with -DGMR1_HIP_PROFILE into libgmr1_hip_prof.so -- the only build in which the
     GMR1_HIP_DBG_STOP / _AMBE_DBG / _RX_IMPL / ... switches exist (tools/ load it through GMR1_HIP_LIBRARY)."""
@@ -124,4 +131,9 @@ def _build(lib: str, extra, suffix: str, verbose: bool, force: bool = False) -> 
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))
+    if "--variant" in sys.argv:
+        # python build.py --variant w5 -DGMR1_EXP_RX4_WAVES=5 [--no-profile]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], [x for x in sys.argv[1:] if x.startswith("-D")], profile="--no-profile" not in sys.argv, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, profile="--profile" in sys.argv))

@@ -577,6 +577,85 @@ __device__ __forceinline__ void load_stats(const float2 *__restrict__ in, int in
 	window_stats<NPL, NFULL>(v, in_len, lane, avr_o, avi_o, inv_o);
 }
 
+// ---- the QUAD layout of a window in registers (rx4_body's QL: the fused batch kernel at 4 samples per symbol) ----
+// Lane l holds window samples 256 b + 4 l + c as v[4 b + c] (b = 0..3, c = 0..3): four CONSECUTIVE samples of each quarter
+// of the window, fetched as two 16-byte loads a quarter (a wave instruction covers 1 KB, every line asked for whole).
+// What it buys: the samples pass 2 keeps -- d, d + 4, d + 8, ... (pi4cxpsk.c:292-295) -- are sub-slot c = d & 3 of EVERY lane
+// of every quarter, one per lane and quarter, in lane order: kept sample i sits in lane (i + (d >> 2)) & 63 of quarter
+// (i + (d >> 2)) >> 6.  A lane ROTATION by d >> 2 (ds_bpermute, no LDS memory) puts kept sample l + 64 r into lane l --
+// pass 2's own assignment -- while the window is still in registers: no second trip to memory for it (rx4_body, QX).
+// With the samples stored polyphase-planar the same assignment is lane l <- place l + 64 b of plane c: a coalesced 512-byte
+// load, and the per-lane partial sums below are formed over the same samples in the same order, so the planar call's
+// statistics equal the interleaved call's bit for bit.
+typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));
+__device__ __forceinline__ void window_fetch_q(const float2 *__restrict__ in, int in_len, int lane, float2 (&v)[16])
+{
+	const v4f_a8 *__restrict__ p = reinterpret_cast<const v4f_a8 *>(in + 4 * lane);
+#pragma unroll
+	for (int b = 0; b < 4; b++) {
+		const int s0 = 256 * b + 4 * lane;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			float2 lo = make_float2(0.f, 0.f), hi = make_float2(0.f, 0.f);
+			if (b < 3 || s0 + 2 * h + 1 < in_len) {        // (in_len >= 960: the first three quarters are whole)
+				const v4f_a8 u = p[128 * b + h];
+				lo = make_float2(u.x, u.y);
+				hi = make_float2(u.z, u.w);
+			} else if (s0 + 2 * h < in_len) {
+				lo = in[s0 + 2 * h];
+			}
+			v[4 * b + 2 * h] = lo;
+			v[4 * b + 2 * h + 1] = hi;
+		}
+	}
+}
+
+// the same assignment out of a polyphase-planar array: `pl` = the array, o = the window's first sample (flat count)
+__device__ __forceinline__ void window_fetch_q_planar(const float2 *__restrict__ pl, long long plane_stride, uint64_t o, int in_len,
+                                                      int lane, float2 (&v)[16])
+{
+#pragma unroll
+	for (int c = 0; c < 4; c++) {
+		const uint64_t oc = o + (uint64_t)c;
+		const float2 *__restrict__ src = pl + (long long)(oc & 3) * plane_stride + (long long)(oc >> 2) + lane;
+#pragma unroll
+		for (int b = 0; b < 4; b++) {
+			const int sidx = 256 * b + 4 * lane + c;
+			v[4 * b + c] = (b < 3 || sidx < in_len) ? src[64 * b] : make_float2(0.f, 0.f);
+		}
+	}
+}
+
+// mean and 1 / sigma of a window in the quad layout (osmo_cxvec_sig_normalize's statistics; as window_stats above: packed
+// sums, ONE true division sequence for the two means, reciprocals elsewhere)
+__device__ __forceinline__ void window_stats_q(const float2 (&v)[16], int in_len, int lane, float &avr_o, float &avi_o, float &inv_o)
+{
+	v2f s2 = {0.f, 0.f};
+#pragma unroll
+	for (int k = 0; k < 16; k++)
+		s2 += (v2f){v[k].x, v[k].y};                        // (samples beyond the window are zeros)
+	const float sr = wave_sum(s2.x);
+	const float si = wave_sum(s2.y);
+	const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
+	const float quot = ((lane & 1) ? si : sr) / (float)in_len;
+	const float avr = lane_val(quot, 0), avi = lane_val(quot, 1);
+	const v2f av = {avr, avi};
+	v2f acc2 = {0.f, 0.f};
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		if (k < 12 || 256 * 3 + 4 * lane + (k & 3) < in_len) {
+			const v2f d = (v2f){v[k].x, v[k].y} - av;
+			acc2 = __builtin_elementwise_fma(d, d, acc2);
+		}
+	}
+	float stddev = __builtin_amdgcn_sqrtf(wave_sum(acc2.x + acc2.y) * inv_n);
+	if (stddev == 0.0f)
+		stddev = 1.0f;
+	avr_o = avr;
+	avi_o = avi;
+	inv_o = __builtin_amdgcn_rcpf(stddev);
+}
+
 // burst_energy() of the caller (gmr1_rx.c:172-182): sum |x|^2 over [len>>5, len - len>>5) of the RAW
 // window, divided by len.  Only the receive driver asks for it (RxArgs::energy); the window was
 // read a moment ago, so this second read is served by L1 / L2.
@@ -1805,10 +1884,11 @@ __device__ __forceinline__ void pk_cmac(v2f &acc, unsigned long long c, v2f x)
 }
 
 // (lags [j_begin, j_end) of the w there are; j_end < 0: all)
+// (best / best_j, optional: the largest magnitude among this lane's lags and its lag -- rx4_body's QX speculates on it)
 template <int SPS, int T0, int T1, int T2>
 __device__ __forceinline__ void corr_fixed(const float2 *__restrict__ xs, int sps_rt, int w, int lane,
                                            const float2 *__restrict__ ctab, float2 cfl, float *__restrict__ corr,
-                                           int j_begin = 0, int j_end = -1)
+                                           int j_begin = 0, int j_end = -1, uint32_t *best = nullptr, int *best_j = nullptr)
 {
 	constexpr int T[3] = {T0, T1, T2};
 	constexpr int NT = T0 + T1 + T2;
@@ -1843,6 +1923,11 @@ __device__ __forceinline__ void corr_fixed(const float2 *__restrict__ xs, int sp
 			cj += __builtin_amdgcn_sqrtf(fmaf(acc.x, acc.x, acc.y * acc.y));
 		}
 		corr[j] = cj;
+		if (best) {
+			// (a sum of square roots is not negative: its bits order like its value)
+			const uint32_t cb = __builtin_bit_cast(uint32_t, cj);
+			if (cb > *best) { *best = cb; *best_j = j; }
+		}
 	}
 }
 
@@ -1919,6 +2004,7 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k)
 // cycle stamps of ONE burst of the receive loop (chain 0, the BCCH burst of round kStampRound): tools/loop_stamps.py
 __device__ unsigned long long g_stamp[32];
 __device__ int g_prof_flag;              // experiments of the profiling build (gmr1_hip_prof_flag)
+__device__ int g_prof_miss;              // bursts of k_rx4's QX path whose speculated pick did not hold (gmr1_hip_prof_miss)
 constexpr int kStampRound = 55;    // (late in a time slice: its first rounds share the CU with the previous slice's CCCH batch)
 #define GMR1_STAMP(k)                                                        \
 	do {                                                                    \
@@ -2288,12 +2374,24 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	float avr_r = 0.f, avi_r = 0.f;                    // window mean of this row's burst
 	const float2 *xst_lat = L.x;                       // LAT: where the one burst's sync-chunk windows are staged
 
-	// KEEP: the window of the wave's LAST burst stays in registers through the timing rows, and its kept samples (and sync
-	// symbols) reach pass 2 through 2 KB of LDS instead of a second trip to memory -- a quarter of the second read's
-	// bytes never travels.  (One window is what the register budget of six waves holds; the interleaved layout only:
-	// the planar one's second read is compact already.)
-	constexpr bool KEEP = !GEN && !LAT && !PL && !EN && SPS == 4 && NPL == 16;
-	const bool keep3 = KEEP && g0 + 3 < n_end;
+	// QL (the fused batch kernel at 4 samples per symbol, both sample layouts): the window sits in registers in the QUAD layout
+	// (window_fetch_q).  QX (interleaved samples): pass 2's kept samples never make a second trip to memory.  Right behind a
+	// burst's correlation its pick d = round(toa) is SPECULATED as the lag of the largest correlation magnitude (the timing
+	// rows below start their early / late walk on the strongest lag p of the best three-lag window and end within a lag of it,
+	// pi4cxpsk.c:240, so round(toa) is p - 1, p or p + 1, and p is the largest magnitude itself whenever the peak is clean);
+	// the 234 kept samples d + 4 i are then one sub-slot of every lane of the window registers, a lane rotation away from
+	// pass 2's assignment, and what pass 2 takes from a kept sample -- its phase -- is formed on the spot: four registers a
+	// burst instead of a window.  The timing rows then compute the pick as ever; a burst whose pick is NOT the speculated one
+	// (a few per cent: noise decides where toa lies half-way between two samples) takes the old route -- kept samples and sync
+	// symbols re-read from memory, the same operations on the same numbers -- so no output depends on the speculation.
+	constexpr bool QL = !GEN && !LAT && !EN && SPS == 4 && NPL == 16;
+	constexpr bool QX = QL && !PL;
+	static_assert(!PL || QL, "the planar layout exists for the fused batch kernel");
+	float th_q[QX ? 4 : 1][4];                         // QX: phase (turns) of kept sample lane + 64 r of burst q
+	uint32_t zm_q = 0;                                 // bit 4 q + r: that sample counts as 0 + 0j (outside the window, or zero)
+	float2 xs_q[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};   // row q: normalised samples of sync symbols col, col + 16 at the speculated pick
+	int dspec_r = -0x40000000;                         // row q: burst q's speculated pick
+	float inv_r = 1.0f;                                // row q: 1 / sigma of burst q's window
 	// a burst's operands: the arrays of `io`, or (the loop's pipeline stages) the caller's registers (LatPre (5))
 	auto op_kind = [&](int g) -> int {
 		if constexpr (LAT && PART != 0) return 0; else return io.kind[g] ? 1 : 0;
@@ -2431,6 +2529,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 	} else {
 	float2 (&wv)[NPL] = wv_own;
+	// (QX: unrolled, the bursts' phase registers th_q[q] are picked at compile time)
+#pragma clang loop unroll_count(QX ? 4 : 1)
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
 		if (g >= n_end)
@@ -2494,7 +2594,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				fetch_window(in);
 		} else {
 			if constexpr (PL) {
-				window_fetch<NPL, NFULL, 16>(pl_in, in_len, sl, wv);
+				window_fetch_q_planar(a.iq, a.plane_stride, io.offset[g], in_len, lane, wv);
 #pragma unroll
 				for (int c = 0; c < NCHK; c++) {
 					const int wl = F::clen(bt, kind, c) * sps + w - 1;
@@ -2506,7 +2606,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 					}
 				}
 			} else {
-			if (q == 0 || !PREFETCH_NEXT)
+			if constexpr (QL)
+				window_fetch_q(in, in_len, lane, wv);
+			else if (q == 0 || !PREFETCH_NEXT)
 				window_fetch<NPL, NFULL>(in, in_len, lane, wv);
 #pragma unroll
 			for (int c = 0; c < NCHK; c++) {
@@ -2554,7 +2656,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (io.energy && lane == 0)
 				io.energy[g] = pre->h_stat[3];
 		} else {
-		window_stats<NPL, NFULL>(wv, in_len, sl, avr, avi, inv, PL ? 16 * (lane & 3) + (lane >> 2) : -1, PL ? 16 : 1);
+		if constexpr (QL)
+			window_stats_q(wv, in_len, lane, avr, avi, inv);
+		else
+			window_stats<NPL, NFULL>(wv, in_len, sl, avr, avi, inv, -1, 1);
 		if constexpr (LAT && PART == 1) {
 			if (pre->win_w) {
 #pragma unroll
@@ -2575,7 +2680,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 		}
 		GMR1_STAMP(1);
-		if (row == q) { avr_r = avr; avi_r = avi; }
+		if (row == q) { avr_r = avr; avi_r = avi; inv_r = inv; }
 		if (PREFETCH_NEXT && !LAT && q + 1 < 4 && g + 1 < n_end) {
 			// the next burst's window travels during this burst's correlation
 			const int kind1 = GEN ? 0 : __builtin_amdgcn_readfirstlane(io.kind[g + 1] ? 1 : 0);
@@ -2617,6 +2722,69 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 						corr[j0 + lane] = pre->co->tail[lane];
 				} else
 					corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, ctab, cfl, corr, j0, w);
+			} else if constexpr (QX) {
+				uint32_t cbest = 0;
+				int cbj = 0;
+				if (kind == 0)
+					corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, ctab, cfl, corr, 0, -1, &cbest, &cbj);
+				else
+					corr_fixed<SPS, 7, 3, 3>(xst, sps, w, lane, ctab, cfl, corr, 0, -1, &cbest, &cbj);
+				// the lag of the largest magnitude (any lane that holds it): the speculated pick
+				uint32_t mx = cbest, o;
+				o = dpp<0xB1>(mx); mx = o > mx ? o : mx;
+				o = dpp<0x4E>(mx); mx = o > mx ? o : mx;
+				o = dpp<0x141>(mx); mx = o > mx ? o : mx;
+				o = dpp<0x140>(mx); mx = o > mx ? o : mx;
+				const uint32_t m01 = max((uint32_t)__builtin_amdgcn_readlane((int)mx, 0), (uint32_t)__builtin_amdgcn_readlane((int)mx, 16));
+				const uint32_t m23 = max((uint32_t)__builtin_amdgcn_readlane((int)mx, 32), (uint32_t)__builtin_amdgcn_readlane((int)mx, 48));
+				const uint32_t M = max(m01, m23);
+				const unsigned long long holders = __ballot(cbest == M);
+				const int d = __builtin_amdgcn_readlane(cbj, holders ? __builtin_ctzll(holders) : 0);     // 0 <= d < w <= 81
+				// row q keeps what the rows below need of this burst at that pick: the normalised samples under its sync symbols
+				// (still staged) ...
+				if (row == q) {
+					dspec_r = d;
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						const int n = col + 16 * h;
+						const int c0 = kind ? 7 : 11;
+						const int ch = n < c0 ? 0 : (n < c0 + 3 ? 1 : 2);
+						const int nn = n - (ch == 0 ? 0 : (ch == 1 ? c0 : c0 + 3));
+						const int wb = ch == 0 ? 0 : (ch == 1 ? c0 * 4 + w - 1 : c0 * 4 + w - 1 + 3 * 4 + w - 1);
+						if (n < c0 + 6)
+							xs_q[h] = xst[wb + nn * 4 + d];
+					}
+				}
+				// ... and every lane the phases of its four kept samples i = lane + 64 r: sample 4 i + d is sub-slot d & 3 of lane
+				// (i + (d >> 2)) & 63 in quarter (i + (d >> 2)) >> 6 of the window registers
+				{
+					const int srcl = lane + (d >> 2);
+					const int addr = (srcl & 63) << 2;
+					const bool up = srcl >= 64;
+					float2 rot[4];
+					auto pull = [&](const float2 &v) {
+						return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v.x))),
+						                   __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v.y))));
+					};
+					switch (d & 3) {                                  // (wave-uniform)
+					case 0: rot[0] = pull(wv[0]); rot[1] = pull(wv[4]); rot[2] = pull(wv[8]); rot[3] = pull(wv[12]); break;
+					case 1: rot[0] = pull(wv[1]); rot[1] = pull(wv[5]); rot[2] = pull(wv[9]); rot[3] = pull(wv[13]); break;
+					case 2: rot[0] = pull(wv[2]); rot[1] = pull(wv[6]); rot[2] = pull(wv[10]); rot[3] = pull(wv[14]); break;
+					default: rot[0] = pull(wv[3]); rot[1] = pull(wv[7]); rot[2] = pull(wv[11]); rot[3] = pull(wv[15]); break;
+					}
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						const int i = lane + 64 * r;
+						float2 x = up ? (r < 3 ? rot[r < 3 ? r + 1 : 3] : make_float2(0.f, 0.f)) : rot[r];
+						const bool ok = i < 234 && 4 * i + d < in_len;
+						// (as pass 2 does it: the mean is subtracted whether or not the lane has a sample; the zero test knows)
+						x.x -= avr;
+						x.y -= avi;
+						th_q[q][r] = atan2_turns(x.y, x.x);
+						if (!ok || (x.x == 0.0f && x.y == 0.0f))
+							zm_q |= 1u << (4 * q + r);
+					}
+				}
 			} else if (kind == 0)
 				corr_fixed<SPS, 11, 3, 3>(xst, sps, w, lane, ctab, cfl, corr);
 			else
@@ -3009,35 +3177,14 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	}
 	const int d_r = (int)roundf(toa_r);
 
-	// KEEP: samples d, d + 4, ... of burst 3's window are registers k = 0..15 of the lanes with lane = d (mod 4) (lane l
-	// holds samples l + 64 k): they go to slots i = (l + 64 k - d) / 4 of an exchange buffer over the staged windows and
-	// the correlation, which nothing reads any more
-	float2 *const exch = reinterpret_cast<float2 *>(lds_raw);
-	if constexpr (KEEP) {
-		if (keep3) {
-			const int d3 = __builtin_amdgcn_readlane(d_r, 48);
-			WSYNC();
-			if (((lane - d3) & 3) == 0) {
-				const int i0 = (lane - d3) >> 2;
-				if (d3 >= 0 && d3 < 128) {
-					// (-32 <= i0 <= 15: only registers 0 and 1 can fall before slot 0, none behind slot 255)
-					if (i0 >= 0)
-						exch[i0] = wv_own[0];
-					if (i0 >= -16)
-						exch[i0 + 16] = wv_own[1];
-#pragma unroll
-					for (int k = 2; k < NPL; k++)
-						exch[i0 + 16 * k] = wv_own[k];
-				} else {
-#pragma unroll
-					for (int k = 0; k < NPL; k++)
-						if ((unsigned)(i0 + 16 * k) < 256u)
-							exch[i0 + 16 * k] = wv_own[k];
-				}
-			}
-			WSYNC();
-		}
+	// QX: whose speculated pick held (per row; a burst that was not found has no pass 2 at all)
+	const bool hit_r = QX && found_r && d_r == dspec_r && a.dbg_stop != 101;      // (101: experiment, every burst takes the old route)
+#ifdef GMR1_HIP_PROFILE
+	if constexpr (QX) {
+		if (col == 0 && row_live && found_r && !hit_r)
+			atomicAdd(&g_prof_miss, 1);
 	}
+#endif
 
 	// pass-2 operands of a burst (its 234 symbols at stride sps from sample d, re-read from
 	// L2 / Infinity Cache): fetched two bursts ahead of their use
@@ -3061,15 +3208,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			const long long sr = (long long)io.offset[g] + d;
 			in = a.iq + (sr & 3) * a.plane_stride + (sr >> 2);
 		}
-		const bool from_exch = KEEP && q == 3 && keep3;
 #pragma unroll
 		for (int r = 0; r < NSYM; r++) {
 			const int i = lane + 64 * r;
 			const int j = i * sps + d;
 			if (i < blen && j >= 0 && j < in_len) {
-				if (KEEP && from_exch)
-					o.x[r] = exch[i];
-				else if (LAT && PART == 2)
+				if (LAT && PART == 2)
 					o.x[r] = pre->win_r[j];
 				else
 					o.x[r] = PL ? in[i] : in[j];
@@ -3135,8 +3279,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 						// sample sp sps + d of the window = place sp of the plane the kept samples lie in
 						const long long sr = (long long)(row_live ? io.offset[g_row] : 0) + d_r;
 						xr[h] = (a.iq + (sr & 3) * a.plane_stride + (sr >> 2))[sp];
-					} else if (KEEP && keep3 && row == 3) {
-						xr[h] = exch[sp];           // sample sp sps + d = slot sp
+					} else if (QX && hit_r) {
+						xr[h] = xs_q[h];            // taken from the staged windows when the pick was speculated (normalised)
 					} else
 					xr[h] = LAT ? xst_lat[wb + nn * sps + d_r] : in_r[idx];
 				}
@@ -3149,7 +3293,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		if constexpr (LAT) {
 			if constexpr (PART == 0)
 				fetch(0, first);        // the one burst's kept samples travel during the whole sync-term phase
-		} else {
+		} else if constexpr (!QX) {
 			fetch(3, first);
 			fetch(2, second);
 		}
@@ -3158,9 +3302,15 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (chn[h] >= 0) {
 				const int idx = idxv[h], ch = chn[h], nn = nnv[h], sp = spos[h];
 				float2 x = xr[h];
-				if (!LAT && idx >= 0 && idx < in_len_r) {
+				if (!LAT && idx >= 0 && idx < in_len_r && !(QX && hit_r)) {
 					x.x -= avr_r;
 					x.y -= avi_r;
+					if constexpr (QL) {
+						// as the staged windows are normalised (a scale no angle below notices; the same numbers whichever
+						// way the sample came)
+						x.x *= inv_r;
+						x.y *= inv_r;
+					}
 				}
 				float s, c;
 				sincos_fast(fs_r * (float)idx, s, c);
@@ -3250,7 +3400,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		WSYNC();
 	}
 	int row_ok = 0, row_chain = 0;
-	Sym4 nxt1 = first, nxt2 = second;
+	Sym4 nxt1, nxt2;
+	if constexpr (!QX) { nxt1 = first; nxt2 = second; }
 #pragma unroll
 	for (int q = 3; q >= 0; q--) {
 		const int g = g0 + q;
@@ -3259,6 +3410,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			if (q != 0)
 				continue;
 			cur = first;
+		} else if constexpr (QX) {
+			cur.ok = 0;
+#pragma unroll
+			for (int r = 0; r < NSYM; r++) cur.x[r] = make_float2(0.f, 0.f);
 		} else {
 			cur = nxt1;
 			nxt1 = nxt2;
@@ -3267,6 +3422,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		if (g >= n_end)
 			continue;
 		const int src = 16 * q;
+		const bool hit = QX && __builtin_amdgcn_readlane((int)hit_r, src) != 0;
+		if constexpr (QX) {
+			if (!hit && __builtin_amdgcn_readlane((int)found_r, src) != 0)
+				fetch(q, cur);          // the pick is not the speculated one: this burst's kept samples come from memory
+		}
 		const bool found = __builtin_amdgcn_readlane((int)found_r, src) != 0;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);
 		const int type = GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
@@ -3319,8 +3479,16 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			float2 x = cur.x[r];
 			x.x -= avr;
 			x.y -= avi;
-			const float th2 = fmaf(A2, (float)i, fmaf(atan2_turns(x.y, x.x), 2048.0f, B2));
-			const bool zero = !(cur.ok & (1 << r)) || (x.x == 0.0f && x.y == 0.0f);   // cargf(0) = 0
+			float at;
+			bool zero;
+			if (QX && hit) {
+				at = th_q[QX ? q : 0][r];
+				zero = ((zm_q >> (4 * q + r)) & 1u) != 0;
+			} else {
+				at = atan2_turns(x.y, x.x);
+				zero = !(cur.ok & (1 << r)) || (x.x == 0.0f && x.y == 0.0f);   // cargf(0) = 0
+			}
+			const float th2 = fmaf(A2, (float)i, fmaf(at, 2048.0f, B2));
 			if (gss) {
 				float th = th2 * (1.0f / 2048.0f);
 				th -= rintf(th);
@@ -3405,8 +3573,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 // resident waves per SIMD each instantiation is compiled for: the headline one (windows <= 1024 samples at sps 4) fits six
 // without spilling, the run-time-sps one five; the long windows (sps 8: 32 samples per lane) need the registers of three
 // (the receive loop's instantiation, EN, keeps the window registers for the burst energy: five)
+#ifndef GMR1_EXP_RX4_WAVES
+#define GMR1_EXP_RX4_WAVES 6
+#endif
 template <int NPL, int SPS, bool EN = false>
-constexpr int kRx4Waves = NPL > 16 ? 3 : ((SPS == 4 && !EN) ? 6 : 5);   // (seven: 72 VGPRs; measured again in round 4 with the LDS of seven -- no gain interleaved, spills and 4 % slower planar)
+constexpr int kRx4Waves = NPL > 16 ? 3 : ((SPS == 4 && !EN) ? GMR1_EXP_RX4_WAVES : 5);   // (seven: 72 VGPRs; measured again in round 4 with the LDS of seven -- no gain interleaved, spills and 4 % slower planar)
 
 template <int NPL, int SPS, bool ACC = false, bool EN = false, bool PL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kRx4Waves<NPL, SPS, EN>, kRx4Waves<NPL, SPS, EN>)))
@@ -3871,6 +4042,16 @@ extern "C" int gmr1_hip_prof_stamps(unsigned long long *out16)
 {
 	return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamp), sizeof(g_stamp)) == hipSuccess ? 0 : -5;
 }
+// reads (and clears) the count of mis-speculated picks
+extern "C" int gmr1_hip_prof_miss(void)
+{
+	int v = 0, z = 0;
+	if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_prof_miss), sizeof(v)) != hipSuccess)
+		return -5;
+	hipMemcpyToSymbol(HIP_SYMBOL(g_prof_miss), &z, sizeof(z));
+	return v;
+}
+
 extern "C" int gmr1_hip_prof_flag(int v)
 {
 	return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_flag), &v, sizeof(v)) == hipSuccess ? 0 : -5;

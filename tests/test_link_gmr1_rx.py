@@ -12,6 +12,8 @@ import textwrap
 
 import pytest
 
+import tp_headers
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 
@@ -21,66 +23,6 @@ pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "src", "gmr
 THIRD_PARTY = {   # what gmr1_rx.c + gsmtap.c take from libosmocore / libosmo-dsp
     "cfile_load", "cfile_release", "osmo_cxvec_init_from_data", "osmo_hexparse", "osmo_hexdump_nospc",
     "gsmtap_source_init", "gsmtap_source_add_sink", "gsmtap_sendmsg", "msgb_alloc", "msgb_free", "msgb_put",
-}
-
-HEADERS = {
-    "osmocom/core/bits.h": """
-        #include <stdint.h>
-        typedef int8_t sbit_t; typedef uint8_t ubit_t; typedef uint8_t pbit_t;
-    """,
-    "osmocom/core/utils.h": """
-        #include <stdint.h>
-        int osmo_hexparse(const char *str, uint8_t *b, int max_len);
-        char *osmo_hexdump_nospc(const unsigned char *buf, int len);
-    """,
-    "osmocom/core/msgb.h": """
-        #include <stdint.h>
-        struct msgb;
-        struct msgb *msgb_alloc(uint16_t size, const char *name);
-        void msgb_free(struct msgb *m);
-        unsigned char *msgb_put(struct msgb *msgb, unsigned int len);
-    """,
-    "osmocom/core/gsmtap.h": """
-        #include <stdint.h>
-        #define GSMTAP_VERSION 0x02
-        #define GSMTAP_UDP_PORT 4729
-        #define GSMTAP_TYPE_GMR1_UM 0x0a
-        #define GSMTAP_GMR1_BCCH 0x01
-        #define GSMTAP_GMR1_CCCH 0x02
-        #define GSMTAP_GMR1_TCH3 0x10
-        #define GSMTAP_GMR1_TCH9 0x18
-        #define GSMTAP_GMR1_FACCH 0x02
-        struct gsmtap_hdr {
-            uint8_t version, hdr_len, type, timeslot; uint16_t arfcn; int8_t signal_dbm, snr_db;
-            uint32_t frame_number; uint8_t sub_type, antenna_nr, sub_slot, res;
-        } __attribute__((packed));
-    """,
-    "osmocom/core/gsmtap_util.h": """
-        #include <stdint.h>
-        #include <osmocom/core/msgb.h>
-        struct gsmtap_inst;
-        struct gsmtap_inst *gsmtap_source_init(const char *host, uint16_t port, int ofd_wq_mode);
-        int gsmtap_source_add_sink(struct gsmtap_inst *gti);
-        int gsmtap_sendmsg(struct gsmtap_inst *gti, struct msgb *msg);
-    """,
-    "osmocom/dsp/cxvec.h": """
-        #include <complex.h>
-        #define CXVEC_FLG_REAL_ONLY (1 << 0)
-        struct osmo_cxvec { int len, max_len, flags; float complex *data; float complex _data[0]; };
-        void osmo_cxvec_init_from_data(struct osmo_cxvec *cv, float complex *data, int len);
-    """,
-    "osmocom/dsp/cxvec_math.h": """
-        #include <complex.h>
-        #include <math.h>
-        #define M_PIf ((float)M_PI)
-        static inline float osmo_normsqf(float complex c) { return crealf(c) * crealf(c) + cimagf(c) * cimagf(c); }
-    """,
-    "osmocom/dsp/cfile.h": """
-        #include <complex.h>
-        struct cfile { float complex *data; unsigned int len; unsigned int _blen; };
-        struct cfile *cfile_load(const char *filename);
-        void cfile_release(struct cfile *cf);
-    """,
 }
 
 STUBS = """
@@ -97,11 +39,7 @@ def _nm(path, *flags):
 
 
 def test_gmr1_rx_compiles_and_links_unchanged(pkg, tmp_path):
-    for rel, txt in HEADERS.items():
-        p = tmp_path / "tp" / rel
-        p.parent.mkdir(parents=True, exist_ok=True)
-        guard = rel.replace("/", "_").replace(".", "_").upper()
-        p.write_text(f"#ifndef {guard}\n#define {guard}\n{textwrap.dedent(txt)}\n#endif\n")
+    tp_headers.write(tmp_path / "tp")
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + str(tmp_path / "tp"), "-DGMR1_HIP_USE_SYSTEM_OSMOCOM"]
     objs = []
     for src in ("gmr1_rx.c", "gsmtap.c"):
