@@ -92,6 +92,24 @@ def parse():
     return args
 
 
+def valu_profile(name):
+    """profiles/valu_<name>.json (tools/valu_summary.py: machine-wide vector-ALU busy share and resident waves of a kernel from
+    the builder's own PMC run) -- reported only while the kernel sources it was taken on are the ones in the tree."""
+    vf = os.path.join(ROOT, "profiles", f"valu_{name}.json")
+    if not os.path.exists(vf):
+        return None
+    try:
+        vj = json.load(open(vf))
+        if vj.get("kernel_sources_sha256") != kernel_sources_hash():
+            return {"note": f"profiles/valu_{name}.json was taken on other kernel sources: not reported"}
+        return {"kernel": vj.get("kernel"), "valu_busy": vj["valu_busy"], "avg_resident_waves": vj["avg_resident_waves"],
+                "compiled_waves_per_simd": vj.get("compiled_waves_per_simd"), "valu_insts_per_wave": vj.get("valu_insts_per_wave"),
+                "source": f"builder-measured, hash-gated file: {vj.get('source')} (build {vj.get('tag')}); machine-wide: sum SQ_ACTIVE_INST_VALU "
+                          "resp. sum SQ_WAVE_CYCLES / (1024 SIMDs x kernel quad-cycles)"}
+    except Exception as e:
+        return {"note": f"profiles/valu_{name}.json unreadable: {e!r}"}
+
+
 def emit(out, **kw):
     """Print the one JSON line; every line names the Viterbi decoder the run reproduced."""
     if isinstance(out.get("config"), dict):
@@ -175,7 +193,8 @@ def run_chan_workload(args):
                        "realtime_factor": args.wide_seconds * args.steps / wall},
             "roofline": {"bound": "hbm", "kernel": "k_pfb64 + k_resamp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg}}
+                         "algorithmic_bytes_per_launch": alg,
+                         "limited_by": "hbm (filterbank: vector issue 72 %; resampler: LDS delivery and vector issue about even)"}}
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc_chan
@@ -249,7 +268,7 @@ def run_ambe_workload(args):
                        "realtime_factor": total * 0.02 * args.steps / wall, "pcm_msamp_per_s": total * 160 * args.steps / wall / 1e6},
             "roofline": {"bound": "hbm", "kernel": "k_ambe", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg,
+                         "algorithmic_bytes_per_launch": alg, "limited_by": "valu_issue + dependent chains",
                          "note": "330 bytes per frame against tens of thousands of table-cosine multiply-adds: the kernel is "
                                  "VALU / LDS bound by construction (DESIGN.md 4.7), the HBM fraction is reported for form"},
             "checks": {"workload_gen_s": round(t_gen, 2), "rejected_frames": int((rv != 0).sum().item())}}
@@ -350,7 +369,9 @@ def run_rx_workload(args):
     out["roofline"] = {"bound": "hbm", "kernel": "k_rx_chain + k_rx4 + k_rx_merge (+ FCCH acquisition), whole step", "achieved": alg / step_s / 1e9,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                        "kernel_ms": step_s * 1e3, "algorithmic_bytes_per_launch": alg,
-                       "note": "latency-bound feedback chain: 187 dependent BCCH bursts per carrier-minute"}
+                       "limited_by": "latency (dependent chain)",
+                       "note": "latency-bound feedback chain: 187 dependent BCCH bursts per carrier-minute, each waiting for the "
+                               "front half of the one before (DESIGN.md 4.4); the HBM fraction is nominal for it"}
     out["phases_ms"] = {k: round(v, 4) for k, v in phases.items()}
     if not args.no_cpu:
         oracle_lib.lib()
@@ -522,6 +543,14 @@ def run_side_workload(args):
            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                         "algorithmic_bytes_per_launch": bytes_per_launch}}
+    if args.workload == "tch3":
+        # 244 algorithmic bytes per burst against ~ 825 vector instructions: the 8 TB/s roof is nominal for this kernel
+        out["roofline"]["limited_by"] = "valu_issue"
+        vp = valu_profile("k_tch3")
+        if vp:
+            out["roofline_valu"] = dict({"bound": "valu_issue"}, **vp)
+    else:
+        out["roofline"]["limited_by"] = "hbm"
     if args.workload == "fcch":
         # The sweep is a sliding correlation: every lag of every stream takes 117 multiply-adds of a complex sample with a
         # REAL tap (the dual chirp is real: 2 FMA = 4 flops executed; the reference's generic complex correlation spends 8)
@@ -734,9 +763,16 @@ def run_nt3_workload(args):
         tj = json.load(open(tfile))
         if tj.get("kernel_sources_sha256") == kernel_sources_hash():
             out["roofline"]["traffic"] = tj.get("step_bytes_1M")
-            out["roofline"]["traffic_source"] = f"PMC FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels, separate passes, build {tj.get('tag')}"
+            out["roofline"]["traffic_source"] = (f"builder-measured, hash-gated file profiles/hbm_traffic_nt3.json (not measured in this run): PMC "
+                                                 f"FETCH_SIZE x2 + WRITE_SIZE summed over the step's kernels, separate passes, build {tj.get('tag')}")
         else:
             out["roofline"]["traffic_source"] = "profiles/hbm_traffic_nt3.json was taken on other kernel sources: not reported"
+    # nine tenths of the step are k_rx4g_tch3, whose vector ALUs are saturated (machine-wide busy share ~ 1.0): the limit is
+    # instruction issue, the 8 TB/s roof is nominal
+    out["roofline"]["limited_by"] = "valu_issue"
+    vp = valu_profile("k_rx4g_tch3")
+    if vp:
+        out["roofline_valu"] = dict({"bound": "valu_issue"}, **vp)
     if sharded_same is not None:
         out["checks"]["sharded_outputs_identical_to_single_gpu_run"] = bool(sharded_same)
     # what came back, against what was sent (class-1 speech bits are protected, the 32 class-2 bits of a frame are not);
@@ -914,21 +950,36 @@ def start_side_runner(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--side-runner", "--steps", str(args.steps), "--preroll-s", str(args.preroll_s),
            "--conv-decoder", args.conv_decoder]
     try:
-        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        # (its own session = its own process group: a timeout ends the runner AND the `bench.py --workload X` child it is waiting
+        # for, which would otherwise stay on the GPU under whatever runs next)
+        return subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, start_new_session=True)
     except OSError as e:
         print(f"bench.py: no side-workload runner: {e!r}", file=sys.stderr)
         return None
 
 
-def collect_side(runner, timeout=400):
+SIDE_CHILD_TIMEOUT_S = 100
+
+
+def collect_side(runner, timeout=None):
     if runner is None:
         return {"error": "the side-workload runner could not be started"}
+    if timeout is None:
+        timeout = len(SIDE_WORKLOADS) * SIDE_CHILD_TIMEOUT_S + 30      # never shorter than what the runner allows its children
     try:
         out, _ = runner.communicate("go\n", timeout=timeout)
         return json.loads(out.strip().splitlines()[-1])
     except Exception as e:
+        import signal
         try:
-            runner.kill()
+            os.killpg(runner.pid, signal.SIGKILL)      # the runner's whole group (start_new_session): its current child too
+        except Exception:
+            try:
+                runner.kill()
+            except Exception:
+                pass
+        try:
+            runner.wait(timeout=10)
         except Exception:
             pass
         return {"error": repr(e)}
@@ -953,15 +1004,21 @@ def side_workloads(args):
                                                                     "--conv-decoder", args.conv_decoder]
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=100)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=SIDE_CHILD_TIMEOUT_S)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             rf = d.get("roofline") or {}
-            side[key] = {"ms": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "frac": rf.get("frac"), "bound": rf.get("bound"),
+            side[key] = {"ms": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "frac": rf.get("frac"),
+                         # what the workload is actually limited by (its own line's roofline.limited_by); `frac` is always the
+                         # algorithmic bytes against the 8 TB/s HBM roof, nominal where the limit is something else
+                         "bound": rf.get("limited_by") or rf.get("bound"), "frac_is_of": "hbm 8 TB/s",
                          "identical_to_oracle": same(d.get("checks") or {}), "workload": (d.get("config") or {}).get("workload"),
                          "wall_s": round(time.perf_counter() - t0, 1)}
             for k in ("gpu_vs_all_cores", "phases_ms"):
                 if k in d:
                     side[key][k] = d[k]
+            if isinstance(d.get("roofline_valu"), dict) and "valu_busy" in d["roofline_valu"]:
+                side[key]["valu_busy"] = d["roofline_valu"]["valu_busy"]
+                side[key]["avg_resident_waves"] = d["roofline_valu"].get("avg_resident_waves")
             if key == "chan":
                 side[key]["max_abs_err_vs_oracle"] = (d.get("checks") or {}).get("max_abs_err_vs_oracle")
                 side[key]["identical_to_oracle_means"] = "within 2e-4 of the numpy oracle (floating point)"
@@ -1518,7 +1575,8 @@ def main():
             else:
                 traffic = tj.get("k_rx_planar_bytes_per_launch_100k" if args.layout == "planar" else "k_rx_bytes_per_launch_100k")
                 traffic_planar = tj.get("k_rx_planar_bytes_per_launch_100k")
-                traffic_note = f"PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, build {tj.get('tag')}"
+                traffic_note = (f"builder-measured, hash-gated file profiles/hbm_traffic.json (not measured in this run): PMC FETCH_SIZE x2 + "
+                                f"WRITE_SIZE, separate passes, build {tj.get('tag')}")
         except Exception as e:
             traffic_note = f"profiles/hbm_traffic.json unreadable: {e!r}"
 
@@ -1547,24 +1605,19 @@ def main():
     if smi:
         out["clock"]["driver"] = smi
     out["config"]["layout"] = args.layout
-    # What the HBM fraction above is up against: the kernel's vector ALUs (PMC summary of the same kernel on the same sources,
-    # tools/pmc_rx4.sh -> tools/valu_summary.py; like the traffic figure it is reported only while the sources' hash matches)
-    vf = os.path.join(ROOT, "profiles", "valu_k_rx4.json")
-    if os.path.exists(vf) and args.layout == "interleaved":
-        try:
-            vj = json.load(open(vf))
-            if vj.get("kernel_sources_sha256") == kernel_sources_hash():
-                busy = float(vj["valu_busy"])
-                out["roofline_valu"] = {"bound": "valu_issue", "kernel": "k_rx4<16,4>", "valu_busy": busy,
-                                        "valu_insts_per_wave_of_4_bursts": vj["valu_insts_per_wave"], "waves_per_simd": vj["waves_per_simd"],
-                                        "hbm_frac_if_valu_were_100pct_busy": achieved / HBM_PEAK_GBS / busy,
-                                        "source": f"{vj.get('source')} (build {vj.get('tag')})",
-                                        "note": "the kernel is bound by vector-instruction issue, not by HBM: at this instruction count "
-                                                "the HBM fraction cannot pass the figure above; the 8 TB/s roof is nominal for it"}
-            else:
-                out["roofline_valu"] = {"note": "profiles/valu_k_rx4.json was taken on other kernel sources: not reported"}
-        except Exception as e:
-            out["roofline_valu"] = {"note": f"profiles/valu_k_rx4.json unreadable: {e!r}"}
+    # What the HBM fraction above is up against: the kernel's vector ALUs, machine-wide (PMC summary of the same kernel on the
+    # same sources, tools/pmc_rx4.sh -> tools/valu_summary.py; like the traffic figure it is reported only while the sources'
+    # hash matches)
+    if args.layout == "interleaved":
+        vp = valu_profile("k_rx4")
+        if vp and "valu_busy" in vp:
+            out["roofline_valu"] = dict({"bound": "valu_issue",
+                                         "hbm_frac_if_valu_were_100pct_busy": achieved / HBM_PEAK_GBS / vp["valu_busy"],
+                                         "note": "share of the launch a SIMD's vector ALU is executing, and waves resident per SIMD, both "
+                                                 "averaged over the whole launch (ramp and drain included); at this instruction count "
+                                                 "the HBM fraction cannot pass the figure above"}, **vp)
+        elif vp:
+            out["roofline_valu"] = vp
     if "planar" in extras:
         ms_pl, same = extras["planar"]
         ach = bytes_per_launch / (ms_pl * 1e-3) / 1e9

@@ -703,6 +703,22 @@ int one_server_call()
 	const uint32_t seq = ++g_one.seq;
 	std::atomic_thread_fence(std::memory_order_release);
 	*v_req = seq;
+	// Giving up on the server must not leave a live request behind: a server that starts late (queued behind a long kernel)
+	// would serve it after this call has returned and the lock is released -- into a block the next call is rewriting.  So
+	// the generation is retired first (a server reads the request number BEFORE the generation: none of an older generation
+	// takes the request any more), the servers' stream is drained (one that was in the middle of the request finishes; every
+	// server ends by itself), and the call goes on as a launch per call (return 1) instead of failing.
+	auto give_up = [&](const char *why) -> int {
+		volatile uint32_t *v_gen = &mh->gen;
+		*v_gen = ++g_one.gen;
+		std::atomic_thread_fence(std::memory_order_seq_cst);
+		const hipError_t e = hipStreamSynchronize(g_one.srv_st);
+		*v_ended = g_one.gen;                         // nothing is alive: the next call starts a server of its own
+		*v_done = seq;                                // (and no later server may mistake the abandoned request for a new one)
+		if (e != hipSuccess)
+			return fail(-EIO, "one-burst server: %s, and its stream does not drain: %s", why, hipGetErrorString(e));
+		return 1;
+	};
 	const auto t0 = std::chrono::steady_clock::now();
 	for (unsigned spins = 0;; spins++) {
 		if (*v_done == seq)
@@ -711,11 +727,11 @@ int one_server_call()
 			// the current generation has ended (idle, lifetime; or none was ever started: both numbers 0): the next one
 			// finds the request waiting
 			if (launches++ >= 4)
-				return fail(-EIO, "one-burst server: ends without answering");
+				return give_up("ends without answering");
 			if ((r = one_server_start(mh))) return r;
 		}
 		if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5))
-			return fail(-ETIMEDOUT, "one-burst server: no answer");
+			return give_up("no answer within 5 s");
 #if defined(__x86_64__)
 		__builtin_ia32_pause();
 #endif

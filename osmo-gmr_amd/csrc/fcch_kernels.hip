@@ -341,8 +341,41 @@ struct SweepDims {
 	static constexpr size_t lds = (size_t)pad16(NS) * 8 + (size_t)RT * 4;
 };
 
-template <int NT>
-__global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a)
+// FOLD (streams of at most 64 tiles): the tile also does what k_fcch_energy did with its lags -- the normalisation applied,
+// |.|^2 per lag, the tile's best 5-lag window -- so that the raw correlation (8 bytes a lag written, and read back by the next
+// kernel) never leaves the chip.  The normalisation needs the mean and deviation of the WHOLE window, i.e. every tile's
+// partial sums: each tile publishes its own as ONE 16-byte coherent store {sum re, sum im, sum |x|^2, launch epoch} as soon as
+// it has read its samples -- before the matrix work, half the kernel's time --, and behind the matrix work reads the
+// stream's records with coherent loads until all of them carry this launch's epoch.  The tiles of a stream are consecutive
+// work-groups and start together, so nothing waits in practice; the wait is BOUNDED all the same, and a tile that gives up
+// writes its raw correlation and a mark in its result slot, for k_fcch_energy (started behind every folded sweep; a tile
+// without the mark costs it one load) to finish the old way.
+// The sums behind the statistics are formed exactly as k_fcch_energy forms them (same partials, same order, in double); the
+// four lags a tile's windows share with the next tile are this tile's own here (the matrix product groups their taps
+// differently than the neighbour's: last bits).
+struct FoldRec { float sr, si, sq; uint32_t epoch; };
+__device__ __forceinline__ void fold_publish(float *rec, float sr, float si, float sq, uint32_t epoch)
+{
+	typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+	const u4 v = {__builtin_bit_cast(uint32_t, sr), __builtin_bit_cast(uint32_t, si), __builtin_bit_cast(uint32_t, sq), epoch};
+	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(rec), "v"(v) : "memory");
+}
+__device__ __forceinline__ FoldRec fold_read(const float *rec)
+{
+	typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+	u4 v;
+	asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(rec) : "memory");
+	return {__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), v.w};
+}
+constexpr float kFoldGaveUp = -2.0f;            // tile_best[0] of a tile whose wait ran out (a window's energy is never negative)
+constexpr int kFoldMaxTiles = 64, kFoldPolls = 1 << 15;
+
+__device__ inline void fcch_pick_body(const FcchRoughArgs &a, const AcqTail &tl, int s, int lane);      // (below)
+constexpr int kPickStreams = 1 << 16;
+__device__ unsigned int g_pick_count[kPickStreams];      // work-groups of the stream that are through (back to 0 by the last one)
+
+template <int NT, bool FOLD = false>
+__global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, AcqTail tl)
 {
 	typedef SweepDims<NT> D;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -434,11 +467,13 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a)
 	if (lane == 0) { red[0][wv] = sr; red[1][wv] = si; red[2][wv] = sq; }
 	__syncthreads();
 	if (tid == 0) {
+		const float p0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+		const float p1 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+		const float p2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
 		float *p = a.partial + ((size_t)s * a.n_stat_tiles + tile) * 4;
-		p[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-		p[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-		p[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-		p[3] = 0.f;
+		p[0] = p0; p[1] = p1; p[2] = p2; p[3] = 0.f;
+		if constexpr (FOLD)
+			fold_publish(a.fold_partial + ((size_t)s * a.n_stat_tiles + tile) * 4, p0, p1, p2, a.epoch);
 	}
 
 	// ---- raw correlation of lags m0 ... m0 + 2047: wave wv takes the sets wv and wv + 4 of 256 lags each
@@ -471,17 +506,153 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a)
 		dr1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x1.x, dr1, 0, 0, 0);
 		di1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r, x1.y, di1, 0, 0, 0);
 	}
-	// each lane holds four consecutive lags: 32 bytes; the tile's own lags only (the next tile writes the four beyond)
 	float2 *__restrict__ acc = a.dec + (size_t)s * a.dec_stride;
+	__shared__ float s_stat[4];
+	__shared__ int s_have;
+	if constexpr (FOLD) {
+		// ---- the window's statistics, once every tile's record carries this launch's epoch (wave 0; bounded)
+		if (wv == 0) {
+			const float *rec = a.fold_partial + ((size_t)s * a.n_stat_tiles + (lane < a.n_stat_tiles ? lane : 0)) * 4;
+			FoldRec r = {0.f, 0.f, 0.f, 0u};
+			bool have = false;
+			for (int poll = 0; poll < kFoldPolls; poll++) {
+				r = fold_read(rec);
+				have = __ballot(lane < a.n_stat_tiles && r.epoch != a.epoch) == 0;
+				if (have)
+					break;
+				__builtin_amdgcn_s_sleep(4);
+			}
+			// (k_fcch_energy's sums: lane t holds tile t's partial, the rest zero; the same butterfly in double)
+			double dr = lane < a.n_stat_tiles ? (double)r.sr : 0.0, di = lane < a.n_stat_tiles ? (double)r.si : 0.0,
+			       dq = lane < a.n_stat_tiles ? (double)r.sq : 0.0;
+			dr = wave_sum_d(dr); di = wave_sum_d(di); dq = wave_sum_d(dq);
+			float rr = 0.f, ri = 0.f;
+			for (int n = lane; n < NT; n += 64) {
+				const float r1 = c_fcch.dual[a.tab][n];
+				float sn = 0.f, cs = 1.f;
+				if (fs != 0.0f)
+					sincos_fast(fs * (float)n, sn, cs);
+				rr = fmaf(r1, cs, rr);
+				ri = fmaf(r1, sn, ri);
+			}
+			rr = wave_sum(rr); ri = fs != 0.0f ? wave_sum(ri) : 0.0f;
+			if (lane == 0) {
+				const double n = (double)a.len;
+				const double ar = dr / n, ai = di / n;
+				double var = dq / n - (ar * ar + ai * ai);
+				if (var < 0.0) var = 0.0;
+				float sd = sqrtf((float)var);
+				if (sd == 0.0f) sd = 1.0f;
+				s_stat[2] = 1.0f / sd;
+				s_stat[0] = (float)ar * rr - (float)ai * ri;
+				s_stat[1] = (float)ar * ri + (float)ai * rr;
+				s_have = have ? 1 : 0;
+			}
+		}
+		__syncthreads();                                  // (also: every wave is through with the staged samples)
+	}
+	const bool folded = FOLD && s_have != 0;
+	if (!folded) {
+		// each lane holds four consecutive lags: 32 bytes; the tile's own lags only (the next tile writes the four beyond)
 #pragma unroll
-	for (int h = 0; h < 2; h++) {
-		const v4f dr = h ? dr1 : dr0, di = h ? di1 : di0;
-		const int i0 = 256 * (wv + 4 * h) + 16 * li + 4 * lk;
+		for (int h = 0; h < 2; h++) {
+			const v4f dr = h ? dr1 : dr0, di = h ? di1 : di0;
+			const int i0 = 256 * (wv + 4 * h) + 16 * li + 4 * lk;
 #pragma unroll
-		for (int v = 0; v < 4; v++) {
-			const int i = i0 + v, m = m0 + i;
-			if (i < kTileStep && m < nlags)
-				acc[m] = make_float2(dr[v], di[v]);
+			for (int v = 0; v < 4; v++) {
+				const int i = i0 + v, m = m0 + i;
+				if (i < kTileStep && m < nlags)
+					acc[m] = make_float2(dr[v], di[v]);
+			}
+		}
+		if constexpr (FOLD) {
+			if (tid == 0)
+				a.tile_best[((size_t)s * a.n_lag_tiles + tile) * 8] = kFoldGaveUp;
+		}
+	}
+	if constexpr (FOLD) {
+		if (folded) {
+			// ---- energies of the tile's 2048 lags over the staged samples (dead), then its best 5-lag window: k_fcch_energy's steps
+			float *en = reinterpret_cast<float *>(lds_raw);
+			const float mr = s_stat[0], mi = s_stat[1], inv = s_stat[2];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const v4f dr = h ? dr1 : dr0, di = h ? di1 : di0;
+				const int i0 = 256 * (wv + 4 * h) + 16 * li + 4 * lk;
+#pragma unroll
+				for (int v = 0; v < 4; v++) {
+					const int i = i0 + v, m = m0 + i;
+					float e = -1.0f;
+					if (m < nlags) {
+						float2 mu = make_float2(mr, mi);
+						if (fs != 0.0f) {
+							float sn, cs;
+							sincos_fast(fs * (float)m, sn, cs);
+							mu = cmul(mu, make_float2(cs, sn));
+						}
+						const float cx = (dr[v] - mu.x) * inv, cy = (di[v] - mu.y) * inv;
+						e = fmaf(cx, cx, cy * cy);
+						if (a.energy && i < kTileStep)
+							a.energy[(size_t)s * a.energy_stride + m] = e;
+					}
+					en[i] = e;
+				}
+			}
+			__syncthreads();
+			__shared__ float s_best[4];
+			__shared__ int s_bidx[4];
+			float bv = -1.0f;
+			int bi = 0x7fffffff;
+			for (int i = tid; i < kTileStep; i += 256) {
+				const int m = m0 + i;
+				if (m + 5 <= nlags) {
+					float e = 0.f;
+#pragma unroll
+					for (int k = 0; k < 5; k++)
+						e += en[i + k];
+					if (e > bv) { bv = e; bi = m; }
+				}
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const float ov = __shfl_xor(bv, o);
+				const int oi = __shfl_xor(bi, o);
+				if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+			}
+			if (lane == 0) { s_best[wv] = bv; s_bidx[wv] = bi; }
+			__syncthreads();
+			if (tid == 0) {
+				for (int q = 1; q < 4; q++)
+					if (s_best[q] > bv || (s_best[q] == bv && s_bidx[q] < bi)) { bv = s_best[q]; bi = s_bidx[q]; }
+				float *o = a.tile_best + ((size_t)s * a.n_lag_tiles + tile) * 8;
+				o[0] = bv;
+				o[1] = __builtin_bit_cast(float, bi);
+				if (bi != 0x7fffffff) {
+					for (int k = 0; k < 5; k++)
+						o[2 + k] = en[bi - m0 + k];
+				}
+			}
+		}
+		if (!pick)
+			return;
+		// small launches: the stream's last work-group picks (as k_fcch_energy's did); a tile that gave up leaves the pick to
+		// the energy pass behind this launch
+		__shared__ int s_last;
+		if (tid == 0) {
+			__threadfence();
+			const unsigned prev = atomicAdd(&g_pick_count[s], folded ? 1u : 0x10000u);      // (high half: tiles that gave up)
+			s_last = (prev & 0xffffu) + (prev >> 16) == gridDim.x - 1 ? (int)(1 + (prev >> 16) + (folded ? 0 : 1)) : 0;
+		}
+		__syncthreads();
+		if (!s_last || wv != 0)
+			return;
+		if (s_last == 1) {
+			if (lane == 0)
+				g_pick_count[s] = 0;
+			__threadfence();
+			fcch_pick_body(a, tl, s, lane);
+		} else if (lane == 0) {
+			g_pick_count[s] = 0x80000000u;                  // some tile gave up: k_fcch_energy's last work-group picks (it resets)
 		}
 	}
 }
@@ -583,12 +754,10 @@ __device__ inline void acq_step4(const AcqArgs &a, int t, int ctoa, float cfe)
 // second half: the normalisation applied to the raw correlation, energies, the tile's best 5-lag window
 // (tiles: lag tiles per work-group -- several where there are thousands of them, so that the statistics are formed once for
 // all; one where the launch is small and its latency is what counts: the receive loop's acquisition)
-__device__ inline void fcch_pick_body(const FcchRoughArgs &a, const AcqTail &tl, int s, int lane);      // (below)
-constexpr int kPickStreams = 1 << 16;
-__device__ unsigned int g_pick_count[kPickStreams];      // work-groups of the stream that are through (back to 0 by the last one)
-
+// (fold: behind a folded sweep -- only the tiles that gave up there are left to do; pick as ever for the small launches, but
+// only if the sweep's last work-group left it here)
 template <int NT>
-__global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnergyTiles, int pick, AcqTail tl)
+__global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnergyTiles, int pick, AcqTail tl, int fold)
 {
 	__shared__ float en[kTileLags];
 	__shared__ int s_last;

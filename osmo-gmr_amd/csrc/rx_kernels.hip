@@ -44,6 +44,15 @@
 
 namespace gmr1 {
 
+#ifndef GMR1_EXP_SINC_TABLE
+#define GMR1_EXP_SINC_TABLE 0       // (experiment, measured and dropped: 1 = the timing rows read their sinc weights from a 48 KB table built by the
+                                    // device instead of forming them -- 490 fewer vector instructions a wave, and nine dependent trips to the L2 in the
+                                    // one phase of the kernel that is a serial chain: the waves lived 6 % longer and the launch took as long as before)
+#endif
+#ifndef GMR1_EXP_SPEC5
+#define GMR1_EXP_SPEC5 0            // (experiment, measured and dropped: 1 = the strongest lag moved by a five-point early / late estimate -- 11.8 % instead of 15.1 % mis-speculated picks for 20 more vector instructions a burst)
+#endif
+
 #define WSYNC()                                                   \
 	do {                                                          \
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");    \
@@ -626,29 +635,28 @@ __device__ __forceinline__ void window_fetch_q_planar(const float2 *__restrict__
 	}
 }
 
-// mean and 1 / sigma of a window in the quad layout (osmo_cxvec_sig_normalize's statistics; as window_stats above: packed
-// sums, ONE true division sequence for the two means, reciprocals elsewhere)
+// mean and 1 / sigma of a window in the quad layout (osmo_cxvec_sig_normalize's statistics), ONE sweep: sum x and sum |x|^2
+// together -- sum |x - m|^2 = sum |x|^2 - n |m|^2, never below zero -- as the small formats' pass 1 has always had it: sigma only
+// sets a scale nothing downstream depends on (every consumer takes an angle, a ratio of energies or the place of a peak), and a
+// second sweep over sixteen register pairs for the variance about the mean is a third of the statistics' instructions.  Packed
+// sums, ONE true division sequence for the two means (a constant window must normalise to exactly zero), reciprocals elsewhere.
 __device__ __forceinline__ void window_stats_q(const float2 (&v)[16], int in_len, int lane, float &avr_o, float &avi_o, float &inv_o)
 {
-	v2f s2 = {0.f, 0.f};
+	v2f s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
-	for (int k = 0; k < 16; k++)
-		s2 += (v2f){v[k].x, v[k].y};                        // (samples beyond the window are zeros)
+	for (int k = 0; k < 16; k++) {
+		const v2f x = {v[k].x, v[k].y};                     // (samples beyond the window are zeros)
+		s2 += x;
+		q2 = __builtin_elementwise_fma(x, x, q2);
+	}
 	const float sr = wave_sum(s2.x);
 	const float si = wave_sum(s2.y);
+	const float sq = wave_sum(q2.x + q2.y);
 	const float inv_n = __builtin_amdgcn_rcpf((float)in_len);
 	const float quot = ((lane & 1) ? si : sr) / (float)in_len;
 	const float avr = lane_val(quot, 0), avi = lane_val(quot, 1);
-	const v2f av = {avr, avi};
-	v2f acc2 = {0.f, 0.f};
-#pragma unroll
-	for (int k = 0; k < 16; k++) {
-		if (k < 12 || 256 * 3 + 4 * lane + (k & 3) < in_len) {
-			const v2f d = (v2f){v[k].x, v[k].y} - av;
-			acc2 = __builtin_elementwise_fma(d, d, acc2);
-		}
-	}
-	float stddev = __builtin_amdgcn_sqrtf(wave_sum(acc2.x + acc2.y) * inv_n);
+	const float var = fmaxf(fmaf(-(float)in_len, fmaf(avr, avr, avi * avi), sq), 0.0f) * inv_n;
+	float stddev = __builtin_amdgcn_sqrtf(var);
 	if (stddev == 0.0f)
 		stddev = 1.0f;
 	avr_o = avr;
@@ -1845,8 +1853,43 @@ __global__ __launch_bounds__(64) void k_coef0(int first, int count)
 	g_coef0[sps][type][n] = v;
 }
 
+// The 21 sinc weights of osmo_cxvec_interpolate_point for every fractional position the early / late walk of the timing rows
+// can stand on (pi4cxpsk.c:240; the walk steps by 1/2, 1/4 ... 1/512 from a whole lag, so the fraction is f = fi / 512):
+// row fi = { w(k - f) : k = -10 .. 10 } and three zeros, w(x) = sin(pi x) / (pi x) formed EXACTLY as rx4_body's interp2 used to
+// form it on the spot -- sin(pi f) by v_sin_f32, sin(pi (k - f)) = -(-1)^k sin(pi f), a v_rcp_f32 reciprocal, the weight 1 within
+// 0.01 of a whole tap -- by the device itself (k_sincw), so that reading a weight gives the bits computing it gave.  What it
+// saves the rows: a sine, three reciprocals and a dozen multiplies, compares and selects per evaluation, nine evaluations a
+// sequence -- a lane's three taps are one 12-byte load from a 48 KB table every wave of the machine keeps reading.
+__device__ float g_sincw[512][24];
+
+__global__ __launch_bounds__(64) void k_sincw()
+{
+	const int fi = blockIdx.x, isub = (int)threadIdx.x;
+	if (isub >= 8)
+		return;
+	const float f = (float)fi * (1.0f / 512.0f);
+	const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f)
+	const int k0 = 3 * isub - 10;
+	const float kf0 = (float)k0, kf1 = (float)(k0 + 1), kf2 = (float)(k0 + 2);
+	const uint32_t sgn0 = (isub & 1) ? 0u : 0x80000000u;
+	const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
+	const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
+	const float w0 = (x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
+	const float w1 = (x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
+	const float w2 = (x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
+	const bool has = isub != 7;                            // (lane 7 would hold taps 11, 12, 13)
+	g_sincw[fi][3 * isub] = has ? w0 : 0.0f;
+	g_sincw[fi][3 * isub + 1] = has ? w1 : 0.0f;
+	g_sincw[fi][3 * isub + 2] = has ? w2 : 0.0f;
+}
+
 hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream)
 {
+#if GMR1_EXP_SINC_TABLE
+	hipLaunchKernelGGL(k_sincw, dim3(512), dim3(64), 0, stream);     // (same stream: ordered before any burst kernel)
+	if (hipError_t e0 = hipGetLastError(); e0 != hipSuccess)
+		return e0;
+#endif
 	hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_types), host, sizeof(DevBurst) * (size_t)count,
 	                                      sizeof(DevBurst) * (size_t)first, hipMemcpyHostToDevice, stream);
 	if (e != hipSuccess)
@@ -2529,12 +2572,36 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		}
 	} else {
 	float2 (&wv)[NPL] = wv_own;
-	// (QX: unrolled, the bursts' phase registers th_q[q] are picked at compile time)
+	const int lane_outer = lane;
+	// QX: where, in the staged sync-chunk windows of a BCCH / of a DC6 burst, the sample under sync symbol `col` lies for pick 0
+	// (chunk c's window starts at staged sample wb_c; symbol nn of it, at pick d, is staged sample wb_c + 4 nn + d); -1: none
+	int xsp_b = -1, xsp_c = -1;
+	if constexpr (QX) {
+		auto place = [&](int kind) -> int {
+			const int w = a.in_len[kind] - 234 * 4 + 1;
+			const int c0 = kind ? 7 : 11;
+			const int n = col;
+			const int ch = n < c0 ? 0 : (n < c0 + 3 ? 1 : 2);
+			const int nn = n - (ch == 0 ? 0 : (ch == 1 ? c0 : c0 + 3));
+			const int wb = ch == 0 ? 0 : (ch == 1 ? c0 * 4 + w - 1 : c0 * 4 + w - 1 + 3 * 4 + w - 1);
+			return n < c0 + 6 ? wb + nn * 4 : -1;
+		};
+		xsp_b = place(0);
+		xsp_c = place(1);
+	}
+	// (QX: unrolled, the bursts' phase registers th_q[q] are picked at compile time and come to life one burst at a time)
 #pragma clang loop unroll_count(QX ? 4 : 1)
 	for (int q = 0; q < 4; q++) {
 		const int g = g0 + q;
 		if (g >= n_end)
 			break;
+		// (QX: the lane number is made opaque once per iteration, so that nothing derived from it -- addresses, staging
+		// predicates, tap places -- is hoisted out of the loop to sit in registers beside the bursts' kept phases)
+		int lane_l = lane_outer;
+		if constexpr (QX)
+			asm volatile("" : "+v"(lane_l));
+		const int lane = lane_l;
+		const int row = lane >> 4, col = lane & 15;
 		const int kind = GEN ? 0 : __builtin_amdgcn_readfirstlane(op_kind(g));
 		const int type = GEN ? a.fixed_type : (kind ? GMR1_HIP_DC6 : GMR1_HIP_BCCH);
 		const int in_len = __builtin_amdgcn_readfirstlane(a.in_len[kind]);
@@ -2545,17 +2612,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const float fs = (fsh - F::rotation(bt)) / (float)sps;
 
 		const float2 *__restrict__ in = a.iq + op_off(g);
-		// PL: lanes 16 p .. 16 p + 15 read 16 consecutive places of ONE plane per load (a full 128-byte line; with lane l
-		// on samples l + 64 k, as in the interleaved layout, adjacent lanes would sit in four different lines and a load
-		// would cost sixteen times the tag look-ups): lane (p, j) holds window samples 64 k + 4 j + p -- those of lane
-		// sl = 4 j + p of the usual assignment, row for row, so only the cross-lane sums need to know (window_stats).
-		const float2 *__restrict__ pl_in = nullptr;
-		const int sl = PL ? 4 * (lane & 15) + (lane >> 4) : lane;
-		if constexpr (PL) {
-			const uint64_t o = io.offset[g];
-			const int t = (int)(o & 3) + (lane >> 4);
-			pl_in = a.iq + (o >> 2) + ((long long)(t & 3) * a.plane_stride + (t >> 2) + (lane & 15));
-		}
+		const int sl = lane;
 		const int tl = F::tl(bt, kind);
 		const int nch = F::nch(bt);
 		constexpr int NFULL = (!GEN && SPS == 4 && NPL == 16) ? 15 : -1;
@@ -2595,16 +2652,6 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		} else {
 			if constexpr (PL) {
 				window_fetch_q_planar(a.iq, a.plane_stride, io.offset[g], in_len, lane, wv);
-#pragma unroll
-				for (int c = 0; c < NCHK; c++) {
-					const int wl = F::clen(bt, kind, c) * sps + w - 1;
-					const float2 *__restrict__ src = pl_in + F::cpos(bt, c);
-#pragma unroll
-					for (int h = 0; h < SIT; h++) {
-						const int sidx = sl + 64 * h;
-						sv[c][h] = sidx < wl ? src[16 * h] : make_float2(0.f, 0.f);
-					}
-				}
 			} else {
 			if constexpr (QL)
 				window_fetch_q(in, in_len, lane, wv);
@@ -2693,6 +2740,30 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				io.energy[g] = e;
 		}
 		// stage the sync-chunk windows, normalised: window c = samples [pos_c sps, pos_c sps + len_c sps + w - 1)
+		if constexpr (PL) {
+			// The quad layout stages out of the window registers (the planar call; the interleaved one asks for the samples under
+			// the sync chunks a second time, as the other instantiations do -- staging out of registers that have to last through
+			// the correlation for the kept samples costs it more registers than it has): a lane's four consecutive samples 256 b + 4 l .. + 3 lie wholly
+			// inside a chunk window or wholly outside it (the windows start on a symbol, 4 | pos sps, and are len sps + w - 1
+			// samples long with w - 1 = 80 or 40), so a lane whose quad is inside writes it with two 16-byte stores.  Chunk 0
+			// ([112, 236) at most) lies in quarter 0, chunk 1 ([476, 568)) in quarters 1 and 2, chunk 2 ([788, 880)) in quarter 3.
+			const int wl0 = F::clen(bt, kind, 0) * 4 + w - 1, wl1 = 3 * 4 + w - 1;
+			const v2f av = {avr, avi}, iv = {inv, inv};
+			auto stage_quad = [&](int b, int start, int wl, int wb) {
+				const int rel = 256 * b + 4 * lane - start;
+				if (rel >= 0 && rel < wl) {
+					v2f n0 = ((v2f){wv[4 * b].x, wv[4 * b].y} - av) * iv, n1 = ((v2f){wv[4 * b + 1].x, wv[4 * b + 1].y} - av) * iv;
+					v2f n2 = ((v2f){wv[4 * b + 2].x, wv[4 * b + 2].y} - av) * iv, n3 = ((v2f){wv[4 * b + 3].x, wv[4 * b + 3].y} - av) * iv;
+					float4 *dst = reinterpret_cast<float4 *>(L.x + wb + rel);
+					dst[0] = make_float4(n0.x, n0.y, n1.x, n1.y);
+					dst[1] = make_float4(n2.x, n2.y, n3.x, n3.y);
+				}
+			};
+			stage_quad(0, 28 * 4, wl0, 0);
+			stage_quad(1, 119 * 4, wl1, wl0);
+			stage_quad(2, 119 * 4, wl1, wl0);
+			stage_quad(3, 197 * 4, wl1, wl0 + wl1);
+		} else
 		if (!prepared) {
 			int wb = 0;
 #pragma unroll
@@ -2739,21 +2810,33 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const uint32_t m23 = max((uint32_t)__builtin_amdgcn_readlane((int)mx, 32), (uint32_t)__builtin_amdgcn_readlane((int)mx, 48));
 				const uint32_t M = max(m01, m23);
 				const unsigned long long holders = __ballot(cbest == M);
-				const int d = __builtin_amdgcn_readlane(cbj, holders ? __builtin_ctzll(holders) : 0);     // 0 <= d < w <= 81
+				int d = __builtin_amdgcn_readlane(cbj, holders ? __builtin_ctzll(holders) : 0);           // 0 <= d < w <= 81
+#if GMR1_EXP_SPEC5
+				// ... moved by one lag where the magnitudes around it say the early / late walk will settle beyond the half-way point:
+				// the walk looks for the t at which the interpolated magnitudes at t - 1 and t + 1 balance; linearised at the
+				// strongest lag p that is t = p + 2 (c[p+1] - c[p-1]) / (2 c[p] - c[p+2] - c[p-2])  (lags outside the array count 0)
+				{
+					const int pm2 = d - 2;
+					const float cm2 = pm2 >= 0 ? corr[pm2 >= 0 ? pm2 : 0] : 0.0f, cm1 = d >= 1 ? corr[d >= 1 ? d - 1 : 0] : 0.0f;
+					const float c0 = corr[d];
+					const float cp1 = d + 1 < w ? corr[d + 1 < w ? d + 1 : d] : 0.0f, cp2 = d + 2 < w ? corr[d + 2 < w ? d + 2 : d] : 0.0f;
+					const float num = 2.0f * (cp1 - cm1), den = 2.0f * c0 - cp2 - cm2;
+					// |num / den| > 1/2 with den > 0  <=>  2 |num| > den
+					const int step = (den > 0.0f && 2.0f * fabsf(num) > den) ? (num > 0.0f ? 1 : -1) : 0;
+					d += __builtin_amdgcn_readfirstlane(step);
+					d = d < 0 ? 0 : (d >= w ? w - 1 : d);
+				}
+#endif
 				// row q keeps what the rows below need of this burst at that pick: the normalised samples under its sync symbols
 				// (still staged) ...
 				if (row == q) {
 					dspec_r = d;
-#pragma unroll
-					for (int h = 0; h < 2; h++) {
-						const int n = col + 16 * h;
-						const int c0 = kind ? 7 : 11;
-						const int ch = n < c0 ? 0 : (n < c0 + 3 ? 1 : 2);
-						const int nn = n - (ch == 0 ? 0 : (ch == 1 ? c0 : c0 + 3));
-						const int wb = ch == 0 ? 0 : (ch == 1 ? c0 * 4 + w - 1 : c0 * 4 + w - 1 + 3 * 4 + w - 1);
-						if (n < c0 + 6)
-							xs_q[h] = xst[wb + nn * 4 + d];
-					}
+					const int pl = kind ? xsp_c : xsp_b;
+					if (pl >= 0)
+						xs_q[0] = xst[pl + d];
+					// (the one symbol beyond the sixteenth: BCCH's n = 16, symbol 2 of the third chunk, on the row's first lane)
+					if (kind == 0 && col == 0)
+						xs_q[1] = xst[11 * 4 + w - 1 + 3 * 4 + w - 1 + 2 * 4 + d];
 				}
 				// ... and every lane the phases of its four kept samples i = lane + 64 r: sample 4 i + d is sub-slot d & 3 of lane
 				// (i + (d >> 2)) & 63 in quarter (i + (d >> 2)) >> 6 of the window registers
@@ -2776,7 +2859,8 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 					for (int r = 0; r < 4; r++) {
 						const int i = lane + 64 * r;
 						float2 x = up ? (r < 3 ? rot[r < 3 ? r + 1 : 3] : make_float2(0.f, 0.f)) : rot[r];
-						const bool ok = i < 234 && 4 * i + d < in_len;
+						// (kept samples 0 .. 191 lie inside any window this kernel is started for: 4 * 191 + 80 < 960 <= in_len)
+						const bool ok = r < 3 || (i < 234 && 4 * i + d < in_len);
 						// (as pass 2 does it: the mean is subtracted whether or not the lane has a sample; the zero test knows)
 						x.x -= avr;
 						x.y -= avi;
@@ -3026,11 +3110,22 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const int i0 = ib + k0;
 				const float *cp = cr + i0;
 				const float c0 = cp[0], c1 = cp[1], c2 = cp[2];
-				const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
-				const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
-				const float w0 = (x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
-				const float w1 = (x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
-				const float w2 = (x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
+				float w0, w1, w2;
+				if constexpr (LAT || !GMR1_EXP_SINC_TABLE) {
+					const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
+					const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
+					w0 = (x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
+					w1 = (x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
+					w2 = (x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
+				} else {
+					// the same three weights out of the table (g_sincw: built by the device with these very operations); the walk
+					// stands on multiples of 1/512, so f * 512 is a whole number -- a position that is not (a non-finite
+					// correlation value upstream) lands on some row and its burst decodes to garbage either way
+					const int fi = (int)(f * 512.0f) & 511;
+					struct W3 { float a, b, c; };
+					const W3 wt = *reinterpret_cast<const W3 *>(&g_sincw[fi][3 * isub]);
+					w0 = wt.a; w1 = wt.b; w2 = wt.c;
+				}
 				const bool v0 = has_taps && (uint32_t)i0 < wlim;
 				const bool v1 = has_taps && (uint32_t)(i0 + 1) < wlim;
 				const bool v2 = has_taps && (uint32_t)(i0 + 2) < wlim;
@@ -3225,6 +3320,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	// in this XCD's L2, burst 0's is long gone from it
 	// (two bursts ahead of their use: asking for all four at once was measured and is no faster)
 	Sym4 first, second;
+	int first_q = -1;                                  // QX: the mis-speculated burst whose samples `first` holds
 
 	// =========================== rows: sync symbols, frequency, phase ===========================
 	const int nbits_r = F::nbits(bt_r);
@@ -3293,7 +3389,15 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		if constexpr (LAT) {
 			if constexpr (PART == 0)
 				fetch(0, first);        // the one burst's kept samples travel during the whole sync-term phase
-		} else if constexpr (!QX) {
+		} else if constexpr (QX) {
+			// the (rare) burst whose pick is not the speculated one: its kept samples travel during the rest of this phase (the last
+			// such burst of the wave; a second one in the same wave waits for its samples in pass 2)
+			const unsigned long long mb = __ballot(found_r && !hit_r && row_live);       // (row-uniform: bit 16 q speaks for burst q)
+			const unsigned missm = (unsigned)((mb & 1ull) | ((mb >> 15) & 2ull) | ((mb >> 30) & 4ull) | ((mb >> 45) & 8ull));
+			first_q = missm ? 31 - __builtin_clz(missm) : -1;
+			if (first_q >= 0)
+				fetch(first_q, first);
+		} else {
 			fetch(3, first);
 			fetch(2, second);
 		}
@@ -3424,8 +3528,13 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const int src = 16 * q;
 		const bool hit = QX && __builtin_amdgcn_readlane((int)hit_r, src) != 0;
 		if constexpr (QX) {
-			if (!hit && __builtin_amdgcn_readlane((int)found_r, src) != 0)
-				fetch(q, cur);          // the pick is not the speculated one: this burst's kept samples come from memory
+			if (!hit && __builtin_amdgcn_readlane((int)found_r, src) != 0) {
+				// the pick is not the speculated one: this burst's kept samples come from memory
+				if (q == first_q)
+					cur = first;
+				else
+					fetch(q, cur);
+			}
 		}
 		const bool found = __builtin_amdgcn_readlane((int)found_r, src) != 0;
 		const int kind = __builtin_amdgcn_readlane(kind_r, src);

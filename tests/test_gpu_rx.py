@@ -21,13 +21,14 @@ def _compare_fused(got, ref, wl, *, label):
     # early/late bisection can take the other branch on a near tie, so toa may also differ by
     # a few steps of 1/1024 without flipping the pick; both must stay rare and small
     assert dtoa.max() < 16.0 / 1024.0, f"{label}: toa differs by {dtoa.max()}"
-    assert flip.mean() <= 0.01, f"{label}: {flip.sum()} / {n} sample-pick flips"
+    # (DESIGN.md section 6 measures 0 ... 0.25 % over sps 2 ... 16: twice that is the bound, so a regression shows)
+    assert flip.mean() <= 0.005, f"{label}: {flip.sum()} / {n} sample-pick flips"
     # at >= 4 samples per symbol everything behind the timing depends on the pick round(toa) alone (pi4cxpsk.c:292-295):
     # soft symbols, frequency error and soft bits are compared on EVERY burst whose pick did not flip; bursts whose toa
     # differs by a bisection step or two without flipping must be rare
     near = (dtoa != 0) & ~flip
     print(f"{label}: toa differs without a flip on {near.mean():.4f} of the bursts, picks flipped on {flip.mean():.4f}")
-    assert near.mean() < 0.01, f"{label}: toa differs on {near.mean():.4f} of the bursts"
+    assert near.mean() < 0.005, f"{label}: toa differs on {near.mean():.4f} of the bursts"
     same = ~flip
     dss = np.abs(got["ssyms"][same] - ref["ssyms"][same])
     # phase wraps at +-2 (QPSK soft symbol range): compare modulo 4

@@ -17,10 +17,24 @@ for f in files:
             continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         grid[k] = (int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+# kernel durations of the same run (rocprofv3 --kernel-trace writes them beside the counters)
+dur = defaultdict(list)
+for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if match and match not in k:
+            continue
+        try:
+            dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        except (KeyError, ValueError):
+            pass
 for k, cs in acc.items():
     g, wg = grid[k]
     waves = g // 64
     print(f"{k[:80]}  grid={g} wg={wg} waves={waves}")
+    if dur.get(k):
+        d = sorted(dur[k])
+        print(f"  {'avg_duration_ns':28s} {sum(d) / len(d):16.1f}  median {d[len(d) // 2]:10.1f}  (n={len(d)}, under the counter collection)")
     for c, v in sorted(cs.items()):
         m = sum(v) / len(v)
         print(f"  {c:28s} {m:16.1f}  per wave {m / max(waves, 1):10.1f}  (n={len(v)})")
