@@ -1,5 +1,6 @@
 // capi_fcch.cpp -- C-ABI entry points of the FCCH acquisition kernels.
 #include "capi_common.h"
+#include "profile_env.h"
 #include "fcch_acq.h"
 
 using namespace gmr1;
@@ -65,6 +66,41 @@ int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq,
 	a.tile_best = reinterpret_cast<float *>(static_cast<char *>(ws) + b_dec + b_par);
 	a.energy = energy; a.energy_stride = energy_stride;
 	a.toa = toa; a.rv = rv;
+	// the folded sweep's statistics records: a buffer of its own (per device, grow-only, zeroed when made), written by these
+	// kernels only, so that a record carrying this launch's epoch can only be this launch's.  Under the workspace lease: one
+	// sweep at a time per device.
+	{
+		struct FoldBuf { float *p = nullptr; size_t bytes = 0; uint32_t epoch = 0; };
+		static FoldBuf fold_of[64];
+		int dev = 0;
+		HIP_TRY(hipGetDevice(&dev));
+		if (dev >= 0 && dev < 64 && a.n_stat_tiles == a.n_lag_tiles) {
+			FoldBuf &fb = fold_of[dev];
+			const size_t need = (size_t)n * a.n_stat_tiles * 16;
+			if (fb.bytes < need) {
+				// (a sweep of an earlier call may still be polling the old buffer)
+				HIP_TRY(hipDeviceSynchronize());
+				if (fb.p) HIP_TRY(hipFree(fb.p));
+				fb.p = nullptr; fb.bytes = 0;
+				const size_t cap = need + need / 2;
+				HIP_TRY(hipMalloc(&fb.p, cap));
+				HIP_TRY(hipMemset(fb.p, 0, cap));
+				fb.bytes = cap;
+				fb.epoch = 0;
+			}
+			if (++fb.epoch == 0) {                     // (once in four billion sweeps)
+				HIP_TRY(hipDeviceSynchronize());
+				HIP_TRY(hipMemset(fb.p, 0, fb.bytes));
+				fb.epoch = 1;
+			}
+			a.fold_partial = fb.p;
+			a.epoch = fb.epoch;
+			// (a poll is a coherent 16-byte load and a short sleep, a microsecond or two: the bound is some tens of milliseconds.
+			// Profiling build: GMR1_HIP_FCCH_FOLD_POLLS=0 makes every tile give up at once -- the fallback path, for the tests)
+			static const int polls = [] { const char *e = profile_env("GMR1_HIP_FCCH_FOLD_POLLS"); return e ? atoi(e) : 1 << 14; }();
+			a.fold_polls = polls;
+		}
+	}
 	HIP_TRY(launch_fcch_rough_tail(a, ntaps, tl, st));
 	return 0;
 }

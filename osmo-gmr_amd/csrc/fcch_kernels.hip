@@ -368,7 +368,7 @@ __device__ __forceinline__ FoldRec fold_read(const float *rec)
 	return {__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), v.w};
 }
 constexpr float kFoldGaveUp = -2.0f;            // tile_best[0] of a tile whose wait ran out (a window's energy is never negative)
-constexpr int kFoldMaxTiles = 64, kFoldPolls = 1 << 15;
+constexpr int kFoldMaxTiles = 64;
 
 __device__ inline void fcch_pick_body(const FcchRoughArgs &a, const AcqTail &tl, int s, int lane);      // (below)
 constexpr int kPickStreams = 1 << 16;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, A
 			const float *rec = a.fold_partial + ((size_t)s * a.n_stat_tiles + (lane < a.n_stat_tiles ? lane : 0)) * 4;
 			FoldRec r = {0.f, 0.f, 0.f, 0u};
 			bool have = false;
-			for (int poll = 0; poll < kFoldPolls; poll++) {
+			for (int poll = 0; poll < a.fold_polls; poll++) {
 				r = fold_read(rec);
 				have = __ballot(lane < a.n_stat_tiles && r.epoch != a.epoch) == 0;
 				if (have)
@@ -769,6 +769,13 @@ __global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnerg
 	const int ndec = a.len / a.sps;
 	const int nlags = ndec - NT + 1;
 	const float fs = a.freq_shift ? a.freq_shift[s] : 0.0f;
+	// behind a folded sweep: is any of this work-group's tiles left?  (the marks were written by the launch before: plain loads)
+	bool todo = !fold;
+	if (fold) {
+		for (int tile = blockIdx.x * kEnergyTiles; tile < min(((int)blockIdx.x + 1) * kEnergyTiles, a.n_lag_tiles); tile++)
+			todo = todo || a.tile_best[((size_t)s * a.n_lag_tiles + tile) * 8] == kFoldGaveUp;
+	}
+	if (todo) {
 	if (wv == 0) {
 		double dr = 0.0, di = 0.0, dq = 0.0;
 		for (int t = lane; t < a.n_stat_tiles; t += 64) {
@@ -805,6 +812,8 @@ __global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnerg
 	const float2 *__restrict__ acc = a.dec + (size_t)s * a.dec_stride;
 	// (kEnergyTiles lag tiles per work-group: the statistics above are formed once for them)
 	for (int tile = blockIdx.x * kEnergyTiles; tile < min(((int)blockIdx.x + 1) * kEnergyTiles, a.n_lag_tiles); tile++) {
+	if (fold && a.tile_best[((size_t)s * a.n_lag_tiles + tile) * 8] != kFoldGaveUp)
+		continue;                                   // (uniform: the sweep finished this tile itself)
 	const int m0 = tile * kTileStep;
 	__syncthreads();
 	// two lags per lane and load: 16 bytes (the stream's array, the tile's first lag and 2 tid are all even)
@@ -870,18 +879,23 @@ __global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnerg
 		}
 	}
 	}
+	}
 	if (!pick)
 		return;
-	// the stream's last work-group picks (thread 0 wrote this group's tiles: its fence, then its count)
+	// the stream's last work-group picks (thread 0 wrote this group's tiles: its fence, then its count); behind a folded sweep
+	// only if that left the pick here (bit 31 of the count: one of its tiles had given up)
 	if (tid == 0) {
 		__threadfence();
-		s_last = atomicAdd(&g_pick_count[s], 1u) == gridDim.x - 1 ? 1 : 0;
+		const unsigned prev = atomicAdd(&g_pick_count[s], 1u);
+		s_last = (prev & 0x7fffffffu) == gridDim.x - 1 ? ((!fold || (prev & 0x80000000u)) ? 1 : 2) : 0;
 	}
 	__syncthreads();
 	if (!s_last || wv != 0)
 		return;
 	if (lane == 0)
 		g_pick_count[s] = 0;
+	if (s_last == 2)
+		return;
 	__threadfence();
 	fcch_pick_body(a, tl, s, lane);
 }
@@ -1412,7 +1426,10 @@ template <int NT>
 static hipError_t launch_sweep(const FcchRoughArgs &a, const AcqTail &tl, hipStream_t st)
 {
 	static_assert(SweepDims<NT>::lds <= 64 * 1024, "above the default dynamic LDS limit the launch would need hipFuncSetAttribute");
-	hipLaunchKernelGGL((k_fcch_sweep<NT>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
+	// the folded form (the tile finishes its lags itself: k_fcch_sweep<NT, true>) wherever a stream's records fit one wave's
+	// poll; the profiling build keeps the other for the comparison (GMR1_HIP_FCCH_UNFOLDED)
+	static const bool unfolded = profile_env("GMR1_HIP_FCCH_UNFOLDED") != nullptr;
+	const bool fold = !unfolded && a.fold_partial && a.n_stat_tiles <= kFoldMaxTiles && a.n_stat_tiles == a.n_lag_tiles;
 	const int tiles = (long long)a.n_lag_tiles * a.n >= 4096 ? 4 : 1;
 	// Small launches (the receive loop's acquisition: their latency is what counts): the stream's last work-group picks its
 	// best tile itself, one launch fewer.  Not for the large ones: the device-scope fence in front of the count writes the
@@ -1420,7 +1437,12 @@ static hipError_t launch_sweep(const FcchRoughArgs &a, const AcqTail &tl, hipStr
 	// 1024 streams of 93 600 samples, measured; already at 2 048 work-groups -- 512 carriers' 330 ms windows -- it costs
 	// 40 us where the launch of its own costs 7).
 	const int pick = (a.toa && (long long)a.n_lag_tiles * a.n <= 512 && a.n <= kPickStreams) ? 1 : 0;
-	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles, pick, tl);
+	if (fold)
+		hipLaunchKernelGGL((k_fcch_sweep<NT, true>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a, pick, tl);
+	else
+		hipLaunchKernelGGL((k_fcch_sweep<NT, false>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a, 0, tl);
+	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles, pick, tl,
+	                   fold ? 1 : 0);
 	if (a.toa && !pick)
 		hipLaunchKernelGGL(k_fcch_pick, dim3(a.n), dim3(64), 0, st, a, tl);
 	return hipGetLastError();

@@ -180,6 +180,7 @@ struct FcchRoughArgs {
 	// the folded sweep (k_fcch_sweep<NT, true>): every tile's statistics partial is a 16-byte record {sum re, sum im, sum |x|^2,
 	// epoch} in a buffer only these kernels write, so a record carrying THIS launch's epoch is this launch's
 	float *fold_partial;  uint32_t epoch;
+	int fold_polls;                          // how often a tile looks for the stream's records before it gives up
 };
 
 struct FcchMultiArgs {

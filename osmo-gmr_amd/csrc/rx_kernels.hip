@@ -38,6 +38,7 @@
 //     state's 32-bit word is [metric:16 | decisions of the current 16-step window:16]; v_min_u32
 //     does compare, select, tie-break and decision recording at once (see decode4_k5_12).
 #include <mutex>
+#include <type_traits>
 
 #include "gmr1_dev.h"
 #include "tch3_body.h"
@@ -3084,7 +3085,12 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 		const bool has_taps = isub != 7;
 		const uint32_t wlim = (uint32_t)(w_p - 1);
 		// -> acc: the lane's own half-row sum (at `pos` in lanes 0-7, at `pos + 2` in lanes 8-15), oth: the other half's
-		auto interp2 = [&](float pos, float &acc_o, float &oth_o) {
+		// (guard: the weight 1 within 0.01 of a whole tap, osmo_sinc's small-argument case.  The walk's levels stand on odd
+		// multiples of 1/2 ... 1/256, at least pi / 256 = 0.0123 from every tap: only the evaluation at the point reached --
+		// a multiple of 1/512 -- can come that close, so the eight evaluations of the walk go without the two compares and the
+		// select per tap)
+		auto interp2 = [&](float pos, float &acc_o, float &oth_o, auto guard_tag) {
+			constexpr bool GUARD = decltype(guard_tag)::value;
 			const float fl = floorf(pos);
 			const int ib = (int)fl + 2 * ipt;
 			const float f = pos - fl;
@@ -3100,7 +3106,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const int k = isub - ib;
 				const float sg = (k & 1) ? S : -S;
 				const float xx = kPif * ((float)k - f);
-				const float wgt = (xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
+				const float wgt = (!GUARD || xx >= 0.01f || xx <= -0.01f) ? sg * __builtin_amdgcn_rcpf(xx) : 1.0f;
 				const bool valid = isub >= b && isub < e;          // (|k| <= 10 follows from b and e)
 				const float c = cr[isub];
 				acc = valid ? c * wgt : 0.0f;
@@ -3114,9 +3120,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				if constexpr (LAT || !GMR1_EXP_SINC_TABLE) {
 					const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
 					const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
-					w0 = (x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
-					w1 = (x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
-					w2 = (x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
+					w0 = (!GUARD || x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
+					w1 = (!GUARD || x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
+					w2 = (!GUARD || x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
 				} else {
 					// the same three weights out of the table (g_sincw: built by the device with these very operations); the walk
 					// stands on multiples of 1/512, so f * 512 is a whole number -- a position that is not (a non-finite
@@ -3222,7 +3228,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			toa_s = early + 1.0f;
 			GMR1_STAMP(9);
 			float pa, po;
-			interp2(toa_s, pa, po);
+			interp2(toa_s, pa, po, std::true_type{});
 			pk_s = ipt ? po : pa;
 		} else {
 			// early energy ee > late energy le: early -= incr, ee < le: early += incr.  Lanes 8-15 hold the late sum as their
@@ -3244,7 +3250,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	#pragma unroll 1
 			for (int it = 1; it < 9; it++) {              // incr = 0.25 ... 1/512 (> 1/1024)
 				float sa, so;
-				interp2(early, sa, so);
+				interp2(early, sa, so, std::false_type{});
 				const float ea = sa * sa, eo = so * so;
 				if (active) {
 					if (ea > eo) early -= sincr;
@@ -3255,7 +3261,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			}
 			toa_s = early + 1.0f;
 			float pa, po;
-			interp2(toa_s, pa, po);
+			interp2(toa_s, pa, po, std::true_type{});
 			pk_s = ipt ? po : pa;
 		}
 		pk_s = pk_s * __builtin_amdgcn_rcpf((float)tl_p);

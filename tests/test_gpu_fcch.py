@@ -122,3 +122,42 @@ def test_fcch_rough_multi(gpu_api, orc, pkg):
     noise = (rng.standard_normal(ns) + 1j * rng.standard_normal(ns)).astype(np.complex64)
     g = gpu_api.fcch_rough_multi_batch(noise, np.zeros(1, np.uint64), ns, sps=SPS)[0][0]
     assert g == orc.fcch_rough_multi(noise, SPS)[0]
+
+
+def test_folded_sweep_fallback_and_dc_offset(gpu_api, orc, pkg):
+    """The folded rough sweep (k_fcch_sweep<NT, true>: a tile finishes its own lags once every tile of the stream has published
+    its statistics) and its fallback.  (1) Streams with a DC offset much larger than the signal -- the mean's contribution to
+    every lag, the one thing a tile cannot know by itself, decides the peak here -- give the oracle's toa.  (2) The profiling
+    build with GMR1_HIP_FCCH_FOLD_POLLS=0 (every tile gives up at once and k_fcch_energy finishes the old way) and with
+    GMR1_HIP_FCCH_UNFOLDED=1 (the two-kernel form) give the same toa, in a child process each."""
+    import json
+    import os
+    import subprocess
+    import sys
+    n, ns = 6, 93600
+    x, _ = _streams(pkg, n, ns, seed=23)
+    x[1] += np.complex64(7.0 - 3.0j)                 # noise deviation ~ 1
+    x[2] += np.complex64(-40.0 + 25.0j)
+    x[4] *= np.float32(1e-3)
+    offset = (np.arange(n) * ns).astype(np.uint64)
+    toa, rv = gpu_api.fcch_rough_batch(x, offset, ns, sps=SPS)
+    assert not rv.any()
+    want = [orc.fcch_rough(x[i], SPS) for i in range(n)]
+    assert all(w[0] == 0 for w in want)
+    assert list(toa) == [w[1] for w in want]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "osmo-gmr_amd", "libgmr1_hip_prof.so")
+    if not os.path.exists(prof):
+        pytest.skip("the profiling build (python osmo-gmr_amd/build.py --profile) is not there")
+    np.save("/tmp/_fold_streams.npy", x)
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from __graft_entry__ import load_package; pkg = load_package(); "
+            "import torch; torch.cuda.init(); pkg.api.load(); pkg.api.init(0); x = np.load('/tmp/_fold_streams.npy'); "
+            "toa, rv = pkg.api.fcch_rough_batch(x, (np.arange(%d) * %d).astype(np.uint64), %d, sps=%d); "
+            "print(json.dumps([int(t) for t in toa] + [int(r) for r in rv]))" % (root, n, ns, ns, SPS))
+    for switch in ("GMR1_HIP_FCCH_FOLD_POLLS", "GMR1_HIP_FCCH_UNFOLDED"):
+        env = dict(os.environ, GMR1_HIP_LIBRARY=prof)
+        env[switch] = "0" if switch.endswith("POLLS") else "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = json.loads(r.stdout.strip().splitlines()[-1])
+        assert got == [int(t) for t in toa] + [0] * n, (switch, got)
