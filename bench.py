@@ -420,6 +420,10 @@ def run_rx_workload(args):
         out["projected_n8"] = {"carriers_per_gpu": A8, "rx_ms_per_gpu_measured_here": t8 * 1e3, "scatter_ms_at_153_GB_per_s_per_link": scatter_s * 1e3,
                                "total_ms": (t8 + scatter_s) * 1e3, "speedup_over_one_gpu": step_s / (t8 + scatter_s),
                                "speedup_without_scatter": step_s / t8,
+                               # the floor of ANY root scatter: 7/8 of the capture has to leave rank 0 over its seven links, so a
+                               # scatter chunked in time with the walk gated on arrival flags (not built) could at best hide the
+                               # loop under the transfer -- it cannot bring the exchange under the transfer's own time
+                               "total_ms_if_the_loop_ran_under_the_scatter": (max(t8, scatter_s) + scatter_s / max(args.seconds, 1.0)) * 1e3,
                                "note": "latency chain: the rounds of a carrier cannot be shortened by adding GPUs; 8 GPUs carry 8x the carriers in the same time (weak scaling), they do not finish these sooner"}
     emit(out)
 

@@ -70,30 +70,35 @@ int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq,
 	// kernels only, so that a record carrying this launch's epoch can only be this launch's.  Under the workspace lease: one
 	// sweep at a time per device.
 	{
-		struct FoldBuf { float *p = nullptr; size_t bytes = 0; uint32_t epoch = 0; };
+		// layout: [flag words, one per record slot of the buffer's capacity | 16-byte records]; slot = stream * tiles + tile.  The
+		// flag words only ever hold epochs (or the zero they were made with), so whatever geometry the last sweep had, a flag
+		// equal to THIS launch's epoch was written by this launch
+		struct FoldBuf { char *p = nullptr; size_t slots = 0; uint32_t epoch = 0; };
 		static FoldBuf fold_of[64];
 		int dev = 0;
 		HIP_TRY(hipGetDevice(&dev));
 		if (dev >= 0 && dev < 64 && a.n_stat_tiles == a.n_lag_tiles) {
 			FoldBuf &fb = fold_of[dev];
-			const size_t need = (size_t)n * a.n_stat_tiles * 16;
-			if (fb.bytes < need) {
+			const size_t n_rec = (size_t)n * a.n_stat_tiles;
+			auto bytes_of = [](size_t slots) { return ((slots * 4 + 255) & ~(size_t)255) + slots * 16; };
+			if (fb.slots < n_rec) {
 				// (a sweep of an earlier call may still be polling the old buffer)
 				HIP_TRY(hipDeviceSynchronize());
 				if (fb.p) HIP_TRY(hipFree(fb.p));
-				fb.p = nullptr; fb.bytes = 0;
-				const size_t cap = need + need / 2;
-				HIP_TRY(hipMalloc(&fb.p, cap));
-				HIP_TRY(hipMemset(fb.p, 0, cap));
-				fb.bytes = cap;
+				fb.p = nullptr; fb.slots = 0;
+				const size_t cap = n_rec + n_rec / 2;
+				HIP_TRY(hipMalloc(&fb.p, bytes_of(cap)));
+				HIP_TRY(hipMemset(fb.p, 0, bytes_of(cap)));
+				fb.slots = cap;
 				fb.epoch = 0;
 			}
 			if (++fb.epoch == 0) {                     // (once in four billion sweeps)
 				HIP_TRY(hipDeviceSynchronize());
-				HIP_TRY(hipMemset(fb.p, 0, fb.bytes));
+				HIP_TRY(hipMemset(fb.p, 0, bytes_of(fb.slots)));
 				fb.epoch = 1;
 			}
-			a.fold_partial = fb.p;
+			a.fold_flag = reinterpret_cast<uint32_t *>(fb.p);
+			a.fold_partial = reinterpret_cast<float *>(fb.p + ((fb.slots * 4 + 255) & ~(size_t)255));
 			a.epoch = fb.epoch;
 			// (a poll is a coherent 16-byte load and a short sleep, a microsecond or two: the bound is some tens of milliseconds.
 			// Profiling build: GMR1_HIP_FCCH_FOLD_POLLS=0 makes every tile give up at once -- the fallback path, for the tests)

@@ -344,29 +344,45 @@ struct SweepDims {
 // FOLD (streams of at most 64 tiles): the tile also does what k_fcch_energy did with its lags -- the normalisation applied,
 // |.|^2 per lag, the tile's best 5-lag window -- so that the raw correlation (8 bytes a lag written, and read back by the next
 // kernel) never leaves the chip.  The normalisation needs the mean and deviation of the WHOLE window, i.e. every tile's
-// partial sums: each tile publishes its own as ONE 16-byte coherent store {sum re, sum im, sum |x|^2, launch epoch} as soon as
-// it has read its samples -- before the matrix work, half the kernel's time --, and behind the matrix work reads the
-// stream's records with coherent loads until all of them carry this launch's epoch.  The tiles of a stream are consecutive
+// partial sums: each tile publishes its own with coherent stores -- {sum re, sum im, sum |x|^2}, then the launch's epoch in a
+// flag word -- as soon as it has read its samples, before the matrix work (half the kernel's time), and behind the matrix
+// work reads the stream's flags with coherent loads until all of them carry this launch's epoch.  The tiles of a stream are consecutive
 // work-groups and start together, so nothing waits in practice; the wait is BOUNDED all the same, and a tile that gives up
 // writes its raw correlation and a mark in its result slot, for k_fcch_energy (started behind every folded sweep; a tile
 // without the mark costs it one load) to finish the old way.
 // The sums behind the statistics are formed exactly as k_fcch_energy forms them (same partials, same order, in double); the
 // four lags a tile's windows share with the next tile are this tile's own here (the matrix product groups their taps
 // differently than the neighbour's: last bits).
-struct FoldRec { float sr, si, sq; uint32_t epoch; };
-__device__ __forceinline__ void fold_publish(float *rec, float sr, float si, float sq, uint32_t epoch)
+// (record first, flag second: the lane waits for the record's coherent stores to be acknowledged and only then stores the epoch
+// into the tile's flag word; a reader looks at the flags, and at the records once all flags are up -- nothing here depends on a
+// 16-byte store reaching memory as a whole)
+struct FoldRec { float sr, si, sq; };
+__device__ __forceinline__ void fold_publish(float *rec, uint32_t *flag, float sr, float si, float sq, uint32_t epoch)
 {
-	typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-	const u4 v = {__builtin_bit_cast(uint32_t, sr), __builtin_bit_cast(uint32_t, si), __builtin_bit_cast(uint32_t, sq), epoch};
-	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(rec), "v"(v) : "memory");
+	asm volatile("global_store_dword %0, %1, off sc0 sc1\n\tglobal_store_dword %0, %2, off offset:4 sc0 sc1\n\t"
+	             "global_store_dword %0, %3, off offset:8 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+	             :: "v"(rec), "v"(sr), "v"(si), "v"(sq) : "memory");
+	asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(flag), "v"(epoch) : "memory");
+}
+__device__ __forceinline__ uint32_t fold_flag(const uint32_t *flag)
+{
+	uint32_t v;
+	asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(flag) : "memory");
+	return v;
 }
 __device__ __forceinline__ FoldRec fold_read(const float *rec)
 {
-	typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-	u4 v;
-	asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(rec) : "memory");
-	return {__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z), v.w};
+	// (three 4-byte loads with a register each: a 16-byte inline-asm load into one vector operand came back with the compiler
+	// using its first word for all three sums -- seen in the ISA, and on streams whose mean matters)
+	uint32_t x, y, z;
+	asm volatile("global_load_dword %0, %3, off sc0 sc1\n\tglobal_load_dword %1, %3, off offset:4 sc0 sc1\n\t"
+	             "global_load_dword %2, %3, off offset:8 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+	             : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(rec) : "memory");
+	return {__builtin_bit_cast(float, x), __builtin_bit_cast(float, y), __builtin_bit_cast(float, z)};
 }
+#ifdef GMR1_HIP_PROFILE
+__device__ float g_fold_dbg[2][64][4];         // stream 1's statistics as the folded sweep's tiles [0] / k_fcch_energy's groups [1] formed them
+#endif
 constexpr float kFoldGaveUp = -2.0f;            // tile_best[0] of a tile whose wait ran out (a window's energy is never negative)
 constexpr int kFoldMaxTiles = 64;
 
@@ -473,7 +489,8 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, A
 		float *p = a.partial + ((size_t)s * a.n_stat_tiles + tile) * 4;
 		p[0] = p0; p[1] = p1; p[2] = p2; p[3] = 0.f;
 		if constexpr (FOLD)
-			fold_publish(a.fold_partial + ((size_t)s * a.n_stat_tiles + tile) * 4, p0, p1, p2, a.epoch);
+			fold_publish(a.fold_partial + ((size_t)s * a.n_stat_tiles + tile) * 4, a.fold_flag + (size_t)s * a.n_stat_tiles + tile, p0, p1, p2,
+			             a.epoch);
 	}
 
 	// ---- raw correlation of lags m0 ... m0 + 2047: wave wv takes the sets wv and wv + 4 of 256 lags each
@@ -512,16 +529,16 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, A
 	if constexpr (FOLD) {
 		// ---- the window's statistics, once every tile's record carries this launch's epoch (wave 0; bounded)
 		if (wv == 0) {
-			const float *rec = a.fold_partial + ((size_t)s * a.n_stat_tiles + (lane < a.n_stat_tiles ? lane : 0)) * 4;
-			FoldRec r = {0.f, 0.f, 0.f, 0u};
+			const size_t slot = (size_t)s * a.n_stat_tiles + (lane < a.n_stat_tiles ? lane : 0);
 			bool have = false;
 			for (int poll = 0; poll < a.fold_polls; poll++) {
-				r = fold_read(rec);
-				have = __ballot(lane < a.n_stat_tiles && r.epoch != a.epoch) == 0;
+				have = __ballot(lane < a.n_stat_tiles && fold_flag(a.fold_flag + slot) != a.epoch) == 0;
 				if (have)
 					break;
 				__builtin_amdgcn_s_sleep(4);
 			}
+			// (behind the flags: every record was acknowledged before its flag went out)
+			const FoldRec r = fold_read(a.fold_partial + slot * 4);
 			// (k_fcch_energy's sums: lane t holds tile t's partial, the rest zero; the same butterfly in double)
 			double dr = lane < a.n_stat_tiles ? (double)r.sr : 0.0, di = lane < a.n_stat_tiles ? (double)r.si : 0.0,
 			       dq = lane < a.n_stat_tiles ? (double)r.sq : 0.0;
@@ -547,6 +564,12 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, A
 				s_stat[0] = (float)ar * rr - (float)ai * ri;
 				s_stat[1] = (float)ar * ri + (float)ai * rr;
 				s_have = have ? 1 : 0;
+#ifdef GMR1_HIP_PROFILE
+				if (s == 1 && tile < 64) {
+					g_fold_dbg[0][tile][0] = s_stat[0]; g_fold_dbg[0][tile][1] = s_stat[1]; g_fold_dbg[0][tile][2] = s_stat[2];
+					g_fold_dbg[0][tile][3] = (float)dr;
+				}
+#endif
 			}
 		}
 		__syncthreads();                                  // (also: every wave is through with the staged samples)
@@ -805,6 +828,12 @@ __global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnerg
 			// mu * sum_n r[n] e^{j fs n}
 			s_stat[0] = (float)ar * rr - (float)ai * ri;
 			s_stat[1] = (float)ar * ri + (float)ai * rr;
+#ifdef GMR1_HIP_PROFILE
+			if (s == 1 && blockIdx.x < 64) {
+				g_fold_dbg[1][blockIdx.x][0] = s_stat[0]; g_fold_dbg[1][blockIdx.x][1] = s_stat[1]; g_fold_dbg[1][blockIdx.x][2] = s_stat[2];
+				g_fold_dbg[1][blockIdx.x][3] = (float)dr;
+			}
+#endif
 		}
 	}
 	__syncthreads();
@@ -1407,6 +1436,15 @@ __global__ __launch_bounds__(256) void k_fcch_multi(FcchMultiArgs a, AcqTail tl)
 	}
 }
 
+#ifdef GMR1_HIP_PROFILE
+}  // namespace gmr1
+extern "C" int gmr1_hip_prof_fold_dbg(float *out512)
+{
+	return hipDeviceSynchronize() == hipSuccess &&
+	       hipMemcpyFromSymbol(out512, HIP_SYMBOL(gmr1::g_fold_dbg), sizeof(gmr1::g_fold_dbg)) == hipSuccess ? 0 : -5;
+}
+namespace gmr1 {
+#endif
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
