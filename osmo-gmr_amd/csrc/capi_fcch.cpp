@@ -70,9 +70,8 @@ int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq,
 	// kernels only, so that a record carrying this launch's epoch can only be this launch's.  Under the workspace lease: one
 	// sweep at a time per device.
 	{
-		// layout: [flag words, one per record slot of the buffer's capacity | 16-byte records]; slot = stream * tiles + tile.  The
-		// flag words only ever hold epochs (or the zero they were made with), so whatever geometry the last sweep had, a flag
-		// equal to THIS launch's epoch was written by this launch
+		// 32 bytes a record slot, slot = stream * tiles + tile; the epoch words only ever hold epochs (or the zero they were made
+		// with), so whatever geometry the last sweep had, a word carrying THIS launch's epoch was written by this launch
 		struct FoldBuf { char *p = nullptr; size_t slots = 0; uint32_t epoch = 0; };
 		static FoldBuf fold_of[64];
 		int dev = 0;
@@ -80,27 +79,25 @@ int rough_dev(hipStream_t st, int tab, int n, int sps, int len, const float *iq,
 		if (dev >= 0 && dev < 64 && a.n_stat_tiles == a.n_lag_tiles) {
 			FoldBuf &fb = fold_of[dev];
 			const size_t n_rec = (size_t)n * a.n_stat_tiles;
-			auto bytes_of = [](size_t slots) { return ((slots * 4 + 255) & ~(size_t)255) + slots * 16; };
 			if (fb.slots < n_rec) {
 				// (a sweep of an earlier call may still be polling the old buffer)
 				HIP_TRY(hipDeviceSynchronize());
 				if (fb.p) HIP_TRY(hipFree(fb.p));
 				fb.p = nullptr; fb.slots = 0;
 				const size_t cap = n_rec + n_rec / 2;
-				HIP_TRY(hipMalloc(&fb.p, bytes_of(cap)));
-				HIP_TRY(hipMemset(fb.p, 0, bytes_of(cap)));
+				HIP_TRY(hipMalloc(&fb.p, cap * 32));
+				HIP_TRY(hipMemset(fb.p, 0, cap * 32));
 				fb.slots = cap;
 				fb.epoch = 0;
 			}
 			if (++fb.epoch == 0) {                     // (once in four billion sweeps)
 				HIP_TRY(hipDeviceSynchronize());
-				HIP_TRY(hipMemset(fb.p, 0, bytes_of(fb.slots)));
+				HIP_TRY(hipMemset(fb.p, 0, fb.slots * 32));
 				fb.epoch = 1;
 			}
-			a.fold_flag = reinterpret_cast<uint32_t *>(fb.p);
-			a.fold_partial = reinterpret_cast<float *>(fb.p + ((fb.slots * 4 + 255) & ~(size_t)255));
+			a.fold_partial = reinterpret_cast<float *>(fb.p);
 			a.epoch = fb.epoch;
-			// (a poll is a coherent 16-byte load and a short sleep, a microsecond or two: the bound is some tens of milliseconds.
+			// (a poll is three coherent 8-byte loads and a short sleep, a microsecond or two: the bound is some tens of milliseconds.
 			// Profiling build: GMR1_HIP_FCCH_FOLD_POLLS=0 makes every tile give up at once -- the fallback path, for the tests)
 			static const int polls = [] { const char *e = profile_env("GMR1_HIP_FCCH_FOLD_POLLS"); return e ? atoi(e) : 1 << 14; }();
 			a.fold_polls = polls;

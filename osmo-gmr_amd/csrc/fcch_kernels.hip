@@ -341,44 +341,41 @@ struct SweepDims {
 	static constexpr size_t lds = (size_t)pad16(NS) * 8 + (size_t)RT * 4;
 };
 
-// FOLD (streams of at most 64 tiles): the tile also does what k_fcch_energy did with its lags -- the normalisation applied,
+// FOLD (large launches of streams of at most 64 tiles; the receive loop's acquisition -- a few hundred work-groups whose LATENCY
+// counts -- keeps the two-kernel form: a folded tile spends two coherent store round trips before its matrix work and two
+// coherent load round trips behind it, 14 us more on a 10 us kernel, measured): the tile also does what k_fcch_energy did with its lags -- the normalisation applied,
 // |.|^2 per lag, the tile's best 5-lag window -- so that the raw correlation (8 bytes a lag written, and read back by the next
 // kernel) never leaves the chip.  The normalisation needs the mean and deviation of the WHOLE window, i.e. every tile's
-// partial sums: each tile publishes its own with coherent stores -- {sum re, sum im, sum |x|^2}, then the launch's epoch in a
-// flag word -- as soon as it has read its samples, before the matrix work (half the kernel's time), and behind the matrix
-// work reads the stream's flags with coherent loads until all of them carry this launch's epoch.  The tiles of a stream are consecutive
+// partial sums: each tile publishes its own with coherent stores -- sum re, sum im, sum |x|^2, each word with the launch's
+// epoch beside it -- as soon as it has read its samples, before the matrix work (half the kernel's time), and behind the
+// matrix work reads the stream's records with coherent loads until every word of them carries this launch's epoch.  The tiles of a stream are consecutive
 // work-groups and start together, so nothing waits in practice; the wait is BOUNDED all the same, and a tile that gives up
 // writes its raw correlation and a mark in its result slot, for k_fcch_energy (started behind every folded sweep; a tile
 // without the mark costs it one load) to finish the old way.
 // The sums behind the statistics are formed exactly as k_fcch_energy forms them (same partials, same order, in double); the
 // four lags a tile's windows share with the next tile are this tile's own here (the matrix product groups their taps
 // differently than the neighbour's: last bits).
-// (record first, flag second: the lane waits for the record's coherent stores to be acknowledged and only then stores the epoch
-// into the tile's flag word; a reader looks at the flags, and at the records once all flags are up -- nothing here depends on a
-// 16-byte store reaching memory as a whole)
-struct FoldRec { float sr, si, sq; };
-__device__ __forceinline__ void fold_publish(float *rec, uint32_t *flag, float sr, float si, float sq, uint32_t epoch)
+// (every word carries its epoch: the three sums go out as three 8-byte coherent stores {value, epoch} -- an aligned 8-byte store
+// of one lane is one transaction --, fire and forget: the publishing wave does not wait for them, and a reader needs ONE round
+// trip to see whether all three words of a record are this launch's)
+struct FoldRec { float sr, si, sq; bool ok; };
+__device__ __forceinline__ void fold_publish(float *rec, float sr, float si, float sq, uint32_t epoch)
 {
-	asm volatile("global_store_dword %0, %1, off sc0 sc1\n\tglobal_store_dword %0, %2, off offset:4 sc0 sc1\n\t"
-	             "global_store_dword %0, %3, off offset:8 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-	             :: "v"(rec), "v"(sr), "v"(si), "v"(sq) : "memory");
-	asm volatile("global_store_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" :: "v"(flag), "v"(epoch) : "memory");
+	const unsigned long long a = (unsigned long long)__builtin_bit_cast(uint32_t, sr) | ((unsigned long long)epoch << 32);
+	const unsigned long long b = (unsigned long long)__builtin_bit_cast(uint32_t, si) | ((unsigned long long)epoch << 32);
+	const unsigned long long c = (unsigned long long)__builtin_bit_cast(uint32_t, sq) | ((unsigned long long)epoch << 32);
+	asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\tglobal_store_dwordx2 %0, %2, off offset:8 sc0 sc1\n\t"
+	             "global_store_dwordx2 %0, %3, off offset:16 sc0 sc1"
+	             :: "v"(rec), "v"(a), "v"(b), "v"(c) : "memory");
 }
-__device__ __forceinline__ uint32_t fold_flag(const uint32_t *flag)
+__device__ __forceinline__ FoldRec fold_read(const float *rec, uint32_t epoch)
 {
-	uint32_t v;
-	asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(flag) : "memory");
-	return v;
-}
-__device__ __forceinline__ FoldRec fold_read(const float *rec)
-{
-	// (three 4-byte loads with a register each: a 16-byte inline-asm load into one vector operand came back with the compiler
-	// using its first word for all three sums -- seen in the ISA, and on streams whose mean matters)
-	uint32_t x, y, z;
-	asm volatile("global_load_dword %0, %3, off sc0 sc1\n\tglobal_load_dword %1, %3, off offset:4 sc0 sc1\n\t"
-	             "global_load_dword %2, %3, off offset:8 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-	             : "=&v"(x), "=&v"(y), "=&v"(z) : "v"(rec) : "memory");
-	return {__builtin_bit_cast(float, x), __builtin_bit_cast(float, y), __builtin_bit_cast(float, z)};
+	unsigned long long a, b, c;
+	asm volatile("global_load_dwordx2 %0, %3, off sc0 sc1\n\tglobal_load_dwordx2 %1, %3, off offset:8 sc0 sc1\n\t"
+	             "global_load_dwordx2 %2, %3, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+	             : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(rec) : "memory");
+	const bool ok = (uint32_t)(a >> 32) == epoch && (uint32_t)(b >> 32) == epoch && (uint32_t)(c >> 32) == epoch;
+	return {__builtin_bit_cast(float, (uint32_t)a), __builtin_bit_cast(float, (uint32_t)b), __builtin_bit_cast(float, (uint32_t)c), ok};
 }
 #ifdef GMR1_HIP_PROFILE
 __device__ float g_fold_dbg[2][64][4];         // stream 1's statistics as the folded sweep's tiles [0] / k_fcch_energy's groups [1] formed them
@@ -391,7 +388,7 @@ constexpr int kPickStreams = 1 << 16;
 __device__ unsigned int g_pick_count[kPickStreams];      // work-groups of the stream that are through (back to 0 by the last one)
 
 template <int NT, bool FOLD = false>
-__global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, AcqTail tl)
+__global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a)
 {
 	typedef SweepDims<NT> D;
 	extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -489,8 +486,7 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, A
 		float *p = a.partial + ((size_t)s * a.n_stat_tiles + tile) * 4;
 		p[0] = p0; p[1] = p1; p[2] = p2; p[3] = 0.f;
 		if constexpr (FOLD)
-			fold_publish(a.fold_partial + ((size_t)s * a.n_stat_tiles + tile) * 4, a.fold_flag + (size_t)s * a.n_stat_tiles + tile, p0, p1, p2,
-			             a.epoch);
+			fold_publish(a.fold_partial + ((size_t)s * a.n_stat_tiles + tile) * 8, p0, p1, p2, a.epoch);
 	}
 
 	// ---- raw correlation of lags m0 ... m0 + 2047: wave wv takes the sets wv and wv + 4 of 256 lags each
@@ -530,15 +526,15 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, A
 		// ---- the window's statistics, once every tile's record carries this launch's epoch (wave 0; bounded)
 		if (wv == 0) {
 			const size_t slot = (size_t)s * a.n_stat_tiles + (lane < a.n_stat_tiles ? lane : 0);
+			FoldRec r = {0.f, 0.f, 0.f, false};
 			bool have = false;
 			for (int poll = 0; poll < a.fold_polls; poll++) {
-				have = __ballot(lane < a.n_stat_tiles && fold_flag(a.fold_flag + slot) != a.epoch) == 0;
+				r = fold_read(a.fold_partial + slot * 8, a.epoch);
+				have = __ballot(lane < a.n_stat_tiles && !r.ok) == 0;
 				if (have)
 					break;
 				__builtin_amdgcn_s_sleep(4);
 			}
-			// (behind the flags: every record was acknowledged before its flag went out)
-			const FoldRec r = fold_read(a.fold_partial + slot * 4);
 			// (k_fcch_energy's sums: lane t holds tile t's partial, the rest zero; the same butterfly in double)
 			double dr = lane < a.n_stat_tiles ? (double)r.sr : 0.0, di = lane < a.n_stat_tiles ? (double)r.si : 0.0,
 			       dq = lane < a.n_stat_tiles ? (double)r.sq : 0.0;
@@ -656,27 +652,6 @@ __global__ __launch_bounds__(256) void k_fcch_sweep(FcchRoughArgs a, int pick, A
 				}
 			}
 		}
-		if (!pick)
-			return;
-		// small launches: the stream's last work-group picks (as k_fcch_energy's did); a tile that gave up leaves the pick to
-		// the energy pass behind this launch
-		__shared__ int s_last;
-		if (tid == 0) {
-			__threadfence();
-			const unsigned prev = atomicAdd(&g_pick_count[s], folded ? 1u : 0x10000u);      // (high half: tiles that gave up)
-			s_last = (prev & 0xffffu) + (prev >> 16) == gridDim.x - 1 ? (int)(1 + (prev >> 16) + (folded ? 0 : 1)) : 0;
-		}
-		__syncthreads();
-		if (!s_last || wv != 0)
-			return;
-		if (s_last == 1) {
-			if (lane == 0)
-				g_pick_count[s] = 0;
-			__threadfence();
-			fcch_pick_body(a, tl, s, lane);
-		} else if (lane == 0) {
-			g_pick_count[s] = 0x80000000u;                  // some tile gave up: k_fcch_energy's last work-group picks (it resets)
-		}
 	}
 }
 
@@ -777,8 +752,7 @@ __device__ inline void acq_step4(const AcqArgs &a, int t, int ctoa, float cfe)
 // second half: the normalisation applied to the raw correlation, energies, the tile's best 5-lag window
 // (tiles: lag tiles per work-group -- several where there are thousands of them, so that the statistics are formed once for
 // all; one where the launch is small and its latency is what counts: the receive loop's acquisition)
-// (fold: behind a folded sweep -- only the tiles that gave up there are left to do; pick as ever for the small launches, but
-// only if the sweep's last work-group left it here)
+// (fold: behind a folded sweep -- only the tiles that gave up there are left to do)
 template <int NT>
 __global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnergyTiles, int pick, AcqTail tl, int fold)
 {
@@ -911,20 +885,17 @@ __global__ __launch_bounds__(256) void k_fcch_energy(FcchRoughArgs a, int kEnerg
 	}
 	if (!pick)
 		return;
-	// the stream's last work-group picks (thread 0 wrote this group's tiles: its fence, then its count); behind a folded sweep
-	// only if that left the pick here (bit 31 of the count: one of its tiles had given up)
+	// the stream's last work-group picks (thread 0 wrote this group's tiles: its fence, then its count); small launches only,
+	// which are never folded
 	if (tid == 0) {
 		__threadfence();
-		const unsigned prev = atomicAdd(&g_pick_count[s], 1u);
-		s_last = (prev & 0x7fffffffu) == gridDim.x - 1 ? ((!fold || (prev & 0x80000000u)) ? 1 : 2) : 0;
+		s_last = atomicAdd(&g_pick_count[s], 1u) == gridDim.x - 1 ? 1 : 0;
 	}
 	__syncthreads();
 	if (!s_last || wv != 0)
 		return;
 	if (lane == 0)
 		g_pick_count[s] = 0;
-	if (s_last == 2)
-		return;
 	__threadfence();
 	fcch_pick_body(a, tl, s, lane);
 }
@@ -1464,10 +1435,10 @@ template <int NT>
 static hipError_t launch_sweep(const FcchRoughArgs &a, const AcqTail &tl, hipStream_t st)
 {
 	static_assert(SweepDims<NT>::lds <= 64 * 1024, "above the default dynamic LDS limit the launch would need hipFuncSetAttribute");
-	// the folded form (the tile finishes its lags itself: k_fcch_sweep<NT, true>) wherever a stream's records fit one wave's
-	// poll; the profiling build keeps the other for the comparison (GMR1_HIP_FCCH_UNFOLDED)
+	// the folded form (the tile finishes its lags itself: k_fcch_sweep<NT, true>) for LARGE launches of streams whose records fit
+	// one wave's poll (small ones are latency-bound: see the kernel); the profiling build keeps the other for the comparison
+	// (GMR1_HIP_FCCH_UNFOLDED)
 	static const bool unfolded = profile_env("GMR1_HIP_FCCH_UNFOLDED") != nullptr;
-	const bool fold = !unfolded && a.fold_partial && a.n_stat_tiles <= kFoldMaxTiles && a.n_stat_tiles == a.n_lag_tiles;
 	const int tiles = (long long)a.n_lag_tiles * a.n >= 4096 ? 4 : 1;
 	// Small launches (the receive loop's acquisition: their latency is what counts): the stream's last work-group picks its
 	// best tile itself, one launch fewer.  Not for the large ones: the device-scope fence in front of the count writes the
@@ -1475,10 +1446,12 @@ static hipError_t launch_sweep(const FcchRoughArgs &a, const AcqTail &tl, hipStr
 	// 1024 streams of 93 600 samples, measured; already at 2 048 work-groups -- 512 carriers' 330 ms windows -- it costs
 	// 40 us where the launch of its own costs 7).
 	const int pick = (a.toa && (long long)a.n_lag_tiles * a.n <= 512 && a.n <= kPickStreams) ? 1 : 0;
+	const bool fold = !unfolded && (long long)a.n_lag_tiles * a.n > 512 && a.fold_partial && a.n_stat_tiles <= kFoldMaxTiles &&
+	                  a.n_stat_tiles == a.n_lag_tiles;
 	if (fold)
-		hipLaunchKernelGGL((k_fcch_sweep<NT, true>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a, pick, tl);
+		hipLaunchKernelGGL((k_fcch_sweep<NT, true>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
 	else
-		hipLaunchKernelGGL((k_fcch_sweep<NT, false>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a, 0, tl);
+		hipLaunchKernelGGL((k_fcch_sweep<NT, false>), dim3(a.n_lag_tiles, a.n), dim3(256), SweepDims<NT>::lds, st, a);
 	hipLaunchKernelGGL((k_fcch_energy<NT>), dim3((a.n_lag_tiles + tiles - 1) / tiles, a.n), dim3(256), 0, st, a, tiles, pick, tl,
 	                   fold ? 1 : 0);
 	if (a.toa && !pick)

@@ -177,9 +177,9 @@ struct FcchRoughArgs {
 	float *tile_best;  int n_lag_tiles;     // 8 floats per (stream, lag tile)
 	float *energy;  size_t energy_stride;   // optional |corr|^2 per lag
 	int32_t *toa, *rv;
-	// the folded sweep (k_fcch_sweep<NT, true>): every tile's statistics partial is a 16-byte record {sum re, sum im, sum |x|^2, -}
-	// and a flag word holding the epoch of the launch that wrote it, in a buffer only these kernels write
-	float *fold_partial;  uint32_t *fold_flag;  uint32_t epoch;
+	// the folded sweep (k_fcch_sweep<NT, true>): every tile's statistics partial is a 32-byte record {sum re, epoch, sum im, epoch,
+	// sum |x|^2, epoch, -, -} in a buffer only these kernels write: a word whose epoch is THIS launch's was written by this launch
+	float *fold_partial;  uint32_t epoch;
 	int fold_polls;                          // how often a tile looks for the stream's records before it gives up
 };
 

@@ -134,11 +134,12 @@ def test_folded_sweep_fallback_and_dc_offset(gpu_api, orc, pkg):
     import os
     import subprocess
     import sys
-    n, ns = 6, 93600
+    n, ns = 44, 93600                                # 44 x 12 tiles: a launch large enough to be folded (> 512 work-groups)
     x, _ = _streams(pkg, n, ns, seed=23)
     x[1] += np.complex64(7.0 - 3.0j)                 # noise deviation ~ 1
     x[2] += np.complex64(-40.0 + 25.0j)
     x[4] *= np.float32(1e-3)
+    x[43] += np.complex64(3.0 + 11.0j)
     offset = (np.arange(n) * ns).astype(np.uint64)
     toa, rv = gpu_api.fcch_rough_batch(x, offset, ns, sps=SPS)
     assert not rv.any()
