@@ -45,15 +45,6 @@
 
 namespace gmr1 {
 
-#ifndef GMR1_EXP_SINC_TABLE
-#define GMR1_EXP_SINC_TABLE 0       // (experiment, measured and dropped: 1 = the timing rows read their sinc weights from a 48 KB table built by the
-                                    // device instead of forming them -- 490 fewer vector instructions a wave, and nine dependent trips to the L2 in the
-                                    // one phase of the kernel that is a serial chain: the waves lived 6 % longer and the launch took as long as before)
-#endif
-#ifndef GMR1_EXP_SPEC5
-#define GMR1_EXP_SPEC5 0            // (experiment, measured and dropped: 1 = the strongest lag moved by a five-point early / late estimate -- 11.8 % instead of 15.1 % mis-speculated picks for 20 more vector instructions a burst)
-#endif
-
 #define WSYNC()                                                   \
 	do {                                                          \
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");    \
@@ -1854,43 +1845,8 @@ __global__ __launch_bounds__(64) void k_coef0(int first, int count)
 	g_coef0[sps][type][n] = v;
 }
 
-// The 21 sinc weights of osmo_cxvec_interpolate_point for every fractional position the early / late walk of the timing rows
-// can stand on (pi4cxpsk.c:240; the walk steps by 1/2, 1/4 ... 1/512 from a whole lag, so the fraction is f = fi / 512):
-// row fi = { w(k - f) : k = -10 .. 10 } and three zeros, w(x) = sin(pi x) / (pi x) formed EXACTLY as rx4_body's interp2 used to
-// form it on the spot -- sin(pi f) by v_sin_f32, sin(pi (k - f)) = -(-1)^k sin(pi f), a v_rcp_f32 reciprocal, the weight 1 within
-// 0.01 of a whole tap -- by the device itself (k_sincw), so that reading a weight gives the bits computing it gave.  What it
-// saves the rows: a sine, three reciprocals and a dozen multiplies, compares and selects per evaluation, nine evaluations a
-// sequence -- a lane's three taps are one 12-byte load from a 48 KB table every wave of the machine keeps reading.
-__device__ float g_sincw[512][24];
-
-__global__ __launch_bounds__(64) void k_sincw()
-{
-	const int fi = blockIdx.x, isub = (int)threadIdx.x;
-	if (isub >= 8)
-		return;
-	const float f = (float)fi * (1.0f / 512.0f);
-	const float S = __builtin_amdgcn_sinf(0.5f * f);       // sin(pi f)
-	const int k0 = 3 * isub - 10;
-	const float kf0 = (float)k0, kf1 = (float)(k0 + 1), kf2 = (float)(k0 + 2);
-	const uint32_t sgn0 = (isub & 1) ? 0u : 0x80000000u;
-	const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
-	const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
-	const float w0 = (x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
-	const float w1 = (x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
-	const float w2 = (x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
-	const bool has = isub != 7;                            // (lane 7 would hold taps 11, 12, 13)
-	g_sincw[fi][3 * isub] = has ? w0 : 0.0f;
-	g_sincw[fi][3 * isub + 1] = has ? w1 : 0.0f;
-	g_sincw[fi][3 * isub + 2] = has ? w2 : 0.0f;
-}
-
 hipError_t upload_types(const DevBurst *host, int first, int count, hipStream_t stream)
 {
-#if GMR1_EXP_SINC_TABLE
-	hipLaunchKernelGGL(k_sincw, dim3(512), dim3(64), 0, stream);     // (same stream: ordered before any burst kernel)
-	if (hipError_t e0 = hipGetLastError(); e0 != hipSuccess)
-		return e0;
-#endif
 	hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_types), host, sizeof(DevBurst) * (size_t)count,
 	                                      sizeof(DevBurst) * (size_t)first, hipMemcpyHostToDevice, stream);
 	if (e != hipSuccess)
@@ -1990,7 +1946,8 @@ __host__ __device__ inline size_t lds4_layout(int stage_samples, int cw, size_t 
                                               int ebrow = 432)
 {
 	// pass 1 keeps only the sync-chunk windows of the burst in LDS (everything else it needs is in
-	// registers; pass 2 re-reads from L2).  Decode-time data overlays all of it:
+	// registers; pass 2 takes its kept samples out of the window registers -- the fused sps-4 kernel -- or re-reads them).
+	// Decode-time data overlays all of it:
 	//   [stage | corr 4 x cw | coef]   during pass 1 and the timing rows
 	//   [bm | ubits | 4 soft-bit rows / window decisions]   from pass 2 on; during pass 2 itself the soft-bit
 	//   table (2 KB, g_sb_lut) sits where the branch metrics will go
@@ -2370,10 +2327,10 @@ __device__ __forceinline__ void lat_prepare(const RxArgs &a, uint64_t off, int k
 // write traffic -- which is how it was found).
 // PL (fused batch kernel at 4 samples per symbol only): the sample array is stored POLYPHASE-PLANAR -- sample s of the flat
 // array sits at iq[(s & 3) * plane_stride + (s >> 2)] (include/gmr1_hip.h, gmr1_hip_rx_bcch_ccch_batch_planar_dev).  Only
-// addresses change: lane l still holds samples l, l + 64, ... of the window in pass 1 (four runs of 16 consecutive
-// samples of one plane each per load instead of one run of 64), so every sum is formed in the same order and every
-// result is bit-identical; pass 2's 234 samples at stride 4 from sample d (pi4cxpsk.c:292-295) are 234 CONSECUTIVE
-// samples of plane (offset + d) & 3 -- 15 lines of 128 bytes instead of every line of the window.
+// addresses change: the window sits in registers in the same QUAD layout as the interleaved call's (lane l holds samples
+// 256 b + 4 l + c: place l + 64 b of plane c, a coalesced 512-byte load), so every sum is formed over the same samples in the
+// same order and every result is bit-identical; pass 2's 234 samples at stride 4 from sample d (pi4cxpsk.c:292-295) are 234
+// CONSECUTIVE samples of plane (offset + d) & 3 -- 15 lines of 128 bytes instead of every line of the window.
 // EBROW (GEN only): bytes between the four bursts' soft-bit rows in LDS.  432 holds any format; the kernel that decodes NT3
 // speech bursts right behind the demodulator (k_rx4g_tch3) packs its 212-byte rows at 216 to leave the decoder its tables.
 // PART (LAT only): 0 the whole burst; 1 its front -- pass 1, timing, sync-symbol terms; rv / toa / freq_err / energy to
@@ -2811,23 +2768,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const uint32_t m23 = max((uint32_t)__builtin_amdgcn_readlane((int)mx, 32), (uint32_t)__builtin_amdgcn_readlane((int)mx, 48));
 				const uint32_t M = max(m01, m23);
 				const unsigned long long holders = __ballot(cbest == M);
-				int d = __builtin_amdgcn_readlane(cbj, holders ? __builtin_ctzll(holders) : 0);           // 0 <= d < w <= 81
-#if GMR1_EXP_SPEC5
-				// ... moved by one lag where the magnitudes around it say the early / late walk will settle beyond the half-way point:
-				// the walk looks for the t at which the interpolated magnitudes at t - 1 and t + 1 balance; linearised at the
-				// strongest lag p that is t = p + 2 (c[p+1] - c[p-1]) / (2 c[p] - c[p+2] - c[p-2])  (lags outside the array count 0)
-				{
-					const int pm2 = d - 2;
-					const float cm2 = pm2 >= 0 ? corr[pm2 >= 0 ? pm2 : 0] : 0.0f, cm1 = d >= 1 ? corr[d >= 1 ? d - 1 : 0] : 0.0f;
-					const float c0 = corr[d];
-					const float cp1 = d + 1 < w ? corr[d + 1 < w ? d + 1 : d] : 0.0f, cp2 = d + 2 < w ? corr[d + 2 < w ? d + 2 : d] : 0.0f;
-					const float num = 2.0f * (cp1 - cm1), den = 2.0f * c0 - cp2 - cm2;
-					// |num / den| > 1/2 with den > 0  <=>  2 |num| > den
-					const int step = (den > 0.0f && 2.0f * fabsf(num) > den) ? (num > 0.0f ? 1 : -1) : 0;
-					d += __builtin_amdgcn_readfirstlane(step);
-					d = d < 0 ? 0 : (d >= w ? w - 1 : d);
-				}
-#endif
+				const int d = __builtin_amdgcn_readlane(cbj, holders ? __builtin_ctzll(holders) : 0);     // 0 <= d < w <= 81
 				// row q keeps what the rows below need of this burst at that pick: the normalised samples under its sync symbols
 				// (still staged) ...
 				if (row == q) {
@@ -3116,22 +3057,11 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				const int i0 = ib + k0;
 				const float *cp = cr + i0;
 				const float c0 = cp[0], c1 = cp[1], c2 = cp[2];
-				float w0, w1, w2;
-				if constexpr (LAT || !GMR1_EXP_SINC_TABLE) {
-					const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
-					const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
-					w0 = (!GUARD || x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
-					w1 = (!GUARD || x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
-					w2 = (!GUARD || x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
-				} else {
-					// the same three weights out of the table (g_sincw: built by the device with these very operations); the walk
-					// stands on multiples of 1/512, so f * 512 is a whole number -- a position that is not (a non-finite
-					// correlation value upstream) lands on some row and its burst decodes to garbage either way
-					const int fi = (int)(f * 512.0f) & 511;
-					struct W3 { float a, b, c; };
-					const W3 wt = *reinterpret_cast<const W3 *>(&g_sincw[fi][3 * isub]);
-					w0 = wt.a; w1 = wt.b; w2 = wt.c;
-				}
+				const float S0 = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, S) ^ sgn0);
+				const float x0 = kPif * (kf0 - f), x1 = kPif * (kf1 - f), x2 = kPif * (kf2 - f);
+				const float w0 = (!GUARD || x0 >= 0.01f || x0 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x0) : 1.0f;
+				const float w1 = (!GUARD || x1 >= 0.01f || x1 <= -0.01f) ? -S0 * __builtin_amdgcn_rcpf(x1) : 1.0f;
+				const float w2 = (!GUARD || x2 >= 0.01f || x2 <= -0.01f) ? S0 * __builtin_amdgcn_rcpf(x2) : 1.0f;
 				const bool v0 = has_taps && (uint32_t)i0 < wlim;
 				const bool v1 = has_taps && (uint32_t)(i0 + 1) < wlim;
 				const bool v2 = has_taps && (uint32_t)(i0 + 2) < wlim;
