@@ -1,4 +1,6 @@
-# Every number DESIGN.md quotes for a round, from one build in one gpurun call (GPU box, repo root): bash tools/final_measure.sh <tag>
+# Every number DESIGN.md quotes for a round, from one build (GPU box, repo root), in two gpurun calls of at most 20 minutes each:
+#   bash tools/final_measure.sh <tag>     traffic, bench lines, kernel statistics
+#   bash tools/final_measure_b.sh <tag>   SQ counters, phase times, the -m gpu suite, the N > 1 paths rehearsed on one GPU
 # Default decoder mode = ACC (the library's default); the generic mode is taken beside it on the same box.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 t=$1
@@ -31,22 +33,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats_chan -- python3
 cp $(ls $o/stats_chan/*/*kernel_stats.csv | head -1) $o/kernel_stats_chan.csv
 rm -rf $o/stats_bench $o/stats_nt3 $o/stats_rx $o/stats_fcch $o/stats_chan
 echo "stats done"
-# 4. SQ counters and per-phase times of the headline kernel (both layouts), SQ counters of the nt3 kernels
-for lay in interleaved planar; do
-  bash tools/pmc_rx4.sh ${t}_$lay --layout $lay > /dev/null 2>&1; cp gpurun_out/pmc_${t}_$lay.txt $o/pmc_sq_k_rx4_$lay.txt
-  python3 tools/phase_times.py --no-extras --layout $lay > $o/phase_times_$lay.txt 2>&1
-done
-python3 tools/valu_summary.py $o/pmc_sq_k_rx4_interleaved.txt $t > $o/valu_k_rx4.log 2>&1     # -> profiles/valu_k_rx4.json
-bash tools/pmc_nt3.sh ${t}_pmc_nt3 > /dev/null 2>&1; cp gpurun_out/${t}_pmc_nt3_kernels.txt $o/pmc_nt3_kernels.txt
-python3 tools/loop_stamps.py > $o/loop_stamps.txt 2>&1
-python3 tools/time_legacy.py > $o/legacy_one_burst_calls.json 2> $o/legacy.err
-echo "pmc done"
-# 5. the N > 1 paths rehearsed on the one GPU: two gloo ranks (headline with the sharded receive loop, configs[4] both ways), RCCL with one rank
-GMR1_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 --shard-arfcns 16 --shard-seconds 20 > $o/bench_gloo2_one_gpu.json 2> $o/bench_gloo2.err
-GMR1_BENCH_BACKEND=gloo python3 bench.py --workload nt3 --gpus 2 --steps 20 --warmup 5 --no-cpu > $o/bench_nt3_gloo2_one_gpu.json 2> $o/bench_nt3_gloo2.err
-GMR1_BENCH_BACKEND=gloo python3 bench.py --workload tch3 --gpus 2 --steps 20 --warmup 5 --no-cpu > $o/bench_tch3_gloo2_one_gpu.json 2> $o/bench_tch3_gloo2.err
-GMR1_BENCH_FORCE_GROUP=1 python3 bench.py --no-cpu --steps 20 --shard-arfcns 16 --shard-seconds 20 > $o/bench_rccl_one_rank.json 2> $o/bench_rccl1.err
-rm -rf gpurun_out/traffic_${t}_* gpurun_out/pmc_${t}_* gpurun_out/pmc2_${t}_*
 ls -la $o | head -60
 for f in bench_100k bench_100k_generic bench_nt3 bench_nt3_generic bench_tch3 bench_tch3_generic bench_fcch bench_rx bench_rx_generic bench_chan bench_ambe bench_rx_512x20s bench_nt3_two_launches; do echo "== $f"; python3 -c "
 import json,sys

@@ -32,8 +32,8 @@ sys.path.insert(0, ".")
 import bench
 out = {"_comment": "Fabric-side bytes per launch of k_rx4<16,4> over 100000 bursts: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate "
                    "passes (tools/measure_traffic.sh), FETCH_SIZE doubled per MI355X_MICROARCH.md. The counters sit above the Infinity "
-                   "Cache: its hits are included. The kernel reads each burst twice on purpose (pass 2 re-reads the 234 kept samples at "
-                   "stride sps, which touches every line again).",
+                   "Cache: its hits are included. Since round 6 pass 2's kept samples come out of the window registers at a speculated pick; "
+                   "only the bursts whose pick is another (about 15 %) read their window a second time.",
        "tag": tag, "launches_averaged": n, "fetch_size_raw_kb": fetch, "write_size_raw_kb": write,
        "tcc_hit_rate": hit / (hit + miss) if hit + miss else None,
        "k_rx_bytes_per_launch_100k": int(2 * fetch * 1024 + write * 1024),
