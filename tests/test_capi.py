@@ -242,3 +242,35 @@ def test_exported_code_descriptions_agree_with_the_oracle(pkg, orc):
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))["conv_spot"]["k5_12"]
     for s, row in g["next_output_rows"].items():
         assert [code.next_output[int(s)][0], code.next_output[int(s)][1]] == row
+
+
+def test_plain_makefile_recipe(tmp_path):
+    """The repository's Makefile (what a C maintainer runs instead of build.py; reference src/Makefile.am:1-24,
+    src/sdr/Makefile.am:5-7, src/l1/Makefile.am:5-9): a dry run of `make all check install` names hipcc for every source build.py
+    compiles, the pkg-config file comes out right, and `make install` of an (already built) library lays out lib/, include/ and
+    lib/pkgconfig/ under DESTDIR.  (The compile itself is __graft_entry__.build()'s: the same commands.)"""
+    import shutil
+    import subprocess
+    if shutil.which("make") is None:
+        pytest.skip("no make")
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    r = subprocess.run(["make", "-n", "-B", "all", "check"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for src in pkg.build.HIP_SOURCES + pkg.build.CXX_SOURCES:
+        assert f"osmo-gmr_amd/csrc/{src}" in r.stdout, src
+    assert "--offload-arch=gfx950" in r.stdout and "-shared" in r.stdout and "abi_smoke" in r.stdout
+    bdir = str(tmp_path / "b")
+    r = subprocess.run(["make", f"BUILD={bdir}", f"{bdir}/gmr1_hip.pc", "PREFIX=/opt/gmr1"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    pc = open(os.path.join(bdir, "gmr1_hip.pc")).read()
+    assert "prefix=/opt/gmr1" in pc and "Libs: -L${libdir} -lgmr1_hip" in pc and "Cflags: -I${includedir}" in pc
+    # install: the library is there already (build()), so only the copy runs -- never a compile (-o: the objects are not remade)
+    dest = str(tmp_path / "dest")
+    r = subprocess.run(["make", "-o", pkg.build.LIB.replace(ROOT + "/", ""), f"BUILD={bdir}", "install", "PREFIX=/usr", f"DESTDIR={dest}"],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(os.path.join(dest, "usr/lib/libgmr1_hip.so"))
+    assert os.path.exists(os.path.join(dest, "usr/lib/pkgconfig/gmr1_hip.pc"))
+    assert os.path.exists(os.path.join(dest, "usr/include/gmr1_hip.h"))
+    assert os.path.exists(os.path.join(dest, "usr/include/osmocom/gmr1/sdr/pi4cxpsk.h"))

@@ -61,13 +61,17 @@ if not total or dur_ns is None:
 quad = dur_ns * 1e-9 * args.clock_mhz * 1e6 / 4.0
 resident = total["SQ_WAVE_CYCLES"] / (args.simds * quad)
 busy = total["SQ_ACTIVE_INST_VALU"] / (args.simds * quad)
-assert 0.0 < busy <= 1.02 and resident <= args.waves_per_simd * 1.02, (busy, resident)
+# (the counter charges every vector instruction one quad-cycle; a kernel of instructions that issue faster than that -- k_tch3's
+# packed 16-bit butterflies -- can come out a little above 1: it is then simply saturated, and the file says so)
+assert 0.0 < busy <= 1.25 and resident <= args.waves_per_simd * 1.02, (busy, resident)
 out = {"_comment": "SQ counters of one launch (mean over the run's launches), machine-wide: valu_busy = sum SQ_ACTIVE_INST_VALU / "
                    "(SIMDs x kernel quad-cycles), avg_resident_waves = sum SQ_WAVE_CYCLES / the same; kernel quad-cycles = duration x "
                    "clock / 4 (tools/valu_summary.py)",
        "tag": args.tag, "source": os.path.relpath(args.src, ROOT), "kernel": name, "waves": waves,
        "kernel_ns": dur_ns, "clock_mhz": args.clock_mhz, "simds": args.simds, "compiled_waves_per_simd": args.waves_per_simd,
        "avg_resident_waves": resident, "valu_busy": busy,
+       **({"note": "above 1: SQ_ACTIVE_INST_VALU charges one quad-cycle per instruction, this kernel issues some faster; read as saturated"}
+          if busy > 1.0 else {}),
        "valu_insts_per_wave": per_wave.get("SQ_INSTS_VALU"), "salu_insts_per_wave": per_wave.get("SQ_INSTS_SALU"),
        "lds_insts_per_wave": per_wave.get("SQ_INSTS_LDS"), "active_inst_valu_per_wave": per_wave.get("SQ_ACTIVE_INST_VALU"),
        "wave_cycles_per_wave": per_wave.get("SQ_WAVE_CYCLES"),
