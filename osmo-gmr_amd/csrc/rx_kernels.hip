@@ -2389,9 +2389,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	constexpr bool QX = QL && !PL;
 	static_assert(!PL || QL, "the planar layout exists for the fused batch kernel");
 	float th_q[QX ? 4 : 1][4];                         // QX: phase (turns) of kept sample lane + 64 r of burst q
-	uint32_t zm_q = 0;                                 // bit 4 q + r: that sample counts as 0 + 0j (outside the window, or zero)
+	uint32_t zm_q = 0xff000000u;                       // bit 4 q + r: that sample counts as 0 + 0j (outside the window, or zero);
+	                                                   // bits 24-31 (row q's lanes): burst q's speculated pick (0 ... 80; 255: none)
 	float2 xs_q[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};   // row q: normalised samples of sync symbols col, col + 16 at the speculated pick
-	int dspec_r = -0x40000000;                         // row q: burst q's speculated pick
 	float inv_r = 1.0f;                                // row q: 1 / sigma of burst q's window
 	// a burst's operands: the arrays of `io`, or (the loop's pipeline stages) the caller's registers (LatPre (5))
 	auto op_kind = [&](int g) -> int {
@@ -2533,7 +2533,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const int lane_outer = lane;
 	// QX: where, in the staged sync-chunk windows of a BCCH / of a DC6 burst, the sample under sync symbol `col` lies for pick 0
 	// (chunk c's window starts at staged sample wb_c; symbol nn of it, at pick d, is staged sample wb_c + 4 nn + d); -1: none
-	int xsp_b = -1, xsp_c = -1;
+	int xsp_bc = 0xffff;                               // (the two places in one register, a byte each; 255: none)
 	if constexpr (QX) {
 		auto place = [&](int kind) -> int {
 			const int w = a.in_len[kind] - 234 * 4 + 1;
@@ -2544,8 +2544,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 			const int wb = ch == 0 ? 0 : (ch == 1 ? c0 * 4 + w - 1 : c0 * 4 + w - 1 + 3 * 4 + w - 1);
 			return n < c0 + 6 ? wb + nn * 4 : -1;
 		};
-		xsp_b = place(0);
-		xsp_c = place(1);
+		xsp_bc = (place(0) & 0xff) | ((place(1) & 0xff) << 8);      // (places are below 240)
 	}
 	// (QX: unrolled, the bursts' phase registers th_q[q] are picked at compile time and come to life one burst at a time)
 #pragma clang loop unroll_count(QX ? 4 : 1)
@@ -2772,9 +2771,9 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 				// row q keeps what the rows below need of this burst at that pick: the normalised samples under its sync symbols
 				// (still staged) ...
 				if (row == q) {
-					dspec_r = d;
-					const int pl = kind ? xsp_c : xsp_b;
-					if (pl >= 0)
+					zm_q = (zm_q & 0x00ffffffu) | ((uint32_t)d << 24);
+					const int pl = (xsp_bc >> (kind ? 8 : 0)) & 0xff;
+					if (pl != 0xff)
 						xs_q[0] = xst[pl + d];
 					// (the one symbol beyond the sixteenth: BCCH's n = 16, symbol 2 of the third chunk, on the row's first lane)
 					if (kind == 0 && col == 0)
@@ -3209,7 +3208,7 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const int d_r = (int)roundf(toa_r);
 
 	// QX: whose speculated pick held (per row; a burst that was not found has no pass 2 at all)
-	const bool hit_r = QX && found_r && d_r == dspec_r && a.dbg_stop != 101;      // (101: experiment, every burst takes the old route)
+	const bool hit_r = QX && found_r && d_r == (int)(zm_q >> 24) && a.dbg_stop != 101;      // (101: experiment, every burst takes the old route)
 #ifdef GMR1_HIP_PROFILE
 	if constexpr (QX) {
 		if (col == 0 && row_live && found_r && !hit_r)
