@@ -3211,7 +3211,10 @@ __device__ __forceinline__ void rx4_body(const RxArgs &a, const RxIo io, int sta
 	const bool hit_r = QX && found_r && d_r == (int)(zm_q >> 24) && a.dbg_stop != 101;      // (101: experiment, every burst takes the old route)
 #ifdef GMR1_HIP_PROFILE
 	if constexpr (QX) {
-		if (col == 0 && row_live && found_r && !hit_r)
+		// (counted only when asked for, GMR1_HIP_DBG_STOP=105: fifteen thousand atomic adds to one word per launch cost the profiling
+		// build a tenth of the kernel's time -- and made an experiment that switched them off with the mis-speculation look like
+		// a 10 % gain)
+		if (a.dbg_stop == 105 && col == 0 && row_live && found_r && !hit_r)
 			atomicAdd(&g_prof_miss, 1);
 	}
 #endif
