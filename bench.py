@@ -1003,8 +1003,10 @@ def side_workloads(args):
     side = {}
     t_all = time.perf_counter()
     for key, argv, same in SIDE_WORKLOADS:
-        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(min(args.steps, 50)), "--warmup", "3",
-                                                                    "--preroll-s", str(min(args.preroll_s, 0.2)),
+        # (the same untimed pre-roll and warm-up as the headline: these children start on a GPU that sat idle through the CPU
+        # baseline, and with 0.2 s / 3 steps the channelizer read 8 % slower here than in its own bench line)
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--steps", str(min(args.steps, 50)), "--warmup", str(min(args.warmup, 10)),
+                                                                    "--preroll-s", str(args.preroll_s),
                                                                     "--conv-decoder", args.conv_decoder]
         t0 = time.perf_counter()
         try:
