@@ -255,6 +255,7 @@ def test_plain_makefile_recipe(tmp_path):
         pytest.skip("no make")
     from __graft_entry__ import load_package
     pkg = load_package()
+    pkg.build.build()                      # (a no-op when the library is up to date)
     r = subprocess.run(["make", "-n", "-B", "all", "check"], cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for src in pkg.build.HIP_SOURCES + pkg.build.CXX_SOURCES:
