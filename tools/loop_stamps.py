@@ -61,3 +61,6 @@ for name, k, k0 in [("pred published, barrier passed", 17, 16), ("verdict checke
                     ("burst operands set, front started", 0, 19), ("front", 4, 0), ("results read, feedback assumed, hand-over written", 20, 4),
                     ("frame logged, chain advanced", 21, 20), ("round logged (global)", 22, 21), ("next round listed", 23, 22)]:
     print(f"  {name:50s} +{t[k] - t[k0]:6d}")
+if t[25] > 0:
+    print(f"chain 0's whole walk: {t[27]} rounds in {t[25]} ticks ({t[26]} squashes), {t[28]} shader cycles = {t[28] / t[25]:.0f} per tick; "
+          f"{t[29] / 100.0:.1f} us on the 100 MHz clock = {t[29] / 100.0 / t[25]:.3f} us per tick, shader clock {t[28] / (t[29] / 100.0) / 1e3:.2f} GHz")
