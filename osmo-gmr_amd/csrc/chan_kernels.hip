@@ -217,8 +217,11 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 			pf_stage<1>(xe, xo, pf_partner<4>(xe), pf_partner<4>(xo), sg23, tw[3]);
 			pf_stage<0>(xe, xo, pf_partner<2>(xe), pf_partner<2>(xo), sg45, tw[4]);
 			pf_stage_last<1>(xe, xo, pf_partner<1>(xe), pf_partner<1>(xo), sg45);
-			tile[chan * (kPfbTile + 1) + u] = make_float2(xe.x, xe.y);
-			tile[chan * (kPfbTile + 1) + u + 1] = make_float2(xo.x, xo.y);
+			// (a half-wave's channels are all even or all odd -- bit-reversed lanes --: their 136-byte rows start 4 k banks
+			// apart, k = 0 ... 31, so rows k and k + 16 would meet; the upper half of the channels sits one column on, in the
+			// row's spare seventeenth place)
+			tile[chan * (kPfbTile + 1) + (chan >> 5) + u] = make_float2(xe.x, xe.y);
+			tile[chan * (kPfbTile + 1) + (chan >> 5) + u + 1] = make_float2(xo.x, xo.y);
 		}
 		// (the next tile's "previous blocks": what the last block's window held, one further back)
 #pragma unroll
@@ -226,12 +229,14 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 			w[q] = W[q - 1];
 		WSYNC();
 		// write-out: 16 instants x 8 bytes = one 128-byte run per kept channel
-		for (int e = r; e < 64 * kPfbTile; e += 64) {
-			const int c = e / kPfbTile, u = e % kPfbTile;
+		// (sixteen lanes per channel; the two channels a half-wave reads are sixteen apart: their rows start 32 banks apart)
+		static_assert(kPfbTile == 16, "the write-out's lane map is for sixteen instants per tile");
+		for (int i = 0; i < 16; i++) {
+			const int c = i + 16 * (r >> 4), u = r & 15;
 			const int sl = slot_of[c];
 			const long long t = t0 + tt + u;
 			if (sl >= 0 && t < a.T)
-				a.y[(long long)sl * a.T + t] = tile[c * (kPfbTile + 1) + u];
+				a.y[(long long)sl * a.T + t] = tile[c * (kPfbTile + 1) + (c >> 5) + u];
 		}
 		WSYNC();
 	}
