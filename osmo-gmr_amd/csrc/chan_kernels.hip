@@ -42,6 +42,7 @@ namespace gmr1 {
 static constexpr float kPif = 3.14159265358979323846f;
 static constexpr int kPfbSteps = 64;        // output instants per wavefront (32 new blocks)
 static constexpr int kPfbTile = 16;         // instants per LDS transpose tile
+static constexpr int kPfbWb = 4;            // tile reads answered together in k_pfb64's write-out
 
 // (every lane of these permutations has a source lane: no "old" value is needed, and none is set up)
 template <int CTRL>
@@ -137,9 +138,7 @@ template <bool ROT>
 __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 {
 	__shared__ float2 tile[64 * (kPfbTile + 1)];
-	__shared__ int slot_of[64];                  // output slot of every channel: the write-out loop asks for one per store
 	const int r = threadIdx.x;
-	slot_of[r] = a.slot[r];
 	const long long t0 = (long long)blockIdx.x * kPfbSteps;       // first instant of this wave (even)
 	const int NB = a.n_blocks;
 
@@ -165,6 +164,13 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 	const pf_v2f sg01 = {hb[0], hb[1]}, sg23 = {hb[2], hb[3]}, sg45 = {hb[4], hb[5]};
 	const int chan = (int)(__brev((unsigned)r) >> 26);
 	const int slot = a.slot[chan];
+	// output slots of the sixteen channels this lane writes out (16 (r >> 4) + i), a byte each, 0xff = not kept
+	unsigned slpk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+	for (int i = 0; i < 16; i++) {
+		const int sv = a.slot[16 * (r >> 4) + i];
+		slpk[i >> 2] |= (sv < 0 ? 0xffu : (unsigned)sv & 0xffu) << (8 * (i & 3));
+	}
 
 	// window of the lane's samples: w[q] = x[64 (b - q) + r] for the current block b
 	pf_v2f w[kPfbMaxBlocks];
@@ -230,13 +236,32 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 		WSYNC();
 		// write-out: 16 instants x 8 bytes = one 128-byte run per kept channel
 		// (sixteen lanes per channel; the two channels a half-wave reads are sixteen apart: their rows start 32 banks apart)
+		// The slots come out of four registers (slpk), the tile in batches of kPfbWb reads answered together: with a slot
+		// lookup and a tile read each waited for, one after the other, a tile's write-out was 32 trips to LDS in a row.
 		static_assert(kPfbTile == 16, "the write-out's lane map is for sixteen instants per tile");
-		for (int i = 0; i < 16; i++) {
-			const int c = i + 16 * (r >> 4), u = r & 15;
-			const int sl = slot_of[c];
+		{
+			const int u = r & 15, hq = r >> 4;
 			const long long t = t0 + tt + u;
-			if (sl >= 0 && t < a.T)
-				a.y[(long long)sl * a.T + t] = tile[c * (kPfbTile + 1) + (c >> 5) + u];
+			const bool tin = t < a.T;
+			const float2 *row = &tile[(16 * hq) * (kPfbTile + 1) + (hq >> 1) + u];      // channel 16 hq + i is (kPfbTile + 1) i on
+			// (the slots looked at afresh per tile: sixteen store addresses carried across the loop are 32 registers and a wave)
+#pragma unroll
+			for (int j = 0; j < 4; j++)
+				asm volatile("" : "+v"(slpk[j]));
+#pragma unroll
+			for (int i0 = 0; i0 < 16; i0 += kPfbWb) {
+				float2 v[kPfbWb];
+#pragma unroll
+				for (int k = 0; k < kPfbWb; k++)
+					v[k] = row[(i0 + k) * (kPfbTile + 1)];
+#pragma unroll
+				for (int k = 0; k < kPfbWb; k++) {
+					const int i = i0 + k;
+					const unsigned sl = (slpk[i >> 2] >> (8 * (i & 3))) & 0xffu;
+					if (sl != 0xffu && tin)
+						a.y[(long long)sl * a.T + t] = v[k];
+				}
+			}
 		}
 		WSYNC();
 	}
