@@ -28,6 +28,7 @@
 // 8 B in + 12 B out per channel sample.
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include "gmr1_dev.h"
 #include "profile_env.h"
 
@@ -258,8 +259,10 @@ __global__ __launch_bounds__(64) void k_pfb64(PfbArgs a)
 				for (int k = 0; k < kPfbWb; k++) {
 					const int i = i0 + k;
 					const unsigned sl = (slpk[i >> 2] >> (8 * (i & 3))) & 0xffu;
+					// (streamed past the caches: nothing of it is read again before the launch is over -- with ordinary stores the
+					// 640 MB evict the input still to be read and are written back under the next kernel; A/B profiles/r06am)
 					if (sl != 0xffu && tin)
-						a.y[(long long)sl * a.T + t] = v[k];
+						__builtin_nontemporal_store((pf_v2f){v[k].x, v[k].y}, reinterpret_cast<pf_v2f *>(&a.y[(long long)sl * a.T + t]));
 				}
 			}
 		}
@@ -688,7 +691,12 @@ void k_resamp2(ResampArgs a, long long P, long long Q, int span)
 			acc[r] = (rs_v2f){0.f, 0.f};
 		rs_v4f pr[2][4];
 		const unsigned rdb = rd - 16u * (unsigned)(LP - 1);            // lowest pair of the lane; pair q at offset 16 (LP - 1 - q)
+#if defined(GMR1_EXP_RS) && (GMR1_EXP_RS & 2)
+		// (timing experiment: no window reads -- results are garbage)
+#define GMR1_RS_READ(dst, q) asm volatile("" : "=v"(dst))
+#else
 #define GMR1_RS_READ(dst, q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(rdb), "n"(16 * (LP - 1 - (q))))
+#endif
 #pragma unroll
 		for (int q = 0; q < 4; q++)
 			GMR1_RS_READ(pr[0][q], q);
@@ -720,10 +728,15 @@ void k_resamp2(ResampArgs a, long long P, long long Q, int span)
 							sv[r] = outside ? (rs_v2f){0.f, 0.f} : sv[r];
 						}
 					}
+#if defined(GMR1_EXP_RS) && (GMR1_EXP_RS & 1)
+					// (timing experiment: no multiply-adds -- results are garbage)
+					asm volatile("" :: "v"(sv[0]), "v"(sv[1]));
+#else
 					if (h)
 						rs_mac2<true>(acc[0], acc[1], E[0][q], E[1][q], sv[0], sv[1]);
 					else
 						rs_mac2<false>(acc[0], acc[1], E[0][q], E[1][q], sv[0], sv[1]);
+#endif
 				}
 			}
 		}
@@ -731,7 +744,8 @@ void k_resamp2(ResampArgs a, long long P, long long Q, int span)
 		const long long pl = p0 + (long long)R * lane;
 		const long long n = m * P + pl;
 		if (pl + 1 < P && n + 1 < a.n_out && ((reinterpret_cast<uintptr_t>(out + n) & 15) == 0)) {
-			*reinterpret_cast<float4 *>(out + n) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+			// (a streaming store, as k_pfb64's: -8 % on this kernel, -5 % on the one before it in the step)
+			__builtin_nontemporal_store((rs_v4f){acc[0].x, acc[0].y, acc[1].x, acc[1].y}, reinterpret_cast<rs_v4f *>(out + n));
 		} else {
 #pragma unroll
 			for (int r = 0; r < R; r++)
@@ -741,6 +755,258 @@ void k_resamp2(ResampArgs a, long long P, long long Q, int span)
 		slot = slot + 1 == kRing ? 0 : slot + 1;
 	}
 	// nothing of this wave is left in flight towards its LDS when it ends
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+// ---------------------------------------------------------------------------
+// k_resamp2w -- k_resamp2 with ONE window ring per work-group of kRsWg waves.  AN EXPERIMENT THAT LOST: only the profiling
+// build runs it (GMR1_HIP_RESAMP_WG=1), for the comparison; results are bit for bit k_resamp2's.
+//
+// Of the bytes k_resamp2 moves the reads are mostly waste -- every wave fetches a 128-sample window for 128 outputs that
+// consume 85.5 new inputs at 2/3, and waves that share input drift periods apart, so no L2 holds a line for the next one:
+// 1 426 MB fetched for a 640 MB input (tools/exp/traffic_chan.sh).  Here the kRsWg waves that own consecutive 128-output
+// groups of a period share the union of their windows: it is fetched ONCE per period as `nch` consecutive 128-sample
+// chunks (wave w brings chunk w: six chunks for eight waves at 2/3), every wave reads its own thirty-one-sample stretches
+// out of the shared slot exactly as k_resamp2 does out of its own, with the same taps, order and selects.  Fetched:
+// 783 MB.  Time: 0.47 ms with a barrier per period, 0.50 ms with the counters below, against 0.42 ms -- the loads, stores
+// and synchronisation alone (arithmetic and window reads compiled out, -DGMR1_EXP_RS=3) take 0.38 ms in this form and
+// 0.39 ms in k_resamp2's: neither form is bound by the bytes it reads, and what the waves of a group now wait for each
+// other costs more than the reads saved (profiles/r06ah, r06aj, r06ak).  What did move both kernels were streaming stores.
+//   * No barrier per period (tried first: the eight waves in step took 0.47 ms for 0.78 GB of reads, against 0.42 ms for
+//     1.43 GB the other way -- every wave waiting for the slowest at every period, all of them in the same phase of their
+//     work).  Two counters per slot instead, in LDS: `ready` (a wave adds one once its chunk of the slot's period has
+//     landed: behind its own s_waitcnt vmcnt) and `done` (a wave adds one behind its last read of the slot).  A wave reads
+//     period m's slot once ready says all nch chunks of that period are in, and sends its chunk of period m + kRsAhead
+//     into the slot of period m + kRsAhead - kRing once done says every computing wave is through with that one: the
+//     waves may drift kRing - kRsAhead - 1 periods apart.  Waits at period i depend on events of periods <= i only, and the
+//     wave furthest behind never waits for one ahead of it: no cycle.  Polls are bounded; a bound that runs out traps.
+//   * All LDS traffic inside the loop is inline assembly: the compiler answers LDS operations of its own behind an
+//     LDS-DMA with vmcnt(0), which would drain the ring.
+//   * Every wave issues exactly one DMA per period (the vmcnt arithmetic of k_resamp2): waves without a chunk fetch into
+//     a dump slot.  Waves beyond the period's last output group still fetch and count as producers; they skip the rest.
+// ---------------------------------------------------------------------------
+static constexpr int kRsWg = 8;              // waves of a k_resamp2w work-group
+static constexpr int kRsAhead = 4;           // periods its chunks are asked for ahead of their use
+
+__device__ __forceinline__ unsigned rsw_peek(unsigned addr)
+{
+	unsigned v;
+	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+	return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void rsw_wait_ge(unsigned addr, unsigned want)
+{
+#pragma clang loop unroll(disable)
+	for (int spin = 0; rsw_peek(addr) < want; spin++) {
+		if (spin > (1 << 20))
+			__builtin_trap();                 // (a counter that never arrives: cannot happen, must not hang)
+		__builtin_amdgcn_s_sleep(1);
+	}
+}
+__device__ __forceinline__ void rsw_add1(unsigned addr, int lane)
+{
+	if (lane == 0) {
+		const unsigned one = 1u;
+		asm volatile("ds_add_u32 %0, %1" ::"v"(addr), "v"(one) : "memory");
+	}
+}
+
+template <int kRing>
+__global__ __launch_bounds__(64 * kRsWg) __attribute__((amdgpu_waves_per_eu(4)))
+void k_resamp2w(ResampArgs a, long long P, long long Q, int nch)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+	constexpr int R = 2;
+	constexpr int kTaps = kRsTapsShort;
+	constexpr int L = kTaps + R;
+	constexpr int LP = L / 2;
+	constexpr int kPad = 2;                   // union sample k sits in slot position k + 2 (T - 31 >= -2); two more behind the last
+	static_assert(LP % 4 == 0, "batches of four pairs");
+	extern __shared__ float4 ringw[];         // kRing slots of (nch 128 + 4) samples, then the dump slot (128 samples)
+	__shared__ unsigned cnt_ready[kRing], cnt_done[kRing];
+	const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // (the wave's number: a scalar)
+	const int sl = blockIdx.y;
+	const long long p0u = (long long)blockIdx.x * kRsWg * 64 * R;        // first phase of the work-group
+	const long long p0 = p0u + (long long)w * 64 * R;                     // ... of this wave
+	const bool live_wave = p0 < P;
+	const int slot_pairs = (nch * 128 + 2 * kPad) / 2;
+	long long ip[R];
+	int jf[R];
+	float frac[R];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		const long long p = p0 + (long long)R * lane + r;
+		const long long Np = (long long)a.j0 * a.den + (p < P ? p : P - 1) * a.num;
+		const long long fl = Np / a.den;
+		frac[r] = (float)(Np - fl * a.den) / (float)a.den;
+		jf[r] = (int)(fl % a.nfilt);
+		ip[r] = fl / a.nfilt;
+	}
+	const long long N0 = (long long)a.j0 * a.den + p0u * a.num;
+	const long long i_first = (N0 / a.den) / a.nfilt - (kTaps - 1);     // first input the WORK-GROUP needs (period 0)
+	const int top = (int)(ip[R - 1] - i_first) + kPad;
+	const int T = top | 1;
+	int sh[R];
+	rs_v2f E[R][LP];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		sh[r] = T - ((int)(ip[r] - i_first) + kPad);
+#pragma unroll
+		for (int i = 0; i < L; i += 2) {
+			float e[2];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const int k = i + h - sh[r];
+				const bool in = k >= 0 && k < kTaps;
+				const float2 b = a.bank[jf[r] * kTaps + (k < 0 ? 0 : (k >= kTaps ? kTaps - 1 : k))];
+				e[h] = fmaf(frac[r], b.y, b.x) * (in ? 1.0f : 0.0f);
+			}
+			E[r][i / 2] = (rs_v2f){e[0], e[1]};
+		}
+	}
+#pragma unroll
+	for (int r = 0; r < R; r++)
+#pragma unroll
+		for (int q = 0; q < LP; q++)
+			asm volatile("" : "+v"(E[r][q]));
+	const float2 *__restrict__ y = a.y + (long long)sl * a.T;
+	float2 *__restrict__ out = a.out + (long long)sl * a.out_stride;
+	const long long m0 = (long long)blockIdx.z * kRsPeriods;
+	const long long periods = (a.n_out + P - 1) / P;
+	const bool has_chunk = w < nch;
+	// computing waves of this work-group (those with an output group inside the period)
+	const long long groups_left = (P - p0u + 64 * R - 1) / (64 * R);
+	const unsigned n_live = (unsigned)(groups_left < kRsWg ? (groups_left > 0 ? groups_left : 0) : kRsWg);
+	if (threadIdx.x < kRing) {
+		cnt_ready[threadIdx.x] = 0u;
+		cnt_done[threadIdx.x] = 0u;
+	}
+	__syncthreads();
+	const unsigned a_ready = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void *)&cnt_ready[0]));
+	const unsigned a_done = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void *)&cnt_done[0]));
+	// this wave's chunk of period m: inputs i_first + m Q + 128 w + [0, 128), lane l brings samples 2 l and 2 l + 1
+	auto issue = [&](long long m, int slot) {
+		if (m >= periods)
+			m = periods - 1;
+		long long s0 = i_first + m * Q + (has_chunk ? 128 * w : 0) + 2 * lane;
+		s0 = s0 < 0 ? 0 : (s0 > a.T - 2 ? a.T - 2 : s0);
+		float4 *dst = has_chunk ? &ringw[slot * slot_pairs + kPad / 2 + 64 * w] : &ringw[kRing * slot_pairs];
+		__builtin_amdgcn_global_load_lds(y + s0, dst, 16, 0, 0);
+	};
+	const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) void *)&ringw[0]);
+	const unsigned rd0 = lds0 + (unsigned)(T >> 1) * 16u;
+
+	static_assert(kRsAhead >= 1 && kRsAhead < kRing, "a slot is refilled kRing - kRsAhead periods after its use");
+#pragma unroll
+	for (int d = 0; d < kRsAhead; d++)
+		issue(m0 + d, d);
+	int slot = 0;
+	for (int mm = 0; mm < kRsPeriods; mm++) {
+		const long long m = m0 + mm;
+		if (m * P >= a.n_out)
+			break;
+		{
+			// the chunk of period m + kRsAhead, into the slot whose earlier periods every computing wave is through with
+			const int sa = (mm + kRsAhead) % kRing;
+			if (has_chunk && mm + kRsAhead >= kRing)
+				rsw_wait_ge(a_done + 4u * (unsigned)sa, n_live * (unsigned)((mm + kRsAhead) / kRing));
+			issue(m + kRsAhead, sa);
+		}
+		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kRsAhead) : "memory");
+		if (has_chunk) {
+			// a chunk that crosses the stream's ends: its outside samples are zeros, whatever the clamped addresses brought
+			const long long c0 = i_first + m * Q + 128 * w;
+			if (c0 < 0 || c0 + 128 > a.T) {
+				float2 *xs = reinterpret_cast<float2 *>(&ringw[slot * slot_pairs + kPad / 2 + 64 * w]);
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const long long sidx = c0 + 2 * lane + h;
+					float2 v = make_float2(0.f, 0.f);
+					if (sidx >= 0 && sidx < a.T)
+						v = y[sidx];
+					xs[2 * lane + h] = v;
+				}
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			}
+		}
+		if (has_chunk)
+			rsw_add1(a_ready + 4u * (unsigned)slot, lane);
+		if (live_wave) {
+			// every chunk of this period is in its slot
+			rsw_wait_ge(a_ready + 4u * (unsigned)slot, (unsigned)nch * (unsigned)(mm / kRing + 1));
+			const unsigned rd = rd0 + (unsigned)slot * (unsigned)(slot_pairs * 16);
+			rs_v2f acc[R];
+#pragma unroll
+			for (int r = 0; r < R; r++)
+				acc[r] = (rs_v2f){0.f, 0.f};
+			// (pairs in batches of kB, the next batch in flight while one is used: two, not k_resamp2's four -- the counters'
+			// operands and the wider slot arithmetic need the registers, and a spilled tap comes back behind vmcnt(0))
+			constexpr int kB = 2;
+			static_assert(LP % kB == 0, "whole batches");
+			rs_v4f pr[2][kB];
+			const unsigned rdb = rd - 16u * (unsigned)(LP - 1);
+#if defined(GMR1_EXP_RS) && (GMR1_EXP_RS & 2)
+#define GMR1_RS_READ(dst, q) asm volatile("" : "=v"(dst))
+#else
+#define GMR1_RS_READ(dst, q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(rdb), "n"(16 * (LP - 1 - (q))))
+#endif
+#pragma unroll
+			for (int q = 0; q < kB; q++)
+				GMR1_RS_READ(pr[0][q], q);
+#pragma unroll
+			for (int b = 0; b < LP / kB; b++) {
+				if (b + 1 < LP / kB) {
+#pragma unroll
+					for (int q = 0; q < kB; q++)
+						GMR1_RS_READ(pr[(b + 1) & 1][q], kB * (b + 1) + q);
+					asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(pr[b & 1][0]), "+v"(pr[b & 1][1]) : "n"(kB));
+				} else {
+					asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[b & 1][0]), "+v"(pr[b & 1][1]));
+					rsw_add1(a_done + 4u * (unsigned)slot, lane);       // (the slot's last read of this wave has returned)
+				}
+#pragma unroll
+				for (int qq = 0; qq < kB; qq++) {
+					const int q = kB * b + qq;
+					const rs_v4f pq = pr[b & 1][qq];
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						const int i = 2 * q + h;
+						rs_v2f sv[R];
+#pragma unroll
+						for (int r = 0; r < R; r++) {
+							sv[r] = h ? (rs_v2f){pq.x, pq.y} : (rs_v2f){pq.z, pq.w};
+							if (i < R || i >= kTaps) {
+								const bool outside = i < sh[r] || i > sh[r] + kTaps - 1;
+								sv[r] = outside ? (rs_v2f){0.f, 0.f} : sv[r];
+							}
+						}
+#if defined(GMR1_EXP_RS) && (GMR1_EXP_RS & 1)
+						asm volatile("" :: "v"(sv[0]), "v"(sv[1]));
+#else
+						if (h)
+							rs_mac2<true>(acc[0], acc[1], E[0][q], E[1][q], sv[0], sv[1]);
+						else
+							rs_mac2<false>(acc[0], acc[1], E[0][q], E[1][q], sv[0], sv[1]);
+#endif
+					}
+				}
+			}
+#undef GMR1_RS_READ
+			const long long pl = p0 + (long long)R * lane;
+			const long long n = m * P + pl;
+			if (pl + 1 < P && n + 1 < a.n_out && ((reinterpret_cast<uintptr_t>(out + n) & 15) == 0)) {
+				*reinterpret_cast<float4 *>(out + n) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+			} else {
+#pragma unroll
+				for (int r = 0; r < R; r++)
+					if (pl + r < P && n + r < a.n_out)
+						out[n + r] = make_float2(acc[r].x, acc[r].y);
+			}
+		}
+		slot = slot + 1 == kRing ? 0 : slot + 1;
+	}
+	// nothing of this wave is left in flight towards the work-group's LDS when it ends
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
@@ -842,8 +1108,37 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinTight, true>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	else if (ext)
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinShort, true>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
-	else if (multi_r > 1)
-		hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing>), dim3((unsigned)((P + 127) / 128), (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span_r);
+	else if (multi_r > 1) {
+		// one window ring per work-group of kRsWg waves where the union of their windows is fewer chunks than they are and
+		// the period has at least that many output groups (k_resamp2w); else a ring per wave
+		const long long gx2 = (P + 127) / 128;
+		const int span_w = (int)(((long long)(kRsWg * 128 - 1) * a.num) / (a.den * a.nfilt)) + taps + 2;
+		const int nch = (span_w + 127) / 128;
+		// (measured slower than a ring per wave -- 0.47-0.50 against 0.42 ms with 0.78 against 1.43 GB fetched: DESIGN 4.7 --, so
+		// only the profiling build runs it, on request)
+		static const bool shared_ring = profile_env("GMR1_HIP_RESAMP_WG") != nullptr;
+		if (shared_ring && nch < kRsWg && gx2 >= kRsWg) {
+			const size_t lds_w = ((size_t)kRsRing * (nch * 128 + 4) + 128) * sizeof(float2);
+			static std::mutex mu;
+			static bool told[64] = {};
+			int dev = 0;
+			if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+				return hipErrorInvalidDevice;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				if (!told[dev]) {
+					const hipError_t e = hipFuncSetAttribute((const void *)k_resamp2w<kRsRing>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(((size_t)kRsRing * (kRsWg * 128 + 4) + 128) * sizeof(float2)));
+					if (e != hipSuccess)
+						return e;
+					told[dev] = true;
+				}
+			}
+			hipLaunchKernelGGL((k_resamp2w<kRsRing>), dim3((unsigned)((gx2 + kRsWg - 1) / kRsWg), (unsigned)a.n_slots, gz), dim3(64 * kRsWg), lds_w, stream, a, P, Q, nch);
+		} else {
+			hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing>), dim3((unsigned)gx2, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span_r);
+		}
+	}
+
 	else if (span <= kRsWinTight)
 		hipLaunchKernelGGL((k_resamp<kRsTapsShort, kRsWinTight>), dim3(gx, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span);
 	else

@@ -311,3 +311,29 @@ def test_non_finite_sample_poisons_only_the_instants_its_taps_reach(gpu_api):
         assert np.array_equal(g[:lo], b[:lo]) and np.array_equal(g[hi:], b[hi:])
         assert not np.isfinite(b[lo:hi]).all()
         assert np.isfinite(b[:lo]).all() and np.isfinite(b[hi:]).all()
+
+
+def test_resampler_with_one_ring_per_work_group_is_bit_identical(gpu_api):
+    """k_resamp2w (the profiling build's GMR1_HIP_RESAMP_WG=1: the eight waves of a period share one window ring, fetched once,
+    released to each other through counters in LDS) against k_resamp2 in the product build: the same streams bit for bit, stream
+    ends included (windows that cross them, periods past the last output).  A child process on the profiling library."""
+    import subprocess
+    rng = np.random.default_rng(11)
+    n = 420000
+    x = (rng.standard_normal((n, 2)) * 0.5).astype(np.float32).view(np.complex64).reshape(-1)
+    chans = [0, 7, 31, 32, 63]
+    got = gpu_api.channelize(x, FS, chans)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "osmo-gmr_amd", "libgmr1_hip_prof.so")
+    if not os.path.exists(prof):
+        pytest.skip("the profiling build (python osmo-gmr_amd/build.py --profile) is not there")
+    np.save("/tmp/_rsw_in.npy", x)
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from __graft_entry__ import load_package; pkg = load_package(); "
+            "import torch; torch.cuda.init(); pkg.api.load(); pkg.api.init(0); x = np.load('/tmp/_rsw_in.npy'); "
+            "y = pkg.api.channelize(x, %r, %r); np.save('/tmp/_rsw_out.npy', np.stack(y))" % (root, FS, chans))
+    env = dict(os.environ, GMR1_HIP_LIBRARY=prof, GMR1_HIP_RESAMP_WG="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    other = np.load("/tmp/_rsw_out.npy")
+    assert other.shape == np.stack(got).shape
+    assert np.array_equal(other.view(np.uint32), np.stack(got).view(np.uint32))
