@@ -194,7 +194,7 @@ def run_chan_workload(args):
             "roofline": {"bound": "hbm", "kernel": "k_pfb64 + k_resamp", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg,
-                         "limited_by": "hbm (both kernels' loads and stores alone take 85 % of their time; the resampler fetches 2.2 x its input, and fetching less did not make it faster: DESIGN 4.7)"}}
+                         "limited_by": "hbm (both kernels' loads and stores alone take 85 % of their time; the resampler's reads and writes together run at the box's mixed rate and its arithmetic hides under neither completely: DESIGN 4.7)"}}
     if not args.no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import orc_chan

@@ -579,8 +579,8 @@ void k_resamp(ResampArgs a, long long P, long long Q, int span)
 //   * The compiler does not know what an LDS-DMA writes and answers any LDS read of its own with vmcnt(0), which would
 //     drain the ring every period: the window is read with inline ds_read_b128 and counted lgkmcnt waits (LDS operations of
 //     a wave complete in order), four pairs per batch, the next batch in flight while one is used.
-template <int kRsWin, int kRing>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+template <int kRsWin, int kRing, int WG = 1>
+__global__ __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(4)))
 void k_resamp2(ResampArgs a, long long P, long long Q, int span)
 {
 	// (the body exists in the device pass only: the host pass drops the whole stub, silently, over the LDS-DMA builtin)
@@ -593,10 +593,18 @@ void k_resamp2(ResampArgs a, long long P, long long Q, int span)
 	constexpr int kSlot = (kRsWin + kPad) / 2;          // 16-byte pairs per ring slot
 	static_assert(kRsWin == 128, "one global_load_lds_dwordx4 per window: 64 lanes x two samples");
 	static_assert(LP % 4 == 0, "batches of four pairs");
-	__shared__ float4 ring4[kRing][kSlot];
-	const int lane = threadIdx.x;
+	// (WG > 1: the waves of WG consecutive output groups in one work-group -- nothing shared, nothing synchronised, each its
+	// own ring: they run on one CU at about one pace, so where their windows overlap -- a third of each, at 2/3 -- the second
+	// to ask finds the line in the CU's or the XCD's cache.  As single-wave work-groups, even dealt to one XCD, they drift
+	// periods apart and every window comes through the fabric: 1 426 MB fetched for a 640 MB input, 750 MB this way)
+	__shared__ float4 ring_all[WG][kRing][kSlot];
+	const int lane = threadIdx.x & 63;
+	const int wv = WG > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+	float4 (*ring4)[kSlot] = ring_all[wv];
 	const int sl = blockIdx.y;
-	const long long p0 = (long long)blockIdx.x * 64 * R;
+	const long long p0 = ((long long)blockIdx.x * WG + wv) * 64 * R;
+	if (WG > 1 && p0 >= P)
+		return;
 	// phases of this lane's outputs: exact integer arithmetic, once (an output past the period's last takes the last one's
 	// phase: it is not stored, and its window stays inside the wave's)
 	long long ip[R];
@@ -743,6 +751,12 @@ void k_resamp2(ResampArgs a, long long P, long long Q, int span)
 #undef GMR1_RS_READ
 		const long long pl = p0 + (long long)R * lane;
 		const long long n = m * P + pl;
+#if defined(GMR1_EXP_RS) && (GMR1_EXP_RS & 4)
+		// (timing experiment: no output -- one store per wave keeps the sums alive)
+		if (m == m0 + kRsPeriods - 1 && lane == 0)
+			out[n] = make_float2(acc[0].x + acc[1].x, acc[0].y + acc[1].y);
+		else if (false)
+#endif
 		if (pl + 1 < P && n + 1 < a.n_out && ((reinterpret_cast<uintptr_t>(out + n) & 15) == 0)) {
 			// (a streaming store, as k_pfb64's: -8 % on this kernel, -5 % on the one before it in the step)
 			__builtin_nontemporal_store((rs_v4f){acc[0].x, acc[0].y, acc[1].x, acc[1].y}, reinterpret_cast<rs_v4f *>(out + n));
@@ -1135,7 +1149,14 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 			}
 			hipLaunchKernelGGL((k_resamp2w<kRsRing>), dim3((unsigned)((gx2 + kRsWg - 1) / kRsWg), (unsigned)a.n_slots, gz), dim3(64 * kRsWg), lds_w, stream, a, P, Q, nch);
 		} else {
-			hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing>), dim3((unsigned)gx2, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span_r);
+			// eight consecutive output groups per work-group (each wave its own ring, nothing synchronised): the same time as a
+			// wave per work-group, 750 MB fetched instead of 1 426 MB (profiles/r06aq; the profiling build keeps the other form:
+			// GMR1_HIP_RESAMP_WG1=1)
+			static const bool wg1 = profile_env("GMR1_HIP_RESAMP_WG1") != nullptr;
+			if (wg1)
+				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing>), dim3((unsigned)gx2, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span_r);
+			else
+				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing, kRsWg>), dim3((unsigned)((gx2 + kRsWg - 1) / kRsWg), (unsigned)a.n_slots, gz), dim3(64 * kRsWg), 0, stream, a, P, Q, span_r);
 		}
 	}
 
