@@ -1152,11 +1152,19 @@ hipError_t launch_resamp(const ResampArgs &a, hipStream_t stream)
 			// eight consecutive output groups per work-group (each wave its own ring, nothing synchronised): the same time as a
 			// wave per work-group, 750 MB fetched instead of 1 426 MB (profiles/r06aq; the profiling build keeps the other form:
 			// GMR1_HIP_RESAMP_WG1=1)
+			// (the largest of 8, 4, 2 groups that divides the period's groups: a work-group's LDS is its waves' rings whether or
+			// not they have an output group, so a part-filled one would cost residency)
 			static const bool wg1 = profile_env("GMR1_HIP_RESAMP_WG1") != nullptr;
-			if (wg1)
-				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing>), dim3((unsigned)gx2, (unsigned)a.n_slots, gz), dim3(64), 0, stream, a, P, Q, span_r);
+			const int wgw = wg1 ? 1 : (gx2 % 8 == 0 ? 8 : (gx2 % 4 == 0 ? 4 : (gx2 % 2 == 0 ? 2 : 1)));
+			const dim3 grid2((unsigned)(gx2 / wgw), (unsigned)a.n_slots, gz);
+			if (wgw == 8)
+				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing, 8>), grid2, dim3(64 * 8), 0, stream, a, P, Q, span_r);
+			else if (wgw == 4)
+				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing, 4>), grid2, dim3(64 * 4), 0, stream, a, P, Q, span_r);
+			else if (wgw == 2)
+				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing, 2>), grid2, dim3(64 * 2), 0, stream, a, P, Q, span_r);
 			else
-				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing, kRsWg>), dim3((unsigned)((gx2 + kRsWg - 1) / kRsWg), (unsigned)a.n_slots, gz), dim3(64 * kRsWg), 0, stream, a, P, Q, span_r);
+				hipLaunchKernelGGL((k_resamp2<kRsWinTight, kRsRing>), grid2, dim3(64), 0, stream, a, P, Q, span_r);
 		}
 	}
 
