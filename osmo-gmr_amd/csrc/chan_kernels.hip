@@ -41,7 +41,7 @@ namespace gmr1 {
 	} while (0)
 
 static constexpr float kPif = 3.14159265358979323846f;
-static constexpr int kPfbSteps = 64;        // output instants per wavefront (32 new blocks)
+static constexpr int kPfbSteps = 64;        // output instants per wavefront (32 new blocks; 128 / 256: 5 / 22 % slower, r06aq)
 static constexpr int kPfbTile = 16;         // instants per LDS transpose tile
 static constexpr int kPfbWb = 4;            // tile reads answered together in k_pfb64's write-out
 
